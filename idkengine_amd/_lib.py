@@ -1,0 +1,59 @@
+"""ctypes binding of libidkpt.so (include/idkpt.h).  There is NO fallback: if the HIP library is missing or no GPU is
+visible, creating a PathTracer raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libidkpt.so")
+
+# every symbol include/idkpt.h declares (tests/test_abi.py checks the header against this list and the .so)
+SYMBOLS = [
+    "idkptCreate", "idkptDestroy", "idkptGetLastError", "idkptGetDeviceCount", "idkptGetVersionString",
+    "idkptSetSize", "idkptSetRowSharding", "idkptSetSlotBases", "idkptSetSettings", "idkptGetSettings",
+    "idkptSetPerFrame", "idkptSetPerFrameData", "idkptUploadScene", "idkptUpdateBuffer", "idkptSetLightCount",
+    "idkptBuildTlas", "idkptRefitBlas", "idkptUploadUnskinnedVertices", "idkptSkin", "idkptDownloadBuffer",
+    "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptRender", "idkptSynchronize", "idkptDownload",
+    "idkptDownloadRays", "idkptDownloadAliveQueue", "idkptEnablePrimaryHitCapture", "idkptDownloadPrimaryHits",
+    "idkptGetStats", "idkptResetStats", "idkptEnableCounters", "idkptEnableTiming", "idkptGetImageDevicePtr",
+    "idkptSetStream", "idkptGetStream",
+]
+
+_lib = None
+
+
+class IdkPtError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libidkpt.so; raises IdkPtError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IdkPtError("libidkpt.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(hipcc --offload-arch=gfx950); there is no CPU fallback for the path tracer")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t
+    sig = {
+        "idkptCreate": [i32, C.POINTER(i32), C.POINTER(vp)], "idkptDestroy": [vp], "idkptGetLastError": [vp, C.POINTER(C.c_char_p)],
+        "idkptGetDeviceCount": [C.POINTER(i32)], "idkptSetSize": [vp, i32, i32], "idkptSetRowSharding": [vp, i32, i32],
+        "idkptSetSlotBases": [vp, vp, i32], "idkptSetSettings": [vp, vp], "idkptGetSettings": [vp, vp],
+        "idkptSetPerFrame": [vp, vp, vp, vp], "idkptSetPerFrameData": [vp, vp], "idkptUploadScene": [vp, vp],
+        "idkptUpdateBuffer": [vp, i32, sz, sz, vp], "idkptSetLightCount": [vp, i32], "idkptBuildTlas": [vp, vp, i32],
+        "idkptRefitBlas": [vp, i32], "idkptUploadUnskinnedVertices": [vp, vp, i32], "idkptSkin": [vp, u32, u32, u32, u32],
+        "idkptDownloadBuffer": [vp, i32, sz, sz, vp], "idkptResetAccumulation": [vp], "idkptGetAccumulatedSamples": [vp, C.POINTER(u32)],
+        "idkptRender": [vp], "idkptSynchronize": [vp], "idkptDownload": [vp, i32, vp, sz], "idkptDownloadRays": [vp, vp, sz],
+        "idkptDownloadAliveQueue": [vp, vp, sz, C.POINTER(u32)], "idkptEnablePrimaryHitCapture": [vp, i32],
+        "idkptDownloadPrimaryHits": [vp, vp, vp, vp, sz], "idkptGetStats": [vp, vp], "idkptResetStats": [vp],
+        "idkptEnableCounters": [vp, i32], "idkptEnableTiming": [vp, i32], "idkptGetImageDevicePtr": [vp, i32, C.POINTER(vp), C.POINTER(sz)],
+        "idkptSetStream": [vp, vp], "idkptGetStream": [vp, C.POINTER(vp)],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i32
+    L.idkptGetVersionString.argtypes = []
+    L.idkptGetVersionString.restype = C.c_char_p
+    _lib = L
+    return L

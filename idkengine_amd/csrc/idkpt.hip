@@ -1,0 +1,950 @@
+// idkpt.hip — libidkpt.so: kernels' __global__ entry points and the C-ABI of include/idkpt.h.
+// Host schedule mirrors PathTracer.Compute (Source/Render/PathTracer.cs:214-271); see DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/idkpt.h"
+#include "pt_kernels.hpp"
+
+using namespace ptd;
+
+#define WAVE 64
+#define MAX_DEPTH_SLOTS 64
+
+// =================================================================================================== kernels
+
+DEV uint32_t wave_grab(uint32_t* counter, uint32_t amount)
+{
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, amount);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+DEV void flush_counters(uint64_t* counters, uint32_t nPairs, uint32_t nTris)
+{
+    // wave reduction then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) { nPairs += __shfl_down(nPairs, off); nTris += __shfl_down(nTris, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd((unsigned long long*)&counters[0], (unsigned long long)nPairs); atomicAdd((unsigned long long*)&counters[1], (unsigned long long)nTris); }
+}
+
+// FirstHit part 1: ray generation + closest-hit trace of the primary rays (FirstHit/compute.glsl:44-77,100-106).
+// Persistent waves; each wave pulls packets of 64 consecutive pixels.
+template <bool COUNT, bool COST>
+__global__ __launch_bounds__(WAVE) void k_trace_primary(DScene s, Frame f, RayBufs rays, HitBufs hits, uint32_t N, uint32_t* workCounter, uint64_t* counters)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    uint32_t* stk = lds + lane;
+    uint32_t nPairs = 0, nTris = 0;
+    while (true) {
+        uint32_t base = wave_grab(workCounter, WAVE);
+        if (base >= N) break;
+        uint32_t pix = base + lane;
+        if (pix < N) {
+            f3 origin; f2 pd; uint32_t seed;
+            gen_primary(f, pix, origin, pd, seed);
+            rays.o_ior[pix] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+            rays.thr_px[pix] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
+            rays.rad_py[pix] = make_float4(0.0f, 0.0f, 0.0f, pd.y);
+            f3 rd = DecodeUnitVec(pd.x, pd.y);
+            HitRec hit; float cost;
+            TraceRay<COUNT, COST>(s, f, origin, rd, hit, cost, stk, WAVE, nPairs, nTris);
+            hits.hit[pix] = make_float4(hit.T, hit.bx, hit.by, __uint_as_float(hit.tri));
+            hits.xformId[pix] = hit.xform;
+            if (COST) hits.cost[pix] = cost;
+        }
+    }
+    if (COUNT) flush_counters(counters, nPairs, nTris);
+}
+
+// NHit part 1: closest-hit trace of the alive queue (NHit/compute.glsl:56-58,93-98)
+template <bool COUNT>
+__global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    uint32_t* stk = lds + lane;
+    const uint32_t N = *countPtr;
+    uint32_t nPairs = 0, nTris = 0;
+    while (true) {
+        uint32_t base = wave_grab(workCounter, WAVE);
+        if (base >= N) break;
+        uint32_t slot = base + lane;
+        if (slot < N) {
+            uint32_t idx = queue[slot];
+            float4 o = rays.o_ior[idx];
+            float pdx = rays.thr_px[idx].w, pdy = rays.rad_py[idx].w;
+            f3 rd = DecodeUnitVec(pdx, pdy);
+            HitRec hit; float cost;
+            TraceRay<COUNT, false>(s, f, mk3(o.x, o.y, o.z), rd, hit, cost, stk, WAVE, nPairs, nTris);
+            hits.hit[slot] = make_float4(hit.T, hit.bx, hit.by, __uint_as_float(hit.tri));
+            hits.xformId[slot] = hit.xform;
+        }
+    }
+    if (COUNT) flush_counters(counters, nPairs, nTris);
+}
+
+// FirstHit / NHit part 2: shade + BSDF sample + continue decision.  One thread per queue slot; the continue bits of a
+// wave are published as one 64-bit ballot + popcount for the ordered compaction that follows.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm,
+                                               uint32_t slotBase, unsigned long long* contMask, uint32_t* waveCounts, uint32_t* keysTmp)
+{
+    const uint32_t N = FIRST ? countImm : *countPtr;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((slot & ~63u) >= N) return; // whole wave out of range
+    bool cont = false;
+    uint32_t key = 0;
+    if (slot < N) {
+        const uint32_t idx = FIRST ? slot : queue[slot];
+        float4 a = rays.o_ior[idx], b = rays.thr_px[idx], c = rays.rad_py[idx];
+        float4 h = hits.hit[slot];
+        HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[slot];
+        if (FIRST && f.g.DoDebugBVHTraversal) {
+            rays.o_ior[idx] = make_float4(a.x, a.y, a.z, hits.cost[slot]); // FirstHit:108-112
+        } else {
+            RayState r; r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;
+            AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
+            if (!FIRST && f.outputAovs) { float4 aa = rays.aovA[idx], an = rays.aovN[idx]; aov.albedo = mk3(aa.x, aa.y, aa.z); aov.newWeight = aa.w; aov.normal = mk3(an.x, an.y, an.z); }
+            uint32_t rng, gidSeed;
+            if (FIRST) {
+                f3 o2; f2 pd2; gen_primary(f, idx, o2, pd2, rng); // re-derives the RNG state after ray generation (cheaper than 4 B/pixel of HBM)
+                int lx = (int)(idx % (uint32_t)f.W), ly = (int)(idx / (uint32_t)f.W);
+                gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
+            } else {
+                uint32_t gslot = slotBase + slot;
+                rng = gslot * 4096u + f.accumulated; // NHit:54
+                gidSeed = gslot;                      // Shading.glsl:74 with gl_GlobalInvocationID = (slot, 0)
+            }
+            f3 rd = DecodeUnitVec(r.pdx, r.pdy);
+            bool hitScene = hit.T != PT_FLOAT_MAX;
+            cont = ShadeHit<FIRST>(s, f, hit, hitScene, rd, r, aov, rng, gidSeed, key);
+            rays.o_ior[idx] = make_float4(r.origin.x, r.origin.y, r.origin.z, r.prevIor);
+            rays.thr_px[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
+            rays.rad_py[idx] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
+            if (f.outputAovs) { rays.aovA[idx] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[idx] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
+        }
+        keysTmp[slot] = key & ((1u << IDKPT_SORT_KEY_BITS) - 1u); // NHit:81
+    }
+    unsigned long long m = __ballot(cont);
+    if ((threadIdx.x & 63) == 0) { uint32_t w = slot >> 6; contMask[w] = m; waveCounts[w] = (uint32_t)__popcll(m); }
+}
+
+// Ordered exclusive scan of the per-wave continue counts (single workgroup): reproduces the sequential enqueue order.
+__global__ __launch_bounds__(1024) void k_scan_waves(const uint32_t* countPtr, uint32_t countImm, uint32_t* waveCounts, uint32_t* nextCount, unsigned long long* tracedRays)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t N = countPtr ? *countPtr : countImm;
+    const uint32_t nW = (N + 63) / 64;
+    const uint32_t per = (nW + 1023) / 1024;
+    const uint32_t t = threadIdx.x;
+    uint32_t b = t * per, e = min(b + per, nW);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += waveCounts[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+        uint32_t v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t i = b; i < e; i++) { uint32_t c = waveCounts[i]; waveCounts[i] = run; run += c; }
+    if (t == 1023) { *nextCount = part[1023]; if (tracedRays) atomicAdd(tracedRays, (unsigned long long)part[1023]); }
+}
+
+// Scatter of the surviving ray indices (and their sort keys) to their ordered slots.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_compact(const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm, const unsigned long long* contMask, const uint32_t* waveOffsets,
+                                                 const uint32_t* keysTmp, uint32_t* queueNext, uint32_t* keysNext)
+{
+    const uint32_t N = FIRST ? countImm : *countPtr;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= N) return;
+    const uint32_t w = slot >> 6, lane = slot & 63;
+    unsigned long long m = contMask[w];
+    if ((m >> lane) & 1ull) {
+        uint32_t dst = waveOffsets[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        queueNext[dst] = FIRST ? slot : queue[slot];
+        keysNext[dst] = keysTmp[slot];
+    }
+}
+
+// ---- stable LSD radix sort of the alive queue by the 21-bit key (replaces CountingSort/**; PathTracer.cs:273-297).
+// 3 passes x 7 bits.  Per pass: (1) per-block digit histogram, (2) exclusive scan over [digit][block], (3) stable scatter.
+#define SORT_BLOCK 256
+#define SORT_ITEMS 4                      // items per thread
+#define SORT_TILE (SORT_BLOCK * SORT_ITEMS)
+#define SORT_RADIX 128
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_hist(const uint32_t* keys, const uint32_t* countPtr, uint32_t shift, uint32_t* hist /*[RADIX][numTiles]*/, uint32_t numTilesMax)
+{
+    __shared__ uint32_t h[SORT_RADIX];
+    const uint32_t N = *countPtr;
+    const uint32_t tile = blockIdx.x;
+    if (tile * SORT_TILE >= N) return;
+    if (threadIdx.x < SORT_RADIX) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = 0; k < SORT_ITEMS; k++) { uint32_t i = tile * SORT_TILE + k * SORT_BLOCK + threadIdx.x; if (i < N) atomicAdd(&h[(keys[i] >> shift) & (SORT_RADIX - 1)], 1u); }
+    __syncthreads();
+    if (threadIdx.x < SORT_RADIX) hist[threadIdx.x * numTilesMax + tile] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_sort_scan(const uint32_t* countPtr, uint32_t* hist, uint32_t numTilesMax)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t N = *countPtr;
+    const uint32_t nT = (N + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t total = SORT_RADIX * nT;          // logical index = digit * nT + tile
+    const uint32_t per = (total + 1023) / 1024;
+    const uint32_t t = threadIdx.x;
+    uint32_t b = t * per, e = min(b + per, total);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += hist[(i / nT) * numTilesMax + (i % nT)];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) { uint32_t v = (t >= off) ? part[t - off] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+    uint32_t run = part[t] - sum;
+    for (uint32_t i = b; i < e; i++) { uint32_t* p = &hist[(i / nT) * numTilesMax + (i % nT)]; uint32_t c = *p; *p = run; run += c; }
+}
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, const uint32_t* countPtr, uint32_t shift, const uint32_t* hist, uint32_t numTilesMax,
+                                                             uint32_t* keysOut, uint32_t* valsOut)
+{
+    // stable within the tile: items are visited in index order (k-major, then wave, then lane)
+    __shared__ uint32_t digitBase[SORT_RADIX];
+    __shared__ uint32_t waveDigit[SORT_BLOCK / 64][SORT_RADIX];
+    const uint32_t N = *countPtr;
+    const uint32_t tile = blockIdx.x;
+    if (tile * SORT_TILE >= N) return;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < SORT_RADIX) digitBase[threadIdx.x] = hist[threadIdx.x * numTilesMax + tile];
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        uint32_t i = tile * SORT_TILE + k * SORT_BLOCK + threadIdx.x;
+        bool valid = i < N;
+        uint32_t key = valid ? keys[i] : 0, val = valid ? vals[i] : 0;
+        uint32_t d = (key >> shift) & (SORT_RADIX - 1);
+        // rank among lanes of this wave with the same digit (match via 7 ballots)
+        unsigned long long same = __ballot(valid);
+        for (int bit = 0; bit < 7; bit++) { unsigned long long bm = __ballot((d >> bit) & 1u); same &= ((d >> bit) & 1u) ? bm : ~bm; }
+        uint32_t rankInWave = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        uint32_t cntInWave = (uint32_t)__popcll(same);
+        for (uint32_t x = threadIdx.x; x < (SORT_BLOCK / 64) * SORT_RADIX; x += SORT_BLOCK) (&waveDigit[0][0])[x] = 0;
+        __syncthreads();
+        if (valid && rankInWave == 0) waveDigit[wv][d] = cntInWave;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w2 = 0; w2 < wv; w2++) before += waveDigit[w2][d];
+        uint32_t dst = digitBase[d] + before + rankInWave;
+        if (valid) { keysOut[dst] = key; valsOut[dst] = val; }
+        __syncthreads();
+        if (threadIdx.x < SORT_RADIX) { uint32_t tot = 0; for (uint32_t w2 = 0; w2 < SORT_BLOCK / 64; w2++) tot += waveDigit[w2][threadIdx.x]; digitBase[threadIdx.x] += tot; }
+        __syncthreads();
+    }
+}
+
+// FinalDraw/compute.glsl:24-62
+DEV f3 TurboColormap(float x)
+{
+    x = gclamp(x, 0.0f, 1.0f);
+    float v0 = 1.0f, v1 = x, v2 = x * x, v3 = x * x * x;
+    float w0 = v2 * v2, w1 = v3 * v2;
+    float r = (((v0 * 0.13572138f + v1 * 4.61539260f) + v2 * -42.66032258f) + v3 * 132.13108234f) + (w0 * -152.94239396f + w1 * 59.28637943f);
+    float g = (((v0 * 0.09140261f + v1 * 2.19418839f) + v2 * 4.84296658f) + v3 * -14.18503333f) + (w0 * 4.27729857f + w1 * 2.82956604f);
+    float b = (((v0 * 0.10667330f + v1 * 12.64194608f) + v2 * -60.58204836f) + v3 * 110.36276771f) + (w0 * -89.90310912f + w1 * 27.34824973f);
+    return mk3(r, g, b);
+}
+__global__ __launch_bounds__(256) void k_final_draw(Frame f, RayBufs rays, float4* imgResult, float4* imgAlbedo, float4* imgNormal, uint32_t N)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float w = 1.0f / ((float)f.accumulated + 1.0f);
+    float4 c = rays.rad_py[i];
+    f3 nr = mk3(c.x, c.y, c.z);
+    if (f.g.DoDebugBVHTraversal) nr = TurboColormap(rays.o_ior[i].w / 150.0f);
+    float4 o = imgResult[i];
+    f3 r = gmix(mk3(o.x, o.y, o.z), nr, w);
+    imgResult[i] = make_float4(r.x, r.y, r.z, 1.0f);
+    if (f.outputAovs) {
+        float4 a = rays.aovA[i], n = rays.aovN[i];
+        float4 oa = imgAlbedo[i], on = imgNormal[i];
+        f3 ra = gmix(mk3(oa.x, oa.y, oa.z), mk3(a.x, a.y, a.z), w), rn = gmix(mk3(on.x, on.y, on.z), mk3(n.x, n.y, n.z), w);
+        imgAlbedo[i] = make_float4(ra.x, ra.y, ra.z, 1.0f); imgNormal[i] = make_float4(rn.x, rn.y, rn.z, 1.0f);
+    }
+}
+
+// derived layout: positions of each BLAS triangle's vertices, in leaf order (48 B/triangle, one contiguous fetch in the leaf loop)
+__global__ void k_gather_triverts(const uint4* tris, const float* positions, float4* triVerts, uint32_t first, uint32_t count)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint4 t = tris[first + i];
+    const float* a = positions + 3 * (size_t)t.x; const float* b = positions + 3 * (size_t)t.y; const float* c = positions + 3 * (size_t)t.z;
+    float4* o = triVerts + 3 * (size_t)(first + i);
+    o[0] = make_float4(a[0], a[1], a[2], 0.0f); o[1] = make_float4(b[0], b[1], b[2], 0.0f); o[2] = make_float4(c[0], c[1], c[2], 0.0f);
+}
+
+// BLAS refit (Shaders/BLASRefit/compute.glsl).  The reference walks leaf->root inside one dispatch behind an
+// atomicExchange "second arrival" lock; here the same unions are evaluated level by level (deepest first), one launch
+// per level, so no workgroup ever consumes another workgroup's stores inside a launch (per-XCD L2s are not coherent).
+__global__ void k_refit_leaves(float4* nodes, const uint4* tris, const float4* triVerts, const int32_t* leafIds, uint32_t leafCount, uint32_t nodeOffset, uint32_t triOffset)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= leafCount) return;
+    uint32_t id = nodeOffset + (uint32_t)leafIds[i];
+    float4 mn = nodes[2 * (size_t)id], mx = nodes[2 * (size_t)id + 1];
+    uint32_t start = triOffset + __float_as_uint(mn.w), count = __float_as_uint(mx.w);
+    f3 bmin = splat3(PT_FLOAT_MAX), bmax = splat3(-PT_FLOAT_MAX);
+    for (uint32_t k = start; k < start + count; k++) {
+        for (int v = 0; v < 3; v++) { float4 p = triVerts[3 * (size_t)k + v]; bmin = mk3(gmin(bmin.x, p.x), gmin(bmin.y, p.y), gmin(bmin.z, p.z)); bmax = mk3(gmax(bmax.x, p.x), gmax(bmax.y, p.y), gmax(bmax.z, p.z)); }
+    }
+    nodes[2 * (size_t)id] = make_float4(bmin.x, bmin.y, bmin.z, mn.w); nodes[2 * (size_t)id + 1] = make_float4(bmax.x, bmax.y, bmax.z, mx.w);
+}
+__global__ void k_refit_level(float4* nodes, const int32_t* levelNodes, uint32_t count, uint32_t nodeOffset)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t id = nodeOffset + (uint32_t)levelNodes[i];
+    float4 mn = nodes[2 * (size_t)id], mx = nodes[2 * (size_t)id + 1];
+    uint32_t child = nodeOffset + __float_as_uint(mn.w);
+    float4 lmn = nodes[2 * (size_t)child], lmx = nodes[2 * (size_t)child + 1], rmn = nodes[2 * (size_t)child + 2], rmx = nodes[2 * (size_t)child + 3];
+    nodes[2 * (size_t)id] = make_float4(gmin(lmn.x, rmn.x), gmin(lmn.y, rmn.y), gmin(lmn.z, rmn.z), mn.w);
+    nodes[2 * (size_t)id + 1] = make_float4(gmax(lmx.x, rmx.x), gmax(lmx.y, rmx.y), gmax(lmx.z, rmx.z), mx.w);
+}
+
+// Skinning (Shaders/Skinning/compute.glsl:14-47): 4-weight linear blend; joint matrices are row_major mat4x3 (3 x float4)
+__global__ void k_skin(const GpuUnskinnedVertex* unskinned, const float4* joints, float* positions, float* prevPositions, uint4* vertices,
+                       uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    GpuUnskinnedVertex u = unskinned[inOff + i];
+    float4 m[3];
+    for (int r = 0; r < 3; r++) {
+        float4 a = joints[3 * (size_t)(jointOff + u.JointIndices[0]) + r], b = joints[3 * (size_t)(jointOff + u.JointIndices[1]) + r];
+        float4 c = joints[3 * (size_t)(jointOff + u.JointIndices[2]) + r], d = joints[3 * (size_t)(jointOff + u.JointIndices[3]) + r];
+        float w0 = u.JointWeights[0], w1 = u.JointWeights[1], w2 = u.JointWeights[2], w3 = u.JointWeights[3];
+        m[r] = make_float4(((w0 * a.x + w1 * b.x) + w2 * c.x) + w3 * d.x, ((w0 * a.y + w1 * b.y) + w2 * c.y) + w3 * d.y,
+                           ((w0 * a.z + w1 * b.z) + w2 * c.z) + w3 * d.z, ((w0 * a.w + w1 * b.w) + w2 * c.w) + w3 * d.w);
+    }
+    M34 M; M.r0 = m[0]; M.r1 = m[1]; M.r2 = m[2];
+    f3 p = mk3(u.Position[0], u.Position[1], u.Position[2]);
+    f3 n = DecompressSR11G11B10(u.Normal), t = DecompressSR11G11B10(u.Tangent);
+    f3 np = xform34(M, p, 1.0f);
+    // mat3(skinMatrix) * v : out_i = (R[i][0]*v.x + R[i][1]*v.y) + R[i][2]*v.z
+    f3 nn = normalize(mk3((M.r0.x * n.x + M.r0.y * n.y) + M.r0.z * n.z, (M.r1.x * n.x + M.r1.y * n.y) + M.r1.z * n.z, (M.r2.x * n.x + M.r2.y * n.y) + M.r2.z * n.z));
+    f3 nt = normalize(mk3((M.r0.x * t.x + M.r0.y * t.y) + M.r0.z * t.z, (M.r1.x * t.x + M.r1.y * t.y) + M.r1.z * t.z, (M.r2.x * t.x + M.r2.y * t.y) + M.r2.z * t.z));
+    size_t o = (size_t)(outOff + i);
+    if (prevPositions) { prevPositions[3 * o] = positions[3 * o]; prevPositions[3 * o + 1] = positions[3 * o + 1]; prevPositions[3 * o + 2] = positions[3 * o + 2]; }
+    positions[3 * o] = np.x; positions[3 * o + 1] = np.y; positions[3 * o + 2] = np.z;
+    uint4 v = vertices[o]; v.w = CompressSR11G11B10(nn); v.z = CompressSR11G11B10(nt); vertices[o] = v;
+}
+
+// =================================================================================================== host side
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n) { if (n <= bytes && p) return hipSuccess; if (p) (void)hipFree(p); p = nullptr; bytes = 0; if (n == 0) return hipSuccess; hipError_t e = hipMalloc(&p, n); if (e == hipSuccess) bytes = n; return e; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct idkpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr; bool ownStream = true;
+    std::string lastError;
+    int numCUs = 256;
+    // config
+    idkpt_settings st;
+    int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0;
+    float invProj[16], invView[16], viewPos[3];
+    uint32_t accumulated = 0;
+    bool counters = false, timing = false, capturePrimary = false;
+    // scene
+    bool haveScene = false;
+    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes;
+    std::vector<DevBuf> texData;
+    std::vector<GpuBlasDesc> hDescs;
+    std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
+    std::vector<uint32_t> levelBase;                 // per BLAS base into levelNodes
+    int nodeCount = 0, triCount = 0, instanceCount = 0, tlasCount = 0, vertexCount = 0, meshCount = 0, materialCount = 0, xformCount = 0, lightCount = 0, skySize = 0, textureCount = 0, unskinnedCount = 0;
+    int sceneStack = 1;
+    // wavefront state
+    DevBuf rayO, rayT, rayR, aovA, aovN, hit, hitX, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, contMask, waveCounts, counts, work, sortHist, counters64;
+    DevBuf img[3];
+    float4* extImg[3] = {nullptr, nullptr, nullptr};
+    uint32_t slotBases[MAX_DEPTH_SLOTS];
+    // stats
+    idkpt_stats stats;
+    uint32_t* hCounts = nullptr; // pinned
+    hipEvent_t evFrame[2] = {nullptr, nullptr};
+    int lastQueueSide = 0; int lastQueueCountSlot = 0;
+};
+
+static int fail(idkpt_ctx* c, int code, const std::string& msg) { if (c) c->lastError = msg; return code; }
+#define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(ctx, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+#define REQUIRE(cond, msg) do { if (!(cond)) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
+
+static int local_rows(int H, int mod, int rem) { int n = 0; for (int y = rem; y < H; y += mod) n++; return n; }
+
+static int alloc_frame(idkpt_ctx* ctx)
+{
+    size_t N = (size_t)ctx->W * ctx->rows;
+    HIPC(ctx->rayO.ensure(N * 16)); HIPC(ctx->rayT.ensure(N * 16)); HIPC(ctx->rayR.ensure(N * 16));
+    HIPC(ctx->aovA.ensure(N * 16)); HIPC(ctx->aovN.ensure(N * 16));
+    HIPC(ctx->hit.ensure(N * 16)); HIPC(ctx->hitX.ensure(N * 4)); HIPC(ctx->hitCost.ensure(N * 4));
+    for (int i = 0; i < 2; i++) { HIPC(ctx->queue[i].ensure(N * 4)); HIPC(ctx->keys[i].ensure(N * 4)); }
+    HIPC(ctx->keysTmp.ensure(N * 4)); HIPC(ctx->sortKeys.ensure(N * 4)); HIPC(ctx->sortVals.ensure(N * 4));
+    size_t nW = (N + 63) / 64;
+    HIPC(ctx->contMask.ensure(nW * 8)); HIPC(ctx->waveCounts.ensure(nW * 4));
+    HIPC(ctx->counts.ensure(MAX_DEPTH_SLOTS * 4)); HIPC(ctx->work.ensure(4 * MAX_DEPTH_SLOTS * 4)); HIPC(ctx->counters64.ensure(32));
+    size_t nTiles = (N + SORT_TILE - 1) / SORT_TILE;
+    HIPC(ctx->sortHist.ensure(SORT_RADIX * nTiles * 4));
+    for (int i = 0; i < 3; i++) { HIPC(ctx->img[i].ensure(N * 16)); HIPC(hipMemsetAsync(ctx->img[i].p, 0, N * 16, ctx->stream)); }
+    HIPC(hipMemsetAsync(ctx->counters64.p, 0, 32, ctx->stream));
+    HIPC(hipMemsetAsync(ctx->aovA.p, 0, N * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, N * 16, ctx->stream));
+    ctx->accumulated = 0;
+    return IDKPT_OK;
+}
+
+extern "C" {
+
+const char* idkptGetVersionString(void) { return "idkpt 0.1 (gfx950)"; }
+
+int32_t idkptGetDeviceCount(int32_t* outCount)
+{
+    int n = 0; hipError_t e = hipGetDeviceCount(&n);
+    if (outCount) *outCount = (e == hipSuccess) ? n : 0;
+    return e == hipSuccess ? IDKPT_OK : IDKPT_ERR_NO_DEVICE;
+}
+
+int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** outCtx)
+{
+    if (!outCtx) return IDKPT_ERR_INVALID_ARGUMENT;
+    *outCtx = nullptr;
+    if (deviceCount != 1) return IDKPT_ERR_INVALID_ARGUMENT; // one context per process per GPU
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return IDKPT_ERR_NO_DEVICE;
+    int dev = deviceIds ? deviceIds[0] : 0;
+    if (dev < 0 || dev >= n) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(dev) != hipSuccess) return IDKPT_ERR_HIP;
+    idkpt_ctx* ctx = new idkpt_ctx();
+    ctx->device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->numCUs = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return IDKPT_ERR_HIP; }
+    memset(&ctx->st, 0, sizeof(ctx->st));
+    ctx->st.Gpu.FocalLength = 8.0f; ctx->st.Gpu.DoRussianRoulette = 1; ctx->st.RayDepth = 7; ctx->st.SamplesPerPixel = 1;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    memset(ctx->slotBases, 0, sizeof(ctx->slotBases));
+    memset(ctx->invProj, 0, 64); memset(ctx->invView, 0, 64); memset(ctx->viewPos, 0, 12);
+    if (hipHostMalloc((void**)&ctx->hCounts, MAX_DEPTH_SLOTS * 4 + 16, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
+    memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4 + 16);
+    hipEventCreate(&ctx->evFrame[0]); hipEventCreate(&ctx->evFrame[1]);
+    *outCtx = ctx;
+    return IDKPT_OK;
+}
+
+int32_t idkptDestroy(idkpt_ctx* ctx)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* all[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
+                     &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
+                     &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
+    for (DevBuf* b : all) b->release();
+    for (auto& t : ctx->texData) t.release();
+    if (ctx->hCounts) (void)hipHostFree(ctx->hCounts);
+    if (ctx->evFrame[0]) (void)hipEventDestroy(ctx->evFrame[0]);
+    if (ctx->evFrame[1]) (void)hipEventDestroy(ctx->evFrame[1]);
+    if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return IDKPT_OK;
+}
+
+int32_t idkptGetLastError(idkpt_ctx* ctx, const char** outMessage)
+{
+    if (!ctx || !outMessage) return IDKPT_ERR_INVALID_ARGUMENT;
+    *outMessage = ctx->lastError.c_str();
+    return IDKPT_OK;
+}
+
+int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
+    HIPC(hipSetDevice(ctx->device));
+    ctx->W = width; ctx->H = height; ctx->rows = local_rows(height, ctx->rowMod, ctx->rowRem);
+    return alloc_frame(ctx);
+}
+
+int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemainder)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(rowModulo >= 1 && rowRemainder >= 0 && rowRemainder < rowModulo, "idkptSetRowSharding: need 0 <= remainder < modulo");
+    ctx->rowMod = rowModulo; ctx->rowRem = rowRemainder;
+    if (ctx->W > 0) { HIPC(hipSetDevice(ctx->device)); ctx->rows = local_rows(ctx->H, rowModulo, rowRemainder); return alloc_frame(ctx); }
+    return IDKPT_OK;
+}
+
+int32_t idkptSetSlotBases(idkpt_ctx* ctx, const uint32_t* slotBases, int32_t count)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(count >= 0 && count <= MAX_DEPTH_SLOTS, "idkptSetSlotBases: count out of range");
+    memset(ctx->slotBases, 0, sizeof(ctx->slotBases));
+    for (int i = 0; i < count; i++) ctx->slotBases[i] = slotBases[i];
+    return IDKPT_OK;
+}
+
+int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* s)
+{
+    if (!ctx || !s) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(s->RayDepth >= 1 && s->RayDepth < MAX_DEPTH_SLOTS - 1, "idkptSetSettings: RayDepth out of range");
+    REQUIRE(s->SamplesPerPixel >= 1, "idkptSetSettings: SamplesPerPixel must be >= 1");
+    const idkpt_settings& o = ctx->st;
+    // PathTracer setters that call ResetAccumulation (PathTracer.cs:17-98): RayDepth, FocalLength, LenseRadius, DoDebugBVHTraversal, DoTraceLights
+    bool reset = o.RayDepth != s->RayDepth || o.Gpu.FocalLength != s->Gpu.FocalLength || o.Gpu.LenseRadius != s->Gpu.LenseRadius ||
+                 o.Gpu.DoDebugBVHTraversal != s->Gpu.DoDebugBVHTraversal || o.Gpu.DoTraceLights != s->Gpu.DoTraceLights || o.UseTlas != s->UseTlas;
+    ctx->st = *s;
+    if (ctx->st.Gpu.DoDebugBVHTraversal) ctx->st.RayDepth = 1; // PathTracer.cs:67-71
+    if (reset) ctx->accumulated = 0;
+    return IDKPT_OK;
+}
+int32_t idkptGetSettings(idkpt_ctx* ctx, idkpt_settings* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->st; return IDKPT_OK; }
+
+int32_t idkptSetPerFrame(idkpt_ctx* ctx, const float invProjection[16], const float invView[16], const float viewPos[3])
+{
+    if (!ctx || !invProjection || !invView || !viewPos) return IDKPT_ERR_INVALID_ARGUMENT;
+    memcpy(ctx->invProj, invProjection, 64); memcpy(ctx->invView, invView, 64); memcpy(ctx->viewPos, viewPos, 12);
+    return IDKPT_OK;
+}
+int32_t idkptSetPerFrameData(idkpt_ctx* ctx, const GpuPerFrameData* p) { if (!ctx || !p) return IDKPT_ERR_INVALID_ARGUMENT; return idkptSetPerFrame(ctx, p->InvProjection, p->InvView, p->ViewPos); }
+
+static int regather_triverts(idkpt_ctx* ctx, uint32_t first, uint32_t count)
+{
+    if (count == 0) return IDKPT_OK;
+    hipLaunchKernelGGL(k_gather_triverts, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, ctx->tris.as<uint4>(), ctx->positions.as<float>(), ctx->triVerts.as<float4>(), first, count);
+    HIPC(hipGetLastError());
+    return IDKPT_OK;
+}
+
+static int upload(idkpt_ctx* ctx, DevBuf& b, const void* src, size_t bytes)
+{
+    HIPC(b.ensure(std::max<size_t>(bytes, 16)));
+    if (bytes) HIPC(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return IDKPT_OK;
+}
+
+int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
+{
+    if (!ctx || !sc) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(sc->BlasNodes && sc->BlasNodeCount >= 4, "idkptUploadScene: BlasNodes missing");
+    REQUIRE(sc->BlasTriangles && sc->BlasTriangleCount > 0, "idkptUploadScene: BlasTriangles missing");
+    REQUIRE(sc->BlasDescs && sc->BlasDescCount > 0 && sc->BlasInstances && sc->BlasInstanceCount > 0, "idkptUploadScene: BlasDescs/BlasInstances missing");
+    REQUIRE(sc->VertexPositions && sc->Vertices && sc->VertexCount > 0, "idkptUploadScene: vertices missing");
+    REQUIRE(sc->Meshes && sc->MeshCount > 0 && sc->Materials && sc->MaterialCount > 0 && sc->MeshTransforms && sc->MeshTransformCount > 0, "idkptUploadScene: meshes/materials/transforms missing");
+    REQUIRE(sc->LightCount >= 0 && sc->LightCount <= IDKPT_MAX_LIGHTS, "idkptUploadScene: more than 256 lights");
+    // validate indices so that a bad host array cannot fault the GPU
+    for (int i = 0; i < sc->BlasTriangleCount; i++) { const GpuBlasTriangle& t = sc->BlasTriangles[i]; REQUIRE(t.X < (uint32_t)sc->VertexCount && t.Y < (uint32_t)sc->VertexCount && t.Z < (uint32_t)sc->VertexCount && t.MeshId < (uint32_t)sc->MeshCount, "idkptUploadScene: BlasTriangle index out of range"); }
+    for (int i = 0; i < sc->MeshCount; i++) REQUIRE(sc->Meshes[i].MaterialId >= 0 && sc->Meshes[i].MaterialId < sc->MaterialCount, "idkptUploadScene: Mesh.MaterialId out of range");
+    for (int i = 0; i < sc->BlasInstanceCount; i++) REQUIRE(sc->BlasInstances[i].BlasId < (uint32_t)sc->BlasDescCount && sc->BlasInstances[i].MeshTransformId < (uint32_t)sc->MeshTransformCount, "idkptUploadScene: BlasInstance out of range");
+    int maxStack = 1;
+    for (int i = 0; i < sc->BlasDescCount; i++) {
+        const GpuBlasDesc& d = sc->BlasDescs[i];
+        REQUIRE(d.NodeOffset >= 0 && d.NodeCount >= 4 && d.NodeOffset + d.NodeCount <= sc->BlasNodeCount && d.TriangleOffset >= 0 && d.TriangleOffset + d.TriangleCount <= sc->BlasTriangleCount, "idkptUploadScene: BlasDesc range out of bounds");
+        maxStack = std::max(maxStack, d.RequiredStackSize);
+        for (int n = 1; n < d.NodeCount; n++) {
+            const GpuBlasNode& nd = sc->BlasNodes[d.NodeOffset + n];
+            if (nd.TriCount > 0) REQUIRE((uint64_t)nd.TriStartOrChild + nd.TriCount <= (uint64_t)d.TriangleCount, "idkptUploadScene: leaf triangle range out of bounds");
+            else if (n == 1 || nd.TriStartOrChild != 0) REQUIRE(nd.TriStartOrChild >= 2 && nd.TriStartOrChild + 1 < (uint32_t)d.NodeCount, "idkptUploadScene: child index out of bounds");
+        }
+    }
+    HIPC(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->nodes, sc->BlasNodes, (size_t)sc->BlasNodeCount * 32))) return rc;
+    if ((rc = upload(ctx, ctx->tris, sc->BlasTriangles, (size_t)sc->BlasTriangleCount * 16))) return rc;
+    if ((rc = upload(ctx, ctx->descs, sc->BlasDescs, (size_t)sc->BlasDescCount * sizeof(GpuBlasDesc)))) return rc;
+    if ((rc = upload(ctx, ctx->instances, sc->BlasInstances, (size_t)sc->BlasInstanceCount * 8))) return rc;
+    if ((rc = upload(ctx, ctx->tlas, sc->TlasNodes, (size_t)(sc->TlasNodes ? sc->TlasNodeCount : 0) * 32))) return rc;
+    if ((rc = upload(ctx, ctx->parents, sc->BlasParentIndices, (size_t)(sc->BlasParentIndices ? sc->BlasParentIndexCount : 0) * 4))) return rc;
+    if ((rc = upload(ctx, ctx->leaves, sc->BlasLeafIndices, (size_t)(sc->BlasLeafIndices ? sc->BlasLeafIndexCount : 0) * 4))) return rc;
+    if ((rc = upload(ctx, ctx->positions, sc->VertexPositions, (size_t)sc->VertexCount * 12))) return rc;
+    if ((rc = upload(ctx, ctx->vertices, sc->Vertices, (size_t)sc->VertexCount * 16))) return rc;
+    if ((rc = upload(ctx, ctx->meshes, sc->Meshes, (size_t)sc->MeshCount * sizeof(GpuMesh)))) return rc;
+    if ((rc = upload(ctx, ctx->materials, sc->Materials, (size_t)sc->MaterialCount * sizeof(GpuMaterial)))) return rc;
+    if ((rc = upload(ctx, ctx->xforms, sc->MeshTransforms, (size_t)sc->MeshTransformCount * sizeof(GpuMeshTransform)))) return rc;
+    HIPC(ctx->lights.ensure(IDKPT_MAX_LIGHTS * sizeof(GpuLight)));
+    if (sc->Lights && sc->LightCount) HIPC(hipMemcpyAsync(ctx->lights.p, sc->Lights, (size_t)sc->LightCount * sizeof(GpuLight), hipMemcpyHostToDevice, ctx->stream));
+    ctx->skySize = (sc->SkyFaces && sc->SkyFaceSize > 0) ? sc->SkyFaceSize : 0;
+    if ((rc = upload(ctx, ctx->sky, sc->SkyFaces, (size_t)6 * ctx->skySize * ctx->skySize * 16))) return rc;
+    for (auto& t : ctx->texData) t.release();
+    ctx->texData.clear();
+    std::vector<TexDesc> td;
+    for (int i = 0; i < sc->TextureCount; i++) {
+        const idkpt_texture& t = sc->Textures[i];
+        REQUIRE(t.width > 0 && t.height > 0 && t.rgba, "idkptUploadScene: bad texture");
+        ctx->texData.emplace_back();
+        if ((rc = upload(ctx, ctx->texData.back(), t.rgba, (size_t)t.width * t.height * 16))) return rc;
+        td.push_back({ctx->texData.back().as<float4>(), t.width, t.height});
+    }
+    if ((rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)))) return rc;
+    HIPC(ctx->triVerts.ensure((size_t)sc->BlasTriangleCount * 48));
+    ctx->nodeCount = sc->BlasNodeCount; ctx->triCount = sc->BlasTriangleCount; ctx->instanceCount = sc->BlasInstanceCount; ctx->tlasCount = sc->TlasNodes ? sc->TlasNodeCount : 0;
+    ctx->vertexCount = sc->VertexCount; ctx->meshCount = sc->MeshCount; ctx->materialCount = sc->MaterialCount; ctx->xformCount = sc->MeshTransformCount;
+    ctx->lightCount = sc->Lights ? sc->LightCount : 0; ctx->textureCount = sc->TextureCount;
+    ctx->hDescs.assign(sc->BlasDescs, sc->BlasDescs + sc->BlasDescCount);
+    ctx->sceneStack = maxStack;
+    // refit schedule: internal nodes of every refittable BLAS grouped by depth (children have larger ids than parents)
+    ctx->levelOffsets.assign(sc->BlasDescCount, {}); ctx->levelBase.assign(sc->BlasDescCount, 0);
+    std::vector<int32_t> allLevels;
+    for (int bi = 0; bi < sc->BlasDescCount; bi++) {
+        const GpuBlasDesc& d = sc->BlasDescs[bi];
+        if (!d.IsRefittable) continue;
+        std::vector<int> depth(d.NodeCount, 0); int maxD = 0;
+        for (int n = 1; n < d.NodeCount; n++) { const GpuBlasNode& nd = sc->BlasNodes[d.NodeOffset + n]; if (nd.TriCount == 0) { int c = (int)nd.TriStartOrChild; depth[c] = depth[c + 1] = depth[n] + 1; maxD = std::max(maxD, depth[n]); } }
+        std::vector<std::vector<int32_t>> lv(maxD + 1);
+        for (int n = 1; n < d.NodeCount; n++) if (sc->BlasNodes[d.NodeOffset + n].TriCount == 0 && (n == 1 || n >= 2)) lv[depth[n]].push_back(n);
+        ctx->levelBase[bi] = (uint32_t)allLevels.size();
+        uint32_t off = 0;
+        for (auto& l : lv) { ctx->levelOffsets[bi].push_back(off); off += (uint32_t)l.size(); allLevels.insert(allLevels.end(), l.begin(), l.end()); }
+        ctx->levelOffsets[bi].push_back(off);
+    }
+    if ((rc = upload(ctx, ctx->levelNodes, allLevels.data(), allLevels.size() * 4))) return rc;
+    if ((rc = regather_triverts(ctx, 0, (uint32_t)sc->BlasTriangleCount))) return rc;
+    HIPC(hipStreamSynchronize(ctx->stream)); // host arrays are only borrowed for the duration of the call
+    ctx->haveScene = true;
+    ctx->accumulated = 0;
+    return IDKPT_OK;
+}
+
+int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(count >= 0 && count <= IDKPT_MAX_LIGHTS, "idkptSetLightCount: out of range");
+    ctx->lightCount = count; return IDKPT_OK;
+}
+
+static DevBuf* which_buffer(idkpt_ctx* ctx, int which, size_t* cap)
+{
+    switch (which) {
+        case IDKPT_BUF_MESH_TRANSFORMS: *cap = (size_t)ctx->xformCount * sizeof(GpuMeshTransform); return &ctx->xforms;
+        case IDKPT_BUF_VERTEX_POSITIONS: *cap = (size_t)ctx->vertexCount * 12; return &ctx->positions;
+        case IDKPT_BUF_VERTICES: *cap = (size_t)ctx->vertexCount * 16; return &ctx->vertices;
+        case IDKPT_BUF_MESHES: *cap = (size_t)ctx->meshCount * sizeof(GpuMesh); return &ctx->meshes;
+        case IDKPT_BUF_MATERIALS: *cap = (size_t)ctx->materialCount * sizeof(GpuMaterial); return &ctx->materials;
+        case IDKPT_BUF_LIGHTS: *cap = (size_t)IDKPT_MAX_LIGHTS * sizeof(GpuLight); return &ctx->lights;
+        case IDKPT_BUF_BLAS_NODES: *cap = (size_t)ctx->nodeCount * 32; return &ctx->nodes;
+        case IDKPT_BUF_TLAS_NODES: *cap = (size_t)ctx->tlasCount * 32; return &ctx->tlas;
+        case IDKPT_BUF_JOINT_MATRICES: *cap = ctx->joints.bytes; return &ctx->joints;
+        default: return nullptr;
+    }
+}
+
+int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, const void* data)
+{
+    if (!ctx || !data) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptUpdateBuffer: no scene uploaded");
+    HIPC(hipSetDevice(ctx->device));
+    if (which == IDKPT_BUF_JOINT_MATRICES) { size_t need = offsetBytes + bytes; if (need > ctx->joints.bytes) { DevBuf nb; HIPC(nb.ensure(need)); if (ctx->joints.p) HIPC(hipMemcpy(nb.p, ctx->joints.p, ctx->joints.bytes, hipMemcpyDeviceToDevice)); ctx->joints.release(); ctx->joints = nb; } }
+    size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
+    REQUIRE(b != nullptr, "idkptUpdateBuffer: unknown buffer");
+    REQUIRE(offsetBytes + bytes <= cap, "idkptUpdateBuffer: range exceeds buffer");
+    HIPC(hipMemcpyAsync((char*)b->p + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (which == IDKPT_BUF_VERTEX_POSITIONS) { int rc = regather_triverts(ctx, 0, (uint32_t)ctx->triCount); if (rc) return rc; }
+    HIPC(hipStreamSynchronize(ctx->stream));
+    return IDKPT_OK;
+}
+
+int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst)
+{
+    if (!ctx || !dst) return IDKPT_ERR_INVALID_ARGUMENT;
+    size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
+    REQUIRE(b != nullptr && offsetBytes + bytes <= cap, "idkptDownloadBuffer: bad buffer/range");
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipMemcpyAsync(dst, (char*)b->p + offsetBytes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    return IDKPT_OK;
+}
+
+int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCount)
+{
+    if (!ctx || !nodes || nodeCount <= 0) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    int rc = upload(ctx, ctx->tlas, nodes, (size_t)nodeCount * 32); if (rc) return rc;
+    HIPC(hipStreamSynchronize(ctx->stream));
+    ctx->tlasCount = nodeCount;
+    return IDKPT_OK;
+}
+
+int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRefitBlas: no scene uploaded");
+    REQUIRE(blasId >= 0 && blasId < (int)ctx->hDescs.size(), "idkptRefitBlas: blasId out of range");
+    const GpuBlasDesc& d = ctx->hDescs[blasId];
+    if (!d.IsRefittable || d.LeafIndicesCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRefitBlas: BLAS is not refittable (no leaf/parent indices)");
+    HIPC(hipSetDevice(ctx->device));
+    int rc = regather_triverts(ctx, (uint32_t)d.TriangleOffset, (uint32_t)d.TriangleCount); if (rc) return rc;
+    hipLaunchKernelGGL(k_refit_leaves, dim3((d.LeafIndicesCount + 63) / 64), dim3(64), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->tris.as<uint4>(), ctx->triVerts.as<float4>(),
+                       ctx->leaves.as<int32_t>() + d.LeafIndicesOffset, (uint32_t)d.LeafIndicesCount, (uint32_t)d.NodeOffset, (uint32_t)d.TriangleOffset);
+    const std::vector<uint32_t>& off = ctx->levelOffsets[blasId];
+    for (int l = (int)off.size() - 2; l >= 0; l--) {
+        uint32_t cnt = off[l + 1] - off[l];
+        if (!cnt) continue;
+        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->levelNodes.as<int32_t>() + ctx->levelBase[blasId] + off[l], cnt, (uint32_t)d.NodeOffset);
+    }
+    HIPC(hipGetLastError());
+    return IDKPT_OK;
+}
+
+int32_t idkptUploadUnskinnedVertices(idkpt_ctx* ctx, const GpuUnskinnedVertex* verts, int32_t count)
+{
+    if (!ctx || !verts || count <= 0) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    int rc = upload(ctx, ctx->unskinned, verts, (size_t)count * sizeof(GpuUnskinnedVertex)); if (rc) return rc;
+    HIPC(hipStreamSynchronize(ctx->stream));
+    ctx->unskinnedCount = count;
+    return IDKPT_OK;
+}
+
+int32_t idkptSkin(idkpt_ctx* ctx, uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene || ctx->unskinnedCount == 0 || ctx->joints.bytes == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptSkin: needs scene, unskinned vertices and joint matrices");
+    REQUIRE((uint64_t)inOff + count <= (uint64_t)ctx->unskinnedCount && (uint64_t)outOff + count <= (uint64_t)ctx->vertexCount, "idkptSkin: range out of bounds");
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(ctx->prevPositions.ensure((size_t)ctx->vertexCount * 12));
+    if (count) hipLaunchKernelGGL(k_skin, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, ctx->unskinned.as<GpuUnskinnedVertex>(), ctx->joints.as<float4>(), ctx->positions.as<float>(),
+                                  ctx->prevPositions.as<float>(), ctx->vertices.as<uint4>(), inOff, outOff, jointOff, count);
+    HIPC(hipGetLastError());
+    return IDKPT_OK;
+}
+
+int32_t idkptResetAccumulation(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->accumulated = 0; return IDKPT_OK; }
+int32_t idkptGetAccumulatedSamples(idkpt_ctx* ctx, uint32_t* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->accumulated; return IDKPT_OK; }
+
+static DScene make_dscene(idkpt_ctx* ctx)
+{
+    DScene s;
+    s.nodes = ctx->nodes.as<float4>(); s.tris = ctx->tris.as<uint4>(); s.triVerts = ctx->triVerts.as<float4>();
+    s.descs = ctx->descs.as<GpuBlasDesc>(); s.instances = ctx->instances.as<GpuBlasInstance>(); s.instanceCount = ctx->instanceCount;
+    s.tlas = ctx->tlas.as<float4>(); s.tlasCount = ctx->tlasCount; s.vertices = ctx->vertices.as<uint4>();
+    s.meshes = ctx->meshes.as<GpuMesh>(); s.materials = ctx->materials.as<GpuMaterial>(); s.xforms = ctx->xforms.as<float4>();
+    s.lights = ctx->lights.as<GpuLight>(); s.lightCount = ctx->lightCount; s.sky = ctx->sky.as<float4>(); s.skySize = ctx->skySize;
+    s.textures = ctx->texDescs.as<TexDesc>(); s.textureCount = ctx->textureCount;
+    return s;
+}
+
+static float4* image_ptr(idkpt_ctx* ctx, int i) { return ctx->extImg[i] ? ctx->extImg[i] : ctx->img[i].as<float4>(); }
+
+// One sample: FirstHit -> [sort ->] NHit x (RayDepth-1) -> FinalDraw  (PathTracer.cs:218-270)
+static int render_sample(idkpt_ctx* ctx)
+{
+    const uint32_t N = (uint32_t)((size_t)ctx->W * ctx->rows);
+    DScene s = make_dscene(ctx);
+    Frame f;
+    memcpy(f.invProj, ctx->invProj, 64); memcpy(f.invView, ctx->invView, 64); memcpy(f.viewPos, ctx->viewPos, 12);
+    f.W = ctx->W; f.H = ctx->H; f.rowMod = ctx->rowMod; f.rowRem = ctx->rowRem; f.rows = ctx->rows;
+    f.g = ctx->st.Gpu; f.accumulated = ctx->accumulated; f.useTlas = ctx->st.UseTlas;
+    f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
+    f.outputAovs = ctx->st.OutputAOVs;
+    RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
+    HitBufs hits = {ctx->hit.as<float4>(), ctx->hitX.as<uint32_t>(), ctx->hitCost.as<float>()};
+    uint32_t* counts = ctx->counts.as<uint32_t>();
+    uint32_t* work = ctx->work.as<uint32_t>();
+    uint64_t* counters = ctx->counters64.as<uint64_t>();
+    const int depth = ctx->st.RayDepth;
+    hipStream_t st = ctx->stream;
+    HIPC(hipMemsetAsync(work, 0, 4 * MAX_DEPTH_SLOTS * 4, st));
+    HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
+
+    const size_t ldsBytes = (size_t)(f.stackCap + (f.useTlas ? TLAS_STACK_SIZE : 0)) * WAVE * 4;
+    if (ldsBytes > 64 * 1024) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack");
+    // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)
+    int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
+    wavesPerCU = std::max(1, wavesPerCU);
+    const uint32_t traceGrid = (uint32_t)(ctx->numCUs * wavesPerCU);
+    const bool debug = f.g.DoDebugBVHTraversal != 0;
+    const uint32_t gridN = (N + 255) / 256;
+
+    // ---- FirstHit
+    {
+        uint32_t g = std::min<uint32_t>(traceGrid, (N + 63) / 64);
+        if (ctx->counters) { if (debug) hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<true, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
+        else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
+        if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.p, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
+        hipLaunchKernelGGL((k_shade<true>), dim3(gridN), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, N, 0u,
+                           ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(), ctx->keysTmp.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, (const uint32_t*)nullptr, N, ctx->waveCounts.as<uint32_t>(), counts + 1, (unsigned long long*)(1 < depth ? counters + 2 : nullptr));
+        hipLaunchKernelGGL((k_compact<true>), dim3(gridN), dim3(256), 0, st, (const uint32_t*)nullptr, (const uint32_t*)nullptr, N, ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(),
+                           ctx->keysTmp.as<uint32_t>(), ctx->queue[1].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
+    }
+    int side = 1; // queue[side] holds the rays entering bounce j, its length is counts[j]
+    for (int j = 1; j < depth; j++) {
+        uint32_t* q = ctx->queue[side].as<uint32_t>(); uint32_t* k = ctx->keys[side].as<uint32_t>();
+        const uint32_t* cnt = counts + j;
+        if (ctx->st.DoRaySorting && j > 1) {
+            // RaySorting() (PathTracer.cs:232-237): stable sort of (key, rayIndex) by the 21-bit key
+            const uint32_t nTiles = (N + SORT_TILE - 1) / SORT_TILE;
+            uint32_t* ka = k; uint32_t* va = q; uint32_t* kb = ctx->sortKeys.as<uint32_t>(); uint32_t* vb = ctx->sortVals.as<uint32_t>();
+            for (int pass = 0; pass < 3; pass++) {
+                hipLaunchKernelGGL(k_sort_hist, dim3(nTiles), dim3(SORT_BLOCK), 0, st, ka, cnt, (uint32_t)(7 * pass), ctx->sortHist.as<uint32_t>(), nTiles);
+                hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, cnt, ctx->sortHist.as<uint32_t>(), nTiles);
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nTiles), dim3(SORT_BLOCK), 0, st, ka, va, cnt, (uint32_t)(7 * pass), ctx->sortHist.as<uint32_t>(), nTiles, kb, vb);
+                std::swap(ka, kb); std::swap(va, vb);
+            }
+            // after 3 passes the sorted data sits in (sortKeys, sortVals): copy back into the queue side (A*4 B each; the reference copies W*H*4, PathTracer.cs:296)
+            HIPC(hipMemcpyAsync(q, va, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+        }
+        if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
+        else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
+        hipLaunchKernelGGL((k_shade<false>), dim3(gridN), dim3(256), 0, st, s, f, rays, hits, q, cnt, 0u, ctx->slotBases[j],
+                           ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(), ctx->keysTmp.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, cnt, 0u, ctx->waveCounts.as<uint32_t>(), counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr));
+        hipLaunchKernelGGL((k_compact<false>), dim3(gridN), dim3(256), 0, st, q, cnt, 0u, ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(),
+                           ctx->keysTmp.as<uint32_t>(), ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
+        side = 1 - side;
+    }
+    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth;
+    hipLaunchKernelGGL(k_final_draw, dim3(gridN), dim3(256), 0, st, f, rays, image_ptr(ctx, 0), image_ptr(ctx, 1), image_ptr(ctx, 2), N);
+    HIPC(hipGetLastError());
+    // queue lengths stay on the GPU during the frame; a copy goes to pinned memory for GetStats (no sync here)
+    HIPC(hipMemcpyAsync(ctx->hCounts, counts, MAX_DEPTH_SLOTS * 4, hipMemcpyDeviceToHost, st));
+    ctx->accumulated++;
+    ctx->stats.Frames++;
+    ctx->stats.PrimaryRays += N;
+    return IDKPT_OK;
+}
+
+int32_t idkptRender(idkpt_ctx* ctx)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: no scene uploaded");
+    if (ctx->W <= 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: idkptSetSize not called");
+    if (ctx->st.UseTlas && ctx->tlasCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: UseTlas set but no TLAS nodes uploaded");
+    HIPC(hipSetDevice(ctx->device));
+    if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[0], ctx->stream));
+    for (int i = 0; i < ctx->st.SamplesPerPixel; i++) {
+        int rc = render_sample(ctx); if (rc) return rc;
+    }
+    if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[1], ctx->stream));
+    ctx->stats.LastFrameMs = -1.0f; // resolved lazily in GetStats
+    return IDKPT_OK;
+}
+
+int32_t idkptSynchronize(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); HIPC(hipStreamSynchronize(ctx->stream)); return IDKPT_OK; }
+
+int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes)
+{
+    if (!ctx || !rgba) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(image >= 0 && image < 3, "idkptDownload: bad image id");
+    size_t need = (size_t)ctx->W * ctx->rows * 16;
+    REQUIRE(bytes == need && need > 0, "idkptDownload: bytes must equal localRows*width*16");
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image), need, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    return IDKPT_OK;
+}
+
+int32_t idkptDownloadRays(idkpt_ctx* ctx, GpuWavefrontRay* out, size_t bytes)
+{
+    if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT;
+    size_t N = (size_t)ctx->W * ctx->rows;
+    REQUIRE(bytes == N * sizeof(GpuWavefrontRay) && N > 0, "idkptDownloadRays: bytes must equal pixelCount*48");
+    HIPC(hipSetDevice(ctx->device));
+    std::vector<float4> a(N), b(N), c(N);
+    HIPC(hipMemcpyAsync(a.data(), ctx->rayO.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(b.data(), ctx->rayT.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(c.data(), ctx->rayR.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < N; i++) {
+        GpuWavefrontRay& r = out[i];
+        r.Origin[0] = a[i].x; r.Origin[1] = a[i].y; r.Origin[2] = a[i].z; r.PreviousIOROrTraverseCost = a[i].w;
+        r.Throughput[0] = b[i].x; r.Throughput[1] = b[i].y; r.Throughput[2] = b[i].z; r.PackedDirectionX = b[i].w;
+        r.Radiance[0] = c[i].x; r.Radiance[1] = c[i].y; r.Radiance[2] = c[i].z; r.PackedDirectionY = c[i].w;
+    }
+    return IDKPT_OK;
+}
+
+int32_t idkptDownloadAliveQueue(idkpt_ctx* ctx, uint32_t* indices, size_t capacity, uint32_t* outCount)
+{
+    if (!ctx || !outCount) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    uint32_t n = ctx->hCounts[ctx->lastQueueCountSlot];
+    *outCount = n;
+    if (indices && n) { REQUIRE(capacity >= n, "idkptDownloadAliveQueue: capacity too small"); HIPC(hipMemcpy(indices, ctx->queue[ctx->lastQueueSide].p, (size_t)n * 4, hipMemcpyDeviceToHost)); }
+    return IDKPT_OK;
+}
+
+int32_t idkptEnablePrimaryHitCapture(idkpt_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->capturePrimary = enable != 0; return IDKPT_OK; }
+
+int32_t idkptDownloadPrimaryHits(idkpt_ctx* ctx, float* t, uint32_t* triangleId, float* baryXY, size_t pixelCount)
+{
+    if (!ctx || !t || !triangleId || !baryXY) return IDKPT_ERR_INVALID_ARGUMENT;
+    size_t N = (size_t)ctx->W * ctx->rows;
+    REQUIRE(pixelCount == N, "idkptDownloadPrimaryHits: pixelCount mismatch");
+    if (!ctx->capturePrimary || ctx->primHit.bytes < N * 16) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptDownloadPrimaryHits: call idkptEnablePrimaryHitCapture(ctx,1) before idkptRender");
+    HIPC(hipSetDevice(ctx->device));
+    std::vector<float4> h(N);
+    HIPC(hipMemcpyAsync(h.data(), ctx->primHit.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < N; i++) { t[i] = h[i].x; baryXY[2 * i] = h[i].y; baryXY[2 * i + 1] = h[i].z; memcpy(&triangleId[i], &h[i].w, 4); }
+    return IDKPT_OK;
+}
+
+int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* out)
+{
+    if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    idkpt_stats s = ctx->stats;
+    for (int j = 0; j < 16; j++) s.LastAliveCounts[j] = (j >= 1 && j < ctx->st.RayDepth) ? ctx->hCounts[j] : 0;
+    s.LastFrameMs = 0.0f; s.LastTraceMs = 0.0f;
+    if (ctx->timing && s.Frames > 0) { float ms = 0.0f; if (hipEventElapsedTime(&ms, ctx->evFrame[0], ctx->evFrame[1]) == hipSuccess) s.LastFrameMs = ms; }
+    uint64_t c[4] = {0, 0, 0, 0};
+    HIPC(hipMemcpy(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost));
+    s.NodePairVisits = c[0]; s.TriangleTests = c[1];
+    s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
+    *out = s;
+    return IDKPT_OK;
+}
+
+int32_t idkptResetStats(idkpt_ctx* ctx)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4);
+    HIPC(hipMemset(ctx->counters64.p, 0, 32));
+    return IDKPT_OK;
+}
+
+int32_t idkptEnableCounters(idkpt_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->counters = enable != 0; return IDKPT_OK; }
+int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->timing = enable != 0; return IDKPT_OK; }
+
+int32_t idkptGetImageDevicePtr(idkpt_ctx* ctx, int32_t image, void** outPtr, size_t* outBytes)
+{
+    if (!ctx || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(image >= 0 && image < 3 && ctx->W > 0, "idkptGetImageDevicePtr: bad image / no size");
+    *outPtr = image_ptr(ctx, image);
+    if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
+    return IDKPT_OK;
+}
+
+int32_t idkptSetStream(idkpt_ctx* ctx, void* hipStream)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    if (hipStream) { if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream); ctx->stream = (hipStream_t)hipStream; ctx->ownStream = false; }
+    else if (!ctx->ownStream) { HIPC(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->ownStream = true; }
+    return IDKPT_OK;
+}
+int32_t idkptGetStream(idkpt_ctx* ctx, void** out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = (void*)ctx->stream; return IDKPT_OK; }
+
+} // extern "C"

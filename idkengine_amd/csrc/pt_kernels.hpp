@@ -1,0 +1,409 @@
+// pt_kernels.hpp — gfx950 kernels of the wavefront path tracer (device code only; host API in idkpt.hip).
+//
+// Replaces the reference's GLSL compute pipeline (paths relative to /root/reference/IDKEngine/Resource/Shaders):
+//   PathTracing/FirstHit/compute.glsl, PathTracing/NHit/compute.glsl, PathTracing/FinalDraw/compute.glsl,
+//   PathTracing/CountingSort/**, include/BVHIntersect.glsl.
+// Structure (DESIGN.md "Kernels"): trace and shade are separate kernels so that the pointer-chasing traversal runs at
+// the occupancy its ~48 VGPRs allow and can be scheduled as persistent waves pulling 64-ray packets; the alive queue is
+// compacted with wave64 ballots + an ordered scan, which reproduces the canonical (sequential) enqueue order the
+// oracle defines for the reference's atomicAdd slots.
+#pragma once
+#include "pt_device.hpp"
+
+namespace ptd {
+
+struct TexDesc { const float4* data; int w, h; };
+
+struct DScene {
+    const float4* nodes;        // 2 x float4 per GpuBlasNode: {Min.xyz, TriStartOrChild}, {Max.xyz, TriCount}
+    const uint4* tris;          // GpuBlasTriangle
+    const float4* triVerts;     // derived: 3 x float4 per BLAS triangle (leaf order): positions of X,Y,Z (w unused)
+    const GpuBlasDesc* descs;
+    const GpuBlasInstance* instances; int instanceCount;
+    const float4* tlas; int tlasCount;
+    const uint4* vertices;      // GpuVertex {uv.x, uv.y, tangent, normal} as raw dwords
+    const GpuMesh* meshes;
+    const GpuMaterial* materials;
+    const float4* xforms;       // GpuMeshTransform as 9 x float4 (Model rows 0-2, InvModel rows 3-5, Prev rows 6-8)
+    const GpuLight* lights; int lightCount;
+    const float4* sky; int skySize;
+    const TexDesc* textures; int textureCount;
+};
+
+struct Frame {
+    float invProj[16]; float invView[16]; float viewPos[3];
+    int W, H, rowMod, rowRem, rows;
+    GpuSettings g;
+    uint32_t accumulated;
+    int useTlas, stackCap, outputAovs;
+};
+
+struct RayBufs {                // SoA planes of the reference's GpuWavefrontRay / GpuAovRay, indexed by local pixel
+    float4* o_ior;              // Origin.xyz, PreviousIOROrTraverseCost
+    float4* thr_px;             // Throughput.xyz, PackedDirectionX
+    float4* rad_py;             // Radiance.xyz, PackedDirectionY
+    float4* aovA;               // Albedo.xyz, NewWeight
+    float4* aovN;               // Normal.xyz, pad
+};
+struct HitBufs {                // indexed by queue slot
+    float4* hit;                // T, BaryXY.x, BaryXY.y, TriangleId (bits)
+    uint32_t* xformId;          // MeshTransformId or light index
+    float* cost;                // debugCost (only written in DoDebugBVHTraversal mode)
+};
+
+struct HitRec { float T, bx, by; uint32_t tri, xform; };
+
+#define TLAS_STACK_SIZE 24
+
+// ---------------------------------------------------------------------------------------------------------------
+// BVH traversal (include/BVHIntersect.glsl:27-105, 183-291).  One ray per lane; the per-lane traversal stack lives in
+// LDS as stack[depth][lane] (bank-conflict free: lane l and l+32 never share a cycle on ds_*_b32).
+template <bool COUNT, bool COST>
+DEV bool IntersectBlas(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& d, bool useTlas, HitRec& hit, float& debugCost,
+                       uint32_t* stk, int stride, int cap, uint32_t& nPairs, uint32_t& nTris)
+{
+    bool anyHit = false;
+    float tMinLeft, tMinRight;
+    f3 invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    const float4* nodes = s.nodes + 2 * (size_t)d.NodeOffset;
+    if (!useTlas) {
+        float4 rmin = nodes[2], rmax = nodes[3];
+        if (!(RayBoxIntersect(ro, invDir, rmin, rmax, &tMinLeft) && tMinLeft < hit.T)) return false;
+    }
+    int sp = 0;
+    uint32_t top = 2;
+    while (true) {
+        if (COST) debugCost += 1.0f;
+        if (COUNT) nPairs++;
+        const float4* p = nodes + 2 * (size_t)top;
+        float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+        uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
+        bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= hit.T;
+        bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hit.T;
+        bool intersectLeft = hitLeft && lCount > 0, intersectRight = hitRight && rCount > 0;
+        if (intersectLeft || intersectRight) {
+            uint32_t first = intersectLeft ? lStart : rStart;
+            uint32_t end = !intersectRight ? (lStart + lCount) : (rStart + rCount);
+            first += (uint32_t)d.TriangleOffset; end += (uint32_t)d.TriangleOffset;
+            if (COST) debugCost += (float)(end - first) * 1.1f;
+            if (COUNT) nTris += end - first;
+            for (uint32_t i = first; i < end; i++) {
+                const float4* tv = s.triVerts + 3 * (size_t)i;
+                float4 a = tv[0], b = tv[1], c = tv[2];
+                float by, bz, t;
+                if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hit.T) {
+                    anyHit = true; hit.tri = i; hit.bx = 1.0f - by - bz; hit.by = by; hit.T = t;
+                }
+            }
+        }
+        bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
+        if (traverseLeft || traverseRight) {
+            if (traverseLeft && traverseRight) {
+                bool leftCloser = tMinLeft < tMinRight;
+                top = leftCloser ? lStart : rStart;
+                if (sp < cap) stk[sp * stride] = leftCloser ? rStart : lStart;
+                sp++;
+            } else top = traverseLeft ? lStart : rStart;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            top = stk[sp * stride];
+        }
+    }
+    return anyHit;
+}
+
+DEV M34 load_inv_model(const DScene& s, uint32_t xformId) { const float4* x = s.xforms + 9 * (size_t)xformId; M34 m; m.r0 = x[3]; m.r1 = x[4]; m.r2 = x[5]; return m; }
+
+template <bool COUNT, bool COST>
+DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, float& debugCost, uint32_t* stk, int stride, uint32_t& nPairs, uint32_t& nTris)
+{
+    const float maxDist = PT_FLOAT_MAX;
+    hit.T = maxDist; hit.tri = ~0u; hit.xform = 0; hit.bx = 0.0f; hit.by = 0.0f;
+    debugCost = 0.0f;
+    if (f.g.DoTraceLights) {
+        for (int i = 0; i < s.lightCount; i++) {
+            const GpuLight& l = s.lights[i];
+            float tMin, tMax;
+            if (RaySphereIntersect(ro, rd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hit.T) {
+                hit.T = tMin < 0.0f ? tMax : tMin; hit.xform = (uint32_t)i; hit.tri = ~0u;
+            }
+        }
+    }
+    if (f.useTlas) {
+        if (s.tlasCount == 0) return hit.T != maxDist;
+        uint32_t* tstk = stk + f.stackCap * stride; // TLAS stack rows follow the BLAS rows in the same LDS column
+        float tMinLeft, tMinRight;
+        f3 invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        int sp = 0; uint32_t top = 0;
+        while (true) {
+            float4 pmin = s.tlas[2 * (size_t)top];
+            uint32_t packed = __float_as_uint(pmin.w);
+            bool isLeaf = (packed >> 31) == 1;
+            uint32_t id = packed & 0x7fffffffu;
+            if (isLeaf) {
+                GpuBlasInstance inst = s.instances[id];
+                M34 inv = load_inv_model(s, inst.MeshTransformId);
+                f3 lo = xform34(inv, ro, 1.0f), ld = xform34(inv, rd, 0.0f);
+                if (IntersectBlas<COUNT, COST>(s, lo, ld, s.descs[inst.BlasId], true, hit, debugCost, stk, stride, f.stackCap, nPairs, nTris)) hit.xform = inst.MeshTransformId;
+                if (sp == 0) break;
+                top = tstk[--sp * stride];
+                continue;
+            }
+            uint32_t l = id, r = id + 1;
+            float4 lmin = s.tlas[2 * (size_t)l], lmax = s.tlas[2 * (size_t)l + 1], rmin = s.tlas[2 * (size_t)r], rmax = s.tlas[2 * (size_t)r + 1];
+            bool tl = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft < hit.T;
+            bool tr = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight < hit.T;
+            if (tl || tr) {
+                if (tl && tr) { bool lc = tMinLeft < tMinRight; top = lc ? l : r; if (sp < TLAS_STACK_SIZE) tstk[sp * stride] = lc ? r : l; sp++; }
+                else top = tl ? l : r;
+            } else { if (sp == 0) break; top = tstk[--sp * stride]; }
+        }
+    } else {
+        for (int i = 0; i < s.instanceCount; i++) {
+            GpuBlasInstance inst = s.instances[i];
+            M34 inv = load_inv_model(s, inst.MeshTransformId);
+            f3 lo = xform34(inv, ro, 1.0f), ld = xform34(inv, rd, 0.0f);
+            if (IntersectBlas<COUNT, COST>(s, lo, ld, s.descs[inst.BlasId], false, hit, debugCost, stk, stride, f.stackCap, nPairs, nTris)) hit.xform = inst.MeshTransformId;
+        }
+    }
+    return hit.T != maxDist;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Primary ray generation (FirstHit/compute.glsl:44-77).  `pix` = local pixel index.
+DEV void gen_primary(const Frame& f, uint32_t pix, f3& origin, f2& packedDir, uint32_t& rngSeed)
+{
+    int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
+    int y = ly * f.rowMod + f.rowRem, x = lx;
+    uint32_t seed = (uint32_t)(y * 4096 + x) * (f.accumulated + 1u);
+    float ox = rnd01(seed), oy = rnd01(seed);
+    float nx = ((float)x + ox) / (float)f.W * 2.0f - 1.0f, ny = ((float)y + oy) / (float)f.H * 2.0f - 1.0f;
+    f3 camDir = GetWorldSpaceDirection(f.invProj, f.invView, nx, ny);
+    f3 viewPos = mk3(f.viewPos[0], f.viewPos[1], f.viewPos[2]);
+    f3 focalPoint = viewPos + camDir * f.g.FocalLength;
+    f2 disk = SampleDisk(seed);
+    f3 pointOnLense = mat4_mul_xyz(f.invView, f.g.LenseRadius * disk.x, f.g.LenseRadius * disk.y, 0.0f, 1.0f);
+    camDir = normalize(focalPoint - pointOnLense);
+    origin = pointOnLense;
+    packedDir = EncodeUnitVec(camDir);
+    rngSeed = seed;
+}
+
+// gl_GlobalInvocationID of the FirstHit invocation for pixel (px,py): inverse of ReorderInvocations(20) (FirstHit:236-262)
+DEV uint32_t first_hit_gid_seed(int W, int H, int px, int py)
+{
+    const uint32_t n = 20;
+    uint32_t numX = (uint32_t)(W + 7) / 8, numY = (uint32_t)(H + 7) / 8;
+    uint32_t sx = (uint32_t)px / 8, sy = (uint32_t)py / 8;
+    uint32_t columnSize = numY * n, fullColumnCount = numX / n, lastColumnWidth = numX % n;
+    uint32_t columnIdx = sx / n;
+    uint32_t columnWidth = (columnIdx == fullColumnCount) ? lastColumnWidth : n;
+    uint32_t idxInColumn = sy * columnWidth + (sx - columnIdx * n);
+    uint32_t idx = columnIdx * columnSize + idxInColumn;
+    uint32_t wgY = idx / numX, wgX = idx % numX;
+    uint32_t gx = wgX * 8 + (uint32_t)px % 8, gy = wgY * 8 + (uint32_t)py % 8;
+    return gy * 4096u + gx;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// texture / sky stand-ins for the GL bindless samplers (DESIGN.md "Textures")
+DEV float4 SampleTex(const DScene& s, uint64_t handle, float u, float v)
+{
+    if (handle == 0 || handle > (uint64_t)s.textureCount) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    TexDesc t = s.textures[handle - 1];
+    if (t.w == 1 && t.h == 1) return t.data[0];
+    float fx = u * (float)t.w - 0.5f, fy = v * (float)t.h - 0.5f;
+    float x0f = gfloor(fx), y0f = gfloor(fy);
+    float ax = fx - x0f, ay = fy - y0f;
+    int x0 = (int)x0f % t.w; if (x0 < 0) x0 += t.w;
+    int x1 = (int)(x0f + 1.0f) % t.w; if (x1 < 0) x1 += t.w;
+    int y0 = (int)y0f % t.h; if (y0 < 0) y0 += t.h;
+    int y1 = (int)(y0f + 1.0f) % t.h; if (y1 < 0) y1 += t.h;
+    float4 a = t.data[(size_t)y0 * t.w + x0], b = t.data[(size_t)y0 * t.w + x1], c = t.data[(size_t)y1 * t.w + x0], d = t.data[(size_t)y1 * t.w + x1];
+    return make_float4(gmix(gmix(a.x, b.x, ax), gmix(c.x, d.x, ax), ay), gmix(gmix(a.y, b.y, ax), gmix(c.y, d.y, ax), ay),
+                       gmix(gmix(a.z, b.z, ax), gmix(c.z, d.z, ax), ay), gmix(gmix(a.w, b.w, ax), gmix(c.w, d.w, ax), ay));
+}
+DEV f3 SampleSky(const DScene& s, f3 d)
+{
+    if (s.skySize <= 0) return splat3(0.0f);
+    float ax = gabs(d.x), ay = gabs(d.y), az = gabs(d.z);
+    int face; float sc, tc, ma;
+    if (ax >= ay && ax >= az) { face = d.x >= 0.0f ? 0 : 1; sc = d.x >= 0.0f ? -d.z : d.z; tc = -d.y; ma = ax; }
+    else if (ay >= az) { face = d.y >= 0.0f ? 2 : 3; sc = d.x; tc = d.y >= 0.0f ? d.z : -d.z; ma = ay; }
+    else { face = d.z >= 0.0f ? 4 : 5; sc = d.z >= 0.0f ? d.x : -d.x; tc = -d.y; ma = az; }
+    int S = s.skySize, x = 0, y = 0;
+    if (S > 1) {
+        float u = 0.5f * (sc / ma + 1.0f), v = 0.5f * (tc / ma + 1.0f);
+        x = (int)gmin(gmax(gfloor(u * (float)S), 0.0f), (float)(S - 1)); y = (int)gmin(gmax(gfloor(v * (float)S), 0.0f), (float)(S - 1));
+    }
+    float4 p = s.sky[((size_t)face * S + y) * S + x];
+    return mk3(p.x, p.y, p.z);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shading: FirstHit TraceRay after the trace (FirstHit/compute.glsl:114-233) / NHit TraceRay (NHit/compute.glsl:98-214)
+struct RayState { f3 origin; float prevIor; f3 throughput; float pdx; f3 radiance; float pdy; };
+struct AovState { f3 albedo; float newWeight; f3 normal; };
+
+template <bool FIRST>
+DEV bool ShadeHit(const DScene& s, const Frame& f, const HitRec& hit, bool hitScene, f3 rayDir, RayState& r, AovState& aov, uint32_t& rng, uint32_t gidSeed, uint32_t& sortingKey)
+{
+    if (hitScene) {
+        r.origin = r.origin + rayDir * hit.T;
+        // GetDefaultSurface (Surface.glsl:25-47)
+        f3 sAlbedo = splat3(1.0f), sNormal = splat3(0.0f), sEmissive = splat3(0.0f), sAbsorbance = splat3(0.0f);
+        float sAlpha = 1.0f, sMetallic = 0.0f, sRoughness = 0.0f, sTransmission = 0.0f, sIOR = 1.5f, sAlphaCutoff = 0.5f;
+        bool sIsVolumetric = false, sTint = true;
+        f3 geometricNormal = splat3(0.0f);
+        bool hitLight = hit.tri == ~0u;
+        if (!hitLight) {
+            sortingKey = hit.tri;
+            uint4 tri = s.tris[hit.tri];
+            uint4 v0 = s.vertices[tri.x], v1 = s.vertices[tri.y], v2 = s.vertices[tri.z];
+            f3 bary = mk3(hit.bx, hit.by, 1.0f - hit.bx - hit.by);
+            float u = __uint_as_float(v0.x) * bary.x + __uint_as_float(v1.x) * bary.y + __uint_as_float(v2.x) * bary.z;
+            float v = __uint_as_float(v0.y) * bary.x + __uint_as_float(v1.y) * bary.y + __uint_as_float(v2.y) * bary.z;
+            f3 interpNormal = normalize(Interpolate(DecompressSR11G11B10(v0.w), DecompressSR11G11B10(v1.w), DecompressSR11G11B10(v2.w), bary));
+            f3 interpTangent = normalize(Interpolate(DecompressSR11G11B10(v0.z), DecompressSR11G11B10(v1.z), DecompressSR11G11B10(v2.z), bary));
+            M34 inv = load_inv_model(s, hit.xform);
+            const GpuMesh& mesh = s.meshes[tri.w];
+            const GpuMaterial& mat = s.materials[mesh.MaterialId];
+            { // GetSurface (Surface.glsl:49-77)
+                uint32_t bcf = mat.BaseColorFactor;
+                float4 bc = SampleTex(s, mat.BaseColorTexture, u, v);
+                sAlbedo = mk3(bc.x * ((float)(bcf & 255u) / 255.0f), bc.y * ((float)((bcf >> 8) & 255u) / 255.0f), bc.z * ((float)((bcf >> 16) & 255u) / 255.0f));
+                sAlpha = bc.w * ((float)((bcf >> 24) & 255u) / 255.0f);
+                float4 nm = SampleTex(s, mat.NormalTexture, u, v);
+                sNormal = mk3(nm.x * 2.0f - 1.0f, nm.y * 2.0f - 1.0f, gsqrt(gmax(1.0f - (nm.x * nm.x + nm.y * nm.y), 0.0f)));
+                float4 em = SampleTex(s, mat.EmissiveTexture, u, v);
+                sEmissive = mk3(em.x * mat.EmissiveFactor[0], em.y * mat.EmissiveFactor[1], em.z * mat.EmissiveFactor[2]);
+                sAbsorbance = mk3(mat.Absorbance[0], mat.Absorbance[1], mat.Absorbance[2]);
+                float4 mr = SampleTex(s, mat.MetallicRoughnessTexture, u, v);
+                sMetallic = mr.x * mat.MetallicFactor; sRoughness = mr.y * mat.RoughnessFactor;
+                float4 tr = SampleTex(s, mat.TransmissionTexture, u, v);
+                sTransmission = tr.x * mat.TransmissionFactor; sIOR = mat.IOR;
+                sAlphaCutoff = mat.AlphaCutoff; sIsVolumetric = mat.IsVolumetric != 0;
+            }
+            { // SurfaceApplyModificatons (Surface.glsl:79-91)
+                sEmissive = sEmissive * 1.0f + mesh.EmissiveBias * sAlbedo;
+                sAbsorbance = mk3(gmax(sAbsorbance.x + mesh.AbsorbanceBias[0], 0.0f), gmax(sAbsorbance.y + mesh.AbsorbanceBias[1], 0.0f), gmax(sAbsorbance.z + mesh.AbsorbanceBias[2], 0.0f));
+                sMetallic = gclamp(sMetallic + mesh.SpecularBias, 0.0f, 1.0f);
+                sRoughness = gclamp(sRoughness + mesh.RoughnessBias, 0.0f, 1.0f);
+                sTransmission = gclamp(sTransmission + mesh.TransmissionBias, 0.0f, 1.0f);
+                sIOR = gmax(sIOR + mesh.IORBias, 1.0f);
+                sTint = mesh.TintOnTransmissive != 0;
+            }
+            float alphaCutoff = (sAlphaCutoff == 2.0f) ? rnd01(rng) : sAlphaCutoff;
+            if (sAlpha < alphaCutoff) { r.origin = r.origin + rayDir * 0.001f; return true; }
+            f3 worldNormal = normalize(xform34_transposed3(inv, interpNormal));
+            f3 worldTangent = normalize(xform34_transposed3(inv, interpTangent));
+            f3 N = normalize(worldNormal), T = normalize(worldTangent), B = normalize(cross(N, T));
+            f3 tn = mk3((T.x * sNormal.x + B.x * sNormal.y) + N.x * sNormal.z, (T.y * sNormal.x + B.y * sNormal.y) + N.y * sNormal.z, (T.z * sNormal.x + B.z * sNormal.y) + N.z * sNormal.z);
+            sNormal = normalize(gmix(worldNormal, tn, mesh.NormalMapStrength));
+            const float4* tv = s.triVerts + 3 * (size_t)hit.tri;
+            float4 a = tv[0], b = tv[1], c = tv[2];
+            f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(c.x, c.y, c.z);
+            geometricNormal = normalize(cross(p1 - p0, p2 - p0));
+            geometricNormal = normalize(xform34_transposed3(inv, geometricNormal));
+        } else if (f.g.DoTraceLights) {
+            sortingKey = hit.xform;
+            const GpuLight& l = s.lights[hit.xform];
+            sEmissive = mk3(l.Color[0], l.Color[1], l.Color[2]); sAlbedo = sEmissive;
+            sNormal = (r.origin - mk3(l.Position[0], l.Position[1], l.Position[2])) / l.Radius;
+            geometricNormal = sNormal;
+        }
+        float prevIor = FIRST ? 1.0f : r.prevIor;
+        bool fromInside = dot(-rayDir, geometricNormal) < 0.0f;
+        if (fromInside) {
+            if (FIRST) prevIor = sIOR;
+            geometricNormal = geometricNormal * -1.0f;
+            if (sIsVolumetric) {
+                f3 e = (-sAbsorbance) * hit.T;
+                r.throughput = r.throughput * mk3(gexp(e.x), gexp(e.y), gexp(e.z));
+            }
+        }
+        float cosTheta = dot(-rayDir, sNormal);
+        if (cosTheta < 0.0f) { sNormal = sNormal * -1.0f; }
+        r.radiance = r.radiance + sEmissive * r.throughput;
+
+        // SampleMaterial (Shading.glsl:59-150)
+        float roughness2 = sRoughness * sRoughness;
+        float metallic, transmission;
+        {
+            float ct = dot(-rayDir, sNormal);
+            float diffuseChance = 1.0f - sMetallic - sTransmission;
+            float f0 = BaseReflectivity(prevIor, sIOR);
+            metallic = gmix(sMetallic, 1.0f, FresnelSchlick(f0, 1.0f, ct));
+            transmission = gmax(1.0f - diffuseChance - metallic, 0.0f);
+        }
+        uint32_t bsdfType;
+        {
+            float rnd = rnd01(rng);
+            if (metallic > rnd) bsdfType = 1u;
+            else if (metallic + transmission > rnd) bsdfType = 2u;
+            else bsdfType = 0u;
+        }
+        f3 diffuseRayDir;
+        {
+            uint32_t local = gidSeed;
+            f2 r2 = R2Sequence(f.accumulated);
+            float px = rnd01(local), py = rnd01(local);
+            f2 uv; uv.x = gfract(r2.x + px); uv.y = gfract(r2.y + py);
+            diffuseRayDir = CosineSampleHemisphere(sNormal, uv);
+        }
+        f3 newDir, bsdf; float pdf, newIor;
+        if (bsdfType == 0u) { newDir = diffuseRayDir; newIor = prevIor; bsdf = sAlbedo; pdf = 1.0f; }
+        else if (bsdfType == 1u) {
+            f3 refl = reflect(rayDir, sNormal);
+            newDir = normalize(gmix(refl, diffuseRayDir, roughness2));
+            bsdf = sAlbedo; pdf = 1.0f; newIor = prevIor;
+        } else {
+            newIor = fromInside ? 1.0f : sIOR;
+            f3 refr; bool tir;
+            if (!sIsVolumetric) { refr = rayDir; tir = false; newIor = 1.0f; }
+            else {
+                refr = refract(rayDir, sNormal, prevIor / newIor);
+                tir = (refr.x == 0.0f && refr.y == 0.0f && refr.z == 0.0f);
+                if (tir) { refr = reflect(rayDir, sNormal); newIor = prevIor; }
+            }
+            newDir = normalize(gmix(refr, !tir ? -diffuseRayDir : diffuseRayDir, roughness2));
+            bool gltfWantsTint = sIsVolumetric || !fromInside;
+            bsdf = (gltfWantsTint && sTint) ? sAlbedo : splat3(1.0f);
+            pdf = 1.0f;
+        }
+        pdf = gmax(pdf, 0.0001f);
+        r.throughput = r.throughput * (bsdf / pdf);
+        {
+            // GetSurfaceVariance(surface.Metallic, surface.Transmission, surface.Roughness) uses the caller's `surface`
+            // (SampleMaterial takes it by value), i.e. the un-squared roughness and the un-adjusted chances.
+            float diffuseC = 1.0f - sMetallic - sTransmission;
+            float weight = diffuseC + sMetallic * sRoughness + sTransmission * sRoughness;
+            if (FIRST) { aov.albedo = sAlbedo * weight; aov.normal = sNormal * weight; aov.newWeight = 1.0f - weight; }
+            else { aov.albedo = aov.albedo + aov.newWeight * sAlbedo * weight; aov.normal = aov.normal + aov.newWeight * sNormal * weight; aov.newWeight *= (1.0f - weight); }
+        }
+        if (!FIRST) {
+            if (f.g.DoRussianRoulette) { // RussianRoulette.glsl:3-12
+                float p = gmax(r.throughput.x, gmax(r.throughput.y, r.throughput.z));
+                if (rnd01(rng) > p) return false;
+                r.throughput = r.throughput / p;
+            }
+        }
+        if (bsdfType == 2u) geometricNormal = geometricNormal * -1.0f;
+        r.origin = r.origin + geometricNormal * 0.001f;
+        r.prevIor = newIor;
+        f2 pd = EncodeUnitVec(newDir);
+        r.pdx = pd.x; r.pdy = pd.y;
+        return true;
+    } else {
+        f3 albedo = SampleSky(s, rayDir);
+        f3 fn = CubemapFaceNormal(rayDir);
+        if (FIRST) { aov.albedo = albedo; aov.normal = fn; }
+        else { aov.albedo = aov.albedo + aov.newWeight * albedo; aov.normal = aov.normal + aov.newWeight * fn; }
+        aov.newWeight = 0.0f;
+        r.radiance = r.radiance + albedo * r.throughput;
+        return false;
+    }
+}
+
+} // namespace ptd

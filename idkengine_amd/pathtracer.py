@@ -1,0 +1,219 @@
+"""PathTracer — host-side mirror of IDKEngine's `class PathTracer` (Source/Render/PathTracer.cs:10-365) over the
+C-ABI of libidkpt.so.  Same property names, same reset-accumulation behaviour, same lifecycle
+(ctor(width,height,settings) / Compute() / SetSize / ResetAccumulation / Dispose); the implicit GL bindings the
+reference's shaders read become the explicit UploadScene / SetCamera calls.  The C# drop-in that binds the same
+entry points through LibraryImport is shown in INTEGRATION.md.
+
+No CPU fallback: construction raises when libidkpt.so or a GPU is missing.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from . import gputypes as T
+from ._lib import IdkPtError
+
+
+class PathTracer:
+    def __init__(self, width, height, settings=None, device=0, row_modulo=1, row_remainder=0):
+        self._L = _lib.load()
+        n = C.c_int32(0)
+        self._L.idkptGetDeviceCount(C.byref(n))
+        if n.value <= 0:
+            raise IdkPtError("no HIP device visible: the path tracer has no CPU fallback")
+        ctx = C.c_void_p()
+        dev = (C.c_int32 * 1)(device)
+        rc = self._L.idkptCreate(1, dev, C.byref(ctx))
+        if rc != 0:
+            raise IdkPtError(f"idkptCreate failed with status {rc}")
+        self._ctx = ctx
+        self._settings = settings if settings is not None else T.Settings.default()
+        self._cached_ray_depth = self._settings.RayDepth
+        self._scene = None
+        self.width, self.height = width, height
+        self.row_modulo, self.row_remainder = row_modulo, row_remainder
+        self._check(self._L.idkptSetRowSharding(ctx, row_modulo, row_remainder))
+        self._check(self._L.idkptSetSize(ctx, width, height))
+        self._push_settings()
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            msg = C.c_char_p()
+            self._L.idkptGetLastError(self._ctx, C.byref(msg))
+            raise IdkPtError(f"idkpt status {rc}: {(msg.value or b'').decode()}")
+
+    def _push_settings(self):
+        self._check(self._L.idkptSetSettings(self._ctx, C.addressof(self._settings)))
+
+    @property
+    def rows(self):
+        return len(range(self.row_remainder, self.height, self.row_modulo))
+
+    # ------------------------------------------------------------------ PathTracer.cs public surface
+    def _prop(name, gpu=False):  # noqa: N805
+        def get(self):
+            return getattr(self._settings.Gpu if gpu else self._settings, name)
+
+        def set_(self, v):
+            setattr(self._settings.Gpu if gpu else self._settings, name, type(get(self))(v))
+            self._push_settings()
+        return property(get, set_)
+
+    SamplesPerPixel = _prop("SamplesPerPixel")        # PathTracer.cs:12
+    RayDepth = _prop("RayDepth")                      # :16-25 (resets accumulation)
+    FocalLength = _prop("FocalLength", gpu=True)      # :39-48
+    LenseRadius = _prop("LenseRadius", gpu=True)      # :50-59
+    DoTraceLights = _prop("DoTraceLights", gpu=True)  # :83-92
+    DoRussianRoulette = _prop("DoRussianRoulette", gpu=True)  # :94-102
+    DoRaySorting = _prop("DoRaySorting")              # :104-114
+    OutputAOVs = _prop("OutputAOVs")                  # :116-125
+    UseTlas = _prop("UseTlas")                        # BVH.GpuUseTlas (Bvh/BVH.cs:16-26)
+    BlasStackSize = _prop("BlasStackSize")            # BVH.BlasStackSize (Bvh/BVH.cs:28-45)
+
+    @property
+    def DoDebugBVHTraversal(self):                    # :61-81
+        return self._settings.Gpu.DoDebugBVHTraversal == 1
+
+    @DoDebugBVHTraversal.setter
+    def DoDebugBVHTraversal(self, value):
+        self._settings.Gpu.DoDebugBVHTraversal = 1 if value else 0
+        if value:
+            self._cached_ray_depth = self._settings.RayDepth
+            self._settings.RayDepth = 1
+        else:
+            self._settings.RayDepth = self._cached_ray_depth
+        self._push_settings()
+        self.ResetAccumulation()
+
+    @property
+    def AccumulatedSamples(self):                     # :27-37
+        v = C.c_uint32()
+        self._check(self._L.idkptGetAccumulatedSamples(self._ctx, C.byref(v)))
+        return v.value
+
+    def Compute(self):                                # :214-271
+        self._check(self._L.idkptRender(self._ctx))
+
+    def SetSize(self, width, height):                 # :299-332
+        self.width, self.height = width, height
+        self._check(self._L.idkptSetSize(self._ctx, width, height))
+
+    def ResetAccumulation(self):                      # :334-337
+        self._check(self._L.idkptResetAccumulation(self._ctx))
+
+    def Dispose(self):                                # :344-365
+        if self._ctx:
+            self._L.idkptDestroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.Dispose()
+        except Exception:
+            pass
+
+    @property
+    def Result(self):                                 # :143 (Texture.Download equivalent)
+        return self.download(0)
+
+    @property
+    def AlbedoTexture(self):                          # :167
+        return self.download(1)
+
+    @property
+    def NormalTexture(self):                          # :168
+        return self.download(2)
+
+    # ------------------------------------------------------------------ explicit inputs (implicit GL bindings in the reference)
+    def UploadScene(self, scene):
+        d, keep = scene.desc()
+        self._check(self._L.idkptUploadScene(self._ctx, C.addressof(d)))
+        del keep
+        self._scene = scene
+        if self._settings.BlasStackSize == 0 and scene.blas_stack_size:
+            pass  # library derives the LDS stack depth from BlasDescs when BlasStackSize == 0
+
+    def SetCamera(self, cam):
+        ip = np.ascontiguousarray(cam.inv_projection, np.float32); iv = np.ascontiguousarray(cam.inv_view, np.float32); vp = np.ascontiguousarray(cam.position, np.float32)
+        self._check(self._L.idkptSetPerFrame(self._ctx, ip.ctypes.data, iv.ctypes.data, vp.ctypes.data))
+
+    def UpdateBuffer(self, which, array, offset_bytes=0):
+        a = np.ascontiguousarray(array)
+        self._check(self._L.idkptUpdateBuffer(self._ctx, which, offset_bytes, a.nbytes, a.ctypes.data))
+
+    def DownloadBuffer(self, which, dtype, count, offset_bytes=0):
+        out = np.zeros(count, dtype)
+        self._check(self._L.idkptDownloadBuffer(self._ctx, which, offset_bytes, out.nbytes, out.ctypes.data))
+        return out
+
+    def BuildTlas(self, nodes):
+        n = np.ascontiguousarray(nodes)
+        self._check(self._L.idkptBuildTlas(self._ctx, n.ctypes.data, len(n)))
+
+    def RefitBlas(self, blas_id):
+        self._check(self._L.idkptRefitBlas(self._ctx, blas_id))
+
+    def UploadUnskinnedVertices(self, verts):
+        v = np.ascontiguousarray(verts)
+        self._check(self._L.idkptUploadUnskinnedVertices(self._ctx, v.ctypes.data, len(v)))
+
+    def Skin(self, input_offset, output_offset, joint_offset, count):
+        self._check(self._L.idkptSkin(self._ctx, input_offset, output_offset, joint_offset, count))
+
+    def SetSlotBases(self, bases):
+        b = np.ascontiguousarray(bases, np.uint32)
+        self._check(self._L.idkptSetSlotBases(self._ctx, b.ctypes.data, len(b)))
+
+    # ------------------------------------------------------------------ outputs / instrumentation
+    def synchronize(self):
+        self._check(self._L.idkptSynchronize(self._ctx))
+
+    def download(self, which=0):
+        out = np.zeros((self.rows, self.width, 4), np.float32)
+        self._check(self._L.idkptDownload(self._ctx, which, out.ctypes.data, out.nbytes))
+        return out
+
+    def rays(self):
+        out = np.zeros(self.rows * self.width, T.GpuWavefrontRay)
+        self._check(self._L.idkptDownloadRays(self._ctx, out.ctypes.data, out.nbytes))
+        return out
+
+    def alive_queue(self):
+        n = C.c_uint32()
+        self._check(self._L.idkptDownloadAliveQueue(self._ctx, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint32)
+        if n.value:
+            self._check(self._L.idkptDownloadAliveQueue(self._ctx, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def enable_primary_hit_capture(self, on=True):
+        self._check(self._L.idkptEnablePrimaryHitCapture(self._ctx, 1 if on else 0))
+
+    def primary_hits(self):
+        n = self.rows * self.width
+        t = np.zeros(n, np.float32); tri = np.zeros(n, np.uint32); bary = np.zeros((n, 2), np.float32)
+        self._check(self._L.idkptDownloadPrimaryHits(self._ctx, t.ctypes.data, tri.ctypes.data, bary.ctypes.data, n))
+        return t, tri, bary
+
+    def enable_counters(self, on=True):
+        self._check(self._L.idkptEnableCounters(self._ctx, 1 if on else 0))
+
+    def enable_timing(self, on=True):
+        self._check(self._L.idkptEnableTiming(self._ctx, 1 if on else 0))
+
+    def stats(self):
+        s = T.Stats()
+        self._check(self._L.idkptGetStats(self._ctx, C.addressof(s)))
+        return {"rays_traced": s.RaysTraced, "primary_rays": s.PrimaryRays, "frames": s.Frames, "alive_counts": list(s.LastAliveCounts),
+                "last_frame_ms": s.LastFrameMs, "node_pair_visits": s.NodePairVisits, "triangle_tests": s.TriangleTests}
+
+    def reset_stats(self):
+        self._check(self._L.idkptResetStats(self._ctx))
+
+    def image_device_ptr(self, which=0):
+        p = C.c_void_p(); n = C.c_size_t()
+        self._check(self._L.idkptGetImageDevicePtr(self._ctx, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_stream(self, hip_stream_handle):
+        self._check(self._L.idkptSetStream(self._ctx, C.c_void_p(hip_stream_handle)))

@@ -1,0 +1,308 @@
+"""Scene assembly and synthetic scene generators (host side).
+
+Plays the role of the reference's ModelManager.Add + BVH.Add/BlasesBuild/TlasBuild for generated geometry:
+  IDKEngine/Source/ModelManager.cs:128-216, IDKEngine/Source/Bvh/BVH.cs:236-298,300-470.
+The BLAS/TLAS builders themselves are pluggable (`builder` argument): the product's native SweepSAH builder
+(idkengine_amd.bvh.NativeBuilder) or, in tests only, the oracle's restatement.
+"""
+import math
+import numpy as np
+from . import gputypes as T
+
+# ----------------------------------------------------------------------------------------------- camera (OpenTK math)
+
+
+def look_at(eye, target, up):
+    """OpenTK Matrix4.LookAt (row-vector convention, rows = basis vectors, Row3 = translation)."""
+    eye, target, up = (np.asarray(v, np.float64) for v in (eye, target, up))
+    z = eye - target; z /= np.linalg.norm(z)
+    x = np.cross(up, z); x /= np.linalg.norm(x)
+    y = np.cross(z, x); y /= np.linalg.norm(y)
+    m = np.zeros((4, 4), np.float64)
+    m[0, :3] = (x[0], y[0], z[0]); m[1, :3] = (x[1], y[1], z[1]); m[2, :3] = (x[2], y[2], z[2])
+    m[3] = (-np.dot(x, eye), -np.dot(y, eye), -np.dot(z, eye), 1.0)
+    return m
+
+
+def perspective_zero_to_one(fovy, aspect, near, far):
+    """MyMath.CreatePerspectiveFieldOfViewDepthZeroToOne (Source/Utils/MyMath.cs:180-188)."""
+    max_y = near * math.tan(0.5 * fovy); min_y = -max_y
+    min_x = min_y * aspect; max_x = max_y * aspect
+    m = np.zeros((4, 4), np.float64)
+    m[0, 0] = 2.0 * near / (max_x - min_x)
+    m[1, 1] = 2.0 * near / (max_y - min_y)
+    m[2, 0] = (max_x + min_x) / (max_x - min_x)
+    m[2, 1] = (max_y + min_y) / (max_y - min_y)
+    m[2, 2] = far / (near - far)
+    m[2, 3] = -1.0
+    m[3, 2] = -(far * near) / (far - near)
+    return m
+
+
+class Camera:
+    """Camera defaults of Source/Camera.cs:41-45: near 0.1, far 250, FovY 102 degrees."""
+
+    def __init__(self, width, height, position=(0.0, 0.0, 25.0), view_dir=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0),
+                 fovy_deg=102.0, near=0.1, far=250.0):
+        self.position = np.asarray(position, np.float32)
+        view = look_at(position, np.asarray(position, np.float64) + np.asarray(view_dir, np.float64), up)
+        proj = perspective_zero_to_one(math.radians(fovy_deg), width / float(height), near, far)
+        # GpuPerFrameData.InvView / InvProjection (Application.cs:148-150), OpenTK memory order (row-major rows)
+        self.inv_view = np.ascontiguousarray(np.linalg.inv(view).astype(np.float32).reshape(16))
+        self.inv_projection = np.ascontiguousarray(np.linalg.inv(proj).astype(np.float32).reshape(16))
+
+# ----------------------------------------------------------------------------------------------- vertex packing
+
+
+def compress_sr11g11b10(v):
+    """Utils/Compression.cs:26-40 (MathF.Round = round-half-even)."""
+    v = np.asarray(v, np.float32) * np.float32(0.5) + np.float32(0.5)
+    r = np.rint(v[..., 0] * np.float32(2047)).astype(np.uint32)
+    g = np.rint(v[..., 1] * np.float32(2047)).astype(np.uint32)
+    b = np.rint(v[..., 2] * np.float32(1023)).astype(np.uint32)
+    return (b << 22) | (g << 11) | r
+
+
+def pack_rgba8(rgba):
+    c = np.rint(np.clip(np.asarray(rgba, np.float64), 0, 1) * 255.0).astype(np.uint32)
+    return int(c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24))
+
+
+def transform_from_matrix(model4x4):
+    """GpuMeshTransform from an OpenTK-convention 4x4 (rows = basis, row 3 = translation): stores the transposed
+    3x4 of Model, its inverse and Prev = Model (GpuMeshTransform.cs:17-41)."""
+    m = np.asarray(model4x4, np.float64)
+    out = np.zeros(1, T.GpuMeshTransform)
+    out["Model"][0] = m[:, :3].T.astype(np.float32)
+    out["InvModel"][0] = np.linalg.inv(m)[:, :3].T.astype(np.float32)
+    out["PrevModel"][0] = out["Model"][0]
+    return out
+
+
+def rotation_y(deg):
+    a = math.radians(deg); c, s = math.cos(a), math.sin(a)
+    m = np.eye(4); m[0, 0] = c; m[0, 2] = -s; m[2, 0] = s; m[2, 2] = c
+    return m
+
+
+def translation(t):
+    m = np.eye(4); m[3, :3] = t
+    return m
+
+# ----------------------------------------------------------------------------------------------- materials
+
+
+def make_material(base_color=(0.8, 0.8, 0.8, 1.0), emissive=(0, 0, 0), metallic=0.0, roughness=1.0, transmission=0.0,
+                  ior=1.5, absorbance=(0, 0, 0), alpha_cutoff=0.0, volumetric=False):
+    m = np.zeros(1, T.GpuMaterial)
+    m["EmissiveFactor"] = emissive; m["BaseColorFactor"] = pack_rgba8(base_color)
+    m["Absorbance"] = absorbance; m["IOR"] = ior
+    m["TransmissionFactor"] = transmission; m["RoughnessFactor"] = roughness; m["MetallicFactor"] = metallic
+    m["AlphaCutoff"] = alpha_cutoff; m["IsVolumetric"] = 1 if volumetric else 0
+    return m
+
+
+def make_mesh(material_id, normal_map_strength=0.0, **bias):
+    m = np.zeros(1, T.GpuMesh)
+    m["MaterialId"] = material_id; m["NormalMapStrength"] = normal_map_strength
+    m["InstanceCount"] = 1; m["TintOnTransmissive"] = 1
+    for k, v in bias.items():
+        m[k] = v
+    return m
+
+# ----------------------------------------------------------------------------------------------- assembly
+
+
+class MeshInput:
+    """One glTF-primitive-like mesh: per-vertex positions/normals/tangents/uvs + triangle indices (local)."""
+
+    def __init__(self, positions, indices, material, normals=None, tangents=None, uvs=None, mesh_kwargs=None):
+        self.positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        self.indices = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+        self.material = material
+        self.normals = normals; self.tangents = tangents; self.uvs = uvs
+        self.mesh_kwargs = mesh_kwargs or {}
+
+
+def flat_shaded(tri_positions):
+    """(n,3,3) triangle soup -> unshared vertices with face normal and an in-plane tangent (always valid: the
+    reference's TBN goes NaN on a zero tangent, FirstHit/compute.glsl:148-153)."""
+    tp = np.ascontiguousarray(tri_positions, np.float32).reshape(-1, 3, 3)
+    e1 = (tp[:, 1] - tp[:, 0]).astype(np.float64); e2 = (tp[:, 2] - tp[:, 0]).astype(np.float64)
+    n = np.cross(e1, e2); nl = np.linalg.norm(n, axis=1, keepdims=True); nl[nl == 0] = 1.0; n /= nl
+    t = e1.copy(); tl = np.linalg.norm(t, axis=1, keepdims=True); tl[tl == 0] = 1.0; t /= tl
+    positions = tp.reshape(-1, 3)
+    normals = np.repeat(n, 3, axis=0).astype(np.float32); tangents = np.repeat(t, 3, axis=0).astype(np.float32)
+    indices = np.arange(len(positions), dtype=np.uint32).reshape(-1, 3)
+    return positions, indices, normals, tangents
+
+
+def assemble(blases, builder, lights=None, sky_color=(1.0, 1.0, 1.0), build_tlas=True):
+    """blases: list of dicts {meshes: [MeshInput], transform: 4x4 (OpenTK convention) or None, refittable: bool}.
+    Mirrors ModelManager.Add (global vertex/mesh arrays), BVH.Add (BlasTriangles with global vertex ids + MeshId,
+    Bvh/BVH.cs:236-276), BVH.BlasesBuild (per-BLAS build + offset fix-up, :300-451) and BVH.TlasBuild (:278-298)."""
+    sc = T.Scene()
+    pos, verts, meshes, materials, xforms = [], [], [], [], []
+    per_blas_tris = []
+    vertex_offset = 0
+    for b_id, b in enumerate(blases):
+        tris = []
+        for mi in b["meshes"]:
+            mesh_id = len(meshes)
+            materials.append(mi.material); meshes.append(make_mesh(len(materials) - 1, **mi.mesh_kwargs))
+            nv = len(mi.positions)
+            v = np.zeros(nv, T.GpuVertex)
+            normals = mi.normals if mi.normals is not None else np.tile(np.float32([0, 1, 0]), (nv, 1))
+            tangents = mi.tangents if mi.tangents is not None else np.tile(np.float32([1, 0, 0]), (nv, 1))
+            v["Normal"] = compress_sr11g11b10(normals); v["Tangent"] = compress_sr11g11b10(tangents)
+            if mi.uvs is not None:
+                v["TexCoord"] = mi.uvs
+            t = np.zeros(len(mi.indices), T.GpuBlasTriangle)
+            t["X"] = mi.indices[:, 0] + vertex_offset; t["Y"] = mi.indices[:, 1] + vertex_offset; t["Z"] = mi.indices[:, 2] + vertex_offset
+            t["MeshId"] = mesh_id
+            tris.append(t); pos.append(mi.positions); verts.append(v)
+            vertex_offset += nv
+        per_blas_tris.append(np.concatenate(tris))
+        xf = b.get("transform")
+        xforms.append(transform_from_matrix(np.eye(4) if xf is None else xf))
+    sc.vertex_positions = np.ascontiguousarray(np.concatenate(pos), np.float32)
+    sc.vertices = np.concatenate(verts)
+    sc.meshes = np.concatenate(meshes); sc.materials = np.concatenate(materials); sc.mesh_transforms = np.concatenate(xforms)
+    # per-BLAS build
+    nodes, tris_out, parents, leaves = [], [], [], []
+    descs = np.zeros(len(blases), T.GpuBlasDesc)
+    for i, b in enumerate(blases):
+        r = builder.build_blas(sc.vertex_positions, per_blas_tris[i], bool(b.get("refittable", False)))
+        d = descs[i]
+        d["NodeOffset"] = sum(len(x) for x in nodes); d["NodeCount"] = len(r["nodes"])
+        d["TriangleOffset"] = sum(len(x) for x in tris_out); d["TriangleCount"] = len(r["triangles"])
+        d["LeafIndicesOffset"] = sum(len(x) for x in leaves); d["LeafIndicesCount"] = len(r["leaves"])
+        d["ParentIndicesOffset"] = sum(len(x) for x in parents); d["ParentIndicesCount"] = len(r["parents"])
+        d["RequiredStackSize"] = r["required_stack_size"]; d["IsRefittable"] = 1 if b.get("refittable", False) else 0
+        nodes.append(r["nodes"]); tris_out.append(r["triangles"]); parents.append(r["parents"]); leaves.append(r["leaves"])
+    sc.blas_nodes = np.concatenate(nodes); sc.blas_triangles = np.concatenate(tris_out)
+    sc.blas_parent_indices = np.concatenate(parents).astype(np.int32); sc.blas_leaf_indices = np.concatenate(leaves).astype(np.int32)
+    sc.blas_descs = descs
+    inst = np.zeros(len(blases), T.GpuBlasInstance)
+    inst["BlasId"] = np.arange(len(blases)); inst["MeshTransformId"] = np.arange(len(blases))
+    sc.blas_instances = inst
+    sc.blas_stack_size = int(descs["RequiredStackSize"].max())  # BVH.UpdateBlasStackSize (Bvh/BVH.cs:559-567)
+    if build_tlas:
+        rebuild_tlas(sc, builder)
+    if lights is not None:
+        sc.lights = lights
+    if sky_color is not None:
+        sky = np.zeros((6, 1, 1, 4), np.float32); sky[..., :3] = sky_color; sky[..., 3] = 1.0
+        sc.sky_faces = sky
+    return sc
+
+
+def rebuild_tlas(sc, builder):
+    """BVH.TlasBuild (Bvh/BVH.cs:278-298): world-space bounds of each instance's BLAS root -> PLOC."""
+    bounds = np.zeros((len(sc.blas_instances), 6), np.float32)
+    for i, inst in enumerate(sc.blas_instances):
+        d = sc.blas_descs[inst["BlasId"]]
+        root = sc.blas_nodes[d["NodeOffset"] + 1: d["NodeOffset"] + 2]
+        bounds[i] = builder.instance_world_bounds(root, sc.mesh_transforms[inst["MeshTransformId"]: inst["MeshTransformId"] + 1])
+    sc.tlas_nodes = builder.build_tlas(bounds)
+
+# ----------------------------------------------------------------------------------------------- generators
+
+
+def pcg32_stream(seed, n):
+    """n uint32 outputs of the reference's PCG hash (Shaders/include/Random.glsl:20-27) chained from `seed`."""
+    out = np.empty(n, np.uint32)
+    s = np.uint64(seed)
+    M = np.uint64(0xFFFFFFFF)
+    for i in range(n):
+        s = (s * np.uint64(747796405) + np.uint64(2891336453)) & M
+        w = (((s >> ((s >> np.uint64(28)) + np.uint64(4))) ^ s) * np.uint64(277803737)) & M
+        out[i] = (w >> np.uint64(22)) ^ w
+    return out
+
+
+def soup_triangles(n, seed=1, extent=10.0, edge=0.15):
+    """centres uniform in [-extent,extent]^3, edge vectors uniform in [-edge,edge]^3.
+    Uses numpy's PCG64 Generator(seed) (documented stand-in for a 9n-long scalar PCG32 stream: same distribution,
+    deterministic for a given numpy version; the generated arrays, not the generator, are what both oracle and
+    GPU path consume)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    e1 = rng.uniform(-edge, edge, (n, 3)).astype(np.float32)
+    e2 = rng.uniform(-edge, edge, (n, 3)).astype(np.float32)
+    return np.stack([c, c + e1, c + e2], axis=1)
+
+
+def soup_scene(n_tris, builder, seed=1, refittable=False, albedo=0.8, extent=10.0, edge=0.15, sky_color=(1.0, 1.0, 1.0)):
+    """Headline workload (BASELINE.json configs[2]): one mesh/material (diffuse albedo 0.8, metallic 0, roughness 1,
+    opaque), one BLAS, identity transform, constant white sky."""
+    tp = soup_triangles(n_tris, seed, extent, edge)
+    p, i, nrm, tan = flat_shaded(tp)
+    mat = make_material(base_color=(albedo, albedo, albedo, 1.0), metallic=0.0, roughness=1.0)
+    return assemble([{"meshes": [MeshInput(p, i, mat, nrm, tan)], "refittable": refittable}], builder, sky_color=sky_color)
+
+
+def _quad(a, b, c, d):
+    return np.float32([[a, b, c], [a, c, d]])
+
+
+def _box_faces(lo, hi, with_bottom=False):
+    x0, y0, z0 = lo; x1, y1, z1 = hi
+    f = [
+        _quad((x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)),  # top
+        _quad((x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)),  # front (+z)
+        _quad((x1, y0, z0), (x0, y0, z0), (x0, y1, z0), (x1, y1, z0)),  # back
+        _quad((x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0)),  # left
+        _quad((x1, y0, z1), (x1, y0, z0), (x1, y1, z0), (x1, y1, z1)),  # right
+    ]
+    if with_bottom:
+        f.append(_quad((x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)))
+    return np.concatenate(f)
+
+
+def cornell_meshes(variant="diffuse"):
+    """32 triangles: 5 walls (10) + ceiling light (2) + short box (10) + tall box (10).  The reference ships no
+    Cornell box; this is the generated stand-in of SURVEY.md §8(d) config 1.  Box interior spans [-1,1]^3, open at +z."""
+    white = make_material((0.73, 0.73, 0.73, 1.0)); red = make_material((0.65, 0.05, 0.05, 1.0)); green = make_material((0.12, 0.45, 0.15, 1.0))
+    light = make_material((0.78, 0.78, 0.78, 1.0), emissive=(15.0, 15.0, 15.0))
+    if variant == "diffuse":
+        short_m = make_material((0.73, 0.73, 0.73, 1.0)); tall_m = make_material((0.73, 0.73, 0.73, 1.0))
+    else:  # "mixed": exercises specular + volumetric transmission + alpha paths
+        short_m = make_material((0.9, 0.95, 1.0, 1.0), transmission=1.0, roughness=0.05, ior=1.45, absorbance=(0.3, 0.1, 0.05), volumetric=True)
+        tall_m = make_material((0.95, 0.8, 0.4, 1.0), metallic=1.0, roughness=0.2)
+    walls = np.concatenate([
+        _quad((-1, -1, -1), (-1, -1, 1), (1, -1, 1), (1, -1, -1)),   # floor
+        _quad((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1)),       # ceiling
+        _quad((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)),   # back
+    ])
+    left = _quad((-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (-1, -1, 1))
+    right = _quad((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1))
+    lq = _quad((-0.25, 0.998, -0.25), (0.25, 0.998, -0.25), (0.25, 0.998, 0.25), (-0.25, 0.998, 0.25))
+    short = _box_faces((-0.3, 0.0, -0.3), (0.3, 0.6, 0.3))
+    tall = _box_faces((-0.3, 0.0, -0.3), (0.3, 1.2, 0.3))
+
+    def mk(tp, m):
+        p, i, n, t = flat_shaded(tp)
+        return MeshInput(p, i, m, n, t)
+    return {"walls": [mk(walls, white), mk(left, red), mk(right, green), mk(lq, light)], "short": mk(short, short_m), "tall": mk(tall, tall_m)}
+
+
+def cornell_scene(builder, variant="diffuse", instanced=False, sky_color=(0.0, 0.0, 0.0)):
+    """instanced=False: all 32 triangles hoisted into one BLAS (boxes pre-transformed) — the layout the reference
+    prefers (Application.cs:481).  instanced=True: walls / short box / tall box are three BLASes with their own
+    GpuMeshTransform, exercising RayTransform, the normal matrix and the TLAS."""
+    m = cornell_meshes(variant)
+    xs = rotation_y(-18.0) @ translation((0.33, -1.0, 0.4)); xt = rotation_y(17.0) @ translation((-0.35, -1.0, -0.3))
+    if instanced:
+        blases = [{"meshes": m["walls"]}, {"meshes": [m["short"]], "transform": xs}, {"meshes": [m["tall"]], "transform": xt}]
+    else:
+        def bake(mi, x):
+            p = (np.c_[mi.positions.astype(np.float64), np.ones(len(mi.positions))] @ x)[:, :3].astype(np.float32)
+            pp, ii, nn, tt = flat_shaded(p[mi.indices.reshape(-1)].reshape(-1, 3, 3))
+            return MeshInput(pp, ii, mi.material, nn, tt)
+        blases = [{"meshes": m["walls"] + [bake(m["short"], xs), bake(m["tall"], xt)]}]
+    return assemble(blases, builder, sky_color=sky_color)
+
+
+def cornell_camera(width, height):
+    return Camera(width, height, position=(0.0, 0.0, 3.4), fovy_deg=40.0)

@@ -1,0 +1,190 @@
+/*
+ * idkpt.h — C-ABI of libidkpt.so, the MI355X-native replacement for IDKEngine's
+ * wavefront path tracer (class PathTracer, Source/Render/PathTracer.cs:10-365).
+ *
+ * Every entry point replaces a piece of the reference's PathTracer / BVH GL plumbing;
+ * the replaced interface is cited per function.  Conventions follow the reference's own
+ * native-interop style (Source/OIDN/OIDN.cs:5-122): opaque handle, int32 status
+ * (0 = OK), last-error string, host pointers borrowed only for the duration of a call,
+ * library owns all device memory.  No torch / HIP types appear in any signature; device
+ * pointers and the stream cross as void*.
+ */
+#ifndef IDKPT_H
+#define IDKPT_H
+
+#include "idkpt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDKPT_API __attribute__((visibility("default")))
+
+typedef struct idkpt_ctx idkpt_ctx;
+
+enum idkpt_status {
+    IDKPT_OK = 0,
+    IDKPT_ERR_UNKNOWN = 1,
+    IDKPT_ERR_INVALID_ARGUMENT = 2,
+    IDKPT_ERR_INVALID_OPERATION = 3,
+    IDKPT_ERR_OUT_OF_MEMORY = 4,
+    IDKPT_ERR_NO_DEVICE = 5,
+    IDKPT_ERR_HIP = 6,
+};
+
+/* Which image idkptDownload / idkptGetImageDevicePtr addresses.
+ * PathTracer.Result / AlbedoTexture / NormalTexture (PathTracer.cs:143,167-168), RGBA32F. */
+enum idkpt_image { IDKPT_IMAGE_RESULT = 0, IDKPT_IMAGE_ALBEDO = 1, IDKPT_IMAGE_NORMAL = 2 };
+
+/* Which scene array idkptUpdateBuffer patches (ModelManager.UpdateBuffers, ModelManager.cs:594-621;
+ * LightManager UBO 2; BVH SSBO 20-27). */
+enum idkpt_buffer {
+    IDKPT_BUF_MESH_TRANSFORMS = 0, /* SSBO 4  */
+    IDKPT_BUF_VERTEX_POSITIONS = 1,/* SSBO 8  */
+    IDKPT_BUF_VERTICES = 2,        /* SSBO 7  */
+    IDKPT_BUF_MESHES = 3,          /* SSBO 2  */
+    IDKPT_BUF_MATERIALS = 4,       /* SSBO 3  */
+    IDKPT_BUF_LIGHTS = 5,          /* UBO 2 (GpuLight array; count via idkptSetLightCount) */
+    IDKPT_BUF_BLAS_NODES = 6,      /* SSBO 22 */
+    IDKPT_BUF_TLAS_NODES = 7,      /* SSBO 27 */
+    IDKPT_BUF_JOINT_MATRICES = 8,  /* SSBO 16 (3x4 row-major per joint, Skinning) */
+};
+
+/* One RGBA32F image of the texture table (stand-in for GL bindless textures; sampled at LOD 0 with
+ * bilinear filtering + repeat wrap as defined in DESIGN.md; 1x1 textures are exact). */
+typedef struct idkpt_texture {
+    int32_t width, height;
+    const float* rgba; /* width*height*4 floats, row-major, row 0 = v 0 */
+} idkpt_texture;
+
+/* Everything the reference's PathTracer kernels read through fixed GL bindings
+ * (Shaders/include/StaticStorageBuffers.glsl:9-173, StaticUniformBuffers.glsl:9-55), as explicit
+ * host arrays owned by the caller: BVH.{BlasNodes,BlasTriangles,BlasesDesc,BlasInstances,TlasNodes}
+ * (Bvh/BVH.cs:111-115), ModelManager.{Meshes,GpuMaterials,Vertices,VertexPositions,MeshTransforms}
+ * (ModelManager.cs:40-50), lights, skybox.  The library copies; nothing is retained. */
+typedef struct idkpt_scene_desc {
+    const GpuBlasNode*      BlasNodes;        int32_t BlasNodeCount;        /* SSBO 22 */
+    const GpuBlasTriangle*  BlasTriangles;    int32_t BlasTriangleCount;    /* SSBO 23 */
+    const GpuBlasDesc*      BlasDescs;        int32_t BlasDescCount;        /* SSBO 20 */
+    const GpuBlasInstance*  BlasInstances;    int32_t BlasInstanceCount;    /* SSBO 21 */
+    const GpuTlasNode*      TlasNodes;        int32_t TlasNodeCount;        /* SSBO 27 (may be 0 when !UseTlas) */
+    const int32_t*          BlasParentIndices;int32_t BlasParentIndexCount; /* SSBO 24 (refit; may be 0) */
+    const int32_t*          BlasLeafIndices;  int32_t BlasLeafIndexCount;   /* SSBO 25 (refit; may be 0) */
+    const float*            VertexPositions;  int32_t VertexCount;          /* SSBO 8: packed float3 */
+    const GpuVertex*        Vertices;                                       /* SSBO 7: VertexCount entries */
+    const GpuMesh*          Meshes;           int32_t MeshCount;            /* SSBO 2 */
+    const GpuMaterial*      Materials;        int32_t MaterialCount;        /* SSBO 3 */
+    const GpuMeshTransform* MeshTransforms;   int32_t MeshTransformCount;   /* SSBO 4 */
+    const GpuLight*         Lights;           int32_t LightCount;           /* UBO 2 (<= 256) */
+    const float*            SkyFaces;         int32_t SkyFaceSize;          /* UBO 5: 6 faces (+X,-X,+Y,-Y,+Z,-Z) x S x S x RGBA32F; NULL => black */
+    const idkpt_texture*    Textures;         int32_t TextureCount;         /* texture table for GpuMaterial handles */
+} idkpt_scene_desc;
+
+/* PathTracer's public knobs (PathTracer.cs:12-125) + the two BVH macros the kernels are compiled
+ * against in the reference (USE_TLAS, BLAS_STACK_SIZE; Bvh/BVH.cs:16-45). */
+typedef struct idkpt_settings {
+    GpuSettings Gpu;           /* FocalLength, LenseRadius, DoDebugBVHTraversal, DoTraceLights, DoRussianRoulette */
+    int32_t RayDepth;          /* PathTracer.RayDepth, default 7 (PathTracer.cs:211) */
+    int32_t SamplesPerPixel;   /* PathTracer.SamplesPerPixel, default 1 (:12) */
+    int32_t DoRaySorting;      /* PathTracer.DoRaySorting, default 0 (:173) */
+    int32_t OutputAOVs;        /* PathTracer.OutputAOVs, default 0 (:174) */
+    int32_t UseTlas;           /* BVH.GpuUseTlas, default 0 (Bvh/BVH.cs:156) */
+    int32_t BlasStackSize;     /* BVH.BlasStackSize = max RequiredStackSize (Bvh/BVH.cs:559-567); 0 => derive from BlasDescs */
+} idkpt_settings;
+
+typedef struct idkpt_stats {
+    uint64_t RaysTraced;        /* N + sum_j A_j over all frames since the last idkptResetStats */
+    uint64_t PrimaryRays;
+    uint64_t Frames;            /* samples rendered */
+    uint32_t LastAliveCounts[16]; /* alive-queue length entering bounce j of the last sample (j=1..15) */
+    float    LastTraceMs;       /* HIP-event time of all trace kernels of the last idkptRender (0 if timing disabled) */
+    float    LastFrameMs;       /* HIP-event time of the last idkptRender */
+    uint64_t NodePairVisits;    /* only when counters enabled (idkptEnableCounters) */
+    uint64_t TriangleTests;
+} idkpt_stats;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+/* new PathTracer(w,h,settings) (PathTracer.cs:170-212). deviceCount must be 1: one process per GPU;
+ * multi-GPU runs use one context per process and idkptSetRowSharding (DESIGN.md "Multi-GPU"). */
+IDKPT_API int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** outCtx);
+/* PathTracer.Dispose (PathTracer.cs:344-365) */
+IDKPT_API int32_t idkptDestroy(idkpt_ctx* ctx);
+/* OIDN.GetDeviceError style (OIDN/OIDN.cs:108-112): pointer stays valid until the next call on ctx */
+IDKPT_API int32_t idkptGetLastError(idkpt_ctx* ctx, const char** outMessage);
+/* Library/device probe usable before Create (NativeLibrary.TryLoad pattern, OIDN/OIDN.cs:11-20) */
+IDKPT_API int32_t idkptGetDeviceCount(int32_t* outCount);
+IDKPT_API const char* idkptGetVersionString(void);
+
+/* ---- configuration ---------------------------------------------------------------------- */
+/* PathTracer.SetSize (PathTracer.cs:299-332): (re)allocates ray/queue/sort buffers and images, resets accumulation */
+IDKPT_API int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height);
+/* Multi-GPU framebuffer sharding: this context renders image rows y with y % rowModulo == rowRemainder
+ * (rowModulo = world size, rowRemainder = rank).  Images/ray buffers then hold only the local rows, in
+ * increasing y.  (1,0) = whole frame.  No reference equivalent (single GPU); DESIGN.md "Multi-GPU". */
+IDKPT_API int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemainder);
+/* Per-bounce global queue-slot base for exact N-GPU == 1-GPU RNG seeds (NHit/compute.glsl:54 seeds from the slot).
+ * slotBases[j] is added to the local slot in bounce j (j = 1..count-1).  Optional; default all 0. */
+IDKPT_API int32_t idkptSetSlotBases(idkpt_ctx* ctx, const uint32_t* slotBases, int32_t count);
+/* Property setters of PathTracer (PathTracer.cs:12-125); changing anything but DoRussianRoulette/sorting/AOV
+ * resets accumulation exactly like the reference setters do. */
+IDKPT_API int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* settings);
+IDKPT_API int32_t idkptGetSettings(idkpt_ctx* ctx, idkpt_settings* outSettings);
+/* Upload of UBO 1 (Application.cs:144-159).  Only InvProjection, InvView, ViewPos are consumed. */
+IDKPT_API int32_t idkptSetPerFrame(idkpt_ctx* ctx, const float invProjection[16], const float invView[16], const float viewPos[3]);
+IDKPT_API int32_t idkptSetPerFrameData(idkpt_ctx* ctx, const GpuPerFrameData* perFrame);
+
+/* ---- scene ------------------------------------------------------------------------------ */
+/* Replaces BBG.Buffer.Recreate(...) of SSBO 20-27 (Bvh/BVH.cs:441-451), SSBO 2-8 (ModelManager.cs:594-621),
+ * lights UBO and skybox handle.  Builds the library's derived HBM layouts. */
+IDKPT_API int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* scene);
+/* Partial update: BBG.Buffer.UploadElements on one of the scene buffers (e.g. ModelManager.cs:236-261) */
+IDKPT_API int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, const void* data);
+IDKPT_API int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count);
+/* BVH.TlasBuild upload (Bvh/BVH.cs:278-298): host-built TLAS nodes replace SSBO 27 */
+IDKPT_API int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCount);
+/* BVH.GpuBlasesRefit(blasId,1) (Bvh/BVH.cs:472-489, Shaders/BLASRefit/compute.glsl) */
+IDKPT_API int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId);
+/* ModelManager skinning dispatch (ModelManager.cs:326-353, Shaders/Skinning/compute.glsl):
+ * skins vertexCount vertices from unskinned[inputOffset..] into positions/vertices[outputOffset..] */
+IDKPT_API int32_t idkptUploadUnskinnedVertices(idkpt_ctx* ctx, const GpuUnskinnedVertex* verts, int32_t count);
+IDKPT_API int32_t idkptSkin(idkpt_ctx* ctx, uint32_t inputVertexOffset, uint32_t outputVertexOffset, uint32_t jointMatricesOffset, uint32_t vertexCount);
+/* Read back a scene buffer (tests: refit/skinning results). */
+IDKPT_API int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst);
+
+/* ---- render ----------------------------------------------------------------------------- */
+/* PathTracer.ResetAccumulation (PathTracer.cs:334-337) */
+IDKPT_API int32_t idkptResetAccumulation(idkpt_ctx* ctx);
+IDKPT_API int32_t idkptGetAccumulatedSamples(idkpt_ctx* ctx, uint32_t* outSamples);
+/* PathTracer.Compute (PathTracer.cs:214-271): SamplesPerPixel x [FirstHit, (sort,) NHit x (RayDepth-1), FinalDraw].
+ * Asynchronous on the context's stream; no host read-back inside. */
+IDKPT_API int32_t idkptRender(idkpt_ctx* ctx);
+IDKPT_API int32_t idkptSynchronize(idkpt_ctx* ctx);
+/* Texture.Download of Result/Albedo/Normal (PathTracerPipeline.cs:177-188). Synchronises. bytes must be rows*width*16. */
+IDKPT_API int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes);
+/* Internal wavefront state for parity tests: SSBO 30 (GpuWavefrontRay per local pixel) and the alive queue of the
+ * last bounce (SSBO 32 AliveRayIndices). */
+IDKPT_API int32_t idkptDownloadRays(idkpt_ctx* ctx, GpuWavefrontRay* rays, size_t bytes);
+IDKPT_API int32_t idkptDownloadAliveQueue(idkpt_ctx* ctx, uint32_t* indices, size_t capacityElems, uint32_t* outCount);
+/* First-hit records (T, TriangleId, BaryX, BaryY) of the last sample's primary rays, for the bit-exact traversal gate. */
+/* enable=1: idkptRender keeps a copy of the primary-ray hit records (costs one 16 B/pixel device copy per sample) */
+IDKPT_API int32_t idkptEnablePrimaryHitCapture(idkpt_ctx* ctx, int32_t enable);
+IDKPT_API int32_t idkptDownloadPrimaryHits(idkpt_ctx* ctx, float* t, uint32_t* triangleId, float* baryXY, size_t pixelCount);
+
+/* ---- instrumentation -------------------------------------------------------------------- */
+IDKPT_API int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* outStats);
+IDKPT_API int32_t idkptResetStats(idkpt_ctx* ctx);
+/* enable=1: trace kernels also count node-pair visits / triangle tests (debugCost terms of BVHIntersect.glsl:45,60) */
+IDKPT_API int32_t idkptEnableCounters(idkpt_ctx* ctx, int32_t enable);
+/* enable=1: record HIP events around each idkptRender and around the trace kernels (LastFrameMs / LastTraceMs) */
+IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
+
+/* ---- interop (device pointers as void*, for RCCL gather of row shards by the host process) -- */
+IDKPT_API int32_t idkptGetImageDevicePtr(idkpt_ctx* ctx, int32_t image, void** outPtr, size_t* outBytes);
+/* Use an externally created hipStream_t (e.g. torch's current stream) for all work; NULL = library stream */
+IDKPT_API int32_t idkptSetStream(idkpt_ctx* ctx, void* hipStream);
+IDKPT_API int32_t idkptGetStream(idkpt_ctx* ctx, void** outHipStream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDKPT_H */

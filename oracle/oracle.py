@@ -1,0 +1,212 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY — may be imported from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never from the product package.  PARITY UNPINNED (see ref_math.h): the reference has no golden vectors for this path.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("ref_bvh_build.cpp", "ref_pathtracer.cpp", "ref_cpu_baseline.cpp", "ref_math.h", "Makefile")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("idkpt.h", "idkpt_types.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.ref_blas_build.restype = C.c_void_p
+        L.ref_blas_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        for f in ("ref_blas_node_count", "ref_blas_triangle_count", "ref_blas_fragment_count", "ref_blas_required_stack_size",
+                  "ref_blas_parent_count", "ref_blas_leaf_count"):
+            getattr(L, f).restype = C.c_int; getattr(L, f).argtypes = [C.c_void_p]
+        L.ref_blas_sah.restype = C.c_double; L.ref_blas_sah.argtypes = [C.c_void_p]
+        L.ref_blas_get.argtypes = [C.c_void_p] * 5
+        L.ref_blas_free.argtypes = [C.c_void_p]
+        L.ref_blas_refit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_instance_world_bounds.argtypes = [C.c_void_p] * 3
+        L.ref_tlas_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.ref_scene_create.restype = C.c_void_p; L.ref_scene_create.argtypes = [C.c_void_p]
+        L.ref_scene_destroy.argtypes = [C.c_void_p]
+        L.ref_scene_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ref_scene_set_blas_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ref_pt_create.restype = C.c_void_p; L.ref_pt_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_pt_destroy.argtypes = [C.c_void_p]
+        L.ref_pt_set_settings.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_pt_set_perframe.argtypes = [C.c_void_p] * 4
+        L.ref_pt_reset_accumulation.argtypes = [C.c_void_p]
+        L.ref_pt_enable_counters.argtypes = [C.c_void_p, C.c_int]
+        L.ref_pt_render.argtypes = [C.c_void_p]
+        L.ref_pt_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_pt_get_rays.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_pt_get_primary_hits.argtypes = [C.c_void_p] * 4
+        L.ref_pt_get_alive.restype = C.c_uint32; L.ref_pt_get_alive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.ref_pt_get_stats.argtypes = [C.c_void_p] * 5
+        L.ref_pt_accumulated.restype = C.c_uint32; L.ref_pt_accumulated.argtypes = [C.c_void_p]
+        L.ref_cpu_trace_primary.restype = C.c_uint64
+        L.ref_cpu_trace_primary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_pcg_hash.restype = C.c_uint32; L.ref_pcg_hash.argtypes = [C.POINTER(C.c_uint32)]
+        L.ref_float_to_key.restype = C.c_uint32; L.ref_float_to_key.argtypes = [C.c_float]
+        L.ref_morton30.restype = C.c_uint32; L.ref_morton30.argtypes = [C.c_float] * 3
+        L.ref_half_area.restype = C.c_float; L.ref_half_area.argtypes = [C.c_float] * 3
+        L.ref_compress_sr11g11b10.restype = C.c_uint32; L.ref_compress_sr11g11b10.argtypes = [C.c_void_p]
+        L.ref_decompress_sr11g11b10.argtypes = [C.c_uint32, C.c_void_p]
+        L.ref_encode_unit_vec.argtypes = [C.c_void_p, C.c_void_p]; L.ref_decode_unit_vec.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        L.ref_exp.restype = C.c_float; L.ref_exp.argtypes = [C.c_float]
+        L.ref_turbo.argtypes = [C.c_float, C.c_void_p]
+        L.ref_first_hit_gid.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2
+        L.ref_r2_sequence.argtypes = [C.c_uint32, C.c_void_p]
+        L.ref_ray_triangle.restype = C.c_int; L.ref_ray_triangle.argtypes = [C.c_void_p] * 7
+        L.ref_ray_box.restype = C.c_int; L.ref_ray_box.argtypes = [C.c_void_p] * 5
+        _LIB = L
+    return _LIB
+
+
+def _dtypes():
+    import sys
+    sys.path.insert(0, os.path.join(_HERE, ".."))
+    from idkengine_amd import gputypes as T  # struct mirrors only (interface contract), no product code paths
+    return T
+
+
+class OracleBuilder:
+    """Oracle restatement of BLAS.Build(+PreSplit) / TLAS.Build with the builder interface scenes.assemble expects."""
+
+    def __init__(self, presplit_factor=0.3):
+        self.presplit_factor = presplit_factor
+
+    def build_blas(self, positions, tris, refittable):
+        T = _dtypes(); L = lib()
+        positions = np.ascontiguousarray(positions, np.float32); tris = np.ascontiguousarray(tris)
+        h = L.ref_blas_build(positions.ctypes.data, tris.ctypes.data, len(tris), 1 if refittable else 0, self.presplit_factor)
+        try:
+            nodes = np.zeros(L.ref_blas_node_count(h), T.GpuBlasNode)
+            out_tris = np.zeros(L.ref_blas_triangle_count(h), T.GpuBlasTriangle)
+            parents = np.zeros(L.ref_blas_parent_count(h), np.int32); leaves = np.zeros(L.ref_blas_leaf_count(h), np.int32)
+            L.ref_blas_get(h, nodes.ctypes.data, out_tris.ctypes.data, parents.ctypes.data if len(parents) else None, leaves.ctypes.data if len(leaves) else None)
+            return {"nodes": nodes, "triangles": out_tris, "parents": parents, "leaves": leaves,
+                    "required_stack_size": L.ref_blas_required_stack_size(h), "sah": L.ref_blas_sah(h), "fragments": L.ref_blas_fragment_count(h)}
+        finally:
+            L.ref_blas_free(h)
+
+    def instance_world_bounds(self, root_node, xform):
+        out = np.zeros(6, np.float32)
+        root_node = np.ascontiguousarray(root_node); xform = np.ascontiguousarray(xform)
+        lib().ref_instance_world_bounds(root_node.ctypes.data, xform.ctypes.data, out.ctypes.data)
+        return out
+
+    def build_tlas(self, leaf_bounds, search_radius=15):
+        T = _dtypes()
+        leaf_bounds = np.ascontiguousarray(leaf_bounds, np.float32)
+        n = len(leaf_bounds)
+        nodes = np.zeros(max(2 * n - 1, 0), T.GpuTlasNode)
+        if n:
+            lib().ref_tlas_build(leaf_bounds.ctypes.data, n, nodes.ctypes.data, search_radius)
+        return nodes
+
+    def refit(self, nodes, positions, tris):
+        nodes = np.ascontiguousarray(nodes).copy(); positions = np.ascontiguousarray(positions, np.float32); tris = np.ascontiguousarray(tris)
+        lib().ref_blas_refit(nodes.ctypes.data, len(nodes), positions.ctypes.data, tris.ctypes.data)
+        return nodes
+
+
+class OraclePathTracer:
+    """Sequential CPU execution of the reference's FirstHit/NHit/FinalDraw schedule (PathTracer.cs:214-271)."""
+
+    def __init__(self, scene, width, height, row_modulo=1, row_remainder=0):
+        T = _dtypes(); L = lib()
+        self.T = T
+        d, keep = scene.desc()
+        self._scene = L.ref_scene_create(C.addressof(d))
+        del keep
+        self.width, self.height = width, height
+        self.rows = len(range(row_remainder, height, row_modulo))
+        self._pt = L.ref_pt_create(self._scene, width, height, row_modulo, row_remainder)
+        self.settings = T.Settings.default()
+
+    def close(self):
+        if self._pt:
+            lib().ref_pt_destroy(self._pt); lib().ref_scene_destroy(self._scene)
+            self._pt = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_camera(self, cam):
+        ip = np.ascontiguousarray(cam.inv_projection, np.float32); iv = np.ascontiguousarray(cam.inv_view, np.float32); vp = np.ascontiguousarray(cam.position, np.float32)
+        lib().ref_pt_set_perframe(self._pt, ip.ctypes.data, iv.ctypes.data, vp.ctypes.data)
+
+    def set_positions(self, positions):
+        p = np.ascontiguousarray(positions, np.float32)
+        lib().ref_scene_set_positions(self._scene, p.ctypes.data, len(p))
+
+    def set_blas_nodes(self, nodes):
+        n = np.ascontiguousarray(nodes)
+        lib().ref_scene_set_blas_nodes(self._scene, n.ctypes.data, len(n))
+
+    def reset_accumulation(self):
+        lib().ref_pt_reset_accumulation(self._pt)
+
+    def enable_counters(self, on=True):
+        lib().ref_pt_enable_counters(self._pt, 1 if on else 0)
+
+    def render(self):
+        lib().ref_pt_set_settings(self._pt, C.addressof(self.settings))
+        lib().ref_pt_render(self._pt)
+
+    def image(self, which=0):
+        out = np.zeros((self.rows, self.width, 4), np.float32)
+        lib().ref_pt_get_image(self._pt, which, out.ctypes.data)
+        return out
+
+    def rays(self):
+        out = np.zeros(self.rows * self.width, self.T.GpuWavefrontRay)
+        lib().ref_pt_get_rays(self._pt, out.ctypes.data)
+        return out
+
+    def primary_hits(self):
+        n = self.rows * self.width
+        t = np.zeros(n, np.float32); tri = np.zeros(n, np.uint32); bary = np.zeros((n, 2), np.float32)
+        lib().ref_pt_get_primary_hits(self._pt, t.ctypes.data, tri.ctypes.data, bary.ctypes.data)
+        return t, tri, bary
+
+    def alive_queue(self):
+        n = lib().ref_pt_get_alive(self._pt, None, 0)
+        out = np.zeros(n, np.uint32)
+        if n:
+            lib().ref_pt_get_alive(self._pt, out.ctypes.data, n)
+        return out
+
+    def stats(self):
+        rays = C.c_uint64(); pairs = C.c_uint64(); tris = C.c_uint64(); alive = (C.c_uint32 * 16)()
+        lib().ref_pt_get_stats(self._pt, C.byref(rays), C.byref(pairs), C.byref(tris), alive)
+        return {"rays_traced": rays.value, "node_pair_visits": pairs.value, "triangle_tests": tris.value, "alive_counts": list(alive)}
+
+
+def cpu_trace_primary(scene, cam, width, height, y0=0, y1=None, threads=0, want_hits=True, count=False):
+    """Gui.Test stand-in (C# semantics).  Returns dict(t, tri, rays, box_tests, tri_tests)."""
+    L = lib()
+    y1 = height if y1 is None else y1
+    d, keep = scene.desc()
+    n = (y1 - y0) * width
+    t = np.zeros(n, np.float32) if want_hits else None; tri = np.zeros(n, np.int32) if want_hits else None
+    cnt = np.zeros(2, np.uint64) if count else None
+    ip = np.ascontiguousarray(cam.inv_projection, np.float32); iv = np.ascontiguousarray(cam.inv_view, np.float32); vp = np.ascontiguousarray(cam.position, np.float32)
+    rays = L.ref_cpu_trace_primary(C.addressof(d), width, height, y0, y1, ip.ctypes.data, iv.ctypes.data, vp.ctypes.data, threads,
+                                   t.ctypes.data if want_hits else None, tri.ctypes.data if want_hits else None, cnt.ctypes.data if count else None)
+    del keep
+    return {"t": t, "tri": tri, "rays": rays, "box_tests": int(cnt[0]) if count else None, "tri_tests": int(cnt[1]) if count else None}
