@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -82,6 +83,168 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
             TraceRay<COUNT, false>(s, f, mk3(o.x, o.y, o.z), rd, hit, cost, stk, WAVE, nPairs, nTris);
             hits.hit[slot] = make_float4(hit.T, hit.bx, hit.by, __uint_as_float(hit.tri));
             hits.xformId[slot] = hit.xform;
+        }
+    }
+    if (COUNT) flush_counters(counters, nPairs, nTris);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path (single BLAS instance, no TLAS): coherent ray generation + persistent "while-while" traversal.
+//
+// k_gen_primary: one thread per pixel, 8x8 pixel tiles per wave.  Generates the primary ray (FirstHit:44-77), stores it,
+// and pre-culls rays whose root-box test (BVHIntersect.glsl:32-39 with T = FLOAT_MAX) fails: those get their miss
+// record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
+// wave) to an unordered active list; results are stored per pixel, so the list order is free.
+__global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs rays, HitBufs hits, uint32_t N, int cull, uint32_t* activeList, uint32_t* activeCount)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
+    const uint32_t tx = wave % tilesX, ty = wave / tilesX;
+    const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    const bool valid = x < (uint32_t)f.W && y < (uint32_t)f.rows;
+    const uint32_t pix = y * (uint32_t)f.W + x;
+    bool keep = false;
+    if (valid) {
+        f3 origin; f2 pd; uint32_t seed;
+        gen_primary(f, pix, origin, pd, seed);
+        rays.o_ior[pix] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+        rays.thr_px[pix] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
+        rays.rad_py[pix] = make_float4(0.0f, 0.0f, 0.0f, pd.y);
+        keep = true;
+        if (cull) {
+            GpuBlasInstance inst = s.instances[0];
+            int nodeOffset = s.descs[inst.BlasId].NodeOffset;
+            M34 inv = load_inv_model(s, inst.MeshTransformId);
+            f3 rd = DecodeUnitVec(pd.x, pd.y);
+            f3 lo = xform34(inv, origin, 1.0f), ld = xform34(inv, rd, 0.0f);
+            f3 invDir = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+            const float4* root = s.nodes + 2 * (size_t)nodeOffset + 2;
+            float t1;
+            keep = RayBoxIntersect(lo, invDir, root[0], root[1], &t1) && t1 < PT_FLOAT_MAX;
+            if (!keep) { hits.hit[pix] = make_float4(PT_FLOAT_MAX, 0.0f, 0.0f, __uint_as_float(~0u)); hits.xformId[pix] = 0; }
+        }
+    }
+    unsigned long long m = __ballot(keep);
+    if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(activeCount, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep) activeList[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pix;
+    }
+    (void)N;
+}
+
+// k_trace2: persistent waves; every lane owns one ray at a time and is refilled from the work list as soon as enough
+// lanes of the wave are idle.  Node steps (BVHIntersect.glsl:43-53,81-101) run for all lanes that can step until none
+// can; leaves found on the way are parked per lane and tested together afterwards (BVHIntersect.glsl:54-79).  A lane
+// never takes its next node step before its own pending leaf is tested, so every ray sees exactly the reference's
+// sequence of T updates and pushes: results (T, TriangleId, bary, visit counts) are bit-identical, only the interleaving
+// between different rays changes.
+#define REFILL_MIN 16
+template <bool PRIMARY, bool COUNT>
+__global__ __launch_bounds__(WAVE) void k_trace2(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t* stk = lds + lane;
+    const int cap = f.stackCap;
+    const uint32_t N = *countPtr;
+    // wave-uniform scene constants
+    const GpuBlasInstance inst = s.instances[0];
+    const int nodeOffset = s.descs[inst.BlasId].NodeOffset;
+    const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
+    const M34 inv = load_inv_model(s, inst.MeshTransformId);
+    const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
+
+    bool active = false, leafPending = false, workLeft = true;
+    uint32_t top = 0, slot = 0, leafFirst = 0, leafEnd = 0;
+    int sp = 0;
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
+    float hitT = 0.0f, hbx = 0.0f, hby = 0.0f; uint32_t hitTri = ~0u, hitXform = 0;
+    uint32_t nPairs = 0, nTris = 0;
+
+    while (true) {
+        // ---- refill idle lanes
+        unsigned long long idle = __ballot(!active);
+        if (workLeft && ((uint32_t)__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
+            const uint32_t n = (uint32_t)__popcll(idle);
+            const uint32_t base = wave_grab(workCounter, n);
+            const uint32_t item = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (base + n >= N) workLeft = false;
+            if (!active && item < N) {
+                const uint32_t idx = list[item];
+                slot = PRIMARY ? idx : item;
+                float4 o = rays.o_ior[idx];
+                float pdx = rays.thr_px[idx].w, pdy = rays.rad_py[idx].w;
+                f3 wd = DecodeUnitVec(pdx, pdy);
+                f3 wo = mk3(o.x, o.y, o.z);
+                hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f;
+                if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203
+                    for (int i = 0; i < s.lightCount; i++) {
+                        const GpuLight& l = s.lights[i];
+                        float tMin, tMax;
+                        if (RaySphereIntersect(wo, wd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hitT) { hitT = tMin < 0.0f ? tMax : tMin; hitXform = (uint32_t)i; hitTri = ~0u; }
+                    }
+                }
+                ro = xform34(inv, wo, 1.0f); rd = xform34(inv, wd, 0.0f);
+                invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                float t1;
+                bool enter = RayBoxIntersect(ro, invDir, nodes[2], nodes[3], &t1) && t1 < hitT; // root test (:32-39)
+                active = true; leafPending = false; sp = 0; top = enter ? 2u : 0u;
+            }
+        }
+        if (__ballot(active) == 0ull) { if (!workLeft) break; continue; }
+
+        // ---- node phase
+        while (true) {
+            const bool canStep = active && !leafPending && top != 0u;
+            if (!__any(canStep)) break;
+            if (canStep) {
+                if (COUNT) nPairs++;
+                const float4* p = nodes + 2 * (size_t)top;
+                float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+                const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
+                float tMinLeft, tMinRight;
+                const bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= hitT;
+                const bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hitT;
+                const bool intersectLeft = hitLeft && lCount > 0, intersectRight = hitRight && rCount > 0;
+                if (intersectLeft || intersectRight) {
+                    leafFirst = (intersectLeft ? lStart : rStart) + triOffset;
+                    leafEnd = (!intersectRight ? (lStart + lCount) : (rStart + rCount)) + triOffset;
+                    leafPending = true;
+                    if (COUNT) nTris += leafEnd - leafFirst;
+                }
+                const bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
+                if (traverseLeft || traverseRight) {
+                    if (traverseLeft && traverseRight) {
+                        const bool leftCloser = tMinLeft < tMinRight;
+                        top = leftCloser ? lStart : rStart;
+                        if (sp < cap) stk[sp * WAVE] = leftCloser ? rStart : lStart;
+                        sp++;
+                    } else top = traverseLeft ? lStart : rStart;
+                } else {
+                    if (sp == 0) top = 0u;
+                    else { sp--; top = stk[sp * WAVE]; }
+                }
+            }
+        }
+        // ---- leaf phase
+        if (leafPending) {
+            for (uint32_t i = leafFirst; i < leafEnd; i++) {
+                const float4* tv = s.triVerts + 3 * (size_t)i;
+                float4 a = tv[0], b = tv[1], c = tv[2];
+                float by, bz, t;
+                if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hitT) {
+                    hitTri = i; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = inst.MeshTransformId;
+                }
+            }
+            leafPending = false;
+        }
+        // ---- retire finished rays
+        if (active && top == 0u) {
+            hits.hit[slot] = make_float4(hitT, hbx, hby, __uint_as_float(hitTri));
+            hits.xformId[slot] = hitXform;
+            active = false;
         }
     }
     if (COUNT) flush_counters(counters, nPairs, nTris);
@@ -360,7 +523,7 @@ struct idkpt_ctx {
     int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0;
     float invProj[16], invView[16], viewPos[3];
     uint32_t accumulated = 0;
-    bool counters = false, timing = false, capturePrimary = false;
+    bool counters = false, timing = false, capturePrimary = false, forceGeneric = false;
     // scene
     bool haveScene = false;
     DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes;
@@ -441,7 +604,8 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
     memset(ctx->invProj, 0, 64); memset(ctx->invView, 0, 64); memset(ctx->viewPos, 0, 12);
     if (hipHostMalloc((void**)&ctx->hCounts, MAX_DEPTH_SLOTS * 4 + 16, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4 + 16);
-    hipEventCreate(&ctx->evFrame[0]); hipEventCreate(&ctx->evFrame[1]);
+    (void)hipEventCreate(&ctx->evFrame[0]); (void)hipEventCreate(&ctx->evFrame[1]);
+    if (const char* e = getenv("IDKPT_FORCE_GENERIC")) ctx->forceGeneric = atoi(e) != 0;
     *outCtx = ctx;
     return IDKPT_OK;
 }
@@ -771,10 +935,23 @@ static int render_sample(idkpt_ctx* ctx)
     const uint32_t gridN = (N + 255) / 256;
 
     // ---- FirstHit
+    // fast path: one BLAS instance, no TLAS, no debug-cost output -> coherent gen + cull, persistent while-while traversal
+    const bool fast = ctx->instanceCount == 1 && !f.useTlas && !debug && !ctx->forceGeneric;
+    uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (N uints), free at this point of the sample
+    uint32_t* activeCount = counts + (MAX_DEPTH_SLOTS - 1);
     {
+        if (fast) {
+            const uint32_t tilesX = ((uint32_t)f.W + 7) / 8, tilesY = ((uint32_t)f.rows + 7) / 8;
+            const uint32_t genWaves = tilesX * tilesY;
+            const int cull = f.g.DoTraceLights ? 0 : 1;
+            hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 3) / 4), dim3(256), 0, st, s, f, rays, hits, N, cull, activeList, activeCount);
+            if (ctx->counters) hipLaunchKernelGGL((k_trace2<true, true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
+            else hipLaunchKernelGGL((k_trace2<true, false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
+        } else {
         uint32_t g = std::min<uint32_t>(traceGrid, (N + 63) / 64);
         if (ctx->counters) { if (debug) hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<true, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
         else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
+        }
         if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.p, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
         hipLaunchKernelGGL((k_shade<true>), dim3(gridN), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, N, 0u,
                            ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(), ctx->keysTmp.as<uint32_t>());
@@ -799,8 +976,13 @@ static int render_sample(idkpt_ctx* ctx)
             // after 3 passes the sorted data sits in (sortKeys, sortVals): copy back into the queue side (A*4 B each; the reference copies W*H*4, PathTracer.cs:296)
             HIPC(hipMemcpyAsync(q, va, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
         }
-        if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
-        else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
+        if (fast) {
+            if (ctx->counters) hipLaunchKernelGGL((k_trace2<false, true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
+            else hipLaunchKernelGGL((k_trace2<false, false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
+        } else {
+            if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
+            else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
+        }
         hipLaunchKernelGGL((k_shade<false>), dim3(gridN), dim3(256), 0, st, s, f, rays, hits, q, cnt, 0u, ctx->slotBases[j],
                            ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(), ctx->keysTmp.as<uint32_t>());
         hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, cnt, 0u, ctx->waveCounts.as<uint32_t>(), counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr));

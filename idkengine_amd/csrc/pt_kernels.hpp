@@ -59,12 +59,13 @@ struct HitRec { float T, bx, by; uint32_t tri, xform; };
 // BVH traversal (include/BVHIntersect.glsl:27-105, 183-291).  One ray per lane; the per-lane traversal stack lives in
 // LDS as stack[depth][lane] (bank-conflict free: lane l and l+32 never share a cycle on ds_*_b32).
 template <bool COUNT, bool COST>
-DEV bool IntersectBlas(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& d, bool useTlas, HitRec& hit, float& debugCost,
+DEV bool IntersectBlas(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& dref, bool useTlas, HitRec& hit, float& debugCost,
                        uint32_t* stk, int stride, int cap, uint32_t& nPairs, uint32_t& nTris)
 {
     bool anyHit = false;
     float tMinLeft, tMinRight;
     f3 invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    struct { int NodeOffset, TriangleOffset; } d = {dref.NodeOffset, dref.TriangleOffset}; // keep in registers (no reload in the leaf path)
     const float4* nodes = s.nodes + 2 * (size_t)d.NodeOffset;
     if (!useTlas) {
         float4 rmin = nodes[2], rmax = nodes[3];

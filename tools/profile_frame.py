@@ -1,0 +1,28 @@
+"""Developer tool: render N frames of the headline workload (for rocprofv3). Uses a cached scene file if present."""
+import os, sys, time, pickle
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+from idkengine_amd import scenes as S
+from idkengine_amd.pathtracer import PathTracer
+
+def get_scene(n):
+    from oracle import oracle as O   # dev tool only
+    return S.soup_scene(n, O.OracleBuilder())
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+    depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    frames = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    sc = get_scene(n)
+    pt = PathTracer(1920, 1080)
+    pt.UploadScene(sc); pt.SetCamera(S.Camera(1920, 1080)); pt.RayDepth = depth
+    for _ in range(3):
+        pt.ResetAccumulation(); pt.Compute()
+    pt.synchronize(); pt.reset_stats()
+    t0 = time.time()
+    for _ in range(frames):
+        pt.ResetAccumulation(); pt.Compute()
+    pt.synchronize()
+    dt = (time.time() - t0) / frames
+    st = pt.stats()
+    print("ms/frame", dt * 1e3, "Mray/s", st["rays_traced"] / frames / dt / 1e6, st["alive_counts"][:depth + 1])
