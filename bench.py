@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X-native wavefront path tracer (driver contract: see task statement).
+
+Metric (BASELINE.json): Mray/s (primary + 1 bounce) at 1920x1080 on the synthetic 1M-triangle SweepSAH scene.
+  step      = one frame = one pass of the hot path: FirstHit -> NHit -> FinalDraw at 1 spp, RayDepth 2
+              (PathTracer.Compute, Source/Render/PathTracer.cs:214-271), scene and BVH already resident in HBM.
+  value     = (N + sum_j A_j) rays of all ranks / wall time (max over ranks), exact integer ray counts from the GPU queues.
+  N GPUs    = image rows dealt round-robin to the ranks (idkengine_amd/dist.py); the frame's only exchange is the RCCL
+              all-gather of the row shards, which is inside the timed region.  Total work is fixed -> "strong" scaling.
+  roofline  = traversal kernel (k_trace2): algorithmic bytes (64*P + 52*T + 104 per traversed ray) / HIP-event time of
+              its launches during the timed region, against 8 TB/s HBM.
+  cpu_baseline = the oracle's CPU port of the same path (all host cores, OpenMP) on a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+N_TRIS = 1_000_000
+RAY_DEPTH = 2
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STATE_BYTES_PER_TRAVERSED_RAY = 104  # 48 B ray fetch + 4 B index + 20 B hit record + 32 B root node (DESIGN.md "Roofline")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--tris", type=int, default=N_TRIS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from idkengine_amd import scenes as S
+    from idkengine_amd.bvh import NativeBuilder
+    from idkengine_amd import dist as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- scene: rank 0 builds (native SweepSAH + PreSplit builder), RCCL broadcast to the others
+    t0 = time.time()
+    scene = S.soup_scene(args.tris, NativeBuilder(), seed=1) if rank == 0 else None
+    build_s = time.time() - t0
+    if world > 1:
+        scene = D.broadcast_scene(scene, src=0, device=device)
+    cam = S.Camera(W, H)
+
+    r = D.GpuShardRenderer(W, H, world, rank, local_rank)
+    r.upload_scene(scene); r.set_camera(cam)
+    pt = r.pt
+    pt.RayDepth = RAY_DEPTH; pt.SamplesPerPixel = 1; pt.DoRaySorting = 0
+    frame = D.ShardedFrame(r, W, H) if world > 1 else None
+
+    def step():
+        r.render()
+        if frame is not None:
+            frame.gather()
+
+    # ---- untimed counter pass: exact P (node-pair visits) and T (triangle tests) of one frame of this rank's rows
+    pt.enable_counters(True); pt.reset_stats()
+    step(); pt.synchronize()
+    cs = pt.stats()
+    pairs, tri_tests, rays_frame = cs["node_pair_visits"], cs["triangle_tests"], cs["rays_traced"]
+    traversed = cs["alive_counts"][0] + sum(cs["alive_counts"][1:RAY_DEPTH])   # rays that entered the traversal kernel
+    pt.enable_counters(False)
+
+    for _ in range(args.warmup):
+        step()
+    pt.synchronize(); pt.reset_stats(); pt.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    st = pt.stats()
+    pt.enable_timing(False)
+
+    rays_total = torch.tensor([float(st["rays_traced"])], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rays_total = rays_total.item(); dt = tmax.item()
+    assert st["rays_traced"] == rays_frame * args.steps, (st["rays_traced"], rays_frame, args.steps)  # every step traced the same, complete frame
+
+    if rank == 0:
+        value = rays_total / dt / 1e6
+        # roofline of the traversal kernel (both instantiations of k_trace2: primary + bounce), this rank
+        alg_bytes_frame = 64.0 * pairs + 52.0 * tri_tests + STATE_BYTES_PER_TRAVERSED_RAY * traversed
+        launches = max(1, st["trace_launches"])
+        alg_bytes_launch = alg_bytes_frame * args.steps / launches
+        avg_launch_s = st["trace_ms_total"] * 1e-3 / launches
+        achieved = alg_bytes_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from the committed PMC summary of this same command
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(f"n{world}", {}).get("traversal_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene", "value": round(value, 2), "unit": "Mray/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {RAY_DEPTH}, sort off, white sky",
+                       "rays_per_step": int(rays_total / args.steps), "sharding": "rows round-robin over ranks + all-gather" if world > 1 else "none",
+                       "bvh_build_s": round(build_s, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": int(launches),
+                         "node_pair_visits_per_frame": int(pairs), "triangle_tests_per_frame": int(tri_tests), "traversed_rays_per_frame": int(traversed)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, cam, args.tris)
+        print(json.dumps(out), flush=True)
+    r.pt.Dispose()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, cam, n_tris):
+    """The oracle (CPU port of the reference path, GLSL semantics, OpenMP over all host cores) on a bounded sample of the
+    same frame: every m-th row, m chosen so the run takes roughly 10-30 s."""
+    from oracle import oracle as O   # allowed here: cpu_baseline leg only
+    cores = os.cpu_count() or 1
+
+    def run(mod):
+        o = O.OraclePathTracer(scene, W, H, row_modulo=mod, row_remainder=0)
+        o.set_camera(cam); o.settings.RayDepth = RAY_DEPTH
+        t0 = time.perf_counter(); o.render(); dt = time.perf_counter() - t0
+        rays = o.stats()["rays_traced"]; rows = o.rows
+        o.close()
+        return rays, dt, rows
+    rays, dt, rows = run(32)                       # probe: 34 rows
+    full_est = dt * 32
+    mod = 1 if full_est <= 30.0 else max(1, int(full_est / 20.0 + 0.999))
+    if mod != 32:
+        rays, dt, rows = run(mod)
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": f"rows y%{mod}==0 of the same {W}x{H} frame ({rows} rows, {rays} rays, RayDepth {RAY_DEPTH}) in {dt:.1f} s; C++/OpenMP restatement of the reference path (the C# binary cannot run here: no .NET)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""NativeBuilder — ctypes front-end of libidkbvh.so (include/idkbvh.h): the product's SweepSAH(+PreSplit) BLAS
+builder, PLOC TLAS builder and CPU refit.  Same builder interface scenes.assemble() expects."""
+import ctypes as C
+import os
+import numpy as np
+from . import gputypes as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libidkbvh.so")
+SYMBOLS = ["idkbvhBuildBlas", "idkbvhBlasGetInfo", "idkbvhBlasCopy", "idkbvhBlasFree", "idkbvhInstanceWorldBounds", "idkbvhBuildTlas", "idkbvhRefitBlas"]
+_lib = None
+
+
+class BlasInfo(C.Structure):
+    _fields_ = [("NodeCount", C.c_int32), ("TriangleCount", C.c_int32), ("RequiredStackSize", C.c_int32), ("ParentIndexCount", C.c_int32),
+                ("LeafIndexCount", C.c_int32), ("FragmentCount", C.c_int32), ("Sah", C.c_double), ("BuildMs", C.c_double)]
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libidkbvh.so not built: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.idkbvhBuildBlas.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.POINTER(C.c_void_p)]
+        L.idkbvhBlasGetInfo.argtypes = [C.c_void_p, C.c_void_p]
+        L.idkbvhBlasCopy.argtypes = [C.c_void_p] * 5
+        L.idkbvhBlasFree.argtypes = [C.c_void_p]; L.idkbvhBlasFree.restype = None
+        L.idkbvhInstanceWorldBounds.argtypes = [C.c_void_p] * 3
+        L.idkbvhBuildTlas.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.idkbvhRefitBlas.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class NativeBuilder:
+    def __init__(self, presplit_factor=0.3, threads=0):
+        self.presplit_factor = presplit_factor
+        self.threads = threads
+        self.last_build_ms = 0.0
+
+    def build_blas(self, positions, tris, refittable):
+        L = load()
+        positions = np.ascontiguousarray(positions, np.float32); tris = np.ascontiguousarray(tris)
+        h = C.c_void_p()
+        rc = L.idkbvhBuildBlas(positions.ctypes.data, tris.ctypes.data, len(tris), 1 if refittable else 0, self.presplit_factor, self.threads, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"idkbvhBuildBlas failed: {rc}")
+        try:
+            info = BlasInfo(); L.idkbvhBlasGetInfo(h, C.addressof(info))
+            nodes = np.zeros(info.NodeCount, T.GpuBlasNode); out_tris = np.zeros(info.TriangleCount, T.GpuBlasTriangle)
+            parents = np.zeros(info.ParentIndexCount, np.int32); leaves = np.zeros(info.LeafIndexCount, np.int32)
+            L.idkbvhBlasCopy(h, nodes.ctypes.data, out_tris.ctypes.data, parents.ctypes.data if len(parents) else None, leaves.ctypes.data if len(leaves) else None)
+            self.last_build_ms = info.BuildMs
+            return {"nodes": nodes, "triangles": out_tris, "parents": parents, "leaves": leaves, "required_stack_size": info.RequiredStackSize,
+                    "sah": info.Sah, "fragments": info.FragmentCount, "build_ms": info.BuildMs}
+        finally:
+            L.idkbvhBlasFree(h)
+
+    def instance_world_bounds(self, root_node, xform):
+        out = np.zeros(6, np.float32)
+        root_node = np.ascontiguousarray(root_node); xform = np.ascontiguousarray(xform)
+        load().idkbvhInstanceWorldBounds(root_node.ctypes.data, xform.ctypes.data, out.ctypes.data)
+        return out
+
+    def build_tlas(self, leaf_bounds, search_radius=15):
+        leaf_bounds = np.ascontiguousarray(leaf_bounds, np.float32)
+        n = len(leaf_bounds)
+        nodes = np.zeros(max(2 * n - 1, 0), T.GpuTlasNode)
+        if n:
+            load().idkbvhBuildTlas(leaf_bounds.ctypes.data, n, search_radius, nodes.ctypes.data)
+        return nodes
+
+    def refit(self, nodes, positions, tris):
+        nodes = np.ascontiguousarray(nodes).copy(); positions = np.ascontiguousarray(positions, np.float32); tris = np.ascontiguousarray(tris)
+        load().idkbvhRefitBlas(nodes.ctypes.data, len(nodes), positions.ctypes.data, tris.ctypes.data)
+        return nodes

@@ -1,0 +1,519 @@
+// libidkbvh.so — native SweepSAH (+PreSplit) BLAS builder, PLOC TLAS builder, CPU refit.  See include/idkbvh.h.
+//
+// Host-side product code (C++17, SSE, std::thread).  Must produce the same bytes as the reference's C# builder
+// (Source/Bvh/{BLAS,PreSplitting,TLAS}.cs), so every float operation mirrors it:
+//   * boxes are 4-lane SSE registers updated with minps/maxps (Vector128.MinNative/MaxNative, Shapes/Box.cs:40-70),
+//   * HalfArea = fma(x+y, z, x*y) (Utils/MyMath.cs:222-229),
+//   * no contraction anywhere else (-ffp-contract=off), cbrtf/rintf for MathF.Cbrt/MathF.Round.
+// Node ids do not depend on scheduling: a subtree with L fragments owns the id range reserved for it up front
+// (Bvh/BLAS.cs:221-241), which is what makes the threaded build deterministic.
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#include <immintrin.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
+#include "../../include/idkbvh.h"
+
+namespace {
+
+constexpr int kThreadedRecursionThreshold = 1 << 13; // BLAS.cs:28
+constexpr int kThreadedSortingThreshold = 1 << 16;   // BLAS.cs:29
+constexpr float kTraversalCost = 1.0f;               // BLAS.cs:26
+constexpr float kTriangleCost = 1.1f;                // BuildSettings defaults, BLAS.cs:31-48
+constexpr int kStopSplittingThreshold = 1;
+constexpr int kMaxLeafTriangleCount = 2;
+constexpr int kStackOptThreshold = 16;
+constexpr float kStackOptSahIncreaseAcceptance = 0.0009745f;
+
+struct alignas(16) SBox {
+    __m128 mn, mx;
+    static SBox empty() { return {_mm_set1_ps(FLT_MAX), _mm_set1_ps(-FLT_MAX)}; }
+    static SBox point(__m128 p) { return {p, p}; }
+    void grow(__m128 p) { mn = _mm_min_ps(mn, p); mx = _mm_max_ps(mx, p); }
+    void grow(const SBox& b) { mn = _mm_min_ps(mn, b.mn); mx = _mm_max_ps(mx, b.mx); }
+    void clip(const SBox& b) { mn = _mm_max_ps(mn, b.mn); mx = _mm_min_ps(mx, b.mx); }
+    void size(float s[4]) const { _mm_storeu_ps(s, _mm_sub_ps(mx, mn)); }
+    float halfArea() const { float s[4]; size(s); return fmaf(s[0] + s[1], s[2], s[0] * s[1]); }
+    float area() const { return halfArea() * 2.0f; }
+    float largestExtent() const { float s[4]; size(s); float a = s[1] > s[2] ? s[1] : s[2]; return s[0] > a ? s[0] : a; }
+    int largestAxis() const { float s[4]; size(s); int a = 0; if (s[0] < s[1]) a = 1; if (s[a] < s[2]) a = 2; return a; }
+    float lo(int a) const { float v[4]; _mm_storeu_ps(v, mn); return v[a]; }
+    float hi(int a) const { float v[4]; _mm_storeu_ps(v, mx); return v[a]; }
+};
+inline __m128 load3(const float* p) { return _mm_set_ps(0.0f, p[2], p[1], p[0]); }
+
+struct HNode { float mn[3]; int32_t startOrChild; float mx[3]; int32_t count; };
+static_assert(sizeof(HNode) == sizeof(GpuBlasNode), "node layout");
+inline bool isLeaf(const HNode& n) { return n.count > 0; }
+inline float nodeHalfArea(const HNode& n) { float x = n.mx[0] - n.mn[0], y = n.mx[1] - n.mn[1], z = n.mx[2] - n.mn[2]; return fmaf(x + y, z, x * y); }
+inline void setBounds(HNode& n, const SBox& b) { float v[4]; _mm_storeu_ps(v, b.mn); n.mn[0] = v[0]; n.mn[1] = v[1]; n.mn[2] = v[2]; _mm_storeu_ps(v, b.mx); n.mx[0] = v[0]; n.mx[1] = v[1]; n.mx[2] = v[2]; }
+inline SBox nodeBox(const HNode& n) { return {load3(n.mn), load3(n.mx)}; }
+
+inline int satInt(float f) { if (f != f) return 0; if (f >= 2147483648.0f) return INT32_MAX; if (f <= -2147483648.0f) return INT32_MIN; return (int)f; }
+inline uint32_t satUInt(float f) { if (f != f || f <= 0.0f) return 0u; if (f >= 4294967296.0f) return UINT32_MAX; return (uint32_t)f; }
+inline uint32_t floatToKey(float v) { uint32_t f; memcpy(&f, &v, 4); return f ^ (uint32_t)(((int32_t)f >> 31) | (int32_t)0x80000000); } // Algorithms.cs:15-34
+
+// 3 x 11-bit stable LSD radix sort of ids by key (Algorithms.cs:45-112); keys are precomputed once (same values the
+// reference recomputes per pass)
+void radixSortIds(const uint32_t* keys, int n, int* out)
+{
+    std::vector<int> tmp(n);
+    std::vector<int> hist(3 * 2048, 0);
+    for (int i = 0; i < n; i++) { uint32_t k = keys[i]; hist[k & 2047]++; hist[2048 + ((k >> 11) & 2047)]++; hist[4096 + (k >> 22)]++; }
+    for (int p = 0; p < 3; p++) { int sum = 0; int* h = &hist[p * 2048]; for (int i = 0; i < 2048; i++) { int t = h[i]; h[i] = sum; sum += t; } }
+    int* a = out; int* b = tmp.data();
+    for (int i = 0; i < n; i++) a[i] = i;                          // Helper.FillIncreasing
+    // pass 0: a -> b, pass 1: b -> a, pass 2: a -> b ; then copy to out (the reference ends in its `output` buffer too)
+    for (int i = 0; i < n; i++) { int id = a[i]; b[hist[keys[id] & 2047]++] = id; }
+    for (int i = 0; i < n; i++) { int id = b[i]; a[hist[2048 + ((keys[id] >> 11) & 2047)]++] = id; }
+    for (int i = 0; i < n; i++) { int id = a[i]; b[hist[4096 + (keys[id] >> 22)]++] = id; }
+    memcpy(out, b, sizeof(int) * (size_t)n);
+}
+
+struct Builder {
+    // inputs
+    const float* positions; const GpuBlasTriangle* tris; int triCount;
+    // fragments
+    std::vector<SBox> frag; std::vector<int> origTri;
+    // build state
+    std::vector<int> sorted[3]; std::vector<float> rightCosts; std::vector<uint8_t> leftTable;
+    std::vector<HNode> nodes;
+    int requiredStack = 0;
+    std::atomic<int> liveThreads{1};
+    int maxThreads = 1;
+    // outputs
+    std::vector<GpuBlasTriangle> outTris; std::vector<int> parents, leaves;
+    double sah = 0.0, buildMs = 0.0;
+
+    void triPoints(int i, __m128& a, __m128& b, __m128& c) const { const GpuBlasTriangle& t = tris[i]; a = load3(positions + 3 * (size_t)t.X); b = load3(positions + 3 * (size_t)t.Y); c = load3(positions + 3 * (size_t)t.Z); }
+    SBox triBox(int i) const { __m128 a, b, c; triPoints(i, a, b, c); SBox bx = SBox::point(a); bx.grow(b); bx.grow(c); return bx; } // Box.From(triangle)
+
+    // ---------------- PreSplitting.PreSplit (PreSplitting.cs:26-160)
+    static float triArea(__m128 a, __m128 b, __m128 c)
+    {
+        float p0[4], p1[4], p2[4]; _mm_storeu_ps(p0, a); _mm_storeu_ps(p1, b); _mm_storeu_ps(p2, c);
+        float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+        float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        return sqrtf((cx * cx) + (cy * cy) + (cz * cz)) * 0.5f;
+    }
+    float priority(int i) const { __m128 a, b, c; triPoints(i, a, b, c); SBox bx = SBox::point(a); bx.grow(b); bx.grow(c); float e = bx.largestExtent(); return cbrtf((e * e) * (bx.area() - triArea(a, b, c))); }
+    static int splitCount(float prio, float total, int n, float factor) { float share = prio / total * (float)n; return 1 + satInt(share * factor); }
+    void preSplit(float factor)
+    {
+        std::vector<float> prio(triCount);
+        float total = 0.0f;
+        for (int i = 0; i < triCount; i++) { prio[i] = priority(i); total += prio[i]; }
+        size_t count = 0;
+        for (int i = 0; i < triCount; i++) count += (size_t)splitCount(prio[i], total, triCount, factor);
+        frag.resize(count); origTri.resize(count);
+        SBox global = SBox::empty();
+        for (int i = 0; i < triCount; i++) { __m128 a, b, c; triPoints(i, a, b, c); global.grow(a); global.grow(b); global.grow(c); }
+        float gsz[4]; global.size(gsz);
+        size_t w = 0;
+        struct Item { SBox box; int splits; };
+        Item stack[64];
+        for (int i = 0; i < triCount; i++) {
+            __m128 pa, pb, pc; triPoints(i, pa, pb, pc);
+            float P[3][4]; _mm_storeu_ps(P[0], pa); _mm_storeu_ps(P[1], pb); _mm_storeu_ps(P[2], pc);
+            __m128 PV[3] = {pa, pb, pc};
+            int sp = 0;
+            SBox tb = SBox::point(pa); tb.grow(pb); tb.grow(pc);
+            stack[sp++] = {tb, splitCount(prio[i], total, triCount, factor)};
+            while (sp > 0) {
+                Item it = stack[--sp];
+                if (it.splits == 1) { frag[w] = it.box; origTri[w] = i; w++; continue; }
+                int axis = it.box.largestAxis();
+                float ext = it.box.largestExtent();
+                float alpha = ext / gsz[axis];
+                uint32_t bits; memcpy(&bits, &alpha, 4); bits &= (255u << 23); float p2; memcpy(&p2, &bits, 4);
+                float nodeSize = p2 * gsz[axis];
+                if (nodeSize >= ext - 0.0001f) nodeSize *= 0.5f;
+                float mid = (it.box.lo(axis) + it.box.hi(axis)) * 0.5f;
+                float idx = rintf((mid - global.lo(axis)) / nodeSize);
+                float pos = global.lo(axis) + idx * nodeSize;
+                // Triangle.Split (Shapes/Triangle.cs:48-97)
+                SBox lb = SBox::empty(), rb = SBox::empty();
+                bool q[3];
+                for (int v = 0; v < 3; v++) { q[v] = P[v][axis] <= pos; if (q[v]) lb.grow(PV[v]); else rb.grow(PV[v]); }
+                for (int e = 0; e < 3; e++) {
+                    int a = e, b = (e + 1) % 3;
+                    if (q[a] ^ q[b]) {
+                        float t = (pos - P[a][axis]) / (P[b][axis] - P[a][axis]);
+                        __m128 m = _mm_add_ps(PV[a], _mm_mul_ps(_mm_set1_ps(t), _mm_sub_ps(PV[b], PV[a])));
+                        m = _mm_blend_ps(m, _mm_setzero_ps(), 8); // Vector3 -> Vector128(x,y,z,0)
+                        lb.grow(m); rb.grow(m);
+                    }
+                }
+                lb.clip(it.box); rb.clip(it.box);
+                float le = lb.largestExtent(), re = rb.largestExtent();
+                int lc = satInt((float)it.splits * (le / (le + re)));
+                lc = std::min(std::max(lc, 1), it.splits - 1);
+                stack[sp++] = {rb, it.splits - lc};
+                stack[sp++] = {lb, lc};
+            }
+        }
+    }
+
+    // ---------------- build
+    SBox boundsOf(int start, int count, int axis) const { SBox b = SBox::empty(); const int* ids = sorted[axis].data() + start; for (int i = 0; i < count; i++) b.grow(frag[ids[i]]); return b; }
+    static int stablePartition(int* src, int n, int* aux, const uint8_t* table)
+    {
+        int l = 0, r = 0;
+        for (int i = 0; i < n; i++) { int id = src[i]; if (table[id]) src[l++] = id; else aux[r++] = id; }
+        memcpy(src + l, aux, sizeof(int) * (size_t)r);
+        return l;
+    }
+    // BLAS.TrySplit (BLAS.cs:730-873). Returns split index or -1.
+    int trySplit(const HNode& parent)
+    {
+        if (parent.count <= kStopSplittingThreshold) return -1;
+        const int start = parent.startOrChild, end = start + parent.count;
+        int bestAxis = 0, bestIndex = 0; float bestCost = FLT_MAX;
+        float* rc = rightCosts.data();
+        for (int axis = 0; axis < 3; axis++) {
+            const int* ids = sorted[axis].data();
+            int firstRight = start + 1;
+            SBox acc = SBox::empty(); float cnt = 0.0f;
+            for (int i = end - 1; i >= firstRight; i--) {
+                cnt++; acc.grow(frag[ids[i]]);
+                float c = acc.halfArea() * cnt;
+                rc[i] = c;
+                if (c >= bestCost) { firstRight = i + 1; break; }
+            }
+            SBox lacc = SBox::empty(); float lcnt = (float)(firstRight - start) - 1.0f;
+            for (int i = start; i < firstRight - 1; i++) lacc.grow(frag[ids[i]]);
+            for (int i = firstRight - 1; i < end - 1; i++) {
+                lcnt++; lacc.grow(frag[ids[i]]);
+                float lcost = lacc.halfArea() * lcnt;
+                float cost = lcost + rc[i + 1];
+                if (cost < bestCost) { bestIndex = i + 1; bestAxis = axis; bestCost = cost; }
+                else if (lcost >= bestCost) break;
+            }
+        }
+        if (parent.count <= kMaxLeafTriangleCount) {
+            float notSplit = kTriangleCost * (float)parent.count;
+            float newCost = kTraversalCost + (kTriangleCost * bestCost / nodeHalfArea(parent));
+            if (newCost >= notSplit) return -1;
+        }
+        SBox lb = boundsOf(start, bestIndex - start, bestAxis), rb = boundsOf(bestIndex, end - bestIndex, bestAxis);
+        const bool swap = lb.halfArea() < rb.halfArea();
+        int* ids = sorted[bestAxis].data();
+        for (int i = start; i < bestIndex; i++) leftTable[ids[i]] = !swap;
+        for (int i = bestIndex; i < end; i++) leftTable[ids[i]] = swap;
+        int* aux = reinterpret_cast<int*>(rc + start);
+        if (swap) bestIndex = start + stablePartition(ids + start, parent.count, aux, leftTable.data());
+        stablePartition(sorted[(bestAxis + 1) % 3].data() + start, parent.count, aux, leftTable.data());
+        stablePartition(sorted[(bestAxis + 2) % 3].data() + start, parent.count, aux, leftTable.data());
+        return bestIndex;
+    }
+    void buildSubtree(int parentId, int newNodesId)
+    {
+        // explicit stack instead of recursion; big subtrees are handed to new threads like BLAS.cs:221-231
+        struct Task { int parent, fresh; };
+        std::vector<Task> todo; todo.push_back({parentId, newNodesId});
+        std::vector<std::thread> spawned;
+        while (!todo.empty()) {
+            Task t = todo.back(); todo.pop_back();
+            HNode& p = nodes[t.parent];
+            setBounds(p, boundsOf(p.startOrChild, p.count, 0));
+            int split = trySplit(p);
+            if (split < 0) continue;
+            HNode l = {}, r = {};
+            l.startOrChild = p.startOrChild; l.count = split - l.startOrChild;
+            r.startOrChild = split; r.count = p.count - l.count;
+            const int lid = t.fresh, rid = lid + 1;
+            nodes[lid] = l; nodes[rid] = r;
+            p.startOrChild = lid; p.count = 0;
+            const int leftFresh = rid + 1, rightFresh = rid + (2 * l.count - 1);
+            if (std::min(l.count, r.count) >= kThreadedRecursionThreshold && liveThreads.load() < maxThreads) {
+                liveThreads++;
+                spawned.emplace_back([this, lid, leftFresh]() { buildSubtree(lid, leftFresh); liveThreads--; });
+                todo.push_back({rid, rightFresh});
+            } else {
+                todo.push_back({rid, rightFresh});
+                todo.push_back({lid, leftFresh}); // left first (order is irrelevant for the result, ids are pre-reserved)
+            }
+        }
+        for (auto& th : spawned) th.join();
+    }
+    int requiredStackSize(int nodeId = 2) const // BLAS.cs:672-702
+    {
+        const HNode& l = nodes[nodeId]; const HNode& r = nodes[nodeId + 1];
+        bool tl = !isLeaf(l), tr = !isLeaf(r);
+        if (tl && tr) return std::max(requiredStackSize(l.startOrChild), requiredStackSize(r.startOrChild)) + 1;
+        if (tl || tr) return requiredStackSize(tl ? l.startOrChild : r.startOrChild);
+        return 0;
+    }
+    double globalSAH() const // BLAS.cs:629-657
+    {
+        double cost = 0.0, rootArea = 1.0 / (double)nodeHalfArea(nodes[1]);
+        std::vector<int> st; st.push_back(1);
+        while (!st.empty()) {
+            const HNode& n = nodes[st.back()]; st.pop_back();
+            double prob = (double)nodeHalfArea(n) * rootArea;
+            if (isLeaf(n)) cost += (double)(kTriangleCost * (float)n.count) * prob;
+            else { cost += (double)kTraversalCost * prob; st.push_back(n.startOrChild + 1); st.push_back(n.startOrChild); }
+        }
+        return cost;
+    }
+    void collapseDeepest(int newStackSize, bool firstPass, double& nextCost, int parentId = 1, int depth = 0) // BLAS.cs:897-936
+    {
+        HNode& p = nodes[parentId];
+        const int c = p.startOrChild;
+        if (!isLeaf(nodes[c])) collapseDeepest(newStackSize, firstPass, nextCost, c, depth + 1);
+        if (!isLeaf(nodes[c + 1])) collapseDeepest(newStackSize, firstPass, nextCost, c + 1, depth + 1);
+        const HNode& l = nodes[c]; const HNode& r = nodes[c + 1];
+        if (isLeaf(l) && isLeaf(r)) {
+            if (depth > newStackSize && !firstPass) { p.startOrChild = l.startOrChild; p.count = l.count + r.count; }
+            if ((depth == newStackSize && !firstPass) || (depth > newStackSize && firstPass)) {
+                // StackOptMaxLeafTriangleCount = int.MaxValue: the guard at BLAS.cs:924-928 can never fire
+                double leavesCost = (double)kTriangleCost * ((double)l.count * (double)nodeHalfArea(l) + (double)r.count * (double)nodeHalfArea(r));
+                double newParentLeafCost = (double)kTriangleCost * (double)(l.count + r.count);
+                nextCost += ((double)nodeHalfArea(p) * (newParentLeafCost - (double)kTraversalCost) - leavesCost) / (double)nodeHalfArea(nodes[1]);
+            }
+        }
+    }
+    void optimizeStackSize() // BLAS.cs:875-895
+    {
+        requiredStack = requiredStackSize();
+        if (requiredStack < kStackOptThreshold) return;
+        double current = globalSAH(), added = 0.0;
+        collapseDeepest(requiredStack - 1, true, added);
+        double inc = added / current;
+        while (inc <= (double)kStackOptSahIncreaseAcceptance && requiredStack > 0) { collapseDeepest(--requiredStack, false, added); inc = added / current; }
+    }
+    int compactNodes() // RemoveEmptySubtrees, BLAS.cs:245-273
+    {
+        int counter = 2;
+        std::vector<int> st; st.push_back(1);
+        while (!st.empty()) {
+            int pid = st.back(); st.pop_back();
+            HNode l = nodes[nodes[pid].startOrChild], r = nodes[nodes[pid].startOrChild + 1];
+            nodes[counter] = l; nodes[counter + 1] = r;
+            nodes[pid].startOrChild = counter;
+            if (!isLeaf(r)) st.push_back(counter + 1);
+            if (!isLeaf(l)) st.push_back(counter);
+            counter += 2;
+        }
+        return counter;
+    }
+    void unindexPlain() // BLAS.GetUnindexedTriangles, BLAS.cs:441-466
+    {
+        // single-leaf root: its leaf is duplicated into nodes 2 and 3 (BLAS.cs:173-183; the reference throws here) ->
+        // size by the sum of leaf counts so the duplicated triangles are simply stored twice
+        size_t total = 0;
+        for (size_t i = 2; i < nodes.size(); i++) if (isLeaf(nodes[i])) total += (size_t)nodes[i].count;
+        outTris.resize(std::max(total, frag.size()));
+        int w = 0;
+        for (size_t i = 2; i < nodes.size(); i++) {
+            HNode& n = nodes[i];
+            if (!isLeaf(n)) continue;
+            for (int j = 0; j < n.count; j++) outTris[w + j] = tris[sorted[0][n.startOrChild + j]];
+            n.startOrChild = w; w += n.count;
+        }
+        outTris.resize((size_t)w);
+    }
+    void uniqueIds(const HNode& leaf, std::vector<int>& ids) const
+    {
+        ids.resize(leaf.count);
+        for (int i = 0; i < leaf.count; i++) ids[i] = origTri[sorted[0][leaf.startOrChild + i]];
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    }
+    void unindexPreSplit() // PreSplitting.GetUnindexedTriangles, PreSplitting.cs:169-273
+    {
+        outTris.assign(frag.size(), GpuBlasTriangle{});
+        int g = 0;
+        std::vector<int> st, lu, ru; st.push_back(2);
+        while (!st.empty()) {
+            int top = st.back(); st.pop_back();
+            HNode& l = nodes[top]; HNode& r = nodes[top + 1];
+            if (isLeaf(l) && isLeaf(r)) {
+                uniqueIds(l, lu); uniqueIds(r, ru);
+                int onlyLeft = 0, back = 0, nl = (int)lu.size();
+                for (int id : lu) { if (std::binary_search(ru.begin(), ru.end(), id)) outTris[g + nl - back++ - 1] = tris[id]; else outTris[g + onlyLeft++] = tris[id]; }
+                int onlyRight = 0;
+                for (int id : ru) if (!std::binary_search(lu.begin(), lu.end(), id)) outTris[g + nl + onlyRight++] = tris[id];
+                l.startOrChild = g; l.count = nl;
+                r.startOrChild = g + onlyLeft; r.count = (int)ru.size();
+                g += (r.startOrChild + r.count) - l.startOrChild;
+            } else if (isLeaf(l) || isLeaf(r)) {
+                HNode& leaf = isLeaf(l) ? l : r;
+                uniqueIds(leaf, lu);
+                for (size_t i = 0; i < lu.size(); i++) outTris[g + (int)i] = tris[lu[i]];
+                leaf.startOrChild = g; leaf.count = (int)lu.size(); g += (int)lu.size();
+            }
+            if (!isLeaf(r)) st.push_back(r.startOrChild);
+            if (!isLeaf(l)) st.push_back(l.startOrChild);
+        }
+        outTris.resize(g);
+    }
+
+    void run(bool refittable, float factor, int threads)
+    {
+        auto t0 = std::chrono::steady_clock::now();
+        maxThreads = threads <= 0 ? std::max(1u, std::thread::hardware_concurrency()) : threads;
+        const bool doPreSplit = !refittable;
+        if (doPreSplit) preSplit(factor);
+        else { frag.resize(triCount); for (int i = 0; i < triCount; i++) frag[i] = triBox(i); }
+        const int n = (int)frag.size();
+        nodes.assign((size_t)std::max(2 * n, 4), HNode{});
+        leftTable.assign(n, 0); rightCosts.assign(n, 0.0f);
+        // BLAS.GetBuildData (BLAS.cs:128-157): ids sorted by FloatToKey(min+max) per axis
+        {
+            auto sortAxis = [&](int axis) {
+                std::vector<uint32_t> keys(n);
+                for (int i = 0; i < n; i++) keys[i] = floatToKey(frag[i].lo(axis) + frag[i].hi(axis));
+                sorted[axis].resize(n);
+                radixSortIds(keys.data(), n, sorted[axis].data());
+            };
+            if (n >= kThreadedSortingThreshold && maxThreads > 1) { std::thread a(sortAxis, 0), b(sortAxis, 1); sortAxis(2); a.join(); b.join(); }
+            else for (int a = 0; a < 3; a++) sortAxis(a);
+        }
+        nodes[1].startOrChild = 0; nodes[1].count = n;
+        buildSubtree(1, 2);
+        if (isLeaf(nodes[1])) { nodes[2] = nodes[1]; nodes[3] = nodes[1]; nodes[1].startOrChild = 2; nodes[1].count = 0; } // BLAS.cs:173-183
+        optimizeStackSize();
+        nodes.resize((size_t)compactNodes());
+        if (doPreSplit) unindexPreSplit(); else unindexPlain();
+        if (refittable) {
+            const int nn = (int)nodes.size();
+            parents.assign(nn, -1);
+            for (int i = 1; i < nn; i++) if (!isLeaf(nodes[i])) { parents[nodes[i].startOrChild] = i; parents[nodes[i].startOrChild + 1] = i; }
+            for (int i = 2; i < nn; i++) if (isLeaf(nodes[i])) leaves.push_back(i);
+        }
+        sah = globalSAH();
+        buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+uint32_t spread3(uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; }
+
+} // namespace
+
+struct idkbvh_blas { Builder b; int fragmentCount = 0; };
+
+extern "C" {
+
+int32_t idkbvhBuildBlas(const float* positions, const GpuBlasTriangle* tris, int32_t triCount, int32_t isRefittable, float preSplitFactor, int32_t threads, idkbvh_blas** out)
+{
+    if (!positions || !tris || triCount <= 0 || !out) return 2;
+    idkbvh_blas* h = new idkbvh_blas();
+    h->b.positions = positions; h->b.tris = tris; h->b.triCount = triCount;
+    h->b.run(isRefittable != 0, preSplitFactor, threads);
+    h->fragmentCount = (int)h->b.frag.size();
+    h->b.positions = nullptr; h->b.tris = nullptr; // inputs are only borrowed during the call
+    *out = h;
+    return 0;
+}
+int32_t idkbvhBlasGetInfo(const idkbvh_blas* h, idkbvh_blas_info* o)
+{
+    if (!h || !o) return 2;
+    o->NodeCount = (int)h->b.nodes.size(); o->TriangleCount = (int)h->b.outTris.size(); o->RequiredStackSize = h->b.requiredStack;
+    o->ParentIndexCount = (int)h->b.parents.size(); o->LeafIndexCount = (int)h->b.leaves.size(); o->FragmentCount = h->fragmentCount; o->Sah = h->b.sah; o->BuildMs = h->b.buildMs;
+    return 0;
+}
+int32_t idkbvhBlasCopy(const idkbvh_blas* h, GpuBlasNode* nodes, GpuBlasTriangle* triangles, int32_t* parents, int32_t* leaves)
+{
+    if (!h) return 2;
+    if (nodes) memcpy(nodes, h->b.nodes.data(), h->b.nodes.size() * sizeof(HNode));
+    if (triangles) memcpy(triangles, h->b.outTris.data(), h->b.outTris.size() * sizeof(GpuBlasTriangle));
+    if (parents && !h->b.parents.empty()) memcpy(parents, h->b.parents.data(), h->b.parents.size() * 4);
+    if (leaves && !h->b.leaves.empty()) memcpy(leaves, h->b.leaves.data(), h->b.leaves.size() * 4);
+    return 0;
+}
+void idkbvhBlasFree(idkbvh_blas* h) { delete h; }
+
+int32_t idkbvhInstanceWorldBounds(const GpuBlasNode* root, const GpuMeshTransform* xf, float out[6])
+{
+    if (!root || !xf || !out) return 2;
+    SBox nb = SBox::empty();
+    for (int i = 0; i < 8; i++) {
+        float c[3] = {(i & 1) ? root->Max[0] : root->Min[0], (i & 2) ? root->Max[1] : root->Min[1], (i & 4) ? root->Max[2] : root->Min[2]};
+        float w[3];
+        for (int k = 0; k < 3; k++) w[k] = (c[0] * xf->Model[k][0]) + (c[1] * xf->Model[k][1]) + (c[2] * xf->Model[k][2]) + (1.0f * xf->Model[k][3]); // (Vector4(p,1) * M).Xyz
+        nb.grow(load3(w));
+    }
+    float v[4]; _mm_storeu_ps(v, nb.mn); out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; _mm_storeu_ps(v, nb.mx); out[3] = v[0]; out[4] = v[1]; out[5] = v[2];
+    return 0;
+}
+
+int32_t idkbvhBuildTlas(const float* leafBounds, int32_t count, int32_t searchRadius, GpuTlasNode* outNodes)
+{
+    if (!leafBounds || count <= 0 || !outNodes) return 2;
+    struct TN { float mn[3]; uint32_t id; float mx[3]; float pad; };
+    const int nodeCount = 2 * count - 1;
+    TN* nodes = reinterpret_cast<TN*>(outNodes);
+    memset(nodes, 0, sizeof(TN) * (size_t)nodeCount);
+    std::vector<TN> temp(nodeCount); memset(temp.data(), 0, sizeof(TN) * (size_t)nodeCount);
+    auto boxOf = [](const TN& n) { return SBox{load3(n.mn), load3(n.mx)}; };
+    {   // leaves, Morton-sorted (stable radix, TLAS.cs:36-56)
+        std::vector<TN> leaf(count); SBox global = SBox::empty();
+        for (int i = 0; i < count; i++) { const float* b = leafBounds + 6 * (size_t)i; TN n = {{b[0], b[1], b[2]}, (1u << 31) | (uint32_t)i, {b[3], b[4], b[5]}, 0.0f}; leaf[i] = n; global.grow(boxOf(n)); }
+        float gmn[4], gmx[4]; _mm_storeu_ps(gmn, global.mn); _mm_storeu_ps(gmx, global.mx);
+        std::vector<uint32_t> keys(count);
+        for (int i = 0; i < count; i++) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; a++) {
+                float c = (leaf[i].mx[a] + leaf[i].mn[a]) * 0.5f, ext = gmx[a] - gmn[a];
+                float m = (c - gmn[a]) / ext * (1.0f - 0.0f) + 0.0f; if (ext == 0.0f) m = 0.0f;   // MyMath.MapToZeroOne
+                q[a] = std::min(satUInt(m * 1024.0f), 1023u);
+            }
+            keys[i] = (spread3(q[0]) << 2) | (spread3(q[1]) << 1) | spread3(q[2]);                  // MyMath.GetMortonCode30
+        }
+        std::vector<int> order(count); radixSortIds(keys.data(), count, order.data());
+        for (int i = 0; i < count; i++) nodes[nodeCount - count + i] = leaf[order[i]];
+    }
+    int activeCount = count, activeEnd = nodeCount;
+    std::vector<int> pref(count);
+    while (activeCount > 1) {
+        const int activeStart = activeEnd - activeCount;
+        for (int i = 0; i < activeCount; i++) {
+            const int a = activeStart + i, s0 = std::max(a - searchRadius, activeStart), s1 = std::min(a + searchRadius + 1, activeEnd);
+            float best = FLT_MAX; int bestIdx = -1; const SBox nb = boxOf(nodes[a]);
+            for (int k = s0; k < s1; k++) { if (k == a) continue; SBox m = nb; m.grow(boxOf(nodes[k])); float area = m.halfArea(); if (area < best) { best = area; bestIdx = k; } }
+            pref[i] = bestIdx - activeStart;
+        }
+        int merged = 0;
+        for (int i = 0; i < activeCount; i++) { int b = pref[i]; if (pref[b] == i && i < b) merged += 2; }
+        const int unmerged = activeCount - merged, fresh = merged / 2;
+        int mergedHead = activeEnd - merged; const int newBegin = mergedHead - unmerged - fresh; int unmergedHead = newBegin;
+        for (int i = 0; i < activeCount; i++) {
+            const int b = pref[i], aId = i + activeStart;
+            if (pref[b] == i) {
+                if (i < b) {
+                    temp[mergedHead] = nodes[aId]; temp[mergedHead + 1] = nodes[b + activeStart];
+                    SBox m = boxOf(temp[mergedHead]); m.grow(boxOf(temp[mergedHead + 1]));
+                    TN p; memset(&p, 0, sizeof(p)); float v[4]; _mm_storeu_ps(v, m.mn); p.mn[0] = v[0]; p.mn[1] = v[1]; p.mn[2] = v[2]; _mm_storeu_ps(v, m.mx); p.mx[0] = v[0]; p.mx[1] = v[1]; p.mx[2] = v[2];
+                    p.id = (uint32_t)mergedHead;
+                    temp[unmergedHead++] = p; mergedHead += 2;
+                }
+            } else temp[unmergedHead++] = nodes[aId];
+        }
+        memcpy(&nodes[newBegin], &temp[newBegin], sizeof(TN) * (size_t)(activeEnd - newBegin));
+        activeCount -= merged / 2; activeEnd -= merged;
+    }
+    return 0;
+}
+
+int32_t idkbvhRefitBlas(GpuBlasNode* nodes_, int32_t nodeCount, const float* positions, const GpuBlasTriangle* tris)
+{
+    if (!nodes_ || nodeCount < 4 || !positions || !tris) return 2;
+    HNode* nodes = reinterpret_cast<HNode*>(nodes_);
+    for (int i = nodeCount - 1; i >= 1; i--) {
+        HNode& p = nodes[i];
+        if (isLeaf(p)) {
+            SBox b = SBox::empty();
+            for (int k = 0; k < p.count; k++) { const GpuBlasTriangle& t = tris[p.startOrChild + k]; b.grow(load3(positions + 3 * (size_t)t.X)); b.grow(load3(positions + 3 * (size_t)t.Y)); b.grow(load3(positions + 3 * (size_t)t.Z)); }
+            setBounds(p, b);
+        } else { SBox m = nodeBox(nodes[p.startOrChild]); m.grow(nodeBox(nodes[p.startOrChild + 1])); setBounds(p, m); }
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -542,8 +542,25 @@ struct idkpt_ctx {
     idkpt_stats stats;
     uint32_t* hCounts = nullptr; // pinned
     hipEvent_t evFrame[2] = {nullptr, nullptr};
-    int lastQueueSide = 0; int lastQueueCountSlot = 0;
+    // trace-kernel timing (idkptEnableTiming): one event pair per trace launch, resolved lazily in idkptGetStats
+    std::vector<hipEvent_t> evPool; size_t evUsed = 0;
+    double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
+    int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false;
 };
+
+static hipEvent_t next_event(idkpt_ctx* ctx)
+{
+    if (ctx->evUsed == ctx->evPool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ctx->evPool.push_back(e); }
+    return ctx->evPool[ctx->evUsed++];
+}
+// folds all recorded (start, stop) pairs into the accumulators; requires the stream to be idle
+static void resolve_trace_events(idkpt_ctx* ctx)
+{
+    for (size_t i = 0; i + 1 < ctx->evUsed; i += 2) { float ms = 0.0f; if (hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]) == hipSuccess) { ctx->traceMsAcc += ms; ctx->traceLaunchesAcc++; } }
+    ctx->evUsed = 0;
+}
+#define TRACE_T0() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
+#define TRACE_T1() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
 
 static int fail(idkpt_ctx* c, int code, const std::string& msg) { if (c) c->lastError = msg; return code; }
 #define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(ctx, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
@@ -624,6 +641,7 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     if (ctx->hCounts) (void)hipHostFree(ctx->hCounts);
     if (ctx->evFrame[0]) (void)hipEventDestroy(ctx->evFrame[0]);
     if (ctx->evFrame[1]) (void)hipEventDestroy(ctx->evFrame[1]);
+    for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
     if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return IDKPT_OK;
@@ -945,12 +963,16 @@ static int render_sample(idkpt_ctx* ctx)
             const uint32_t genWaves = tilesX * tilesY;
             const int cull = f.g.DoTraceLights ? 0 : 1;
             hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 3) / 4), dim3(256), 0, st, s, f, rays, hits, N, cull, activeList, activeCount);
+            TRACE_T0();
             if (ctx->counters) hipLaunchKernelGGL((k_trace2<true, true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             else hipLaunchKernelGGL((k_trace2<true, false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
+            TRACE_T1();
         } else {
+        TRACE_T0();
         uint32_t g = std::min<uint32_t>(traceGrid, (N + 63) / 64);
         if (ctx->counters) { if (debug) hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<true, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
         else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
+        TRACE_T1();
         }
         if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.p, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
         hipLaunchKernelGGL((k_shade<true>), dim3(gridN), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, N, 0u,
@@ -976,6 +998,7 @@ static int render_sample(idkpt_ctx* ctx)
             // after 3 passes the sorted data sits in (sortKeys, sortVals): copy back into the queue side (A*4 B each; the reference copies W*H*4, PathTracer.cs:296)
             HIPC(hipMemcpyAsync(q, va, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
         }
+        TRACE_T0();
         if (fast) {
             if (ctx->counters) hipLaunchKernelGGL((k_trace2<false, true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace2<false, false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
@@ -983,6 +1006,7 @@ static int render_sample(idkpt_ctx* ctx)
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
         }
+        TRACE_T1();
         hipLaunchKernelGGL((k_shade<false>), dim3(gridN), dim3(256), 0, st, s, f, rays, hits, q, cnt, 0u, ctx->slotBases[j],
                            ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(), ctx->keysTmp.as<uint32_t>());
         hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, cnt, 0u, ctx->waveCounts.as<uint32_t>(), counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr));
@@ -990,7 +1014,7 @@ static int render_sample(idkpt_ctx* ctx)
                            ctx->keysTmp.as<uint32_t>(), ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
         side = 1 - side;
     }
-    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth;
+    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast;
     hipLaunchKernelGGL(k_final_draw, dim3(gridN), dim3(256), 0, st, f, rays, image_ptr(ctx, 0), image_ptr(ctx, 1), image_ptr(ctx, 2), N);
     HIPC(hipGetLastError());
     // queue lengths stay on the GPU during the frame; a copy goes to pinned memory for GetStats (no sync here)
@@ -1008,6 +1032,7 @@ int32_t idkptRender(idkpt_ctx* ctx)
     if (ctx->W <= 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: idkptSetSize not called");
     if (ctx->st.UseTlas && ctx->tlasCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: UseTlas set but no TLAS nodes uploaded");
     HIPC(hipSetDevice(ctx->device));
+    if (ctx->timing && ctx->evUsed > 4096) { HIPC(hipStreamSynchronize(ctx->stream)); resolve_trace_events(ctx); }
     if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[0], ctx->stream));
     for (int i = 0; i < ctx->st.SamplesPerPixel; i++) {
         int rc = render_sample(ctx); if (rc) return rc;
@@ -1085,8 +1110,13 @@ int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* out)
     HIPC(hipStreamSynchronize(ctx->stream));
     idkpt_stats s = ctx->stats;
     for (int j = 0; j < 16; j++) s.LastAliveCounts[j] = (j >= 1 && j < ctx->st.RayDepth) ? ctx->hCounts[j] : 0;
+    // [0]: primary rays that entered the traversal kernel (all pixels, or the survivors of the root-box pre-cull on the fast path)
+    s.LastAliveCounts[0] = s.Frames ? (ctx->lastFast ? ctx->hCounts[MAX_DEPTH_SLOTS - 1] : (uint32_t)((size_t)ctx->W * ctx->rows)) : 0;
     s.LastFrameMs = 0.0f; s.LastTraceMs = 0.0f;
     if (ctx->timing && s.Frames > 0) { float ms = 0.0f; if (hipEventElapsedTime(&ms, ctx->evFrame[0], ctx->evFrame[1]) == hipSuccess) s.LastFrameMs = ms; }
+    resolve_trace_events(ctx);
+    s.TraceMsTotal = ctx->traceMsAcc; s.TraceLaunches = ctx->traceLaunchesAcc;
+    s.LastTraceMs = s.TraceLaunches ? (float)(s.TraceMsTotal / (double)s.TraceLaunches) : 0.0f;
     uint64_t c[4] = {0, 0, 0, 0};
     HIPC(hipMemcpy(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost));
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
@@ -1101,6 +1131,7 @@ int32_t idkptResetStats(idkpt_ctx* ctx)
     HIPC(hipSetDevice(ctx->device));
     HIPC(hipStreamSynchronize(ctx->stream));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
+    ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;
     memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4);
     HIPC(hipMemset(ctx->counters64.p, 0, 32));
     return IDKPT_OK;

@@ -94,7 +94,8 @@ class SceneDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("RaysTraced", C.c_uint64), ("PrimaryRays", C.c_uint64), ("Frames", C.c_uint64),
                 ("LastAliveCounts", C.c_uint32 * 16), ("LastTraceMs", C.c_float), ("LastFrameMs", C.c_float),
-                ("NodePairVisits", C.c_uint64), ("TriangleTests", C.c_uint64)]
+                ("NodePairVisits", C.c_uint64), ("TriangleTests", C.c_uint64),
+                ("TraceMsTotal", C.c_double), ("TraceLaunches", C.c_uint64)]
 
 
 def _ptr(a):

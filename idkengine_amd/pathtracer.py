@@ -205,7 +205,8 @@ class PathTracer:
         s = T.Stats()
         self._check(self._L.idkptGetStats(self._ctx, C.addressof(s)))
         return {"rays_traced": s.RaysTraced, "primary_rays": s.PrimaryRays, "frames": s.Frames, "alive_counts": list(s.LastAliveCounts),
-                "last_frame_ms": s.LastFrameMs, "node_pair_visits": s.NodePairVisits, "triangle_tests": s.TriangleTests}
+                "last_frame_ms": s.LastFrameMs, "node_pair_visits": s.NodePairVisits, "triangle_tests": s.TriangleTests,
+                "trace_ms_total": s.TraceMsTotal, "trace_launches": s.TraceLaunches}
 
     def reset_stats(self):
         self._check(self._L.idkptResetStats(self._ctx))

@@ -306,3 +306,16 @@ def cornell_scene(builder, variant="diffuse", instanced=False, sky_color=(0.0, 0
 
 def cornell_camera(width, height):
     return Camera(width, height, position=(0.0, 0.0, 3.4), fovy_deg=40.0)
+
+
+def presplit_scene(builder, n_small=5000, seed=3, refittable=False):
+    """Small soup + three scene-spanning triangles: the size contrast makes PreSplitting (Bvh/PreSplitting.cs) split the
+    big ones, so fragment count > triangle count and leaves share straddling triangles."""
+    tp = soup_triangles(n_small, seed=seed, extent=2.0, edge=0.1)
+    big = np.float32([[[-3, -3, -2.5], [3, -3, -2.4], [0, 3, 2.6]], [[-3, 0.1, -3], [3, 0.2, 3], [-3, 0.3, 3]], [[-2.5, -2.5, 2.0], [2.5, -2.0, -2.0], [2.0, 2.5, 0.0]]])
+    p, i, nrm, tan = flat_shaded(np.concatenate([tp, big]))
+    return assemble([{"meshes": [MeshInput(p, i, make_material((0.7, 0.6, 0.5, 1.0)), nrm, tan)], "refittable": refittable}], builder, sky_color=(0.9, 0.95, 1.0))
+
+
+def presplit_camera(width, height):
+    return Camera(width, height, position=(0.5, 0.8, 6.0), fovy_deg=60.0)

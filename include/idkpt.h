@@ -96,11 +96,13 @@ typedef struct idkpt_stats {
     uint64_t RaysTraced;        /* N + sum_j A_j over all frames since the last idkptResetStats */
     uint64_t PrimaryRays;
     uint64_t Frames;            /* samples rendered */
-    uint32_t LastAliveCounts[16]; /* alive-queue length entering bounce j of the last sample (j=1..15) */
-    float    LastTraceMs;       /* HIP-event time of all trace kernels of the last idkptRender (0 if timing disabled) */
+    uint32_t LastAliveCounts[16]; /* [j>=1]: alive-queue length entering bounce j of the last sample; [0]: primary rays that reached the traversal kernel */
+    float    LastTraceMs;       /* mean HIP-event duration of one traversal-kernel launch since idkptResetStats (0 if timing disabled) */
     float    LastFrameMs;       /* HIP-event time of the last idkptRender */
     uint64_t NodePairVisits;    /* only when counters enabled (idkptEnableCounters) */
     uint64_t TriangleTests;
+    double   TraceMsTotal;      /* sum of HIP-event durations of all traversal-kernel launches since idkptResetStats (timing enabled) */
+    uint64_t TraceLaunches;     /* number of traversal-kernel launches in TraceMsTotal */
 } idkpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -175,7 +177,7 @@ IDKPT_API int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* outStats);
 IDKPT_API int32_t idkptResetStats(idkpt_ctx* ctx);
 /* enable=1: trace kernels also count node-pair visits / triangle tests (debugCost terms of BVHIntersect.glsl:45,60) */
 IDKPT_API int32_t idkptEnableCounters(idkpt_ctx* ctx, int32_t enable);
-/* enable=1: record HIP events around each idkptRender and around the trace kernels (LastFrameMs / LastTraceMs) */
+/* enable=1: record HIP events (on the context's stream) around each idkptRender and around every traversal-kernel launch */
 IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
 
 /* ---- interop (device pointers as void*, for RCCL gather of row shards by the host process) -- */

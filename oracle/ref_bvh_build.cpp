@@ -370,7 +370,12 @@ static int Build(Blas& blas, BuildData& bd, const BuildSettings& s) // :159-195
 }
 static void GetUnindexedTriangles(Blas& blas, const BuildData& bd, const Geometry& g) // BLAS.cs:441-466
 {
-    blas.triangles.assign(bd.Bounds.size(), GpuBlasTriangle{});
+    // The reference sizes this array by the fragment count and throws for a single-leaf root, whose leaf is duplicated
+    // into nodes 2 and 3 (BLAS.cs:173-183 "TODO ... causes a crash in GetUnindexedTriangles").  Defined behaviour here:
+    // size by the sum of leaf counts, i.e. the duplicated leaf's triangles are stored twice.
+    size_t total = 0;
+    for (size_t i = 2; i < blas.nodes.size(); i++) if (blas.nodes[i].IsLeaf()) total += blas.nodes[i].TriCount;
+    blas.triangles.assign(std::max(total, bd.Bounds.size()), GpuBlasTriangle{});
     int triCounter = 0;
     for (size_t i = 2; i < blas.nodes.size(); i++) {
         Node& n = blas.nodes[i];
@@ -379,6 +384,7 @@ static void GetUnindexedTriangles(Blas& blas, const BuildData& bd, const Geometr
             n.TriStartOrChild = triCounter; triCounter += n.TriCount;
         }
     }
+    blas.triangles.resize(triCounter);
 }
 static std::vector<int> GetUniqueTriIds(const Node& leaf, const BuildData& bd) // PreSplitting.cs:251-272
 {

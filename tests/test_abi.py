@@ -1,0 +1,74 @@
+"""The drop-in boundary: libidkpt.so / libidkbvh.so load, export every symbol include/*.h declares, the struct
+layouts compile under a plain C compiler, and (without a GPU) the library refuses loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix, macro):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    return sorted(set(re.findall(macro + r"\s+[\w\s\*]+?\b(" + prefix + r"\w+)\s*\(", src)))
+
+
+def test_idkpt_exports_every_declared_symbol():
+    from idkengine_amd import _lib
+    declared = _declared("idkpt.h", "idkpt", "IDKPT_API")
+    assert len(declared) >= 30
+    assert sorted(_lib.SYMBOLS) == declared                      # the Python binding covers the whole ABI
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = sorted(set(re.findall(r" T (idkpt\w+)", out)))
+    assert exported == declared                                  # nothing undeclared leaks out either
+
+
+def test_idkbvh_exports_every_declared_symbol():
+    from idkengine_amd import bvh
+    declared = _declared("idkbvh.h", "idkbvh", "IDKBVH_API")
+    assert sorted(bvh.SYMBOLS) == declared
+    out = subprocess.check_output(["nm", "-D", "--defined-only", bvh.LIB_PATH]).decode()
+    assert sorted(set(re.findall(r" T (idkbvh\w+)", out))) == declared
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h must be consumable by a C compiler (P/Invoke / cgo / JNI generators read C): all the byte-layout
+    static asserts (sizes cited from Source/GpuTypes/*.cs) are checked by gcc here."""
+    c = tmp_path / "t.c"
+    c.write_text('#include "idkpt.h"\n#include "idkbvh.h"\nint main(void){return (int)sizeof(idkpt_scene_desc) > 0 ? 0 : 1;}\n')
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(c)])
+
+
+def test_numpy_mirrors_match_c_layout(tmp_path):
+    from idkengine_amd import gputypes as T
+    names = ["GpuBlasNode", "GpuBlasTriangle", "GpuBlasDesc", "GpuBlasInstance", "GpuTlasNode", "GpuMeshTransform", "GpuMesh", "GpuMaterial", "GpuVertex",
+             "GpuLight", "GpuWavefrontRay", "GpuUnskinnedVertex", "GpuSettings", "idkpt_settings", "idkpt_scene_desc", "idkpt_stats", "idkpt_texture"]
+    c = tmp_path / "s.c"
+    c.write_text('#include <stdio.h>\n#include "idkpt.h"\nint main(void){' + "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "s"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+    py = [getattr(T, n).itemsize for n in names[:12]] + [C.sizeof(T.GpuSettings), C.sizeof(T.Settings), C.sizeof(T.SceneDesc), C.sizeof(T.Stats), C.sizeof(T.Texture)]
+    assert sizes == py
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Host logic without a GPU: argument validation works, and creating a context reports NO_DEVICE (status 5)."""
+    from idkengine_amd import _lib
+    L = _lib.load()
+    assert L.idkptGetVersionString().startswith(b"idkpt")
+    n = C.c_int32(-1)
+    L.idkptGetDeviceCount(C.byref(n))
+    ctx = C.c_void_p()
+    assert L.idkptCreate(2, None, C.byref(ctx)) == 2            # only one device per context (one process per GPU)
+    assert L.idkptCreate(1, None, None) == 2
+    if n.value <= 0:
+        assert L.idkptCreate(1, None, C.byref(ctx)) == 5 and not ctx.value
+        from idkengine_amd.pathtracer import PathTracer, IdkPtError
+        with pytest.raises(IdkPtError):
+            PathTracer(64, 64)
+    assert L.idkptRender(None) == 2 and L.idkptDestroy(None) == 2

@@ -1,0 +1,161 @@
+"""Known-answer / property tests that pin the oracle's third-party building blocks (the reference ships no tests, so
+these published algorithms are the only external anchors; see oracle/ref_math.h "PARITY UNPINNED")."""
+import ctypes as C
+import math
+import numpy as np
+
+
+def _f3(*v):
+    return np.asarray(v, np.float32)
+
+
+def test_pcg_hash_matches_published_algorithm(oracle_mod):
+    """Random.glsl:20-27 cites reedbeta's pcg_hash; compare with an independent arbitrary-precision restatement."""
+    L = oracle_mod.lib()
+
+    def pcg(seed):
+        state = (seed * 747796405 + 2891336453) & 0xFFFFFFFF
+        word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+        return state, (word >> 22) ^ word
+    for s0 in (0, 1, 4096, 0xFFFFFFFF, 123456789):
+        s = C.c_uint32(s0); py = s0
+        for _ in range(8):
+            got = L.ref_pcg_hash(C.byref(s))
+            py, want = pcg(py)
+            assert got == want and s.value == py
+    # the well-known first output of pcg_hash(0)
+    s = C.c_uint32(0)
+    assert L.ref_pcg_hash(C.byref(s)) == 129708002
+
+
+def test_float_to_key_is_order_preserving(oracle_mod):
+    L = oracle_mod.lib()
+    vals = np.float32([-np.inf, -3.5e38, -1.0, -1e-30, -0.0, 0.0, 1e-45, 1e-30, 0.5, 1.0, 3.4e38, np.inf])
+    keys = [L.ref_float_to_key(float(v)) for v in vals]
+    assert keys == sorted(keys)
+    assert L.ref_float_to_key(0.0) == 0x80000000 and L.ref_float_to_key(-0.0) == 0x7FFFFFFF
+
+
+def test_morton30_examples(oracle_mod):
+    L = oracle_mod.lib()
+    assert L.ref_morton30(0.0, 0.0, 0.0) == 0
+    assert L.ref_morton30(1.0, 1.0, 1.0) == (1 << 30) - 1          # clamped to 1023 on every axis
+    assert L.ref_morton30(1.0 / 1024, 0.0, 0.0) == 0b100            # x bit lands at position 2
+    assert L.ref_morton30(0.0, 1.0 / 1024, 0.0) == 0b010
+    assert L.ref_morton30(0.0, 0.0, 1.0 / 1024) == 0b001
+
+
+def test_half_area_is_fused(oracle_mod):
+    L = oracle_mod.lib()
+    x, y, z = np.float32(1.0000001), np.float32(3.0000002), np.float32(7.0000005)
+    want = np.float32(math.fma(float(np.float32(x + y)), float(z), float(np.float32(x * y)))) if hasattr(math, "fma") else None
+    got = L.ref_half_area(float(x), float(y), float(z))
+    exact = (float(np.float32(x + y)) * float(z)) + float(np.float32(x * y))   # float64 holds this exactly enough to round once
+    assert np.float32(exact) == np.float32(got)
+    if want is not None:
+        assert want == np.float32(got)
+
+
+def test_oct_encode_decode_roundtrip(oracle_mod):
+    L = oracle_mod.lib()
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(2000, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v = np.concatenate([v, np.eye(3), -np.eye(3)]).astype(np.float32)
+    for n in v:
+        e = np.zeros(2, np.float32); d = np.zeros(3, np.float32)
+        n = np.ascontiguousarray(n)
+        L.ref_encode_unit_vec(n.ctypes.data, e.ctypes.data)
+        assert (e >= 0).all() and (e <= 1).all()
+        L.ref_decode_unit_vec(e.ctypes.data, d.ctypes.data)
+        assert abs(np.linalg.norm(d) - 1.0) < 1e-6
+        assert np.abs(d - n).max() < 2e-6
+
+
+def test_sr11g11b10_pack_roundtrip_and_python_packer(oracle_mod):
+    from idkengine_amd.scenes import compress_sr11g11b10
+    L = oracle_mod.lib()
+    rng = np.random.default_rng(1)
+    v = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
+    for n in v:
+        n = np.ascontiguousarray(n)
+        p = L.ref_compress_sr11g11b10(n.ctypes.data)
+        assert p == int(compress_sr11g11b10(n))          # host packer (Utils/Compression.cs) == GLSL packer
+        d = np.zeros(3, np.float32)
+        L.ref_decompress_sr11g11b10(p, d.ctypes.data)
+        assert np.abs(d[:2] - n[:2]).max() <= 1.0 / 2047 + 1e-6 and abs(d[2] - n[2]) <= 1.0 / 1023 + 1e-6
+
+
+def test_sincos_exp_accuracy(oracle_mod):
+    L = oracle_mod.lib()
+    xs = np.linspace(0.0, 2.0 * 3.14159265, 4001).astype(np.float32)
+    worst = 0.0
+    for x in xs:
+        s = C.c_float(); c = C.c_float()
+        L.ref_sincos(float(x), C.byref(s), C.byref(c))
+        worst = max(worst, abs(s.value - math.sin(float(x))), abs(c.value - math.cos(float(x))))
+    assert worst < 3e-7
+    for x in np.linspace(-87.0, 0.0, 2001).astype(np.float32):
+        got = L.ref_exp(float(x)); want = math.exp(float(x))
+        assert abs(got - want) <= 3e-7 * want + 1e-44
+    assert L.ref_exp(-100.0) == 0.0 and L.ref_exp(0.0) == 1.0
+
+
+def test_turbo_colormap_endpoints(oracle_mod):
+    L = oracle_mod.lib()
+    out = np.zeros(3, np.float32)
+    L.ref_turbo(0.0, out.ctypes.data)          # Google's published polynomial at x=0 is its constant term
+    assert np.allclose(out, [0.13572138, 0.09140261, 0.10667330], atol=1e-7)
+    L.ref_turbo(0.5, out.ctypes.data)          # mid-range turbo is green-ish
+    assert out[1] > out[0] and out[1] > out[2]
+    lo = out.copy(); L.ref_turbo(-3.0, lo.ctypes.data); z = out.copy(); L.ref_turbo(0.0, z.ctypes.data)
+    assert (lo == z).all()                     # clamp
+
+
+def test_r2_sequence_is_low_discrepancy(oracle_mod):
+    L = oracle_mod.lib()
+    pts = np.zeros((256, 2), np.float32)
+    for i in range(256):
+        L.ref_r2_sequence(i, pts[i].ctypes.data)
+    assert (pts >= 0).all() and (pts < 1).all()
+    hist, _, _ = np.histogram2d(pts[:, 0], pts[:, 1], bins=4, range=[[0, 1], [0, 1]])
+    assert hist.min() >= 10 and hist.max() <= 22   # 16 expected per cell
+
+
+def test_first_hit_gid_is_a_bijection(oracle_mod):
+    """Inverse of ReorderInvocations(20) (FirstHit/compute.glsl:236-262) must hit every invocation id exactly once."""
+    L = oracle_mod.lib()
+    for (w, h) in ((256, 256), (1920 // 8, 1080 // 8 * 1), (168, 72)):
+        seen = set()
+        gx = C.c_uint32(); gy = C.c_uint32()
+        for y in range(0, h):
+            for x in range(0, w):
+                L.ref_first_hit_gid(w, h, x, y, C.byref(gx), C.byref(gy))
+                seen.add((gx.value, gy.value))
+        assert len(seen) == w * h
+        assert max(g[0] for g in seen) < ((w + 7) // 8) * 8 and max(g[1] for g in seen) < ((h + 7) // 8) * 8
+
+
+def test_ray_triangle_and_box_cases(oracle_mod):
+    L = oracle_mod.lib()
+    bary = np.zeros(3, np.float32); t = C.c_float()
+    p0, p1, p2 = _f3(0, 0, 0), _f3(1, 0, 0), _f3(0, 1, 0)
+    o, d = _f3(0.25, 0.25, 1), _f3(0, 0, -1)
+    assert L.ref_ray_triangle(o.ctypes.data, d.ctypes.data, p0.ctypes.data, p1.ctypes.data, p2.ctypes.data, bary.ctypes.data, C.byref(t)) == 1
+    assert abs(t.value - 1.0) < 1e-7 and np.allclose(bary, [0.5, 0.25, 0.25])
+    o2 = _f3(2, 2, 1)
+    assert L.ref_ray_triangle(o2.ctypes.data, d.ctypes.data, p0.ctypes.data, p1.ctypes.data, p2.ctypes.data, bary.ctypes.data, C.byref(t)) == 0
+    o3 = _f3(0.25, 0.25, -1)   # behind the origin: t < 0
+    assert L.ref_ray_triangle(o3.ctypes.data, d.ctypes.data, p0.ctypes.data, p1.ctypes.data, p2.ctypes.data, bary.ctypes.data, C.byref(t)) == 0
+    bmin, bmax = _f3(-1, -1, -1), _f3(1, 1, 1); t1 = C.c_float()
+    dz = _f3(0, 0, -1)
+
+    def box(origin):
+        o_ = _f3(*origin)   # keep the array alive across the call
+        return L.ref_ray_box(o_.ctypes.data, dz.ctypes.data, bmin.ctypes.data, bmax.ctypes.data, C.byref(t1))
+    assert box((0, 0, 5)) == 1 and abs(t1.value - 4.0) < 1e-6
+    assert box((0, 0, 0)) == 1 and t1.value == 0.0   # origin inside
+    assert box((0, 5, 5)) == 0
+    # axis-parallel ray: (min-o)*inf / (max-o)*inf give -inf / +inf and the slab is ignored
+    assert box((0.5, 0, 5)) == 1
+    # axis-parallel ray exactly on a slab plane: 0*inf = NaN is dropped by minNum/maxNum, leaving (-inf, -inf) -> defined miss
+    assert box((1, 0, 5)) == 0
