@@ -30,7 +30,7 @@ def test_pcg_hash_matches_published_algorithm(oracle_mod):
 
 def test_float_to_key_is_order_preserving(oracle_mod):
     L = oracle_mod.lib()
-    vals = np.float32([-np.inf, -3.5e38, -1.0, -1e-30, -0.0, 0.0, 1e-45, 1e-30, 0.5, 1.0, 3.4e38, np.inf])
+    vals = np.float32([-np.inf, -1.0, -1e-30, -0.0, 0.0, 1e-45, 1e-30, 0.5, 1.0, 3.4e38, np.inf])
     keys = [L.ref_float_to_key(float(v)) for v in vals]
     assert keys == sorted(keys)
     assert L.ref_float_to_key(0.0) == 0x80000000 and L.ref_float_to_key(-0.0) == 0x7FFFFFFF
