@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tris", type=int, default=N_TRIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=4, help="samples the library may defer and trace together (idkptSetMaxBatch; results are bit-identical)")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,10 +70,13 @@ def main():
     pt.RayDepth = RAY_DEPTH; pt.SamplesPerPixel = 1; pt.DoRaySorting = 0
     frame = D.ShardedFrame(r, W, H) if world > 1 else None
 
+    step_no = [0]
+
     def step():
-        r.render()
-        if frame is not None:
-            frame.gather()
+        r.render()                                   # ResetAccumulation + Compute: one complete 1-spp frame (deferred by the library)
+        step_no[0] += 1
+        if frame is not None and step_no[0] % args.batch == 0:
+            frame.gather()                           # the frame's exchange: all-gather of the accumulated row shards, once per batch
 
     # ---- untimed counter pass: exact P (node-pair visits) and T (triangle tests) of one frame of this rank's rows
     pt.enable_counters(True); pt.reset_stats()
@@ -82,15 +86,19 @@ def main():
     traversed = cs["alive_counts"][0] + sum(cs["alive_counts"][1:RAY_DEPTH])   # rays that entered the traversal kernel
     pt.enable_counters(False)
 
+    pt.set_max_batch(args.batch)
+    step_no[0] = 0
     for _ in range(args.warmup):
         step()
     pt.synchronize(); pt.reset_stats(); pt.enable_timing(True)
+    step_no[0] = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    pt.synchronize()                                 # launches whatever is still deferred and waits for it
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -126,7 +134,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {RAY_DEPTH}, sort off, white sky",
-                       "rays_per_step": int(rays_total / args.steps), "sharding": "rows round-robin over ranks + all-gather" if world > 1 else "none",
+                       "rays_per_step": int(rays_total / args.steps), "samples_in_flight": args.batch, "sharding": "rows round-robin over ranks + all-gather" if world > 1 else "none",
                        "bvh_build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -15,7 +15,7 @@ SYMBOLS = [
     "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptRender", "idkptSynchronize", "idkptDownload",
     "idkptDownloadRays", "idkptDownloadAliveQueue", "idkptEnablePrimaryHitCapture", "idkptDownloadPrimaryHits",
     "idkptGetStats", "idkptResetStats", "idkptEnableCounters", "idkptEnableTiming", "idkptGetImageDevicePtr",
-    "idkptSetStream", "idkptGetStream",
+    "idkptSetStream", "idkptGetStream", "idkptSetMaxBatch", "idkptFlush",
 ]
 
 _lib = None
@@ -47,7 +47,7 @@ def load():
         "idkptDownloadAliveQueue": [vp, vp, sz, C.POINTER(u32)], "idkptEnablePrimaryHitCapture": [vp, i32],
         "idkptDownloadPrimaryHits": [vp, vp, vp, vp, sz], "idkptGetStats": [vp, vp], "idkptResetStats": [vp],
         "idkptEnableCounters": [vp, i32], "idkptEnableTiming": [vp, i32], "idkptGetImageDevicePtr": [vp, i32, C.POINTER(vp), C.POINTER(sz)],
-        "idkptSetStream": [vp, vp], "idkptGetStream": [vp, C.POINTER(vp)],
+        "idkptSetStream": [vp, vp], "idkptGetStream": [vp, C.POINTER(vp)], "idkptSetMaxBatch": [vp, i32], "idkptFlush": [vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

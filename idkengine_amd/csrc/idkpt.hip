@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WAVE) void k_trace_primary(DScene s, Frame f, RayBu
         uint32_t pix = base + lane;
         if (pix < N) {
             f3 origin; f2 pd; uint32_t seed;
-            gen_primary(f, pix, origin, pd, seed);
+            gen_primary(f, pix, f.accumulated, origin, pd, seed);
             rays.o_ior[pix] = make_float4(origin.x, origin.y, origin.z, 1.0f);
             rays.thr_px[pix] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
             rays.rad_py[pix] = make_float4(0.0f, 0.0f, 0.0f, pd.y);
@@ -95,21 +95,23 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 // and pre-culls rays whose root-box test (BVHIntersect.glsl:32-39 with T = FLOAT_MAX) fails: those get their miss
 // record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
 // wave) to an unordered active list; results are stored per pixel, so the list order is free.
-__global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs rays, HitBufs hits, uint32_t N, int cull, uint32_t* activeList, uint32_t* activeCount)
+__global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs rays, HitBufs hits, int cull, uint32_t* activeList, uint32_t* activeCount)
 {
+    const uint32_t smp = blockIdx.y;                                   // sample of the batch
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
     const uint32_t tx = wave % tilesX, ty = wave / tilesX;
     const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     const bool valid = x < (uint32_t)f.W && y < (uint32_t)f.rows;
     const uint32_t pix = y * (uint32_t)f.W + x;
+    const uint32_t rid = smp * f.Npad + pix;                           // ray id inside the batch
     bool keep = false;
     if (valid) {
         f3 origin; f2 pd; uint32_t seed;
-        gen_primary(f, pix, origin, pd, seed);
-        rays.o_ior[pix] = make_float4(origin.x, origin.y, origin.z, 1.0f);
-        rays.thr_px[pix] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
-        rays.rad_py[pix] = make_float4(0.0f, 0.0f, 0.0f, pd.y);
+        gen_primary(f, pix, f.accum[smp], origin, pd, seed);
+        rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+        rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
+        rays.rad_py[rid] = make_float4(0.0f, 0.0f, 0.0f, pd.y);
         keep = true;
         if (cull) {
             GpuBlasInstance inst = s.instances[0];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs 
             const float4* root = s.nodes + 2 * (size_t)nodeOffset + 2;
             float t1;
             keep = RayBoxIntersect(lo, invDir, root[0], root[1], &t1) && t1 < PT_FLOAT_MAX;
-            if (!keep) { hits.hit[pix] = make_float4(PT_FLOAT_MAX, 0.0f, 0.0f, __uint_as_float(~0u)); hits.xformId[pix] = 0; }
+            if (!keep) { hits.hit[rid] = make_float4(PT_FLOAT_MAX, 0.0f, 0.0f, __uint_as_float(~0u)); hits.xformId[rid] = 0; }
         }
     }
     unsigned long long m = __ballot(keep);
@@ -129,9 +131,8 @@ __global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs 
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(activeCount, (uint32_t)__popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (keep) activeList[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pix;
+        if (keep) activeList[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rid;
     }
-    (void)N;
 }
 
 // k_trace2: persistent waves; every lane owns one ray at a time and is refilled from the work list as soon as enough
@@ -254,15 +255,24 @@ __global__ __launch_bounds__(WAVE) void k_trace2(DScene s, Frame f, RayBufs rays
 // wave are published as one 64-bit ballot + popcount for the ordered compaction that follows.
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm,
-                                               uint32_t slotBase, unsigned long long* contMask, uint32_t* waveCounts, uint32_t* keysTmp)
+                                               const uint32_t* qbase, uint32_t slotBase, unsigned long long* contMask, uint32_t* waveCounts, uint32_t* keysTmp)
 {
+    // FIRST: slots are ray ids (sample-major, Npad per sample, Npad % 64 == 0).  Otherwise slots are positions of the
+    // batch-wide alive queue, which is grouped by sample; qbase[k] = first slot of sample k.
     const uint32_t N = FIRST ? countImm : *countPtr;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if ((slot & ~63u) >= N) return; // whole wave out of range
     bool cont = false;
     uint32_t key = 0;
-    if (slot < N) {
-        const uint32_t idx = FIRST ? slot : queue[slot];
+    bool inRange = slot < N;
+    uint32_t smp = 0, pix = 0, idx = 0;
+    if (inRange) {
+        idx = FIRST ? slot : queue[slot];
+        smp = idx / f.Npad; pix = idx - smp * f.Npad;
+        if (FIRST && pix >= (uint32_t)f.W * (uint32_t)f.rows) inRange = false; // padding of the sample segment
+    }
+    if (inRange) {
+        const uint32_t acc = f.accum[smp];
         float4 a = rays.o_ior[idx], b = rays.thr_px[idx], c = rays.rad_py[idx];
         float4 h = hits.hit[slot];
         HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[slot];
@@ -274,30 +284,32 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
             if (!FIRST && f.outputAovs) { float4 aa = rays.aovA[idx], an = rays.aovN[idx]; aov.albedo = mk3(aa.x, aa.y, aa.z); aov.newWeight = aa.w; aov.normal = mk3(an.x, an.y, an.z); }
             uint32_t rng, gidSeed;
             if (FIRST) {
-                f3 o2; f2 pd2; gen_primary(f, idx, o2, pd2, rng); // re-derives the RNG state after ray generation (cheaper than 4 B/pixel of HBM)
-                int lx = (int)(idx % (uint32_t)f.W), ly = (int)(idx / (uint32_t)f.W);
+                f3 o2; f2 pd2; gen_primary(f, pix, acc, o2, pd2, rng); // re-derives the RNG state after ray generation (cheaper than 4 B/pixel of HBM)
+                int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
                 gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
             } else {
-                uint32_t gslot = slotBase + slot;
-                rng = gslot * 4096u + f.accumulated; // NHit:54
+                uint32_t gslot = slotBase + (slot - qbase[smp]);  // slot inside this sample's own queue
+                rng = gslot * 4096u + acc;            // NHit:54
                 gidSeed = gslot;                      // Shading.glsl:74 with gl_GlobalInvocationID = (slot, 0)
             }
             f3 rd = DecodeUnitVec(r.pdx, r.pdy);
             bool hitScene = hit.T != PT_FLOAT_MAX;
-            cont = ShadeHit<FIRST>(s, f, hit, hitScene, rd, r, aov, rng, gidSeed, key);
+            cont = ShadeHit<FIRST>(s, f, acc, hit, hitScene, rd, r, aov, rng, gidSeed, key);
             rays.o_ior[idx] = make_float4(r.origin.x, r.origin.y, r.origin.z, r.prevIor);
             rays.thr_px[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
             rays.rad_py[idx] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
             if (f.outputAovs) { rays.aovA[idx] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[idx] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
         }
-        keysTmp[slot] = key & ((1u << IDKPT_SORT_KEY_BITS) - 1u); // NHit:81
+        // NHit:81 masks the key to 21 bits; the sample index goes above it so that the batch-wide sort stays grouped by sample
+        keysTmp[slot] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
     }
     unsigned long long m = __ballot(cont);
     if ((threadIdx.x & 63) == 0) { uint32_t w = slot >> 6; contMask[w] = m; waveCounts[w] = (uint32_t)__popcll(m); }
 }
 
 // Ordered exclusive scan of the per-wave continue counts (single workgroup): reproduces the sequential enqueue order.
-__global__ __launch_bounds__(1024) void k_scan_waves(const uint32_t* countPtr, uint32_t countImm, uint32_t* waveCounts, uint32_t* nextCount, unsigned long long* tracedRays)
+__global__ __launch_bounds__(1024) void k_scan_waves(const uint32_t* countPtr, uint32_t countImm, uint32_t* waveCounts, uint32_t* nextCount, unsigned long long* tracedRays,
+                                                     const unsigned long long* contMask, const uint32_t* curBase /* null: FIRST (slots are ray ids) */, uint32_t Npad, int batch, uint32_t* nextBase)
 {
     __shared__ uint32_t part[1024];
     const uint32_t N = countPtr ? *countPtr : countImm;
@@ -318,6 +330,17 @@ __global__ __launch_bounds__(1024) void k_scan_waves(const uint32_t* countPtr, u
     uint32_t run = part[t] - sum;
     for (uint32_t i = b; i < e; i++) { uint32_t c = waveCounts[i]; waveCounts[i] = run; run += c; }
     if (t == 1023) { *nextCount = part[1023]; if (tracedRays) atomicAdd(tracedRays, (unsigned long long)part[1023]); }
+    __threadfence_block();
+    __syncthreads();
+    // first slot of every sample in the NEXT queue = number of survivors in front of the sample's first current slot
+    if (t <= (uint32_t)batch) {
+        uint32_t g = (t == (uint32_t)batch) ? N : (curBase ? curBase[t] : t * Npad);
+        g = min(g, N);
+        uint32_t w = g >> 6, l = g & 63;
+        uint32_t v = part[1023];
+        if (w < nW) v = waveCounts[w] + (uint32_t)__popcll(contMask[w] & ((1ull << l) - 1ull));
+        nextBase[t] = v;
+    }
 }
 
 // Scatter of the surviving ray indices (and their sort keys) to their ordered slots.
@@ -422,19 +445,20 @@ __global__ __launch_bounds__(256) void k_final_draw(Frame f, RayBufs rays, float
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    float w = 1.0f / ((float)f.accumulated + 1.0f);
-    float4 c = rays.rad_py[i];
-    f3 nr = mk3(c.x, c.y, c.z);
-    if (f.g.DoDebugBVHTraversal) nr = TurboColormap(rays.o_ior[i].w / 150.0f);
     float4 o = imgResult[i];
-    f3 r = gmix(mk3(o.x, o.y, o.z), nr, w);
-    imgResult[i] = make_float4(r.x, r.y, r.z, 1.0f);
-    if (f.outputAovs) {
-        float4 a = rays.aovA[i], n = rays.aovN[i];
-        float4 oa = imgAlbedo[i], on = imgNormal[i];
-        f3 ra = gmix(mk3(oa.x, oa.y, oa.z), mk3(a.x, a.y, a.z), w), rn = gmix(mk3(on.x, on.y, on.z), mk3(n.x, n.y, n.z), w);
-        imgAlbedo[i] = make_float4(ra.x, ra.y, ra.z, 1.0f); imgNormal[i] = make_float4(rn.x, rn.y, rn.z, 1.0f);
+    f3 r = mk3(o.x, o.y, o.z), ra = splat3(0.0f), rn = splat3(0.0f);
+    if (f.outputAovs) { float4 oa = imgAlbedo[i], on = imgNormal[i]; ra = mk3(oa.x, oa.y, oa.z); rn = mk3(on.x, on.y, on.z); }
+    for (int k = 0; k < f.batch; k++) {                 // samples are accumulated in submission order, exactly like consecutive FinalDraw dispatches
+        const size_t rid = (size_t)k * f.Npad + i;
+        float w = 1.0f / ((float)f.accum[k] + 1.0f);
+        float4 c = rays.rad_py[rid];
+        f3 nr = mk3(c.x, c.y, c.z);
+        if (f.g.DoDebugBVHTraversal) nr = TurboColormap(rays.o_ior[rid].w / 150.0f);
+        r = gmix(r, nr, w);
+        if (f.outputAovs) { float4 a = rays.aovA[rid], n = rays.aovN[rid]; ra = gmix(ra, mk3(a.x, a.y, a.z), w); rn = gmix(rn, mk3(n.x, n.y, n.z), w); }
     }
+    imgResult[i] = make_float4(r.x, r.y, r.z, 1.0f);
+    if (f.outputAovs) { imgAlbedo[i] = make_float4(ra.x, ra.y, ra.z, 1.0f); imgNormal[i] = make_float4(rn.x, rn.y, rn.z, 1.0f); }
 }
 
 // derived layout: positions of each BLAS triangle's vertices, in leaf order (48 B/triangle, one contiguous fetch in the leaf loop)
@@ -545,7 +569,8 @@ struct idkpt_ctx {
     // trace-kernel timing (idkptEnableTiming): one event pair per trace launch, resolved lazily in idkptGetStats
     std::vector<hipEvent_t> evPool; size_t evUsed = 0;
     double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
-    int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false;
+    int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false; int lastBatch = 1;
+    int maxBatch = 1; uint32_t Npad = 0; std::vector<uint32_t> pending; DevBuf bases; uint32_t* hBases = nullptr;
 };
 
 static hipEvent_t next_event(idkpt_ctx* ctx)
@@ -570,23 +595,41 @@ static int local_rows(int H, int mod, int rem) { int n = 0; for (int y = rem; y 
 
 static int alloc_frame(idkpt_ctx* ctx)
 {
-    size_t N = (size_t)ctx->W * ctx->rows;
-    HIPC(ctx->rayO.ensure(N * 16)); HIPC(ctx->rayT.ensure(N * 16)); HIPC(ctx->rayR.ensure(N * 16));
-    HIPC(ctx->aovA.ensure(N * 16)); HIPC(ctx->aovN.ensure(N * 16));
-    HIPC(ctx->hit.ensure(N * 16)); HIPC(ctx->hitX.ensure(N * 4)); HIPC(ctx->hitCost.ensure(N * 4));
-    for (int i = 0; i < 2; i++) { HIPC(ctx->queue[i].ensure(N * 4)); HIPC(ctx->keys[i].ensure(N * 4)); }
-    HIPC(ctx->keysTmp.ensure(N * 4)); HIPC(ctx->sortKeys.ensure(N * 4)); HIPC(ctx->sortVals.ensure(N * 4));
-    size_t nW = (N + 63) / 64;
+    const size_t N = (size_t)ctx->W * ctx->rows;
+    ctx->Npad = (uint32_t)((N + 63) / 64 * 64);
+    const size_t cap = (size_t)ctx->maxBatch * ctx->Npad;   // ray ids of one batch
+    ctx->pending.clear();
+    HIPC(ctx->rayO.ensure(cap * 16)); HIPC(ctx->rayT.ensure(cap * 16)); HIPC(ctx->rayR.ensure(cap * 16));
+    HIPC(ctx->aovA.ensure(cap * 16)); HIPC(ctx->aovN.ensure(cap * 16));
+    HIPC(ctx->hit.ensure(cap * 16)); HIPC(ctx->hitX.ensure(cap * 4)); HIPC(ctx->hitCost.ensure(cap * 4));
+    for (int i = 0; i < 2; i++) { HIPC(ctx->queue[i].ensure(cap * 4)); HIPC(ctx->keys[i].ensure(cap * 4)); }
+    HIPC(ctx->keysTmp.ensure(cap * 4)); HIPC(ctx->sortKeys.ensure(cap * 4)); HIPC(ctx->sortVals.ensure(cap * 4));
+    size_t nW = (cap + 63) / 64;
     HIPC(ctx->contMask.ensure(nW * 8)); HIPC(ctx->waveCounts.ensure(nW * 4));
     HIPC(ctx->counts.ensure(MAX_DEPTH_SLOTS * 4)); HIPC(ctx->work.ensure(4 * MAX_DEPTH_SLOTS * 4)); HIPC(ctx->counters64.ensure(32));
-    size_t nTiles = (N + SORT_TILE - 1) / SORT_TILE;
+    HIPC(ctx->bases.ensure((size_t)MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4));
+    size_t nTiles = (cap + SORT_TILE - 1) / SORT_TILE;
     HIPC(ctx->sortHist.ensure(SORT_RADIX * nTiles * 4));
     for (int i = 0; i < 3; i++) { HIPC(ctx->img[i].ensure(N * 16)); HIPC(hipMemsetAsync(ctx->img[i].p, 0, N * 16, ctx->stream)); }
     HIPC(hipMemsetAsync(ctx->counters64.p, 0, 32, ctx->stream));
-    HIPC(hipMemsetAsync(ctx->aovA.p, 0, N * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, N * 16, ctx->stream));
+    HIPC(hipMemsetAsync(ctx->aovA.p, 0, cap * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, cap * 16, ctx->stream));
     ctx->accumulated = 0;
     return IDKPT_OK;
 }
+
+// maxBatch changed: the wavefront buffers grow, the accumulation images (and their contents) stay
+static int alloc_frame_keep_images(idkpt_ctx* ctx)
+{
+    const size_t N = (size_t)ctx->W * ctx->rows;
+    DevBuf saved[3];
+    for (int i = 0; i < 3; i++) { saved[i] = ctx->img[i]; ctx->img[i] = DevBuf(); }
+    int rc = alloc_frame(ctx);
+    for (int i = 0; i < 3; i++) { if (rc == IDKPT_OK && saved[i].p) (void)hipMemcpy(ctx->img[i].p, saved[i].p, N * 16, hipMemcpyDeviceToDevice); saved[i].release(); }
+    return rc;
+}
+
+static int flush_batch(idkpt_ctx* ctx);
+#define FLUSH() do { int _rc = flush_batch(ctx); if (_rc) return _rc; } while (0)
 
 extern "C" {
 
@@ -621,6 +664,8 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
     memset(ctx->invProj, 0, 64); memset(ctx->invView, 0, 64); memset(ctx->viewPos, 0, 12);
     if (hipHostMalloc((void**)&ctx->hCounts, MAX_DEPTH_SLOTS * 4 + 16, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4 + 16);
+    if (hipHostMalloc((void**)&ctx->hBases, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
+    memset(ctx->hBases, 0, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4);
     (void)hipEventCreate(&ctx->evFrame[0]); (void)hipEventCreate(&ctx->evFrame[1]);
     if (const char* e = getenv("IDKPT_FORCE_GENERIC")) ctx->forceGeneric = atoi(e) != 0;
     *outCtx = ctx;
@@ -631,14 +676,16 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(ctx->device);
+    ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
                      &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
-                     &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
+                     &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
     for (auto& t : ctx->texData) t.release();
     if (ctx->hCounts) (void)hipHostFree(ctx->hCounts);
+    if (ctx->hBases) (void)hipHostFree(ctx->hBases);
     if (ctx->evFrame[0]) (void)hipEventDestroy(ctx->evFrame[0]);
     if (ctx->evFrame[1]) (void)hipEventDestroy(ctx->evFrame[1]);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
@@ -659,6 +706,7 @@ int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height)
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     ctx->W = width; ctx->H = height; ctx->rows = local_rows(height, ctx->rowMod, ctx->rowRem);
     return alloc_frame(ctx);
 }
@@ -667,6 +715,7 @@ int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemain
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(rowModulo >= 1 && rowRemainder >= 0 && rowRemainder < rowModulo, "idkptSetRowSharding: need 0 <= remainder < modulo");
+    FLUSH();
     ctx->rowMod = rowModulo; ctx->rowRem = rowRemainder;
     if (ctx->W > 0) { HIPC(hipSetDevice(ctx->device)); ctx->rows = local_rows(ctx->H, rowModulo, rowRemainder); return alloc_frame(ctx); }
     return IDKPT_OK;
@@ -676,6 +725,7 @@ int32_t idkptSetSlotBases(idkpt_ctx* ctx, const uint32_t* slotBases, int32_t cou
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(count >= 0 && count <= MAX_DEPTH_SLOTS, "idkptSetSlotBases: count out of range");
+    FLUSH();
     memset(ctx->slotBases, 0, sizeof(ctx->slotBases));
     for (int i = 0; i < count; i++) ctx->slotBases[i] = slotBases[i];
     return IDKPT_OK;
@@ -686,6 +736,7 @@ int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* s)
     if (!ctx || !s) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(s->RayDepth >= 1 && s->RayDepth < MAX_DEPTH_SLOTS - 1, "idkptSetSettings: RayDepth out of range");
     REQUIRE(s->SamplesPerPixel >= 1, "idkptSetSettings: SamplesPerPixel must be >= 1");
+    if (memcmp(&ctx->st, s, sizeof(*s)) != 0) FLUSH();   // pending samples were submitted under the old settings
     const idkpt_settings& o = ctx->st;
     // PathTracer setters that call ResetAccumulation (PathTracer.cs:17-98): RayDepth, FocalLength, LenseRadius, DoDebugBVHTraversal, DoTraceLights
     bool reset = o.RayDepth != s->RayDepth || o.Gpu.FocalLength != s->Gpu.FocalLength || o.Gpu.LenseRadius != s->Gpu.LenseRadius ||
@@ -700,6 +751,7 @@ int32_t idkptGetSettings(idkpt_ctx* ctx, idkpt_settings* out) { if (!ctx || !out
 int32_t idkptSetPerFrame(idkpt_ctx* ctx, const float invProjection[16], const float invView[16], const float viewPos[3])
 {
     if (!ctx || !invProjection || !invView || !viewPos) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (memcmp(ctx->invProj, invProjection, 64) || memcmp(ctx->invView, invView, 64) || memcmp(ctx->viewPos, viewPos, 12)) FLUSH();
     memcpy(ctx->invProj, invProjection, 64); memcpy(ctx->invView, invView, 64); memcpy(ctx->viewPos, viewPos, 12);
     return IDKPT_OK;
 }
@@ -745,6 +797,7 @@ int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
         }
     }
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     int rc;
     if ((rc = upload(ctx, ctx->nodes, sc->BlasNodes, (size_t)sc->BlasNodeCount * 32))) return rc;
     if ((rc = upload(ctx, ctx->tris, sc->BlasTriangles, (size_t)sc->BlasTriangleCount * 16))) return rc;
@@ -806,6 +859,7 @@ int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(count >= 0 && count <= IDKPT_MAX_LIGHTS, "idkptSetLightCount: out of range");
+    FLUSH();
     ctx->lightCount = count; return IDKPT_OK;
 }
 
@@ -830,6 +884,7 @@ int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, siz
     if (!ctx || !data) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptUpdateBuffer: no scene uploaded");
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     if (which == IDKPT_BUF_JOINT_MATRICES) { size_t need = offsetBytes + bytes; if (need > ctx->joints.bytes) { DevBuf nb; HIPC(nb.ensure(need)); if (ctx->joints.p) HIPC(hipMemcpy(nb.p, ctx->joints.p, ctx->joints.bytes, hipMemcpyDeviceToDevice)); ctx->joints.release(); ctx->joints = nb; } }
     size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
     REQUIRE(b != nullptr, "idkptUpdateBuffer: unknown buffer");
@@ -846,6 +901,7 @@ int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, s
     size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
     REQUIRE(b != nullptr && offsetBytes + bytes <= cap, "idkptDownloadBuffer: bad buffer/range");
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     HIPC(hipMemcpyAsync(dst, (char*)b->p + offsetBytes, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
@@ -855,6 +911,7 @@ int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCou
 {
     if (!ctx || !nodes || nodeCount <= 0) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     int rc = upload(ctx, ctx->tlas, nodes, (size_t)nodeCount * 32); if (rc) return rc;
     HIPC(hipStreamSynchronize(ctx->stream));
     ctx->tlasCount = nodeCount;
@@ -869,6 +926,7 @@ int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId)
     const GpuBlasDesc& d = ctx->hDescs[blasId];
     if (!d.IsRefittable || d.LeafIndicesCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRefitBlas: BLAS is not refittable (no leaf/parent indices)");
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     int rc = regather_triverts(ctx, (uint32_t)d.TriangleOffset, (uint32_t)d.TriangleCount); if (rc) return rc;
     hipLaunchKernelGGL(k_refit_leaves, dim3((d.LeafIndicesCount + 63) / 64), dim3(64), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->tris.as<uint4>(), ctx->triVerts.as<float4>(),
                        ctx->leaves.as<int32_t>() + d.LeafIndicesOffset, (uint32_t)d.LeafIndicesCount, (uint32_t)d.NodeOffset, (uint32_t)d.TriangleOffset);
@@ -898,6 +956,7 @@ int32_t idkptSkin(idkpt_ctx* ctx, uint32_t inOff, uint32_t outOff, uint32_t join
     if (!ctx->haveScene || ctx->unskinnedCount == 0 || ctx->joints.bytes == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptSkin: needs scene, unskinned vertices and joint matrices");
     REQUIRE((uint64_t)inOff + count <= (uint64_t)ctx->unskinnedCount && (uint64_t)outOff + count <= (uint64_t)ctx->vertexCount, "idkptSkin: range out of bounds");
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     HIPC(ctx->prevPositions.ensure((size_t)ctx->vertexCount * 12));
     if (count) hipLaunchKernelGGL(k_skin, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, ctx->unskinned.as<GpuUnskinnedVertex>(), ctx->joints.as<float4>(), ctx->positions.as<float>(),
                                   ctx->prevPositions.as<float>(), ctx->vertices.as<uint4>(), inOff, outOff, jointOff, count);
@@ -922,106 +981,129 @@ static DScene make_dscene(idkpt_ctx* ctx)
 
 static float4* image_ptr(idkpt_ctx* ctx, int i) { return ctx->extImg[i] ? ctx->extImg[i] : ctx->img[i].as<float4>(); }
 
-// One sample: FirstHit -> [sort ->] NHit x (RayDepth-1) -> FinalDraw  (PathTracer.cs:218-270)
-static int render_sample(idkpt_ctx* ctx)
+static bool fast_path(idkpt_ctx* ctx) { return ctx->instanceCount == 1 && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
+
+// One batch of B deferred samples: FirstHit -> [sort ->] NHit x (RayDepth-1) -> FinalDraw (PathTracer.cs:218-270), every
+// stage launched once for all B samples.  Sample k owns ray ids [k*Npad, k*Npad+N); alive queues are batch-wide but stay
+// grouped by sample (stable compaction / sort with the sample index above the key), and every ray's NHit slot is its
+// position inside its own sample's queue, so each sample gets exactly the RNG streams of a stand-alone frame.
+static int flush_batch(idkpt_ctx* ctx)
 {
+    const int B = (int)ctx->pending.size();
+    if (B == 0) return IDKPT_OK;
     const uint32_t N = (uint32_t)((size_t)ctx->W * ctx->rows);
+    const uint32_t Npad = ctx->Npad;
+    const uint32_t total = (uint32_t)B * Npad;
     DScene s = make_dscene(ctx);
     Frame f;
     memcpy(f.invProj, ctx->invProj, 64); memcpy(f.invView, ctx->invView, 64); memcpy(f.viewPos, ctx->viewPos, 12);
     f.W = ctx->W; f.H = ctx->H; f.rowMod = ctx->rowMod; f.rowRem = ctx->rowRem; f.rows = ctx->rows;
-    f.g = ctx->st.Gpu; f.accumulated = ctx->accumulated; f.useTlas = ctx->st.UseTlas;
+    f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;
     f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
     f.outputAovs = ctx->st.OutputAOVs;
+    f.batch = B; f.Npad = Npad;
+    for (int k = 0; k < MAX_BATCH; k++) f.accum[k] = k < B ? ctx->pending[k] : 0u;
+    f.accumulated = f.accum[0];
     RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
     HitBufs hits = {ctx->hit.as<float4>(), ctx->hitX.as<uint32_t>(), ctx->hitCost.as<float>()};
     uint32_t* counts = ctx->counts.as<uint32_t>();
+    uint32_t* bases = ctx->bases.as<uint32_t>();             // [MAX_DEPTH_SLOTS][MAX_BATCH+1]
     uint32_t* work = ctx->work.as<uint32_t>();
     uint64_t* counters = ctx->counters64.as<uint64_t>();
     const int depth = ctx->st.RayDepth;
     hipStream_t st = ctx->stream;
+    if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[0], st));
     HIPC(hipMemsetAsync(work, 0, 4 * MAX_DEPTH_SLOTS * 4, st));
     HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
 
     const size_t ldsBytes = (size_t)(f.stackCap + (f.useTlas ? TLAS_STACK_SIZE : 0)) * WAVE * 4;
-    if (ldsBytes > 64 * 1024) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack");
+    if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }
     // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
     wavesPerCU = std::max(1, wavesPerCU);
     const uint32_t traceGrid = (uint32_t)(ctx->numCUs * wavesPerCU);
     const bool debug = f.g.DoDebugBVHTraversal != 0;
-    const uint32_t gridN = (N + 255) / 256;
+    const uint32_t gridTotal = (total + 255) / 256;
+    const bool fast = fast_path(ctx);
+    if (!fast && B != 1) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
+    unsigned long long* contMask = ctx->contMask.as<unsigned long long>();
+    uint32_t* waveCounts = ctx->waveCounts.as<uint32_t>();
+    const int BS = MAX_BATCH + 1;
 
     // ---- FirstHit
-    // fast path: one BLAS instance, no TLAS, no debug-cost output -> coherent gen + cull, persistent while-while traversal
-    const bool fast = ctx->instanceCount == 1 && !f.useTlas && !debug && !ctx->forceGeneric;
-    uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (N uints), free at this point of the sample
+    uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (capacity uints), free at this point of the batch
     uint32_t* activeCount = counts + (MAX_DEPTH_SLOTS - 1);
     {
         if (fast) {
             const uint32_t tilesX = ((uint32_t)f.W + 7) / 8, tilesY = ((uint32_t)f.rows + 7) / 8;
             const uint32_t genWaves = tilesX * tilesY;
             const int cull = f.g.DoTraceLights ? 0 : 1;
-            hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 3) / 4), dim3(256), 0, st, s, f, rays, hits, N, cull, activeList, activeCount);
+            hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 3) / 4, B), dim3(256), 0, st, s, f, rays, hits, cull, activeList, activeCount);
             TRACE_T0();
             if (ctx->counters) hipLaunchKernelGGL((k_trace2<true, true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             else hipLaunchKernelGGL((k_trace2<true, false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
         } else {
-        TRACE_T0();
-        uint32_t g = std::min<uint32_t>(traceGrid, (N + 63) / 64);
-        if (ctx->counters) { if (debug) hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<true, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
-        else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
-        TRACE_T1();
+            TRACE_T0();
+            uint32_t g = std::min<uint32_t>(traceGrid, (N + 63) / 64);
+            if (ctx->counters) { if (debug) hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<true, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
+            else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
+            TRACE_T1();
         }
-        if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.p, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
-        hipLaunchKernelGGL((k_shade<true>), dim3(gridN), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, N, 0u,
-                           ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(), ctx->keysTmp.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, (const uint32_t*)nullptr, N, ctx->waveCounts.as<uint32_t>(), counts + 1, (unsigned long long*)(1 < depth ? counters + 2 : nullptr));
-        hipLaunchKernelGGL((k_compact<true>), dim3(gridN), dim3(256), 0, st, (const uint32_t*)nullptr, (const uint32_t*)nullptr, N, ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(),
-                           ctx->keysTmp.as<uint32_t>(), ctx->queue[1].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
+        if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.as<float4>() + (size_t)(B - 1) * Npad, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
+        hipLaunchKernelGGL((k_shade<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const uint32_t*)nullptr, 0u,
+                           contMask, waveCounts, ctx->keysTmp.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, (const uint32_t*)nullptr, total, waveCounts, counts + 1, (unsigned long long*)(1 < depth ? counters + 2 : nullptr),
+                           (const unsigned long long*)contMask, (const uint32_t*)nullptr, Npad, B, bases + 1 * BS);
+        hipLaunchKernelGGL((k_compact<true>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const unsigned long long*)contMask, (const uint32_t*)waveCounts,
+                           (const uint32_t*)ctx->keysTmp.as<uint32_t>(), ctx->queue[1].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
     }
-    int side = 1; // queue[side] holds the rays entering bounce j, its length is counts[j]
+    int side = 1; // queue[side] holds the rays entering bounce j, its length is counts[j], sample k starts at bases[j][k]
     for (int j = 1; j < depth; j++) {
         uint32_t* q = ctx->queue[side].as<uint32_t>(); uint32_t* k = ctx->keys[side].as<uint32_t>();
         const uint32_t* cnt = counts + j;
         if (ctx->st.DoRaySorting && j > 1) {
-            // RaySorting() (PathTracer.cs:232-237): stable sort of (key, rayIndex) by the 21-bit key
-            const uint32_t nTiles = (N + SORT_TILE - 1) / SORT_TILE;
+            // RaySorting() (PathTracer.cs:232-237): stable sort of (key, rayIndex); key = 21-bit triangle id with the batch's
+            // sample index above it, so one sort orders every sample's queue exactly like a stand-alone counting sort
+            const uint32_t nTiles = (total + SORT_TILE - 1) / SORT_TILE;
+            const int passes = B > 1 ? 4 : 3;
             uint32_t* ka = k; uint32_t* va = q; uint32_t* kb = ctx->sortKeys.as<uint32_t>(); uint32_t* vb = ctx->sortVals.as<uint32_t>();
-            for (int pass = 0; pass < 3; pass++) {
-                hipLaunchKernelGGL(k_sort_hist, dim3(nTiles), dim3(SORT_BLOCK), 0, st, ka, cnt, (uint32_t)(7 * pass), ctx->sortHist.as<uint32_t>(), nTiles);
+            for (int pass = 0; pass < passes; pass++) {
+                hipLaunchKernelGGL(k_sort_hist, dim3(nTiles), dim3(SORT_BLOCK), 0, st, (const uint32_t*)ka, cnt, (uint32_t)(7 * pass), ctx->sortHist.as<uint32_t>(), nTiles);
                 hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, cnt, ctx->sortHist.as<uint32_t>(), nTiles);
-                hipLaunchKernelGGL(k_sort_scatter, dim3(nTiles), dim3(SORT_BLOCK), 0, st, ka, va, cnt, (uint32_t)(7 * pass), ctx->sortHist.as<uint32_t>(), nTiles, kb, vb);
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nTiles), dim3(SORT_BLOCK), 0, st, (const uint32_t*)ka, (const uint32_t*)va, cnt, (uint32_t)(7 * pass), (const uint32_t*)ctx->sortHist.as<uint32_t>(), nTiles, kb, vb);
                 std::swap(ka, kb); std::swap(va, vb);
             }
-            // after 3 passes the sorted data sits in (sortKeys, sortVals): copy back into the queue side (A*4 B each; the reference copies W*H*4, PathTracer.cs:296)
-            HIPC(hipMemcpyAsync(q, va, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+            // odd pass count: the sorted data sits in (sortKeys, sortVals) -> copy the indices back (the reference copies W*H*4 B too, PathTracer.cs:296)
+            if (va != q) HIPC(hipMemcpyAsync(q, va, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
         }
         TRACE_T0();
         if (fast) {
             if (ctx->counters) hipLaunchKernelGGL((k_trace2<false, true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace2<false, false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
         } else {
-            if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
-            else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, q, cnt, work + j, counters);
+            if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
+            else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
         }
         TRACE_T1();
-        hipLaunchKernelGGL((k_shade<false>), dim3(gridN), dim3(256), 0, st, s, f, rays, hits, q, cnt, 0u, ctx->slotBases[j],
-                           ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(), ctx->keysTmp.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, cnt, 0u, ctx->waveCounts.as<uint32_t>(), counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr));
-        hipLaunchKernelGGL((k_compact<false>), dim3(gridN), dim3(256), 0, st, q, cnt, 0u, ctx->contMask.as<unsigned long long>(), ctx->waveCounts.as<uint32_t>(),
-                           ctx->keysTmp.as<uint32_t>(), ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
+        hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), ctx->slotBases[j],
+                           contMask, waveCounts, ctx->keysTmp.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, cnt, 0u, waveCounts, counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr),
+                           (const unsigned long long*)contMask, (const uint32_t*)(bases + j * BS), Npad, B, bases + (j + 1) * BS);
+        hipLaunchKernelGGL((k_compact<false>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)q, cnt, 0u, (const unsigned long long*)contMask, (const uint32_t*)waveCounts,
+                           (const uint32_t*)ctx->keysTmp.as<uint32_t>(), ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
         side = 1 - side;
     }
-    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast;
-    hipLaunchKernelGGL(k_final_draw, dim3(gridN), dim3(256), 0, st, f, rays, image_ptr(ctx, 0), image_ptr(ctx, 1), image_ptr(ctx, 2), N);
+    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast; ctx->lastBatch = B;
+    hipLaunchKernelGGL(k_final_draw, dim3((N + 255) / 256), dim3(256), 0, st, f, rays, image_ptr(ctx, 0), image_ptr(ctx, 1), image_ptr(ctx, 2), N);
     HIPC(hipGetLastError());
-    // queue lengths stay on the GPU during the frame; a copy goes to pinned memory for GetStats (no sync here)
+    // queue lengths stay on the GPU during the batch; a copy goes to pinned memory for GetStats (no sync here)
     HIPC(hipMemcpyAsync(ctx->hCounts, counts, MAX_DEPTH_SLOTS * 4, hipMemcpyDeviceToHost, st));
-    ctx->accumulated++;
-    ctx->stats.Frames++;
-    ctx->stats.PrimaryRays += N;
+    HIPC(hipMemcpyAsync(ctx->hBases, bases, MAX_DEPTH_SLOTS * BS * 4, hipMemcpyDeviceToHost, st));
+    if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[1], st));
+    ctx->stats.Frames += (uint64_t)B;
+    ctx->stats.PrimaryRays += (uint64_t)N * (uint64_t)B;
+    ctx->pending.clear();
     return IDKPT_OK;
 }
 
@@ -1033,16 +1115,33 @@ int32_t idkptRender(idkpt_ctx* ctx)
     if (ctx->st.UseTlas && ctx->tlasCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: UseTlas set but no TLAS nodes uploaded");
     HIPC(hipSetDevice(ctx->device));
     if (ctx->timing && ctx->evUsed > 4096) { HIPC(hipStreamSynchronize(ctx->stream)); resolve_trace_events(ctx); }
-    if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[0], ctx->stream));
+    // every sample is deferred; a batch is launched as soon as maxBatch samples are pending (or on any call that needs
+    // results).  The general path (multi-instance / TLAS / debug cost) is launched sample by sample.
+    const int limit = fast_path(ctx) ? ctx->maxBatch : 1;
     for (int i = 0; i < ctx->st.SamplesPerPixel; i++) {
-        int rc = render_sample(ctx); if (rc) return rc;
+        ctx->pending.push_back(ctx->accumulated++);
+        if ((int)ctx->pending.size() >= limit) { int rc = flush_batch(ctx); if (rc) return rc; }
     }
-    if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[1], ctx->stream));
-    ctx->stats.LastFrameMs = -1.0f; // resolved lazily in GetStats
     return IDKPT_OK;
 }
 
-int32_t idkptSynchronize(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); HIPC(hipStreamSynchronize(ctx->stream)); return IDKPT_OK; }
+int32_t idkptSynchronize(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); HIPC(hipStreamSynchronize(ctx->stream)); return IDKPT_OK; }
+
+// Launches whatever is pending without waiting for it (lets a host overlap its own work with the GPU).
+int32_t idkptFlush(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); return IDKPT_OK; }
+
+int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..8");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    HIPC(hipStreamSynchronize(ctx->stream));
+    if (maxBatch == ctx->maxBatch) return IDKPT_OK;
+    ctx->maxBatch = maxBatch;
+    if (ctx->W > 0) { uint32_t acc = ctx->accumulated; int rc = alloc_frame_keep_images(ctx); if (rc) return rc; ctx->accumulated = acc; }
+    return IDKPT_OK;
+}
 
 int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes)
 {
@@ -1051,6 +1150,7 @@ int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes)
     size_t need = (size_t)ctx->W * ctx->rows * 16;
     REQUIRE(bytes == need && need > 0, "idkptDownload: bytes must equal localRows*width*16");
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image), need, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
@@ -1062,10 +1162,12 @@ int32_t idkptDownloadRays(idkpt_ctx* ctx, GpuWavefrontRay* out, size_t bytes)
     size_t N = (size_t)ctx->W * ctx->rows;
     REQUIRE(bytes == N * sizeof(GpuWavefrontRay) && N > 0, "idkptDownloadRays: bytes must equal pixelCount*48");
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    const size_t off = (size_t)(ctx->lastBatch - 1) * ctx->Npad * 16; // the most recent sample of the last batch
     std::vector<float4> a(N), b(N), c(N);
-    HIPC(hipMemcpyAsync(a.data(), ctx->rayO.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipMemcpyAsync(b.data(), ctx->rayT.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipMemcpyAsync(c.data(), ctx->rayR.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(a.data(), (char*)ctx->rayO.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(b.data(), (char*)ctx->rayT.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(c.data(), (char*)ctx->rayR.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < N; i++) {
         GpuWavefrontRay& r = out[i];
@@ -1080,10 +1182,18 @@ int32_t idkptDownloadAliveQueue(idkpt_ctx* ctx, uint32_t* indices, size_t capaci
 {
     if (!ctx || !outCount) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     HIPC(hipStreamSynchronize(ctx->stream));
-    uint32_t n = ctx->hCounts[ctx->lastQueueCountSlot];
+    // the most recent sample's segment of the batch-wide queue; entries are ray ids -> subtract the sample's id offset
+    const uint32_t* hb = ctx->hBases + (size_t)ctx->lastQueueCountSlot * (MAX_BATCH + 1);
+    const uint32_t first = hb[ctx->lastBatch - 1], n = hb[ctx->lastBatch] - first;
     *outCount = n;
-    if (indices && n) { REQUIRE(capacity >= n, "idkptDownloadAliveQueue: capacity too small"); HIPC(hipMemcpy(indices, ctx->queue[ctx->lastQueueSide].p, (size_t)n * 4, hipMemcpyDeviceToHost)); }
+    if (indices && n) {
+        REQUIRE(capacity >= n, "idkptDownloadAliveQueue: capacity too small");
+        HIPC(hipMemcpy(indices, ctx->queue[ctx->lastQueueSide].as<uint32_t>() + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+        const uint32_t sub = (uint32_t)(ctx->lastBatch - 1) * ctx->Npad;
+        for (uint32_t i = 0; i < n; i++) indices[i] -= sub;
+    }
     return IDKPT_OK;
 }
 
@@ -1094,8 +1204,9 @@ int32_t idkptDownloadPrimaryHits(idkpt_ctx* ctx, float* t, uint32_t* triangleId,
     if (!ctx || !t || !triangleId || !baryXY) return IDKPT_ERR_INVALID_ARGUMENT;
     size_t N = (size_t)ctx->W * ctx->rows;
     REQUIRE(pixelCount == N, "idkptDownloadPrimaryHits: pixelCount mismatch");
-    if (!ctx->capturePrimary || ctx->primHit.bytes < N * 16) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptDownloadPrimaryHits: call idkptEnablePrimaryHitCapture(ctx,1) before idkptRender");
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    if (!ctx->capturePrimary || ctx->primHit.bytes < N * 16) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptDownloadPrimaryHits: call idkptEnablePrimaryHitCapture(ctx,1) before idkptRender");
     std::vector<float4> h(N);
     HIPC(hipMemcpyAsync(h.data(), ctx->primHit.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
@@ -1107,9 +1218,10 @@ int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* out)
 {
     if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     HIPC(hipStreamSynchronize(ctx->stream));
     idkpt_stats s = ctx->stats;
-    for (int j = 0; j < 16; j++) s.LastAliveCounts[j] = (j >= 1 && j < ctx->st.RayDepth) ? ctx->hCounts[j] : 0;
+    for (int j = 0; j < 16; j++) { const uint32_t* hb = ctx->hBases + (size_t)j * (MAX_BATCH + 1); s.LastAliveCounts[j] = (j >= 1 && j < ctx->st.RayDepth) ? hb[ctx->lastBatch] - hb[ctx->lastBatch - 1] : 0; }
     // [0]: primary rays that entered the traversal kernel (all pixels, or the survivors of the root-box pre-cull on the fast path)
     s.LastAliveCounts[0] = s.Frames ? (ctx->lastFast ? ctx->hCounts[MAX_DEPTH_SLOTS - 1] : (uint32_t)((size_t)ctx->W * ctx->rows)) : 0;
     s.LastFrameMs = 0.0f; s.LastTraceMs = 0.0f;
@@ -1129,6 +1241,7 @@ int32_t idkptResetStats(idkpt_ctx* ctx)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     HIPC(hipStreamSynchronize(ctx->stream));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;
@@ -1153,6 +1266,7 @@ int32_t idkptSetStream(idkpt_ctx* ctx, void* hipStream)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
+    FLUSH();
     HIPC(hipStreamSynchronize(ctx->stream));
     if (hipStream) { if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream); ctx->stream = (hipStream_t)hipStream; ctx->ownStream = false; }
     else if (!ctx->ownStream) { HIPC(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->ownStream = true; }

@@ -34,9 +34,12 @@ struct Frame {
     float invProj[16]; float invView[16]; float viewPos[3];
     int W, H, rowMod, rowRem, rows;
     GpuSettings g;
-    uint32_t accumulated;
+    uint32_t accumulated;       // AccumulatedSamples of sample 0 of the batch (== accum[0])
     int useTlas, stackCap, outputAovs;
+    // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
+    int batch; uint32_t Npad; uint32_t accum[8];
 };
+#define MAX_BATCH 8
 
 struct RayBufs {                // SoA planes of the reference's GpuWavefrontRay / GpuAovRay, indexed by local pixel
     float4* o_ior;              // Origin.xyz, PreviousIOROrTraverseCost
@@ -173,11 +176,11 @@ DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, fl
 
 // ---------------------------------------------------------------------------------------------------------------
 // Primary ray generation (FirstHit/compute.glsl:44-77).  `pix` = local pixel index.
-DEV void gen_primary(const Frame& f, uint32_t pix, f3& origin, f2& packedDir, uint32_t& rngSeed)
+DEV void gen_primary(const Frame& f, uint32_t pix, uint32_t acc, f3& origin, f2& packedDir, uint32_t& rngSeed)
 {
     int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
     int y = ly * f.rowMod + f.rowRem, x = lx;
-    uint32_t seed = (uint32_t)(y * 4096 + x) * (f.accumulated + 1u);
+    uint32_t seed = (uint32_t)(y * 4096 + x) * (acc + 1u);
     float ox = rnd01(seed), oy = rnd01(seed);
     float nx = ((float)x + ox) / (float)f.W * 2.0f - 1.0f, ny = ((float)y + oy) / (float)f.H * 2.0f - 1.0f;
     f3 camDir = GetWorldSpaceDirection(f.invProj, f.invView, nx, ny);
@@ -248,7 +251,7 @@ struct RayState { f3 origin; float prevIor; f3 throughput; float pdx; f3 radianc
 struct AovState { f3 albedo; float newWeight; f3 normal; };
 
 template <bool FIRST>
-DEV bool ShadeHit(const DScene& s, const Frame& f, const HitRec& hit, bool hitScene, f3 rayDir, RayState& r, AovState& aov, uint32_t& rng, uint32_t gidSeed, uint32_t& sortingKey)
+DEV bool ShadeHit(const DScene& s, const Frame& f, uint32_t acc, const HitRec& hit, bool hitScene, f3 rayDir, RayState& r, AovState& aov, uint32_t& rng, uint32_t gidSeed, uint32_t& sortingKey)
 {
     if (hitScene) {
         r.origin = r.origin + rayDir * hit.T;
@@ -348,7 +351,7 @@ DEV bool ShadeHit(const DScene& s, const Frame& f, const HitRec& hit, bool hitSc
         f3 diffuseRayDir;
         {
             uint32_t local = gidSeed;
-            f2 r2 = R2Sequence(f.accumulated);
+            f2 r2 = R2Sequence(acc);
             float px = rnd01(local), py = rnd01(local);
             f2 uv; uv.x = gfract(r2.x + px); uv.y = gfract(r2.y + py);
             diffuseRayDir = CosineSampleHemisphere(sNormal, uv);

@@ -216,5 +216,12 @@ class PathTracer:
         self._check(self._L.idkptGetImageDevicePtr(self._ctx, which, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def set_max_batch(self, n):
+        """Up to n consecutive samples are deferred and traced together (bit-identical results; idkptSetMaxBatch)."""
+        self._check(self._L.idkptSetMaxBatch(self._ctx, n))
+
+    def flush(self):
+        self._check(self._L.idkptFlush(self._ctx))
+
     def set_stream(self, hip_stream_handle):
         self._check(self._L.idkptSetStream(self._ctx, C.c_void_p(hip_stream_handle)))

@@ -161,6 +161,13 @@ IDKPT_API int32_t idkptGetAccumulatedSamples(idkpt_ctx* ctx, uint32_t* outSample
  * Asynchronous on the context's stream; no host read-back inside. */
 IDKPT_API int32_t idkptRender(idkpt_ctx* ctx);
 IDKPT_API int32_t idkptSynchronize(idkpt_ctx* ctx);
+/* Deferred batching (no reference equivalent; DESIGN.md "Batching"): idkptRender only queues its samples; up to maxBatch
+ * (1..8, default 1) consecutive samples are traced together by one set of kernel launches, each with its own
+ * AccumulatedSamples index, queue slots and RNG streams, and FinalDraw folds them in submission order — outputs are
+ * bit-identical to maxBatch = 1.  Anything that reads results or changes inputs flushes first. */
+IDKPT_API int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch);
+/* Launch pending samples now, without waiting for them. */
+IDKPT_API int32_t idkptFlush(idkpt_ctx* ctx);
 /* Texture.Download of Result/Albedo/Normal (PathTracerPipeline.cs:177-188). Synchronises. bytes must be rows*width*16. */
 IDKPT_API int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes);
 /* Internal wavefront state for parity tests: SSBO 30 (GpuWavefrontRay per local pixel) and the alive queue of the

@@ -201,6 +201,56 @@ def test_spp_accumulation_equals_repeated_compute(native_builder):
     a.Dispose(); b.Dispose()
 
 
+@pytest.mark.parametrize("batch", [2, 4, 8])
+def test_deferred_batching_is_bit_identical(batch, native_builder, oracle_mod):
+    """idkptSetMaxBatch: up to `batch` consecutive samples are traced by one set of launches.  Accumulating 5 samples
+    (one full batch + a partial one, or a single partial one) must equal 5 sequential samples bit-for-bit — radiance, AOVs, the last sample's ray
+    state / queue / hit records and the exact ray + visit counters — with sorting on (sample-tagged keys) and depth 5."""
+    sc = S.presplit_scene(native_builder); cam = S.presplit_camera(160, 90)
+    ov = dict(RayDepth=5, DoRaySorting=1, OutputAOVs=1)
+    a = gpu_render(sc, cam, 160, 90, frames=5, **ov)
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    b = PathTracer(160, 90, settings=configs.apply_settings(T.Settings.default(), ov))
+    b.UploadScene(sc); b.SetCamera(cam); b.enable_counters(True); b.enable_primary_hit_capture(True)
+    b.set_max_batch(batch)
+    for _ in range(5):
+        b.Compute()
+    assert b.AccumulatedSamples == 5
+    assert (bits(a.Result) == bits(b.Result)).all()
+    assert (bits(a.AlbedoTexture) == bits(b.AlbedoTexture)).all() and (bits(a.NormalTexture) == bits(b.NormalTexture)).all()
+    assert a.rays().tobytes() == b.rays().tobytes() and (a.alive_queue() == b.alive_queue()).all()
+    at, atri, ab = a.primary_hits(); bt, btri, bb = b.primary_hits()
+    assert (atri == btri).all() and (bits(at) == bits(bt)).all() and (bits(ab) == bits(bb)).all()
+    sa, sb = a.stats(), b.stats()
+    for k in ("rays_traced", "primary_rays", "frames", "node_pair_visits", "triangle_tests"):
+        assert sa[k] == sb[k], k
+    assert sa["alive_counts"][1:5] == sb["alive_counts"][1:5]
+    # and against the oracle
+    o = oracle_render(oracle_mod, sc, cam, 160, 90, frames=5, **ov)
+    assert (bits(b.Result) == bits(o.image(0))).all() and b.rays().tobytes() == o.rays().tobytes()
+    a.Dispose(); b.Dispose(); o.close()
+
+
+def test_batched_independent_frames_with_reset(native_builder):
+    """The bench pattern: ResetAccumulation + Compute per step, 8 steps deferred into batches of 4; also a camera change
+    in the middle must flush (pending samples belong to the old camera)."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.soup_scene(30000, native_builder, seed=21); cam = S.Camera(320, 180); cam2 = S.Camera(320, 180, position=(2.0, 1.0, 24.0))
+    ref = gpu_render(sc, cam, 320, 180, RayDepth=3); want = ref.Result
+    ref2 = gpu_render(sc, cam2, 320, 180, RayDepth=3); want2 = ref2.Result
+    p = PathTracer(320, 180); p.UploadScene(sc); p.SetCamera(cam); p.RayDepth = 3; p.set_max_batch(4)
+    for _ in range(8):
+        p.ResetAccumulation(); p.Compute()
+    assert (bits(p.Result) == bits(want)).all() and p.stats()["frames"] == 8
+    p.ResetAccumulation(); p.Compute(); p.ResetAccumulation(); p.Compute()       # 2 pending under cam
+    p.SetCamera(cam2)                                                              # flushes them
+    p.ResetAccumulation(); p.Compute()
+    assert (bits(p.Result) == bits(want2)).all()
+    assert p.stats()["rays_traced"] == 10 * ref.stats()["rays_traced"] + ref2.stats()["rays_traced"]
+    ref.Dispose(); ref2.Dispose(); p.Dispose()
+
+
 def test_refit_and_skinning_match_oracle(oracle_mod, oracle_builder, native_builder):
     """Config 5 stand-in: refittable soup, positions displaced, GPU BLAS refit (BLASRefit/compute.glsl) vs BLAS.Refit,
     then a frame on the refitted BVH vs the oracle on the CPU-refitted BVH.  Skinning (Skinning/compute.glsl) with two
