@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 // and pre-culls rays whose root-box test (BVHIntersect.glsl:32-39 with T = FLOAT_MAX) fails: those get their miss
 // record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
 // wave) to an unordered active list; results are stored per pixel, so the list order is free.
-__global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs rays, HitBufs hits, int cull, uint32_t* activeList, uint32_t* activeCount)
+__global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut)
 {
     const uint32_t smp = blockIdx.y;                                   // sample of the batch
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -109,22 +109,30 @@ __global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs 
     if (valid) {
         f3 origin; f2 pd; uint32_t seed;
         gen_primary(f, pix, f.accum[smp], origin, pd, seed);
-        rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
-        rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
-        rays.rad_py[rid] = make_float4(0.0f, 0.0f, 0.0f, pd.y);
+        f3 rd = DecodeUnitVec(pd.x, pd.y);
+        GpuBlasInstance inst = s.instances[0];
+        M34 inv = load_inv_model(s, inst.MeshTransformId);
+        f3 lo = xform34(inv, origin, 1.0f), ld = xform34(inv, rd, 0.0f);
+        f3 invDir = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
         keep = true;
-        if (cull) {
-            GpuBlasInstance inst = s.instances[0];
-            int nodeOffset = s.descs[inst.BlasId].NodeOffset;
-            M34 inv = load_inv_model(s, inst.MeshTransformId);
-            f3 rd = DecodeUnitVec(pd.x, pd.y);
-            f3 lo = xform34(inv, origin, 1.0f), ld = xform34(inv, rd, 0.0f);
-            f3 invDir = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
-            const float4* root = s.nodes + 2 * (size_t)nodeOffset + 2;
+        if (cull) {   // root-box test of BVHIntersect.glsl:32-39 with T = FLOAT_MAX (no lights): a failing ray is a miss
+            const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
             float t1;
             keep = RayBoxIntersect(lo, invDir, root[0], root[1], &t1) && t1 < PT_FLOAT_MAX;
-            if (!keep) { hits.hit[rid] = make_float4(PT_FLOAT_MAX, 0.0f, 0.0f, __uint_as_float(~0u)); hits.xformId[rid] = 0; }
         }
+        f3 radiance = splat3(0.0f);
+        if (keep) {
+            tr.lo[rid] = make_float4(lo.x, lo.y, lo.z, 0.0f); tr.ld[rid] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.inv[rid] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f);
+            seedOut[rid] = seed;                                        // RNG state after ray generation, consumed by k_shade_first
+        } else {
+            // miss branch of FirstHit TraceRay (FirstHit/compute.glsl:225-233), evaluated right here
+            f3 albedo = SampleSky(s, rd);
+            radiance = radiance + albedo * splat3(1.0f);
+            if (f.outputAovs) { f3 fn = CubemapFaceNormal(rd); rays.aovA[rid] = make_float4(albedo.x, albedo.y, albedo.z, 0.0f); rays.aovN[rid] = make_float4(fn.x, fn.y, fn.z, 0.0f); }
+        }
+        rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+        rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
+        rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, pd.y);
     }
     unsigned long long m = __ballot(keep);
     if (m) {
@@ -141,9 +149,8 @@ __global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs 
 // never takes its next node step before its own pending leaf is tested, so every ray sees exactly the reference's
 // sequence of T updates and pushes: results (T, TriangleId, bary, visit counts) are bit-identical, only the interleaving
 // between different rays changes.
-#define REFILL_MIN 16
-template <bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(WAVE) void k_trace2(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24>
+__global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -154,7 +161,6 @@ __global__ __launch_bounds__(WAVE) void k_trace2(DScene s, Frame f, RayBufs rays
     const GpuBlasInstance inst = s.instances[0];
     const int nodeOffset = s.descs[inst.BlasId].NodeOffset;
     const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
-    const M34 inv = load_inv_model(s, inst.MeshTransformId);
     const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
 
     bool active = false, leafPending = false, workLeft = true;
@@ -163,43 +169,51 @@ __global__ __launch_bounds__(WAVE) void k_trace2(DScene s, Frame f, RayBufs rays
     f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
     float hitT = 0.0f, hbx = 0.0f, hby = 0.0f; uint32_t hitTri = ~0u, hitXform = 0;
     uint32_t nPairs = 0, nTris = 0;
+    // PROF: per-wave cycle buckets [refill, node, leaf, other], step counts and active-lane sums (developer instrumentation)
+    unsigned long long pc[4] = {0, 0, 0, 0}, pn[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tPrev = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+#define PROF_MARK(b) do { if (PROF) { unsigned long long _t = __builtin_amdgcn_s_memtime(); pc[b] += _t - tPrev; tPrev = _t; } } while (0)
 
     while (true) {
+        PROF_MARK(3);
         // ---- refill idle lanes
         unsigned long long idle = __ballot(!active);
         if (workLeft && ((uint32_t)__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
             const uint32_t n = (uint32_t)__popcll(idle);
+            if (PROF) { pn[0]++; pn[1] += n; }
             const uint32_t base = wave_grab(workCounter, n);
             const uint32_t item = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (base + n >= N) workLeft = false;
             if (!active && item < N) {
                 const uint32_t idx = list[item];
                 slot = PRIMARY ? idx : item;
-                float4 o = rays.o_ior[idx];
-                float pdx = rays.thr_px[idx].w, pdy = rays.rad_py[idx].w;
-                f3 wd = DecodeUnitVec(pdx, pdy);
-                f3 wo = mk3(o.x, o.y, o.z);
                 hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f;
-                if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203
+                if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203 (world-space ray)
+                    float4 o = rays.o_ior[idx];
+                    f3 wd = DecodeUnitVec(rays.thr_px[idx].w, rays.rad_py[idx].w), wo = mk3(o.x, o.y, o.z);
                     for (int i = 0; i < s.lightCount; i++) {
                         const GpuLight& l = s.lights[i];
                         float tMin, tMax;
                         if (RaySphereIntersect(wo, wd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hitT) { hitT = tMin < 0.0f ? tMax : tMin; hitXform = (uint32_t)i; hitTri = ~0u; }
                     }
                 }
-                ro = xform34(inv, wo, 1.0f); rd = xform34(inv, wd, 0.0f);
-                invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                // local-space ray and 1/dir were prepared by the (coherent, full-lane) kernel that produced this ray
+                { float4 a = tr.lo[idx], b = tr.ld[idx], c = tr.inv[idx]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z); }
                 float t1;
                 bool enter = RayBoxIntersect(ro, invDir, nodes[2], nodes[3], &t1) && t1 < hitT; // root test (:32-39)
                 active = true; leafPending = false; sp = 0; top = enter ? 2u : 0u;
             }
         }
+        PROF_MARK(0);
         if (__ballot(active) == 0ull) { if (!workLeft) break; continue; }
 
         // ---- node phase
         while (true) {
             const bool canStep = active && !leafPending && top != 0u;
             if (!__any(canStep)) break;
+            // enough lanes are parked on a leaf: test those leaves now instead of letting the stragglers run on alone
+            if (LEAF_MIN <= 64 && (int)__popcll(__ballot(active && leafPending)) >= LEAF_MIN) break;
+            if (PROF) { pn[2]++; pn[3] += (unsigned long long)__popcll(__ballot(canStep)); }
             if (canStep) {
                 if (COUNT) nPairs++;
                 const float4* p = nodes + 2 * (size_t)top;
@@ -229,6 +243,8 @@ __global__ __launch_bounds__(WAVE) void k_trace2(DScene s, Frame f, RayBufs rays
                 }
             }
         }
+        PROF_MARK(1);
+        if (PROF) { unsigned long long lm = __ballot(leafPending); if (lm) { pn[4]++; pn[5] += (unsigned long long)__popcll(lm); } }
         // ---- leaf phase
         if (leafPending) {
             for (uint32_t i = leafFirst; i < leafEnd; i++) {
@@ -241,6 +257,7 @@ __global__ __launch_bounds__(WAVE) void k_trace2(DScene s, Frame f, RayBufs rays
             }
             leafPending = false;
         }
+        PROF_MARK(2);
         // ---- retire finished rays
         if (active && top == 0u) {
             hits.hit[slot] = make_float4(hitT, hbx, hby, __uint_as_float(hitTri));
@@ -249,12 +266,54 @@ __global__ __launch_bounds__(WAVE) void k_trace2(DScene s, Frame f, RayBufs rays
         }
     }
     if (COUNT) flush_counters(counters, nPairs, nTris);
+    if (PROF && lane == 0) { for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)&counters[4 + i], pc[i]); for (int i = 0; i < 6; i++) atomicAdd((unsigned long long*)&counters[8 + i], pn[i]); }
+#undef PROF_MARK
 }
 
 // FirstHit / NHit part 2: shade + BSDF sample + continue decision.  One thread per queue slot; the continue bits of a
 // wave are published as one 64-bit ballot + popcount for the ordered compaction that follows.
+// local-space ray + 1/dir of a continuing ray, for the next traversal launch (single-instance fast path): exactly what
+// NHit does first (decode the packed direction, NHit:93; RayTransform, BVHIntersect.glsl:281-282; 1/dir, IntersectionRoutines.glsl:29)
+DEV void write_trace_ready(const DScene& s, const TraceBufs& tr, uint32_t rid, const RayState& r)
+{
+    GpuBlasInstance inst = s.instances[0];
+    M34 inv = load_inv_model(s, inst.MeshTransformId);
+    f3 rd = DecodeUnitVec(r.pdx, r.pdy);
+    f3 lo = xform34(inv, r.origin, 1.0f), ld = xform34(inv, rd, 0.0f);
+    tr.lo[rid] = make_float4(lo.x, lo.y, lo.z, 0.0f); tr.ld[rid] = make_float4(ld.x, ld.y, ld.z, 0.0f);
+    tr.inv[rid] = make_float4(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z, 0.0f);
+}
+
+// Fast-path FirstHit shading: only the rays that entered the traversal (active list, any order).  The continue decision
+// goes to a per-ray byte (pre-zeroed), which the ordered compaction turns back into pixel order.
+__global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* activeList, const uint32_t* activeCount,
+                                                     uint8_t* contFlag, uint32_t* seedsAndKeys)
+{
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= *activeCount) return;
+    const uint32_t rid = activeList[item];
+    const uint32_t smp = rid / f.Npad, pix = rid - smp * f.Npad;
+    const uint32_t acc = f.accum[smp];
+    float4 a = rays.o_ior[rid], b = rays.thr_px[rid], c = rays.rad_py[rid];
+    float4 h = hits.hit[rid];
+    HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[rid];
+    RayState r; r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;
+    AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
+    uint32_t rng = seedsAndKeys[rid], key = 0;
+    int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
+    uint32_t gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
+    f3 rd = DecodeUnitVec(r.pdx, r.pdy);
+    bool cont = ShadeHit<true>(s, f, acc, hit, hit.T != PT_FLOAT_MAX, rd, r, aov, rng, gidSeed, key);
+    rays.o_ior[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, r.prevIor);
+    rays.thr_px[rid] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
+    rays.rad_py[rid] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
+    if (f.outputAovs) { rays.aovA[rid] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[rid] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
+    seedsAndKeys[rid] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
+    if (cont) { contFlag[rid] = 1; write_trace_ready(s, tr, rid, r); }
+}
+
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm,
+__global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm,
                                                const uint32_t* qbase, uint32_t slotBase, unsigned long long* contMask, uint32_t* waveCounts, uint32_t* keysTmp)
 {
     // FIRST: slots are ray ids (sample-major, Npad per sample, Npad % 64 == 0).  Otherwise slots are positions of the
@@ -299,36 +358,65 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
             rays.thr_px[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
             rays.rad_py[idx] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
             if (f.outputAovs) { rays.aovA[idx] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[idx] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
+            if (cont && tr.lo) write_trace_ready(s, tr, idx, r);
         }
         // NHit:81 masks the key to 21 bits; the sample index goes above it so that the batch-wide sort stays grouped by sample
         keysTmp[slot] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
     }
     unsigned long long m = __ballot(cont);
-    if ((threadIdx.x & 63) == 0) { uint32_t w = slot >> 6; contMask[w] = m; waveCounts[w] = (uint32_t)__popcll(m); }
+    if ((threadIdx.x & 63) == 0) contMask[slot >> 6] = m;
+    (void)waveCounts;
 }
 
-// Ordered exclusive scan of the per-wave continue counts (single workgroup): reproduces the sequential enqueue order.
-__global__ __launch_bounds__(1024) void k_scan_waves(const uint32_t* countPtr, uint32_t countImm, uint32_t* waveCounts, uint32_t* nextCount, unsigned long long* tracedRays,
-                                                     const unsigned long long* contMask, const uint32_t* curBase /* null: FIRST (slots are ray ids) */, uint32_t Npad, int batch, uint32_t* nextBase)
+// Ordered (= sequential enqueue order) compaction in three launches: (1) per 256-wave block: continue masks (from the
+// shade kernel's ballots, or rebuilt from per-ray bytes) -> exclusive offsets inside the block + block total,
+// (2) one workgroup scans the block totals and derives the next queue length and every sample's first slot,
+// (3) scatter (k_compact).
+#define SCAN_WAVES_PER_BLOCK 256
+template <bool FROM_FLAGS>
+__global__ __launch_bounds__(SCAN_WAVES_PER_BLOCK) void k_scan_local(const uint32_t* countPtr, uint32_t countImm, const uint8_t* contFlag, unsigned long long* contMask, uint32_t* waveLocal, uint32_t* blockSums)
+{
+    __shared__ uint32_t part[SCAN_WAVES_PER_BLOCK];
+    const uint32_t N = countPtr ? *countPtr : countImm;
+    const uint32_t nW = (N + 63) / 64;
+    const uint32_t w = blockIdx.x * SCAN_WAVES_PER_BLOCK + threadIdx.x;
+    if (blockIdx.x * SCAN_WAVES_PER_BLOCK >= nW) return;
+    uint32_t c = 0;
+    if (w < nW) {
+        unsigned long long m;
+        if (FROM_FLAGS) {
+            const uint4* p = reinterpret_cast<const uint4*>(contFlag + (size_t)w * 64);
+            m = 0ull;
+            for (int q = 0; q < 4; q++) {
+                uint4 v = p[q]; uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                for (int k = 0; k < 4; k++) for (int bb = 0; bb < 4; bb++) m |= (unsigned long long)((d[k] >> (8 * bb)) & 1u) << (q * 16 + k * 4 + bb);
+            }
+            contMask[w] = m;
+        } else m = contMask[w];
+        c = (uint32_t)__popcll(m);
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t off = 1; off < SCAN_WAVES_PER_BLOCK; off <<= 1) { uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0; __syncthreads(); part[threadIdx.x] += v; __syncthreads(); }
+    if (w < nW) waveLocal[w] = part[threadIdx.x] - c;
+    if (threadIdx.x == SCAN_WAVES_PER_BLOCK - 1) blockSums[blockIdx.x] = part[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* countPtr, uint32_t countImm, uint32_t* blockSums, const uint32_t* waveLocal, uint32_t* nextCount, unsigned long long* tracedRays,
+                                                      const unsigned long long* contMask, const uint32_t* curBase /* null: FIRST (slots are ray ids) */, uint32_t Npad, int batch, uint32_t* nextBase)
 {
     __shared__ uint32_t part[1024];
     const uint32_t N = countPtr ? *countPtr : countImm;
-    const uint32_t nW = (N + 63) / 64;
-    const uint32_t per = (nW + 1023) / 1024;
+    const uint32_t nW = (N + 63) / 64, nB = (nW + SCAN_WAVES_PER_BLOCK - 1) / SCAN_WAVES_PER_BLOCK;
+    const uint32_t per = (nB + 1023) / 1024;
     const uint32_t t = threadIdx.x;
-    uint32_t b = t * per, e = min(b + per, nW);
+    uint32_t b = t * per, e = min(b + per, nB);
     uint32_t sum = 0;
-    for (uint32_t i = b; i < e; i++) sum += waveCounts[i];
+    for (uint32_t i = b; i < e; i++) sum += blockSums[i];
     part[t] = sum;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
-        uint32_t v = (t >= off) ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
+    for (uint32_t off = 1; off < 1024; off <<= 1) { uint32_t v = (t >= off) ? part[t - off] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
     uint32_t run = part[t] - sum;
-    for (uint32_t i = b; i < e; i++) { uint32_t c = waveCounts[i]; waveCounts[i] = run; run += c; }
+    for (uint32_t i = b; i < e; i++) { uint32_t c = blockSums[i]; blockSums[i] = run; run += c; }   // blockSums becomes blockBase
     if (t == 1023) { *nextCount = part[1023]; if (tracedRays) atomicAdd(tracedRays, (unsigned long long)part[1023]); }
     __threadfence_block();
     __syncthreads();
@@ -338,14 +426,14 @@ __global__ __launch_bounds__(1024) void k_scan_waves(const uint32_t* countPtr, u
         g = min(g, N);
         uint32_t w = g >> 6, l = g & 63;
         uint32_t v = part[1023];
-        if (w < nW) v = waveCounts[w] + (uint32_t)__popcll(contMask[w] & ((1ull << l) - 1ull));
+        if (w < nW) v = blockSums[w / SCAN_WAVES_PER_BLOCK] + waveLocal[w] + (uint32_t)__popcll(contMask[w] & ((1ull << l) - 1ull));
         nextBase[t] = v;
     }
 }
 
 // Scatter of the surviving ray indices (and their sort keys) to their ordered slots.
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_compact(const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm, const unsigned long long* contMask, const uint32_t* waveOffsets,
+__global__ __launch_bounds__(256) void k_compact(const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm, const unsigned long long* contMask, const uint32_t* waveOffsets, const uint32_t* blockBase,
                                                  const uint32_t* keysTmp, uint32_t* queueNext, uint32_t* keysNext)
 {
     const uint32_t N = FIRST ? countImm : *countPtr;
@@ -354,7 +442,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* queue, const ui
     const uint32_t w = slot >> 6, lane = slot & 63;
     unsigned long long m = contMask[w];
     if ((m >> lane) & 1ull) {
-        uint32_t dst = waveOffsets[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        uint32_t dst = blockBase[w / SCAN_WAVES_PER_BLOCK] + waveOffsets[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         queueNext[dst] = FIRST ? slot : queue[slot];
         keysNext[dst] = keysTmp[slot];
     }
@@ -461,6 +549,13 @@ __global__ __launch_bounds__(256) void k_final_draw(Frame f, RayBufs rays, float
     if (f.outputAovs) { imgAlbedo[i] = make_float4(ra.x, ra.y, ra.z, 1.0f); imgNormal[i] = make_float4(rn.x, rn.y, rn.z, 1.0f); }
 }
 
+// test support (idkptEnablePrimaryHitCapture): miss records for the pixels the pre-cull removes before the traversal
+__global__ void k_fill_miss(float4* hit, uint32_t* xform, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { hit[i] = make_float4(PT_FLOAT_MAX, 0.0f, 0.0f, __uint_as_float(~0u)); xform[i] = 0; }
+}
+
 // derived layout: positions of each BLAS triangle's vertices, in leaf order (48 B/triangle, one contiguous fetch in the leaf loop)
 __global__ void k_gather_triverts(const uint4* tris, const float* positions, float4* triVerts, uint32_t first, uint32_t count)
 {
@@ -547,7 +642,7 @@ struct idkpt_ctx {
     int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0;
     float invProj[16], invView[16], viewPos[3];
     uint32_t accumulated = 0;
-    bool counters = false, timing = false, capturePrimary = false, forceGeneric = false;
+    bool counters = false, timing = false, capturePrimary = false, forceGeneric = false; int traceVariant = 0;
     // scene
     bool haveScene = false;
     DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes;
@@ -558,7 +653,7 @@ struct idkpt_ctx {
     int nodeCount = 0, triCount = 0, instanceCount = 0, tlasCount = 0, vertexCount = 0, meshCount = 0, materialCount = 0, xformCount = 0, lightCount = 0, skySize = 0, textureCount = 0, unskinnedCount = 0;
     int sceneStack = 1;
     // wavefront state
-    DevBuf rayO, rayT, rayR, aovA, aovN, hit, hitX, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, contMask, waveCounts, counts, work, sortHist, counters64;
+    DevBuf trLo, trLd, trInv, contFlag, blockSums, rayO, rayT, rayR, aovA, aovN, hit, hitX, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, contMask, waveCounts, counts, work, sortHist, counters64;
     DevBuf img[3];
     float4* extImg[3] = {nullptr, nullptr, nullptr};
     uint32_t slotBases[MAX_DEPTH_SLOTS];
@@ -593,6 +688,39 @@ static int fail(idkpt_ctx* c, int code, const std::string& msg) { if (c) c->last
 
 static int local_rows(int H, int mod, int rem) { int n = 0; for (int y = rem; y < H; y += mod) n++; return n; }
 
+template <bool PRIMARY>
+static void launch_trace2(idkpt_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
+                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters)
+{
+    if (ctx->counters) { hipLaunchKernelGGL((k_trace2<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return; }
+    switch (ctx->traceVariant) {   // developer A/B knob (IDKPT_TRACE_VARIANT); all variants are bit-identical
+        case 1: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 8, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 2: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 3: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 1, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 4: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 5: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 8, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 7: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 8: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 9: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 10: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 11: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 12: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 13: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 20: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 21: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 22: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 40>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 23: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 48, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 24: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 48, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 25: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 24, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 26: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 40, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 27: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 64, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 28: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 48, 1, false, 40>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 29: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 64, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 6: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 4, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        default: hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+    }
+}
+
 static int alloc_frame(idkpt_ctx* ctx)
 {
     const size_t N = (size_t)ctx->W * ctx->rows;
@@ -601,17 +729,19 @@ static int alloc_frame(idkpt_ctx* ctx)
     ctx->pending.clear();
     HIPC(ctx->rayO.ensure(cap * 16)); HIPC(ctx->rayT.ensure(cap * 16)); HIPC(ctx->rayR.ensure(cap * 16));
     HIPC(ctx->aovA.ensure(cap * 16)); HIPC(ctx->aovN.ensure(cap * 16));
+    HIPC(ctx->trLo.ensure(cap * 16)); HIPC(ctx->trLd.ensure(cap * 16)); HIPC(ctx->trInv.ensure(cap * 16)); HIPC(ctx->contFlag.ensure(cap));
+    HIPC(ctx->blockSums.ensure(((cap + 63) / 64 + SCAN_WAVES_PER_BLOCK - 1) / SCAN_WAVES_PER_BLOCK * 4 + 16));
     HIPC(ctx->hit.ensure(cap * 16)); HIPC(ctx->hitX.ensure(cap * 4)); HIPC(ctx->hitCost.ensure(cap * 4));
     for (int i = 0; i < 2; i++) { HIPC(ctx->queue[i].ensure(cap * 4)); HIPC(ctx->keys[i].ensure(cap * 4)); }
     HIPC(ctx->keysTmp.ensure(cap * 4)); HIPC(ctx->sortKeys.ensure(cap * 4)); HIPC(ctx->sortVals.ensure(cap * 4));
     size_t nW = (cap + 63) / 64;
     HIPC(ctx->contMask.ensure(nW * 8)); HIPC(ctx->waveCounts.ensure(nW * 4));
-    HIPC(ctx->counts.ensure(MAX_DEPTH_SLOTS * 4)); HIPC(ctx->work.ensure(4 * MAX_DEPTH_SLOTS * 4)); HIPC(ctx->counters64.ensure(32));
+    HIPC(ctx->counts.ensure(MAX_DEPTH_SLOTS * 4)); HIPC(ctx->work.ensure(4 * MAX_DEPTH_SLOTS * 4)); HIPC(ctx->counters64.ensure(128));
     HIPC(ctx->bases.ensure((size_t)MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4));
     size_t nTiles = (cap + SORT_TILE - 1) / SORT_TILE;
     HIPC(ctx->sortHist.ensure(SORT_RADIX * nTiles * 4));
     for (int i = 0; i < 3; i++) { HIPC(ctx->img[i].ensure(N * 16)); HIPC(hipMemsetAsync(ctx->img[i].p, 0, N * 16, ctx->stream)); }
-    HIPC(hipMemsetAsync(ctx->counters64.p, 0, 32, ctx->stream));
+    HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream));
     HIPC(hipMemsetAsync(ctx->aovA.p, 0, cap * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, cap * 16, ctx->stream));
     ctx->accumulated = 0;
     return IDKPT_OK;
@@ -668,6 +798,7 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
     memset(ctx->hBases, 0, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4);
     (void)hipEventCreate(&ctx->evFrame[0]); (void)hipEventCreate(&ctx->evFrame[1]);
     if (const char* e = getenv("IDKPT_FORCE_GENERIC")) ctx->forceGeneric = atoi(e) != 0;
+    if (const char* e = getenv("IDKPT_TRACE_VARIANT")) ctx->traceVariant = atoi(e);
     *outCtx = ctx;
     return IDKPT_OK;
 }
@@ -679,7 +810,7 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -1031,32 +1162,43 @@ static int flush_batch(idkpt_ctx* ctx)
     const int BS = MAX_BATCH + 1;
 
     // ---- FirstHit
-    uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (capacity uints), free at this point of the batch
+    uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (capacity uints), free until the first sort
     uint32_t* activeCount = counts + (MAX_DEPTH_SLOTS - 1);
+    TraceBufs tr = {ctx->trLo.as<float4>(), ctx->trLd.as<float4>(), ctx->trInv.as<float4>()};
+    TraceBufs trNone = {nullptr, nullptr, nullptr};
+    uint32_t* waveLocal = waveCounts;                     // per-wave exclusive offset inside its 256-wave scan block
+    uint32_t* blockSums = ctx->blockSums.as<uint32_t>();
+    const uint32_t scanBlocks = ((total + 63) / 64 + SCAN_WAVES_PER_BLOCK - 1) / SCAN_WAVES_PER_BLOCK;
+    uint32_t* keysTmp = ctx->keysTmp.as<uint32_t>();
     {
         if (fast) {
             const uint32_t tilesX = ((uint32_t)f.W + 7) / 8, tilesY = ((uint32_t)f.rows + 7) / 8;
             const uint32_t genWaves = tilesX * tilesY;
             const int cull = f.g.DoTraceLights ? 0 : 1;
-            hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 3) / 4, B), dim3(256), 0, st, s, f, rays, hits, cull, activeList, activeCount);
+            HIPC(hipMemsetAsync(ctx->contFlag.p, 0, total, st));
+            if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits.hit + (size_t)(B - 1) * Npad, hits.xformId + (size_t)(B - 1) * Npad, N);
+            hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 3) / 4, B), dim3(256), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp);
             TRACE_T0();
-            if (ctx->counters) hipLaunchKernelGGL((k_trace2<true, true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
-            else hipLaunchKernelGGL((k_trace2<true, false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
+            launch_trace2<true>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
+            if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.as<float4>() + (size_t)(B - 1) * Npad, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
+            hipLaunchKernelGGL(k_shade_first, dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp);
+            hipLaunchKernelGGL((k_scan_local<true>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)ctx->contFlag.as<uint8_t>(), contMask, waveLocal, blockSums);
         } else {
             TRACE_T0();
             uint32_t g = std::min<uint32_t>(traceGrid, (N + 63) / 64);
             if (ctx->counters) { if (debug) hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<true, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
             else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
             TRACE_T1();
+            if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.p, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
+            hipLaunchKernelGGL((k_shade<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, trNone, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const uint32_t*)nullptr, 0u,
+                               contMask, waveCounts, keysTmp);
+            hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
         }
-        if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.as<float4>() + (size_t)(B - 1) * Npad, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
-        hipLaunchKernelGGL((k_shade<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const uint32_t*)nullptr, 0u,
-                           contMask, waveCounts, ctx->keysTmp.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, (const uint32_t*)nullptr, total, waveCounts, counts + 1, (unsigned long long*)(1 < depth ? counters + 2 : nullptr),
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, (const uint32_t*)nullptr, total, blockSums, (const uint32_t*)waveLocal, counts + 1, (unsigned long long*)(1 < depth ? counters + 2 : nullptr),
                            (const unsigned long long*)contMask, (const uint32_t*)nullptr, Npad, B, bases + 1 * BS);
-        hipLaunchKernelGGL((k_compact<true>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const unsigned long long*)contMask, (const uint32_t*)waveCounts,
-                           (const uint32_t*)ctx->keysTmp.as<uint32_t>(), ctx->queue[1].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
+        hipLaunchKernelGGL((k_compact<true>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const unsigned long long*)contMask, (const uint32_t*)waveLocal, (const uint32_t*)blockSums,
+                           (const uint32_t*)keysTmp, ctx->queue[1].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
     }
     int side = 1; // queue[side] holds the rays entering bounce j, its length is counts[j], sample k starts at bases[j][k]
     for (int j = 1; j < depth; j++) {
@@ -1078,20 +1220,19 @@ static int flush_batch(idkpt_ctx* ctx)
             if (va != q) HIPC(hipMemcpyAsync(q, va, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
         }
         TRACE_T0();
-        if (fast) {
-            if (ctx->counters) hipLaunchKernelGGL((k_trace2<false, true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
-            else hipLaunchKernelGGL((k_trace2<false, false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
-        } else {
+        if (fast) launch_trace2<false>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)q, cnt, work + j, counters);
+        else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
         }
         TRACE_T1();
-        hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), ctx->slotBases[j],
-                           contMask, waveCounts, ctx->keysTmp.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, cnt, 0u, waveCounts, counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr),
+        hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, fast ? tr : trNone, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), ctx->slotBases[j],
+                           contMask, waveCounts, keysTmp);
+        hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, cnt, 0u, blockSums, (const uint32_t*)waveLocal, counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr),
                            (const unsigned long long*)contMask, (const uint32_t*)(bases + j * BS), Npad, B, bases + (j + 1) * BS);
-        hipLaunchKernelGGL((k_compact<false>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)q, cnt, 0u, (const unsigned long long*)contMask, (const uint32_t*)waveCounts,
-                           (const uint32_t*)ctx->keysTmp.as<uint32_t>(), ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
+        hipLaunchKernelGGL((k_compact<false>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)q, cnt, 0u, (const unsigned long long*)contMask, (const uint32_t*)waveLocal, (const uint32_t*)blockSums,
+                           (const uint32_t*)keysTmp, ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
         side = 1 - side;
     }
     ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast; ctx->lastBatch = B;
@@ -1232,6 +1373,7 @@ int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* out)
     uint64_t c[4] = {0, 0, 0, 0};
     HIPC(hipMemcpy(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost));
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
+    if (ctx->traceVariant == 7 || ctx->traceVariant == 13) { uint64_t d[16]; HIPC(hipMemcpy(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13]); }
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
     *out = s;
     return IDKPT_OK;
@@ -1246,7 +1388,7 @@ int32_t idkptResetStats(idkpt_ctx* ctx)
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;
     memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4);
-    HIPC(hipMemset(ctx->counters64.p, 0, 32));
+    HIPC(hipMemset(ctx->counters64.p, 0, 128));
     return IDKPT_OK;
 }
 

@@ -48,6 +48,11 @@ struct RayBufs {                // SoA planes of the reference's GpuWavefrontRay
     float4* aovA;               // Albedo.xyz, NewWeight
     float4* aovN;               // Normal.xyz, pad
 };
+struct TraceBufs {              // derived, per ray id: the ray in BLAS-local space, ready for the traversal kernel (single-instance fast path)
+    float4* lo;                 // RayTransform(origin)   (Ray.glsl:7-12)
+    float4* ld;                 // RayTransform(direction), not renormalised
+    float4* inv;                // 1 / ld                 (IntersectionRoutines.glsl:29)
+};
 struct HitBufs {                // indexed by queue slot
     float4* hit;                // T, BaryXY.x, BaryXY.y, TriangleId (bits)
     uint32_t* xformId;          // MeshTransformId or light index

@@ -13,9 +13,10 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
     depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     sc = get_scene(n)
     pt = PathTracer(1920, 1080)
-    pt.UploadScene(sc); pt.SetCamera(S.Camera(1920, 1080)); pt.RayDepth = depth
+    pt.UploadScene(sc); pt.SetCamera(S.Camera(1920, 1080)); pt.RayDepth = depth; pt.set_max_batch(batch)
     for _ in range(3):
         pt.ResetAccumulation(); pt.Compute()
     pt.synchronize(); pt.reset_stats()

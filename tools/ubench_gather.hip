@@ -19,6 +19,17 @@ __global__ __launch_bounds__(64) void k_gather(const float4* __restrict__ buf, u
     uint32_t lane = threadIdx.x;
     uint32_t gid = blockIdx.x * 64 + lane;
     uint32_t acc = 0;
+    if (MODE >= 3) { // as A, but only every 2nd (MODE 3) / 4th (MODE 4) lane active, or a random half (MODE 5): does the memory pipeline charge for masked lanes?
+        bool on = MODE == 3 ? (lane & 1) == 0 : MODE == 4 ? (lane & 3) == 0 : (hash32(lane * 7919u) & 1) == 0;
+        uint32_t idx = hash32(gid) & nBlocksMask;
+        if (on) for (int i = 0; i < iters; i++) {
+            const float4* p = buf + (size_t)idx * 4;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            uint32_t v = __float_as_uint(a.x) ^ __float_as_uint(b.w) ^ __float_as_uint(c.y) ^ __float_as_uint(d.z);
+            acc += v;
+            idx = hash32(idx ^ v) & nBlocksMask;
+        }
+    } else
     if (MODE == 0 || MODE == 2) {
         uint32_t idx = hash32(gid) & nBlocksMask;
         for (int i = 0; i < iters; i++) {
@@ -49,14 +60,14 @@ int main()
     int cus = prop.multiProcessorCount;
     printf("device %s CUs %d clock %d kHz\n", prop.name, cus, prop.clockRate);
     uint32_t* out; CHECK(hipMalloc(&out, 4));
-    for (int logBlocks : {16, 20, 24}) { // 4 MB, 64 MB, 1 GB of 64-B blocks
+    for (int logBlocks : {20}) { // 4 MB, 64 MB, 1 GB of 64-B blocks
         size_t nBlocks = (size_t)1 << logBlocks;
         float4* buf; CHECK(hipMalloc(&buf, nBlocks * 64));
         std::vector<uint32_t> h(nBlocks * 16);
         uint32_t s = 12345; for (auto& x : h) { s = s * 1664525u + 1013904223u; x = s; }
         CHECK(hipMemcpy(buf, h.data(), nBlocks * 64, hipMemcpyHostToDevice));
-        for (int wavesPerCU : {8, 16, 32}) {
-            for (int mode = 0; mode < 3; mode++) {
+        for (int wavesPerCU : {16, 32}) {
+            for (int mode = 0; mode < 6; mode++) {
                 int iters = 2000;
                 dim3 grid(cus * wavesPerCU), block(64);
                 hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -65,12 +76,15 @@ int main()
                     if (mode == 0) hipLaunchKernelGGL(k_gather<0>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out);
                     if (mode == 1) hipLaunchKernelGGL(k_gather<1>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out);
                     if (mode == 2) hipLaunchKernelGGL(k_gather<2>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out);
+                    if (mode == 3) hipLaunchKernelGGL(k_gather<3>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out);
+                    if (mode == 4) hipLaunchKernelGGL(k_gather<4>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out);
+                    if (mode == 5) hipLaunchKernelGGL(k_gather<5>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out);
                     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
                 }
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-                double fetches = (double)grid.x * (mode == 1 ? 16 : 64) * iters; // 64-B (or 32-B for mode 2) block fetches
+                double fetches = (double)grid.x * (mode == 1 ? 16 : mode == 3 ? 32 : mode == 4 ? 16 : mode == 5 ? 32 : 64) * iters; // 64-B (or 32-B for mode 2) block fetches
                 double perSec = fetches / (ms * 1e-3);
-                printf("set %4zu MB waves/CU %2d mode %c: %8.3f ms  %7.2f Gfetch/s  %6.3f fetch/clk/CU@2.4GHz  %7.1f GB/s\n", nBlocks * 64 >> 20, wavesPerCU, "ABC"[mode], ms, perSec / 1e9,
+                printf("set %4zu MB waves/CU %2d mode %c: %8.3f ms  %7.2f Gfetch/s  %6.3f fetch/clk/CU@2.4GHz  %7.1f GB/s\n", nBlocks * 64 >> 20, wavesPerCU, "ABCDEF"[mode], ms, perSec / 1e9,
                        perSec / cus / 2.4e9, perSec * (mode == 2 ? 32 : 64) / 1e9);
             }
         }
