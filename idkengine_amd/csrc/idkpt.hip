@@ -95,8 +95,9 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 // and pre-culls rays whose root-box test (BVHIntersect.glsl:32-39 with T = FLOAT_MAX) fails: those get their miss
 // record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
 // wave) to an unordered active list; results are stored per pixel, so the list order is free.
-__global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut)
+__global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut)
 {
+    __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase;
     const uint32_t smp = blockIdx.y;                                   // sample of the batch
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
@@ -134,13 +135,14 @@ __global__ __launch_bounds__(256) void k_gen_primary(DScene s, Frame f, RayBufs 
         rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
         rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, pd.y);
     }
-    unsigned long long m = __ballot(keep);
-    if (m) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(activeCount, (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (keep) activeList[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rid;
-    }
+    // append the survivors: one atomic per 16-wave workgroup (a single counter word saturates at ~88 atomics/us)
+    const unsigned long long m = __ballot(keep);
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 0) waveKeep[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (int i = 0; i < 16; i++) { uint32_t c = waveKeep[i]; waveKeep[i] = tot; tot += c; } blockBase = tot ? atomicAdd(activeCount, tot) : 0u; }
+    __syncthreads();
+    if (keep) activeList[blockBase + waveKeep[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rid;
 }
 
 // k_trace2: persistent waves; every lane owns one ray at a time and is refilled from the work list as soon as enough
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         if (workLeft && ((uint32_t)__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
             const uint32_t n = (uint32_t)__popcll(idle);
             if (PROF) { pn[0]++; pn[1] += n; }
-            const uint32_t base = wave_grab(workCounter, n);
+            const uint32_t base = wave_grab(workCounter, n);      // (chunked grabbing was measured: no gain, worse balance at small N)
             const uint32_t item = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (base + n >= N) workLeft = false;
             if (!active && item < N) {
@@ -1177,7 +1179,7 @@ static int flush_batch(idkpt_ctx* ctx)
             const int cull = f.g.DoTraceLights ? 0 : 1;
             HIPC(hipMemsetAsync(ctx->contFlag.p, 0, total, st));
             if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits.hit + (size_t)(B - 1) * Npad, hits.xformId + (size_t)(B - 1) * Npad, N);
-            hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 3) / 4, B), dim3(256), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp);
+            hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 15) / 16, B), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp);
             TRACE_T0();
             launch_trace2<true>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
