@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tris", type=int, default=N_TRIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=4, help="samples the library may defer and trace together (idkptSetMaxBatch; results are bit-identical)")
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 128")
     args = ap.parse_args()
 
     import numpy as np
@@ -45,6 +45,7 @@ def main():
     from idkengine_amd import dist as D
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.batch = max(1, min(128, args.batch * world))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")

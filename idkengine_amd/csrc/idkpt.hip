@@ -98,8 +98,10 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut)
 {
     __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase;
-    const uint32_t smp = blockIdx.y;                                   // sample of the batch
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
+    // rays of the same screen region (all samples) together -> coherent waves in the traversal kernel
+    const uint32_t smp = blockIdx.x;                                   // sample of the batch
+    const uint32_t wave = (blockIdx.y * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
     const uint32_t tx = wave % tilesX, ty = wave / tilesX;
     const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
@@ -718,6 +720,7 @@ static void launch_trace2(idkpt_ctx* ctx, uint32_t grid, size_t lds, hipStream_t
         case 27: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 64, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
         case 28: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 48, 1, false, 40>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
         case 29: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 64, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 30: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
         case 6: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 4, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
         default: hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
     }
@@ -1179,7 +1182,7 @@ static int flush_batch(idkpt_ctx* ctx)
             const int cull = f.g.DoTraceLights ? 0 : 1;
             HIPC(hipMemsetAsync(ctx->contFlag.p, 0, total, st));
             if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits.hit + (size_t)(B - 1) * Npad, hits.xformId + (size_t)(B - 1) * Npad, N);
-            hipLaunchKernelGGL(k_gen_primary, dim3((genWaves + 15) / 16, B), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp);
+            hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp);
             TRACE_T0();
             launch_trace2<true>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
@@ -1276,7 +1279,7 @@ int32_t idkptFlush(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT
 int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
-    REQUIRE(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..8");
+    REQUIRE(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..128");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     HIPC(hipStreamSynchronize(ctx->stream));

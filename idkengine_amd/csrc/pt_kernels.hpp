@@ -37,9 +37,9 @@ struct Frame {
     uint32_t accumulated;       // AccumulatedSamples of sample 0 of the batch (== accum[0])
     int useTlas, stackCap, outputAovs;
     // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
-    int batch; uint32_t Npad; uint32_t accum[8];
+    int batch; uint32_t Npad; uint32_t accum[128];
 };
-#define MAX_BATCH 8
+#define MAX_BATCH 128
 
 struct RayBufs {                // SoA planes of the reference's GpuWavefrontRay / GpuAovRay, indexed by local pixel
     float4* o_ior;              // Origin.xyz, PreviousIOROrTraverseCost

@@ -105,6 +105,7 @@ class GpuShardRenderer:
         self.pt.Compute()
 
     def local_image(self):
+        self.pt.flush()   # launch whatever the library still defers; the collective that follows is stream-ordered behind it
         ptr, nbytes = self.pt.image_device_ptr(0)
         assert nbytes == self.rows * self.width * 16
         return torch.as_tensor(_DevArray(ptr, (self.rows, self.width, 4)), device=self.device)

@@ -295,6 +295,32 @@ def test_refit_and_skinning_match_oracle(oracle_mod, oracle_builder, native_buil
     pt.Dispose()
 
 
+def test_sharded_frame_over_rccl_world1(native_builder):
+    """The multi-GPU driver path of dist.py / bench.py on one GPU: process group "nccl" (RCCL) with world_size 1, scene
+    broadcast through GPU tensors, renderer on torch's stream, zero-copy alias of the device image, all_gather."""
+    import torch
+    import torch.distributed as dist
+    from idkengine_amd import dist as D
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sc = D.broadcast_scene(S.cornell_scene(native_builder, "mixed"), src=0, device=torch.device("cuda", 0))
+        cam = S.cornell_camera(96, 64)
+        r = D.GpuShardRenderer(96, 64, 1, 0, 0); r.upload_scene(sc); r.set_camera(cam); r.pt.RayDepth = 2; r.pt.set_max_batch(4)
+        frame = D.ShardedFrame(r, 96, 64)
+        for _ in range(4):
+            frame.render()
+        full = frame.gather().cpu().numpy()
+        ref = gpu_render(sc, cam, 96, 64, RayDepth=2)
+        assert (bits(full) == bits(ref.Result)).all()
+        ref.Dispose(); r.pt.Dispose()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_error_paths_fail_loudly(native_builder):
     from idkengine_amd.pathtracer import PathTracer, IdkPtError
     pt = PathTracer(64, 64)
