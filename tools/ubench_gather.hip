@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <vector>
+#include <stdlib.h>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -54,13 +55,14 @@ __global__ __launch_bounds__(64) void k_gather(const float4* __restrict__ buf, u
     if (acc == 0x12345678u) out[0] = acc;
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    int onlyLog = argc > 1 ? atoi(argv[1]) : 20; int onlyMode = argc > 2 ? atoi(argv[2]) : -1;
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     int cus = prop.multiProcessorCount;
     printf("device %s CUs %d clock %d kHz\n", prop.name, cus, prop.clockRate);
     uint32_t* out; CHECK(hipMalloc(&out, 4));
-    for (int logBlocks : {20}) { // 4 MB, 64 MB, 1 GB of 64-B blocks
+    for (int logBlocks : {onlyLog}) { // 4 MB, 64 MB, 1 GB of 64-B blocks
         size_t nBlocks = (size_t)1 << logBlocks;
         float4* buf; CHECK(hipMalloc(&buf, nBlocks * 64));
         std::vector<uint32_t> h(nBlocks * 16);
@@ -68,6 +70,7 @@ int main()
         CHECK(hipMemcpy(buf, h.data(), nBlocks * 64, hipMemcpyHostToDevice));
         for (int wavesPerCU : {16, 32}) {
             for (int mode = 0; mode < 6; mode++) {
+                if (onlyMode >= 0 && mode != onlyMode) continue;
                 int iters = 2000;
                 dim3 grid(cus * wavesPerCU), block(64);
                 hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
