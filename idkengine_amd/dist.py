@@ -90,8 +90,10 @@ class GpuShardRenderer:
         torch.cuda.set_device(device_index)
         self.device = torch.device("cuda", device_index)
         self.pt = PathTracer(width, height, device=device_index, row_modulo=world, row_remainder=rank)
-        # run on torch's current stream so that collectives issued through torch are ordered after the render
-        self.pt.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # render on a dedicated torch stream and issue the collectives under it: RCCL work is then ordered after the
+        # kernels that produce the image, and later renders are ordered after the collective that reads it
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.pt.set_stream(self.stream.cuda_stream)
         self.width, self.height, self.rows = width, height, self.pt.rows
 
     def upload_scene(self, scene):
@@ -103,6 +105,9 @@ class GpuShardRenderer:
     def render(self):
         self.pt.ResetAccumulation()
         self.pt.Compute()
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
 
     def local_image(self):
         self.pt.flush()   # launch whatever the library still defers; the collective that follows is stream-ordered behind it
@@ -127,6 +132,12 @@ class ShardedFrame:
 
     def gather(self):
         """All-gather of the row shards; returns the full (H, W, 4) image on every rank (torch tensor on the renderer's device)."""
+        import contextlib
+        ctx = self.r.stream_ctx() if hasattr(self.r, "stream_ctx") else contextlib.nullcontext()
+        with ctx:
+            return self._gather()
+
+    def _gather(self):
         local = self.r.local_image()
         if local.shape[0] < self.max_rows:  # ranks with one row less pad (all_gather needs equal shapes)
             pad = torch.zeros((self.max_rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

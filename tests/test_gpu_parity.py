@@ -232,6 +232,22 @@ def test_deferred_batching_is_bit_identical(batch, native_builder, oracle_mod):
     a.Dispose(); b.Dispose(); o.close()
 
 
+def test_batching_with_ragged_size_and_row_shard(native_builder, oracle_mod):
+    """N = 77*11 rows is not a multiple of 64: sample segments are padded (Npad) and the padding must stay inert; combined
+    with row sharding (rows y%3==1) and batch 5."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.cornell_scene(native_builder, "mixed"); cam = S.cornell_camera(77, 33)
+    p = PathTracer(77, 33, row_modulo=3, row_remainder=1); p.UploadScene(sc); p.SetCamera(cam); p.RayDepth = 5; p.DoRaySorting = 1; p.set_max_batch(5)
+    for _ in range(7):
+        p.Compute()
+    o = oracle_mod.OraclePathTracer(sc, 77, 33, row_modulo=3, row_remainder=1); o.set_camera(cam); o.settings.RayDepth = 5; o.settings.DoRaySorting = 1
+    for _ in range(7):
+        o.render()
+    assert (bits(p.Result) == bits(o.image())).all() and p.rays().tobytes() == o.rays().tobytes() and (p.alive_queue() == o.alive_queue()).all()
+    assert p.stats()["rays_traced"] == o.stats()["rays_traced"]
+    p.Dispose(); o.close()
+
+
 def test_batched_independent_frames_with_reset(native_builder):
     """The bench pattern: ResetAccumulation + Compute per step, 8 steps deferred into batches of 4; also a camera change
     in the middle must flush (pending samples belong to the old camera)."""
@@ -313,7 +329,8 @@ def test_sharded_frame_over_rccl_world1(native_builder):
         frame = D.ShardedFrame(r, 96, 64)
         for _ in range(4):
             frame.render()
-        full = frame.gather().cpu().numpy()
+        full_t = frame.gather(); torch.cuda.synchronize()
+        full = full_t.cpu().numpy()
         ref = gpu_render(sc, cam, 96, 64, RayDepth=2)
         assert (bits(full) == bits(ref.Result)).all()
         ref.Dispose(); r.pt.Dispose()
