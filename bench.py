@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tris", type=int, default=N_TRIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=RAY_DEPTH, help="RayDepth (headline = 2); other values are secondary-table runs")
+    ap.add_argument("--sort", type=int, default=0, help="DoRaySorting (headline = 0)")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 128")
     args = ap.parse_args()
 
@@ -68,7 +70,8 @@ def main():
     r = D.GpuShardRenderer(W, H, world, rank, local_rank)
     r.upload_scene(scene); r.set_camera(cam)
     pt = r.pt
-    pt.RayDepth = RAY_DEPTH; pt.SamplesPerPixel = 1; pt.DoRaySorting = 0
+    depth = args.depth
+    pt.RayDepth = depth; pt.SamplesPerPixel = 1; pt.DoRaySorting = args.sort
     frame = D.ShardedFrame(r, W, H) if world > 1 else None
 
     step_no = [0]
@@ -84,7 +87,7 @@ def main():
     step(); pt.synchronize()
     cs = pt.stats()
     pairs, tri_tests, rays_frame = cs["node_pair_visits"], cs["triangle_tests"], cs["rays_traced"]
-    traversed = cs["alive_counts"][0] + sum(cs["alive_counts"][1:RAY_DEPTH])   # rays that entered the traversal kernel
+    traversed = cs["alive_counts"][0] + sum(cs["alive_counts"][1:depth])   # rays that entered the traversal kernel
     pt.enable_counters(False)
 
     pt.set_max_batch(args.batch)
@@ -134,7 +137,7 @@ def main():
             "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene", "value": round(value, 2), "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {RAY_DEPTH}, sort off, white sky",
+            "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky",
                        "rays_per_step": int(rays_total / args.steps), "samples_in_flight": args.batch, "sharding": "rows round-robin over ranks + all-gather" if world > 1 else "none",
                        "bvh_build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -143,14 +146,14 @@ def main():
                          "node_pair_visits_per_frame": int(pairs), "triangle_tests_per_frame": int(tri_tests), "traversed_rays_per_frame": int(traversed)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cam, args.tris)
+            out["cpu_baseline"] = cpu_baseline(scene, cam, depth)
         print(json.dumps(out), flush=True)
     r.pt.Dispose()
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(scene, cam, n_tris):
+def cpu_baseline(scene, cam, depth):
     """The oracle (CPU port of the reference path, GLSL semantics, OpenMP over all host cores) on a bounded sample of the
     same frame: every m-th row, m chosen so the run takes roughly 10-30 s."""
     from oracle import oracle as O   # allowed here: cpu_baseline leg only
@@ -158,7 +161,7 @@ def cpu_baseline(scene, cam, n_tris):
 
     def run(mod):
         o = O.OraclePathTracer(scene, W, H, row_modulo=mod, row_remainder=0)
-        o.set_camera(cam); o.settings.RayDepth = RAY_DEPTH
+        o.set_camera(cam); o.settings.RayDepth = depth
         t0 = time.perf_counter(); o.render(); dt = time.perf_counter() - t0
         rays = o.stats()["rays_traced"]; rows = o.rows
         o.close()
@@ -172,7 +175,7 @@ def cpu_baseline(scene, cam, n_tris):
         rays, dt, rows = run(mod)
         tot_rays += rays; tot_dt += dt; reps += 1
     return {"value": round(tot_rays / tot_dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"rows y%{mod}==0 of the same {W}x{H} frame ({rows} rows, {rays} rays, RayDepth {RAY_DEPTH}) x {reps} repetitions = {tot_dt:.1f} s of CPU work; "
+            "sample": f"rows y%{mod}==0 of the same {W}x{H} frame ({rows} rows, {rays} rays, RayDepth {depth}) x {reps} repetitions = {tot_dt:.1f} s of CPU work; "
                       "C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET)"}
 
 

@@ -697,31 +697,9 @@ static void launch_trace2(idkpt_ctx* ctx, uint32_t grid, size_t lds, hipStream_t
                           const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters)
 {
     if (ctx->counters) { hipLaunchKernelGGL((k_trace2<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return; }
-    switch (ctx->traceVariant) {   // developer A/B knob (IDKPT_TRACE_VARIANT); all variants are bit-identical
-        case 1: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 8, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 2: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 3: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 1, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 4: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 5: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 8, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 7: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 8: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 9: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 10: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 11: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 12: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 13: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 20: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 21: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 22: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 40>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 23: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 48, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 24: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 48, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 25: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 24, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 26: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 40, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 27: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 64, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 28: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 48, 1, false, 40>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 29: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 64, 1, false, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 30: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
-        case 6: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 4, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+    switch (ctx->traceVariant) {   // developer knob (IDKPT_TRACE_VARIANT): s_memtime-instrumented builds; results are bit-identical
+        case 7: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 65>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;   // instrumented, old policy
+        case 13: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;  // instrumented, default policy
         default: hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
     }
 }
