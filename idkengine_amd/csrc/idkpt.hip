@@ -113,15 +113,20 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
         f3 origin; f2 pd; uint32_t seed;
         gen_primary(f, pix, f.accum[smp], origin, pd, seed);
         f3 rd = DecodeUnitVec(pd.x, pd.y);
-        GpuBlasInstance inst = s.instances[0];
-        M34 inv = load_inv_model(s, inst.MeshTransformId);
-        f3 lo = xform34(inv, origin, 1.0f), ld = xform34(inv, rd, 0.0f);
-        f3 invDir = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
-        keep = true;
-        if (cull) {   // root-box test of BVHIntersect.glsl:32-39 with T = FLOAT_MAX (no lights): a failing ray is a miss
-            const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
-            float t1;
-            keep = RayBoxIntersect(lo, invDir, root[0], root[1], &t1) && t1 < PT_FLOAT_MAX;
+        f3 lo = origin, ld = rd, invDir = splat3(0.0f);   // several instances: the traversal kernel transforms the world ray per instance
+        keep = !cull;
+        // root-box test of BVHIntersect.glsl:32-39 with T = FLOAT_MAX (no lights): a ray that fails it for every instance is a miss
+        for (int ii = 0; ii < s.instanceCount && (ii == 0 || cull); ii++) {
+            GpuBlasInstance inst = s.instances[ii];
+            M34 inv = load_inv_model(s, inst.MeshTransformId);
+            f3 l0 = xform34(inv, origin, 1.0f), l1 = xform34(inv, rd, 0.0f);
+            f3 iv = mk3(1.0f / l1.x, 1.0f / l1.y, 1.0f / l1.z);
+            if (s.instanceCount == 1) { lo = l0; ld = l1; invDir = iv; }
+            if (cull) {
+                const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
+                float t1;
+                if (RayBoxIntersect(l0, iv, root[0], root[1], &t1) && t1 < PT_FLOAT_MAX) keep = true;
+            }
         }
         f3 radiance = splat3(0.0f);
         if (keep) {
@@ -153,7 +158,9 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
 // never takes its next node step before its own pending leaf is tested, so every ray sees exactly the reference's
 // sequence of T updates and pushes: results (T, TriangleId, bary, visit counts) are bit-identical, only the interleaving
 // between different rays changes.
-template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24>
+// MULTI: several BLAS instances without a TLAS (the reference's default mode, BVHIntersect.glsl:275-287): every lane walks the
+// instance list itself; the trace-ready planes then hold the WORLD-space ray and the per-instance RayTransform happens here.
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, bool MULTI = false>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
     extern __shared__ uint32_t lds[];
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
 
     bool active = false, leafPending = false, workLeft = true;
     uint32_t top = 0, slot = 0, leafFirst = 0, leafEnd = 0;
+    uint32_t instIdx = 0, rayId = 0, nodeOff = 0, triOff = 0, xformId = 0;   // MULTI only: per-lane instance cursor and BLAS offsets
     int sp = 0;
     f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
     float hitT = 0.0f, hbx = 0.0f, hby = 0.0f; uint32_t hitTri = ~0u, hitXform = 0;
@@ -201,15 +209,39 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         if (RaySphereIntersect(wo, wd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hitT) { hitT = tMin < 0.0f ? tMax : tMin; hitXform = (uint32_t)i; hitTri = ~0u; }
                     }
                 }
-                // local-space ray and 1/dir were prepared by the (coherent, full-lane) kernel that produced this ray
-                { float4 a = tr.lo[idx], b = tr.ld[idx], c = tr.inv[idx]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z); }
-                float t1;
-                bool enter = RayBoxIntersect(ro, invDir, nodes[2], nodes[3], &t1) && t1 < hitT; // root test (:32-39)
-                active = true; leafPending = false; sp = 0; top = enter ? 2u : 0u;
+                if (MULTI) { rayId = idx; instIdx = 0; active = true; leafPending = false; sp = 0; top = 0u; }
+                else {
+                    // local-space ray and 1/dir were prepared by the (coherent, full-lane) kernel that produced this ray
+                    { float4 a = tr.lo[idx], b = tr.ld[idx], c = tr.inv[idx]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z); }
+                    float t1;
+                    bool enter = RayBoxIntersect(ro, invDir, nodes[2], nodes[3], &t1) && t1 < hitT; // root test (:32-39)
+                    active = true; leafPending = false; sp = 0; top = enter ? 2u : 0u;
+                }
             }
         }
         PROF_MARK(0);
         if (__ballot(active) == 0ull) { if (!workLeft) break; continue; }
+
+        if (MULTI) {
+            // lanes whose current BLAS is exhausted move on to the next instance (loop: the root test may fail right away)
+            bool adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
+            while (__any(adv)) {
+                if (adv) {
+                    const GpuBlasInstance in2 = s.instances[instIdx];
+                    const M34 inv = load_inv_model(s, in2.MeshTransformId);
+                    float4 a = tr.lo[rayId], b = tr.ld[rayId];                         // world-space origin / direction
+                    ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
+                    invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
+                    const float4* root = s.nodes + 2 * (size_t)nodeOff + 2;
+                    float t1;
+                    const bool enter = RayBoxIntersect(ro, invDir, root[0], root[1], &t1) && t1 < hitT;
+                    sp = 0; top = enter ? 2u : 0u;
+                    instIdx++;
+                }
+                adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
+            }
+        }
 
         // ---- node phase
         while (true) {
@@ -220,7 +252,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             if (PROF) { pn[2]++; pn[3] += (unsigned long long)__popcll(__ballot(canStep)); }
             if (canStep) {
                 if (COUNT) nPairs++;
-                const float4* p = nodes + 2 * (size_t)top;
+                const float4* p = MULTI ? s.nodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top;
                 float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
                 const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
                 float tMinLeft, tMinRight;
@@ -228,8 +260,9 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 const bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hitT;
                 const bool intersectLeft = hitLeft && lCount > 0, intersectRight = hitRight && rCount > 0;
                 if (intersectLeft || intersectRight) {
-                    leafFirst = (intersectLeft ? lStart : rStart) + triOffset;
-                    leafEnd = (!intersectRight ? (lStart + lCount) : (rStart + rCount)) + triOffset;
+                    const uint32_t tOff = MULTI ? triOff : triOffset;
+                    leafFirst = (intersectLeft ? lStart : rStart) + tOff;
+                    leafEnd = (!intersectRight ? (lStart + lCount) : (rStart + rCount)) + tOff;
                     leafPending = true;
                     if (COUNT) nTris += leafEnd - leafFirst;
                 }
@@ -256,14 +289,14 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 float4 a = tv[0], b = tv[1], c = tv[2];
                 float by, bz, t;
                 if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hitT) {
-                    hitTri = i; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = inst.MeshTransformId;
+                    hitTri = i; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = MULTI ? xformId : inst.MeshTransformId;
                 }
             }
             leafPending = false;
         }
         PROF_MARK(2);
-        // ---- retire finished rays
-        if (active && top == 0u) {
+        // ---- retire finished rays (MULTI: only after the last instance)
+        if (active && top == 0u && (!MULTI || instIdx >= (uint32_t)s.instanceCount)) {
             hits.hit[slot] = make_float4(hitT, hbx, hby, __uint_as_float(hitTri));
             hits.xformId[slot] = hitXform;
             active = false;
@@ -280,9 +313,13 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
 // NHit does first (decode the packed direction, NHit:93; RayTransform, BVHIntersect.glsl:281-282; 1/dir, IntersectionRoutines.glsl:29)
 DEV void write_trace_ready(const DScene& s, const TraceBufs& tr, uint32_t rid, const RayState& r)
 {
+    f3 rd = DecodeUnitVec(r.pdx, r.pdy);
+    if (s.instanceCount > 1) {   // the traversal kernel walks the instance list and transforms the world ray itself
+        tr.lo[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, 0.0f); tr.ld[rid] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+        return;
+    }
     GpuBlasInstance inst = s.instances[0];
     M34 inv = load_inv_model(s, inst.MeshTransformId);
-    f3 rd = DecodeUnitVec(r.pdx, r.pdy);
     f3 lo = xform34(inv, r.origin, 1.0f), ld = xform34(inv, rd, 0.0f);
     tr.lo[rid] = make_float4(lo.x, lo.y, lo.z, 0.0f); tr.ld[rid] = make_float4(ld.x, ld.y, ld.z, 0.0f);
     tr.inv[rid] = make_float4(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z, 0.0f);
@@ -696,6 +733,11 @@ template <bool PRIMARY>
 static void launch_trace2(idkpt_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
                           const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters)
 {
+    if (ctx->instanceCount > 1) {   // instance loop inside the kernel
+        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        return;
+    }
     if (ctx->counters) { hipLaunchKernelGGL((k_trace2<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return; }
     switch (ctx->traceVariant) {   // developer knob (IDKPT_TRACE_VARIANT): s_memtime-instrumented builds; results are bit-identical
         case 7: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 65>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;   // instrumented, old policy
@@ -1095,7 +1137,8 @@ static DScene make_dscene(idkpt_ctx* ctx)
 
 static float4* image_ptr(idkpt_ctx* ctx, int i) { return ctx->extImg[i] ? ctx->extImg[i] : ctx->img[i].as<float4>(); }
 
-static bool fast_path(idkpt_ctx* ctx) { return ctx->instanceCount == 1 && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
+// fast path = persistent while-while traversal: any number of BLAS instances as long as no TLAS is used and no debug cost is requested
+static bool fast_path(idkpt_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
 
 // One batch of B deferred samples: FirstHit -> [sort ->] NHit x (RayDepth-1) -> FinalDraw (PathTracer.cs:218-270), every
 // stage launched once for all B samples.  Sample k owns ray ids [k*Npad, k*Npad+N); alive queues are batch-wide but stay

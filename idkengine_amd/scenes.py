@@ -242,6 +242,19 @@ def soup_scene(n_tris, builder, seed=1, refittable=False, albedo=0.8, extent=10.
     return assemble([{"meshes": [MeshInput(p, i, mat, nrm, tan)], "refittable": refittable}], builder, sky_color=sky_color)
 
 
+def soup_scene_multi(n_tris, builder, parts=3, seed=1, albedo=0.8, extent=10.0, edge=0.15, sky_color=(1.0, 1.0, 1.0)):
+    """The soup split into `parts` BLASes with their own (rotated) GpuMeshTransform and no hoisting: the reference's default
+    multi-model layout (one BLAS per model, instance loop in BVHIntersect.glsl:275-287 unless UseTlas)."""
+    blases = []
+    per = n_tris // parts
+    for k in range(parts):
+        n = per if k < parts - 1 else n_tris - per * (parts - 1)
+        p, i, nrm, tan = flat_shaded(soup_triangles(n, seed + 17 * k, extent, edge))
+        mat = make_material(base_color=(albedo, albedo, albedo, 1.0), metallic=0.0, roughness=1.0)
+        blases.append({"meshes": [MeshInput(p, i, mat, nrm, tan)], "transform": None if k == 0 else rotation_y(23.0 * k) @ translation((0.5 * k, -0.25 * k, 0.0))})
+    return assemble(blases, builder, sky_color=sky_color)
+
+
 def _quad(a, b, c, d):
     return np.float32([[a, b, c], [a, c, d]])
 

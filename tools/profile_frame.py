@@ -7,7 +7,8 @@ from idkengine_amd.pathtracer import PathTracer
 
 def get_scene(n):
     from oracle import oracle as O   # dev tool only
-    return S.soup_scene(n, O.OracleBuilder())
+    parts = int(os.environ.get("PARTS", "1"))
+    return S.soup_scene(n, O.OracleBuilder()) if parts == 1 else S.soup_scene_multi(n, O.OracleBuilder(), parts)
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
