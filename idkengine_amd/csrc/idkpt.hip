@@ -113,8 +113,25 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
         f3 origin; f2 pd; uint32_t seed;
         gen_primary(f, pix, f.accum[smp], origin, pd, seed);
         f3 rd = DecodeUnitVec(pd.x, pd.y);
-        f3 lo = origin, ld = rd, invDir = splat3(0.0f);   // several instances: the traversal kernel transforms the world ray per instance
+        f3 lo = origin, ld = rd, invDir = splat3(0.0f);   // several instances / TLAS: the traversal kernel transforms the world ray per instance
         keep = !cull;
+        if (f.useTlas) {
+            // first TLAS step (BVHIntersect.glsl:242-249) with T = FLOAT_MAX: a ray that misses both children of the root is a miss
+            invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            if (cull) {
+                if (s.tlasCount == 0) keep = false;
+                else {
+                    const uint32_t packed = __float_as_uint(s.tlas[0].w), id = packed & 0x7fffffffu;
+                    if ((packed >> 31) == 1u) keep = true;
+                    else {
+                        float t1, t2;
+                        const bool tl = RayBoxIntersect(origin, invDir, s.tlas[2 * (size_t)id], s.tlas[2 * (size_t)id + 1], &t1) && t1 < PT_FLOAT_MAX;
+                        const bool tr2 = RayBoxIntersect(origin, invDir, s.tlas[2 * (size_t)id + 2], s.tlas[2 * (size_t)id + 3], &t2) && t2 < PT_FLOAT_MAX;
+                        keep = tl || tr2;
+                    }
+                }
+            }
+        } else
         // root-box test of BVHIntersect.glsl:32-39 with T = FLOAT_MAX (no lights): a ray that fails it for every instance is a miss
         for (int ii = 0; ii < s.instanceCount && (ii == 0 || cull); ii++) {
             GpuBlasInstance inst = s.instances[ii];
@@ -158,15 +175,20 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
 // never takes its next node step before its own pending leaf is tested, so every ray sees exactly the reference's
 // sequence of T updates and pushes: results (T, TriangleId, bary, visit counts) are bit-identical, only the interleaving
 // between different rays changes.
-// MULTI: several BLAS instances without a TLAS (the reference's default mode, BVHIntersect.glsl:275-287): every lane walks the
-// instance list itself; the trace-ready planes then hold the WORLD-space ray and the per-instance RayTransform happens here.
-template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, bool MULTI = false>
+// MODE 0: one BLAS instance, the trace-ready planes hold the BLAS-local ray.
+// MODE 1: several BLAS instances without a TLAS (the reference's default mode, BVHIntersect.glsl:275-287): every lane walks the
+//         instance list itself; the trace-ready planes hold the WORLD-space ray and the per-instance RayTransform happens here.
+// MODE 2: USE_TLAS (BVHIntersect.glsl:205-272): every lane walks the TLAS with its own stack (LDS rows after the BLAS rows); a
+//         TLAS leaf hands its instance to the same node/leaf phases (no root test, :32), then the TLAS walk resumes.
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
+    constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     uint32_t* stk = lds + lane;
     const int cap = f.stackCap;
+    uint32_t* tstk = stk + cap * WAVE;     // TLAS only
     const uint32_t N = *countPtr;
     // wave-uniform scene constants
     const GpuBlasInstance inst = s.instances[0];
@@ -176,7 +198,8 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
 
     bool active = false, leafPending = false, workLeft = true;
     uint32_t top = 0, slot = 0, leafFirst = 0, leafEnd = 0;
-    uint32_t instIdx = 0, rayId = 0, nodeOff = 0, triOff = 0, xformId = 0;   // MULTI only: per-lane instance cursor and BLAS offsets
+    uint32_t instIdx = 0, rayId = 0, nodeOff = 0, triOff = 0, xformId = 0;   // MULTI only: per-lane instance cursor (TLAS: next TLAS node) and BLAS offsets
+    int tsp = 0; bool moreInst = false;                                       // TLAS stack pointer; "there are instances / TLAS nodes left for this ray"
     int sp = 0;
     f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
     float hitT = 0.0f, hbx = 0.0f, hby = 0.0f; uint32_t hitTri = ~0u, hitXform = 0;
@@ -209,7 +232,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         if (RaySphereIntersect(wo, wd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hitT) { hitT = tMin < 0.0f ? tMax : tMin; hitXform = (uint32_t)i; hitTri = ~0u; }
                     }
                 }
-                if (MULTI) { rayId = idx; instIdx = 0; active = true; leafPending = false; sp = 0; top = 0u; }
+                if (MULTI) { rayId = idx; instIdx = 0; tsp = 0; moreInst = TLAS ? s.tlasCount > 0 : true; active = true; leafPending = false; sp = 0; top = 0u; }
                 else {
                     // local-space ray and 1/dir were prepared by the (coherent, full-lane) kernel that produced this ray
                     { float4 a = tr.lo[idx], b = tr.ld[idx], c = tr.inv[idx]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z); }
@@ -222,7 +245,39 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         PROF_MARK(0);
         if (__ballot(active) == 0ull) { if (!workLeft) break; continue; }
 
-        if (MULTI) {
+        if (TLAS) {
+            // lanes whose current BLAS is exhausted continue their TLAS walk until it reaches the next leaf (= instance) or ends
+            bool adv = active && !leafPending && top == 0u && moreInst;
+            while (__any(adv)) {
+                if (adv) {
+                    const float4 pmin = s.tlas[2 * (size_t)instIdx];
+                    const uint32_t packed = __float_as_uint(pmin.w), id = packed & 0x7fffffffu;
+                    if ((packed >> 31) == 1u) {                                             // leaf: BVHIntersect.glsl:223-240
+                        const GpuBlasInstance in2 = s.instances[id];
+                        const M34 inv = load_inv_model(s, in2.MeshTransformId);
+                        float4 a = tr.lo[rayId], b = tr.ld[rayId];
+                        ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
+                        invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
+                        sp = 0; top = 2u;                                                   // no root test under USE_TLAS (:32)
+                        if (tsp == 0) moreInst = false; else instIdx = tstk[--tsp * WAVE];  // the pop the reference does after the BLAS; order-independent
+                    } else {
+                        const uint32_t l = id, r = id + 1;
+                        float4 a = tr.lo[rayId], c = tr.inv[rayId];                         // world-space origin and 1/dir
+                        const f3 wo = mk3(a.x, a.y, a.z), winv = mk3(c.x, c.y, c.z);
+                        float4 lmin = s.tlas[2 * (size_t)l], lmax = s.tlas[2 * (size_t)l + 1], rmin = s.tlas[2 * (size_t)r], rmax = s.tlas[2 * (size_t)r + 1];
+                        float tMinLeft, tMinRight;
+                        const bool tl = RayBoxIntersect(wo, winv, lmin, lmax, &tMinLeft) && tMinLeft < hitT;
+                        const bool tr2 = RayBoxIntersect(wo, winv, rmin, rmax, &tMinRight) && tMinRight < hitT;
+                        if (tl || tr2) {
+                            if (tl && tr2) { const bool lc = tMinLeft < tMinRight; instIdx = lc ? l : r; if (tsp < f.tlasCap) tstk[tsp * WAVE] = lc ? r : l; tsp++; }
+                            else instIdx = tl ? l : r;
+                        } else { if (tsp == 0) moreInst = false; else instIdx = tstk[--tsp * WAVE]; }
+                    }
+                }
+                adv = active && !leafPending && top == 0u && moreInst;
+            }
+        } else if (MULTI) {
             // lanes whose current BLAS is exhausted move on to the next instance (loop: the root test may fail right away)
             bool adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
             while (__any(adv)) {
@@ -296,7 +351,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         }
         PROF_MARK(2);
         // ---- retire finished rays (MULTI: only after the last instance)
-        if (active && top == 0u && (!MULTI || instIdx >= (uint32_t)s.instanceCount)) {
+        if (active && top == 0u && (!MULTI || (TLAS ? !moreInst : instIdx >= (uint32_t)s.instanceCount))) {
             hits.hit[slot] = make_float4(hitT, hbx, hby, __uint_as_float(hitTri));
             hits.xformId[slot] = hitXform;
             active = false;
@@ -311,11 +366,12 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
 // wave are published as one 64-bit ballot + popcount for the ordered compaction that follows.
 // local-space ray + 1/dir of a continuing ray, for the next traversal launch (single-instance fast path): exactly what
 // NHit does first (decode the packed direction, NHit:93; RayTransform, BVHIntersect.glsl:281-282; 1/dir, IntersectionRoutines.glsl:29)
-DEV void write_trace_ready(const DScene& s, const TraceBufs& tr, uint32_t rid, const RayState& r)
+DEV void write_trace_ready(const DScene& s, const Frame& f, const TraceBufs& tr, uint32_t rid, const RayState& r)
 {
     f3 rd = DecodeUnitVec(r.pdx, r.pdy);
-    if (s.instanceCount > 1) {   // the traversal kernel walks the instance list and transforms the world ray itself
+    if (f.useTlas || s.instanceCount > 1) {   // the traversal kernel walks the TLAS / instance list and transforms the world ray itself
         tr.lo[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, 0.0f); tr.ld[rid] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+        if (f.useTlas) tr.inv[rid] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, 0.0f);   // world 1/dir for the TLAS slab tests (:209)
         return;
     }
     GpuBlasInstance inst = s.instances[0];
@@ -350,7 +406,7 @@ __global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs 
     rays.rad_py[rid] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
     if (f.outputAovs) { rays.aovA[rid] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[rid] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
     seedsAndKeys[rid] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
-    if (cont) { contFlag[rid] = 1; write_trace_ready(s, tr, rid, r); }
+    if (cont) { contFlag[rid] = 1; write_trace_ready(s, f, tr, rid, r); }
 }
 
 template <bool FIRST>
@@ -399,7 +455,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
             rays.thr_px[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
             rays.rad_py[idx] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
             if (f.outputAovs) { rays.aovA[idx] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[idx] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
-            if (cont && tr.lo) write_trace_ready(s, tr, idx, r);
+            if (cont && tr.lo) write_trace_ready(s, f, tr, idx, r);
         }
         // NHit:81 masks the key to 21 bits; the sample index goes above it so that the batch-wide sort stays grouped by sample
         keysTmp[slot] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
@@ -733,9 +789,14 @@ template <bool PRIMARY>
 static void launch_trace2(idkpt_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
                           const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters)
 {
+    if (f.useTlas) {                // TLAS walk inside the kernel
+        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 2>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 2>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        return;
+    }
     if (ctx->instanceCount > 1) {   // instance loop inside the kernel
-        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
-        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
         return;
     }
     if (ctx->counters) { hipLaunchKernelGGL((k_trace2<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return; }
@@ -1137,8 +1198,8 @@ static DScene make_dscene(idkpt_ctx* ctx)
 
 static float4* image_ptr(idkpt_ctx* ctx, int i) { return ctx->extImg[i] ? ctx->extImg[i] : ctx->img[i].as<float4>(); }
 
-// fast path = persistent while-while traversal: any number of BLAS instances as long as no TLAS is used and no debug cost is requested
-static bool fast_path(idkpt_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
+// fast path = persistent while-while traversal (one BLAS, instance list or TLAS); only the debug traversal-cost view uses the general kernel
+static bool fast_path(idkpt_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
 
 // One batch of B deferred samples: FirstHit -> [sort ->] NHit x (RayDepth-1) -> FinalDraw (PathTracer.cs:218-270), every
 // stage launched once for all B samples.  Sample k owns ray ids [k*Npad, k*Npad+N); alive queues are batch-wide but stay
@@ -1173,7 +1234,8 @@ static int flush_batch(idkpt_ctx* ctx)
     HIPC(hipMemsetAsync(work, 0, 4 * MAX_DEPTH_SLOTS * 4, st));
     HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
 
-    const size_t ldsBytes = (size_t)(f.stackCap + (f.useTlas ? TLAS_STACK_SIZE : 0)) * WAVE * 4;
+    f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount));
+    const size_t ldsBytes = (size_t)(f.stackCap + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;
     if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }
     // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));

@@ -36,6 +36,7 @@ struct Frame {
     GpuSettings g;
     uint32_t accumulated;       // AccumulatedSamples of sample 0 of the batch (== accum[0])
     int useTlas, stackCap, outputAovs;
+    int tlasCap;                // rows of the per-lane TLAS stack (<= TLAS_STACK_SIZE; a TLAS over n instances is never deeper than n)
     // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
     int batch; uint32_t Npad; uint32_t accum[128];
 };
@@ -164,7 +165,7 @@ DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, fl
             bool tl = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft < hit.T;
             bool tr = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight < hit.T;
             if (tl || tr) {
-                if (tl && tr) { bool lc = tMinLeft < tMinRight; top = lc ? l : r; if (sp < TLAS_STACK_SIZE) tstk[sp * stride] = lc ? r : l; sp++; }
+                if (tl && tr) { bool lc = tMinLeft < tMinRight; top = lc ? l : r; if (sp < f.tlasCap) tstk[sp * stride] = lc ? r : l; sp++; }
                 else top = tl ? l : r;
             } else { if (sp == 0) break; top = tstk[--sp * stride]; }
         }

@@ -168,6 +168,28 @@ def test_multi_instance_fast_path_equals_generic(native_builder, monkeypatch):
     a.Dispose(); b.Dispose(); c.Dispose()
 
 
+@pytest.mark.parametrize("use_tlas", [0, 1])
+def test_many_instances_fast_path(native_builder, oracle_mod, monkeypatch, use_tlas):
+    """12 rotated BLAS instances (deep PLOC TLAS when use_tlas=1): persistent kernel (instance loop / in-kernel TLAS walk) vs the
+    oracle and vs the general kernel, batched, with exact visit counters."""
+    sc = S.soup_scene_multi(6000, native_builder, parts=12, seed=5); w, h = 160, 96; cam = S.Camera(w, h)
+    ov = dict(RayDepth=4, UseTlas=use_tlas, SamplesPerPixel=3, DoRaySorting=1)
+    o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+    a = gpu_render(sc, cam, w, h, **ov)
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    c = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); c.UploadScene(sc); c.SetCamera(cam)
+    c.set_max_batch(3); c.enable_counters(True); c.Compute(); c.flush()
+    monkeypatch.setenv("IDKPT_FORCE_GENERIC", "1")
+    b = gpu_render(sc, cam, w, h, **ov)
+    assert (bits(a.Result) == bits(o.image(0))).all()
+    assert (bits(a.Result) == bits(b.Result)).all() and (bits(c.Result) == bits(b.Result)).all()
+    os_ = o.stats()
+    for k in ("node_pair_visits", "triangle_tests", "rays_traced"):
+        assert a.stats()[k] == b.stats()[k] == c.stats()[k] == os_[k], k
+    a.Dispose(); b.Dispose(); c.Dispose(); o.close()
+
+
 @pytest.fixture(scope="module")
 def soup1m(native_builder):
     return S.soup_scene(1000000, native_builder, seed=1)
