@@ -11,7 +11,7 @@ SYMBOLS = [
     "idkptCreate", "idkptDestroy", "idkptGetLastError", "idkptGetDeviceCount", "idkptGetVersionString",
     "idkptSetSize", "idkptSetRowSharding", "idkptSetSlotBases", "idkptSetSettings", "idkptGetSettings",
     "idkptSetPerFrame", "idkptSetPerFrameData", "idkptUploadScene", "idkptUpdateBuffer", "idkptSetLightCount",
-    "idkptBuildTlas", "idkptRefitBlas", "idkptUploadUnskinnedVertices", "idkptSkin", "idkptDownloadBuffer",
+    "idkptBuildTlas", "idkptBuildTlasOnDevice", "idkptRefitBlas", "idkptUploadUnskinnedVertices", "idkptSkin", "idkptDownloadBuffer",
     "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptRender", "idkptSynchronize", "idkptDownload",
     "idkptDownloadRays", "idkptDownloadAliveQueue", "idkptEnablePrimaryHitCapture", "idkptDownloadPrimaryHits",
     "idkptGetStats", "idkptResetStats", "idkptEnableCounters", "idkptEnableTiming", "idkptGetImageDevicePtr",
@@ -40,7 +40,7 @@ def load():
         "idkptGetDeviceCount": [C.POINTER(i32)], "idkptSetSize": [vp, i32, i32], "idkptSetRowSharding": [vp, i32, i32],
         "idkptSetSlotBases": [vp, vp, i32], "idkptSetSettings": [vp, vp], "idkptGetSettings": [vp, vp],
         "idkptSetPerFrame": [vp, vp, vp, vp], "idkptSetPerFrameData": [vp, vp], "idkptUploadScene": [vp, vp],
-        "idkptUpdateBuffer": [vp, i32, sz, sz, vp], "idkptSetLightCount": [vp, i32], "idkptBuildTlas": [vp, vp, i32],
+        "idkptUpdateBuffer": [vp, i32, sz, sz, vp], "idkptSetLightCount": [vp, i32], "idkptBuildTlas": [vp, vp, i32], "idkptBuildTlasOnDevice": [vp, i32],
         "idkptRefitBlas": [vp, i32], "idkptUploadUnskinnedVertices": [vp, vp, i32], "idkptSkin": [vp, u32, u32, u32, u32],
         "idkptDownloadBuffer": [vp, i32, sz, sz, vp], "idkptResetAccumulation": [vp], "idkptGetAccumulatedSamples": [vp, C.POINTER(u32)],
         "idkptRender": [vp], "idkptSynchronize": [vp], "idkptDownload": [vp, i32, vp, sz], "idkptDownloadRays": [vp, vp, sz],

@@ -664,6 +664,144 @@ __global__ void k_gather_triverts(const uint4* tris, const float* positions, flo
     o[0] = make_float4(a[0], a[1], a[2], 0.0f); o[1] = make_float4(b[0], b[1], b[2], 0.0f); o[2] = make_float4(c[0], c[1], c[2], 0.0f);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TLAS rebuild on the device: BVH.TlasBuild (Bvh/BVH.cs:278-298) + TLAS.Build (Bvh/TLAS.cs:28-141).
+// One 1024-thread workgroup (instance counts are small; the reference does this serially on the CPU every animated frame and
+// re-uploads): world bounds of every instance's BLAS root (Box.Transformed, Shapes/Box.cs:177-187), Morton-30 order (stable
+// rank = the reference's stable LSD radix sort), then PLOC rounds: every node picks its best partner inside +-searchRadius
+// (FindBestMatch, TLAS.cs:271-301, strict '<' keeps the first best), mutual pairs merge, output positions come from an ordered
+// block scan so the node array is identical to the serial build, bit for bit.
+#define TLAS_BUILD_THREADS 1024
+DEV uint32_t tlas_insert_two_zeros(uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; }
+DEV uint32_t tlas_to_uint_sat(float f) { if (f != f || f <= 0.0f) return 0u; if (f >= 4294967296.0f) return 0xffffffffu; return (uint32_t)f; }
+DEV float tlas_minN(float a, float b) { return a < b ? a : b; }   // minps / float.MinNative (Shapes/Box.cs:40-50)
+DEV float tlas_maxN(float a, float b) { return a > b ? a : b; }
+DEV float tlas_half_area(float4 mn, float4 mx) { float sx = mx.x - mn.x, sy = mx.y - mn.y, sz = mx.z - mn.z; return __fmaf_rn(sx + sy, sz, sx * sy); }   // MyMath.cs:222-229
+
+// ordered exclusive scan of two per-thread counters over the workgroup; returns this thread's bases and the totals
+DEV void block_scan2(uint32_t a, uint32_t b, uint32_t* sa, uint32_t* sb, uint32_t& baseA, uint32_t& baseB, uint32_t& totA, uint32_t& totB)
+{
+    const uint32_t t = threadIdx.x;
+    sa[t] = a; sb[t] = b;
+    __syncthreads();
+    for (uint32_t off = 1; off < TLAS_BUILD_THREADS; off <<= 1) {
+        uint32_t va = t >= off ? sa[t - off] : 0u, vb = t >= off ? sb[t - off] : 0u;
+        __syncthreads();
+        sa[t] += va; sb[t] += vb;
+        __syncthreads();
+    }
+    baseA = sa[t] - a; baseB = sb[t] - b; totA = sa[TLAS_BUILD_THREADS - 1]; totB = sb[TLAS_BUILD_THREADS - 1];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4* blasNodes, const GpuBlasDesc* descs, const GpuBlasInstance* instances, const float4* xforms,
+                                                                    int n, int searchRadius, float4* nodes /* 2n-1 */, float4* temp /* 2n-1 */, float4* leaf /* n */, uint32_t* keys /* n */, int* pref /* n */)
+{
+    __shared__ float red[6][TLAS_BUILD_THREADS / 64];
+    __shared__ float gbox[6];
+    __shared__ uint32_t sa[TLAS_BUILD_THREADS], sb[TLAS_BUILD_THREADS];
+    const int t = (int)threadIdx.x, T = TLAS_BUILD_THREADS;
+    const int nodeCount = 2 * n - 1;
+    // ---- leaves: world-space bounds of every instance
+    float mn[3] = {PT_FLOAT_MAX, PT_FLOAT_MAX, PT_FLOAT_MAX}, mx[3] = {-PT_FLOAT_MAX, -PT_FLOAT_MAX, -PT_FLOAT_MAX};
+    for (int i = t; i < n; i += T) {
+        const GpuBlasInstance in = instances[i];
+        const float4* root = blasNodes + 2 * ((size_t)descs[in.BlasId].NodeOffset + 1);
+        const float4 rmin = root[0], rmax = root[1];
+        const float4* x = xforms + 9 * (size_t)in.MeshTransformId;
+        const float4 m0 = x[0], m1 = x[1], m2 = x[2];
+        float bmn[3] = {PT_FLOAT_MAX, PT_FLOAT_MAX, PT_FLOAT_MAX}, bmx[3] = {-PT_FLOAT_MAX, -PT_FLOAT_MAX, -PT_FLOAT_MAX};
+        for (int c = 0; c < 8; c++) {
+            const float cx = (c & 1) ? rmax.x : rmin.x, cy = (c & 2) ? rmax.y : rmin.y, cz = (c & 4) ? rmax.z : rmin.z;
+            const float w[3] = {(cx * m0.x) + (cy * m0.y) + (cz * m0.z) + (1.0f * m0.w), (cx * m1.x) + (cy * m1.y) + (cz * m1.z) + (1.0f * m1.w), (cx * m2.x) + (cy * m2.y) + (cz * m2.z) + (1.0f * m2.w)};
+            for (int k = 0; k < 3; k++) { bmn[k] = tlas_minN(bmn[k], w[k]); bmx[k] = tlas_maxN(bmx[k], w[k]); }
+        }
+        leaf[2 * (size_t)i] = make_float4(bmn[0], bmn[1], bmn[2], __uint_as_float((1u << 31) | (uint32_t)i));
+        leaf[2 * (size_t)i + 1] = make_float4(bmx[0], bmx[1], bmx[2], 0.0f);
+        for (int k = 0; k < 3; k++) { mn[k] = tlas_minN(mn[k], bmn[k]); mx[k] = tlas_maxN(mx[k], bmx[k]); }
+    }
+    // global box (min/max: order independent)
+    for (int k = 0; k < 3; k++) {
+        float a = mn[k], b = mx[k];
+        for (int off = 32; off > 0; off >>= 1) { a = tlas_minN(a, __shfl_xor(a, off)); b = tlas_maxN(b, __shfl_xor(b, off)); }
+        if ((t & 63) == 0) { red[k][t >> 6] = a; red[3 + k][t >> 6] = b; }
+    }
+    __syncthreads();
+    if (t < 3) { float a = PT_FLOAT_MAX, b = -PT_FLOAT_MAX; for (int w = 0; w < T / 64; w++) { a = tlas_minN(a, red[t][w]); b = tlas_maxN(b, red[3 + t][w]); } gbox[t] = a; gbox[3 + t] = b; }
+    __syncthreads();
+    // ---- Morton-30 keys of the box centres (MyMath.cs:241-257, 283-299)
+    for (int i = t; i < n; i += T) {
+        const float4 a = leaf[2 * (size_t)i], b = leaf[2 * (size_t)i + 1];
+        const float c[3] = {(b.x + a.x) * 0.5f, (b.y + a.y) * 0.5f, (b.z + a.z) * 0.5f};
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            const float ext = gbox[3 + k] - gbox[k];
+            float r = (c[k] - gbox[k]) / ext * (1.0f - 0.0f) + 0.0f;
+            if (ext == 0.0f) r = 0.0f;
+            const uint32_t u = tlas_to_uint_sat(r * 1024.0f);
+            q[k] = u < 1023u ? u : 1023u;
+        }
+        keys[i] = (tlas_insert_two_zeros(q[0]) << 2) | (tlas_insert_two_zeros(q[1]) << 1) | tlas_insert_two_zeros(q[2]);
+    }
+    __syncthreads();
+    // ---- stable sort by key (rank counting) into the tail of the node array
+    for (int i = t; i < n; i += T) {
+        const uint32_t ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) { const uint32_t kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+        const size_t d = (size_t)(nodeCount - n + rank);
+        nodes[2 * d] = leaf[2 * (size_t)i]; nodes[2 * d + 1] = leaf[2 * (size_t)i + 1];
+    }
+    __syncthreads();
+    // ---- PLOC rounds
+    int activeCount = n, activeEnd = nodeCount;
+    while (activeCount > 1) {
+        const int start = activeEnd - activeCount;
+        for (int i = t; i < activeCount; i += T) {
+            const int a = start + i;
+            const int s0 = max(a - searchRadius, start), s1 = min(a + searchRadius + 1, activeEnd);
+            const float4 amn = nodes[2 * (size_t)a], amx = nodes[2 * (size_t)a + 1];
+            float smallest = PT_FLOAT_MAX; int best = -1;
+            for (int k = s0; k < s1; k++) {
+                if (k == a) continue;
+                const float4 omn = nodes[2 * (size_t)k], omx = nodes[2 * (size_t)k + 1];
+                const float4 un = make_float4(tlas_minN(amn.x, omn.x), tlas_minN(amn.y, omn.y), tlas_minN(amn.z, omn.z), 0.0f);
+                const float4 ux = make_float4(tlas_maxN(amx.x, omx.x), tlas_maxN(amx.y, omx.y), tlas_maxN(amx.z, omx.z), 0.0f);
+                const float area = tlas_half_area(un, ux);
+                if (area < smallest) { smallest = area; best = k; }
+            }
+            pref[i] = best - start;
+        }
+        __syncthreads();
+        // contiguous chunk per thread so that the scan order is the serial loop's order
+        const int chunk = (activeCount + T - 1) / T, c0 = min(t * chunk, activeCount), c1 = min(c0 + chunk, activeCount);
+        uint32_t nPairs = 0, nOut = 0;
+        for (int i = c0; i < c1; i++) { const int b = pref[i]; const bool mutual = b >= 0 && pref[b] == i; if (mutual && i < b) nPairs++; if (!mutual || i < b) nOut++; }
+        uint32_t basePairs, baseOut, totPairs, totOut;
+        block_scan2(nPairs, nOut, sa, sb, basePairs, baseOut, totPairs, totOut);
+        const int merged = 2 * (int)totPairs, unmerged = activeCount - merged, newNodes = merged / 2;
+        const int mergedHead0 = activeEnd - merged, newBegin = mergedHead0 - unmerged - newNodes;
+        int mergedHead = mergedHead0 + 2 * (int)basePairs, unmergedHead = newBegin + (int)baseOut;
+        for (int i = c0; i < c1; i++) {
+            const int b = pref[i]; const bool mutual = b >= 0 && pref[b] == i; const size_t aId = (size_t)(i + start);
+            if (mutual) {
+                if (i < b) {
+                    const size_t bId = (size_t)(b + start);
+                    const float4 amn = nodes[2 * aId], amx = nodes[2 * aId + 1], bmn = nodes[2 * bId], bmx = nodes[2 * bId + 1];
+                    temp[2 * (size_t)mergedHead] = amn; temp[2 * (size_t)mergedHead + 1] = amx; temp[2 * (size_t)mergedHead + 2] = bmn; temp[2 * (size_t)mergedHead + 3] = bmx;
+                    temp[2 * (size_t)unmergedHead] = make_float4(tlas_minN(amn.x, bmn.x), tlas_minN(amn.y, bmn.y), tlas_minN(amn.z, bmn.z), __uint_as_float((uint32_t)mergedHead));
+                    temp[2 * (size_t)unmergedHead + 1] = make_float4(tlas_maxN(amx.x, bmx.x), tlas_maxN(amx.y, bmx.y), tlas_maxN(amx.z, bmx.z), 0.0f);
+                    unmergedHead++; mergedHead += 2;
+                }
+            } else { temp[2 * (size_t)unmergedHead] = nodes[2 * aId]; temp[2 * (size_t)unmergedHead + 1] = nodes[2 * aId + 1]; unmergedHead++; }
+        }
+        __syncthreads();
+        for (int i = newBegin + t; i < activeEnd; i += T) { nodes[2 * (size_t)i] = temp[2 * (size_t)i]; nodes[2 * (size_t)i + 1] = temp[2 * (size_t)i + 1]; }
+        __syncthreads();
+        activeCount -= merged / 2; activeEnd -= merged;
+    }
+}
+
 // BLAS refit (Shaders/BLASRefit/compute.glsl).  The reference walks leaf->root inside one dispatch behind an
 // atomicExchange "second arrival" lock; here the same unions are evaluated level by level (deepest first), one launch
 // per level, so no workgroup ever consumes another workgroup's stores inside a launch (per-XCD L2s are not coherent).
@@ -742,7 +880,7 @@ struct idkpt_ctx {
     bool counters = false, timing = false, capturePrimary = false, forceGeneric = false; int traceVariant = 0;
     // scene
     bool haveScene = false;
-    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes;
+    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch;
     std::vector<DevBuf> texData;
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
@@ -896,7 +1034,7 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -1131,6 +1269,26 @@ int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCou
     FLUSH();
     int rc = upload(ctx, ctx->tlas, nodes, (size_t)nodeCount * 32); if (rc) return rc;
     HIPC(hipStreamSynchronize(ctx->stream));
+    ctx->tlasCount = nodeCount;
+    return IDKPT_OK;
+}
+
+int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptBuildTlasOnDevice: no scene uploaded");
+    REQUIRE(searchRadius >= 1, "idkptBuildTlasOnDevice: searchRadius must be >= 1 (reference: 15)");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    const int n = ctx->instanceCount, nodeCount = 2 * n - 1;
+    HIPC(ctx->tlas.ensure((size_t)nodeCount * 32));
+    // scratch: temp nodes (2n-1) + leaves (n) as float4 pairs, keys (n), pref (n)
+    const size_t tempOff = 0, leafOff = (size_t)nodeCount * 32, keyOff = leafOff + (size_t)n * 32, prefOff = keyOff + (size_t)n * 4;
+    HIPC(ctx->tlasScratch.ensure(prefOff + (size_t)n * 4));
+    char* sc = ctx->tlasScratch.as<char>();
+    hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(),
+                       ctx->xforms.as<float4>(), n, (int)searchRadius, ctx->tlas.as<float4>(), (float4*)(sc + tempOff), (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff));
+    HIPC(hipGetLastError());
     ctx->tlasCount = nodeCount;
     return IDKPT_OK;
 }

@@ -160,3 +160,7 @@ class Scene:
             keep.append(arr)
             d.Textures, d.TextureCount = C.addressof(arr), len(self.textures)
         return d, keep
+
+# enum idkpt_buffer (include/idkpt.h)
+(IDKPT_BUF_MESH_TRANSFORMS, IDKPT_BUF_VERTEX_POSITIONS, IDKPT_BUF_VERTICES, IDKPT_BUF_MESHES, IDKPT_BUF_MATERIALS, IDKPT_BUF_LIGHTS,
+ IDKPT_BUF_BLAS_NODES, IDKPT_BUF_TLAS_NODES, IDKPT_BUF_JOINT_MATRICES) = range(9)

@@ -150,6 +150,10 @@ class PathTracer:
         n = np.ascontiguousarray(nodes)
         self._check(self._L.idkptBuildTlas(self._ctx, n.ctypes.data, len(n)))
 
+    def BuildTlasOnDevice(self, search_radius=15):
+        """BVH.TlasBuild on the device from the resident BLAS roots / instances / mesh transforms (Bvh/BVH.cs:278-298)."""
+        self._check(self._L.idkptBuildTlasOnDevice(self._ctx, search_radius))
+
     def RefitBlas(self, blas_id):
         self._check(self._L.idkptRefitBlas(self._ctx, blas_id))
 

@@ -144,6 +144,10 @@ IDKPT_API int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offset
 IDKPT_API int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count);
 /* BVH.TlasBuild upload (Bvh/BVH.cs:278-298): host-built TLAS nodes replace SSBO 27 */
 IDKPT_API int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCount);
+/* BVH.TlasBuild + TLAS.Build (Bvh/BVH.cs:278-298, Bvh/TLAS.cs:28-141) done on the device from the resident BLAS roots, instances
+ * and mesh transforms (after idkptUpdateBuffer(MESH_TRANSFORMS)/idkptRefitBlas): no host round trip per animated frame.
+ * Node array is bit-identical to the serial host build.  searchRadius: TLAS.BuildSettings.SearchRadius (reference: 15). */
+IDKPT_API int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius);
 /* BVH.GpuBlasesRefit(blasId,1) (Bvh/BVH.cs:472-489, Shaders/BLASRefit/compute.glsl) */
 IDKPT_API int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId);
 /* ModelManager skinning dispatch (ModelManager.cs:326-353, Shaders/Skinning/compute.glsl):

@@ -190,6 +190,38 @@ def test_many_instances_fast_path(native_builder, oracle_mod, monkeypatch, use_t
     a.Dispose(); b.Dispose(); c.Dispose(); o.close()
 
 
+@pytest.mark.parametrize("parts,tris", [(1, 500), (2, 600), (3, 900), (12, 6000), (200, 4000), (1500, 6000)])
+def test_device_tlas_build_matches_host_build(native_builder, oracle_builder, parts, tris):
+    """TLAS rebuild on the device (idkptBuildTlasOnDevice: instance world bounds + Morton order + PLOC) must give the node array
+    of the serial host build (TLAS.Build, Bvh/TLAS.cs:28-141) bit for bit, also after the transforms moved."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    sc = S.soup_scene_multi(tris, native_builder, parts=parts, seed=9) if parts > 1 else S.soup_scene(tris, native_builder, seed=9)
+    pt = PathTracer(64, 64); pt.UploadScene(sc)
+    pt.BuildTlasOnDevice()
+    got = pt.DownloadBuffer(T.IDKPT_BUF_TLAS_NODES, T.GpuTlasNode, 2 * parts - 1)
+    assert got.tobytes() == sc.tlas_nodes.tobytes()
+    # move every instance (animated frame), rebuild on both sides
+    rng = np.random.default_rng(parts)
+    xf = sc.mesh_transforms.copy()
+    for i in range(len(xf)):
+        m = S.rotation_y(float(rng.uniform(0, 360))) @ S.translation(tuple(rng.uniform(-6, 6, 3)))
+        xf[i] = S.transform_from_matrix(m)[0]
+    sc.mesh_transforms = xf
+    pt.UpdateBuffer(T.IDKPT_BUF_MESH_TRANSFORMS, xf)
+    pt.BuildTlasOnDevice()
+    S.rebuild_tlas(sc, oracle_builder)
+    got = pt.DownloadBuffer(T.IDKPT_BUF_TLAS_NODES, T.GpuTlasNode, 2 * parts - 1)
+    assert got.tobytes() == sc.tlas_nodes.tobytes()
+    if parts == 12:   # and the frame traced through the device-built TLAS equals the frame through the uploaded one
+        cam = S.Camera(96, 64)
+        a = PathTracer(96, 64); a.UploadScene(sc); a.SetCamera(cam); a.UseTlas = 1; a.RayDepth = 3; a.Compute()
+        b = PathTracer(96, 64); b.UploadScene(sc); b.SetCamera(cam); b.BuildTlasOnDevice(); b.UseTlas = 1; b.RayDepth = 3; b.Compute()
+        assert (bits(a.Result) == bits(b.Result)).all()
+        a.Dispose(); b.Dispose()
+    pt.Dispose()
+
+
 @pytest.fixture(scope="module")
 def soup1m(native_builder):
     return S.soup_scene(1000000, native_builder, seed=1)
