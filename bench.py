@@ -2,11 +2,14 @@
 """bench.py — headline benchmark of the MI355X-native wavefront path tracer (driver contract: see task statement).
 
 Metric (BASELINE.json): Mray/s (primary + 1 bounce) at 1920x1080 on the synthetic 1M-triangle SweepSAH scene.
-  step      = one frame = one pass of the hot path: FirstHit -> NHit -> FinalDraw at 1 spp, RayDepth 2
+  step      = one pass of the hot path over the whole frame: FirstHit -> NHit -> FinalDraw at 1 spp, RayDepth 2
               (PathTracer.Compute, Source/Render/PathTracer.cs:214-271), scene and BVH already resident in HBM.
+              Steps accumulate progressively like the reference's render loop (AccumulatedSamples 0,1,2,...); after every
+              `samples_in_flight` steps the displayed frame is complete: its row shards are exchanged (N > 1) and the
+              accumulation is reset (PathTracer.ResetAccumulation), so every sample that is traced ends up in an exchanged image.
   value     = (N + sum_j A_j) rays of all ranks / wall time (max over ranks), exact integer ray counts from the GPU queues.
-  N GPUs    = image rows dealt round-robin to the ranks (idkengine_amd/dist.py); the frame's only exchange is the RCCL
-              all-gather of the row shards, which is inside the timed region.  Total work is fixed -> "strong" scaling.
+  N GPUs    = image rows dealt round-robin to the ranks (idkengine_amd/dist.py); the only exchange is the RCCL all-gather of
+              the finished row shards, inside the timed region.  Total work per step is fixed -> "strong" scaling.
   roofline  = traversal kernel (k_trace2): algorithmic bytes (64*P + 52*T + 104 per traversed ray) / HIP-event time of
               its launches during the timed region, against 8 TB/s HBM.
   cpu_baseline = the oracle's CPU port of the same path (all host cores, OpenMP) on a bounded sample of the same frame.
@@ -28,6 +31,7 @@ STATE_BYTES_PER_TRAVERSED_RAY = 104  # 48 B ray fetch + 4 B index + 20 B hit rec
 
 
 def main():
+    global W, H
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -36,6 +40,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=RAY_DEPTH, help="RayDepth (headline = 2); other values are secondary-table runs")
     ap.add_argument("--sort", type=int, default=0, help="DoRaySorting (headline = 0)")
+    ap.add_argument("--width", type=int, default=W, help="secondary-table runs only (headline = 1920)")
+    ap.add_argument("--height", type=int, default=H, help="secondary-table runs only (headline = 1080)")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 128")
     args = ap.parse_args()
 
@@ -65,6 +71,7 @@ def main():
     build_s = time.time() - t0
     if world > 1:
         scene = D.broadcast_scene(scene, src=0, device=device)
+    W, H = args.width, args.height
     cam = S.Camera(W, H)
 
     r = D.GpuShardRenderer(W, H, world, rank, local_rank)
@@ -74,26 +81,40 @@ def main():
     pt.RayDepth = depth; pt.SamplesPerPixel = 1; pt.DoRaySorting = args.sort
     frame = D.ShardedFrame(r, W, H) if world > 1 else None
 
+    B = args.batch
     step_no = [0]
 
+    def finish_frame():
+        if frame is not None:
+            frame.gather()                           # the displayed frame's exchange: all-gather of the accumulated row shards
+
     def step():
-        r.render()                                   # ResetAccumulation + Compute: one complete 1-spp frame (deferred by the library)
+        if step_no[0] % B == 0:
+            pt.ResetAccumulation()                   # a new displayed frame starts (PathTracer.cs:334-342)
+        pt.Compute()                                 # one 1-spp pass over the whole frame (deferred by the library)
         step_no[0] += 1
-        if frame is not None and step_no[0] % args.batch == 0:
-            frame.gather()                           # the frame's exchange: all-gather of the accumulated row shards, once per batch
+        if step_no[0] % B == 0:
+            finish_frame()
 
-    # ---- untimed counter pass: exact P (node-pair visits) and T (triangle tests) of one frame of this rank's rows
-    pt.enable_counters(True); pt.reset_stats()
-    step(); pt.synchronize()
-    cs = pt.stats()
-    pairs, tri_tests, rays_frame = cs["node_pair_visits"], cs["triangle_tests"], cs["rays_traced"]
-    traversed = cs["alive_counts"][0] + sum(cs["alive_counts"][1:depth])   # rays that entered the traversal kernel
+    # ---- untimed counter pass over one displayed frame (B samples, one at a time): exact cumulative P (node-pair visits),
+    #      T (triangle tests), traversed rays and traced rays after each sample index of this rank's rows
+    pt.enable_counters(True); pt.reset_stats(); pt.ResetAccumulation()
+    cum = [(0, 0, 0, 0)]
+    for _ in range(B):
+        pt.Compute(); pt.synchronize()
+        cs = pt.stats()
+        trav = cs["alive_counts"][0] + sum(cs["alive_counts"][1:depth])   # rays of this sample that entered the traversal kernel
+        cum.append((cs["node_pair_visits"], cs["triangle_tests"], cum[-1][2] + trav, cs["rays_traced"]))
     pt.enable_counters(False)
+    q, rem = divmod(args.steps, B)
+    pairs, tri_tests, traversed, rays_expected = (q * cum[B][i] + cum[rem][i] for i in range(4))
 
-    pt.set_max_batch(args.batch)
+    pt.set_max_batch(B)
     step_no[0] = 0
     for _ in range(args.warmup):
         step()
+    if step_no[0] % B:
+        finish_frame()
     pt.synchronize(); pt.reset_stats(); pt.enable_timing(True)
     step_no[0] = 0
     if world > 1:
@@ -102,6 +123,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if step_no[0] % B:
+        finish_frame()                               # the last, partial displayed frame is exchanged too
     pt.synchronize()                                 # launches whatever is still deferred and waits for it
     torch.cuda.synchronize()
     if world > 1:
@@ -116,34 +139,36 @@ def main():
         dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     rays_total = rays_total.item(); dt = tmax.item()
-    assert st["rays_traced"] == rays_frame * args.steps, (st["rays_traced"], rays_frame, args.steps)  # every step traced the same, complete frame
+    assert st["rays_traced"] == rays_expected, (st["rays_traced"], rays_expected, args.steps)  # every step traced its complete sample (exact ray count)
 
     if rank == 0:
         value = rays_total / dt / 1e6
         # roofline of the traversal kernel (both instantiations of k_trace2: primary + bounce), this rank
-        alg_bytes_frame = 64.0 * pairs + 52.0 * tri_tests + STATE_BYTES_PER_TRAVERSED_RAY * traversed
+        alg_bytes_total = 64.0 * pairs + 52.0 * tri_tests + STATE_BYTES_PER_TRAVERSED_RAY * traversed   # over all timed steps
         launches = max(1, st["trace_launches"])
-        alg_bytes_launch = alg_bytes_frame * args.steps / launches
+        alg_bytes_launch = alg_bytes_total / launches
         avg_launch_s = st["trace_ms_total"] * 1e-3 / launches
         achieved = alg_bytes_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from the committed PMC summary of this same command
-        if os.path.exists(prof):
+        headline = (args.tris, depth, args.sort, W, H, args.batch) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(128, 32 * world))
+        if os.path.exists(prof) and headline:        # the PMC pass was taken on the headline command only
             try:
                 traffic = json.load(open(prof)).get(f"n{world}", {}).get("traversal_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene", "value": round(value, 2), "unit": "Mray/s",
+            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri scene (secondary config)", "value": round(value, 2), "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky",
-                       "rays_per_step": int(rays_total / args.steps), "samples_in_flight": args.batch, "sharding": "rows round-robin over ranks + all-gather" if world > 1 else "none",
+                       "rays_per_step": int(rays_total / args.steps), "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": "rows round-robin over ranks + all-gather" if world > 1 else "none",
                        "bvh_build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": int(launches),
-                         "node_pair_visits_per_frame": int(pairs), "triangle_tests_per_frame": int(tri_tests), "traversed_rays_per_frame": int(traversed)},
+                         "node_pair_visits_per_step": int(pairs / args.steps), "triangle_tests_per_step": int(tri_tests / args.steps), "traversed_rays_per_step": int(traversed / args.steps),
+                         "hbm_copy_measured_gbs": hbm_copy_gbs(torch, device)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, depth)
@@ -151,6 +176,19 @@ def main():
     r.pt.Dispose()
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_copy_gbs(torch, device):
+    """Achievable HBM bandwidth on this box: device-to-device copy of 1 GiB, read + write bytes / time."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device); b = torch.empty_like(a)
+    a.zero_(); b.copy_(a); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    return round(2.0 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
 def cpu_baseline(scene, cam, depth):
