@@ -89,6 +89,121 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Adjacent consumers of the traversal core.
+// k_trace_query: batched TraceRay / TraceRayAny calls with explicit maxDist and traceLights (BVHIntersect.glsl:183-411).
+template <bool ANY>
+__global__ __launch_bounds__(WAVE) void k_trace_query(DScene s, Frame f, const idkpt_ray* rays, idkpt_hit* out, uint32_t N, int traceLights, uint32_t* workCounter)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    uint32_t* stk = lds + lane;
+    uint32_t nPairs = 0, nTris = 0;
+    while (true) {
+        uint32_t base = wave_grab(workCounter, WAVE);
+        if (base >= N) break;
+        uint32_t i = base + lane;
+        if (i < N) {
+            const float4 a = ((const float4*)rays)[2 * (size_t)i], b = ((const float4*)rays)[2 * (size_t)i + 1];
+            HitRec hit; float cost; bool h;
+            if (ANY) h = TraceRayAny(s, f, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), hit, stk, WAVE, traceLights != 0, a.w);
+            else h = TraceRay<false, false>(s, f, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), hit, cost, stk, WAVE, nPairs, nTris, traceLights != 0, a.w);
+            ((float4*)out)[2 * (size_t)i] = make_float4(hit.T, hit.bx, hit.by, __uint_as_float(hit.tri));
+            ((uint4*)out)[2 * (size_t)i + 1] = make_uint4(hit.xform, h ? 1u : 0u, 0u, 0u);
+        }
+    }
+}
+
+// k_shadows: Shaders/ShadowsRayTraced/compute.glsl:19-127 for one point shadow; one thread per pixel, 8x8 tiles per wave.
+DEV float InterleavedGradientNoise(float cx, float cy, uint32_t index) // Random.glsl:35-41
+{
+    const float add = (float)index * 5.588238f;
+    cx = cx + add; cy = cy + add;
+    return gfract(52.9829189f * gfract(0.06711056f * cx + 0.00583715f * cy));
+}
+DEV f3 SampleSphereCone(f3 toSphere, float sphereRadius, float rnd0, float rnd1, float* distanceToSphere) // Sampling.glsl:21-52 + ConstructBasis (Math.glsl:112-127)
+{
+    const float radiusSq = sphereRadius * sphereRadius;
+    const float distanceSq = dot(toSphere, toSphere);
+    const float sinThetaMaxSq = radiusSq / distanceSq;
+    const float cosThetaMax = gsqrt(gmax(1.0f - sinThetaMaxSq, 0.0f));
+    const float phiMax = 2.0f * PT_PI;
+    const float phi = phiMax * rnd0;
+    const float cosTheta = gmix(cosThetaMax, 1.0f, gmax(rnd1, 0.001f));
+    const float sinTheta = gsqrt(gmax(1.0f - cosTheta * cosTheta, 0.0f));
+    *distanceToSphere = gsqrt(dot(toSphere, toSphere)) * cosTheta - gsqrt(radiusSq - distanceSq * sinTheta * sinTheta);
+    float sp, cp; gsincos(phi, &sp, &cp);
+    const f3 local = mk3(cp * sinTheta, cosTheta, sp * sinTheta);
+    const f3 normal = normalize(toSphere);
+    const f3 up = gabs(normal.z) < 0.999f ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f);
+    const f3 tangent = normalize(cross(up, normal));
+    const f3 bitangent = cross(normal, tangent);
+    return mk3((tangent.x * local.x + normal.x * local.y) + bitangent.x * local.z,
+               (tangent.y * local.x + normal.y * local.y) + bitangent.y * local.z,
+               (tangent.z * local.x + normal.z * local.y) + bitangent.z * local.z);
+}
+__global__ __launch_bounds__(WAVE) void k_shadows(DScene s, Frame f, idkpt_shadow_params p, const float* depthImg, const float2* normalImg, float* vis)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    uint32_t* stk = lds + lane;
+    const uint32_t tilesX = ((uint32_t)p.Width + 7) / 8;
+    const int x = (int)((blockIdx.x % tilesX) * 8 + (lane & 7)), y = (int)((blockIdx.x / tilesX) * 8 + (lane >> 3));
+    if (x >= p.Width || y >= p.Height) return;
+    const size_t pix = (size_t)y * p.Width + x;
+    uint32_t noiseIndex = p.NoiseIndex, rng = 0u, nPairs = 0, nTris = 0;
+    const float depth = depthImg[pix];
+    if (depth == 1.0f) return;
+    const GpuLight& light = s.lights[p.LightIndex];
+    const f3 lightPos = mk3(light.Position[0], light.Position[1], light.Position[2]);
+    const float u = ((float)x + 0.5f) / (float)p.Width, v = ((float)y + 0.5f) / (float)p.Height;
+    const float nx = (u * 2.0f - 1.0f) - p.TaaJitter[0], ny = (v * 2.0f - 1.0f) - p.TaaJitter[1];
+    const float* m = p.InvProjView;
+    const f3 wp = mat4_mul_xyz(m, nx, ny, depth, 1.0f);
+    const float ww = ((m[3] * nx + m[7] * ny) + m[11] * depth) + m[15] * 1.0f;
+    const f3 fragPos = wp / ww;
+    const float2 nrg = normalImg[pix];
+    const f3 normal = DecodeUnitVec(nrg.x, nrg.y);
+    const float cosTheta = dot(normal, normalize(lightPos - fragPos));
+    if (cosTheta <= 0.0f) { vis[pix] = 0.0f; return; }
+    float visibility = 0.0f;
+    for (int i = 0; i < p.RayTracingSamples; i++) {
+        const f3 biased = fragPos + normal * 0.01f;
+        const float rnd0 = InterleavedGradientNoise((float)x, (float)y, noiseIndex + 0u);
+        const float rnd1 = InterleavedGradientNoise((float)x, (float)y, noiseIndex + 1u);
+        noiseIndex++;
+        const f3 fragToLight = lightPos - biased;
+        float distanceToLight;
+        const f3 direction = SampleSphereCone(fragToLight, light.Radius, rnd0, rnd1, &distanceToLight);
+        f3 ro = biased;
+        HitRec hit; float cost;
+        float thisVisibility = 1.0f;
+        while (TraceRay<false, false>(s, f, ro, direction, hit, cost, stk, WAVE, nPairs, nTris, true, distanceToLight - 0.001f)) {
+            if (hit.tri == ~0u) { if (hit.xform != (uint32_t)p.LightIndex) thisVisibility = 0.0f; break; }
+            const uint4 tri = s.tris[hit.tri];
+            const uint4 v0 = s.vertices[tri.x], v1 = s.vertices[tri.y], v2 = s.vertices[tri.z];
+            const f3 bary = mk3(hit.bx, hit.by, 1.0f - hit.bx - hit.by);
+            const float tu = __uint_as_float(v0.x) * bary.x + __uint_as_float(v1.x) * bary.y + __uint_as_float(v2.x) * bary.z;
+            const float tv = __uint_as_float(v0.y) * bary.x + __uint_as_float(v1.y) * bary.y + __uint_as_float(v2.y) * bary.z;
+            const GpuMesh& mesh = s.meshes[tri.w];
+            const GpuMaterial& mat = s.materials[mesh.MaterialId];
+            const float4 bc = SampleTex(s, mat.BaseColorTexture, tu, tv);                     // GetSurface: only Alpha / AlphaCutoff matter here
+            const float alpha = bc.w * ((float)((mat.BaseColorFactor >> 24) & 255u) / 255.0f);
+            const bool blend = mat.AlphaCutoff == 2.0f;
+            const float alphaCutoff = blend ? rnd01(rng) : mat.AlphaCutoff;
+            if (blend) thisVisibility *= 1.0f - alpha;
+            else if (alpha > alphaCutoff) thisVisibility = 0.0f;
+            if (thisVisibility < 0.01f) break;
+            const float dist = hit.T + 0.001f;
+            ro = ro + direction * dist;
+            distanceToLight -= dist;
+        }
+        visibility += thisVisibility;
+    }
+    visibility /= (float)p.RayTracingSamples;
+    vis[pix] = visibility;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Fast path (single BLAS instance, no TLAS): coherent ray generation + persistent "while-while" traversal.
 //
 // k_gen_primary: one thread per pixel, 8x8 pixel tiles per wave.  Generates the primary ray (FirstHit:44-77), stores it,
@@ -880,7 +995,7 @@ struct idkpt_ctx {
     bool counters = false, timing = false, capturePrimary = false, forceGeneric = false; int traceVariant = 0;
     // scene
     bool haveScene = false;
-    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch;
+    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut;
     std::vector<DevBuf> texData;
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
@@ -1034,7 +1149,7 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -1290,6 +1405,78 @@ int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius)
                        ctx->xforms.as<float4>(), n, (int)searchRadius, ctx->tlas.as<float4>(), (float4*)(sc + tempOff), (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff));
     HIPC(hipGetLastError());
     ctx->tlasCount = nodeCount;
+    return IDKPT_OK;
+}
+
+static DScene make_dscene(idkpt_ctx* ctx);
+// frame constants for the ray-query / shadow kernels: only the traversal-related fields are read
+static int query_frame(idkpt_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& grid)
+{
+    memset(&f, 0, sizeof(f));
+    f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;
+    f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
+    f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount));
+    ldsBytes = (size_t)(f.stackCap + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;
+    if (ldsBytes > 64 * 1024) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack");
+    int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
+    grid = (uint32_t)(ctx->numCUs * std::max(1, wavesPerCU));
+    return IDKPT_OK;
+}
+
+int32_t idkptTraceRays(idkpt_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceRays: no scene uploaded");
+    REQUIRE(count == 0 || (rays && hits), "idkptTraceRays: null rays/hits");
+    REQUIRE(count < (1ull << 31), "idkptTraceRays: too many rays in one call");
+    REQUIRE((flags & ~3u) == 0, "idkptTraceRays: unknown flags");
+    if (ctx->st.UseTlas && ctx->tlasCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceRays: UseTlas set but no TLAS nodes uploaded");
+    if (count == 0) return IDKPT_OK;
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    Frame f; size_t ldsBytes; uint32_t grid;
+    int rc = query_frame(ctx, f, ldsBytes, grid); if (rc) return rc;
+    DScene s = make_dscene(ctx);
+    HIPC(ctx->queryIn.ensure(count * sizeof(idkpt_ray))); HIPC(ctx->queryOut.ensure(count * sizeof(idkpt_hit)));
+    hipStream_t st = ctx->stream;
+    HIPC(hipMemcpyAsync(ctx->queryIn.p, rays, count * sizeof(idkpt_ray), hipMemcpyHostToDevice, st));
+    uint32_t* work = ctx->work.as<uint32_t>();
+    HIPC(hipMemsetAsync(work, 0, 4, st));
+    const int lights = (flags & IDKPT_TRACE_LIGHTS) ? 1 : 0;
+    if (flags & IDKPT_TRACE_ANY_HIT) hipLaunchKernelGGL((k_trace_query<true>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, ctx->queryIn.as<idkpt_ray>(), ctx->queryOut.as<idkpt_hit>(), (uint32_t)count, lights, work);
+    else hipLaunchKernelGGL((k_trace_query<false>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, ctx->queryIn.as<idkpt_ray>(), ctx->queryOut.as<idkpt_hit>(), (uint32_t)count, lights, work);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(hits, ctx->queryOut.p, count * sizeof(idkpt_hit), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    return IDKPT_OK;
+}
+
+int32_t idkptTraceShadows(idkpt_ctx* ctx, const idkpt_shadow_params* p, const float* depth, const float* normalOct, float* visibility)
+{
+    if (!ctx || !p) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceShadows: no scene uploaded");
+    REQUIRE(depth && normalOct && visibility, "idkptTraceShadows: null image");
+    REQUIRE(p->Width > 0 && p->Height > 0 && (size_t)p->Width * p->Height < (1ull << 30), "idkptTraceShadows: bad image size");
+    REQUIRE(p->RayTracingSamples >= 1, "idkptTraceShadows: RayTracingSamples must be >= 1");
+    REQUIRE(p->LightIndex >= 0 && p->LightIndex < ctx->lightCount, "idkptTraceShadows: LightIndex out of range");
+    if (ctx->st.UseTlas && ctx->tlasCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceShadows: UseTlas set but no TLAS nodes uploaded");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    Frame f; size_t ldsBytes; uint32_t grid;
+    int rc = query_frame(ctx, f, ldsBytes, grid); if (rc) return rc;
+    DScene s = make_dscene(ctx);
+    const size_t N = (size_t)p->Width * p->Height;
+    HIPC(ctx->queryIn.ensure(N * 12)); HIPC(ctx->queryOut.ensure(N * 4));
+    hipStream_t st = ctx->stream;
+    float* dDepth = ctx->queryIn.as<float>(); float2* dNormal = (float2*)(dDepth + N); float* dVis = ctx->queryOut.as<float>();
+    HIPC(hipMemcpyAsync(dDepth, depth, N * 4, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(dNormal, normalOct, N * 8, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(dVis, visibility, N * 4, hipMemcpyHostToDevice, st));
+    const uint32_t tiles = (uint32_t)(((p->Width + 7) / 8) * ((p->Height + 7) / 8));
+    hipLaunchKernelGGL(k_shadows, dim3(tiles), dim3(WAVE), ldsBytes, st, s, f, *p, (const float*)dDepth, (const float2*)dNormal, dVis);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(visibility, dVis, N * 4, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
     return IDKPT_OK;
 }
 

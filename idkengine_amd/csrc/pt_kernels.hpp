@@ -125,13 +125,15 @@ DEV bool IntersectBlas(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& dref, b
 
 DEV M34 load_inv_model(const DScene& s, uint32_t xformId) { const float4* x = s.xforms + 9 * (size_t)xformId; M34 m; m.r0 = x[3]; m.r1 = x[4]; m.r2 = x[5]; return m; }
 
+// traceLights / maxDist: the path tracer passes (settings.DoTraceLights, FLOAT_MAX) (FirstHit:106, NHit:96); ray queries and the
+// shadow kernel pass their own (BVHIntersect.glsl:183, ShadowsRayTraced/compute.glsl:73)
 template <bool COUNT, bool COST>
-DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, float& debugCost, uint32_t* stk, int stride, uint32_t& nPairs, uint32_t& nTris)
+DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, float& debugCost, uint32_t* stk, int stride, uint32_t& nPairs, uint32_t& nTris,
+                  bool traceLights, float maxDist)
 {
-    const float maxDist = PT_FLOAT_MAX;
     hit.T = maxDist; hit.tri = ~0u; hit.xform = 0; hit.bx = 0.0f; hit.by = 0.0f;
     debugCost = 0.0f;
-    if (f.g.DoTraceLights) {
+    if (traceLights) {
         for (int i = 0; i < s.lightCount; i++) {
             const GpuLight& l = s.lights[i];
             float tMin, tMax;
@@ -178,6 +180,112 @@ DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, fl
         }
     }
     return hit.T != maxDist;
+}
+
+template <bool COUNT, bool COST>
+DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, float& debugCost, uint32_t* stk, int stride, uint32_t& nPairs, uint32_t& nTris)
+{
+    return TraceRay<COUNT, COST>(s, f, ro, rd, hit, debugCost, stk, stride, nPairs, nTris, f.g.DoTraceLights != 0, PT_FLOAT_MAX);
+}
+
+// Any-hit variants (BVHIntersect.glsl:107-181, 299-411): first intersection found wins; children visited left first.
+DEV bool IntersectBlasAny(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& dref, bool useTlas, HitRec& hit, uint32_t* stk, int stride, int cap)
+{
+    float tMinLeft, tMinRight;
+    f3 invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    const int triOffset = dref.TriangleOffset;
+    const float4* nodes = s.nodes + 2 * (size_t)dref.NodeOffset;
+    if (!useTlas) {
+        float4 rmin = nodes[2], rmax = nodes[3];
+        if (!(RayBoxIntersect(ro, invDir, rmin, rmax, &tMinLeft) && tMinLeft < hit.T)) return false;
+    }
+    int sp = 0;
+    uint32_t top = 2;
+    while (true) {
+        const float4* p = nodes + 2 * (size_t)top;
+        float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+        uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
+        bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= hit.T;
+        bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hit.T;
+        bool intersectLeft = hitLeft && lCount > 0, intersectRight = hitRight && rCount > 0;
+        if (intersectLeft || intersectRight) {
+            uint32_t first = intersectLeft ? lStart : rStart;
+            uint32_t end = !intersectRight ? (lStart + lCount) : (rStart + rCount);
+            first += (uint32_t)triOffset; end += (uint32_t)triOffset;
+            for (uint32_t i = first; i < end; i++) {
+                const float4* tv = s.triVerts + 3 * (size_t)i;
+                float4 a = tv[0], b = tv[1], c = tv[2];
+                float by, bz, t;
+                if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hit.T) {
+                    hit.tri = i; hit.bx = 1.0f - by - bz; hit.by = by; hit.T = t;
+                    return true;
+                }
+            }
+        }
+        bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
+        if (traverseLeft || traverseRight) {
+            if (traverseLeft && traverseRight) { top = lStart; if (sp < cap) stk[sp * stride] = rStart; sp++; }
+            else top = traverseLeft ? lStart : rStart;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            top = stk[sp * stride];
+        }
+    }
+    return false;
+}
+
+DEV bool TraceRayAny(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, uint32_t* stk, int stride, bool traceLights, float maxDist)
+{
+    hit.T = maxDist; hit.tri = ~0u; hit.xform = 0; hit.bx = 0.0f; hit.by = 0.0f;
+    if (traceLights) {
+        for (int i = 0; i < s.lightCount; i++) {
+            const GpuLight& l = s.lights[i];
+            float tMin, tMax;
+            if (RaySphereIntersect(ro, rd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hit.T) {
+                hit.T = tMin < 0.0f ? tMax : tMin; hit.xform = (uint32_t)i;
+                return true;
+            }
+        }
+    }
+    if (f.useTlas) {
+        if (s.tlasCount == 0) return false;
+        uint32_t* tstk = stk + f.stackCap * stride;
+        float tMinLeft, tMinRight;
+        f3 invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        int sp = 0; uint32_t top = 0;
+        while (true) {
+            float4 pmin = s.tlas[2 * (size_t)top];
+            uint32_t packed = __float_as_uint(pmin.w);
+            bool isLeaf = (packed >> 31) == 1;
+            uint32_t id = packed & 0x7fffffffu;
+            if (isLeaf) {
+                GpuBlasInstance inst = s.instances[id];
+                M34 inv = load_inv_model(s, inst.MeshTransformId);
+                f3 lo = xform34(inv, ro, 1.0f), ld = xform34(inv, rd, 0.0f);
+                if (IntersectBlasAny(s, lo, ld, s.descs[inst.BlasId], true, hit, stk, stride, f.stackCap)) { hit.xform = inst.MeshTransformId; return true; }
+                if (sp == 0) break;
+                top = tstk[--sp * stride];
+                continue;
+            }
+            uint32_t l = id, r = id + 1;
+            float4 lmin = s.tlas[2 * (size_t)l], lmax = s.tlas[2 * (size_t)l + 1], rmin = s.tlas[2 * (size_t)r], rmax = s.tlas[2 * (size_t)r + 1];
+            bool tl = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft < hit.T;
+            bool tr = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight < hit.T;
+            if (tl || tr) {
+                if (tl && tr) { bool lc = tMinLeft < tMinRight; top = lc ? l : r; if (sp < f.tlasCap) tstk[sp * stride] = lc ? r : l; sp++; }
+                else top = tl ? l : r;
+            } else { if (sp == 0) break; top = tstk[--sp * stride]; }
+        }
+    } else {
+        for (int i = 0; i < s.instanceCount; i++) {
+            GpuBlasInstance inst = s.instances[i];
+            M34 inv = load_inv_model(s, inst.MeshTransformId);
+            f3 lo = xform34(inv, ro, 1.0f), ld = xform34(inv, rd, 0.0f);
+            if (IntersectBlasAny(s, lo, ld, s.descs[inst.BlasId], false, hit, stk, stride, f.stackCap)) { hit.xform = inst.MeshTransformId; return true; }
+        }
+    }
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -164,3 +164,26 @@ class Scene:
 # enum idkpt_buffer (include/idkpt.h)
 (IDKPT_BUF_MESH_TRANSFORMS, IDKPT_BUF_VERTEX_POSITIONS, IDKPT_BUF_VERTICES, IDKPT_BUF_MESHES, IDKPT_BUF_MATERIALS, IDKPT_BUF_LIGHTS,
  IDKPT_BUF_BLAS_NODES, IDKPT_BUF_TLAS_NODES, IDKPT_BUF_JOINT_MATRICES) = range(9)
+
+
+# ray queries / RT shadows (include/idkpt.h: idkpt_ray, idkpt_hit, idkpt_shadow_params, enum idkpt_trace_flags)
+RayQuery = np.dtype([("Origin", "<f4", 3), ("MaxDist", "<f4"), ("Direction", "<f4", 3), ("_pad0", "<u4")])
+RayHit = np.dtype([("T", "<f4"), ("BaryX", "<f4"), ("BaryY", "<f4"), ("TriangleId", "<u4"), ("MeshTransformId", "<u4"), ("Hit", "<u4"),
+                   ("_pad0", "<u4"), ("_pad1", "<u4")])
+assert RayQuery.itemsize == 32 and RayHit.itemsize == 32
+IDKPT_TRACE_ANY_HIT, IDKPT_TRACE_LIGHTS = 1, 2
+
+
+class ShadowParams(C.Structure):
+    _fields_ = [("InvProjView", C.c_float * 16), ("TaaJitter", C.c_float * 2), ("Width", C.c_int32), ("Height", C.c_int32),
+                ("LightIndex", C.c_int32), ("RayTracingSamples", C.c_int32), ("NoiseIndex", C.c_uint32), ("_pad0", C.c_uint32)]
+
+    @staticmethod
+    def make(inv_proj_view, width, height, light_index, samples=1, noise_index=0, jitter=(0.0, 0.0)):
+        p = ShadowParams()
+        m = np.ascontiguousarray(inv_proj_view, np.float32).reshape(16)
+        for i in range(16):
+            p.InvProjView[i] = float(m[i])
+        p.TaaJitter[0], p.TaaJitter[1] = float(jitter[0]), float(jitter[1])
+        p.Width, p.Height, p.LightIndex, p.RayTracingSamples, p.NoiseIndex = width, height, light_index, samples, noise_index
+        return p

@@ -154,6 +154,24 @@ class PathTracer:
         """BVH.TlasBuild on the device from the resident BLAS roots / instances / mesh transforms (Bvh/BVH.cs:278-298)."""
         self._check(self._L.idkptBuildTlasOnDevice(self._ctx, search_radius))
 
+    def TraceRays(self, rays, any_hit=False, trace_lights=False):
+        """Batched TraceRay / TraceRayAny calls (Shaders/include/BVHIntersect.glsl:183-411) with per-ray maxDist.
+        rays: array of gputypes.RayQuery; returns an array of gputypes.RayHit."""
+        from . import gputypes as T
+        r = np.ascontiguousarray(rays, T.RayQuery)
+        out = np.zeros(len(r), T.RayHit)
+        flags = (T.IDKPT_TRACE_ANY_HIT if any_hit else 0) | (T.IDKPT_TRACE_LIGHTS if trace_lights else 0)
+        self._check(self._L.idkptTraceRays(self._ctx, r.ctypes.data, len(r), flags, out.ctypes.data))
+        return out
+
+    def TraceShadows(self, params, depth, normal_oct, visibility=None):
+        """Shaders/ShadowsRayTraced/compute.glsl for one point shadow.  depth (H,W), normal_oct (H,W,2); returns visibility (H,W)."""
+        import ctypes as C
+        d = np.ascontiguousarray(depth, np.float32); n = np.ascontiguousarray(normal_oct, np.float32)
+        v = np.zeros(d.shape, np.float32) if visibility is None else np.ascontiguousarray(visibility, np.float32).copy()
+        self._check(self._L.idkptTraceShadows(self._ctx, C.addressof(params), d.ctypes.data, n.ctypes.data, v.ctypes.data))
+        return v
+
     def RefitBlas(self, blas_id):
         self._check(self._L.idkptRefitBlas(self._ctx, blas_id))
 

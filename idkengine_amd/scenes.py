@@ -48,6 +48,9 @@ class Camera:
         view = look_at(position, np.asarray(position, np.float64) + np.asarray(view_dir, np.float64), up)
         proj = perspective_zero_to_one(math.radians(fovy_deg), width / float(height), near, far)
         # GpuPerFrameData.InvView / InvProjection (Application.cs:148-150), OpenTK memory order (row-major rows)
+        self.view, self.proj = view, proj
+        # GpuPerFrameData.InvProjView = (View * Projection).Inverted(), same memory order
+        self.inv_proj_view = np.ascontiguousarray(np.linalg.inv(view @ proj).astype(np.float32).reshape(16))
         self.inv_view = np.ascontiguousarray(np.linalg.inv(view).astype(np.float32).reshape(16))
         self.inv_projection = np.ascontiguousarray(np.linalg.inv(proj).astype(np.float32).reshape(16))
 
@@ -253,6 +256,59 @@ def soup_scene_multi(n_tris, builder, parts=3, seed=1, albedo=0.8, extent=10.0, 
         mat = make_material(base_color=(albedo, albedo, albedo, 1.0), metallic=0.0, roughness=1.0)
         blases.append({"meshes": [MeshInput(p, i, mat, nrm, tan)], "transform": None if k == 0 else rotation_y(23.0 * k) @ translation((0.5 * k, -0.25 * k, 0.0))})
     return assemble(blases, builder, sky_color=sky_color)
+
+
+def make_lights(specs):
+    """specs: [(position, radius, color)] -> GpuLight array (Source/GpuTypes/GpuLight.cs:5-45)."""
+    l = np.zeros(len(specs), T.GpuLight)
+    for i, (pos, radius, color) in enumerate(specs):
+        l[i]["Position"] = pos; l[i]["Radius"] = radius; l[i]["Color"] = color; l[i]["PointShadowIndex"] = -1; l[i]["PrevPosition"] = pos
+    return l
+
+
+def primary_ray_queries(cam, width, height, max_dist=3.4028235e+38):
+    """One ray per pixel centre (gputypes.RayQuery), row-major; used to make ray-query test sets and stand-in G-buffers."""
+    ys, xs = np.mgrid[0:height, 0:width]
+    ndc = np.stack([(xs + 0.5) / width * 2.0 - 1.0, (ys + 0.5) / height * 2.0 - 1.0, np.ones_like(xs, np.float64), np.ones_like(xs, np.float64)], -1).reshape(-1, 4)
+    w = ndc @ cam.inv_proj_view.reshape(4, 4).astype(np.float64)
+    p = w[:, :3] / w[:, 3:4]
+    d = p - cam.position.astype(np.float64); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros(width * height, T.RayQuery)
+    r["Origin"] = cam.position; r["Direction"] = d.astype(np.float32); r["MaxDist"] = max_dist
+    return r
+
+
+def oct_encode(n):
+    """Compression.glsl:54-60 (EncodeUnitVec) in numpy; used to fabricate G-buffer normals (inputs only)."""
+    n = np.asarray(n, np.float64); n = n / np.abs(n).sum(-1, keepdims=True)
+    xy = n[..., :2].copy()
+    wrap = (1.0 - np.abs(xy[..., ::-1])) * np.where(xy >= 0.0, 1.0, -1.0)
+    xy = np.where(n[..., 2:3] >= 0.0, xy, wrap)
+    return (xy * 0.5 + 0.5).astype(np.float32)
+
+
+def gbuffer_from_hits(sc, cam, width, height, rays, hits):
+    """Stand-in for the rasterizer's G-buffer (gBufferDataUBO.Depth / .Normal): zero-to-one depth of the primary hit point and
+    the oct-encoded world-space face normal (turned towards the camera); sky pixels get depth 1.0."""
+    hit = hits["Hit"] != 0
+    P = rays["Origin"].astype(np.float64) + rays["Direction"].astype(np.float64) * hits["T"].astype(np.float64)[:, None]
+    clip = np.c_[P, np.ones(len(P))] @ (cam.view @ cam.proj)
+    depth = np.where(hit, clip[:, 2] / clip[:, 3], 1.0).astype(np.float32)
+    depth[hit & (depth >= 1.0)] = np.float32(0.99999)
+    tri = sc.blas_triangles[np.where(hit, hits["TriangleId"], 0)]
+    nrm = np.zeros((len(P), 3))
+    for k in np.unique(hits["MeshTransformId"][hit]):
+        sel = hit & (hits["MeshTransformId"] == k)
+        x = sc.mesh_transforms[k]["Model"].astype(np.float64)          # 3x4 (transposed 4x3): p_world = M[:, :3] @ p + M[:, 3]
+        def world(ids):
+            p = sc.vertex_positions[ids].astype(np.float64)
+            return p @ x[:, :3].T + x[:, 3]
+        p0, p1, p2 = world(tri["X"][sel]), world(tri["Y"][sel]), world(tri["Z"][sel])
+        n = np.cross(p1 - p0, p2 - p0); n /= np.linalg.norm(n, axis=1, keepdims=True)
+        n *= np.where((n * rays["Direction"][sel]).sum(1, keepdims=True) > 0.0, -1.0, 1.0)
+        nrm[sel] = n
+    nrm[~hit] = (0.0, 0.0, 1.0)
+    return depth.reshape(height, width), oct_encode(nrm).reshape(height, width, 2)
 
 
 def _quad(a, b, c, d):

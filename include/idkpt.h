@@ -57,6 +57,35 @@ typedef struct idkpt_texture {
     const float* rgba; /* width*height*4 floats, row-major, row 0 = v 0 */
 } idkpt_texture;
 
+/* ---- adjacent consumers of the traversal core ---- */
+/* One ray of a batched query = one call of TraceRay(ray, hitInfo, traceLights, maxDist)
+ * (Shaders/include/BVHIntersect.glsl:293-297) or TraceRayAny (:299-411).  Direction is used as given (not renormalised). */
+typedef struct idkpt_ray {
+    float Origin[3];   float MaxDist;     /* maxDist argument (PT uses FLOAT_MAX) */
+    float Direction[3]; uint32_t _pad0;
+} idkpt_ray;                              /* 32 B */
+/* HitInfo (BVHIntersect.glsl:10-16) + the function's bool result.  Miss: T = MaxDist, TriangleId = ~0.
+ * Light hit (traceLights): TriangleId = ~0, MeshTransformId = light index.  Fields the reference leaves undefined are 0. */
+typedef struct idkpt_hit {
+    float T; float BaryX, BaryY; uint32_t TriangleId;
+    uint32_t MeshTransformId; uint32_t Hit; uint32_t _pad0, _pad1;
+} idkpt_hit;                              /* 32 B */
+enum idkpt_trace_flags {
+    IDKPT_TRACE_ANY_HIT = 1,              /* TraceRayAny: first intersection found wins, children visited left-first */
+    IDKPT_TRACE_LIGHTS  = 2               /* traceLights = true (brute-force sphere lights, :189-203 / :304-320) */
+};
+/* Shaders/ShadowsRayTraced/compute.glsl for ONE point shadow (= one gl_GlobalInvocationID.z slice): what the reference reads from
+ * gBufferDataUBO / shadowsUBO / taaDataUBO / perFrameDataUBO crosses as explicit values. */
+typedef struct idkpt_shadow_params {
+    float   InvProjView[16];              /* perFrameDataUBO.InvProjView, OpenTK memory order (like idkptSetPerFrame) */
+    float   TaaJitter[2];                 /* taaDataUBO.Jitter */
+    int32_t Width, Height;                /* imageSize(RayTracedShadowMapImage) == g-buffer size */
+    int32_t LightIndex;                   /* pointShadow.LightIndex */
+    int32_t RayTracingSamples;            /* uniform RayTracingSamples (>= 1) */
+    uint32_t NoiseIndex;                  /* taaEnabled ? (Frame % SampleCount) * RayTracingSamples : 0  (compute.glsl:22-23) */
+    uint32_t _pad0;
+} idkpt_shadow_params;
+
 /* Everything the reference's PathTracer kernels read through fixed GL bindings
  * (Shaders/include/StaticStorageBuffers.glsl:9-173, StaticUniformBuffers.glsl:9-55), as explicit
  * host arrays owned by the caller: BVH.{BlasNodes,BlasTriangles,BlasesDesc,BlasInstances,TlasNodes}
@@ -154,6 +183,14 @@ IDKPT_API int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId);
  * skins vertexCount vertices from unskinned[inputOffset..] into positions/vertices[outputOffset..] */
 IDKPT_API int32_t idkptUploadUnskinnedVertices(idkpt_ctx* ctx, const GpuUnskinnedVertex* verts, int32_t count);
 IDKPT_API int32_t idkptSkin(idkpt_ctx* ctx, uint32_t inputVertexOffset, uint32_t outputVertexOffset, uint32_t jointMatricesOffset, uint32_t vertexCount);
+/* Batched ray queries through the same BVH/TLAS/light data and the same traversal code as the path tracer (uses the context's
+ * UseTlas / BlasStackSize settings).  Host pointers, synchronous.  flags: enum idkpt_trace_flags. */
+IDKPT_API int32_t idkptTraceRays(idkpt_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits);
+/* Ray-traced point-light shadows (Shaders/ShadowsRayTraced/compute.glsl:19-127): depth = W*H floats (gBuffer Depth, 1.0 = sky),
+ * normalOct = W*H*2 floats (gBuffer Normal .rg, oct-encoded), visibility = W*H floats in/out (pixels the shader returns early
+ * on keep their value).  The shader's GetRandomFloat01() (stochastic alpha) runs on an un-seeded RNG in the reference
+ * (InitializeRandomSeed is commented out, :24); here the seed is 0 per invocation. */
+IDKPT_API int32_t idkptTraceShadows(idkpt_ctx* ctx, const idkpt_shadow_params* params, const float* depth, const float* normalOct, float* visibility);
 /* Read back a scene buffer (tests: refit/skinning results). */
 IDKPT_API int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst);
 

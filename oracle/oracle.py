@@ -121,6 +121,34 @@ class OracleBuilder:
         return nodes
 
 
+def trace_rays(scene, rays, any_hit=False, trace_lights=False, use_tlas=False):
+    """CPU checker for idkptTraceRays: TraceRay / TraceRayAny (BVHIntersect.glsl:183-411) per ray."""
+    T = _dtypes(); L = lib()
+    d, keep = scene.desc()
+    h = L.ref_scene_create(C.addressof(d))
+    try:
+        r = np.ascontiguousarray(rays, T.RayQuery); out = np.zeros(len(r), T.RayHit)
+        flags = (1 if any_hit else 0) | (2 if trace_lights else 0)
+        L.ref_trace_rays(C.c_void_p(h), int(use_tlas), C.c_void_p(r.ctypes.data), C.c_size_t(len(r)), C.c_uint32(flags), C.c_void_p(out.ctypes.data))
+        return out
+    finally:
+        L.ref_scene_destroy(C.c_void_p(h)); del keep
+
+
+def trace_shadows(scene, params, depth, normal_oct, visibility=None, use_tlas=False):
+    """CPU checker for idkptTraceShadows (Shaders/ShadowsRayTraced/compute.glsl)."""
+    L = lib()
+    d, keep = scene.desc()
+    h = L.ref_scene_create(C.addressof(d))
+    try:
+        dp = np.ascontiguousarray(depth, np.float32); n = np.ascontiguousarray(normal_oct, np.float32)
+        v = np.zeros(dp.shape, np.float32) if visibility is None else np.ascontiguousarray(visibility, np.float32).copy()
+        L.ref_trace_shadows(C.c_void_p(h), int(use_tlas), C.c_void_p(C.addressof(params)), C.c_void_p(dp.ctypes.data), C.c_void_p(n.ctypes.data), C.c_void_p(v.ctypes.data))
+        return v
+    finally:
+        L.ref_scene_destroy(C.c_void_p(h)); del keep
+
+
 class OraclePathTracer:
     """Sequential CPU execution of the reference's FirstHit/NHit/FinalDraw schedule (PathTracer.cs:214-271)."""
 

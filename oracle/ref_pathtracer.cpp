@@ -131,6 +131,98 @@ static bool TraceRay(const Scene& s, const Ray& ray, HitInfo& hit, float& debugC
     return hit.T != maxDist;
 }
 
+// include/BVHIntersect.glsl:107-181 — any-hit BLAS traversal: returns at the first triangle with hitT < T; children are always
+// visited left first (no near/far ordering, :163-167).
+static bool IntersectBlasAny(const Scene& s, const Ray& ray, const GpuBlasDesc& d, bool useTlas, HitInfo& hit)
+{
+    float tMinLeft, tMinRight;
+    v3 invDir = V3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const GpuBlasNode* nodes = s.nodes.data() + d.NodeOffset;
+    if (!useTlas) { // :112-118
+        const GpuBlasNode& root = nodes[1];
+        if (!(RayBoxIntersect(ray.o, invDir, root.Min, root.Max, &tMinLeft) && tMinLeft < hit.T)) return false;
+    }
+    std::vector<uint32_t> stack; stack.reserve(64);
+    uint32_t stackTop = 2;
+    while (true) {
+        const GpuBlasNode& L = nodes[stackTop]; const GpuBlasNode& R = nodes[stackTop + 1];
+        bool hitLeft = RayBoxIntersect(ray.o, invDir, L.Min, L.Max, &tMinLeft) && tMinLeft <= hit.T;
+        bool hitRight = RayBoxIntersect(ray.o, invDir, R.Min, R.Max, &tMinRight) && tMinRight <= hit.T;
+        bool intersectLeft = hitLeft && L.TriCount > 0, intersectRight = hitRight && R.TriCount > 0;
+        if (intersectLeft || intersectRight) {
+            uint32_t first = intersectLeft ? L.TriStartOrChild : R.TriStartOrChild;
+            uint32_t end = !intersectRight ? (L.TriStartOrChild + L.TriCount) : (R.TriStartOrChild + R.TriCount);
+            first += (uint32_t)d.TriangleOffset; end += (uint32_t)d.TriangleOffset;
+            for (uint32_t i = first; i < end; i++) {
+                const GpuBlasTriangle& t = s.tris[i];
+                v3 bary; float hitT;
+                if (RayTriangleIntersect(ray, P(s, t.X), P(s, t.Y), P(s, t.Z), &bary, &hitT) && hitT < hit.T) {
+                    hit.TriangleId = i; hit.bary.x = bary.x; hit.bary.y = bary.y; hit.T = hitT;
+                    return true;
+                }
+            }
+        }
+        bool traverseLeft = hitLeft && L.TriCount == 0, traverseRight = hitRight && R.TriCount == 0;
+        if (traverseLeft || traverseRight) {
+            if (traverseLeft && traverseRight) { stackTop = L.TriStartOrChild; stack.push_back(R.TriStartOrChild); }
+            else stackTop = traverseLeft ? L.TriStartOrChild : R.TriStartOrChild;
+        } else {
+            if (stack.empty()) break;
+            stackTop = stack.back(); stack.pop_back();
+        }
+    }
+    return false;
+}
+
+// include/BVHIntersect.glsl:299-411
+static bool TraceRayAny(const Scene& s, const Ray& ray, HitInfo& hit, bool traceLights, bool useTlas, float maxDist)
+{
+    hit.T = maxDist; hit.TriangleId = ~0u; hit.MeshTransformId = 0; hit.bary.x = hit.bary.y = 0.0f;
+    if (traceLights) { // :304-320
+        for (int i = 0; i < (int)s.lights.size(); i++) {
+            const GpuLight& l = s.lights[i]; float tMin, tMax;
+            if (RaySphereIntersect(ray, V3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hit.T) {
+                hit.T = tMin < 0.0f ? tMax : tMin; hit.MeshTransformId = (uint32_t)i;
+                return true;
+            }
+        }
+    }
+    if (useTlas) { // :323-385
+        if (s.tlas.empty()) return false;
+        float tMinLeft, tMinRight;
+        v3 invDir = V3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+        std::vector<uint32_t> stack; uint32_t stackTop = 0;
+        while (true) {
+            const GpuTlasNode& parent = s.tlas[stackTop];
+            bool isLeaf = (parent.IsLeafAndChildOrInstanceId >> 31) == 1;
+            uint32_t id = parent.IsLeafAndChildOrInstanceId & ((1u << 31) - 1);
+            if (isLeaf) {
+                const GpuBlasInstance& inst = s.instances[id];
+                Ray local = RayTransform(ray, s.xforms[inst.MeshTransformId].InvModel);
+                if (IntersectBlasAny(s, local, s.descs[inst.BlasId], true, hit)) { hit.MeshTransformId = inst.MeshTransformId; return true; }
+                if (stack.empty()) break;
+                stackTop = stack.back(); stack.pop_back();
+                continue;
+            }
+            uint32_t l = id, r = id + 1;
+            const GpuTlasNode& ln = s.tlas[l]; const GpuTlasNode& rn = s.tlas[r];
+            bool tl = RayBoxIntersect(ray.o, invDir, ln.Min, ln.Max, &tMinLeft) && tMinLeft < hit.T;
+            bool tr = RayBoxIntersect(ray.o, invDir, rn.Min, rn.Max, &tMinRight) && tMinRight < hit.T;
+            if (tl || tr) {
+                if (tl && tr) { bool lc = tMinLeft < tMinRight; stackTop = lc ? l : r; stack.push_back(lc ? r : l); }
+                else stackTop = tl ? l : r;
+            } else { if (stack.empty()) break; stackTop = stack.back(); stack.pop_back(); }
+        }
+    } else { // :388-408
+        for (size_t i = 0; i < s.instances.size(); i++) {
+            const GpuBlasInstance& inst = s.instances[i];
+            Ray local = RayTransform(ray, s.xforms[inst.MeshTransformId].InvModel);
+            if (IntersectBlasAny(s, local, s.descs[inst.BlasId], false, hit)) { hit.MeshTransformId = inst.MeshTransformId; return true; }
+        }
+    }
+    return false;
+}
+
 // ---- texture / sky sampling (stand-in for GL bindless samplers; DESIGN.md "Textures") ----
 // handle 0 = 1x1 white (Utils/ModelLoader.cs:1857-1877).  Bilinear, repeat wrap, LOD 0, texel centres at (i+0.5)/w.
 struct RGBA { float r, g, b, a; };
@@ -510,6 +602,98 @@ static void RenderSample(PT& pt)
 
 } // namespace
 
+// ---- Shaders/ShadowsRayTraced/compute.glsl:19-127 (one point shadow) --------------------------------------------------------
+static inline float InterleavedGradientNoise(float cx, float cy, uint32_t index) // Random.glsl:35-41
+{
+    float add = (float)index * 5.588238f;
+    cx = cx + add; cy = cy + add;
+    return gfract(52.9829189f * gfract(0.06711056f * cx + 0.00583715f * cy));
+}
+static inline v3 ConstructBasisMul(v3 normal, v3 local) // Math.glsl:112-127: mat3(tangent, normal, bitangent) * local
+{
+    v3 up = gabs(normal.z) < 0.999f ? V3(0.0f, 0.0f, 1.0f) : V3(1.0f, 0.0f, 0.0f);
+    v3 tangent = normalize(cross(up, normal));
+    v3 bitangent = cross(normal, tangent);
+    return V3((tangent.x * local.x + normal.x * local.y) + bitangent.x * local.z,
+              (tangent.y * local.x + normal.y * local.y) + bitangent.y * local.z,
+              (tangent.z * local.x + normal.z * local.y) + bitangent.z * local.z);
+}
+static inline v3 SampleSphereCone(v3 toSphere, float sphereRadius, float rnd0, float rnd1, float* distanceToSphere) // Sampling.glsl:21-52
+{
+    const float PI = 3.14159265f;
+    float radiusSq = sphereRadius * sphereRadius;
+    float distanceSq = dot(toSphere, toSphere);
+    float sinThetaMaxSq = radiusSq / distanceSq;
+    float cosThetaMax = gsqrt(gmax(1.0f - sinThetaMaxSq, 0.0f));
+    float phiMax = 2.0f * PI;
+    float phi = phiMax * rnd0;
+    float cosTheta = gmix(cosThetaMax, 1.0f, gmax(rnd1, 0.001f));
+    float sinTheta = gsqrt(gmax(1.0f - cosTheta * cosTheta, 0.0f));
+    *distanceToSphere = length(toSphere) * cosTheta - gsqrt(radiusSq - distanceSq * sinTheta * sinTheta);
+    float sp, cp; gsincos(phi, &sp, &cp);
+    v3 local = V3(cp * sinTheta, cosTheta, sp * sinTheta);
+    return ConstructBasisMul(normalize(toSphere), local);
+}
+static void ShadowPixel(const Scene& s, bool useTlas, const idkpt_shadow_params& p, int x, int y, const float* depthImg, const float* normalImg, float* vis)
+{
+    size_t pix = (size_t)y * p.Width + x;
+    uint32_t noiseIndex = p.NoiseIndex;
+    Rng rng = {0u};                                        // un-seeded in the reference (:24 commented out); defined as 0 here
+    float depth = depthImg[pix];
+    if (depth == 1.0f) return;                             // :28-32 (bounds are the launch bounds here)
+    const GpuLight& light = s.lights[p.LightIndex];
+    v3 lightPos = V3(light.Position[0], light.Position[1], light.Position[2]);
+    float u = ((float)x + 0.5f) / (float)p.Width, v = ((float)y + 0.5f) / (float)p.Height;
+    float nx = (u * 2.0f - 1.0f) - p.TaaJitter[0], ny = (v * 2.0f - 1.0f) - p.TaaJitter[1];
+    const float* m = p.InvProjView;                        // PerspectiveTransform (Math.glsl:75-79)
+    v3 wp = mat4_mul_xyz(m, nx, ny, depth, 1.0f);
+    float ww = ((m[3] * nx + m[7] * ny) + m[11] * depth) + m[15] * 1.0f;
+    v3 fragPos = wp / ww;
+    v2 nrg = {normalImg[2 * pix], normalImg[2 * pix + 1]};
+    v3 normal = DecodeUnitVec(nrg);
+    float cosTheta = dot(normal, normalize(lightPos - fragPos));
+    if (cosTheta <= 0.0f) { vis[pix] = 0.0f; return; }    // :44-49
+    float visibility = 0.0f;
+    for (int i = 0; i < p.RayTracingSamples; i++) {
+        v3 biased = fragPos + normal * 0.01f;
+        float rnd0 = InterleavedGradientNoise((float)x, (float)y, noiseIndex + 0u);
+        float rnd1 = InterleavedGradientNoise((float)x, (float)y, noiseIndex + 1u);
+        noiseIndex++;
+        v3 fragToLight = lightPos - biased;
+        float distanceToLight;
+        v3 direction = SampleSphereCone(fragToLight, light.Radius, rnd0, rnd1, &distanceToLight);
+        Ray ray; ray.o = biased; ray.d = direction;
+        HitInfo hit; float cost;
+        float thisVisibility = 1.0f;
+        while (TraceRay(s, ray, hit, cost, true, useTlas, distanceToLight - 0.001f, nullptr)) { // :73
+            if (hit.TriangleId == ~0u) {                   // :75-87
+                if (hit.MeshTransformId != (uint32_t)p.LightIndex) thisVisibility = 0.0f;
+                break;
+            }
+            const GpuBlasTriangle& t = s.tris[hit.TriangleId];
+            v3 bary = V3(hit.bary.x, hit.bary.y, 1.0f - hit.bary.x - hit.bary.y);
+            const GpuVertex& v0 = s.vertices[t.X]; const GpuVertex& v1 = s.vertices[t.Y]; const GpuVertex& v2_ = s.vertices[t.Z];
+            v2 t0 = {v0.TexCoord[0], v0.TexCoord[1]}, t1 = {v1.TexCoord[0], v1.TexCoord[1]}, t2 = {v2_.TexCoord[0], v2_.TexCoord[1]};
+            v2 uv = Interpolate2(t0, t1, t2, bary);
+            const GpuMesh& mesh = s.meshes[t.MeshId];
+            const GpuMaterial& mat = s.materials[mesh.MaterialId];
+            Surface surface = GetSurface(s, mat, uv);
+            SurfaceApplyModificatons(surface, mesh);
+            bool blend = surface.AlphaCutoff == 2.0f;      // SurfaceHasAlphaBlending (Surface.glsl:93-96)
+            float alphaCutoff = blend ? rnd01(&rng) : surface.AlphaCutoff;
+            if (blend) thisVisibility *= 1.0f - surface.Alpha;
+            else if (surface.Alpha > alphaCutoff) thisVisibility = 0.0f;
+            if (thisVisibility < 0.01f) break;
+            float dist = hit.T + 0.001f;
+            ray.o = ray.o + ray.d * dist;
+            distanceToLight -= dist;
+        }
+        visibility += thisVisibility;
+    }
+    visibility /= (float)p.RayTracingSamples;
+    vis[pix] = visibility;
+}
+
 extern "C" {
 
 void* ref_scene_create(const idkpt_scene_desc* d)
@@ -533,6 +717,29 @@ void* ref_scene_create(const idkpt_scene_desc* d)
 void ref_scene_destroy(void* s) { delete (Scene*)s; }
 void ref_scene_set_positions(void* s, const float* positions, int vertexCount) { ((Scene*)s)->positions.assign(positions, positions + 3 * (size_t)vertexCount); }
 void ref_scene_set_blas_nodes(void* s, const GpuBlasNode* nodes, int count) { ((Scene*)s)->nodes.assign(nodes, nodes + count); }
+
+// Batched ray queries (TraceRay / TraceRayAny with explicit maxDist and traceLights) — checker for idkptTraceRays
+void ref_trace_rays(void* scene, int useTlas, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
+{
+    const Scene& s = *(Scene*)scene;
+    #pragma omp parallel for schedule(dynamic, 256)
+    for (long long i = 0; i < (long long)count; i++) {
+        Ray r; r.o = V3(rays[i].Origin[0], rays[i].Origin[1], rays[i].Origin[2]); r.d = V3(rays[i].Direction[0], rays[i].Direction[1], rays[i].Direction[2]);
+        HitInfo h; float cost; bool hit;
+        if (flags & IDKPT_TRACE_ANY_HIT) hit = TraceRayAny(s, r, h, (flags & IDKPT_TRACE_LIGHTS) != 0, useTlas != 0, rays[i].MaxDist);
+        else hit = TraceRay(s, r, h, cost, (flags & IDKPT_TRACE_LIGHTS) != 0, useTlas != 0, rays[i].MaxDist, nullptr);
+        idkpt_hit o; memset(&o, 0, sizeof(o));
+        o.T = h.T; o.BaryX = h.bary.x; o.BaryY = h.bary.y; o.TriangleId = h.TriangleId; o.MeshTransformId = h.MeshTransformId; o.Hit = hit ? 1u : 0u;
+        hits[i] = o;
+    }
+}
+// Checker for idkptTraceShadows
+void ref_trace_shadows(void* scene, int useTlas, const idkpt_shadow_params* p, const float* depth, const float* normalOct, float* visibility)
+{
+    const Scene& s = *(Scene*)scene;
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < p->Height; y++) for (int x = 0; x < p->Width; x++) ShadowPixel(s, useTlas != 0, *p, x, y, depth, normalOct, visibility);
+}
 
 void* ref_pt_create(void* scene, int w, int h, int rowMod, int rowRem)
 {
