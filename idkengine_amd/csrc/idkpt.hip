@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WAVE) void k_shadows(DScene s, Frame f, idkpt_shado
 // and pre-culls rays whose root-box test (BVHIntersect.glsl:32-39 with T = FLOAT_MAX) fails: those get their miss
 // record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
 // wave) to an unordered active list; results are stored per pixel, so the list order is free.
-__global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut)
+__global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut, uint8_t* contFlag)
 {
     __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase;
     // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
@@ -270,8 +270,10 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
             radiance = radiance + albedo * splat3(1.0f);
             if (f.outputAovs) { f3 fn = CubemapFaceNormal(rd); rays.aovA[rid] = make_float4(albedo.x, albedo.y, albedo.z, 0.0f); rays.aovN[rid] = make_float4(fn.x, fn.y, fn.z, 0.0f); }
         }
-        rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
-        rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
+        // A culled pixel's ray is finished: FinalDraw only needs its radiance.  Origin/throughput planes (32 of the 48 B) are not
+        // written; the flag lets idkptDownloadRays regenerate them on demand (k_regen_culled).
+        if (keep) { rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f); rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x); }
+        contFlag[rid] = keep ? 0 : 2;       // also resets the continue flag of this ray id (k_shade_first sets 1); pad ids stay 0 from allocation
         rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, pd.y);
     }
     // append the survivors: one atomic per 16-wave workgroup (a single counter word saturates at ~88 atomics/us)
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* queue, const ui
 // ---- stable LSD radix sort of the alive queue by the 21-bit key (replaces CountingSort/**; PathTracer.cs:273-297).
 // 3 passes x 7 bits.  Per pass: (1) per-block digit histogram, (2) exclusive scan over [digit][block], (3) stable scatter.
 #define SORT_BLOCK 256
-#define SORT_ITEMS 4                      // items per thread
+#define SORT_ITEMS 8                      // items per thread
 #define SORT_TILE (SORT_BLOCK * SORT_ITEMS)
 #define SORT_RADIX 128
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_hist(const uint32_t* keys, const uint32_t* countPtr, uint32_t shift, uint32_t* hist /*[RADIX][numTiles]*/, uint32_t numTilesMax)
@@ -678,25 +680,29 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_hist(const uint32_t* keys, 
     __syncthreads();
     if (threadIdx.x < SORT_RADIX) hist[threadIdx.x * numTilesMax + tile] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(1024) void k_sort_scan(const uint32_t* countPtr, uint32_t* hist, uint32_t numTilesMax)
+// one workgroup per digit: exclusive scan of that digit's per-tile counts (a contiguous row) + the digit's total.  The scatter
+// kernel adds the exclusive prefix over the 128 digit totals itself, so the global offset of (digit, tile) is
+// sum(totals[0..digit)) + row prefix — the same value a single serial scan over [digit][tile] would give.
+__global__ __launch_bounds__(1024) void k_sort_scan(const uint32_t* countPtr, uint32_t* hist, uint32_t numTilesMax, uint32_t* digitTotals)
 {
     __shared__ uint32_t part[1024];
     const uint32_t N = *countPtr;
     const uint32_t nT = (N + SORT_TILE - 1) / SORT_TILE;
-    const uint32_t total = SORT_RADIX * nT;          // logical index = digit * nT + tile
-    const uint32_t per = (total + 1023) / 1024;
+    uint32_t* row = hist + (size_t)blockIdx.x * numTilesMax;
+    const uint32_t per = (nT + 1023) / 1024;
     const uint32_t t = threadIdx.x;
-    uint32_t b = t * per, e = min(b + per, total);
+    const uint32_t b = min(t * per, nT), e = min(b + per, nT);
     uint32_t sum = 0;
-    for (uint32_t i = b; i < e; i++) sum += hist[(i / nT) * numTilesMax + (i % nT)];
+    for (uint32_t i = b; i < e; i++) sum += row[i];
     part[t] = sum;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) { uint32_t v = (t >= off) ? part[t - off] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
     uint32_t run = part[t] - sum;
-    for (uint32_t i = b; i < e; i++) { uint32_t* p = &hist[(i / nT) * numTilesMax + (i % nT)]; uint32_t c = *p; *p = run; run += c; }
+    for (uint32_t i = b; i < e; i++) { uint32_t c = row[i]; row[i] = run; run += c; }
+    if (t == 1023) digitTotals[blockIdx.x] = part[1023];
 }
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, const uint32_t* countPtr, uint32_t shift, const uint32_t* hist, uint32_t numTilesMax,
-                                                             uint32_t* keysOut, uint32_t* valsOut)
+                                                             const uint32_t* digitTotals, uint32_t* keysOut, uint32_t* valsOut)
 {
     // stable within the tile: items are visited in index order (k-major, then wave, then lane)
     __shared__ uint32_t digitBase[SORT_RADIX];
@@ -705,7 +711,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_scatter(const uint32_t* key
     const uint32_t tile = blockIdx.x;
     if (tile * SORT_TILE >= N) return;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x < SORT_RADIX) digitBase[threadIdx.x] = hist[threadIdx.x * numTilesMax + tile];
+    if (threadIdx.x < SORT_RADIX) {
+        uint32_t base = 0;
+        for (uint32_t d2 = 0; d2 < threadIdx.x; d2++) base += digitTotals[d2];       // exclusive prefix over the digit totals
+        digitBase[threadIdx.x] = base + hist[(size_t)threadIdx.x * numTilesMax + tile];
+    }
     for (int k = 0; k < SORT_ITEMS; k++) {
         uint32_t i = tile * SORT_TILE + k * SORT_BLOCK + threadIdx.x;
         bool valid = i < N;
@@ -759,6 +769,19 @@ __global__ __launch_bounds__(256) void k_final_draw(Frame f, RayBufs rays, float
     }
     imgResult[i] = make_float4(r.x, r.y, r.z, 1.0f);
     if (f.outputAovs) { imgAlbedo[i] = make_float4(ra.x, ra.y, ra.z, 1.0f); imgNormal[i] = make_float4(rn.x, rn.y, rn.z, 1.0f); }
+}
+
+// idkptDownloadRays support: the ray-state planes k_gen_primary skipped for culled pixels (flag 2) of one sample of the batch
+__global__ __launch_bounds__(256) void k_regen_culled(Frame f, RayBufs rays, const uint8_t* contFlag, uint32_t smp, uint32_t N)
+{
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= N) return;
+    const size_t rid = (size_t)smp * f.Npad + pix;
+    if (contFlag[rid] != 2) return;
+    f3 origin; f2 pd; uint32_t seed;
+    gen_primary(f, pix, f.accum[smp], origin, pd, seed);
+    rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+    rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
 }
 
 // test support (idkptEnablePrimaryHitCapture): miss records for the pixels the pre-cull removes before the traversal
@@ -1014,7 +1037,7 @@ struct idkpt_ctx {
     // trace-kernel timing (idkptEnableTiming): one event pair per trace launch, resolved lazily in idkptGetStats
     std::vector<hipEvent_t> evPool; size_t evUsed = 0;
     double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
-    int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false; int lastBatch = 1;
+    int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false; int lastBatch = 1; Frame lastFrame;
     int maxBatch = 1; uint32_t Npad = 0; std::vector<uint32_t> pending; DevBuf bases; uint32_t* hBases = nullptr;
 };
 
@@ -1066,6 +1089,7 @@ static int alloc_frame(idkpt_ctx* ctx)
     ctx->Npad = (uint32_t)((N + 63) / 64 * 64);
     const size_t cap = (size_t)ctx->maxBatch * ctx->Npad;   // ray ids of one batch
     ctx->pending.clear();
+    ctx->lastFast = false; ctx->lastBatch = 1;   // nothing rendered into the new buffers yet
     HIPC(ctx->rayO.ensure(cap * 16)); HIPC(ctx->rayT.ensure(cap * 16)); HIPC(ctx->rayR.ensure(cap * 16));
     HIPC(ctx->aovA.ensure(cap * 16)); HIPC(ctx->aovN.ensure(cap * 16));
     HIPC(ctx->trLo.ensure(cap * 16)); HIPC(ctx->trLd.ensure(cap * 16)); HIPC(ctx->trInv.ensure(cap * 16)); HIPC(ctx->contFlag.ensure(cap));
@@ -1078,10 +1102,11 @@ static int alloc_frame(idkpt_ctx* ctx)
     HIPC(ctx->counts.ensure(MAX_DEPTH_SLOTS * 4)); HIPC(ctx->work.ensure(4 * MAX_DEPTH_SLOTS * 4)); HIPC(ctx->counters64.ensure(128));
     HIPC(ctx->bases.ensure((size_t)MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4));
     size_t nTiles = (cap + SORT_TILE - 1) / SORT_TILE;
-    HIPC(ctx->sortHist.ensure(SORT_RADIX * nTiles * 4));
+    HIPC(ctx->sortHist.ensure((SORT_RADIX * nTiles + SORT_RADIX) * 4));
     for (int i = 0; i < 3; i++) { HIPC(ctx->img[i].ensure(N * 16)); HIPC(hipMemsetAsync(ctx->img[i].p, 0, N * 16, ctx->stream)); }
     HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream));
     HIPC(hipMemsetAsync(ctx->aovA.p, 0, cap * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, cap * 16, ctx->stream));
+    HIPC(hipMemsetAsync(ctx->contFlag.p, 0, cap, ctx->stream));   // per-batch values are written by k_gen_primary; the pad ids [N, Npad) must read 0
     ctx->accumulated = 0;
     return IDKPT_OK;
 }
@@ -1608,9 +1633,8 @@ static int flush_batch(idkpt_ctx* ctx)
             const uint32_t tilesX = ((uint32_t)f.W + 7) / 8, tilesY = ((uint32_t)f.rows + 7) / 8;
             const uint32_t genWaves = tilesX * tilesY;
             const int cull = f.g.DoTraceLights ? 0 : 1;
-            HIPC(hipMemsetAsync(ctx->contFlag.p, 0, total, st));
             if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits.hit + (size_t)(B - 1) * Npad, hits.xformId + (size_t)(B - 1) * Npad, N);
-            hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp);
+            hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>());
             TRACE_T0();
             launch_trace2<true>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
@@ -1642,11 +1666,12 @@ static int flush_batch(idkpt_ctx* ctx)
             // sample index above it, so one sort orders every sample's queue exactly like a stand-alone counting sort
             const uint32_t nTiles = (total + SORT_TILE - 1) / SORT_TILE;
             const int passes = B > 1 ? 4 : 3;
+            uint32_t* digitTotals = ctx->sortHist.as<uint32_t>() + (size_t)SORT_RADIX * nTiles;   // 128 words behind the [digit][tile] table
             uint32_t* ka = k; uint32_t* va = q; uint32_t* kb = ctx->sortKeys.as<uint32_t>(); uint32_t* vb = ctx->sortVals.as<uint32_t>();
             for (int pass = 0; pass < passes; pass++) {
                 hipLaunchKernelGGL(k_sort_hist, dim3(nTiles), dim3(SORT_BLOCK), 0, st, (const uint32_t*)ka, cnt, (uint32_t)(7 * pass), ctx->sortHist.as<uint32_t>(), nTiles);
-                hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, cnt, ctx->sortHist.as<uint32_t>(), nTiles);
-                hipLaunchKernelGGL(k_sort_scatter, dim3(nTiles), dim3(SORT_BLOCK), 0, st, (const uint32_t*)ka, (const uint32_t*)va, cnt, (uint32_t)(7 * pass), (const uint32_t*)ctx->sortHist.as<uint32_t>(), nTiles, kb, vb);
+                hipLaunchKernelGGL(k_sort_scan, dim3(SORT_RADIX), dim3(1024), 0, st, cnt, ctx->sortHist.as<uint32_t>(), nTiles, digitTotals);
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nTiles), dim3(SORT_BLOCK), 0, st, (const uint32_t*)ka, (const uint32_t*)va, cnt, (uint32_t)(7 * pass), (const uint32_t*)ctx->sortHist.as<uint32_t>(), nTiles, (const uint32_t*)digitTotals, kb, vb);
                 std::swap(ka, kb); std::swap(va, vb);
             }
             // odd pass count: the sorted data sits in (sortKeys, sortVals) -> copy the indices back (the reference copies W*H*4 B too, PathTracer.cs:296)
@@ -1668,7 +1693,7 @@ static int flush_batch(idkpt_ctx* ctx)
                            (const uint32_t*)keysTmp, ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
         side = 1 - side;
     }
-    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast; ctx->lastBatch = B;
+    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast; ctx->lastBatch = B; ctx->lastFrame = f;
     hipLaunchKernelGGL(k_final_draw, dim3((N + 255) / 256), dim3(256), 0, st, f, rays, image_ptr(ctx, 0), image_ptr(ctx, 1), image_ptr(ctx, 2), N);
     HIPC(hipGetLastError());
     // queue lengths stay on the GPU during the batch; a copy goes to pinned memory for GetStats (no sync here)
@@ -1738,6 +1763,10 @@ int32_t idkptDownloadRays(idkpt_ctx* ctx, GpuWavefrontRay* out, size_t bytes)
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     const size_t off = (size_t)(ctx->lastBatch - 1) * ctx->Npad * 16; // the most recent sample of the last batch
+    if (ctx->lastFast) {   // complete the planes the ray generation left out for pre-culled pixels
+        RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
+        hipLaunchKernelGGL(k_regen_culled, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ctx->lastFrame, rays, (const uint8_t*)ctx->contFlag.as<uint8_t>(), (uint32_t)(ctx->lastBatch - 1), (uint32_t)N);
+    }
     std::vector<float4> a(N), b(N), c(N);
     HIPC(hipMemcpyAsync(a.data(), (char*)ctx->rayO.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipMemcpyAsync(b.data(), (char*)ctx->rayT.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));

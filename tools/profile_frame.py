@@ -17,7 +17,7 @@ if __name__ == "__main__":
     batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     sc = get_scene(n)
     pt = PathTracer(1920, 1080)
-    pt.UploadScene(sc); pt.SetCamera(S.Camera(1920, 1080)); pt.RayDepth = depth; pt.set_max_batch(batch)
+    pt.UploadScene(sc); pt.SetCamera(S.Camera(1920, 1080)); pt.RayDepth = depth; pt.DoRaySorting = int(os.environ.get('SORT', '0')); pt.set_max_batch(batch)
     for _ in range(3):
         pt.ResetAccumulation(); pt.Compute()
     pt.synchronize(); pt.reset_stats()
