@@ -1605,7 +1605,8 @@ static int flush_batch(idkpt_ctx* ctx)
     HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
 
     f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount));
-    const size_t ldsBytes = (size_t)(f.stackCap + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;
+    size_t ldsBytes = (size_t)(f.stackCap + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;
+    if (const char* e = getenv("IDKPT_LDS_PAD")) ldsBytes += (size_t)atoi(e);   // developer knob: caps the waves per CU (occupancy experiments)
     if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }
     // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));

@@ -217,10 +217,15 @@ DEV bool RayTriangleIntersect(f3 ro, f3 rd, f3 p0, f3 p1, f3 p2, float* by, floa
     return bx >= 0.0f && *by >= 0.0f && *bz >= 0.0f && *t >= 0.0f;
 }
 // :25-46
+// The x/y slabs go through 2-wide vectors so that the compiler emits v_pk_add_f32 / v_pk_mul_f32 (gfx950 packed FP32: two IEEE
+// operations per instruction, same roundings); the traversal kernel is VALU-issue bound, this takes 8 of ~65 instructions off a node step.
+typedef float v2f __attribute__((ext_vector_type(2)));
 DEV bool RayBoxIntersect(f3 o, f3 invDir, float4 bmin, float4 bmax, float* t1)
 {
-    f3 t0s = mk3((bmin.x - o.x) * invDir.x, (bmin.y - o.y) * invDir.y, (bmin.z - o.z) * invDir.z);
-    f3 t1s = mk3((bmax.x - o.x) * invDir.x, (bmax.y - o.y) * invDir.y, (bmax.z - o.z) * invDir.z);
+    const v2f oxy = {o.x, o.y}, ixy = {invDir.x, invDir.y};
+    const v2f lo2 = (v2f{bmin.x, bmin.y} - oxy) * ixy, hi2 = (v2f{bmax.x, bmax.y} - oxy) * ixy;
+    f3 t0s = mk3(lo2.x, lo2.y, (bmin.z - o.z) * invDir.z);
+    f3 t1s = mk3(hi2.x, hi2.y, (bmax.z - o.z) * invDir.z);
     f3 tsm = mk3(gmin(t0s.x, t1s.x), gmin(t0s.y, t1s.y), gmin(t0s.z, t1s.z));
     f3 tbg = mk3(gmax(t0s.x, t1s.x), gmax(t0s.y, t1s.y), gmax(t0s.z, t1s.z));
     *t1 = gmax(tsm.x, gmax(tsm.y, gmax(tsm.z, 0.0f)));
