@@ -31,7 +31,7 @@ def _hipcc():
 
 def build_hip(force=False, verbose=False):
     out = os.path.join(_HERE, "libidkpt.so")
-    srcs = [os.path.join(CSRC, f) for f in ("idkpt.hip", "pt_kernels.hpp", "pt_device.hpp")] + [os.path.join(INCLUDE, f) for f in ("idkpt.h", "idkpt_types.h")]
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [os.path.join(INCLUDE, f) for f in ("idkpt.h", "idkpt_types.h")]
     if force or _stale(out, srcs):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", out, os.path.join(CSRC, "idkpt.hip")]
         if verbose:

@@ -1,0 +1,197 @@
+// kernels_scene.hpp — what runs before the path on animated frames: TLAS rebuild (PLOC), BLAS refit, skinning.
+// Part of the single translation unit idkpt.hip (included there, in this order); see DESIGN.md §4 for the kernel table.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------------------
+// TLAS rebuild on the device: BVH.TlasBuild (Bvh/BVH.cs:278-298) + TLAS.Build (Bvh/TLAS.cs:28-141).
+// One 1024-thread workgroup (instance counts are small; the reference does this serially on the CPU every animated frame and
+// re-uploads): world bounds of every instance's BLAS root (Box.Transformed, Shapes/Box.cs:177-187), Morton-30 order (stable
+// rank = the reference's stable LSD radix sort), then PLOC rounds: every node picks its best partner inside +-searchRadius
+// (FindBestMatch, TLAS.cs:271-301, strict '<' keeps the first best), mutual pairs merge, output positions come from an ordered
+// block scan so the node array is identical to the serial build, bit for bit.
+#define TLAS_BUILD_THREADS 1024
+DEV uint32_t tlas_insert_two_zeros(uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; }
+DEV uint32_t tlas_to_uint_sat(float f) { if (f != f || f <= 0.0f) return 0u; if (f >= 4294967296.0f) return 0xffffffffu; return (uint32_t)f; }
+DEV float tlas_minN(float a, float b) { return a < b ? a : b; }   // minps / float.MinNative (Shapes/Box.cs:40-50)
+DEV float tlas_maxN(float a, float b) { return a > b ? a : b; }
+DEV float tlas_half_area(float4 mn, float4 mx) { float sx = mx.x - mn.x, sy = mx.y - mn.y, sz = mx.z - mn.z; return __fmaf_rn(sx + sy, sz, sx * sy); }   // MyMath.cs:222-229
+
+// ordered exclusive scan of two per-thread counters over the workgroup; returns this thread's bases and the totals
+DEV void block_scan2(uint32_t a, uint32_t b, uint32_t* sa, uint32_t* sb, uint32_t& baseA, uint32_t& baseB, uint32_t& totA, uint32_t& totB)
+{
+    const uint32_t t = threadIdx.x;
+    sa[t] = a; sb[t] = b;
+    __syncthreads();
+    for (uint32_t off = 1; off < TLAS_BUILD_THREADS; off <<= 1) {
+        uint32_t va = t >= off ? sa[t - off] : 0u, vb = t >= off ? sb[t - off] : 0u;
+        __syncthreads();
+        sa[t] += va; sb[t] += vb;
+        __syncthreads();
+    }
+    baseA = sa[t] - a; baseB = sb[t] - b; totA = sa[TLAS_BUILD_THREADS - 1]; totB = sb[TLAS_BUILD_THREADS - 1];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4* blasNodes, const GpuBlasDesc* descs, const GpuBlasInstance* instances, const float4* xforms,
+                                                                    int n, int searchRadius, float4* nodes /* 2n-1 */, float4* temp /* 2n-1 */, float4* leaf /* n */, uint32_t* keys /* n */, int* pref /* n */)
+{
+    __shared__ float red[6][TLAS_BUILD_THREADS / 64];
+    __shared__ float gbox[6];
+    __shared__ uint32_t sa[TLAS_BUILD_THREADS], sb[TLAS_BUILD_THREADS];
+    const int t = (int)threadIdx.x, T = TLAS_BUILD_THREADS;
+    const int nodeCount = 2 * n - 1;
+    // ---- leaves: world-space bounds of every instance
+    float mn[3] = {PT_FLOAT_MAX, PT_FLOAT_MAX, PT_FLOAT_MAX}, mx[3] = {-PT_FLOAT_MAX, -PT_FLOAT_MAX, -PT_FLOAT_MAX};
+    for (int i = t; i < n; i += T) {
+        const GpuBlasInstance in = instances[i];
+        const float4* root = blasNodes + 2 * ((size_t)descs[in.BlasId].NodeOffset + 1);
+        const float4 rmin = root[0], rmax = root[1];
+        const float4* x = xforms + 9 * (size_t)in.MeshTransformId;
+        const float4 m0 = x[0], m1 = x[1], m2 = x[2];
+        float bmn[3] = {PT_FLOAT_MAX, PT_FLOAT_MAX, PT_FLOAT_MAX}, bmx[3] = {-PT_FLOAT_MAX, -PT_FLOAT_MAX, -PT_FLOAT_MAX};
+        for (int c = 0; c < 8; c++) {
+            const float cx = (c & 1) ? rmax.x : rmin.x, cy = (c & 2) ? rmax.y : rmin.y, cz = (c & 4) ? rmax.z : rmin.z;
+            const float w[3] = {(cx * m0.x) + (cy * m0.y) + (cz * m0.z) + (1.0f * m0.w), (cx * m1.x) + (cy * m1.y) + (cz * m1.z) + (1.0f * m1.w), (cx * m2.x) + (cy * m2.y) + (cz * m2.z) + (1.0f * m2.w)};
+            for (int k = 0; k < 3; k++) { bmn[k] = tlas_minN(bmn[k], w[k]); bmx[k] = tlas_maxN(bmx[k], w[k]); }
+        }
+        leaf[2 * (size_t)i] = make_float4(bmn[0], bmn[1], bmn[2], __uint_as_float((1u << 31) | (uint32_t)i));
+        leaf[2 * (size_t)i + 1] = make_float4(bmx[0], bmx[1], bmx[2], 0.0f);
+        for (int k = 0; k < 3; k++) { mn[k] = tlas_minN(mn[k], bmn[k]); mx[k] = tlas_maxN(mx[k], bmx[k]); }
+    }
+    // global box (min/max: order independent)
+    for (int k = 0; k < 3; k++) {
+        float a = mn[k], b = mx[k];
+        for (int off = 32; off > 0; off >>= 1) { a = tlas_minN(a, __shfl_xor(a, off)); b = tlas_maxN(b, __shfl_xor(b, off)); }
+        if ((t & 63) == 0) { red[k][t >> 6] = a; red[3 + k][t >> 6] = b; }
+    }
+    __syncthreads();
+    if (t < 3) { float a = PT_FLOAT_MAX, b = -PT_FLOAT_MAX; for (int w = 0; w < T / 64; w++) { a = tlas_minN(a, red[t][w]); b = tlas_maxN(b, red[3 + t][w]); } gbox[t] = a; gbox[3 + t] = b; }
+    __syncthreads();
+    // ---- Morton-30 keys of the box centres (MyMath.cs:241-257, 283-299)
+    for (int i = t; i < n; i += T) {
+        const float4 a = leaf[2 * (size_t)i], b = leaf[2 * (size_t)i + 1];
+        const float c[3] = {(b.x + a.x) * 0.5f, (b.y + a.y) * 0.5f, (b.z + a.z) * 0.5f};
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            const float ext = gbox[3 + k] - gbox[k];
+            float r = (c[k] - gbox[k]) / ext * (1.0f - 0.0f) + 0.0f;
+            if (ext == 0.0f) r = 0.0f;
+            const uint32_t u = tlas_to_uint_sat(r * 1024.0f);
+            q[k] = u < 1023u ? u : 1023u;
+        }
+        keys[i] = (tlas_insert_two_zeros(q[0]) << 2) | (tlas_insert_two_zeros(q[1]) << 1) | tlas_insert_two_zeros(q[2]);
+    }
+    __syncthreads();
+    // ---- stable sort by key (rank counting) into the tail of the node array
+    for (int i = t; i < n; i += T) {
+        const uint32_t ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) { const uint32_t kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+        const size_t d = (size_t)(nodeCount - n + rank);
+        nodes[2 * d] = leaf[2 * (size_t)i]; nodes[2 * d + 1] = leaf[2 * (size_t)i + 1];
+    }
+    __syncthreads();
+    // ---- PLOC rounds
+    int activeCount = n, activeEnd = nodeCount;
+    while (activeCount > 1) {
+        const int start = activeEnd - activeCount;
+        for (int i = t; i < activeCount; i += T) {
+            const int a = start + i;
+            const int s0 = max(a - searchRadius, start), s1 = min(a + searchRadius + 1, activeEnd);
+            const float4 amn = nodes[2 * (size_t)a], amx = nodes[2 * (size_t)a + 1];
+            float smallest = PT_FLOAT_MAX; int best = -1;
+            for (int k = s0; k < s1; k++) {
+                if (k == a) continue;
+                const float4 omn = nodes[2 * (size_t)k], omx = nodes[2 * (size_t)k + 1];
+                const float4 un = make_float4(tlas_minN(amn.x, omn.x), tlas_minN(amn.y, omn.y), tlas_minN(amn.z, omn.z), 0.0f);
+                const float4 ux = make_float4(tlas_maxN(amx.x, omx.x), tlas_maxN(amx.y, omx.y), tlas_maxN(amx.z, omx.z), 0.0f);
+                const float area = tlas_half_area(un, ux);
+                if (area < smallest) { smallest = area; best = k; }
+            }
+            pref[i] = best - start;
+        }
+        __syncthreads();
+        // contiguous chunk per thread so that the scan order is the serial loop's order
+        const int chunk = (activeCount + T - 1) / T, c0 = min(t * chunk, activeCount), c1 = min(c0 + chunk, activeCount);
+        uint32_t nPairs = 0, nOut = 0;
+        for (int i = c0; i < c1; i++) { const int b = pref[i]; const bool mutual = b >= 0 && pref[b] == i; if (mutual && i < b) nPairs++; if (!mutual || i < b) nOut++; }
+        uint32_t basePairs, baseOut, totPairs, totOut;
+        block_scan2(nPairs, nOut, sa, sb, basePairs, baseOut, totPairs, totOut);
+        const int merged = 2 * (int)totPairs, unmerged = activeCount - merged, newNodes = merged / 2;
+        const int mergedHead0 = activeEnd - merged, newBegin = mergedHead0 - unmerged - newNodes;
+        int mergedHead = mergedHead0 + 2 * (int)basePairs, unmergedHead = newBegin + (int)baseOut;
+        for (int i = c0; i < c1; i++) {
+            const int b = pref[i]; const bool mutual = b >= 0 && pref[b] == i; const size_t aId = (size_t)(i + start);
+            if (mutual) {
+                if (i < b) {
+                    const size_t bId = (size_t)(b + start);
+                    const float4 amn = nodes[2 * aId], amx = nodes[2 * aId + 1], bmn = nodes[2 * bId], bmx = nodes[2 * bId + 1];
+                    temp[2 * (size_t)mergedHead] = amn; temp[2 * (size_t)mergedHead + 1] = amx; temp[2 * (size_t)mergedHead + 2] = bmn; temp[2 * (size_t)mergedHead + 3] = bmx;
+                    temp[2 * (size_t)unmergedHead] = make_float4(tlas_minN(amn.x, bmn.x), tlas_minN(amn.y, bmn.y), tlas_minN(amn.z, bmn.z), __uint_as_float((uint32_t)mergedHead));
+                    temp[2 * (size_t)unmergedHead + 1] = make_float4(tlas_maxN(amx.x, bmx.x), tlas_maxN(amx.y, bmx.y), tlas_maxN(amx.z, bmx.z), 0.0f);
+                    unmergedHead++; mergedHead += 2;
+                }
+            } else { temp[2 * (size_t)unmergedHead] = nodes[2 * aId]; temp[2 * (size_t)unmergedHead + 1] = nodes[2 * aId + 1]; unmergedHead++; }
+        }
+        __syncthreads();
+        for (int i = newBegin + t; i < activeEnd; i += T) { nodes[2 * (size_t)i] = temp[2 * (size_t)i]; nodes[2 * (size_t)i + 1] = temp[2 * (size_t)i + 1]; }
+        __syncthreads();
+        activeCount -= merged / 2; activeEnd -= merged;
+    }
+}
+
+// BLAS refit (Shaders/BLASRefit/compute.glsl).  The reference walks leaf->root inside one dispatch behind an
+// atomicExchange "second arrival" lock; here the same unions are evaluated level by level (deepest first), one launch
+// per level, so no workgroup ever consumes another workgroup's stores inside a launch (per-XCD L2s are not coherent).
+__global__ void k_refit_leaves(float4* nodes, const uint4* tris, const float4* triVerts, const int32_t* leafIds, uint32_t leafCount, uint32_t nodeOffset, uint32_t triOffset)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= leafCount) return;
+    uint32_t id = nodeOffset + (uint32_t)leafIds[i];
+    float4 mn = nodes[2 * (size_t)id], mx = nodes[2 * (size_t)id + 1];
+    uint32_t start = triOffset + __float_as_uint(mn.w), count = __float_as_uint(mx.w);
+    f3 bmin = splat3(PT_FLOAT_MAX), bmax = splat3(-PT_FLOAT_MAX);
+    for (uint32_t k = start; k < start + count; k++) {
+        for (int v = 0; v < 3; v++) { float4 p = triVerts[3 * (size_t)k + v]; bmin = mk3(gmin(bmin.x, p.x), gmin(bmin.y, p.y), gmin(bmin.z, p.z)); bmax = mk3(gmax(bmax.x, p.x), gmax(bmax.y, p.y), gmax(bmax.z, p.z)); }
+    }
+    nodes[2 * (size_t)id] = make_float4(bmin.x, bmin.y, bmin.z, mn.w); nodes[2 * (size_t)id + 1] = make_float4(bmax.x, bmax.y, bmax.z, mx.w);
+}
+__global__ void k_refit_level(float4* nodes, const int32_t* levelNodes, uint32_t count, uint32_t nodeOffset)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t id = nodeOffset + (uint32_t)levelNodes[i];
+    float4 mn = nodes[2 * (size_t)id], mx = nodes[2 * (size_t)id + 1];
+    uint32_t child = nodeOffset + __float_as_uint(mn.w);
+    float4 lmn = nodes[2 * (size_t)child], lmx = nodes[2 * (size_t)child + 1], rmn = nodes[2 * (size_t)child + 2], rmx = nodes[2 * (size_t)child + 3];
+    nodes[2 * (size_t)id] = make_float4(gmin(lmn.x, rmn.x), gmin(lmn.y, rmn.y), gmin(lmn.z, rmn.z), mn.w);
+    nodes[2 * (size_t)id + 1] = make_float4(gmax(lmx.x, rmx.x), gmax(lmx.y, rmx.y), gmax(lmx.z, rmx.z), mx.w);
+}
+
+// Skinning (Shaders/Skinning/compute.glsl:14-47): 4-weight linear blend; joint matrices are row_major mat4x3 (3 x float4)
+__global__ void k_skin(const GpuUnskinnedVertex* unskinned, const float4* joints, float* positions, float* prevPositions, uint4* vertices,
+                       uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    GpuUnskinnedVertex u = unskinned[inOff + i];
+    float4 m[3];
+    for (int r = 0; r < 3; r++) {
+        float4 a = joints[3 * (size_t)(jointOff + u.JointIndices[0]) + r], b = joints[3 * (size_t)(jointOff + u.JointIndices[1]) + r];
+        float4 c = joints[3 * (size_t)(jointOff + u.JointIndices[2]) + r], d = joints[3 * (size_t)(jointOff + u.JointIndices[3]) + r];
+        float w0 = u.JointWeights[0], w1 = u.JointWeights[1], w2 = u.JointWeights[2], w3 = u.JointWeights[3];
+        m[r] = make_float4(((w0 * a.x + w1 * b.x) + w2 * c.x) + w3 * d.x, ((w0 * a.y + w1 * b.y) + w2 * c.y) + w3 * d.y,
+                           ((w0 * a.z + w1 * b.z) + w2 * c.z) + w3 * d.z, ((w0 * a.w + w1 * b.w) + w2 * c.w) + w3 * d.w);
+    }
+    M34 M; M.r0 = m[0]; M.r1 = m[1]; M.r2 = m[2];
+    f3 p = mk3(u.Position[0], u.Position[1], u.Position[2]);
+    f3 n = DecompressSR11G11B10(u.Normal), t = DecompressSR11G11B10(u.Tangent);
+    f3 np = xform34(M, p, 1.0f);
+    // mat3(skinMatrix) * v : out_i = (R[i][0]*v.x + R[i][1]*v.y) + R[i][2]*v.z
+    f3 nn = normalize(mk3((M.r0.x * n.x + M.r0.y * n.y) + M.r0.z * n.z, (M.r1.x * n.x + M.r1.y * n.y) + M.r1.z * n.z, (M.r2.x * n.x + M.r2.y * n.y) + M.r2.z * n.z));
+    f3 nt = normalize(mk3((M.r0.x * t.x + M.r0.y * t.y) + M.r0.z * t.z, (M.r1.x * t.x + M.r1.y * t.y) + M.r1.z * t.z, (M.r2.x * t.x + M.r2.y * t.y) + M.r2.z * t.z));
+    size_t o = (size_t)(outOff + i);
+    if (prevPositions) { prevPositions[3 * o] = positions[3 * o]; prevPositions[3 * o + 1] = positions[3 * o + 1]; prevPositions[3 * o + 2] = positions[3 * o + 2]; }
+    positions[3 * o] = np.x; positions[3 * o + 1] = np.y; positions[3 * o + 2] = np.z;
+    uint4 v = vertices[o]; v.w = CompressSR11G11B10(nn); v.z = CompressSR11G11B10(nt); vertices[o] = v;
+}

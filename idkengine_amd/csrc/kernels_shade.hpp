@@ -1,0 +1,106 @@
+// kernels_shade.hpp — FirstHit / NHit shading kernels (FirstHit/compute.glsl:114-233, NHit/compute.glsl:98-214).
+// Part of the single translation unit idkpt.hip (included there, in this order); see DESIGN.md §4 for the kernel table.
+#pragma once
+
+// FirstHit / NHit part 2: shade + BSDF sample + continue decision.  One thread per queue slot; the continue bits of a
+// wave are published as one 64-bit ballot + popcount for the ordered compaction that follows.
+// local-space ray + 1/dir of a continuing ray, for the next traversal launch (single-instance fast path): exactly what
+// NHit does first (decode the packed direction, NHit:93; RayTransform, BVHIntersect.glsl:281-282; 1/dir, IntersectionRoutines.glsl:29)
+DEV void write_trace_ready(const DScene& s, const Frame& f, const TraceBufs& tr, uint32_t rid, const RayState& r)
+{
+    f3 rd = DecodeUnitVec(r.pdx, r.pdy);
+    if (f.useTlas || s.instanceCount > 1) {   // the traversal kernel walks the TLAS / instance list and transforms the world ray itself
+        tr.lo[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, 0.0f); tr.ld[rid] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+        if (f.useTlas) tr.inv[rid] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, 0.0f);   // world 1/dir for the TLAS slab tests (:209)
+        return;
+    }
+    GpuBlasInstance inst = s.instances[0];
+    M34 inv = load_inv_model(s, inst.MeshTransformId);
+    f3 lo = xform34(inv, r.origin, 1.0f), ld = xform34(inv, rd, 0.0f);
+    tr.lo[rid] = make_float4(lo.x, lo.y, lo.z, 0.0f); tr.ld[rid] = make_float4(ld.x, ld.y, ld.z, 0.0f);
+    tr.inv[rid] = make_float4(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z, 0.0f);
+}
+
+// Fast-path FirstHit shading: only the rays that entered the traversal (active list, any order).  The continue decision
+// goes to a per-ray byte (pre-zeroed), which the ordered compaction turns back into pixel order.
+__global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* activeList, const uint32_t* activeCount,
+                                                     uint8_t* contFlag, uint32_t* seedsAndKeys)
+{
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= *activeCount) return;
+    const uint32_t rid = activeList[item];
+    const uint32_t smp = rid / f.Npad, pix = rid - smp * f.Npad;
+    const uint32_t acc = f.accum[smp];
+    float4 a = rays.o_ior[rid], b = rays.thr_px[rid], c = rays.rad_py[rid];
+    float4 h = hits.hit[rid];
+    HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[rid];
+    RayState r; r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;
+    AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
+    uint32_t rng = seedsAndKeys[rid], key = 0;
+    int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
+    uint32_t gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
+    f3 rd = DecodeUnitVec(r.pdx, r.pdy);
+    bool cont = ShadeHit<true>(s, f, acc, hit, hit.T != PT_FLOAT_MAX, rd, r, aov, rng, gidSeed, key);
+    rays.o_ior[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, r.prevIor);
+    rays.thr_px[rid] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
+    rays.rad_py[rid] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
+    if (f.outputAovs) { rays.aovA[rid] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[rid] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
+    seedsAndKeys[rid] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
+    if (cont) { contFlag[rid] = 1; write_trace_ready(s, f, tr, rid, r); }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm,
+                                               const uint32_t* qbase, uint32_t slotBase, unsigned long long* contMask, uint32_t* waveCounts, uint32_t* keysTmp)
+{
+    // FIRST: slots are ray ids (sample-major, Npad per sample, Npad % 64 == 0).  Otherwise slots are positions of the
+    // batch-wide alive queue, which is grouped by sample; qbase[k] = first slot of sample k.
+    const uint32_t N = FIRST ? countImm : *countPtr;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((slot & ~63u) >= N) return; // whole wave out of range
+    bool cont = false;
+    uint32_t key = 0;
+    bool inRange = slot < N;
+    uint32_t smp = 0, pix = 0, idx = 0;
+    if (inRange) {
+        idx = FIRST ? slot : queue[slot];
+        smp = idx / f.Npad; pix = idx - smp * f.Npad;
+        if (FIRST && pix >= (uint32_t)f.W * (uint32_t)f.rows) inRange = false; // padding of the sample segment
+    }
+    if (inRange) {
+        const uint32_t acc = f.accum[smp];
+        float4 a = rays.o_ior[idx], b = rays.thr_px[idx], c = rays.rad_py[idx];
+        float4 h = hits.hit[slot];
+        HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[slot];
+        if (FIRST && f.g.DoDebugBVHTraversal) {
+            rays.o_ior[idx] = make_float4(a.x, a.y, a.z, hits.cost[slot]); // FirstHit:108-112
+        } else {
+            RayState r; r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;
+            AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
+            if (!FIRST && f.outputAovs) { float4 aa = rays.aovA[idx], an = rays.aovN[idx]; aov.albedo = mk3(aa.x, aa.y, aa.z); aov.newWeight = aa.w; aov.normal = mk3(an.x, an.y, an.z); }
+            uint32_t rng, gidSeed;
+            if (FIRST) {
+                f3 o2; f2 pd2; gen_primary(f, pix, acc, o2, pd2, rng); // re-derives the RNG state after ray generation (cheaper than 4 B/pixel of HBM)
+                int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
+                gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
+            } else {
+                uint32_t gslot = slotBase + (slot - qbase[smp]);  // slot inside this sample's own queue
+                rng = gslot * 4096u + acc;            // NHit:54
+                gidSeed = gslot;                      // Shading.glsl:74 with gl_GlobalInvocationID = (slot, 0)
+            }
+            f3 rd = DecodeUnitVec(r.pdx, r.pdy);
+            bool hitScene = hit.T != PT_FLOAT_MAX;
+            cont = ShadeHit<FIRST>(s, f, acc, hit, hitScene, rd, r, aov, rng, gidSeed, key);
+            rays.o_ior[idx] = make_float4(r.origin.x, r.origin.y, r.origin.z, r.prevIor);
+            rays.thr_px[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
+            rays.rad_py[idx] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
+            if (f.outputAovs) { rays.aovA[idx] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[idx] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
+            if (cont && tr.lo) write_trace_ready(s, f, tr, idx, r);
+        }
+        // NHit:81 masks the key to 21 bits; the sample index goes above it so that the batch-wide sort stays grouped by sample
+        keysTmp[slot] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
+    }
+    unsigned long long m = __ballot(cont);
+    if ((threadIdx.x & 63) == 0) contMask[slot >> 6] = m;
+    (void)waveCounts;
+}

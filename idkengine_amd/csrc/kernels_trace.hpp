@@ -1,0 +1,337 @@
+// kernels_trace.hpp — traversal kernels: thread-per-ray general kernels (k_trace_primary / k_trace_queue), coherent primary-ray generation with pre-cull (k_gen_primary) and the persistent while-while kernel k_trace2 (BVHIntersect.glsl:27-105, 183-291).
+// Part of the single translation unit idkpt.hip (included there, in this order); see DESIGN.md §4 for the kernel table.
+#pragma once
+
+// FirstHit part 1: ray generation + closest-hit trace of the primary rays (FirstHit/compute.glsl:44-77,100-106).
+// Persistent waves; each wave pulls packets of 64 consecutive pixels.
+template <bool COUNT, bool COST>
+__global__ __launch_bounds__(WAVE) void k_trace_primary(DScene s, Frame f, RayBufs rays, HitBufs hits, uint32_t N, uint32_t* workCounter, uint64_t* counters)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    uint32_t* stk = lds + lane;
+    uint32_t nPairs = 0, nTris = 0;
+    while (true) {
+        uint32_t base = wave_grab(workCounter, WAVE);
+        if (base >= N) break;
+        uint32_t pix = base + lane;
+        if (pix < N) {
+            f3 origin; f2 pd; uint32_t seed;
+            gen_primary(f, pix, f.accumulated, origin, pd, seed);
+            rays.o_ior[pix] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+            rays.thr_px[pix] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
+            rays.rad_py[pix] = make_float4(0.0f, 0.0f, 0.0f, pd.y);
+            f3 rd = DecodeUnitVec(pd.x, pd.y);
+            HitRec hit; float cost;
+            TraceRay<COUNT, COST>(s, f, origin, rd, hit, cost, stk, WAVE, nPairs, nTris);
+            hits.hit[pix] = make_float4(hit.T, hit.bx, hit.by, __uint_as_float(hit.tri));
+            hits.xformId[pix] = hit.xform;
+            if (COST) hits.cost[pix] = cost;
+        }
+    }
+    if (COUNT) flush_counters(counters, nPairs, nTris);
+}
+
+// NHit part 1: closest-hit trace of the alive queue (NHit/compute.glsl:56-58,93-98)
+template <bool COUNT>
+__global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    uint32_t* stk = lds + lane;
+    const uint32_t N = *countPtr;
+    uint32_t nPairs = 0, nTris = 0;
+    while (true) {
+        uint32_t base = wave_grab(workCounter, WAVE);
+        if (base >= N) break;
+        uint32_t slot = base + lane;
+        if (slot < N) {
+            uint32_t idx = queue[slot];
+            float4 o = rays.o_ior[idx];
+            float pdx = rays.thr_px[idx].w, pdy = rays.rad_py[idx].w;
+            f3 rd = DecodeUnitVec(pdx, pdy);
+            HitRec hit; float cost;
+            TraceRay<COUNT, false>(s, f, mk3(o.x, o.y, o.z), rd, hit, cost, stk, WAVE, nPairs, nTris);
+            hits.hit[slot] = make_float4(hit.T, hit.bx, hit.by, __uint_as_float(hit.tri));
+            hits.xformId[slot] = hit.xform;
+        }
+    }
+    if (COUNT) flush_counters(counters, nPairs, nTris);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path (single BLAS instance, no TLAS): coherent ray generation + persistent "while-while" traversal.
+//
+// k_gen_primary: one thread per pixel, 8x8 pixel tiles per wave.  Generates the primary ray (FirstHit:44-77), stores it,
+// and pre-culls rays whose root-box test (BVHIntersect.glsl:32-39 with T = FLOAT_MAX) fails: those get their miss
+// record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
+// wave) to an unordered active list; results are stored per pixel, so the list order is free.
+__global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut, uint8_t* contFlag)
+{
+    __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase;
+    // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
+    // rays of the same screen region (all samples) together -> coherent waves in the traversal kernel
+    const uint32_t smp = blockIdx.x;                                   // sample of the batch
+    const uint32_t wave = (blockIdx.y * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
+    const uint32_t tx = wave % tilesX, ty = wave / tilesX;
+    const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    const bool valid = x < (uint32_t)f.W && y < (uint32_t)f.rows;
+    const uint32_t pix = y * (uint32_t)f.W + x;
+    const uint32_t rid = smp * f.Npad + pix;                           // ray id inside the batch
+    bool keep = false;
+    if (valid) {
+        f3 origin; f2 pd; uint32_t seed;
+        gen_primary(f, pix, f.accum[smp], origin, pd, seed);
+        f3 rd = DecodeUnitVec(pd.x, pd.y);
+        f3 lo = origin, ld = rd, invDir = splat3(0.0f);   // several instances / TLAS: the traversal kernel transforms the world ray per instance
+        keep = !cull;
+        if (f.useTlas) {
+            // first TLAS step (BVHIntersect.glsl:242-249) with T = FLOAT_MAX: a ray that misses both children of the root is a miss
+            invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            if (cull) {
+                if (s.tlasCount == 0) keep = false;
+                else {
+                    const uint32_t packed = __float_as_uint(s.tlas[0].w), id = packed & 0x7fffffffu;
+                    if ((packed >> 31) == 1u) keep = true;
+                    else {
+                        float t1, t2;
+                        const bool tl = RayBoxIntersect(origin, invDir, s.tlas[2 * (size_t)id], s.tlas[2 * (size_t)id + 1], &t1) && t1 < PT_FLOAT_MAX;
+                        const bool tr2 = RayBoxIntersect(origin, invDir, s.tlas[2 * (size_t)id + 2], s.tlas[2 * (size_t)id + 3], &t2) && t2 < PT_FLOAT_MAX;
+                        keep = tl || tr2;
+                    }
+                }
+            }
+        } else
+        // root-box test of BVHIntersect.glsl:32-39 with T = FLOAT_MAX (no lights): a ray that fails it for every instance is a miss
+        for (int ii = 0; ii < s.instanceCount && (ii == 0 || cull); ii++) {
+            GpuBlasInstance inst = s.instances[ii];
+            M34 inv = load_inv_model(s, inst.MeshTransformId);
+            f3 l0 = xform34(inv, origin, 1.0f), l1 = xform34(inv, rd, 0.0f);
+            f3 iv = mk3(1.0f / l1.x, 1.0f / l1.y, 1.0f / l1.z);
+            if (s.instanceCount == 1) { lo = l0; ld = l1; invDir = iv; }
+            if (cull) {
+                const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
+                float t1;
+                if (RayBoxIntersect(l0, iv, root[0], root[1], &t1) && t1 < PT_FLOAT_MAX) keep = true;
+            }
+        }
+        f3 radiance = splat3(0.0f);
+        if (keep) {
+            tr.lo[rid] = make_float4(lo.x, lo.y, lo.z, 0.0f); tr.ld[rid] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.inv[rid] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f);
+            seedOut[rid] = seed;                                        // RNG state after ray generation, consumed by k_shade_first
+        } else {
+            // miss branch of FirstHit TraceRay (FirstHit/compute.glsl:225-233), evaluated right here
+            f3 albedo = SampleSky(s, rd);
+            radiance = radiance + albedo * splat3(1.0f);
+            if (f.outputAovs) { f3 fn = CubemapFaceNormal(rd); rays.aovA[rid] = make_float4(albedo.x, albedo.y, albedo.z, 0.0f); rays.aovN[rid] = make_float4(fn.x, fn.y, fn.z, 0.0f); }
+        }
+        // A culled pixel's ray is finished: FinalDraw only needs its radiance.  Origin/throughput planes (32 of the 48 B) are not
+        // written; the flag lets idkptDownloadRays regenerate them on demand (k_regen_culled).
+        if (keep) { rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f); rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x); }
+        contFlag[rid] = keep ? 0 : 2;       // also resets the continue flag of this ray id (k_shade_first sets 1); pad ids stay 0 from allocation
+        rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, pd.y);
+    }
+    // append the survivors: one atomic per 16-wave workgroup (a single counter word saturates at ~88 atomics/us)
+    const unsigned long long m = __ballot(keep);
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 0) waveKeep[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (int i = 0; i < 16; i++) { uint32_t c = waveKeep[i]; waveKeep[i] = tot; tot += c; } blockBase = tot ? atomicAdd(activeCount, tot) : 0u; }
+    __syncthreads();
+    if (keep) activeList[blockBase + waveKeep[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rid;
+}
+
+// k_trace2: persistent waves; every lane owns one ray at a time and is refilled from the work list as soon as enough
+// lanes of the wave are idle.  Node steps (BVHIntersect.glsl:43-53,81-101) run for all lanes that can step until none
+// can; leaves found on the way are parked per lane and tested together afterwards (BVHIntersect.glsl:54-79).  A lane
+// never takes its next node step before its own pending leaf is tested, so every ray sees exactly the reference's
+// sequence of T updates and pushes: results (T, TriangleId, bary, visit counts) are bit-identical, only the interleaving
+// between different rays changes.
+// MODE 0: one BLAS instance, the trace-ready planes hold the BLAS-local ray.
+// MODE 1: several BLAS instances without a TLAS (the reference's default mode, BVHIntersect.glsl:275-287): every lane walks the
+//         instance list itself; the trace-ready planes hold the WORLD-space ray and the per-instance RayTransform happens here.
+// MODE 2: USE_TLAS (BVHIntersect.glsl:205-272): every lane walks the TLAS with its own stack (LDS rows after the BLAS rows); a
+//         TLAS leaf hands its instance to the same node/leaf phases (no root test, :32), then the TLAS walk resumes.
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0>
+__global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
+{
+    constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t* stk = lds + lane;
+    const int cap = f.stackCap;
+    uint32_t* tstk = stk + cap * WAVE;     // TLAS only
+    const uint32_t N = *countPtr;
+    // wave-uniform scene constants
+    const GpuBlasInstance inst = s.instances[0];
+    const int nodeOffset = s.descs[inst.BlasId].NodeOffset;
+    const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
+    const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
+
+    bool active = false, leafPending = false, workLeft = true;
+    uint32_t top = 0, slot = 0, leafFirst = 0, leafEnd = 0;
+    uint32_t instIdx = 0, rayId = 0, nodeOff = 0, triOff = 0, xformId = 0;   // MULTI only: per-lane instance cursor (TLAS: next TLAS node) and BLAS offsets
+    int tsp = 0; bool moreInst = false;                                       // TLAS stack pointer; "there are instances / TLAS nodes left for this ray"
+    int sp = 0;
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
+    float hitT = 0.0f, hbx = 0.0f, hby = 0.0f; uint32_t hitTri = ~0u, hitXform = 0;
+    uint32_t nPairs = 0, nTris = 0;
+    // PROF: per-wave cycle buckets [refill, node, leaf, other], step counts and active-lane sums (developer instrumentation)
+    unsigned long long pc[4] = {0, 0, 0, 0}, pn[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tPrev = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+#define PROF_MARK(b) do { if (PROF) { unsigned long long _t = __builtin_amdgcn_s_memtime(); pc[b] += _t - tPrev; tPrev = _t; } } while (0)
+
+    while (true) {
+        PROF_MARK(3);
+        // ---- refill idle lanes
+        unsigned long long idle = __ballot(!active);
+        if (workLeft && ((uint32_t)__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
+            const uint32_t n = (uint32_t)__popcll(idle);
+            if (PROF) { pn[0]++; pn[1] += n; }
+            const uint32_t base = wave_grab(workCounter, n);      // (chunked grabbing was measured: no gain, worse balance at small N)
+            const uint32_t item = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (base + n >= N) workLeft = false;
+            if (!active && item < N) {
+                const uint32_t idx = list[item];
+                slot = PRIMARY ? idx : item;
+                hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f;
+                if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203 (world-space ray)
+                    float4 o = rays.o_ior[idx];
+                    f3 wd = DecodeUnitVec(rays.thr_px[idx].w, rays.rad_py[idx].w), wo = mk3(o.x, o.y, o.z);
+                    for (int i = 0; i < s.lightCount; i++) {
+                        const GpuLight& l = s.lights[i];
+                        float tMin, tMax;
+                        if (RaySphereIntersect(wo, wd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hitT) { hitT = tMin < 0.0f ? tMax : tMin; hitXform = (uint32_t)i; hitTri = ~0u; }
+                    }
+                }
+                if (MULTI) { rayId = idx; instIdx = 0; tsp = 0; moreInst = TLAS ? s.tlasCount > 0 : true; active = true; leafPending = false; sp = 0; top = 0u; }
+                else {
+                    // local-space ray and 1/dir were prepared by the (coherent, full-lane) kernel that produced this ray
+                    { float4 a = tr.lo[idx], b = tr.ld[idx], c = tr.inv[idx]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z); }
+                    float t1;
+                    bool enter = RayBoxIntersect(ro, invDir, nodes[2], nodes[3], &t1) && t1 < hitT; // root test (:32-39)
+                    active = true; leafPending = false; sp = 0; top = enter ? 2u : 0u;
+                }
+            }
+        }
+        PROF_MARK(0);
+        if (__ballot(active) == 0ull) { if (!workLeft) break; continue; }
+
+        if (TLAS) {
+            // lanes whose current BLAS is exhausted continue their TLAS walk until it reaches the next leaf (= instance) or ends
+            bool adv = active && !leafPending && top == 0u && moreInst;
+            while (__any(adv)) {
+                if (adv) {
+                    const float4 pmin = s.tlas[2 * (size_t)instIdx];
+                    const uint32_t packed = __float_as_uint(pmin.w), id = packed & 0x7fffffffu;
+                    if ((packed >> 31) == 1u) {                                             // leaf: BVHIntersect.glsl:223-240
+                        const GpuBlasInstance in2 = s.instances[id];
+                        const M34 inv = load_inv_model(s, in2.MeshTransformId);
+                        float4 a = tr.lo[rayId], b = tr.ld[rayId];
+                        ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
+                        invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
+                        sp = 0; top = 2u;                                                   // no root test under USE_TLAS (:32)
+                        if (tsp == 0) moreInst = false; else instIdx = tstk[--tsp * WAVE];  // the pop the reference does after the BLAS; order-independent
+                    } else {
+                        const uint32_t l = id, r = id + 1;
+                        float4 a = tr.lo[rayId], c = tr.inv[rayId];                         // world-space origin and 1/dir
+                        const f3 wo = mk3(a.x, a.y, a.z), winv = mk3(c.x, c.y, c.z);
+                        float4 lmin = s.tlas[2 * (size_t)l], lmax = s.tlas[2 * (size_t)l + 1], rmin = s.tlas[2 * (size_t)r], rmax = s.tlas[2 * (size_t)r + 1];
+                        float tMinLeft, tMinRight;
+                        const bool tl = RayBoxIntersect(wo, winv, lmin, lmax, &tMinLeft) && tMinLeft < hitT;
+                        const bool tr2 = RayBoxIntersect(wo, winv, rmin, rmax, &tMinRight) && tMinRight < hitT;
+                        if (tl || tr2) {
+                            if (tl && tr2) { const bool lc = tMinLeft < tMinRight; instIdx = lc ? l : r; if (tsp < f.tlasCap) tstk[tsp * WAVE] = lc ? r : l; tsp++; }
+                            else instIdx = tl ? l : r;
+                        } else { if (tsp == 0) moreInst = false; else instIdx = tstk[--tsp * WAVE]; }
+                    }
+                }
+                adv = active && !leafPending && top == 0u && moreInst;
+            }
+        } else if (MULTI) {
+            // lanes whose current BLAS is exhausted move on to the next instance (loop: the root test may fail right away)
+            bool adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
+            while (__any(adv)) {
+                if (adv) {
+                    const GpuBlasInstance in2 = s.instances[instIdx];
+                    const M34 inv = load_inv_model(s, in2.MeshTransformId);
+                    float4 a = tr.lo[rayId], b = tr.ld[rayId];                         // world-space origin / direction
+                    ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
+                    invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
+                    const float4* root = s.nodes + 2 * (size_t)nodeOff + 2;
+                    float t1;
+                    const bool enter = RayBoxIntersect(ro, invDir, root[0], root[1], &t1) && t1 < hitT;
+                    sp = 0; top = enter ? 2u : 0u;
+                    instIdx++;
+                }
+                adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
+            }
+        }
+
+        // ---- node phase
+        while (true) {
+            const bool canStep = active && !leafPending && top != 0u;
+            if (!__any(canStep)) break;
+            // enough lanes are parked on a leaf: test those leaves now instead of letting the stragglers run on alone
+            if (LEAF_MIN <= 64 && (int)__popcll(__ballot(active && leafPending)) >= LEAF_MIN) break;
+            if (PROF) { pn[2]++; pn[3] += (unsigned long long)__popcll(__ballot(canStep)); }
+            if (canStep) {
+                if (COUNT) nPairs++;
+                const float4* p = MULTI ? s.nodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top;
+                float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+                const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
+                float tMinLeft, tMinRight;
+                const bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= hitT;
+                const bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hitT;
+                const bool intersectLeft = hitLeft && lCount > 0, intersectRight = hitRight && rCount > 0;
+                if (intersectLeft || intersectRight) {
+                    const uint32_t tOff = MULTI ? triOff : triOffset;
+                    leafFirst = (intersectLeft ? lStart : rStart) + tOff;
+                    leafEnd = (!intersectRight ? (lStart + lCount) : (rStart + rCount)) + tOff;
+                    leafPending = true;
+                    if (COUNT) nTris += leafEnd - leafFirst;
+                }
+                const bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
+                if (traverseLeft || traverseRight) {
+                    if (traverseLeft && traverseRight) {
+                        const bool leftCloser = tMinLeft < tMinRight;
+                        top = leftCloser ? lStart : rStart;
+                        if (sp < cap) stk[sp * WAVE] = leftCloser ? rStart : lStart;
+                        sp++;
+                    } else top = traverseLeft ? lStart : rStart;
+                } else {
+                    if (sp == 0) top = 0u;
+                    else { sp--; top = stk[sp * WAVE]; }
+                }
+            }
+        }
+        PROF_MARK(1);
+        if (PROF) { unsigned long long lm = __ballot(leafPending); if (lm) { pn[4]++; pn[5] += (unsigned long long)__popcll(lm); } }
+        // ---- leaf phase
+        if (leafPending) {
+            for (uint32_t i = leafFirst; i < leafEnd; i++) {
+                const float4* tv = s.triVerts + 3 * (size_t)i;
+                float4 a = tv[0], b = tv[1], c = tv[2];
+                float by, bz, t;
+                if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hitT) {
+                    hitTri = i; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = MULTI ? xformId : inst.MeshTransformId;
+                }
+            }
+            leafPending = false;
+        }
+        PROF_MARK(2);
+        // ---- retire finished rays (MULTI: only after the last instance)
+        if (active && top == 0u && (!MULTI || (TLAS ? !moreInst : instIdx >= (uint32_t)s.instanceCount))) {
+            hits.hit[slot] = make_float4(hitT, hbx, hby, __uint_as_float(hitTri));
+            hits.xformId[slot] = hitXform;
+            active = false;
+        }
+    }
+    if (COUNT) flush_counters(counters, nPairs, nTris);
+    if (PROF && lane == 0) { for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)&counters[4 + i], pc[i]); for (int i = 0; i < 6; i++) atomicAdd((unsigned long long*)&counters[8 + i], pn[i]); }
+#undef PROF_MARK
+}
