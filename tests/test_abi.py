@@ -72,3 +72,16 @@ def test_no_gpu_means_loud_failure_not_fallback():
         with pytest.raises(IdkPtError):
             PathTracer(64, 64)
     assert L.idkptRender(None) == 2 and L.idkptDestroy(None) == 2
+
+
+def test_plain_c_host_compiles_and_links():
+    """tests/c_driver/abi_driver.c (the C11 host used by the GPU parity test) builds against include/idkpt.h and links libidkpt.so."""
+    import subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from idkengine_amd import build
+    build.build_hip()
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "abi_driver")
+        subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_driver", "abi_driver.c"),
+                               "-L", os.path.join(root, "idkengine_amd"), "-lidkpt", "-Wl,-rpath," + os.path.join(root, "idkengine_amd"), "-o", exe])
+        assert os.path.exists(exe)

@@ -289,6 +289,32 @@ def test_rt_shadows_match_oracle(native_builder, oracle_mod, variant, use_tlas):
     pt.Dispose()
 
 
+def test_plain_c_host_matches_python_host(native_builder, tmp_path):
+    """The boundary is a C ABI: a plain C11 program (tests/c_driver/abi_driver.c; gcc, include/idkpt.h, -lidkpt; no Python, torch or
+    C++ on its side) uploads the same arrays, renders, and must produce the same bits and counters as the Python host."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "abi_driver")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(root, "include"), os.path.join(HERE, "c_driver", "abi_driver.c"),
+                           "-L", os.path.join(root, "idkengine_amd"), "-lidkpt", "-Wl,-rpath," + os.path.join(root, "idkengine_amd"), "-o", exe])
+    sc = S.cornell_scene(native_builder, "mixed", True); w, h = 96, 64; cam = S.cornell_camera(w, h)
+    for name in ("blas_nodes", "blas_triangles", "blas_descs", "blas_instances", "tlas_nodes", "vertex_positions", "vertices", "meshes", "materials", "mesh_transforms", "lights"):
+        np.ascontiguousarray(getattr(sc, name)).tofile(str(tmp_path / (name + ".bin")))
+    np.ascontiguousarray(sc.sky_faces, np.float32).tofile(str(tmp_path / "sky_faces.bin"))
+    np.concatenate([cam.inv_projection, cam.inv_view, cam.position.astype(np.float32)]).astype(np.float32).tofile(str(tmp_path / "camera.bin"))
+    for use_tlas in (0, 1):
+        out = subprocess.run([exe, str(tmp_path), str(w), str(h), "4", "2", str(use_tlas)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.startswith("ok ")
+        got = np.fromfile(str(tmp_path / "result.bin"), np.float32).reshape(h, w, 4)
+        rays, pairs, tris, acc = (int(x) for x in open(str(tmp_path / "stats.txt")).read().split())
+        pt = gpu_render(sc, cam, w, h, RayDepth=4, SamplesPerPixel=2, UseTlas=use_tlas)
+        st = pt.stats()
+        assert (bits(got) == bits(pt.Result)).all()
+        assert (rays, pairs, tris, acc) == (st["rays_traced"], st["node_pair_visits"], st["triangle_tests"], pt.AccumulatedSamples)
+        pt.Dispose()
+
+
 @pytest.fixture(scope="module")
 def soup1m(native_builder):
     return S.soup_scene(1000000, native_builder, seed=1)
