@@ -67,6 +67,16 @@ MATRIX = [
     ("soup100k_d5_sort", lambda b: S.soup_scene(100000, b), lambda w, h: S.Camera(w, h), 640, 360, dict(RayDepth=5, DoRaySorting=1)),
     ("ragged_size_77x33", lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 77, 33, dict(RayDepth=4)),   # not a multiple of 8 / 64
     ("tiny_1x1", lambda b: S.cornell_scene(b), S.cornell_camera, 1, 1, dict(RayDepth=3)),
+    # edge cases: widest legal image (FirstHit packs x into 12 bits), a frame where every primary ray misses (empty queues through
+    # the sort and every bounce), a single-triangle BLAS (root with one duplicated leaf), primary rays only, less than one tile
+    ("max_width_4096x3", lambda b: S.soup_scene(3000, b, seed=4), lambda w, h: S.Camera(w, h, fovy_deg=0.04), 4096, 3, dict(RayDepth=3)),
+    ("all_rays_miss_d5_sort", lambda b: S.cornell_scene(b, "mixed", True), lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 30.0), view_dir=(0.0, 0.0, 1.0)), 64, 40, dict(RayDepth=5, DoRaySorting=1, SamplesPerPixel=2)),
+    ("all_rays_miss_tlas", lambda b: S.cornell_scene(b, "mixed", True), lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 30.0), view_dir=(0.0, 0.0, 1.0)), 64, 40, dict(RayDepth=3, UseTlas=1)),
+    ("single_triangle_blas", lambda b: S.assemble([{"meshes": [S.MeshInput(*S.flat_shaded(np.float32([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]]))[:2], S.make_material((0.9, 0.5, 0.2, 1.0)),
+                                                                            *S.flat_shaded(np.float32([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]]))[2:])]}], b),
+     lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 3.0), fovy_deg=50.0), 48, 48, dict(RayDepth=4)),
+    ("primary_only_d1", lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 100, 60, dict(RayDepth=1, SamplesPerPixel=2)),
+    ("sub_tile_5x3", lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 5, 3, dict(RayDepth=6, DoRaySorting=1)),
 ]
 
 
