@@ -212,7 +212,13 @@ def cpu_baseline(scene, cam, depth):
     while tot_dt < 10.0 and reps < 400:
         rays, dt, rows = run(mod)
         tot_rays += rays; tot_dt += dt; reps += 1
+    # the reference's own CPU path (C# semantics: Gui.Test -> BVH.Intersect -> BLAS.Intersect, Render/Gui.cs:1484-1503): primary rays only
+    p_rays, p_dt = 0, 0.0
+    while p_dt < 3.0:
+        t0 = time.perf_counter(); r = O.cpu_trace_primary(scene, cam, W, H, want_hits=False); p_dt += time.perf_counter() - t0
+        p_rays += int(r["rays"])
     return {"value": round(tot_rays / tot_dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "primary_only_csharp_semantics": {"value": round(p_rays / p_dt / 1e6, 3), "unit": "Mray/s", "sample": f"{p_rays // (W * H)} full {W}x{H} frames of centre-of-pixel primary rays, closest hit only (no shading), {p_dt:.1f} s"},
             "sample": f"rows y%{mod}==0 of the same {W}x{H} frame ({rows} rows, {rays} rays, RayDepth {depth}) x {reps} repetitions = {tot_dt:.1f} s of CPU work; "
                       "C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET)"}
 
