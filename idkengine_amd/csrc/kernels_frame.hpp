@@ -39,11 +39,13 @@ __global__ __launch_bounds__(256) void k_regen_culled(Frame f, RayBufs rays, con
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= N) return;
     const size_t rid = (size_t)smp * f.Npad + pix;
-    if (contFlag[rid] != 2) return;
+    const uint8_t flag = contFlag[rid];
+    if (flag != 2 && flag != 4) return;                                 // 2: culled per pixel, 4: culled per tile (no ray was generated at all); bit 0 = continues
     f3 origin; f2 pd; uint32_t seed;
     gen_primary(f, pix, f.accum[smp], origin, pd, seed);
     rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
     rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
+    if (flag == 4) { float4 c = rays.rad_py[rid]; c.w = pd.y; rays.rad_py[rid] = c; }
 }
 
 // test support (idkptEnablePrimaryHitCapture): miss records for the pixels the pre-cull removes before the traversal

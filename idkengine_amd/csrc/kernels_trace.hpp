@@ -60,6 +60,75 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 }
 
 
+// k_classify_tiles: once per batch, one thread per 8x8 tile (sample-independent).  A tile whose whole beam of possible primary rays
+// — every jitter offset, every point of the lens — provably misses the root box, and provably looks at one face of a constant-per-face
+// sky, needs no per-pixel ray generation at all: its pixels are the FirstHit miss branch with a known colour (FirstHit:225-233).
+// The test is CONSERVATIVE (box strictly outside one side plane of the tile's pyramid, by a margin that covers the lens radius, the
+// direction tilt LenseRadius/FocalLength, one extra pixel of jitter and rounding); tiles that fail it take the exact per-pixel path,
+// so results are bit-identical either way.  class 0 = per-pixel path, 1..6 = miss + sky face (class-1), 7 = miss + no sky (black).
+__global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8_t* tileClass, uint32_t tilesX, uint32_t tilesY)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tilesX * tilesY) return;
+    const uint32_t tx = t % tilesX, ty = t / tilesX;
+    uint8_t cls = 0;
+    const float r = f.g.LenseRadius, F = f.g.FocalLength;
+    if (s.instanceCount == 1 && !f.useTlas && s.skySize <= 1 && !f.outputAovs && r >= 0.0f && F > 1e-3f && r / F <= 0.05f) {
+        const float W = (float)f.W, H = (float)f.H;
+        const int gy0 = (int)(ty * 8) * f.rowMod + f.rowRem, gy1 = (int)(ty * 8 + 7) * f.rowMod + f.rowRem;   // global rows of the tile's first / last local row
+        const float nx0 = ((float)(tx * 8) - 1.0f) / W * 2.0f - 1.0f, nx1 = ((float)(tx * 8) + 9.0f) / W * 2.0f - 1.0f;   // one pixel of slack on every side
+        const float ny0 = ((float)gy0 - 1.0f) / H * 2.0f - 1.0f, ny1 = ((float)gy1 + 2.0f) / H * 2.0f - 1.0f;
+        const f3 u[4] = {GetWorldSpaceDirection(f.invProj, f.invView, nx0, ny0), GetWorldSpaceDirection(f.invProj, f.invView, nx1, ny0),
+                         GetWorldSpaceDirection(f.invProj, f.invView, nx1, ny1), GetWorldSpaceDirection(f.invProj, f.invView, nx0, ny1)};
+        const f3 mid = (u[0] + u[1]) + (u[2] + u[3]);
+        // root box of the only BLAS, corners in world space (Model rows of its GpuMeshTransform)
+        const GpuBlasInstance inst = s.instances[0];
+        const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
+        const float4 bmin = root[0], bmax = root[1];
+        const float4* x = s.xforms + 9 * (size_t)inst.MeshTransformId;
+        const float4 m0 = x[0], m1 = x[1], m2 = x[2];
+        const f3 C = mk3(f.viewPos[0], f.viewPos[1], f.viewPos[2]);
+        f3 rel[8]; float D = 0.0f;
+        for (int c = 0; c < 8; c++) {
+            const float cx = (c & 1) ? bmax.x : bmin.x, cy = (c & 2) ? bmax.y : bmin.y, cz = (c & 4) ? bmax.z : bmin.z;
+            rel[c] = mk3(m0.x * cx + m0.y * cy + m0.z * cz + m0.w, m1.x * cx + m1.y * cy + m1.z * cz + m1.w, m2.x * cx + m2.y * cy + m2.z * cz + m2.w) - C;
+            D = gmax(D, gsqrt(dot(rel[c], rel[c])));
+        }
+        const float margin = r + (D + r) * (r / F) * 1.5f + 1e-4f * (D + 1.0f);
+        bool outside = false;
+        for (int i = 0; i < 4; i++) {
+            f3 n = cross(u[i], u[(i + 1) & 3]);
+            const float len = gsqrt(dot(n, n));
+            if (!(len > 1e-12f)) continue;                          // degenerate side (cannot happen for a real tile): no decision from it
+            n = n * (1.0f / len);
+            if (dot(n, mid) > 0.0f) n = n * -1.0f;                  // outward
+            float dmin = PT_FLOAT_MAX;
+            for (int c = 0; c < 8; c++) dmin = gmin(dmin, dot(n, rel[c]));
+            if (dmin > margin) outside = true;
+        }
+        if (outside) {
+            if (s.skySize <= 0) cls = 7;
+            else {
+                // one sky face for every direction of the beam: a strictly dominant axis, same sign, at all four corners, by more than
+                // twice the possible tilt (lens + oct-encoding round trip)
+                const float eta = 2.0f * (r / F) + 1e-4f;
+                int face = -1; bool same = true;
+                for (int i = 0; i < 4; i++) {
+                    const float ax = gabs(u[i].x), ay = gabs(u[i].y), az = gabs(u[i].z);
+                    int fc = -1;
+                    if (ax >= gmax(ay, az) + eta) fc = u[i].x > 0.0f ? 0 : 1;
+                    else if (ay >= gmax(ax, az) + eta) fc = u[i].y > 0.0f ? 2 : 3;
+                    else if (az >= gmax(ax, ay) + eta) fc = u[i].z > 0.0f ? 4 : 5;
+                    if (fc < 0 || (face >= 0 && fc != face)) same = false;
+                    face = fc;
+                }
+                if (same && face >= 0) cls = (uint8_t)(1 + face);
+            }
+        }
+    }
+    tileClass[t] = cls;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Fast path (single BLAS instance, no TLAS): coherent ray generation + persistent "while-while" traversal.
 //
@@ -67,7 +136,8 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 // and pre-culls rays whose root-box test (BVHIntersect.glsl:32-39 with T = FLOAT_MAX) fails: those get their miss
 // record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
 // wave) to an unordered active list; results are stored per pixel, so the list order is free.
-__global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut, uint8_t* contFlag)
+__global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut, uint8_t* contFlag,
+                                                     const uint8_t* tileClass /* null: no tile pre-classification */)
 {
     __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase;
     // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
@@ -81,7 +151,15 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
     const uint32_t pix = y * (uint32_t)f.W + x;
     const uint32_t rid = smp * f.Npad + pix;                           // ray id inside the batch
     bool keep = false;
-    if (valid) {
+    const uint32_t cls = (tileClass && wave < tilesX * (((uint32_t)f.rows + 7) / 8)) ? tileClass[wave] : 0u;   // wave-uniform
+    if (valid && cls != 0u) {
+        // the whole tile is a proven miss with a known sky colour (k_classify_tiles): FirstHit's miss branch without generating the ray
+        f3 albedo = splat3(0.0f);
+        if (cls <= 6u) { const float4 p = s.sky[cls - 1u]; albedo = mk3(p.x, p.y, p.z); }
+        const f3 radiance = splat3(0.0f) + albedo * splat3(1.0f);
+        contFlag[rid] = 4;                                               // (bit 0 = "continues" must stay clear) origin / direction planes regenerated on demand (k_regen_culled)
+        rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    } else if (valid) {
         f3 origin; f2 pd; uint32_t seed;
         gen_primary(f, pix, f.accum[smp], origin, pd, seed);
         f3 rd = DecodeUnitVec(pd.x, pd.y);
