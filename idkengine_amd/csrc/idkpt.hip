@@ -66,7 +66,7 @@ struct idkpt_ctx {
     // trace-kernel timing (idkptEnableTiming): one event pair per trace launch, resolved lazily in idkptGetStats
     std::vector<hipEvent_t> evPool; size_t evUsed = 0;
     double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
-    int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false; int lastBatch = 1; Frame lastFrame;
+    int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false, lastNeedsRegen = false; int lastBatch = 1; Frame lastFrame;
     int maxBatch = 1; uint32_t Npad = 0; std::vector<uint32_t> pending; DevBuf bases; uint32_t* hBases = nullptr;
 };
 
@@ -118,7 +118,7 @@ static int alloc_frame(idkpt_ctx* ctx)
     ctx->Npad = (uint32_t)((N + 63) / 64 * 64);
     const size_t cap = (size_t)ctx->maxBatch * ctx->Npad;   // ray ids of one batch
     ctx->pending.clear();
-    ctx->lastFast = false; ctx->lastBatch = 1;   // nothing rendered into the new buffers yet
+    ctx->lastFast = false; ctx->lastNeedsRegen = false; ctx->lastBatch = 1;   // nothing rendered into the new buffers yet
     HIPC(ctx->rayO.ensure(cap * 16)); HIPC(ctx->rayT.ensure(cap * 16)); HIPC(ctx->rayR.ensure(cap * 16));
     HIPC(ctx->aovA.ensure(cap * 16)); HIPC(ctx->aovN.ensure(cap * 16));
     HIPC(ctx->trLo.ensure(cap * 16)); HIPC(ctx->trLd.ensure(cap * 16)); HIPC(ctx->trInv.ensure(cap * 16)); HIPC(ctx->contFlag.ensure(cap));
@@ -297,6 +297,21 @@ static int upload(idkpt_ctx* ctx, DevBuf& b, const void* src, size_t bytes)
     return IDKPT_OK;
 }
 
+// The fast path stores nothing but a flag for pre-culled pixels of the most recent sample; this completes their ray state (origin,
+// direction, miss radiance) from the frame constants of that batch.  Must run while the scene the batch was rendered with is still
+// resident (the sky decides the miss radiance): called by idkptDownloadRays and before a new scene replaces the old one.
+static DScene make_dscene(idkpt_ctx* ctx);
+static int materialize_culled_rays(idkpt_ctx* ctx)
+{
+    if (!ctx->lastNeedsRegen) return IDKPT_OK;
+    const size_t N = (size_t)ctx->W * ctx->rows;
+    RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
+    hipLaunchKernelGGL(k_regen_culled, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, make_dscene(ctx), ctx->lastFrame, rays, (const uint8_t*)ctx->contFlag.as<uint8_t>(), (uint32_t)(ctx->lastBatch - 1), (uint32_t)N);
+    HIPC(hipGetLastError());
+    ctx->lastNeedsRegen = false;
+    return IDKPT_OK;
+}
+
 int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
 {
     if (!ctx || !sc) return IDKPT_ERR_INVALID_ARGUMENT;
@@ -323,6 +338,7 @@ int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
     }
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
+    { int rc = materialize_culled_rays(ctx); if (rc) return rc; }   // while the old sky is still resident
     int rc;
     if ((rc = upload(ctx, ctx->nodes, sc->BlasNodes, (size_t)sc->BlasNodeCount * 32))) return rc;
     if ((rc = upload(ctx, ctx->tris, sc->BlasTriangles, (size_t)sc->BlasTriangleCount * 16))) return rc;
@@ -650,6 +666,7 @@ static int flush_batch(idkpt_ctx* ctx)
     uint32_t* waveCounts = ctx->waveCounts.as<uint32_t>();
     const int BS = MAX_BATCH + 1;
 
+    const uint8_t* tileClass = nullptr;                   // per-tile pre-classification of this batch (fast path with pre-cull only)
     // ---- FirstHit
     uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (capacity uints), free until the first sort
     uint32_t* activeCount = counts + (MAX_DEPTH_SLOTS - 1);
@@ -665,7 +682,7 @@ static int flush_batch(idkpt_ctx* ctx)
             const uint32_t genWaves = tilesX * tilesY;
             const int cull = f.g.DoTraceLights ? 0 : 1;
             if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits.hit + (size_t)(B - 1) * Npad, hits.xformId + (size_t)(B - 1) * Npad, N);
-            const uint8_t* tileClass = nullptr;
+            tileClass = nullptr;
             if (cull && !ctx->noTileCull) {   // sample-independent pre-classification of the 8x8 tiles (conservative whole-tile miss test)
                 HIPC(ctx->tileClass.ensure(genWaves));
                 hipLaunchKernelGGL(k_classify_tiles, dim3((genWaves + 255) / 256), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
@@ -730,8 +747,8 @@ static int flush_batch(idkpt_ctx* ctx)
                            (const uint32_t*)keysTmp, ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
         side = 1 - side;
     }
-    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast; ctx->lastBatch = B; ctx->lastFrame = f;
-    hipLaunchKernelGGL(k_final_draw, dim3((N + 255) / 256), dim3(256), 0, st, f, rays, image_ptr(ctx, 0), image_ptr(ctx, 1), image_ptr(ctx, 2), N);
+    ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast; ctx->lastNeedsRegen = fast; ctx->lastBatch = B; ctx->lastFrame = f;
+    hipLaunchKernelGGL(k_final_draw, dim3((N + 255) / 256), dim3(256), 0, st, s, f, rays, image_ptr(ctx, 0), image_ptr(ctx, 1), image_ptr(ctx, 2), N, tileClass);
     HIPC(hipGetLastError());
     // queue lengths stay on the GPU during the batch; a copy goes to pinned memory for GetStats (no sync here)
     HIPC(hipMemcpyAsync(ctx->hCounts, counts, MAX_DEPTH_SLOTS * 4, hipMemcpyDeviceToHost, st));
@@ -800,10 +817,7 @@ int32_t idkptDownloadRays(idkpt_ctx* ctx, GpuWavefrontRay* out, size_t bytes)
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     const size_t off = (size_t)(ctx->lastBatch - 1) * ctx->Npad * 16; // the most recent sample of the last batch
-    if (ctx->lastFast) {   // complete the planes the ray generation left out for pre-culled pixels
-        RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
-        hipLaunchKernelGGL(k_regen_culled, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ctx->lastFrame, rays, (const uint8_t*)ctx->contFlag.as<uint8_t>(), (uint32_t)(ctx->lastBatch - 1), (uint32_t)N);
-    }
+    { int rc = materialize_culled_rays(ctx); if (rc) return rc; }   // complete what the ray generation left out for pre-culled pixels
     std::vector<float4> a(N), b(N), c(N);
     HIPC(hipMemcpyAsync(a.data(), (char*)ctx->rayO.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipMemcpyAsync(b.data(), (char*)ctx->rayT.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));

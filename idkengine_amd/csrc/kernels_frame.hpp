@@ -13,18 +13,23 @@ DEV f3 TurboColormap(float x)
     float b = (((v0 * 0.10667330f + v1 * 12.64194608f) + v2 * -60.58204836f) + v3 * 110.36276771f) + (w0 * -89.90310912f + w1 * 27.34824973f);
     return mk3(r, g, b);
 }
-__global__ __launch_bounds__(256) void k_final_draw(Frame f, RayBufs rays, float4* imgResult, float4* imgAlbedo, float4* imgNormal, uint32_t N)
+__global__ __launch_bounds__(256) void k_final_draw(DScene s, Frame f, RayBufs rays, float4* imgResult, float4* imgAlbedo, float4* imgNormal, uint32_t N, const uint8_t* tileClass)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     float4 o = imgResult[i];
     f3 r = mk3(o.x, o.y, o.z), ra = splat3(0.0f), rn = splat3(0.0f);
     if (f.outputAovs) { float4 oa = imgAlbedo[i], on = imgNormal[i]; ra = mk3(oa.x, oa.y, oa.z); rn = mk3(on.x, on.y, on.z); }
+    // pixels of a pre-classified tile (k_classify_tiles): every sample's radiance is the same known sky colour; nothing was stored per sample
+    uint32_t cls = 0;
+    if (tileClass) { const uint32_t x = i % (uint32_t)f.W, y = i / (uint32_t)f.W; cls = tileClass[(y >> 3) * (((uint32_t)f.W + 7) / 8) + (x >> 3)]; }
+    f3 tileColor = splat3(0.0f);
+    if (cls >= 1u && cls <= 6u) { const float4 p = s.sky[cls - 1u]; tileColor = splat3(0.0f) + mk3(p.x, p.y, p.z) * splat3(1.0f); }
     for (int k = 0; k < f.batch; k++) {                 // samples are accumulated in submission order, exactly like consecutive FinalDraw dispatches
         const size_t rid = (size_t)k * f.Npad + i;
         float w = 1.0f / ((float)f.accum[k] + 1.0f);
-        float4 c = rays.rad_py[rid];
-        f3 nr = mk3(c.x, c.y, c.z);
+        f3 nr = tileColor;
+        if (cls == 0u) { float4 c = rays.rad_py[rid]; nr = mk3(c.x, c.y, c.z); }
         if (f.g.DoDebugBVHTraversal) nr = TurboColormap(rays.o_ior[rid].w / 150.0f);
         r = gmix(r, nr, w);
         if (f.outputAovs) { float4 a = rays.aovA[rid], n = rays.aovN[rid]; ra = gmix(ra, mk3(a.x, a.y, a.z), w); rn = gmix(rn, mk3(n.x, n.y, n.z), w); }
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(256) void k_final_draw(Frame f, RayBufs rays, float
 }
 
 // idkptDownloadRays support: the ray-state planes k_gen_primary skipped for culled pixels (flag 2) of one sample of the batch
-__global__ __launch_bounds__(256) void k_regen_culled(Frame f, RayBufs rays, const uint8_t* contFlag, uint32_t smp, uint32_t N)
+__global__ __launch_bounds__(256) void k_regen_culled(DScene s, Frame f, RayBufs rays, const uint8_t* contFlag, uint32_t smp, uint32_t N)
 {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= N) return;
@@ -45,7 +50,11 @@ __global__ __launch_bounds__(256) void k_regen_culled(Frame f, RayBufs rays, con
     gen_primary(f, pix, f.accum[smp], origin, pd, seed);
     rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
     rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
-    if (flag == 4) { float4 c = rays.rad_py[rid]; c.w = pd.y; rays.rad_py[rid] = c; }
+    if (flag == 4) {                                                    // the miss branch of FirstHit (FirstHit:225-233) for a pixel nothing was stored for
+        const f3 albedo = SampleSky(s, DecodeUnitVec(pd.x, pd.y));
+        const f3 radiance = splat3(0.0f) + albedo * splat3(1.0f);
+        rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, pd.y);
+    }
 }
 
 // test support (idkptEnablePrimaryHitCapture): miss records for the pixels the pre-cull removes before the traversal

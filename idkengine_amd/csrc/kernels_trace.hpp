@@ -154,11 +154,8 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
     const uint32_t cls = (tileClass && wave < tilesX * (((uint32_t)f.rows + 7) / 8)) ? tileClass[wave] : 0u;   // wave-uniform
     if (valid && cls != 0u) {
         // the whole tile is a proven miss with a known sky colour (k_classify_tiles): FirstHit's miss branch without generating the ray
-        f3 albedo = splat3(0.0f);
-        if (cls <= 6u) { const float4 p = s.sky[cls - 1u]; albedo = mk3(p.x, p.y, p.z); }
-        const f3 radiance = splat3(0.0f) + albedo * splat3(1.0f);
+        // k_final_draw takes the colour from the tile class, idkptDownloadRays regenerates the ray state: one flag byte is all that is stored
         contFlag[rid] = 4;                                               // (bit 0 = "continues" must stay clear) origin / direction planes regenerated on demand (k_regen_culled)
-        rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     } else if (valid) {
         f3 origin; f2 pd; uint32_t seed;
         gen_primary(f, pix, f.accum[smp], origin, pd, seed);

@@ -178,7 +178,11 @@ def test_tile_preclassification_is_conservative(native_builder, oracle_mod, monk
         monkeypatch.delenv("IDKPT_NO_TILE_CULL")
         assert (bits(a.Result) == bits(b.Result)).all() and a.rays().tobytes() == b.rays().tobytes()
         assert a.stats()["alive_counts"][:2] == b.stats()["alive_counts"][:2]
-        a.Dispose(); b.Dispose(); o.close()
+        # the lazily completed ray state must not depend on what happens to the scene afterwards (the sky decides the miss radiance)
+        c = gpu_render(sc, cam, w, h, **ov)
+        c.UploadScene(S.soup_scene(500, native_builder, seed=3, sky_color=(0.1, 0.2, 0.3)))
+        assert c.rays().tobytes() == b.rays().tobytes()
+        a.Dispose(); b.Dispose(); c.Dispose(); o.close()
     # row-sharded context: the tile's rows are every 3rd image row
     from idkengine_amd.pathtracer import PathTracer
     cam = S.Camera(w, h, position=(0.0, 0.0, 9.0))
