@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
     const uint32_t tx = t % tilesX, ty = t / tilesX;
     uint8_t cls = 0;
     const float r = f.g.LenseRadius, F = f.g.FocalLength;
-    if (s.instanceCount == 1 && !f.useTlas && s.skySize <= 1 && !f.outputAovs && r >= 0.0f && F > 1e-3f && r / F <= 0.05f) {
+    if (s.instanceCount >= 1 && s.instanceCount <= 256 && s.skySize <= 1 && !f.outputAovs && r >= 0.0f && F > 1e-3f && r / F <= 0.05f) {
         const float W = (float)f.W, H = (float)f.H;
         const int gy0 = (int)(ty * 8) * f.rowMod + f.rowRem, gy1 = (int)(ty * 8 + 7) * f.rowMod + f.rowRem;   // global rows of the tile's first / last local row
         const float nx0 = ((float)(tx * 8) - 1.0f) / W * 2.0f - 1.0f, nx1 = ((float)(tx * 8) + 9.0f) / W * 2.0f - 1.0f;   // one pixel of slack on every side
@@ -81,30 +81,52 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
         const f3 u[4] = {GetWorldSpaceDirection(f.invProj, f.invView, nx0, ny0), GetWorldSpaceDirection(f.invProj, f.invView, nx1, ny0),
                          GetWorldSpaceDirection(f.invProj, f.invView, nx1, ny1), GetWorldSpaceDirection(f.invProj, f.invView, nx0, ny1)};
         const f3 mid = (u[0] + u[1]) + (u[2] + u[3]);
-        // root box of the only BLAS, corners in world space (Model rows of its GpuMeshTransform)
-        const GpuBlasInstance inst = s.instances[0];
-        const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
-        const float4 bmin = root[0], bmax = root[1];
-        const float4* x = s.xforms + 9 * (size_t)inst.MeshTransformId;
-        const float4 m0 = x[0], m1 = x[1], m2 = x[2];
-        const f3 C = mk3(f.viewPos[0], f.viewPos[1], f.viewPos[2]);
-        f3 rel[8]; float D = 0.0f;
-        for (int c = 0; c < 8; c++) {
-            const float cx = (c & 1) ? bmax.x : bmin.x, cy = (c & 2) ? bmax.y : bmin.y, cz = (c & 4) ? bmax.z : bmin.z;
-            rel[c] = mk3(m0.x * cx + m0.y * cy + m0.z * cz + m0.w, m1.x * cx + m1.y * cy + m1.z * cz + m1.w, m2.x * cx + m2.y * cy + m2.z * cz + m2.w) - C;
-            D = gmax(D, gsqrt(dot(rel[c], rel[c])));
-        }
-        const float margin = r + (D + r) * (r / F) * 1.5f + 1e-4f * (D + 1.0f);
-        bool outside = false;
+        f3 pn[4]; bool planeOk[4];                                  // outward unit normals of the four side planes of the tile's pyramid
         for (int i = 0; i < 4; i++) {
             f3 n = cross(u[i], u[(i + 1) & 3]);
             const float len = gsqrt(dot(n, n));
-            if (!(len > 1e-12f)) continue;                          // degenerate side (cannot happen for a real tile): no decision from it
-            n = n * (1.0f / len);
-            if (dot(n, mid) > 0.0f) n = n * -1.0f;                  // outward
-            float dmin = PT_FLOAT_MAX;
-            for (int c = 0; c < 8; c++) dmin = gmin(dmin, dot(n, rel[c]));
-            if (dmin > margin) outside = true;
+            planeOk[i] = len > 1e-12f;                              // a degenerate side (cannot happen for a real tile) gives no decision
+            n = n * (1.0f / (planeOk[i] ? len : 1.0f));
+            if (dot(n, mid) > 0.0f) n = n * -1.0f;
+            pn[i] = n;
+        }
+        const f3 C = mk3(f.viewPos[0], f.viewPos[1], f.viewPos[2]);
+        // The boxes the traversal itself tests first (so that skipped rays would not have visited — or counted — anything):
+        //   no TLAS: every instance's BLAS root box, an oriented box in world space (Model rows of its GpuMeshTransform; BVHIntersect.glsl:32-39)
+        //   USE_TLAS: the two children of the TLAS root, world-space AABBs (:242-249); a leaf root is entered unconditionally -> no shortcut
+        // Each must lie beyond one side plane by more than the margin.
+        int nBoxes = s.instanceCount;
+        uint32_t tlasChild = 0;
+        if (f.useTlas) {
+            nBoxes = 0;
+            if (s.tlasCount > 0) { const uint32_t packed = __float_as_uint(s.tlas[0].w); if ((packed >> 31) == 0u) { nBoxes = 2; tlasChild = packed & 0x7fffffffu; } }
+        }
+        bool outside = nBoxes > 0;
+        for (int ii = 0; ii < nBoxes && outside; ii++) {
+            float4 bmin, bmax, m0 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), m1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f), m2 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+            if (f.useTlas) { bmin = s.tlas[2 * (size_t)(tlasChild + ii)]; bmax = s.tlas[2 * (size_t)(tlasChild + ii) + 1]; }
+            else {
+                const GpuBlasInstance inst = s.instances[ii];
+                const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
+                bmin = root[0]; bmax = root[1];
+                const float4* x = s.xforms + 9 * (size_t)inst.MeshTransformId;
+                m0 = x[0]; m1 = x[1]; m2 = x[2];
+            }
+            f3 rel[8]; float D = 0.0f;
+            for (int c = 0; c < 8; c++) {
+                const float cx = (c & 1) ? bmax.x : bmin.x, cy = (c & 2) ? bmax.y : bmin.y, cz = (c & 4) ? bmax.z : bmin.z;
+                rel[c] = mk3(m0.x * cx + m0.y * cy + m0.z * cz + m0.w, m1.x * cx + m1.y * cy + m1.z * cz + m1.w, m2.x * cx + m2.y * cy + m2.z * cz + m2.w) - C;
+                D = gmax(D, gsqrt(dot(rel[c], rel[c])));
+            }
+            const float margin = r + (D + r) * (r / F) * 1.5f + 1e-4f * (D + 1.0f);
+            bool boxOutside = false;
+            for (int i = 0; i < 4; i++) {
+                if (!planeOk[i]) continue;
+                float dmin = PT_FLOAT_MAX;
+                for (int c = 0; c < 8; c++) dmin = gmin(dmin, dot(pn[i], rel[c]));
+                if (dmin > margin) boxOutside = true;
+            }
+            outside = boxOutside;
         }
         if (outside) {
             if (s.skySize <= 0) cls = 7;
