@@ -85,3 +85,15 @@ def test_plain_c_host_compiles_and_links():
         subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_driver", "abi_driver.c"),
                                "-L", os.path.join(root, "idkengine_amd"), "-lidkpt", "-Wl,-rpath," + os.path.join(root, "idkengine_amd"), "-o", exe])
         assert os.path.exists(exe)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path only: without a device it must stop with a clear message, not fall back to the CPU oracle."""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--tris", "1000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "needs a GPU" in (out.stderr + out.stdout)
+    assert not any(line.startswith("{") for line in out.stdout.splitlines())      # no metric line
