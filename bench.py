@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--sort", type=int, default=0, help="DoRaySorting (headline = 0)")
     ap.add_argument("--width", type=int, default=W, help="secondary-table runs only (headline = 1920)")
     ap.add_argument("--height", type=int, default=H, help="secondary-table runs only (headline = 1080)")
+    ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: contiguous strips + per-bounce count exchange (gloo control group) so that RayDepth > 2 output equals the 1-GPU output bit for bit; default = interleaved rows (exact at RayDepth 2)")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 128")
     args = ap.parse_args()
 
@@ -74,7 +75,8 @@ def main():
     W, H = args.width, args.height
     cam = S.Camera(W, H)
 
-    r = D.GpuShardRenderer(W, H, world, rank, local_rank)
+    control = dist.new_group(backend="gloo") if (world > 1 and args.exact_deep_paths) else None   # CPU-side group for the tiny count exchange
+    r = D.GpuShardRenderer(W, H, world, rank, local_rank, exact_deep_paths=bool(control), control_group=control)
     r.upload_scene(scene); r.set_camera(cam)
     pt = r.pt
     depth = args.depth
@@ -162,7 +164,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky",
-                       "rays_per_step": int(rays_total / args.steps), "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": "rows round-robin over ranks + all-gather" if world > 1 else "none",
+                       "rays_per_step": int(rays_total / args.steps), "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather") if world > 1 else "none",
                        "bvh_build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

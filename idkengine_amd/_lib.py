@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libidkpt.so")
 # every symbol include/idkpt.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
     "idkptCreate", "idkptDestroy", "idkptGetLastError", "idkptGetDeviceCount", "idkptGetVersionString",
-    "idkptSetSize", "idkptSetRowSharding", "idkptSetSlotBases", "idkptSetSettings", "idkptGetSettings",
+    "idkptSetSize", "idkptSetRowSharding", "idkptSetRowRange", "idkptSetBounceExchange", "idkptSetSettings", "idkptGetSettings",
     "idkptSetPerFrame", "idkptSetPerFrameData", "idkptUploadScene", "idkptUpdateBuffer", "idkptSetLightCount",
     "idkptBuildTlas", "idkptBuildTlasOnDevice", "idkptRefitBlas", "idkptUploadUnskinnedVertices", "idkptSkin", "idkptDownloadBuffer",
     "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptRender", "idkptSynchronize", "idkptDownload",
@@ -38,7 +38,7 @@ def load():
     sig = {
         "idkptCreate": [i32, C.POINTER(i32), C.POINTER(vp)], "idkptDestroy": [vp], "idkptGetLastError": [vp, C.POINTER(C.c_char_p)],
         "idkptGetDeviceCount": [C.POINTER(i32)], "idkptSetSize": [vp, i32, i32], "idkptSetRowSharding": [vp, i32, i32],
-        "idkptSetSlotBases": [vp, vp, i32], "idkptSetSettings": [vp, vp], "idkptGetSettings": [vp, vp],
+        "idkptSetRowRange": [vp, i32, i32], "idkptSetBounceExchange": [vp, vp, vp], "idkptSetSettings": [vp, vp], "idkptGetSettings": [vp, vp],
         "idkptSetPerFrame": [vp, vp, vp, vp], "idkptSetPerFrameData": [vp, vp], "idkptUploadScene": [vp, vp],
         "idkptUpdateBuffer": [vp, i32, sz, sz, vp], "idkptSetLightCount": [vp, i32], "idkptBuildTlas": [vp, vp, i32], "idkptBuildTlasOnDevice": [vp, i32], "idkptTraceRays": [vp, vp, sz, u32, vp], "idkptTraceShadows": [vp, vp, vp, vp, vp],
         "idkptRefitBlas": [vp, i32], "idkptUploadUnskinnedVertices": [vp, vp, i32], "idkptSkin": [vp, u32, u32, u32, u32],

@@ -47,7 +47,7 @@ struct idkpt_ctx {
     bool counters = false, timing = false, capturePrimary = false, forceGeneric = false, noTileCull = false; int traceVariant = 0;
     // scene
     bool haveScene = false;
-    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass;
+    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;
     std::vector<DevBuf> texData;
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
@@ -58,7 +58,8 @@ struct idkpt_ctx {
     DevBuf trLo, trLd, trInv, contFlag, blockSums, rayO, rayT, rayR, aovA, aovN, hit, hitX, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, contMask, waveCounts, counts, work, sortHist, counters64;
     DevBuf img[3];
     float4* extImg[3] = {nullptr, nullptr, nullptr};
-    uint32_t slotBases[MAX_DEPTH_SLOTS];
+    int rowLimit = 0x7fffffff;                           // idkptSetRowRange: at most this many local rows
+    idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // exact multi-GPU deep paths (idkptSetBounceExchange)
     // stats
     idkpt_stats stats;
     uint32_t* hCounts = nullptr; // pinned
@@ -183,7 +184,6 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
     memset(&ctx->st, 0, sizeof(ctx->st));
     ctx->st.Gpu.FocalLength = 8.0f; ctx->st.Gpu.DoRussianRoulette = 1; ctx->st.RayDepth = 7; ctx->st.SamplesPerPixel = 1;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
-    memset(ctx->slotBases, 0, sizeof(ctx->slotBases));
     memset(ctx->invProj, 0, 64); memset(ctx->invView, 0, 64); memset(ctx->viewPos, 0, 12);
     if (hipHostMalloc((void**)&ctx->hCounts, MAX_DEPTH_SLOTS * 4 + 16, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4 + 16);
@@ -204,7 +204,7 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -232,7 +232,7 @@ int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height)
     REQUIRE(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
-    ctx->W = width; ctx->H = height; ctx->rows = local_rows(height, ctx->rowMod, ctx->rowRem);
+    ctx->W = width; ctx->H = height; ctx->rows = std::min(ctx->rowLimit, local_rows(height, ctx->rowMod, ctx->rowRem));
     return alloc_frame(ctx);
 }
 
@@ -241,18 +241,27 @@ int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemain
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(rowModulo >= 1 && rowRemainder >= 0 && rowRemainder < rowModulo, "idkptSetRowSharding: need 0 <= remainder < modulo");
     FLUSH();
-    ctx->rowMod = rowModulo; ctx->rowRem = rowRemainder;
+    ctx->rowMod = rowModulo; ctx->rowRem = rowRemainder; ctx->rowLimit = 0x7fffffff;
     if (ctx->W > 0) { HIPC(hipSetDevice(ctx->device)); ctx->rows = local_rows(ctx->H, rowModulo, rowRemainder); return alloc_frame(ctx); }
     return IDKPT_OK;
 }
 
-int32_t idkptSetSlotBases(idkpt_ctx* ctx, const uint32_t* slotBases, int32_t count)
+int32_t idkptSetRowRange(idkpt_ctx* ctx, int32_t firstRow, int32_t rowCount)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
-    REQUIRE(count >= 0 && count <= MAX_DEPTH_SLOTS, "idkptSetSlotBases: count out of range");
+    REQUIRE(firstRow >= 0 && rowCount >= 1, "idkptSetRowRange: need firstRow >= 0 and rowCount >= 1");
+    REQUIRE(ctx->W <= 0 || firstRow + rowCount <= ctx->H, "idkptSetRowRange: strip exceeds the image height");
     FLUSH();
-    memset(ctx->slotBases, 0, sizeof(ctx->slotBases));
-    for (int i = 0; i < count; i++) ctx->slotBases[i] = slotBases[i];
+    ctx->rowMod = 1; ctx->rowRem = firstRow; ctx->rowLimit = rowCount;
+    if (ctx->W > 0) { HIPC(hipSetDevice(ctx->device)); ctx->rows = std::min(ctx->rowLimit, local_rows(ctx->H, 1, firstRow)); return alloc_frame(ctx); }
+    return IDKPT_OK;
+}
+
+int32_t idkptSetBounceExchange(idkpt_ctx* ctx, idkpt_bounce_exchange_fn fn, void* user)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    FLUSH();
+    ctx->exchangeFn = fn; ctx->exchangeUser = user;
     return IDKPT_OK;
 }
 
@@ -702,7 +711,7 @@ static int flush_batch(idkpt_ctx* ctx)
             else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.p, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
-            hipLaunchKernelGGL((k_shade<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, trNone, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const uint32_t*)nullptr, 0u,
+            hipLaunchKernelGGL((k_shade<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, trNone, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                                contMask, waveCounts, keysTmp);
             hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
         }
@@ -715,6 +724,19 @@ static int flush_batch(idkpt_ctx* ctx)
     for (int j = 1; j < depth; j++) {
         uint32_t* q = ctx->queue[side].as<uint32_t>(); uint32_t* k = ctx->keys[side].as<uint32_t>();
         const uint32_t* cnt = counts + j;
+        // exact multi-GPU deep paths: the host tells every sample how many alive rays the contexts above this strip hold (idkpt.h)
+        const uint32_t* gbase = nullptr;
+        if (ctx->exchangeFn) {
+            std::vector<uint32_t> hb(B + 1), local(B), outBases(B, 0u);
+            HIPC(hipMemcpyAsync(hb.data(), bases + j * BS, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            for (int b2 = 0; b2 < B; b2++) local[b2] = hb[b2 + 1] - hb[b2];
+            ctx->exchangeFn(ctx->exchangeUser, j, B, local.data(), outBases.data());
+            HIPC(ctx->gbases.ensure((size_t)MAX_BATCH * 4));
+            HIPC(hipMemcpyAsync(ctx->gbases.p, outBases.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+            HIPC(hipStreamSynchronize(st));                      // outBases is a stack vector
+            gbase = ctx->gbases.as<uint32_t>();
+        }
         if (ctx->st.DoRaySorting && j > 1) {
             // RaySorting() (PathTracer.cs:232-237): stable sort of (key, rayIndex); key = 21-bit triangle id with the batch's
             // sample index above it, so one sort orders every sample's queue exactly like a stand-alone counting sort
@@ -738,7 +760,7 @@ static int flush_batch(idkpt_ctx* ctx)
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
         }
         TRACE_T1();
-        hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, fast ? tr : trNone, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), ctx->slotBases[j],
+        hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, fast ? tr : trNone, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), gbase,
                            contMask, waveCounts, keysTmp);
         hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, cnt, 0u, blockSums, (const uint32_t*)waveLocal, counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr),

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs 
 
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm,
-                                               const uint32_t* qbase, uint32_t slotBase, unsigned long long* contMask, uint32_t* waveCounts, uint32_t* keysTmp)
+                                               const uint32_t* qbase, const uint32_t* gbase /* null: single context */, unsigned long long* contMask, uint32_t* waveCounts, uint32_t* keysTmp)
 {
     // FIRST: slots are ray ids (sample-major, Npad per sample, Npad % 64 == 0).  Otherwise slots are positions of the
     // batch-wide alive queue, which is grouped by sample; qbase[k] = first slot of sample k.
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
                 int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
                 gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
             } else {
-                uint32_t gslot = slotBase + (slot - qbase[smp]);  // slot inside this sample's own queue
+                uint32_t gslot = (gbase ? gbase[smp] : 0u) + (slot - qbase[smp]);  // slot inside this sample's own queue (+ the alive rays of the strips above, idkptSetBounceExchange)
                 rng = gslot * 4096u + acc;            // NHit:54
                 gidSeed = gslot;                      // Shading.glsl:74 with gl_GlobalInvocationID = (slot, 0)
             }

@@ -6,8 +6,10 @@ CPU tests).  The reference is single-GPU; this is the MI355X-n
     rank r renders rows y with y % world == r (interleaving balances sky rows against geometry rows);
   * per frame the only exchange is the all-gather of the finished row shards (4.1 MB per GPU at 1080p on 8 GPUs);
   * no data-path collective inside a frame.  At RayDepth 2 (the headline metric) radiance is independent of the queue
-    slot, so N-GPU output == 1-GPU output bit-for-bit; for deeper paths the NHit RNG seeds use
-    the local slot unless `slot_bases` are supplied (idkptSetSlotBases), i.e. parity is statistical beyond depth 2.
+    slot, so N-GPU output == 1-GPU output bit-for-bit.  For deeper paths the NHit RNG seeds depend on the
+    queue slot: `exact_deep_paths` switches to contiguous strips + an all-gather of the per-sample alive counts per bounce
+    (idkptSetRowRange / idkptSetBounceExchange, make_count_exchange), which restores bit-exact parity at any depth (sorting off);
+    without it parity beyond depth 2 is statistical.
 """
 import numpy as np
 import torch
@@ -19,6 +21,30 @@ _SCENE_FIELDS = ["blas_nodes", "blas_triangles", "blas_descs", "blas_instances",
 
 def rows_of_rank(height, world, rank):
     return list(range(rank, height, world))
+
+
+def strip_of_rank(height, world, rank):
+    """Contiguous strip (first_row, row_count) of rank `rank`: rows are dealt as evenly as possible, earlier ranks get the extra row."""
+    base, extra = divmod(height, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def make_count_exchange(group=None):
+    """Host side of idkptSetBounceExchange for one process per strip: all-gather of the per-sample alive counts (a few uint32 per
+    bounce and batch, on the CPU: use a gloo group next to the RCCL one), base[k] = sum of count[k] over the ranks above.
+    Ranks own strips in rank order (strip_of_rank), so "above" = lower rank."""
+    rank = dist.get_rank(group); world = dist.get_world_size(group)
+
+    def exchange(bounce, local_counts):
+        mine = torch.from_numpy(np.ascontiguousarray(local_counts, np.int64).astype(np.int64))
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        base = np.zeros(len(local_counts), np.int64)
+        for r in range(rank):
+            base += parts[r].numpy()
+        return base.astype(np.uint32)
+    return exchange
 
 
 def broadcast_scene(scene, src=0, device=None, group=None):
@@ -85,11 +111,20 @@ class GpuShardRenderer:
     """Adapter: idkengine_amd.PathTracer rendering this rank's rows; exposes the local RGBA rows as a torch tensor that
     aliases the library's device image (no host copy before the RCCL all-gather)."""
 
-    def __init__(self, width, height, world, rank, device_index):
+    def __init__(self, width, height, world, rank, device_index, exact_deep_paths=False, control_group=None):
+        """exact_deep_paths: contiguous strips + per-bounce count exchange over `control_group` (a CPU/gloo group), so that N-GPU
+        output equals 1-GPU output bit for bit at any RayDepth (sorting off); default: interleaved rows, exact at RayDepth 2."""
         from .pathtracer import PathTracer
         torch.cuda.set_device(device_index)
         self.device = torch.device("cuda", device_index)
-        self.pt = PathTracer(width, height, device=device_index, row_modulo=world, row_remainder=rank)
+        self.exact = exact_deep_paths
+        if exact_deep_paths:
+            self.pt = PathTracer(width, height, device=device_index)
+            first, count = strip_of_rank(height, world, rank)
+            self.pt.SetRowRange(first, count)
+            self.pt.SetBounceExchange(make_count_exchange(control_group))
+        else:
+            self.pt = PathTracer(width, height, device=device_index, row_modulo=world, row_remainder=rank)
         # render on a dedicated torch stream and issue the collectives under it: RCCL work is then ordered after the
         # kernels that produce the image, and later renders are ordered after the collective that reads it
         self.stream = torch.cuda.Stream(device=self.device)
@@ -125,7 +160,8 @@ class ShardedFrame:
         self.world = dist.get_world_size(group); self.rank = dist.get_rank(group)
         self.width, self.height = width, height
         self.max_rows = (height + self.world - 1) // self.world
-        assert renderer.rows == len(rows_of_rank(height, self.world, self.rank))
+        self.strips = bool(getattr(renderer, "exact", False))           # contiguous strips (exact deep paths) or interleaved rows
+        assert renderer.rows == (strip_of_rank(height, self.world, self.rank)[1] if self.strips else len(rows_of_rank(height, self.world, self.rank)))
 
     def render(self):
         self.r.render()
@@ -146,6 +182,10 @@ class ShardedFrame:
         dist.all_gather(parts, local.contiguous(), group=self.group)
         full = torch.empty((self.height, self.width, 4), dtype=local.dtype, device=local.device)
         for r in range(self.world):
-            n = len(rows_of_rank(self.height, self.world, r))
-            full[r::self.world] = parts[r][:n]
+            if self.strips:
+                first, n = strip_of_rank(self.height, self.world, r)
+                full[first:first + n] = parts[r][:n]
+            else:
+                n = len(rows_of_rank(self.height, self.world, r))
+                full[r::self.world] = parts[r][:n]
         return full

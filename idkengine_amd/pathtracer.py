@@ -31,6 +31,7 @@ class PathTracer:
         self._scene = None
         self.width, self.height = width, height
         self.row_modulo, self.row_remainder = row_modulo, row_remainder
+        self._row_limit = None
         self._check(self._L.idkptSetRowSharding(ctx, row_modulo, row_remainder))
         self._check(self._L.idkptSetSize(ctx, width, height))
         self._push_settings()
@@ -47,7 +48,8 @@ class PathTracer:
 
     @property
     def rows(self):
-        return len(range(self.row_remainder, self.height, self.row_modulo))
+        n = len(range(self.row_remainder, self.height, self.row_modulo))
+        return n if self._row_limit is None else min(n, self._row_limit)
 
     # ------------------------------------------------------------------ PathTracer.cs public surface
     def _prop(name, gpu=False):  # noqa: N805
@@ -182,11 +184,28 @@ class PathTracer:
     def Skin(self, input_offset, output_offset, joint_offset, count):
         self._check(self._L.idkptSkin(self._ctx, input_offset, output_offset, joint_offset, count))
 
-    def SetSlotBases(self, bases):
-        b = np.ascontiguousarray(bases, np.uint32)
-        self._check(self._L.idkptSetSlotBases(self._ctx, b.ctypes.data, len(b)))
+    def SetRowRange(self, first_row, row_count):
+        """idkptSetRowRange: this context renders the contiguous strip [first_row, first_row + row_count)."""
+        self._check(self._L.idkptSetRowRange(self._ctx, int(first_row), int(row_count)))
+        self.row_modulo, self.row_remainder, self._row_limit = 1, int(first_row), int(row_count)
 
-    # ------------------------------------------------------------------ outputs / instrumentation
+    def SetBounceExchange(self, fn):
+        """idkptSetBounceExchange: fn(bounce, local_counts ndarray[samples]) -> bases ndarray[samples] (alive rays of the same sample
+        held by the contexts that own earlier rows); None disables.  Needed for exact N-GPU == 1-GPU results beyond RayDepth 2."""
+        import ctypes as C
+        if fn is None:
+            self._xfn = None
+            self._check(self._L.idkptSetBounceExchange(self._ctx, None, None))
+            return
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+
+        def tramp(user, bounce, n, counts, out):
+            b = fn(int(bounce), np.array([counts[i] for i in range(n)], np.uint32))
+            for i in range(n):
+                out[i] = int(b[i])
+        self._xfn = proto(tramp)       # keep the trampoline alive as long as the context uses it
+        self._check(self._L.idkptSetBounceExchange(self._ctx, self._xfn, None))
+
     def synchronize(self):
         self._check(self._L.idkptSynchronize(self._ctx))
 

@@ -153,9 +153,18 @@ IDKPT_API int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height);
  * (rowModulo = world size, rowRemainder = rank).  Images/ray buffers then hold only the local rows, in
  * increasing y.  (1,0) = whole frame.  No reference equivalent (single GPU); DESIGN.md "Multi-GPU". */
 IDKPT_API int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemainder);
-/* Per-bounce global queue-slot base for exact N-GPU == 1-GPU RNG seeds (NHit/compute.glsl:54 seeds from the slot).
- * slotBases[j] is added to the local slot in bounce j (j = 1..count-1).  Optional; default all 0. */
-IDKPT_API int32_t idkptSetSlotBases(idkpt_ctx* ctx, const uint32_t* slotBases, int32_t count);
+/* Contiguous strip instead of interleaved rows: this context renders image rows [firstRow, firstRow + rowCount).  Strips keep every
+ * context's pixels contiguous in the canonical (pixel-index) order, which the exact multi-GPU mode below needs; interleaved rows
+ * balance better and are the default for RayDepth 2. */
+IDKPT_API int32_t idkptSetRowRange(idkpt_ctx* ctx, int32_t firstRow, int32_t rowCount);
+/* Exact N-GPU == 1-GPU results for RayDepth > 2 (no reference equivalent: single GPU).  NHit seeds its RNG from the queue slot
+ * (NHit/compute.glsl:54), so a context that renders a strip must number its slots from the alive rays of all strips above it.
+ * At the start of bounce j the library calls fn(user, j, sampleCount, localCounts, outBases) on the caller's thread (it synchronises
+ * the stream first): localCounts[k] = this context's alive rays of in-flight sample k entering bounce j; the host fills
+ * outBases[k] = sum of the same count over all contexts that own EARLIER rows (one small all-gather per bounce and batch).
+ * Exact with DoRaySorting off; with sorting on the per-context sort is local and parity beyond depth 2 is statistical.  NULL disables. */
+typedef void (*idkpt_bounce_exchange_fn)(void* user, int32_t bounce, int32_t sampleCount, const uint32_t* localCounts, uint32_t* outBases);
+IDKPT_API int32_t idkptSetBounceExchange(idkpt_ctx* ctx, idkpt_bounce_exchange_fn fn, void* user);
 /* Property setters of PathTracer (PathTracer.cs:12-125); changing anything but DoRussianRoulette/sorting/AOV
  * resets accumulation exactly like the reference setters do. */
 IDKPT_API int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* settings);

@@ -163,6 +163,26 @@ class OraclePathTracer:
         self._pt = L.ref_pt_create(self._scene, width, height, row_modulo, row_remainder)
         self.settings = T.Settings.default()
 
+    def set_row_range(self, first_row, row_count):
+        """idkptSetRowRange: contiguous strip [first_row, first_row + row_count)."""
+        lib().ref_pt_set_row_range(C.c_void_p(self._pt), int(first_row), int(row_count))
+        self.rows = min(int(row_count), self.height - int(first_row))
+
+    def set_bounce_exchange(self, fn):
+        """idkptSetBounceExchange: fn(bounce, local_counts ndarray) -> bases ndarray (same length); None disables."""
+        if fn is None:
+            self._xfn = None
+            lib().ref_pt_set_bounce_exchange(C.c_void_p(self._pt), None, None)
+            return
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+
+        def tramp(user, bounce, n, counts, out):
+            b = fn(int(bounce), np.array([counts[i] for i in range(n)], np.uint32))
+            for i in range(n):
+                out[i] = int(b[i])
+        self._xfn = proto(tramp)       # keep the trampoline alive
+        lib().ref_pt_set_bounce_exchange(C.c_void_p(self._pt), self._xfn, None)
+
     def close(self):
         if self._pt:
             lib().ref_pt_destroy(self._pt); lib().ref_scene_destroy(self._scene)

@@ -374,6 +374,7 @@ struct PT {
     std::vector<uint32_t> keys;
     std::vector<float> primT, primBary; std::vector<uint32_t> primTri;
     uint32_t aliveCounts[16];
+    idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // multi-context exact mode (idkptSetBounceExchange)
     Counters counters; bool countersOn = false;
     uint64_t raysTraced = 0;
 };
@@ -558,6 +559,9 @@ static void RenderSample(PT& pt)
             for (size_t i = 0; i < A; i++) sorted[i] = pt.alive[order[i]];
             pt.alive.swap(sorted);
         }
+        // exact multi-context mode: global slot = local slot + alive rays of the contexts that own earlier rows (include/idkpt.h)
+        uint32_t slotBase = 0;
+        if (pt.exchangeFn) { uint32_t localCount = (uint32_t)A; pt.exchangeFn(pt.exchangeUser, j, 1, &localCount, &slotBase); }
         std::vector<uint8_t> cont2(A); std::vector<uint32_t> keyOut(A, 0u);
         std::vector<Counters> chunkCnt((A + 255) / 256);
         // ---- NHit main (NHit/compute.glsl:40-89), one invocation per queue slot ----
@@ -565,7 +569,7 @@ static void RenderSample(PT& pt)
         for (long long chunk = 0; chunk < (long long)((A + 255) / 256); chunk++) {
             for (size_t slot = (size_t)chunk * 256; slot < std::min(A, (size_t)(chunk + 1) * 256); slot++) {
                 uint32_t rayIndex = pt.alive[slot];
-                uint32_t gslot = (uint32_t)slot;
+                uint32_t gslot = slotBase + (uint32_t)slot;
                 Rng rng; rng.seed = gslot * 4096u + pt.accumulated;
                 GpuWavefrontRay wr = pt.rays[rayIndex]; GpuAovRay ar = pt.aov[rayIndex];
                 uint32_t key = 0;
@@ -754,6 +758,17 @@ void* ref_pt_create(void* scene, int w, int h, int rowMod, int rowRem)
     return pt;
 }
 void ref_pt_destroy(void* p) { delete (PT*)p; }
+// idkptSetRowRange / idkptSetBounceExchange counterparts
+void ref_pt_set_row_range(void* p, int firstRow, int rowCount)
+{
+    PT* pt = (PT*)p; pt->rowMod = 1; pt->rowRem = firstRow; pt->rows = std::min(rowCount, pt->H - firstRow);
+    size_t N = (size_t)pt->W * pt->rows;
+    pt->rays.assign(N, GpuWavefrontRay{}); pt->aov.assign(N, GpuAovRay{});
+    for (int i = 0; i < 3; i++) pt->img[i].assign(4 * N, 0.0f);
+    pt->primT.assign(N, 0.0f); pt->primTri.assign(N, 0u); pt->primBary.assign(2 * N, 0.0f);
+    pt->accumulated = 0;
+}
+void ref_pt_set_bounce_exchange(void* p, idkpt_bounce_exchange_fn fn, void* user) { PT* pt = (PT*)p; pt->exchangeFn = fn; pt->exchangeUser = user; }
 void ref_pt_set_settings(void* p, const idkpt_settings* s) { ((PT*)p)->st = *s; }
 void ref_pt_set_perframe(void* p, const float* invProj, const float* invView, const float* viewPos) { PT* pt = (PT*)p; memcpy(pt->invProj, invProj, 64); memcpy(pt->invView, invView, 64); memcpy(pt->viewPos, viewPos, 12); }
 void ref_pt_reset_accumulation(void* p) { ((PT*)p)->accumulated = 0; }

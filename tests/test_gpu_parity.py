@@ -407,6 +407,69 @@ def test_full_size_frames_are_bit_exact(soup1m, oracle_mod, depth, sort, batch):
     pt.Dispose(); o.close()
 
 
+@pytest.mark.parametrize("batch", [1, 3])
+def test_exact_deep_paths_across_contexts(native_builder, oracle_mod, batch):
+    """idkptSetRowRange + idkptSetBounceExchange: three contexts (one per strip, driven by three host threads in lockstep, the
+    exchange function summing the counts of the strips above) reproduce the single-context frame bit for bit at RayDepth 6 —
+    image, ray state and the total ray count — also when several accumulated samples are traced per batch."""
+    import threading
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import dist as D, gputypes as T
+    sc = S.soup_scene(30000, native_builder, seed=6, extent=3.0); w, h = 200, 131; cam = S.Camera(w, h, position=(0.0, 0.0, 7.0))
+    ov = dict(RayDepth=6)
+    frames = 3
+    one = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); one.UploadScene(sc); one.SetCamera(cam)
+    for _ in range(frames):
+        one.Compute()
+    want = one.Result; want_rays = one.rays(); want_count = one.stats()["rays_traced"]
+    world = 3
+    barrier = threading.Barrier(world)
+    board = {}
+
+    def exchange_for(rank):
+        def fn(bounce, counts):
+            board[(bounce, rank)] = counts.copy()
+            barrier.wait(timeout=60)
+            base = np.zeros(len(counts), np.uint32)
+            for r in range(rank):
+                base += board[(bounce, r)]
+            barrier.wait(timeout=60)                     # nobody overwrites the board before everybody has read it
+            return base
+        return fn
+
+    pts, errs = [], []
+    for r in range(world):
+        p = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); p.UploadScene(sc); p.SetCamera(cam)
+        first, count = D.strip_of_rank(h, world, r); p.SetRowRange(first, count); p.SetBounceExchange(exchange_for(r)); p.set_max_batch(batch)
+        pts.append(p)
+
+    def run(p):
+        try:
+            for _ in range(frames):
+                p.Compute()
+            p.flush(); p.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e); barrier.abort()
+    threads = [threading.Thread(target=run, args=(p,)) for p in pts]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errs, errs
+    got = np.concatenate([p.Result for p in pts]); got_rays = np.concatenate([p.rays() for p in pts])
+    assert (bits(got) == bits(want)).all()
+    assert got_rays.tobytes() == want_rays.tobytes()
+    assert sum(p.stats()["rays_traced"] for p in pts) == want_count
+    # control: the same strips without the exchange differ at this depth
+    q = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); q.UploadScene(sc); q.SetCamera(cam)
+    first, count = D.strip_of_rank(h, world, 1); q.SetRowRange(first, count)
+    for _ in range(frames):
+        q.Compute()
+    assert (bits(q.Result) != bits(want[first:first + count])).any()
+    for p in pts + [one, q]:
+        p.Dispose()
+
+
 def test_row_sharded_contexts_reassemble_the_frame(soup1m):
     """Two contexts on one GPU, rows y%2==r: the multi-GPU sharding of dist.py without the transport."""
     from idkengine_amd.pathtracer import PathTracer
