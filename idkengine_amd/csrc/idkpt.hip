@@ -34,6 +34,8 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+struct PendingSample { uint32_t accum; int slot; float cam[36]; };   // cam = invProj[16] invView[16] viewPos[3] pad
+
 struct idkpt_ctx {
     int device = 0;
     hipStream_t stream = nullptr; bool ownStream = true;
@@ -43,11 +45,13 @@ struct idkpt_ctx {
     idkpt_settings st;
     int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0;
     float invProj[16], invView[16], viewPos[3];
-    uint32_t accumulated = 0;
+    // frame ring (idkptSetFrameRing): ringSize result-image sets; every queued sample remembers its slot, its camera and its
+    // AccumulatedSamples index, so several frames (different cameras) can be in flight in one batch
+    int ringSize = 1, curSlot = 0; std::vector<uint32_t> accum = std::vector<uint32_t>(1, 0u);
     bool counters = false, timing = false, capturePrimary = false, forceGeneric = false, noTileCull = false; int traceVariant = 0;
     // scene
     bool haveScene = false;
-    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;
+    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;   // (+ camTab below)
     std::vector<DevBuf> texData;
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
@@ -57,7 +61,7 @@ struct idkpt_ctx {
     // wavefront state
     DevBuf trLo, trLd, trInv, contFlag, blockSums, rayO, rayT, rayR, aovA, aovN, hit, hitX, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, contMask, waveCounts, counts, work, sortHist, counters64;
     DevBuf img[3];
-    float4* extImg[3] = {nullptr, nullptr, nullptr};
+    DevBuf camTab;                                       // per-sample cameras of the batch being launched (ring mode)
     int rowLimit = 0x7fffffff;                           // idkptSetRowRange: at most this many local rows
     idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // exact multi-GPU deep paths (idkptSetBounceExchange)
     // stats
@@ -68,7 +72,7 @@ struct idkpt_ctx {
     std::vector<hipEvent_t> evPool; size_t evUsed = 0;
     double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
     int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false, lastNeedsRegen = false; int lastBatch = 1; Frame lastFrame;
-    int maxBatch = 1; uint32_t Npad = 0; std::vector<uint32_t> pending; DevBuf bases; uint32_t* hBases = nullptr;
+    int maxBatch = 1; uint32_t Npad = 0; std::vector<PendingSample> pending; DevBuf bases; uint32_t* hBases = nullptr;
 };
 
 static hipEvent_t next_event(idkpt_ctx* ctx)
@@ -133,11 +137,11 @@ static int alloc_frame(idkpt_ctx* ctx)
     HIPC(ctx->bases.ensure((size_t)MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4));
     size_t nTiles = (cap + SORT_TILE - 1) / SORT_TILE;
     HIPC(ctx->sortHist.ensure((SORT_RADIX * nTiles + SORT_RADIX) * 4));
-    for (int i = 0; i < 3; i++) { HIPC(ctx->img[i].ensure(N * 16)); HIPC(hipMemsetAsync(ctx->img[i].p, 0, N * 16, ctx->stream)); }
+    for (int i = 0; i < 3; i++) { HIPC(ctx->img[i].ensure(N * 16 * ctx->ringSize)); HIPC(hipMemsetAsync(ctx->img[i].p, 0, N * 16 * ctx->ringSize, ctx->stream)); }   // slot s at offset s*N
     HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream));
     HIPC(hipMemsetAsync(ctx->aovA.p, 0, cap * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, cap * 16, ctx->stream));
     HIPC(hipMemsetAsync(ctx->contFlag.p, 0, cap, ctx->stream));   // per-batch values are written by k_gen_primary; the pad ids [N, Npad) must read 0
-    ctx->accumulated = 0;
+    ctx->accum.assign(ctx->ringSize, 0u); ctx->curSlot = 0;
     return IDKPT_OK;
 }
 
@@ -148,7 +152,7 @@ static int alloc_frame_keep_images(idkpt_ctx* ctx)
     DevBuf saved[3];
     for (int i = 0; i < 3; i++) { saved[i] = ctx->img[i]; ctx->img[i] = DevBuf(); }
     int rc = alloc_frame(ctx);
-    for (int i = 0; i < 3; i++) { if (rc == IDKPT_OK && saved[i].p) (void)hipMemcpy(ctx->img[i].p, saved[i].p, N * 16, hipMemcpyDeviceToDevice); saved[i].release(); }
+    for (int i = 0; i < 3; i++) { if (rc == IDKPT_OK && saved[i].p) (void)hipMemcpy(ctx->img[i].p, saved[i].p, N * 16 * ctx->ringSize, hipMemcpyDeviceToDevice); saved[i].release(); }
     return rc;
 }
 
@@ -204,7 +208,7 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->trLo, &ctx->trLd, &ctx->trInv, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -277,7 +281,7 @@ int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* s)
                  o.Gpu.DoDebugBVHTraversal != s->Gpu.DoDebugBVHTraversal || o.Gpu.DoTraceLights != s->Gpu.DoTraceLights || o.UseTlas != s->UseTlas;
     ctx->st = *s;
     if (ctx->st.Gpu.DoDebugBVHTraversal) ctx->st.RayDepth = 1; // PathTracer.cs:67-71
-    if (reset) ctx->accumulated = 0;
+    if (reset) std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
     return IDKPT_OK;
 }
 int32_t idkptGetSettings(idkpt_ctx* ctx, idkpt_settings* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->st; return IDKPT_OK; }
@@ -285,7 +289,8 @@ int32_t idkptGetSettings(idkpt_ctx* ctx, idkpt_settings* out) { if (!ctx || !out
 int32_t idkptSetPerFrame(idkpt_ctx* ctx, const float invProjection[16], const float invView[16], const float viewPos[3])
 {
     if (!ctx || !invProjection || !invView || !viewPos) return IDKPT_ERR_INVALID_ARGUMENT;
-    if (memcmp(ctx->invProj, invProjection, 64) || memcmp(ctx->invView, invView, 64) || memcmp(ctx->viewPos, viewPos, 12)) FLUSH();
+    // one camera per batch unless a frame ring is active (then every queued sample carries its own camera)
+    if (ctx->ringSize == 1 && (memcmp(ctx->invProj, invProjection, 64) || memcmp(ctx->invView, invView, 64) || memcmp(ctx->viewPos, viewPos, 12))) FLUSH();
     memcpy(ctx->invProj, invProjection, 64); memcpy(ctx->invView, invView, 64); memcpy(ctx->viewPos, viewPos, 12);
     return IDKPT_OK;
 }
@@ -401,7 +406,7 @@ int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
     if ((rc = regather_triverts(ctx, 0, (uint32_t)sc->BlasTriangleCount))) return rc;
     HIPC(hipStreamSynchronize(ctx->stream)); // host arrays are only borrowed for the duration of the call
     ctx->haveScene = true;
-    ctx->accumulated = 0;
+    std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
     return IDKPT_OK;
 }
 
@@ -606,8 +611,8 @@ int32_t idkptSkin(idkpt_ctx* ctx, uint32_t inOff, uint32_t outOff, uint32_t join
     return IDKPT_OK;
 }
 
-int32_t idkptResetAccumulation(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->accumulated = 0; return IDKPT_OK; }
-int32_t idkptGetAccumulatedSamples(idkpt_ctx* ctx, uint32_t* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->accumulated; return IDKPT_OK; }
+int32_t idkptResetAccumulation(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->accum[ctx->curSlot] = 0; return IDKPT_OK; }
+int32_t idkptGetAccumulatedSamples(idkpt_ctx* ctx, uint32_t* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->accum[ctx->curSlot]; return IDKPT_OK; }
 
 static DScene make_dscene(idkpt_ctx* ctx)
 {
@@ -621,7 +626,7 @@ static DScene make_dscene(idkpt_ctx* ctx)
     return s;
 }
 
-static float4* image_ptr(idkpt_ctx* ctx, int i) { return ctx->extImg[i] ? ctx->extImg[i] : ctx->img[i].as<float4>(); }
+static float4* image_ptr(idkpt_ctx* ctx, int i, int slot) { return ctx->img[i].as<float4>() + (size_t)slot * ((size_t)ctx->W * ctx->rows); }
 
 // fast path = persistent while-while traversal (one BLAS, instance list or TLAS); only the debug traversal-cost view uses the general kernel
 static bool fast_path(idkpt_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
@@ -639,14 +644,23 @@ static int flush_batch(idkpt_ctx* ctx)
     const uint32_t total = (uint32_t)B * Npad;
     DScene s = make_dscene(ctx);
     Frame f;
-    memcpy(f.invProj, ctx->invProj, 64); memcpy(f.invView, ctx->invView, 64); memcpy(f.viewPos, ctx->viewPos, 12);
+    memcpy(f.invProj, ctx->pending[0].cam, 64); memcpy(f.invView, ctx->pending[0].cam + 16, 64); memcpy(f.viewPos, ctx->pending[0].cam + 32, 12);   // the camera the samples were queued with
     f.W = ctx->W; f.H = ctx->H; f.rowMod = ctx->rowMod; f.rowRem = ctx->rowRem; f.rows = ctx->rows;
     f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;
     f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
     f.outputAovs = ctx->st.OutputAOVs;
     f.batch = B; f.Npad = Npad;
-    for (int k = 0; k < MAX_BATCH; k++) f.accum[k] = k < B ? ctx->pending[k] : 0u;
+    for (int k = 0; k < MAX_BATCH; k++) { f.accum[k] = k < B ? ctx->pending[k].accum : 0u; f.slotOf[k] = (uint8_t)(k < B ? ctx->pending[k].slot : 0); }
     f.accumulated = f.accum[0];
+    f.cams = nullptr;
+    if (ctx->ringSize > 1) {   // frame ring: every sample renders with the camera it was queued with
+        std::vector<float> cams((size_t)B * 36);
+        for (int k = 0; k < B; k++) memcpy(&cams[(size_t)k * 36], ctx->pending[k].cam, 36 * 4);
+        HIPC(ctx->camTab.ensure((size_t)MAX_BATCH * 36 * 4));
+        HIPC(hipMemcpyAsync(ctx->camTab.p, cams.data(), cams.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));            // cams is a stack vector
+        f.cams = ctx->camTab.as<float>();
+    }
     RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
     HitBufs hits = {ctx->hit.as<float4>(), ctx->hitX.as<uint32_t>(), ctx->hitCost.as<float>()};
     uint32_t* counts = ctx->counts.as<uint32_t>();
@@ -693,8 +707,9 @@ static int flush_batch(idkpt_ctx* ctx)
             if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits.hit + (size_t)(B - 1) * Npad, hits.xformId + (size_t)(B - 1) * Npad, N);
             tileClass = nullptr;
             if (cull && !ctx->noTileCull) {   // sample-independent pre-classification of the 8x8 tiles (conservative whole-tile miss test)
-                HIPC(ctx->tileClass.ensure(genWaves));
-                hipLaunchKernelGGL(k_classify_tiles, dim3((genWaves + 255) / 256), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
+                const uint32_t classSets = f.cams ? (uint32_t)B : 1u;       // one classification per camera
+                HIPC(ctx->tileClass.ensure((size_t)genWaves * classSets));
+                hipLaunchKernelGGL(k_classify_tiles, dim3((genWaves + 255) / 256, classSets), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
                 tileClass = ctx->tileClass.as<uint8_t>();
             }
             hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass);
@@ -770,7 +785,7 @@ static int flush_batch(idkpt_ctx* ctx)
         side = 1 - side;
     }
     ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast; ctx->lastNeedsRegen = fast; ctx->lastBatch = B; ctx->lastFrame = f;
-    hipLaunchKernelGGL(k_final_draw, dim3((N + 255) / 256), dim3(256), 0, st, s, f, rays, image_ptr(ctx, 0), image_ptr(ctx, 1), image_ptr(ctx, 2), N, tileClass);
+    hipLaunchKernelGGL(k_final_draw, dim3((N + 255) / 256), dim3(256), 0, st, s, f, rays, image_ptr(ctx, 0, 0), image_ptr(ctx, 1, 0), image_ptr(ctx, 2, 0), N, tileClass);
     HIPC(hipGetLastError());
     // queue lengths stay on the GPU during the batch; a copy goes to pinned memory for GetStats (no sync here)
     HIPC(hipMemcpyAsync(ctx->hCounts, counts, MAX_DEPTH_SLOTS * 4, hipMemcpyDeviceToHost, st));
@@ -794,7 +809,9 @@ int32_t idkptRender(idkpt_ctx* ctx)
     // results).  The general path (multi-instance / TLAS / debug cost) is launched sample by sample.
     const int limit = fast_path(ctx) ? ctx->maxBatch : 1;
     for (int i = 0; i < ctx->st.SamplesPerPixel; i++) {
-        ctx->pending.push_back(ctx->accumulated++);
+        PendingSample ps; ps.accum = ctx->accum[ctx->curSlot]++; ps.slot = ctx->curSlot;
+        memcpy(ps.cam, ctx->invProj, 64); memcpy(ps.cam + 16, ctx->invView, 64); memcpy(ps.cam + 32, ctx->viewPos, 12); ps.cam[35] = 0.0f;
+        ctx->pending.push_back(ps);
         if ((int)ctx->pending.size() >= limit) { int rc = flush_batch(ctx); if (rc) return rc; }
     }
     return IDKPT_OK;
@@ -814,7 +831,54 @@ int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
     HIPC(hipStreamSynchronize(ctx->stream));
     if (maxBatch == ctx->maxBatch) return IDKPT_OK;
     ctx->maxBatch = maxBatch;
-    if (ctx->W > 0) { uint32_t acc = ctx->accumulated; int rc = alloc_frame_keep_images(ctx); if (rc) return rc; ctx->accumulated = acc; }
+    if (ctx->W > 0) { std::vector<uint32_t> acc = ctx->accum; int slot = ctx->curSlot; int rc = alloc_frame_keep_images(ctx); if (rc) return rc; ctx->accum = acc; ctx->curSlot = slot; }
+    return IDKPT_OK;
+}
+
+int32_t idkptSetFrameRing(idkpt_ctx* ctx, int32_t frames)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(frames >= 1 && frames <= 128, "idkptSetFrameRing: 1..128 frames");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    HIPC(hipStreamSynchronize(ctx->stream));
+    if (frames == ctx->ringSize) return IDKPT_OK;
+    ctx->ringSize = frames;
+    if (ctx->W > 0) return alloc_frame(ctx);       // images are re-created (cleared); accumulation restarts in slot 0
+    ctx->accum.assign(frames, 0u); ctx->curSlot = 0;
+    return IDKPT_OK;
+}
+
+int32_t idkptBeginFrame(idkpt_ctx* ctx, int32_t* outSlot)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    ctx->curSlot = (ctx->curSlot + 1) % ctx->ringSize;
+    ctx->accum[ctx->curSlot] = 0;                   // a new frame: its first sample overwrites whatever the slot held
+    if (outSlot) *outSlot = ctx->curSlot;
+    return IDKPT_OK;
+}
+
+int32_t idkptDownloadFrame(idkpt_ctx* ctx, int32_t slot, int32_t image, float* rgba, size_t bytes)
+{
+    if (!ctx || !rgba) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(image >= 0 && image < 3, "idkptDownloadFrame: bad image id");
+    REQUIRE(slot >= 0 && slot < ctx->ringSize, "idkptDownloadFrame: slot outside the frame ring");
+    size_t need = (size_t)ctx->W * ctx->rows * 16;
+    REQUIRE(bytes == need && need > 0, "idkptDownloadFrame: bytes must equal localRows*width*16");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image, slot), need, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    return IDKPT_OK;
+}
+
+int32_t idkptGetFrameDevicePtr(idkpt_ctx* ctx, int32_t slot, int32_t image, void** outPtr, size_t* outBytes)
+{
+    if (!ctx || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(image >= 0 && image < 3, "idkptGetFrameDevicePtr: bad image id");
+    REQUIRE(slot >= 0 && slot < ctx->ringSize, "idkptGetFrameDevicePtr: slot outside the frame ring");
+    *outPtr = image_ptr(ctx, image, slot);
+    if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
     return IDKPT_OK;
 }
 
@@ -826,7 +890,7 @@ int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes)
     REQUIRE(bytes == need && need > 0, "idkptDownload: bytes must equal localRows*width*16");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
-    HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image), need, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image, ctx->curSlot), need, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
 }
@@ -934,7 +998,7 @@ int32_t idkptGetImageDevicePtr(idkpt_ctx* ctx, int32_t image, void** outPtr, siz
 {
     if (!ctx || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(image >= 0 && image < 3 && ctx->W > 0, "idkptGetImageDevicePtr: bad image / no size");
-    *outPtr = image_ptr(ctx, image);
+    *outPtr = image_ptr(ctx, image, ctx->curSlot);
     if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
     return IDKPT_OK;
 }

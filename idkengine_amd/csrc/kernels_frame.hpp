@@ -17,25 +17,35 @@ __global__ __launch_bounds__(256) void k_final_draw(DScene s, Frame f, RayBufs r
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    float4 o = imgResult[i];
+    // the images of ring slot q start at q*N; samples are accumulated in submission order, exactly like consecutive FinalDraw dispatches,
+    // each into the image of its own frame (consecutive samples of one frame share a slot)
+    uint32_t slot = f.slotOf[0];
+    float4 o = imgResult[(size_t)slot * N + i];
     f3 r = mk3(o.x, o.y, o.z), ra = splat3(0.0f), rn = splat3(0.0f);
-    if (f.outputAovs) { float4 oa = imgAlbedo[i], on = imgNormal[i]; ra = mk3(oa.x, oa.y, oa.z); rn = mk3(on.x, on.y, on.z); }
-    // pixels of a pre-classified tile (k_classify_tiles): every sample's radiance is the same known sky colour; nothing was stored per sample
-    uint32_t cls = 0;
-    if (tileClass) { const uint32_t x = i % (uint32_t)f.W, y = i / (uint32_t)f.W; cls = tileClass[(y >> 3) * (((uint32_t)f.W + 7) / 8) + (x >> 3)]; }
-    f3 tileColor = splat3(0.0f);
-    if (cls >= 1u && cls <= 6u) { const float4 p = s.sky[cls - 1u]; tileColor = splat3(0.0f) + mk3(p.x, p.y, p.z) * splat3(1.0f); }
-    for (int k = 0; k < f.batch; k++) {                 // samples are accumulated in submission order, exactly like consecutive FinalDraw dispatches
+    if (f.outputAovs) { float4 oa = imgAlbedo[(size_t)slot * N + i], on = imgNormal[(size_t)slot * N + i]; ra = mk3(oa.x, oa.y, oa.z); rn = mk3(on.x, on.y, on.z); }
+    const uint32_t px = i % (uint32_t)f.W, py = i / (uint32_t)f.W, tilesX = ((uint32_t)f.W + 7) / 8;
+    const uint32_t tile = (py >> 3) * tilesX + (px >> 3), nTilesAll = tilesX * (((uint32_t)f.rows + 7) / 8);
+    for (int k = 0; k < f.batch; k++) {
+        if (f.slotOf[k] != slot) {                       // next frame of the ring: store, switch, load
+            imgResult[(size_t)slot * N + i] = make_float4(r.x, r.y, r.z, 1.0f);
+            if (f.outputAovs) { imgAlbedo[(size_t)slot * N + i] = make_float4(ra.x, ra.y, ra.z, 1.0f); imgNormal[(size_t)slot * N + i] = make_float4(rn.x, rn.y, rn.z, 1.0f); }
+            slot = f.slotOf[k];
+            o = imgResult[(size_t)slot * N + i]; r = mk3(o.x, o.y, o.z);
+            if (f.outputAovs) { float4 oa = imgAlbedo[(size_t)slot * N + i], on = imgNormal[(size_t)slot * N + i]; ra = mk3(oa.x, oa.y, oa.z); rn = mk3(on.x, on.y, on.z); }
+        }
         const size_t rid = (size_t)k * f.Npad + i;
         float w = 1.0f / ((float)f.accum[k] + 1.0f);
-        f3 nr = tileColor;
+        // pixels of a pre-classified tile (k_classify_tiles): the radiance is the known sky colour of the class; nothing was stored per sample
+        const uint32_t cls = tileClass ? tileClass[(f.cams ? (size_t)k * nTilesAll : 0) + tile] : 0u;
+        f3 nr = splat3(0.0f);
         if (cls == 0u) { float4 c = rays.rad_py[rid]; nr = mk3(c.x, c.y, c.z); }
+        else if (cls <= 6u) { const float4 p = s.sky[cls - 1u]; nr = splat3(0.0f) + mk3(p.x, p.y, p.z) * splat3(1.0f); }
         if (f.g.DoDebugBVHTraversal) nr = TurboColormap(rays.o_ior[rid].w / 150.0f);
         r = gmix(r, nr, w);
         if (f.outputAovs) { float4 a = rays.aovA[rid], n = rays.aovN[rid]; ra = gmix(ra, mk3(a.x, a.y, a.z), w); rn = gmix(rn, mk3(n.x, n.y, n.z), w); }
     }
-    imgResult[i] = make_float4(r.x, r.y, r.z, 1.0f);
-    if (f.outputAovs) { imgAlbedo[i] = make_float4(ra.x, ra.y, ra.z, 1.0f); imgNormal[i] = make_float4(rn.x, rn.y, rn.z, 1.0f); }
+    imgResult[(size_t)slot * N + i] = make_float4(r.x, r.y, r.z, 1.0f);
+    if (f.outputAovs) { imgAlbedo[(size_t)slot * N + i] = make_float4(ra.x, ra.y, ra.z, 1.0f); imgNormal[(size_t)slot * N + i] = make_float4(rn.x, rn.y, rn.z, 1.0f); }
 }
 
 // idkptDownloadRays support: the ray-state planes k_gen_primary skipped for culled pixels (flag 2) of one sample of the batch
@@ -47,7 +57,7 @@ __global__ __launch_bounds__(256) void k_regen_culled(DScene s, Frame f, RayBufs
     const uint8_t flag = contFlag[rid];
     if (flag != 2 && flag != 4) return;                                 // 2: culled per pixel, 4: culled per tile (no ray was generated at all); bit 0 = continues
     f3 origin; f2 pd; uint32_t seed;
-    gen_primary(f, pix, f.accum[smp], origin, pd, seed);
+    gen_primary(f, smp, pix, f.accum[smp], origin, pd, seed);
     rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
     rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
     if (flag == 4) {                                                    // the miss branch of FirstHit (FirstHit:225-233) for a pixel nothing was stored for

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
             if (!FIRST && f.outputAovs) { float4 aa = rays.aovA[idx], an = rays.aovN[idx]; aov.albedo = mk3(aa.x, aa.y, aa.z); aov.newWeight = aa.w; aov.normal = mk3(an.x, an.y, an.z); }
             uint32_t rng, gidSeed;
             if (FIRST) {
-                f3 o2; f2 pd2; gen_primary(f, pix, acc, o2, pd2, rng); // re-derives the RNG state after ray generation (cheaper than 4 B/pixel of HBM)
+                f3 o2; f2 pd2; gen_primary(f, smp, pix, acc, o2, pd2, rng); // re-derives the RNG state after ray generation (cheaper than 4 B/pixel of HBM)
                 int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
                 gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
             } else {

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(WAVE) void k_trace_primary(DScene s, Frame f, RayBu
         uint32_t pix = base + lane;
         if (pix < N) {
             f3 origin; f2 pd; uint32_t seed;
-            gen_primary(f, pix, f.accumulated, origin, pd, seed);
+            gen_primary(f, 0u, pix, f.accumulated, origin, pd, seed);
             rays.o_ior[pix] = make_float4(origin.x, origin.y, origin.z, 1.0f);
             rays.thr_px[pix] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
             rays.rad_py[pix] = make_float4(0.0f, 0.0f, 0.0f, pd.y);
@@ -70,6 +70,9 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tilesX * tilesY) return;
+    const uint32_t smp = blockIdx.y;                                 // > 0 only with per-sample cameras (frame ring): one classification per sample
+    const float* cam = f.cams ? f.cams + 36u * smp : f.invProj;
+    const float* invProj = cam; const float* invView = cam + 16; const float* vp = cam + 32;
     const uint32_t tx = t % tilesX, ty = t / tilesX;
     uint8_t cls = 0;
     const float r = f.g.LenseRadius, F = f.g.FocalLength;
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
         const int gy0 = (int)(ty * 8) * f.rowMod + f.rowRem, gy1 = (int)(ty * 8 + 7) * f.rowMod + f.rowRem;   // global rows of the tile's first / last local row
         const float nx0 = ((float)(tx * 8) - 1.0f) / W * 2.0f - 1.0f, nx1 = ((float)(tx * 8) + 9.0f) / W * 2.0f - 1.0f;   // one pixel of slack on every side
         const float ny0 = ((float)gy0 - 1.0f) / H * 2.0f - 1.0f, ny1 = ((float)gy1 + 2.0f) / H * 2.0f - 1.0f;
-        const f3 u[4] = {GetWorldSpaceDirection(f.invProj, f.invView, nx0, ny0), GetWorldSpaceDirection(f.invProj, f.invView, nx1, ny0),
-                         GetWorldSpaceDirection(f.invProj, f.invView, nx1, ny1), GetWorldSpaceDirection(f.invProj, f.invView, nx0, ny1)};
+        const f3 u[4] = {GetWorldSpaceDirection(invProj, invView, nx0, ny0), GetWorldSpaceDirection(invProj, invView, nx1, ny0),
+                         GetWorldSpaceDirection(invProj, invView, nx1, ny1), GetWorldSpaceDirection(invProj, invView, nx0, ny1)};
         const f3 mid = (u[0] + u[1]) + (u[2] + u[3]);
         f3 pn[4]; bool planeOk[4];                                  // outward unit normals of the four side planes of the tile's pyramid
         for (int i = 0; i < 4; i++) {
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
             if (dot(n, mid) > 0.0f) n = n * -1.0f;
             pn[i] = n;
         }
-        const f3 C = mk3(f.viewPos[0], f.viewPos[1], f.viewPos[2]);
+        const f3 C = mk3(vp[0], vp[1], vp[2]);
         // The boxes the traversal itself tests first (so that skipped rays would not have visited — or counted — anything):
         //   no TLAS: every instance's BLAS root box, an oriented box in world space (Model rows of its GpuMeshTransform; BVHIntersect.glsl:32-39)
         //   USE_TLAS: the two children of the TLAS root, world-space AABBs (:242-249); a leaf root is entered unconditionally -> no shortcut
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
             }
         }
     }
-    tileClass[t] = cls;
+    tileClass[(size_t)smp * (tilesX * tilesY) + t] = cls;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -173,14 +176,15 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
     const uint32_t pix = y * (uint32_t)f.W + x;
     const uint32_t rid = smp * f.Npad + pix;                           // ray id inside the batch
     bool keep = false;
-    const uint32_t cls = (tileClass && wave < tilesX * (((uint32_t)f.rows + 7) / 8)) ? tileClass[wave] : 0u;   // wave-uniform
+    const uint32_t nTilesAll = tilesX * (((uint32_t)f.rows + 7) / 8);
+    const uint32_t cls = (tileClass && wave < nTilesAll) ? tileClass[(f.cams ? (size_t)smp * nTilesAll : 0) + wave] : 0u;   // wave-uniform
     if (valid && cls != 0u) {
         // the whole tile is a proven miss with a known sky colour (k_classify_tiles): FirstHit's miss branch without generating the ray
         // k_final_draw takes the colour from the tile class, idkptDownloadRays regenerates the ray state: one flag byte is all that is stored
         contFlag[rid] = 4;                                               // (bit 0 = "continues" must stay clear) origin / direction planes regenerated on demand (k_regen_culled)
     } else if (valid) {
         f3 origin; f2 pd; uint32_t seed;
-        gen_primary(f, pix, f.accum[smp], origin, pd, seed);
+        gen_primary(f, smp, pix, f.accum[smp], origin, pd, seed);
         f3 rd = DecodeUnitVec(pd.x, pd.y);
         f3 lo = origin, ld = rd, invDir = splat3(0.0f);   // several instances / TLAS: the traversal kernel transforms the world ray per instance
         keep = !cull;

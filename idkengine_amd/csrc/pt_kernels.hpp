@@ -39,6 +39,8 @@ struct Frame {
     int tlasCap;                // rows of the per-lane TLAS stack (<= TLAS_STACK_SIZE; a TLAS over n instances is never deeper than n)
     // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
     int batch; uint32_t Npad; uint32_t accum[128];
+    // frame ring (idkptSetFrameRing): sample k renders with camera cams[36*k ..] (null: the one camera above) into result-image slot slotOf[k]
+    const float* cams; uint8_t slotOf[128];
 };
 #define MAX_BATCH 128
 
@@ -290,18 +292,20 @@ DEV bool TraceRayAny(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit,
 
 // ---------------------------------------------------------------------------------------------------------------
 // Primary ray generation (FirstHit/compute.glsl:44-77).  `pix` = local pixel index.
-DEV void gen_primary(const Frame& f, uint32_t pix, uint32_t acc, f3& origin, f2& packedDir, uint32_t& rngSeed)
+DEV void gen_primary(const Frame& f, uint32_t smp, uint32_t pix, uint32_t acc, f3& origin, f2& packedDir, uint32_t& rngSeed)
 {
+    const float* cam = f.cams ? f.cams + 36u * smp : f.invProj;      // invProj[16] invView[16] viewPos[3], contiguous in both places
+    const float* invProj = cam; const float* invView = cam + 16; const float* vp = cam + 32;
     int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
     int y = ly * f.rowMod + f.rowRem, x = lx;
     uint32_t seed = (uint32_t)(y * 4096 + x) * (acc + 1u);
     float ox = rnd01(seed), oy = rnd01(seed);
     float nx = ((float)x + ox) / (float)f.W * 2.0f - 1.0f, ny = ((float)y + oy) / (float)f.H * 2.0f - 1.0f;
-    f3 camDir = GetWorldSpaceDirection(f.invProj, f.invView, nx, ny);
-    f3 viewPos = mk3(f.viewPos[0], f.viewPos[1], f.viewPos[2]);
+    f3 camDir = GetWorldSpaceDirection(invProj, invView, nx, ny);
+    f3 viewPos = mk3(vp[0], vp[1], vp[2]);
     f3 focalPoint = viewPos + camDir * f.g.FocalLength;
     f2 disk = SampleDisk(seed);
-    f3 pointOnLense = mat4_mul_xyz(f.invView, f.g.LenseRadius * disk.x, f.g.LenseRadius * disk.y, 0.0f, 1.0f);
+    f3 pointOnLense = mat4_mul_xyz(invView, f.g.LenseRadius * disk.x, f.g.LenseRadius * disk.y, 0.0f, 1.0f);
     camDir = normalize(focalPoint - pointOnLense);
     origin = pointOnLense;
     packedDir = EncodeUnitVec(camDir);

@@ -257,6 +257,26 @@ class PathTracer:
         self._check(self._L.idkptGetImageDevicePtr(self._ctx, which, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    # ---- frame ring: several frames (cameras) in flight, idkptSetFrameRing / idkptBeginFrame / idkptDownloadFrame
+    def SetFrameRing(self, frames):
+        self._check(self._L.idkptSetFrameRing(self._ctx, int(frames)))
+
+    def BeginFrame(self):
+        """The next ring slot becomes current (accumulation restarts); returns the slot to read the finished frame from later."""
+        slot = C.c_int32()
+        self._check(self._L.idkptBeginFrame(self._ctx, C.byref(slot)))
+        return slot.value
+
+    def FrameResult(self, slot, which=0):
+        out = np.zeros((self.rows, self.width, 4), np.float32)
+        self._check(self._L.idkptDownloadFrame(self._ctx, int(slot), which, out.ctypes.data, out.nbytes))
+        return out
+
+    def frame_device_ptr(self, slot, which=0):
+        p = C.c_void_p(); n = C.c_size_t()
+        self._check(self._L.idkptGetFrameDevicePtr(self._ctx, int(slot), which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def set_max_batch(self, n):
         """Up to n consecutive samples are deferred and traced together (bit-identical results; idkptSetMaxBatch)."""
         self._check(self._L.idkptSetMaxBatch(self._ctx, n))

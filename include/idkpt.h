@@ -203,6 +203,22 @@ IDKPT_API int32_t idkptTraceShadows(idkpt_ctx* ctx, const idkpt_shadow_params* p
 /* Read back a scene buffer (tests: refit/skinning results). */
 IDKPT_API int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst);
 
+/* ---- frame ring: several frames in flight (no reference equivalent) ------------------------ */
+/* The reference renders one frame at a time: Compute(), look at Result, move the camera, ResetAccumulation(), Compute() ...  One
+ * 1080p frame does not fill an MI355X, so a host that can tolerate a few frames of latency keeps a ring of result images:
+ *   idkptSetFrameRing(ctx, n)      n independent result-image sets (slots); 1 = the reference's behaviour (default)
+ *   idkptBeginFrame(ctx, &slot)    next slot becomes current and its accumulation restarts; the camera set by idkptSetPerFrame
+ *                                  and the samples queued by idkptRender from now on belong to this frame
+ *   idkptDownloadFrame / idkptGetFrameDevicePtr(ctx, slot, ...)   the finished image of a slot (launches what is still deferred)
+ * With idkptSetMaxBatch(m) up to m queued samples — of different frames, each with its own camera — are traced by one set of
+ * launches; every frame's image is bit-identical to rendering that frame alone.  The ring must hold at least as many slots as
+ * frames are in flight (a slot that is reused before it was read is overwritten).  idkptDownload / idkptGetImageDevicePtr /
+ * idkptResetAccumulation / idkptGetAccumulatedSamples refer to the current slot. */
+IDKPT_API int32_t idkptSetFrameRing(idkpt_ctx* ctx, int32_t frames);
+IDKPT_API int32_t idkptBeginFrame(idkpt_ctx* ctx, int32_t* outSlot);
+IDKPT_API int32_t idkptDownloadFrame(idkpt_ctx* ctx, int32_t slot, int32_t image, float* rgba, size_t bytes);
+IDKPT_API int32_t idkptGetFrameDevicePtr(idkpt_ctx* ctx, int32_t slot, int32_t image, void** outPtr, size_t* outBytes);
+
 /* ---- render ----------------------------------------------------------------------------- */
 /* PathTracer.ResetAccumulation (PathTracer.cs:334-337) */
 IDKPT_API int32_t idkptResetAccumulation(idkpt_ctx* ctx);

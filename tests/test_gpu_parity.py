@@ -470,6 +470,39 @@ def test_exact_deep_paths_across_contexts(native_builder, oracle_mod, batch):
         p.Dispose()
 
 
+@pytest.mark.parametrize("batch,use_tlas", [(1, 0), (4, 0), (5, 1)])
+def test_frame_ring_frames_equal_stand_alone_frames(native_builder, oracle_mod, batch, use_tlas):
+    """idkptSetFrameRing: 6 frames with 6 different cameras (and 2 spp each) queued back to back into a ring of 8 slots and traced
+    `batch` samples at a time — every frame's image must equal that frame rendered alone, and the oracle, bit for bit (per-sample
+    camera, per-sample tile classification, per-frame result images)."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    sc = S.soup_scene_multi(9000, native_builder, parts=3, seed=2, extent=3.0) if use_tlas else S.soup_scene(9000, native_builder, seed=2, extent=3.0)
+    w, h = 150, 90
+    cams = [S.Camera(w, h, position=(0.3 * k - 0.8, 0.1 * k, 8.0 - 0.7 * k), view_dir=(0.05 * k - 0.1, -0.02 * k, -1.0), fovy_deg=60.0 + 5 * k) for k in range(6)]
+    ov = dict(RayDepth=4, SamplesPerPixel=2, UseTlas=use_tlas)
+    ring = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); ring.UploadScene(sc)
+    ring.SetFrameRing(8); ring.set_max_batch(batch)
+    slots = []
+    for cam in cams:
+        slots.append(ring.BeginFrame()); ring.SetCamera(cam); ring.Compute()
+    assert len(set(slots)) == len(slots)
+    for k, cam in enumerate(cams):
+        alone = gpu_render(sc, cam, w, h, **ov)
+        got = ring.FrameResult(slots[k])
+        assert (bits(got) == bits(alone.Result)).all(), k
+        if k in (0, 5):
+            o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+            assert (bits(got) == bits(o.image(0))).all()
+            o.close()
+        alone.Dispose()
+    # progressive accumulation inside one slot still works with the ring on: 2 more samples into the last frame
+    ring.Compute()
+    two = gpu_render(sc, cams[-1], w, h, frames=2, **ov)
+    assert (bits(ring.FrameResult(slots[-1])) == bits(two.Result)).all() and ring.AccumulatedSamples == 4
+    ring.Dispose(); two.Dispose()
+
+
 def test_row_sharded_contexts_reassemble_the_frame(soup1m):
     """Two contexts on one GPU, rows y%2==r: the multi-GPU sharding of dist.py without the transport."""
     from idkengine_amd.pathtracer import PathTracer
