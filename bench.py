@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--width", type=int, default=W, help="secondary-table runs only (headline = 1920)")
     ap.add_argument("--height", type=int, default=H, help="secondary-table runs only (headline = 1080)")
     ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: contiguous strips + per-bounce count exchange (gloo control group) so that RayDepth > 2 output equals the 1-GPU output bit for bit; default = interleaved rows (exact at RayDepth 2)")
+    ap.add_argument("--interactive", type=int, default=0, metavar="F", help="secondary mode: every step is a NEW frame (own camera, own image, ResetAccumulation semantics) with F frames in flight through the frame ring; every finished frame is exchanged when N > 1")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 128")
     args = ap.parse_args()
 
@@ -83,6 +84,8 @@ def main():
     pt.RayDepth = depth; pt.SamplesPerPixel = 1; pt.DoRaySorting = args.sort
     frame = D.ShardedFrame(r, W, H) if world > 1 else None
 
+    if args.interactive > 0:
+        return interactive(args, r, frame, pt, world, rank, device, scene, build_s, dist, torch, S)
     B = args.batch
     step_no = [0]
 
@@ -175,6 +178,53 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, depth)
         print(json.dumps(out), flush=True)
+    r.pt.Dispose()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def interactive(args, r, frame, pt, world, rank, device, scene, build_s, dist, torch, S):
+    """Secondary mode (not the headline): F frames in flight, each with its own camera and result image (frame ring); after every
+    F frames the F finished images are exchanged (one all-gather carrying every frame's row shard)."""
+    import math
+    F = max(1, min(64, args.interactive))
+    pt.SetFrameRing(2 * F); pt.set_max_batch(F)
+    cams = [S.Camera(W, H, position=(2.0 * math.sin(0.02 * k), 1.0 * math.sin(0.013 * k), 25.0)) for k in range(64)]
+    state = {"k": 0, "first": None}
+
+    def step():
+        slot = pt.BeginFrame(); pt.SetCamera(cams[state["k"] % len(cams)]); pt.Compute()
+        if state["k"] % F == 0:
+            state["first"] = slot
+        state["k"] += 1
+        if state["k"] % F == 0 and frame is not None:
+            frame.gather_frames(state["first"], F)                 # slots of one group are consecutive (ring size 2F)
+
+    for _ in range(((args.warmup + F - 1) // F) * F):
+        step()
+    pt.synchronize(); pt.reset_stats()
+    steps = ((args.steps + F - 1) // F) * F                         # whole groups
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    pt.synchronize(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    st = pt.stats()
+    rays = torch.tensor([float(st["rays_traced"])], dtype=torch.float64, device=device); tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        dt = tmax.item()
+        print(json.dumps({"metric": f"Mray/s, interactive: a new camera every frame, {F} frames in flight (secondary)", "value": round(rays.item() / dt / 1e6, 2), "unit": "Mray/s",
+                          "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"soup-{args.tris}, {W}x{H}, 1 spp, RayDepth {args.depth}, every frame its own camera and image", "frames_in_flight": F,
+                                     "frame_latency_ms": round(F * dt / steps * 1e3, 3), "exchange": "all-gather of every finished frame's row shards, once per F frames" if world > 1 else "none"}}), flush=True)
     r.pt.Dispose()
     if world > 1:
         dist.destroy_process_group()

@@ -144,6 +144,13 @@ class GpuShardRenderer:
     def stream_ctx(self):
         return torch.cuda.stream(self.stream)
 
+    def local_frames(self, first_slot, count):
+        """The finished images of `count` consecutive ring slots as one (count, rows, W, 4) tensor aliasing the library's memory
+        (slots are contiguous; idkptGetFrameDevicePtr)."""
+        self.pt.flush()
+        ptr, nbytes = self.pt.frame_device_ptr(first_slot, 0)
+        return torch.as_tensor(_DevArray(ptr, (count, self.rows, self.width, 4)), device=self.device)
+
     def local_image(self):
         self.pt.flush()   # launch whatever the library still defers; the collective that follows is stream-ordered behind it
         ptr, nbytes = self.pt.image_device_ptr(0)
@@ -172,6 +179,28 @@ class ShardedFrame:
         ctx = self.r.stream_ctx() if hasattr(self.r, "stream_ctx") else contextlib.nullcontext()
         with ctx:
             return self._gather()
+
+    def gather_frames(self, first_slot, count):
+        """Frame ring: all-gather of the row shards of `count` finished frames (consecutive ring slots) in one collective; returns
+        (count, H, W, 4) on every rank.  Every frame that was rendered is exchanged."""
+        import contextlib
+        ctx = self.r.stream_ctx() if hasattr(self.r, "stream_ctx") else contextlib.nullcontext()
+        with ctx:
+            local = self.r.local_frames(first_slot, count)
+            if local.shape[1] < self.max_rows:
+                pad = torch.zeros((count, self.max_rows - local.shape[1]) + tuple(local.shape[2:]), dtype=local.dtype, device=local.device)
+                local = torch.cat([local, pad], dim=1)
+            parts = [torch.empty_like(local) for _ in range(self.world)]
+            dist.all_gather(parts, local.contiguous(), group=self.group)
+            full = torch.empty((count, self.height, self.width, 4), dtype=local.dtype, device=local.device)
+            for r in range(self.world):
+                if self.strips:
+                    first, n = strip_of_rank(self.height, self.world, r)
+                    full[:, first:first + n] = parts[r][:, :n]
+                else:
+                    n = len(rows_of_rank(self.height, self.world, r))
+                    full[:, r::self.world] = parts[r][:, :n]
+            return full
 
     def _gather(self):
         local = self.r.local_image()

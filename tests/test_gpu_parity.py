@@ -657,6 +657,18 @@ def test_sharded_frame_over_rccl_world1(native_builder):
         full = full_t.cpu().numpy()
         ref = gpu_render(sc, cam, 96, 64, RayDepth=2)
         assert (bits(full) == bits(ref.Result)).all()
+        # frame ring over the same transport: 3 frames with their own cameras in flight, one all-gather carrying all three
+        r.pt.SetFrameRing(6); r.pt.set_max_batch(3)
+        cams = [S.cornell_camera(96, 64), S.Camera(96, 64, position=(0.2, 0.1, 3.0), fovy_deg=45.0), S.Camera(96, 64, position=(-0.3, 0.0, 3.2), fovy_deg=50.0)]
+        slots = []
+        for c in cams:
+            slots.append(r.pt.BeginFrame()); r.set_camera(c); r.pt.Compute()
+        assert slots == list(range(slots[0], slots[0] + 3))
+        frames_t = frame.gather_frames(slots[0], 3); torch.cuda.synchronize()
+        for k, c in enumerate(cams):
+            alone = gpu_render(sc, c, 96, 64, RayDepth=2)
+            assert (bits(frames_t[k].cpu().numpy()) == bits(alone.Result)).all()
+            alone.Dispose()
         ref.Dispose(); r.pt.Dispose()
     finally:
         dist.destroy_process_group()
