@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--height", type=int, default=H, help="secondary-table runs only (headline = 1080)")
     ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: contiguous strips + per-bounce count exchange (gloo control group) so that RayDepth > 2 output equals the 1-GPU output bit for bit; default = interleaved rows (exact at RayDepth 2)")
     ap.add_argument("--interactive", type=int, default=0, metavar="F", help="secondary mode: every step is a NEW frame (own camera, own image, ResetAccumulation semantics) with F frames in flight through the frame ring; every finished frame is exchanged when N > 1")
-    ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 128")
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 256")
     args = ap.parse_args()
 
     import numpy as np
@@ -55,7 +55,7 @@ def main():
     from idkengine_amd import dist as D
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    args.batch = max(1, min(128, args.batch * world))
+    args.batch = max(1, min(256, args.batch * world))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
@@ -156,7 +156,7 @@ def main():
         achieved = alg_bytes_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from the committed PMC summary of this same command
-        headline = (args.tris, depth, args.sort, W, H, args.batch) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(128, 32 * world))
+        headline = (args.tris, depth, args.sort, W, H, args.batch) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world))
         if os.path.exists(prof) and headline:        # the PMC pass was taken on the headline command only
             try:
                 traffic = json.load(open(prof)).get(f"n{world}", {}).get("traversal_hbm_bytes_per_launch")

@@ -756,7 +756,8 @@ static int flush_batch(idkpt_ctx* ctx)
             // RaySorting() (PathTracer.cs:232-237): stable sort of (key, rayIndex); key = 21-bit triangle id with the batch's
             // sample index above it, so one sort orders every sample's queue exactly like a stand-alone counting sort
             const uint32_t nTiles = (total + SORT_TILE - 1) / SORT_TILE;
-            const int passes = B > 1 ? 4 : 3;
+            int sampleBits = 0; while ((1 << sampleBits) < B) sampleBits++;
+            const int passes = (IDKPT_SORT_KEY_BITS + sampleBits + 6) / 7;    // 7-bit digits over key + sample index: 3 passes alone, 4 up to 128 samples, 5 up to 256
             uint32_t* digitTotals = ctx->sortHist.as<uint32_t>() + (size_t)SORT_RADIX * nTiles;   // 128 words behind the [digit][tile] table
             uint32_t* ka = k; uint32_t* va = q; uint32_t* kb = ctx->sortKeys.as<uint32_t>(); uint32_t* vb = ctx->sortVals.as<uint32_t>();
             for (int pass = 0; pass < passes; pass++) {
@@ -825,7 +826,7 @@ int32_t idkptFlush(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT
 int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
-    REQUIRE(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..128");
+    REQUIRE(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..256");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     HIPC(hipStreamSynchronize(ctx->stream));

@@ -38,11 +38,11 @@ struct Frame {
     int useTlas, stackCap, outputAovs;
     int tlasCap;                // rows of the per-lane TLAS stack (<= TLAS_STACK_SIZE; a TLAS over n instances is never deeper than n)
     // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
-    int batch; uint32_t Npad; uint32_t accum[128];
+    int batch; uint32_t Npad; uint32_t accum[256];   // [MAX_BATCH]
     // frame ring (idkptSetFrameRing): sample k renders with camera cams[36*k ..] (null: the one camera above) into result-image slot slotOf[k]
-    const float* cams; uint8_t slotOf[128];
+    const float* cams; uint8_t slotOf[256];
 };
-#define MAX_BATCH 128
+#define MAX_BATCH 256
 
 struct RayBufs {                // SoA planes of the reference's GpuWavefrontRay / GpuAovRay, indexed by local pixel
     float4* o_ior;              // Origin.xyz, PreviousIOROrTraverseCost

@@ -228,7 +228,7 @@ IDKPT_API int32_t idkptGetAccumulatedSamples(idkpt_ctx* ctx, uint32_t* outSample
 IDKPT_API int32_t idkptRender(idkpt_ctx* ctx);
 IDKPT_API int32_t idkptSynchronize(idkpt_ctx* ctx);
 /* Deferred batching (no reference equivalent; DESIGN.md "Batching"): idkptRender only queues its samples; up to maxBatch
- * (1..128, default 1) consecutive samples are traced together by one set of kernel launches, each with its own
+ * (1..256, default 1) consecutive samples are traced together by one set of kernel launches, each with its own
  * AccumulatedSamples index, queue slots and RNG streams, and FinalDraw folds them in submission order — outputs are
  * bit-identical to maxBatch = 1.  Anything that reads results or changes inputs flushes first. */
 IDKPT_API int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch);

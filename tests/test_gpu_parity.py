@@ -503,6 +503,22 @@ def test_frame_ring_frames_equal_stand_alone_frames(native_builder, oracle_mod, 
     ring.Dispose(); two.Dispose()
 
 
+def test_maximum_batch_of_256_samples(native_builder):
+    """idkptSetMaxBatch(256): 200 accumulated samples of a small frame traced by ONE set of launches (5 radix passes over key + sample
+    index) equal 200 samples traced one at a time."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.cornell_scene(native_builder, "mixed", True); w, h = 33, 21; cam = S.cornell_camera(w, h)
+    res = []
+    for batch in (256, 1):
+        p = PathTracer(w, h); p.UploadScene(sc); p.SetCamera(cam); p.RayDepth = 5; p.DoRaySorting = 1; p.set_max_batch(batch)
+        for _ in range(200):
+            p.Compute()
+        res.append((p.Result, p.rays(), p.stats()["rays_traced"], p.AccumulatedSamples)); p.Dispose()
+    assert (bits(res[0][0]) == bits(res[1][0])).all() and res[0][1].tobytes() == res[1][1].tobytes() and res[0][2:] == res[1][2:]
+    with pytest.raises(Exception):
+        p = PathTracer(w, h); p.set_max_batch(257)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_api_sequences_match_unbatched_replay(native_builder, seed):
     """State-machine check of the deferral logic: a random sequence of host calls (camera moves, Compute, ResetAccumulation, settings,
