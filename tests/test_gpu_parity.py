@@ -766,4 +766,17 @@ def test_error_paths_fail_loudly(native_builder):
         pt.RefitBlas(0)                               # BLAS is not refittable
     with pytest.raises(IdkPtError):
         pt.SetSize(8192, 64)                          # FirstHit seeds pack x into 12 bits
+    # the adjacent entry points report misuse the same way
+    from idkengine_amd import gputypes as T
+    pt.UseTlas = 0
+    cam = S.cornell_camera(16, 16)
+    with pytest.raises(IdkPtError):
+        pt.TraceShadows(T.ShadowParams.make(cam.inv_proj_view, 16, 16, light_index=0), np.zeros((16, 16), np.float32), np.zeros((16, 16, 2), np.float32))   # the scene has no lights
+    with pytest.raises(IdkPtError):
+        pt.SetFrameRing(0)
+    with pytest.raises(IdkPtError):
+        pt.SetFrameRing(2); pt.FrameResult(5)         # slot outside the ring
+    with pytest.raises(IdkPtError):
+        pt.SetRowRange(60, 10)                        # strip exceeds the image
+    assert len(pt.TraceRays(np.zeros(0, T.RayQuery))) == 0   # empty query is fine
     pt.Dispose()
