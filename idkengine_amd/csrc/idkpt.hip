@@ -650,7 +650,7 @@ static int flush_batch(idkpt_ctx* ctx)
     f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
     f.outputAovs = ctx->st.OutputAOVs;
     f.batch = B; f.Npad = Npad;
-    for (int k = 0; k < MAX_BATCH; k++) { f.accum[k] = k < B ? ctx->pending[k].accum : 0u; f.slotOf[k] = (uint8_t)(k < B ? ctx->pending[k].slot : 0); }
+    for (int k = 0; k < MAX_BATCH; k++) { f.accum[k] = k < B ? ctx->pending[k].accum : 0u; f.slotOf[k] = (uint32_t)(k < B ? ctx->pending[k].slot : 0); }
     f.accumulated = f.accum[0];
     f.cams = nullptr;
     if (ctx->ringSize > 1) {   // frame ring: every sample renders with the camera it was queued with

@@ -40,7 +40,7 @@ struct Frame {
     // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
     int batch; uint32_t Npad; uint32_t accum[256];   // [MAX_BATCH]
     // frame ring (idkptSetFrameRing): sample k renders with camera cams[36*k ..] (null: the one camera above) into result-image slot slotOf[k]
-    const float* cams; uint8_t slotOf[256];
+    const float* cams; uint32_t slotOf[256];   // (dwords: scalar loads from the kernel-argument segment; gfx9 has no scalar byte load)
 };
 #define MAX_BATCH 256
 
