@@ -33,6 +33,16 @@ struct Counters { uint64_t pairs = 0, tris = 0; };
 
 static inline v3 P(const Scene& s, uint32_t i) { const float* p = &s.positions[3 * (size_t)i]; return V3(p[0], p[1], p[2]); }
 
+// Traversal stack: the capacity is not part of the semantics (the reference sizes it from the BVH, Bvh/BVH.cs:559-567); fixed storage for the
+// depths real BVHs reach (no allocation per ray, like the C# path's stackalloc, Bvh/BLAS.cs:318), heap beyond that.
+struct TraversalStack {
+    uint32_t fixed[128]; int n = 0; std::vector<uint32_t> spill;
+    void push_back(uint32_t v) { if (n < 128) fixed[n] = v; else spill.push_back(v); n++; }
+    uint32_t back() const { return n <= 128 ? fixed[n - 1] : spill.back(); }
+    void pop_back() { if (n > 128) spill.pop_back(); n--; }
+    bool empty() const { return n == 0; }
+};
+
 // include/BVHIntersect.glsl:27-105
 static bool IntersectBlas(const Scene& s, const Ray& ray, const GpuBlasDesc& d, bool useTlas, HitInfo& hit, float& debugCost, Counters* cnt)
 {
@@ -44,7 +54,7 @@ static bool IntersectBlas(const Scene& s, const Ray& ray, const GpuBlasDesc& d, 
         const GpuBlasNode& root = nodes[1];
         if (!(RayBoxIntersect(ray.o, invDir, root.Min, root.Max, &tMinLeft) && tMinLeft < hit.T)) return false;
     }
-    std::vector<uint32_t> stack; stack.reserve(64); // shared uint BlasTraversalStack[BLAS_STACK_SIZE][..] (:18-22); capacity is not part of the semantics
+    TraversalStack stack; // shared uint BlasTraversalStack[BLAS_STACK_SIZE][..] (:18-22)
     uint32_t stackTop = 2;
     while (true) {
         debugCost += 1.0f; if (cnt) cnt->pairs++;
@@ -99,7 +109,7 @@ static bool TraceRay(const Scene& s, const Ray& ray, HitInfo& hit, float& debugC
         if (s.tlas.empty()) return hit.T != maxDist;
         float tMinLeft, tMinRight;
         v3 invDir = V3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-        std::vector<uint32_t> stack; uint32_t stackTop = 0;
+        TraversalStack stack; uint32_t stackTop = 0;
         while (true) {
             const GpuTlasNode& parent = s.tlas[stackTop];
             bool isLeaf = (parent.IsLeafAndChildOrInstanceId >> 31) == 1;
@@ -142,7 +152,7 @@ static bool IntersectBlasAny(const Scene& s, const Ray& ray, const GpuBlasDesc& 
         const GpuBlasNode& root = nodes[1];
         if (!(RayBoxIntersect(ray.o, invDir, root.Min, root.Max, &tMinLeft) && tMinLeft < hit.T)) return false;
     }
-    std::vector<uint32_t> stack; stack.reserve(64);
+    TraversalStack stack;
     uint32_t stackTop = 2;
     while (true) {
         const GpuBlasNode& L = nodes[stackTop]; const GpuBlasNode& R = nodes[stackTop + 1];
@@ -191,7 +201,7 @@ static bool TraceRayAny(const Scene& s, const Ray& ray, HitInfo& hit, bool trace
         if (s.tlas.empty()) return false;
         float tMinLeft, tMinRight;
         v3 invDir = V3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-        std::vector<uint32_t> stack; uint32_t stackTop = 0;
+        TraversalStack stack; uint32_t stackTop = 0;
         while (true) {
             const GpuTlasNode& parent = s.tlas[stackTop];
             bool isLeaf = (parent.IsLeafAndChildOrInstanceId >> 31) == 1;
