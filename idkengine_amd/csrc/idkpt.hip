@@ -73,6 +73,7 @@ struct idkpt_ctx {
     double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
     int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false, lastNeedsRegen = false; int lastBatch = 1; Frame lastFrame;
     int maxBatch = 1; uint32_t Npad = 0; std::vector<PendingSample> pending; DevBuf bases; uint32_t* hBases = nullptr;
+    float* hCams = nullptr; hipEvent_t evCams[2] = {nullptr, nullptr}; int camHalf = 0;   // pinned, double-buffered staging of the per-sample cameras (frame ring)
 };
 
 static hipEvent_t next_event(idkpt_ctx* ctx)
@@ -215,6 +216,8 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     for (auto& t : ctx->texData) t.release();
     if (ctx->hCounts) (void)hipHostFree(ctx->hCounts);
     if (ctx->hBases) (void)hipHostFree(ctx->hBases);
+    if (ctx->hCams) (void)hipHostFree(ctx->hCams);
+    for (int i = 0; i < 2; i++) if (ctx->evCams[i]) (void)hipEventDestroy(ctx->evCams[i]);
     if (ctx->evFrame[0]) (void)hipEventDestroy(ctx->evFrame[0]);
     if (ctx->evFrame[1]) (void)hipEventDestroy(ctx->evFrame[1]);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
@@ -654,11 +657,18 @@ static int flush_batch(idkpt_ctx* ctx)
     f.accumulated = f.accum[0];
     f.cams = nullptr;
     if (ctx->ringSize > 1) {   // frame ring: every sample renders with the camera it was queued with
-        std::vector<float> cams((size_t)B * 36);
-        for (int k = 0; k < B; k++) memcpy(&cams[(size_t)k * 36], ctx->pending[k].cam, 36 * 4);
+        // pinned double-buffered staging: no stream synchronisation per batch (the host may run ahead of the GPU)
+        if (!ctx->hCams) {
+            HIPC(hipHostMalloc((void**)&ctx->hCams, (size_t)2 * MAX_BATCH * 36 * 4, hipHostMallocDefault));
+            for (int i = 0; i < 2; i++) HIPC(hipEventCreateWithFlags(&ctx->evCams[i], hipEventDisableTiming));
+            ctx->camHalf = 0;
+        } else HIPC(hipEventSynchronize(ctx->evCams[ctx->camHalf]));          // the copy that last read this half has finished
+        float* stage = ctx->hCams + (size_t)ctx->camHalf * MAX_BATCH * 36;
+        for (int k = 0; k < B; k++) memcpy(stage + (size_t)k * 36, ctx->pending[k].cam, 36 * 4);
         HIPC(ctx->camTab.ensure((size_t)MAX_BATCH * 36 * 4));
-        HIPC(hipMemcpyAsync(ctx->camTab.p, cams.data(), cams.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPC(hipStreamSynchronize(ctx->stream));            // cams is a stack vector
+        HIPC(hipMemcpyAsync(ctx->camTab.p, stage, (size_t)B * 36 * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipEventRecord(ctx->evCams[ctx->camHalf], ctx->stream));
+        ctx->camHalf ^= 1;
         f.cams = ctx->camTab.as<float>();
     }
     RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
