@@ -234,6 +234,21 @@ def test_many_instances_fast_path(native_builder, oracle_mod, monkeypatch, use_t
     a.Dispose(); b.Dispose(); c.Dispose(); o.close()
 
 
+@pytest.mark.parametrize("use_tlas", [1, 0])
+def test_many_small_instances_deep_tlas(native_builder, oracle_mod, use_tlas):
+    """600 BLAS instances of a few triangles each: a deep PLOC TLAS (per-lane TLAS stack in LDS) or a long instance list, with the
+    ray-query entry point on top — frame, counters and 20 000 closest/any-hit queries equal the oracle."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.soup_scene_multi(3600, native_builder, parts=600, seed=13, extent=4.0, edge=0.4); w, h = 160, 96; cam = S.Camera(w, h, position=(0.0, 0.0, 11.0), fovy_deg=60.0)
+    ov = dict(RayDepth=3, UseTlas=use_tlas)
+    pt = gpu_render(sc, cam, w, h, **ov); o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+    assert_equal(pt, o)
+    rays = _queries(20000, 17, 6.0)
+    for any_hit in (False, True):
+        assert pt.TraceRays(rays, any_hit=any_hit).tobytes() == oracle_mod.trace_rays(sc, rays, any_hit=any_hit, use_tlas=bool(use_tlas)).tobytes()
+    pt.Dispose(); o.close()
+
+
 @pytest.mark.parametrize("parts,tris", [(1, 500), (2, 600), (3, 900), (12, 6000), (200, 4000), (1500, 6000)])
 def test_device_tlas_build_matches_host_build(native_builder, oracle_builder, parts, tris):
     """TLAS rebuild on the device (idkptBuildTlasOnDevice: instance world bounds + Morton order + PLOC) must give the node array
