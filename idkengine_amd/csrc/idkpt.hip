@@ -91,7 +91,8 @@ static void resolve_trace_events(idkpt_ctx* ctx)
 #define TRACE_T1() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
 
 static int fail(idkpt_ctx* c, int code, const std::string& msg) { if (c) c->lastError = msg; return code; }
-#define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(ctx, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+// (a failed runtime call leaves its code in the thread's last-error slot: reset it, or the next hipGetLastError() check would report it again)
+#define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
 #define REQUIRE(cond, msg) do { if (!(cond)) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
 
 static int local_rows(int H, int mod, int rem) { int n = 0; for (int y = rem; y < H; y += mod) n++; return n; }
@@ -841,8 +842,19 @@ int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
     FLUSH();
     HIPC(hipStreamSynchronize(ctx->stream));
     if (maxBatch == ctx->maxBatch) return IDKPT_OK;
+    const int previous = ctx->maxBatch;
     ctx->maxBatch = maxBatch;
-    if (ctx->W > 0) { std::vector<uint32_t> acc = ctx->accum; int slot = ctx->curSlot; int rc = alloc_frame_keep_images(ctx); if (rc) return rc; ctx->accum = acc; ctx->curSlot = slot; }
+    if (ctx->W > 0) {
+        std::vector<uint32_t> acc = ctx->accum; int slot = ctx->curSlot;
+        int rc = alloc_frame_keep_images(ctx);
+        if (rc) {   // e.g. out of device memory: fall back to the previous (smaller) buffer set; the accumulation restarts
+            const std::string why = ctx->lastError;
+            ctx->maxBatch = previous;
+            (void)alloc_frame(ctx);
+            return fail(ctx, rc, "idkptSetMaxBatch: could not allocate the wavefront buffers for " + std::to_string(maxBatch) + " samples in flight (" + why + "); kept " + std::to_string(previous));
+        }
+        ctx->accum = acc; ctx->curSlot = slot;
+    }
     return IDKPT_OK;
 }
 

@@ -795,3 +795,11 @@ def test_error_paths_fail_loudly(native_builder):
         pt.SetRowRange(60, 10)                        # strip exceeds the image
     assert len(pt.TraceRays(np.zeros(0, T.RayQuery))) == 0   # empty query is fine
     pt.Dispose()
+    # more samples in flight than the device can hold: a clean error, the previous configuration stays usable
+    big = PathTracer(4096, 16384); big.UploadScene(sc); big.SetCamera(S.cornell_camera(4096, 16384))
+    with pytest.raises(IdkPtError, match="samples in flight"):
+        big.set_max_batch(256)                        # 3 ray planes alone would need 3 x 275 GB
+    big.SetSize(64, 64); big.SetCamera(S.cornell_camera(64, 64)); big.RayDepth = 2; big.Compute()
+    ref = PathTracer(64, 64); ref.UploadScene(sc); ref.SetCamera(S.cornell_camera(64, 64)); ref.RayDepth = 2; ref.Compute()
+    assert (bits(big.Result) == bits(ref.Result)).all()
+    big.Dispose(); ref.Dispose()
