@@ -50,7 +50,7 @@ struct idkpt_ctx {
     int ringSize = 1, curSlot = 0; std::vector<uint32_t> accum = std::vector<uint32_t>(1, 0u);
     bool counters = false, timing = false, capturePrimary = false, forceGeneric = false, noTileCull = false; int traceVariant = 0;
     // scene
-    bool haveScene = false;
+    bool haveScene = false, frameOk = false;
     DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;   // (+ camTab below)
     std::vector<DevBuf> texData;
     std::vector<GpuBlasDesc> hDescs;
@@ -119,7 +119,7 @@ static void launch_trace2(idkpt_ctx* ctx, uint32_t grid, size_t lds, hipStream_t
     }
 }
 
-static int alloc_frame(idkpt_ctx* ctx)
+static int alloc_frame_impl(idkpt_ctx* ctx)
 {
     const size_t N = (size_t)ctx->W * ctx->rows;
     ctx->Npad = (uint32_t)((N + 63) / 64 * 64);
@@ -146,6 +146,9 @@ static int alloc_frame(idkpt_ctx* ctx)
     ctx->accum.assign(ctx->ringSize, 0u); ctx->curSlot = 0;
     return IDKPT_OK;
 }
+
+// a failed allocation leaves the context without a usable frame (idkptRender refuses) until a later idkptSetSize / idkptSetMaxBatch succeeds
+static int alloc_frame(idkpt_ctx* ctx) { int rc = alloc_frame_impl(ctx); ctx->frameOk = rc == IDKPT_OK; return rc; }
 
 // maxBatch changed: the wavefront buffers grow, the accumulation images (and their contents) stay
 static int alloc_frame_keep_images(idkpt_ctx* ctx)
@@ -813,7 +816,7 @@ int32_t idkptRender(idkpt_ctx* ctx)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: no scene uploaded");
-    if (ctx->W <= 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: idkptSetSize not called");
+    if (ctx->W <= 0 || !ctx->frameOk) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: no frame buffers (idkptSetSize not called, or its allocation failed)");
     if (ctx->st.UseTlas && ctx->tlasCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: UseTlas set but no TLAS nodes uploaded");
     HIPC(hipSetDevice(ctx->device));
     if (ctx->timing && ctx->evUsed > 4096) { HIPC(hipStreamSynchronize(ctx->stream)); resolve_trace_events(ctx); }
