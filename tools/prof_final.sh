@@ -5,6 +5,7 @@ TAG=${1:-r01f}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
+[ -x tools/ubench_lines.bin ] || hipcc --offload-arch=gfx950 -O3 tools/ubench_lines.hip -o tools/ubench_lines.bin
 CMD="python bench.py --steps 64 --warmup 32 --no-cpu-baseline"
 timeout 200 $CMD > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- $CMD > $OUT/bench_stats.log 2>&1
