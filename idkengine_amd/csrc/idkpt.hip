@@ -47,7 +47,7 @@ struct idkpt_ctx {
     float invProj[16], invView[16], viewPos[3];
     // frame ring (idkptSetFrameRing): ringSize result-image sets; every queued sample remembers its slot, its camera and its
     // AccumulatedSamples index, so several frames (different cameras) can be in flight in one batch
-    int ringSize = 1, curSlot = 0; std::vector<uint32_t> accum = std::vector<uint32_t>(1, 0u);
+    int ringSize = 1, curSlot = 0; bool ringStarted = false; std::vector<uint32_t> accum = std::vector<uint32_t>(1, 0u);
     bool counters = false, timing = false, capturePrimary = false, forceGeneric = false, noTileCull = false; int traceVariant = 0;
     // scene
     bool haveScene = false, frameOk = false;
@@ -143,7 +143,7 @@ static int alloc_frame_impl(idkpt_ctx* ctx)
     HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream));
     HIPC(hipMemsetAsync(ctx->aovA.p, 0, cap * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, cap * 16, ctx->stream));
     HIPC(hipMemsetAsync(ctx->contFlag.p, 0, cap, ctx->stream));   // per-batch values are written by k_gen_primary; the pad ids [N, Npad) must read 0
-    ctx->accum.assign(ctx->ringSize, 0u); ctx->curSlot = 0;
+    ctx->accum.assign(ctx->ringSize, 0u); ctx->curSlot = 0; ctx->ringStarted = false;
     return IDKPT_OK;
 }
 
@@ -848,7 +848,7 @@ int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
     const int previous = ctx->maxBatch;
     ctx->maxBatch = maxBatch;
     if (ctx->W > 0) {
-        std::vector<uint32_t> acc = ctx->accum; int slot = ctx->curSlot;
+        std::vector<uint32_t> acc = ctx->accum; int slot = ctx->curSlot; const bool started = ctx->ringStarted;
         int rc = alloc_frame_keep_images(ctx);
         if (rc) {   // e.g. out of device memory: fall back to the previous (smaller) buffer set; the accumulation restarts
             const std::string why = ctx->lastError;
@@ -856,7 +856,7 @@ int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
             (void)alloc_frame(ctx);
             return fail(ctx, rc, "idkptSetMaxBatch: could not allocate the wavefront buffers for " + std::to_string(maxBatch) + " samples in flight (" + why + "); kept " + std::to_string(previous));
         }
-        ctx->accum = acc; ctx->curSlot = slot;
+        ctx->accum = acc; ctx->curSlot = slot; ctx->ringStarted = started;
     }
     return IDKPT_OK;
 }
@@ -871,14 +871,15 @@ int32_t idkptSetFrameRing(idkpt_ctx* ctx, int32_t frames)
     if (frames == ctx->ringSize) return IDKPT_OK;
     ctx->ringSize = frames;
     if (ctx->W > 0) return alloc_frame(ctx);       // images are re-created (cleared); accumulation restarts in slot 0
-    ctx->accum.assign(frames, 0u); ctx->curSlot = 0;
+    ctx->accum.assign(frames, 0u); ctx->curSlot = 0; ctx->ringStarted = false;
     return IDKPT_OK;
 }
 
 int32_t idkptBeginFrame(idkpt_ctx* ctx, int32_t* outSlot)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
-    ctx->curSlot = (ctx->curSlot + 1) % ctx->ringSize;
+    if (ctx->ringStarted) ctx->curSlot = (ctx->curSlot + 1) % ctx->ringSize;   // the first frame after idkptSetFrameRing / idkptSetSize uses slot 0
+    ctx->ringStarted = true;
     ctx->accum[ctx->curSlot] = 0;                   // a new frame: its first sample overwrites whatever the slot held
     if (outSlot) *outSlot = ctx->curSlot;
     return IDKPT_OK;

@@ -149,6 +149,7 @@ class GpuShardRenderer:
         (slots are contiguous; idkptGetFrameDevicePtr)."""
         self.pt.flush()
         ptr, nbytes = self.pt.frame_device_ptr(first_slot, 0)
+        self.pt.frame_device_ptr(first_slot + count - 1, 0)       # raises if the group runs past the end of the ring (slots must be consecutive)
         return torch.as_tensor(_DevArray(ptr, (count, self.rows, self.width, 4)), device=self.device)
 
     def local_image(self):

@@ -207,7 +207,8 @@ IDKPT_API int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offs
 /* The reference renders one frame at a time: Compute(), look at Result, move the camera, ResetAccumulation(), Compute() ...  One
  * 1080p frame does not fill an MI355X, so a host that can tolerate a few frames of latency keeps a ring of result images:
  *   idkptSetFrameRing(ctx, n)      n independent result-image sets (slots); 1 = the reference's behaviour (default)
- *   idkptBeginFrame(ctx, &slot)    next slot becomes current and its accumulation restarts; the camera set by idkptSetPerFrame
+ *   idkptBeginFrame(ctx, &slot)    next slot (0 for the first frame after idkptSetFrameRing / idkptSetSize, then 1, 2, ... wrapping) becomes
+ *                                  current and its accumulation restarts; the camera set by idkptSetPerFrame
  *                                  and the samples queued by idkptRender from now on belong to this frame
  *   idkptDownloadFrame / idkptGetFrameDevicePtr(ctx, slot, ...)   the finished image of a slot (launches what is still deferred)
  * With idkptSetMaxBatch(m) up to m queued samples — of different frames, each with its own camera — are traced by one set of
