@@ -192,7 +192,7 @@ class ShardedFrame:
                 pad = torch.zeros((count, self.max_rows - local.shape[1]) + tuple(local.shape[2:]), dtype=local.dtype, device=local.device)
                 local = torch.cat([local, pad], dim=1)
             parts = [torch.empty_like(local) for _ in range(self.world)]
-            dist.all_gather(parts, local.contiguous(), group=self.group)
+            dist.all_gather(parts, local.contiguous().clone(), group=self.group)   # clone: the collective works on torch-owned memory, the ring slots are free again
             full = torch.empty((count, self.height, self.width, 4), dtype=local.dtype, device=local.device)
             for r in range(self.world):
                 if self.strips:
@@ -209,7 +209,7 @@ class ShardedFrame:
             pad = torch.zeros((self.max_rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             local = torch.cat([local, pad], dim=0)
         parts = [torch.empty_like(local) for _ in range(self.world)]
-        dist.all_gather(parts, local.contiguous(), group=self.group)
+        dist.all_gather(parts, local.contiguous().clone(), group=self.group)       # clone (4 MB): torch-owned send buffer, decoupled from the library's image
         full = torch.empty((self.height, self.width, 4), dtype=local.dtype, device=local.device)
         for r in range(self.world):
             if self.strips:
