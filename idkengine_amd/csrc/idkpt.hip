@@ -157,7 +157,14 @@ static int alloc_frame_keep_images(idkpt_ctx* ctx)
     DevBuf saved[3];
     for (int i = 0; i < 3; i++) { saved[i] = ctx->img[i]; ctx->img[i] = DevBuf(); }
     int rc = alloc_frame(ctx);
-    for (int i = 0; i < 3; i++) { if (rc == IDKPT_OK && saved[i].p) (void)hipMemcpy(ctx->img[i].p, saved[i].p, N * 16 * ctx->ringSize, hipMemcpyDeviceToDevice); saved[i].release(); }
+    // The restore is ordered on the context's stream, behind the zero-fill alloc_frame_impl queued there: the stream is non-blocking, so
+    // a null-stream copy would be unordered against that fill (the fill could land after the restore and wipe the accumulation).
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 3 && rc == IDKPT_OK && e == hipSuccess; i++)
+        if (saved[i].p) e = hipMemcpyAsync(ctx->img[i].p, saved[i].p, std::min(saved[i].bytes, N * 16 * ctx->ringSize), hipMemcpyDeviceToDevice, ctx->stream);
+    if (rc == IDKPT_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the saved buffers are released right below
+    for (int i = 0; i < 3; i++) saved[i].release();
+    if (rc == IDKPT_OK && e != hipSuccess) { (void)hipGetLastError(); ctx->frameOk = false; return fail(ctx, IDKPT_ERR_HIP, std::string("alloc_frame_keep_images: ") + hipGetErrorString(e)); }
     return rc;
 }
 
@@ -447,7 +454,7 @@ int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, siz
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptUpdateBuffer: no scene uploaded");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
-    if (which == IDKPT_BUF_JOINT_MATRICES) { size_t need = offsetBytes + bytes; if (need > ctx->joints.bytes) { DevBuf nb; HIPC(nb.ensure(need)); if (ctx->joints.p) HIPC(hipMemcpy(nb.p, ctx->joints.p, ctx->joints.bytes, hipMemcpyDeviceToDevice)); ctx->joints.release(); ctx->joints = nb; } }
+    if (which == IDKPT_BUF_JOINT_MATRICES) { size_t need = offsetBytes + bytes; if (need > ctx->joints.bytes) { DevBuf nb; HIPC(nb.ensure(need)); if (ctx->joints.p) { HIPC(hipMemcpyAsync(nb.p, ctx->joints.p, ctx->joints.bytes, hipMemcpyDeviceToDevice, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); } ctx->joints.release(); ctx->joints = nb; } }
     size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
     REQUIRE(b != nullptr, "idkptUpdateBuffer: unknown buffer");
     REQUIRE(offsetBytes + bytes <= cap, "idkptUpdateBuffer: range exceeds buffer");
@@ -957,7 +964,7 @@ int32_t idkptDownloadAliveQueue(idkpt_ctx* ctx, uint32_t* indices, size_t capaci
     *outCount = n;
     if (indices && n) {
         REQUIRE(capacity >= n, "idkptDownloadAliveQueue: capacity too small");
-        HIPC(hipMemcpy(indices, ctx->queue[ctx->lastQueueSide].as<uint32_t>() + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpyAsync(indices, ctx->queue[ctx->lastQueueSide].as<uint32_t>() + first, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
         const uint32_t sub = (uint32_t)(ctx->lastBatch - 1) * ctx->Npad;
         for (uint32_t i = 0; i < n; i++) indices[i] -= sub;
     }
@@ -997,9 +1004,9 @@ int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* out)
     s.TraceMsTotal = ctx->traceMsAcc; s.TraceLaunches = ctx->traceLaunchesAcc;
     s.LastTraceMs = s.TraceLaunches ? (float)(s.TraceMsTotal / (double)s.TraceLaunches) : 0.0f;
     uint64_t c[4] = {0, 0, 0, 0};
-    HIPC(hipMemcpy(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpyAsync(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
-    if (ctx->traceVariant == 7 || ctx->traceVariant == 13) { uint64_t d[16]; HIPC(hipMemcpy(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13]); }
+    if (ctx->traceVariant == 7 || ctx->traceVariant == 13) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13]); }
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
     *out = s;
     return IDKPT_OK;
@@ -1014,7 +1021,7 @@ int32_t idkptResetStats(idkpt_ctx* ctx)
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;
     memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4);
-    HIPC(hipMemset(ctx->counters64.p, 0, 128));
+    HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
 }
 
