@@ -42,7 +42,8 @@ struct idkpt_ctx {
     std::string lastError;
     int numCUs = 256;
     // config
-    idkpt_settings st;
+    idkpt_settings st;          // effective settings
+    idkpt_settings stCaller;    // the struct the host passed last (idkptSetSettings compares against this one)
     int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0;
     float invProj[16], invView[16], viewPos[3];
     // frame ring (idkptSetFrameRing): ringSize result-image sets; every queued sample remembers its slot, its camera and its
@@ -67,6 +68,8 @@ struct idkpt_ctx {
     // stats
     idkpt_stats stats;
     uint32_t* hCounts = nullptr; // pinned
+    uint32_t* hOverflow = nullptr; uint32_t* dOverflow = nullptr;   // host-mapped word the kernels set when a traversal-stack push is dropped (checked after every sync)
+    int tlasNeed = 1;            // rows the TLAS walk needs (validated for host-built TLAS nodes; min(instances, TLAS_STACK_SIZE) for a device build)
     hipEvent_t evFrame[2] = {nullptr, nullptr};
     // trace-kernel timing (idkptEnableTiming): one event pair per trace launch, resolved lazily in idkptGetStats
     std::vector<hipEvent_t> evPool; size_t evUsed = 0;
@@ -169,7 +172,47 @@ static int alloc_frame_keep_images(idkpt_ctx* ctx)
 }
 
 static int flush_batch(idkpt_ctx* ctx);
+// After a stream synchronisation: did any traversal drop a stack push?  (Cannot happen for scenes that passed idkptUploadScene's
+// validation with BlasStackSize >= the computed need; the flag is the safety net for buffers patched later with idkptUpdateBuffer
+// and for device-built TLASes deeper than TLAS_STACK_SIZE.)  The results of the affected batch are invalid: report, never return them silently.
+static int check_overflow(idkpt_ctx* ctx)
+{
+    if (!ctx->hOverflow || *(volatile uint32_t*)ctx->hOverflow == 0u) return IDKPT_OK;
+    *(volatile uint32_t*)ctx->hOverflow = 0u;
+    return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "traversal stack overflow: a BLAS/TLAS is deeper than the traversal stack (BlasStackSize / TLAS_STACK_SIZE); results since the last synchronisation are invalid");
+}
+#define SYNC_CHECKED() do { HIPC(hipStreamSynchronize(ctx->stream)); int _rc = check_overflow(ctx); if (_rc) return _rc; } while (0)
 #define FLUSH() do { int _rc = flush_batch(ctx); if (_rc) return _rc; } while (0)
+
+// Rows a traversal stack needs for one BLAS: BLAS.ComputeRequiredStackSize (Bvh/BLAS.cs:672-702) evaluated bottom-up.  Requires what the
+// validation established first: every child pair lies behind its parent (acyclic), so one reverse sweep over the node array suffices.
+static int blas_stack_need(const GpuBlasNode* nodes, int nodeCount)
+{
+    std::vector<int> need((size_t)nodeCount, 0);                       // need[p] = stack rows while traversing the pair (p, p+1)
+    for (int p = nodeCount - 2; p >= 2; p--) {
+        const GpuBlasNode& l = nodes[p]; const GpuBlasNode& r = nodes[p + 1];
+        const bool tl = l.TriCount == 0 && l.TriStartOrChild != 0, tr = r.TriCount == 0 && r.TriStartOrChild != 0;
+        if (tl && tr) need[p] = std::max(need[l.TriStartOrChild], need[r.TriStartOrChild]) + 1;
+        else if (tl || tr) need[p] = need[tl ? l.TriStartOrChild : r.TriStartOrChild];
+    }
+    return nodeCount > 2 ? need[2] : 0;
+}
+
+// Host-built TLAS nodes (BVH.TlasBuild / TLAS.Build, Bvh/TLAS.cs:28-141: parents are placed in front of their children): index
+// validation + the depth the per-lane TLAS stack must hold.  Returns < 0 with `why` set when the array is not a valid tree.
+static int tlas_validate(const GpuTlasNode* nodes, int nodeCount, int instanceCount, const char** why)
+{
+    if (nodeCount <= 0) return 0;
+    const uint32_t* w = (const uint32_t*)nodes;                         // 8 dwords per node: Min.xyz, IsLeaf:1|ChildOrInstanceID:31, Max.xyz, pad
+    std::vector<int> need((size_t)nodeCount, 0);
+    for (int i = nodeCount - 1; i >= 0; i--) {
+        const uint32_t packed = w[8 * (size_t)i + 3], id = packed & 0x7fffffffu;
+        if (packed >> 31) { if (id >= (uint32_t)instanceCount) { *why = "TLAS leaf references an instance out of range"; return -1; } continue; }
+        if (id <= (uint32_t)i || (uint64_t)id + 1 >= (uint64_t)nodeCount) { *why = "TLAS child index out of range (children must lie behind their parent)"; return -1; }
+        need[i] = std::max(need[id], need[id + 1]) + 1;
+    }
+    return need[0];
+}
 
 extern "C" {
 
@@ -199,10 +242,13 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return IDKPT_ERR_HIP; }
     memset(&ctx->st, 0, sizeof(ctx->st));
     ctx->st.Gpu.FocalLength = 8.0f; ctx->st.Gpu.DoRussianRoulette = 1; ctx->st.RayDepth = 7; ctx->st.SamplesPerPixel = 1;
+    ctx->stCaller = ctx->st;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     memset(ctx->invProj, 0, 64); memset(ctx->invView, 0, 64); memset(ctx->viewPos, 0, 12);
     if (hipHostMalloc((void**)&ctx->hCounts, MAX_DEPTH_SLOTS * 4 + 16, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4 + 16);
+    if (hipHostMalloc((void**)&ctx->hOverflow, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&ctx->dOverflow, ctx->hOverflow, 0) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
+    *ctx->hOverflow = 0;
     if (hipHostMalloc((void**)&ctx->hBases, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     memset(ctx->hBases, 0, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4);
     (void)hipEventCreate(&ctx->evFrame[0]); (void)hipEventCreate(&ctx->evFrame[1]);
@@ -226,6 +272,7 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     for (DevBuf* b : all) b->release();
     for (auto& t : ctx->texData) t.release();
     if (ctx->hCounts) (void)hipHostFree(ctx->hCounts);
+    if (ctx->hOverflow) (void)hipHostFree(ctx->hOverflow);
     if (ctx->hBases) (void)hipHostFree(ctx->hBases);
     if (ctx->hCams) (void)hipHostFree(ctx->hCams);
     for (int i = 0; i < 2; i++) if (ctx->evCams[i]) (void)hipEventDestroy(ctx->evCams[i]);
@@ -250,6 +297,8 @@ int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height)
     REQUIRE(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
+    REQUIRE(ctx->rowLimit == 0x7fffffff || ctx->rowRem + ctx->rowLimit <= height, "idkptSetSize: the strip set by idkptSetRowRange exceeds the new image height (set a new range first)");
+    REQUIRE(ctx->rowRem < height, "idkptSetSize: this context's row remainder (idkptSetRowSharding) is outside the new image height");
     ctx->W = width; ctx->H = height; ctx->rows = std::min(ctx->rowLimit, local_rows(height, ctx->rowMod, ctx->rowRem));
     return alloc_frame(ctx);
 }
@@ -258,6 +307,7 @@ int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemain
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(rowModulo >= 1 && rowRemainder >= 0 && rowRemainder < rowModulo, "idkptSetRowSharding: need 0 <= remainder < modulo");
+    REQUIRE(ctx->W <= 0 || rowRemainder < ctx->H, "idkptSetRowSharding: no row of the image has this remainder");
     FLUSH();
     ctx->rowMod = rowModulo; ctx->rowRem = rowRemainder; ctx->rowLimit = 0x7fffffff;
     if (ctx->W > 0) { HIPC(hipSetDevice(ctx->device)); ctx->rows = local_rows(ctx->H, rowModulo, rowRemainder); return alloc_frame(ctx); }
@@ -288,8 +338,13 @@ int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* s)
     if (!ctx || !s) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(s->RayDepth >= 1 && s->RayDepth < MAX_DEPTH_SLOTS - 1, "idkptSetSettings: RayDepth out of range");
     REQUIRE(s->SamplesPerPixel >= 1, "idkptSetSettings: SamplesPerPixel must be >= 1");
-    if (memcmp(&ctx->st, s, sizeof(*s)) != 0) FLUSH();   // pending samples were submitted under the old settings
-    const idkpt_settings& o = ctx->st;
+    REQUIRE(s->BlasStackSize >= 0, "idkptSetSettings: BlasStackSize must be >= 0 (0 = derive from BlasDescs)");
+    // BVH.BlasStackSize is the maximum RequiredStackSize of all BLASes (Bvh/BVH.cs:559-567): a smaller stack cannot hold the traversal
+    REQUIRE(s->BlasStackSize == 0 || !ctx->haveScene || s->BlasStackSize >= ctx->sceneStack, "idkptSetSettings: BlasStackSize is smaller than the scene's maximum RequiredStackSize");
+    if (memcmp(&ctx->stCaller, s, sizeof(*s)) == 0) return IDKPT_OK;   // the struct the host pushed last time: nothing changed
+    FLUSH();                                                            // pending samples were submitted under the old settings
+    ctx->stCaller = *s;
+    const idkpt_settings o = ctx->st;
     // PathTracer setters that call ResetAccumulation (PathTracer.cs:17-98): RayDepth, FocalLength, LenseRadius, DoDebugBVHTraversal, DoTraceLights
     bool reset = o.RayDepth != s->RayDepth || o.Gpu.FocalLength != s->Gpu.FocalLength || o.Gpu.LenseRadius != s->Gpu.LenseRadius ||
                  o.Gpu.DoDebugBVHTraversal != s->Gpu.DoDebugBVHTraversal || o.Gpu.DoTraceLights != s->Gpu.DoTraceLights || o.UseTlas != s->UseTlas;
@@ -357,12 +412,24 @@ int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
     for (int i = 0; i < sc->BlasDescCount; i++) {
         const GpuBlasDesc& d = sc->BlasDescs[i];
         REQUIRE(d.NodeOffset >= 0 && d.NodeCount >= 4 && d.NodeOffset + d.NodeCount <= sc->BlasNodeCount && d.TriangleOffset >= 0 && d.TriangleOffset + d.TriangleCount <= sc->BlasTriangleCount, "idkptUploadScene: BlasDesc range out of bounds");
-        maxStack = std::max(maxStack, d.RequiredStackSize);
         for (int n = 1; n < d.NodeCount; n++) {
             const GpuBlasNode& nd = sc->BlasNodes[d.NodeOffset + n];
             if (nd.TriCount > 0) REQUIRE((uint64_t)nd.TriStartOrChild + nd.TriCount <= (uint64_t)d.TriangleCount, "idkptUploadScene: leaf triangle range out of bounds");
-            else if (n == 1 || nd.TriStartOrChild != 0) REQUIRE(nd.TriStartOrChild >= 2 && nd.TriStartOrChild + 1 < (uint32_t)d.NodeCount, "idkptUploadScene: child index out of bounds");
+            else if (n == 1 || nd.TriStartOrChild != 0) REQUIRE(nd.TriStartOrChild >= 2 && nd.TriStartOrChild > (uint32_t)n && nd.TriStartOrChild + 1 < (uint32_t)d.NodeCount, "idkptUploadScene: child index out of bounds (children must lie behind their parent)");
         }
+        // the traversal stack is sized from what the tree really needs (BLAS.ComputeRequiredStackSize, Bvh/BLAS.cs:672-702); a host that
+        // claims less in RequiredStackSize would have compiled the reference's shaders with too small a BLAS_STACK_SIZE (Bvh/BVH.cs:559-567)
+        const int need = blas_stack_need(sc->BlasNodes + d.NodeOffset, d.NodeCount);
+        REQUIRE(d.RequiredStackSize >= need, "idkptUploadScene: BlasDesc.RequiredStackSize is smaller than the stack the BLAS needs");
+        maxStack = std::max(maxStack, need);
+    }
+    REQUIRE(ctx->st.BlasStackSize == 0 || ctx->st.BlasStackSize >= maxStack, "idkptUploadScene: the BlasStackSize set with idkptSetSettings is smaller than this scene's maximum RequiredStackSize");
+    int tlasNeed = 1;
+    if (sc->TlasNodes && sc->TlasNodeCount > 0) {
+        const char* why = nullptr;
+        tlasNeed = tlas_validate(sc->TlasNodes, sc->TlasNodeCount, sc->BlasInstanceCount, &why);
+        REQUIRE(tlasNeed >= 0, std::string("idkptUploadScene: ") + (why ? why : "bad TLAS"));
+        REQUIRE(tlasNeed <= TLAS_STACK_SIZE, "idkptUploadScene: TLAS deeper than TLAS_STACK_SIZE (32)");
     }
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
@@ -400,7 +467,7 @@ int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
     ctx->vertexCount = sc->VertexCount; ctx->meshCount = sc->MeshCount; ctx->materialCount = sc->MaterialCount; ctx->xformCount = sc->MeshTransformCount;
     ctx->lightCount = sc->Lights ? sc->LightCount : 0; ctx->textureCount = sc->TextureCount;
     ctx->hDescs.assign(sc->BlasDescs, sc->BlasDescs + sc->BlasDescCount);
-    ctx->sceneStack = maxStack;
+    ctx->sceneStack = maxStack; ctx->tlasNeed = std::max(1, tlasNeed);
     // refit schedule: internal nodes of every refittable BLAS grouped by depth (children have larger ids than parents)
     ctx->levelOffsets.assign(sc->BlasDescCount, {}); ctx->levelBase.assign(sc->BlasDescCount, 0);
     std::vector<int32_t> allLevels;
@@ -479,11 +546,16 @@ int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, s
 int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCount)
 {
     if (!ctx || !nodes || nodeCount <= 0) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptBuildTlas: no scene uploaded");
+    const char* why = nullptr;
+    const int need = tlas_validate(nodes, nodeCount, ctx->instanceCount, &why);
+    REQUIRE(need >= 0, std::string("idkptBuildTlas: ") + (why ? why : "bad TLAS"));
+    REQUIRE(need <= TLAS_STACK_SIZE, "idkptBuildTlas: TLAS deeper than TLAS_STACK_SIZE (32)");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     int rc = upload(ctx, ctx->tlas, nodes, (size_t)nodeCount * 32); if (rc) return rc;
     HIPC(hipStreamSynchronize(ctx->stream));
-    ctx->tlasCount = nodeCount;
+    ctx->tlasCount = nodeCount; ctx->tlasNeed = std::max(1, need);
     return IDKPT_OK;
 }
 
@@ -503,7 +575,7 @@ int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius)
     hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(),
                        ctx->xforms.as<float4>(), n, (int)searchRadius, ctx->tlas.as<float4>(), (float4*)(sc + tempOff), (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff));
     HIPC(hipGetLastError());
-    ctx->tlasCount = nodeCount;
+    ctx->tlasCount = nodeCount; ctx->tlasNeed = std::min(TLAS_STACK_SIZE, std::max(1, n));   // depth unknown on the host: all rows a tree over n leaves can need, up to the limit (beyond it: overflow flag)
     return IDKPT_OK;
 }
 
@@ -514,7 +586,7 @@ static int query_frame(idkpt_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& gri
     memset(&f, 0, sizeof(f));
     f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;
     f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
-    f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount));
+    f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->tlasNeed));
     ldsBytes = (size_t)(f.stackCap + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;
     if (ldsBytes > 64 * 1024) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack");
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
@@ -546,7 +618,7 @@ int32_t idkptTraceRays(idkpt_ctx* ctx, const idkpt_ray* rays, size_t count, uint
     else hipLaunchKernelGGL((k_trace_query<false>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, ctx->queryIn.as<idkpt_ray>(), ctx->queryOut.as<idkpt_hit>(), (uint32_t)count, lights, work);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(hits, ctx->queryOut.p, count * sizeof(idkpt_hit), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
+    SYNC_CHECKED();
     return IDKPT_OK;
 }
 
@@ -575,7 +647,7 @@ int32_t idkptTraceShadows(idkpt_ctx* ctx, const idkpt_shadow_params* p, const fl
     hipLaunchKernelGGL(k_shadows, dim3(tiles), dim3(WAVE), ldsBytes, st, s, f, *p, (const float*)dDepth, (const float2*)dNormal, dVis);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(visibility, dVis, N * 4, hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
+    SYNC_CHECKED();
     return IDKPT_OK;
 }
 
@@ -637,6 +709,7 @@ static DScene make_dscene(idkpt_ctx* ctx)
     s.meshes = ctx->meshes.as<GpuMesh>(); s.materials = ctx->materials.as<GpuMaterial>(); s.xforms = ctx->xforms.as<float4>();
     s.lights = ctx->lights.as<GpuLight>(); s.lightCount = ctx->lightCount; s.sky = ctx->sky.as<float4>(); s.skySize = ctx->skySize;
     s.textures = ctx->texDescs.as<TexDesc>(); s.textureCount = ctx->textureCount;
+    s.overflow = ctx->dOverflow;
     return s;
 }
 
@@ -694,7 +767,7 @@ static int flush_batch(idkpt_ctx* ctx)
     HIPC(hipMemsetAsync(work, 0, 4 * MAX_DEPTH_SLOTS * 4, st));
     HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
 
-    f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount));
+    f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->tlasNeed));
     size_t ldsBytes = (size_t)(f.stackCap + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;
     if (const char* e = getenv("IDKPT_LDS_PAD")) ldsBytes += (size_t)atoi(e);   // developer knob: caps the waves per CU (occupancy experiments)
     if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }
@@ -839,7 +912,7 @@ int32_t idkptRender(idkpt_ctx* ctx)
     return IDKPT_OK;
 }
 
-int32_t idkptSynchronize(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); HIPC(hipStreamSynchronize(ctx->stream)); return IDKPT_OK; }
+int32_t idkptSynchronize(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); SYNC_CHECKED(); return IDKPT_OK; }
 
 // Launches whatever is pending without waiting for it (lets a host overlap its own work with the GPU).
 int32_t idkptFlush(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); return IDKPT_OK; }
@@ -902,7 +975,7 @@ int32_t idkptDownloadFrame(idkpt_ctx* ctx, int32_t slot, int32_t image, float* r
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image, slot), need, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipStreamSynchronize(ctx->stream));
+    SYNC_CHECKED();
     return IDKPT_OK;
 }
 
@@ -911,6 +984,8 @@ int32_t idkptGetFrameDevicePtr(idkpt_ctx* ctx, int32_t slot, int32_t image, void
     if (!ctx || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(image >= 0 && image < 3, "idkptGetFrameDevicePtr: bad image id");
     REQUIRE(slot >= 0 && slot < ctx->ringSize, "idkptGetFrameDevicePtr: slot outside the frame ring");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();                                        // launches what is still deferred (stream-ordered: a consumer on the context's stream sees the finished image)
     *outPtr = image_ptr(ctx, image, slot);
     if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
     return IDKPT_OK;
@@ -925,7 +1000,7 @@ int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes)
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image, ctx->curSlot), need, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipStreamSynchronize(ctx->stream));
+    SYNC_CHECKED();
     return IDKPT_OK;
 }
 
@@ -942,7 +1017,7 @@ int32_t idkptDownloadRays(idkpt_ctx* ctx, GpuWavefrontRay* out, size_t bytes)
     HIPC(hipMemcpyAsync(a.data(), (char*)ctx->rayO.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipMemcpyAsync(b.data(), (char*)ctx->rayT.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipMemcpyAsync(c.data(), (char*)ctx->rayR.p + off, N * 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipStreamSynchronize(ctx->stream));
+    SYNC_CHECKED();
     for (size_t i = 0; i < N; i++) {
         GpuWavefrontRay& r = out[i];
         r.Origin[0] = a[i].x; r.Origin[1] = a[i].y; r.Origin[2] = a[i].z; r.PreviousIOROrTraverseCost = a[i].w;
@@ -993,7 +1068,7 @@ int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* out)
     if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
-    HIPC(hipStreamSynchronize(ctx->stream));
+    SYNC_CHECKED();
     idkpt_stats s = ctx->stats;
     for (int j = 0; j < 16; j++) { const uint32_t* hb = ctx->hBases + (size_t)j * (MAX_BATCH + 1); s.LastAliveCounts[j] = (j >= 1 && j < ctx->st.RayDepth) ? hb[ctx->lastBatch] - hb[ctx->lastBatch - 1] : 0; }
     // [0]: primary rays that entered the traversal kernel (all pixels, or the survivors of the root-box pre-cull on the fast path)
@@ -1032,6 +1107,8 @@ int32_t idkptGetImageDevicePtr(idkpt_ctx* ctx, int32_t image, void** outPtr, siz
 {
     if (!ctx || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(image >= 0 && image < 3 && ctx->W > 0, "idkptGetImageDevicePtr: bad image / no size");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();                                        // launches what is still deferred
     *outPtr = image_ptr(ctx, image, ctx->curSlot);
     if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
     return IDKPT_OK;

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
                         sp = 0; top = 2u;                                                   // no root test under USE_TLAS (:32)
-                        if (tsp == 0) moreInst = false; else instIdx = tstk[--tsp * WAVE];  // the pop the reference does after the BLAS; order-independent
+                        if (tsp == 0 || tsp > f.tlasCap) moreInst = false; else instIdx = tstk[--tsp * WAVE];  // the pop the reference does after the BLAS; order-independent
                     } else {
                         const uint32_t l = id, r = id + 1;
                         float4 a = tr.lo[rayId], c = tr.inv[rayId];                         // world-space origin and 1/dir
@@ -345,9 +345,9 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         const bool tl = RayBoxIntersect(wo, winv, lmin, lmax, &tMinLeft) && tMinLeft < hitT;
                         const bool tr2 = RayBoxIntersect(wo, winv, rmin, rmax, &tMinRight) && tMinRight < hitT;
                         if (tl || tr2) {
-                            if (tl && tr2) { const bool lc = tMinLeft < tMinRight; instIdx = lc ? l : r; if (tsp < f.tlasCap) tstk[tsp * WAVE] = lc ? r : l; tsp++; }
+                            if (tl && tr2) { const bool lc = tMinLeft < tMinRight; instIdx = lc ? l : r; if (tsp < f.tlasCap) tstk[tsp * WAVE] = lc ? r : l; else *s.overflow = 1u; tsp++; }
                             else instIdx = tl ? l : r;
-                        } else { if (tsp == 0) moreInst = false; else instIdx = tstk[--tsp * WAVE]; }
+                        } else { if (tsp == 0 || tsp > f.tlasCap) moreInst = false; else instIdx = tstk[--tsp * WAVE]; }
                     }
                 }
                 adv = active && !leafPending && top == 0u && moreInst;
@@ -401,12 +401,12 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                     if (traverseLeft && traverseRight) {
                         const bool leftCloser = tMinLeft < tMinRight;
                         top = leftCloser ? lStart : rStart;
-                        if (sp < cap) stk[sp * WAVE] = leftCloser ? rStart : lStart;
+                        if (sp < cap) stk[sp * WAVE] = leftCloser ? rStart : lStart; else *s.overflow = 1u;
                         sp++;
                     } else top = traverseLeft ? lStart : rStart;
                 } else {
                     if (sp == 0) top = 0u;
-                    else { sp--; top = stk[sp * WAVE]; }
+                    else { sp--; top = sp < cap ? stk[sp * WAVE] : 0u; }   // (sp >= cap: the matching push was dropped and flagged)
                 }
             }
         }

@@ -28,6 +28,7 @@ struct DScene {
     const GpuLight* lights; int lightCount;
     const float4* sky; int skySize;
     const TexDesc* textures; int textureCount;
+    uint32_t* overflow;         // host-mapped word: set when a traversal-stack push had to be dropped (idkpt.hip turns it into an error at the next sync)
 };
 
 struct Frame {
@@ -64,7 +65,7 @@ struct HitBufs {                // indexed by queue slot
 
 struct HitRec { float T, bx, by; uint32_t tri, xform; };
 
-#define TLAS_STACK_SIZE 24
+#define TLAS_STACK_SIZE 32
 
 // ---------------------------------------------------------------------------------------------------------------
 // BVH traversal (include/BVHIntersect.glsl:27-105, 183-291).  One ray per lane; the per-lane traversal stack lives in
@@ -113,12 +114,13 @@ DEV bool IntersectBlas(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& dref, b
             if (traverseLeft && traverseRight) {
                 bool leftCloser = tMinLeft < tMinRight;
                 top = leftCloser ? lStart : rStart;
-                if (sp < cap) stk[sp * stride] = leftCloser ? rStart : lStart;
+                if (sp < cap) stk[sp * stride] = leftCloser ? rStart : lStart; else *s.overflow = 1u;
                 sp++;
             } else top = traverseLeft ? lStart : rStart;
         } else {
             if (sp == 0) break;
             sp--;
+            if (sp >= cap) break;          // the matching push was dropped (flagged): stop instead of following a garbage index
             top = stk[sp * stride];
         }
     }
@@ -160,7 +162,7 @@ DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, fl
                 M34 inv = load_inv_model(s, inst.MeshTransformId);
                 f3 lo = xform34(inv, ro, 1.0f), ld = xform34(inv, rd, 0.0f);
                 if (IntersectBlas<COUNT, COST>(s, lo, ld, s.descs[inst.BlasId], true, hit, debugCost, stk, stride, f.stackCap, nPairs, nTris)) hit.xform = inst.MeshTransformId;
-                if (sp == 0) break;
+                if (sp == 0 || sp > f.tlasCap) break;
                 top = tstk[--sp * stride];
                 continue;
             }
@@ -169,9 +171,9 @@ DEV bool TraceRay(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit, fl
             bool tl = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft < hit.T;
             bool tr = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight < hit.T;
             if (tl || tr) {
-                if (tl && tr) { bool lc = tMinLeft < tMinRight; top = lc ? l : r; if (sp < f.tlasCap) tstk[sp * stride] = lc ? r : l; sp++; }
+                if (tl && tr) { bool lc = tMinLeft < tMinRight; top = lc ? l : r; if (sp < f.tlasCap) tstk[sp * stride] = lc ? r : l; else *s.overflow = 1u; sp++; }
                 else top = tl ? l : r;
-            } else { if (sp == 0) break; top = tstk[--sp * stride]; }
+            } else { if (sp == 0 || sp > f.tlasCap) break; top = tstk[--sp * stride]; }
         }
     } else {
         for (int i = 0; i < s.instanceCount; i++) {
@@ -226,11 +228,12 @@ DEV bool IntersectBlasAny(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& dref
         }
         bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
         if (traverseLeft || traverseRight) {
-            if (traverseLeft && traverseRight) { top = lStart; if (sp < cap) stk[sp * stride] = rStart; sp++; }
+            if (traverseLeft && traverseRight) { top = lStart; if (sp < cap) stk[sp * stride] = rStart; else *s.overflow = 1u; sp++; }
             else top = traverseLeft ? lStart : rStart;
         } else {
             if (sp == 0) break;
             sp--;
+            if (sp >= cap) break;
             top = stk[sp * stride];
         }
     }
@@ -266,7 +269,7 @@ DEV bool TraceRayAny(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit,
                 M34 inv = load_inv_model(s, inst.MeshTransformId);
                 f3 lo = xform34(inv, ro, 1.0f), ld = xform34(inv, rd, 0.0f);
                 if (IntersectBlasAny(s, lo, ld, s.descs[inst.BlasId], true, hit, stk, stride, f.stackCap)) { hit.xform = inst.MeshTransformId; return true; }
-                if (sp == 0) break;
+                if (sp == 0 || sp > f.tlasCap) break;
                 top = tstk[--sp * stride];
                 continue;
             }
@@ -275,9 +278,9 @@ DEV bool TraceRayAny(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit,
             bool tl = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft < hit.T;
             bool tr = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight < hit.T;
             if (tl || tr) {
-                if (tl && tr) { bool lc = tMinLeft < tMinRight; top = lc ? l : r; if (sp < f.tlasCap) tstk[sp * stride] = lc ? r : l; sp++; }
+                if (tl && tr) { bool lc = tMinLeft < tMinRight; top = lc ? l : r; if (sp < f.tlasCap) tstk[sp * stride] = lc ? r : l; else *s.overflow = 1u; sp++; }
                 else top = tl ? l : r;
-            } else { if (sp == 0) break; top = tstk[--sp * stride]; }
+            } else { if (sp == 0 || sp > f.tlasCap) break; top = tstk[--sp * stride]; }
         }
     } else {
         for (int i = 0; i < s.instanceCount; i++) {

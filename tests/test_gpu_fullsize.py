@@ -1,0 +1,76 @@
+"""BASELINE.json full size (1M triangles, 1920x1080): whole frames against the oracle + size-independent properties."""
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import configs  # noqa: E402,F401
+from idkengine_amd import scenes as S  # noqa: E402,F401
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402,F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def soup1m(native_builder):
+    return S.soup_scene(1000000, native_builder, seed=1)
+
+
+def test_full_size_headline_frame_properties(soup1m, oracle_mod):
+    """BASELINE.json configs[2] at full size: 1M triangles, 1920x1080, RayDepth 2.  Size-independent properties +
+    a strided-row exact comparison against the oracle (every 16th row = 67 rows, seconds on CPU)."""
+    w, h = 1920, 1080; cam = S.Camera(w, h)
+    pt = gpu_render(soup1m, cam, w, h, RayDepth=2)
+    img = pt.Result; st = pt.stats()
+    assert np.isfinite(img).all() and img[..., :3].max() <= 1.0 and (img[..., 3] == 1.0).all()
+    t, tri, _ = pt.primary_hits()
+    assert (img.reshape(-1, 4)[tri == 0xFFFFFFFF, :3] == 1.0).all()                 # white sky on every miss
+    assert st["alive_counts"][1] == int((tri != 0xFFFFFFFF).sum())                   # every primary hit continues (opaque diffuse, no RR on the first hit)
+    assert st["rays_traced"] == w * h + st["alive_counts"][1]
+    # determinism: same frame twice -> identical bits
+    pt.ResetAccumulation(); pt.Compute()
+    assert (bits(pt.Result) == bits(img)).all()
+    # sort on == sort off at depth 2
+    pt.DoRaySorting = 1; pt.ResetAccumulation(); pt.Compute()
+    assert (bits(pt.Result) == bits(img)).all()
+    # exact oracle comparison on a row shard (rows y % 16 == 3)
+    o = oracle_mod.OraclePathTracer(soup1m, w, h, row_modulo=16, row_remainder=3); o.set_camera(cam); o.settings.RayDepth = 2; o.render()
+    assert (bits(img[3::16]) == bits(o.image())).all()
+    pt.Dispose(); o.close()
+
+
+@pytest.mark.parametrize("depth,sort,batch", [(2, 0, 4), (5, 0, 2), (5, 1, 3)])
+def test_full_size_frames_are_bit_exact(soup1m, oracle_mod, depth, sort, batch):
+    """BASELINE.json's full size (1M triangles, 1920x1080), whole frames against the oracle (OpenMP over the host cores of the GPU
+    box: a few seconds): image, ray state, queue, counters — 3 accumulated samples traced `batch` at a time."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    w, h = 1920, 1080; cam = S.Camera(w, h)
+    ov = dict(RayDepth=depth, DoRaySorting=sort)
+    pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); pt.UploadScene(soup1m); pt.SetCamera(cam)
+    pt.set_max_batch(batch); pt.enable_counters(True)
+    o = oracle_render(oracle_mod, soup1m, cam, w, h, frames=3, **ov)
+    for _ in range(3):
+        pt.Compute()
+    assert (bits(pt.Result) == bits(o.image(0))).all()
+    assert pt.rays().tobytes() == o.rays().tobytes() and (pt.alive_queue() == o.alive_queue()).all()
+    gs, os_ = pt.stats(), o.stats()
+    assert gs["rays_traced"] == os_["rays_traced"] and gs["node_pair_visits"] == os_["node_pair_visits"] and gs["triangle_tests"] == os_["triangle_tests"]
+    pt.Dispose(); o.close()
+
+
+def test_row_sharded_contexts_reassemble_the_frame(soup1m):
+    """Two contexts on one GPU, rows y%2==r: the multi-GPU sharding of dist.py without the transport."""
+    from idkengine_amd.pathtracer import PathTracer
+    w, h = 960, 540; cam = S.Camera(w, h)
+    full = gpu_render(soup1m, cam, w, h, RayDepth=2, counters=False, capture=False)
+    want = full.Result
+    out = np.zeros_like(want)
+    for r in range(2):
+        p = PathTracer(w, h, row_modulo=2, row_remainder=r); p.UploadScene(soup1m); p.SetCamera(cam); p.RayDepth = 2
+        p.Compute(); out[r::2] = p.Result; p.Dispose()
+    assert (bits(out) == bits(want)).all()
+    full.Dispose()

@@ -1,0 +1,100 @@
+"""Instance list / TLAS paths of the persistent traversal kernel and the device TLAS build (BVHIntersect.glsl:205-287, Bvh/TLAS.cs)."""
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import configs  # noqa: E402,F401
+from idkengine_amd import scenes as S  # noqa: E402,F401
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402,F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_multi_instance_fast_path_equals_generic(native_builder, monkeypatch):
+    """Several BLAS instances without a TLAS (the reference's default mode) run on the persistent traversal kernel with the
+    per-lane instance loop; it must agree bit-for-bit with the general kernel, with and without sample batching."""
+    sc = S.cornell_scene(native_builder, "mixed", True); cam = S.cornell_camera(200, 120)
+    a = gpu_render(sc, cam, 200, 120, RayDepth=5, DoRaySorting=1, SamplesPerPixel=2)
+    from idkengine_amd.pathtracer import PathTracer
+    c = PathTracer(200, 120); c.UploadScene(sc); c.SetCamera(cam); c.RayDepth = 5; c.DoRaySorting = 1; c.SamplesPerPixel = 2
+    c.set_max_batch(4); c.enable_counters(True); c.Compute(); c.flush()
+    monkeypatch.setenv("IDKPT_FORCE_GENERIC", "1")
+    b = gpu_render(sc, cam, 200, 120, RayDepth=5, DoRaySorting=1, SamplesPerPixel=2)
+    assert (bits(a.Result) == bits(b.Result)).all() and a.rays().tobytes() == b.rays().tobytes()
+    assert (bits(c.Result) == bits(b.Result)).all()
+    for k in ("node_pair_visits", "triangle_tests", "rays_traced"):
+        assert a.stats()[k] == b.stats()[k] == c.stats()[k], k
+    a.Dispose(); b.Dispose(); c.Dispose()
+
+
+@pytest.mark.parametrize("use_tlas", [0, 1])
+def test_many_instances_fast_path(native_builder, oracle_mod, monkeypatch, use_tlas):
+    """12 rotated BLAS instances (deep PLOC TLAS when use_tlas=1): persistent kernel (instance loop / in-kernel TLAS walk) vs the
+    oracle and vs the general kernel, batched, with exact visit counters."""
+    sc = S.soup_scene_multi(6000, native_builder, parts=12, seed=5); w, h = 160, 96; cam = S.Camera(w, h)
+    ov = dict(RayDepth=4, UseTlas=use_tlas, SamplesPerPixel=3, DoRaySorting=1)
+    o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+    a = gpu_render(sc, cam, w, h, **ov)
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    c = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); c.UploadScene(sc); c.SetCamera(cam)
+    c.set_max_batch(3); c.enable_counters(True); c.Compute(); c.flush()
+    monkeypatch.setenv("IDKPT_FORCE_GENERIC", "1")
+    b = gpu_render(sc, cam, w, h, **ov)
+    assert (bits(a.Result) == bits(o.image(0))).all()
+    assert (bits(a.Result) == bits(b.Result)).all() and (bits(c.Result) == bits(b.Result)).all()
+    os_ = o.stats()
+    for k in ("node_pair_visits", "triangle_tests", "rays_traced"):
+        assert a.stats()[k] == b.stats()[k] == c.stats()[k] == os_[k], k
+    a.Dispose(); b.Dispose(); c.Dispose(); o.close()
+
+
+@pytest.mark.parametrize("use_tlas", [1, 0])
+def test_many_small_instances_deep_tlas(native_builder, oracle_mod, use_tlas):
+    """600 BLAS instances of a few triangles each: a deep PLOC TLAS (per-lane TLAS stack in LDS) or a long instance list, with the
+    ray-query entry point on top — frame, counters and 20 000 closest/any-hit queries equal the oracle."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.soup_scene_multi(3600, native_builder, parts=600, seed=13, extent=4.0, edge=0.4); w, h = 160, 96; cam = S.Camera(w, h, position=(0.0, 0.0, 11.0), fovy_deg=60.0)
+    ov = dict(RayDepth=3, UseTlas=use_tlas)
+    pt = gpu_render(sc, cam, w, h, **ov); o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+    assert_equal(pt, o)
+    rays = _queries(20000, 17, 6.0)
+    for any_hit in (False, True):
+        assert pt.TraceRays(rays, any_hit=any_hit).tobytes() == oracle_mod.trace_rays(sc, rays, any_hit=any_hit, use_tlas=bool(use_tlas)).tobytes()
+    pt.Dispose(); o.close()
+
+
+@pytest.mark.parametrize("parts,tris", [(1, 500), (2, 600), (3, 900), (12, 6000), (200, 4000), (1500, 6000)])
+def test_device_tlas_build_matches_host_build(native_builder, oracle_builder, parts, tris):
+    """TLAS rebuild on the device (idkptBuildTlasOnDevice: instance world bounds + Morton order + PLOC) must give the node array
+    of the serial host build (TLAS.Build, Bvh/TLAS.cs:28-141) bit for bit, also after the transforms moved."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    sc = S.soup_scene_multi(tris, native_builder, parts=parts, seed=9) if parts > 1 else S.soup_scene(tris, native_builder, seed=9)
+    pt = PathTracer(64, 64); pt.UploadScene(sc)
+    pt.BuildTlasOnDevice()
+    got = pt.DownloadBuffer(T.IDKPT_BUF_TLAS_NODES, T.GpuTlasNode, 2 * parts - 1)
+    assert got.tobytes() == sc.tlas_nodes.tobytes()
+    # move every instance (animated frame), rebuild on both sides
+    rng = np.random.default_rng(parts)
+    xf = sc.mesh_transforms.copy()
+    for i in range(len(xf)):
+        m = S.rotation_y(float(rng.uniform(0, 360))) @ S.translation(tuple(rng.uniform(-6, 6, 3)))
+        xf[i] = S.transform_from_matrix(m)[0]
+    sc.mesh_transforms = xf
+    pt.UpdateBuffer(T.IDKPT_BUF_MESH_TRANSFORMS, xf)
+    pt.BuildTlasOnDevice()
+    S.rebuild_tlas(sc, oracle_builder)
+    got = pt.DownloadBuffer(T.IDKPT_BUF_TLAS_NODES, T.GpuTlasNode, 2 * parts - 1)
+    assert got.tobytes() == sc.tlas_nodes.tobytes()
+    if parts == 12:   # and the frame traced through the device-built TLAS equals the frame through the uploaded one
+        cam = S.Camera(96, 64)
+        a = PathTracer(96, 64); a.UploadScene(sc); a.SetCamera(cam); a.UseTlas = 1; a.RayDepth = 3; a.Compute()
+        b = PathTracer(96, 64); b.UploadScene(sc); b.SetCamera(cam); b.BuildTlasOnDevice(); b.UseTlas = 1; b.RayDepth = 3; b.Compute()
+        assert (bits(a.Result) == bits(b.Result)).all()
+        a.Dispose(); b.Dispose()
+    pt.Dispose()

@@ -1,0 +1,74 @@
+"""State-machine check of the deferral logic (runs last: a failure here must not hide the other files under pytest -x)."""
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import configs  # noqa: E402,F401
+from idkengine_amd import scenes as S  # noqa: E402,F401
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402,F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_api_sequences_match_unbatched_replay(native_builder, seed):
+    """State-machine check of the deferral logic: a random sequence of host calls (camera moves, Compute, ResetAccumulation, settings,
+    SetMaxBatch, SetSize, scene swap, reads in between) must leave the same image as the same logical sequence replayed on a context
+    that never defers (max batch 1)."""
+    from idkengine_amd.pathtracer import PathTracer
+    rng = np.random.default_rng(100 + seed)
+    scenes = [S.cornell_scene(native_builder, "mixed", True), S.soup_scene(4000, native_builder, seed=3, extent=2.5)]
+    sizes = [(64, 40), (57, 33)]
+    cams = lambda w, h: [S.cornell_camera(w, h), S.Camera(w, h, position=(0.3, 0.2, 5.0), fovy_deg=55.0), S.Camera(w, h, position=(-0.4, 0.1, 4.0), fovy_deg=70.0)]   # noqa: E731
+    a = PathTracer(*sizes[0]); b = PathTracer(*sizes[0])
+    a.set_max_batch(int(rng.integers(2, 9)))
+    size = sizes[0]
+    for p in (a, b):
+        p.UploadScene(scenes[0]); p.SetCamera(cams(*size)[0]); p.RayDepth = 3
+    for step in range(24):
+        op = rng.choice(["cam", "compute", "compute", "compute", "reset", "depth", "sort", "batch", "size", "scene", "read", "spp"])
+        if op == "cam":
+            k = int(rng.integers(0, 3))
+            for p in (a, b):
+                p.SetCamera(cams(*size)[k])
+        elif op == "compute":
+            for p in (a, b):
+                p.Compute()
+        elif op == "reset":
+            for p in (a, b):
+                p.ResetAccumulation()
+        elif op == "depth":
+            d = int(rng.integers(1, 6))
+            for p in (a, b):
+                p.RayDepth = d
+        elif op == "sort":
+            v = int(rng.integers(0, 2))
+            for p in (a, b):
+                p.DoRaySorting = v
+        elif op == "spp":
+            v = int(rng.integers(1, 4))
+            for p in (a, b):
+                p.SamplesPerPixel = v
+        elif op == "batch":
+            a.set_max_batch(int(rng.integers(1, 9)))
+        elif op == "size":
+            size = sizes[int(rng.integers(0, 2))]
+            for p in (a, b):
+                p.SetSize(*size); p.SetCamera(cams(*size)[0])
+        elif op == "scene":
+            k = int(rng.integers(0, 2))
+            for p in (a, b):
+                p.UploadScene(scenes[k])
+        elif op == "read":
+            assert (bits(a.Result) == bits(b.Result)).all(), (seed, step)
+            assert a.AccumulatedSamples == b.AccumulatedSamples
+    assert (bits(a.Result) == bits(b.Result)).all(), seed
+    assert a.AccumulatedSamples == b.AccumulatedSamples
+    for p in (a, b):                       # the ray state is only defined right after a sample
+        p.Compute()
+    assert a.rays().tobytes() == b.rays().tobytes() and (bits(a.Result) == bits(b.Result)).all()
+    a.Dispose(); b.Dispose()
