@@ -10,15 +10,21 @@ DEV void write_trace_ready(const DScene& s, const Frame& f, const TraceBufs& tr,
 {
     f3 rd = DecodeUnitVec(r.pdx, r.pdy);
     if (f.useTlas || s.instanceCount > 1) {   // the traversal kernel walks the TLAS / instance list and transforms the world ray itself
-        tr.lo[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, 0.0f); tr.ld[rid] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-        if (f.useTlas) tr.inv[rid] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, 0.0f);   // world 1/dir for the TLAS slab tests (:209)
+        tr.rec[4 * (size_t)rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, 0.0f); tr.rec[4 * (size_t)rid + 1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+        if (f.useTlas) tr.rec[4 * (size_t)rid + 2] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, 0.0f);   // world 1/dir for the TLAS slab tests (:209)
         return;
     }
     GpuBlasInstance inst = s.instances[0];
     M34 inv = load_inv_model(s, inst.MeshTransformId);
     f3 lo = xform34(inv, r.origin, 1.0f), ld = xform34(inv, rd, 0.0f);
-    tr.lo[rid] = make_float4(lo.x, lo.y, lo.z, 0.0f); tr.ld[rid] = make_float4(ld.x, ld.y, ld.z, 0.0f);
-    tr.inv[rid] = make_float4(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z, 0.0f);
+    const f3 iv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+    // lo.w = tMin of the root-box test IntersectBlas does first (BVHIntersect.glsl:32-39), +inf when the ray misses the box: the traversal
+    // kernel only has to compare it with its T, the box arithmetic runs here with all lanes busy
+    const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
+    float t1;
+    const float rootT = RayBoxIntersect(lo, iv, root[0], root[1], &t1) ? t1 : __builtin_inff();
+    tr.rec[4 * (size_t)rid] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)rid + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f);
+    tr.rec[4 * (size_t)rid + 2] = make_float4(iv.x, iv.y, iv.z, 0.0f);
 }
 
 // Fast-path FirstHit shading: only the rays that entered the traversal (active list, any order).  The continue decision
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
             rays.thr_px[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
             rays.rad_py[idx] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
             if (f.outputAovs) { rays.aovA[idx] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[idx] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
-            if (cont && tr.lo) write_trace_ready(s, f, tr, idx, r);
+            if (cont && tr.rec) write_trace_ready(s, f, tr, idx, r);
         }
         // NHit:81 masks the key to 21 bits; the sample index goes above it so that the batch-wide sort stays grouped by sample
         keysTmp[slot] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);

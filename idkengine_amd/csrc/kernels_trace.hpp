@@ -187,6 +187,7 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
         gen_primary(f, smp, pix, f.accum[smp], origin, pd, seed);
         f3 rd = DecodeUnitVec(pd.x, pd.y);
         f3 lo = origin, ld = rd, invDir = splat3(0.0f);   // several instances / TLAS: the traversal kernel transforms the world ray per instance
+        float rootT = __builtin_inff();                   // single instance: tMin of the root-box test (+inf = miss), consumed by k_trace2
         keep = !cull;
         if (f.useTlas) {
             // first TLAS step (BVHIntersect.glsl:242-249) with T = FLOAT_MAX: a ray that misses both children of the root is a miss
@@ -212,15 +213,17 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
             f3 l0 = xform34(inv, origin, 1.0f), l1 = xform34(inv, rd, 0.0f);
             f3 iv = mk3(1.0f / l1.x, 1.0f / l1.y, 1.0f / l1.z);
             if (s.instanceCount == 1) { lo = l0; ld = l1; invDir = iv; }
-            if (cull) {
+            if (cull || s.instanceCount == 1) {
                 const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
                 float t1;
-                if (RayBoxIntersect(l0, iv, root[0], root[1], &t1) && t1 < PT_FLOAT_MAX) keep = true;
+                const bool boxHit = RayBoxIntersect(l0, iv, root[0], root[1], &t1);
+                if (s.instanceCount == 1 && boxHit) rootT = t1;
+                if (cull && boxHit && t1 < PT_FLOAT_MAX) keep = true;
             }
         }
         f3 radiance = splat3(0.0f);
         if (keep) {
-            tr.lo[rid] = make_float4(lo.x, lo.y, lo.z, 0.0f); tr.ld[rid] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.inv[rid] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f);
+            tr.rec[4 * (size_t)rid] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)rid + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.rec[4 * (size_t)rid + 2] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f);
             seedOut[rid] = seed;                                        // RNG state after ray generation, consumed by k_shade_first
         } else {
             // miss branch of FirstHit TraceRay (FirstHit/compute.glsl:225-233), evaluated right here
@@ -310,9 +313,9 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 if (MULTI) { rayId = idx; instIdx = 0; tsp = 0; moreInst = TLAS ? s.tlasCount > 0 : true; active = true; leafPending = false; sp = 0; top = 0u; }
                 else {
                     // local-space ray and 1/dir were prepared by the (coherent, full-lane) kernel that produced this ray
-                    { float4 a = tr.lo[idx], b = tr.ld[idx], c = tr.inv[idx]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z); }
-                    float t1;
-                    bool enter = RayBoxIntersect(ro, invDir, nodes[2], nodes[3], &t1) && t1 < hitT; // root test (:32-39)
+                    float rootT;
+                    { float4 a = tr.rec[4 * (size_t)idx], b = tr.rec[4 * (size_t)idx + 1], c = tr.rec[4 * (size_t)idx + 2]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z); rootT = a.w; }
+                    const bool enter = rootT < hitT;   // root test (:32-39): the box arithmetic ran in the kernel that produced the ray (record[0].w = tMin, +inf = miss)
                     active = true; leafPending = false; sp = 0; top = enter ? 2u : 0u;
                 }
             }
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                     if ((packed >> 31) == 1u) {                                             // leaf: BVHIntersect.glsl:223-240
                         const GpuBlasInstance in2 = s.instances[id];
                         const M34 inv = load_inv_model(s, in2.MeshTransformId);
-                        float4 a = tr.lo[rayId], b = tr.ld[rayId];
+                        float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];
                         ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                         invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         if (tsp == 0 || tsp > f.tlasCap) moreInst = false; else instIdx = tstk[--tsp * WAVE];  // the pop the reference does after the BLAS; order-independent
                     } else {
                         const uint32_t l = id, r = id + 1;
-                        float4 a = tr.lo[rayId], c = tr.inv[rayId];                         // world-space origin and 1/dir
+                        float4 a = tr.rec[4 * (size_t)rayId], c = tr.rec[4 * (size_t)rayId + 2];                         // world-space origin and 1/dir
                         const f3 wo = mk3(a.x, a.y, a.z), winv = mk3(c.x, c.y, c.z);
                         float4 lmin = s.tlas[2 * (size_t)l], lmax = s.tlas[2 * (size_t)l + 1], rmin = s.tlas[2 * (size_t)r], rmax = s.tlas[2 * (size_t)r + 1];
                         float tMinLeft, tMinRight;
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 if (adv) {
                     const GpuBlasInstance in2 = s.instances[instIdx];
                     const M34 inv = load_inv_model(s, in2.MeshTransformId);
-                    float4 a = tr.lo[rayId], b = tr.ld[rayId];                         // world-space origin / direction
+                    float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];                         // world-space origin / direction
                     ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                     invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;

@@ -52,11 +52,10 @@ struct RayBufs {                // SoA planes of the reference's GpuWavefrontRay
     float4* aovA;               // Albedo.xyz, NewWeight
     float4* aovN;               // Normal.xyz, pad
 };
-struct TraceBufs {              // derived, per ray id: the ray in BLAS-local space, ready for the traversal kernel (single-instance fast path)
-    float4* lo;                 // RayTransform(origin)   (Ray.glsl:7-12)
-    float4* ld;                 // RayTransform(direction), not renormalised
-    float4* inv;                // 1 / ld                 (IntersectionRoutines.glsl:29)
-};
+struct TraceBufs {              // derived, per ray id: the ray ready for the traversal kernel, one 64-B record (the size and alignment of a node pair, so
+    float4* rec;                // that a refill touches one cache line per ray instead of three): [0] RayTransform(origin) (Ray.glsl:7-12), .w = tMin of
+};                              // the root-box test (+inf = miss), so that the traversal kernel's root test is one compare; [1] RayTransform(direction), not renormalised; [2] 1 / [1] (IntersectionRoutines.glsl:29); [3] unused.
+                                // Several instances / TLAS: [0],[1] hold the WORLD-space ray, [2] the world 1/dir (TLAS only).
 struct HitBufs {                // indexed by queue slot
     float4* hit;                // T, BaryXY.x, BaryXY.y, TriangleId (bits)
     uint32_t* xformId;          // MeshTransformId or light index

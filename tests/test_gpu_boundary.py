@@ -103,7 +103,9 @@ def test_undersized_traversal_stacks_are_rejected(native_builder):
     with pytest.raises(IdkPtError, match="RequiredStackSize"):
         pt.UploadScene(bad)
     # a scene that needs more than the BlasStackSize that is already set
-    small = PathTracer(w, h); small.UploadScene(S.cornell_scene(native_builder)); small.BlasStackSize = 2
+    cornell = S.cornell_scene(native_builder)
+    small = PathTracer(w, h); small.UploadScene(cornell); small.BlasStackSize = int(cornell.blas_descs["RequiredStackSize"].max())
+    assert small.BlasStackSize < need
     with pytest.raises(IdkPtError, match="BlasStackSize"):
         small.UploadScene(sc)
     # child indices that point backwards (a cycle would hang the traversal) never reach the GPU

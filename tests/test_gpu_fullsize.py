@@ -42,8 +42,8 @@ def test_full_size_headline_frame_properties(soup1m, oracle_mod):
     pt.Dispose(); o.close()
 
 
-@pytest.mark.parametrize("depth,sort,batch", [(2, 0, 4), (5, 0, 2), (5, 1, 3)])
-def test_full_size_frames_are_bit_exact(soup1m, oracle_mod, depth, sort, batch):
+@pytest.mark.parametrize("depth,sort,batch,counters", [(2, 0, 4, True), (5, 0, 2, True), (5, 1, 3, True), (2, 0, 3, False), (5, 1, 3, False), (9, 0, 1, False)])
+def test_full_size_frames_are_bit_exact(soup1m, oracle_mod, depth, sort, batch, counters):
     """BASELINE.json's full size (1M triangles, 1920x1080), whole frames against the oracle (OpenMP over the host cores of the GPU
     box: a few seconds): image, ray state, queue, counters — 3 accumulated samples traced `batch` at a time."""
     from idkengine_amd.pathtracer import PathTracer
@@ -51,14 +51,16 @@ def test_full_size_frames_are_bit_exact(soup1m, oracle_mod, depth, sort, batch):
     w, h = 1920, 1080; cam = S.Camera(w, h)
     ov = dict(RayDepth=depth, DoRaySorting=sort)
     pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); pt.UploadScene(soup1m); pt.SetCamera(cam)
-    pt.set_max_batch(batch); pt.enable_counters(True)
+    pt.set_max_batch(batch); pt.enable_counters(counters)          # counters on / off: the counting and the plain build of the traversal kernel
     o = oracle_render(oracle_mod, soup1m, cam, w, h, frames=3, **ov)
     for _ in range(3):
         pt.Compute()
     assert (bits(pt.Result) == bits(o.image(0))).all()
     assert pt.rays().tobytes() == o.rays().tobytes() and (pt.alive_queue() == o.alive_queue()).all()
     gs, os_ = pt.stats(), o.stats()
-    assert gs["rays_traced"] == os_["rays_traced"] and gs["node_pair_visits"] == os_["node_pair_visits"] and gs["triangle_tests"] == os_["triangle_tests"]
+    assert gs["rays_traced"] == os_["rays_traced"]
+    if counters:
+        assert gs["node_pair_visits"] == os_["node_pair_visits"] and gs["triangle_tests"] == os_["triangle_tests"]
     pt.Dispose(); o.close()
 
 

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 sys.path.insert(0, HERE)
 import configs  # noqa: E402,F401
 from idkengine_amd import scenes as S  # noqa: E402,F401
-from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402,F401
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal, _queries  # noqa: E402,F401
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,10 @@ def test_many_instances_fast_path(native_builder, oracle_mod, monkeypatch, use_t
     os_ = o.stats()
     for k in ("node_pair_visits", "triangle_tests", "rays_traced"):
         assert a.stats()[k] == b.stats()[k] == c.stats()[k] == os_[k], k
-    a.Dispose(); b.Dispose(); c.Dispose(); o.close()
+    monkeypatch.delenv("IDKPT_FORCE_GENERIC")
+    d = gpu_render(sc, cam, w, h, counters=False, **ov)      # counters off: the plain (non-counting) build of the traversal kernel
+    assert_equal(d, o, counters=False)
+    a.Dispose(); b.Dispose(); c.Dispose(); d.Dispose(); o.close()
 
 
 @pytest.mark.parametrize("use_tlas", [1, 0])
@@ -62,6 +65,8 @@ def test_many_small_instances_deep_tlas(native_builder, oracle_mod, use_tlas):
     ov = dict(RayDepth=3, UseTlas=use_tlas)
     pt = gpu_render(sc, cam, w, h, **ov); o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
     assert_equal(pt, o)
+    p3 = gpu_render(sc, cam, w, h, counters=False, **ov)     # plain (non-counting) build
+    assert_equal(p3, o, counters=False); p3.Dispose()
     rays = _queries(20000, 17, 6.0)
     for any_hit in (False, True):
         assert pt.TraceRays(rays, any_hit=any_hit).tobytes() == oracle_mod.trace_rays(sc, rays, any_hit=any_hit, use_tlas=bool(use_tlas)).tobytes()

@@ -46,6 +46,10 @@ def test_gpu_equals_oracle(name, mk_scene, mk_cam, w, h, ov, oracle_mod, native_
     sc = mk_scene(native_builder); cam = mk_cam(w, h)
     pt = gpu_render(sc, cam, w, h, **ov); o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
     assert_equal(pt, o, aov=bool(ov.get("OutputAOVs")))
+    pt.Dispose()
+    # the same frame with the non-counting build of the traversal kernel (the one the bench times): everything but the counters must be identical
+    pt = gpu_render(sc, cam, w, h, counters=False, **ov)
+    assert_equal(pt, o, aov=bool(ov.get("OutputAOVs")), counters=False)
     pt.Dispose(); o.close()
 
 

@@ -9,19 +9,9 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 sys.path.insert(0, HERE)
 import configs  # noqa: E402,F401
 from idkengine_amd import scenes as S  # noqa: E402,F401
-from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402,F401
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal, _queries  # noqa: E402,F401
 
 pytestmark = pytest.mark.gpu
-
-
-def _queries(n, seed, extent, max_dist=3.4028235e+38):
-    from idkengine_amd import gputypes as T
-    rng = np.random.default_rng(seed)
-    r = np.zeros(n, T.RayQuery)
-    r["Origin"] = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
-    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
-    r["Direction"] = d.astype(np.float32); r["MaxDist"] = max_dist
-    return r
 
 
 @pytest.mark.parametrize("use_tlas", [0, 1])
