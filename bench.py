@@ -1,22 +1,35 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark of the MI355X-native wavefront path tracer (driver contract: see task statement).
 
-Metric (BASELINE.json): Mray/s (primary + 1 bounce) at 1920x1080 on the synthetic 1M-triangle SweepSAH scene.
+Metric (BASELINE.json): Mray/s (primary + 1 bounce) at 1920x1080 on the synthetic 1M-triangle SweepSAH scene (configs[2]).
   step      = one pass of the hot path over the whole frame: FirstHit -> NHit -> FinalDraw at 1 spp, RayDepth 2
               (PathTracer.Compute, Source/Render/PathTracer.cs:214-271), scene and BVH already resident in HBM.
               Steps accumulate progressively like the reference's render loop (AccumulatedSamples 0,1,2,...); after every
               `samples_in_flight` steps the displayed frame is complete: its row shards are exchanged (N > 1) and the
               accumulation is reset (PathTracer.ResetAccumulation), so every sample that is traced ends up in an exchanged image.
-  value     = (N + sum_j A_j) rays of all ranks / wall time (max over ranks), exact integer ray counts from the GPU queues.
+  value     = (N + sum_j A_j) rays of all ranks / wall time of the timed region (max over ranks), exact integer ray counts from the
+              GPU queues.  The region (exactly --steps steps between barrier + synchronize) is repeated --repeats times; the MEDIAN
+              repetition is reported (`ms_per_step` x `steps` = that repetition), all repetitions are listed under "repeat_ms".
+  honesty   = the same line carries `traversed_mray_s` (only the rays that enter the BVH traversal kernel: the pre-cull answers the
+              others from the root box), `single_frame` (one frame at a time with a synchronisation per frame, SURVEY 8(d)'s
+              protocol: what a host sees that cannot keep 32 samples in flight) and `interior` (camera inside the soup: every pixel
+              traverses — the stand-in for a Sponza-class view).
   N GPUs    = image rows dealt round-robin to the ranks (idkengine_amd/dist.py); the only exchange is the RCCL all-gather of
               the finished row shards, inside the timed region.  Total work per step is fixed -> "strong" scaling.
-  roofline  = traversal kernel (k_trace2): algorithmic bytes (64*P + 52*T + 104 per traversed ray) / HIP-event time of
-              its launches during the timed region, against 8 TB/s HBM.
-  cpu_baseline = the oracle's CPU port of the same path (all host cores, OpenMP) on a bounded sample of the same frame.
+              `python bench.py --gpus N` without a launcher starts its own ranks (torch.distributed.run, 127.0.0.1).
+  roofline  = traversal kernel (k_trace2).  achieved = algorithmic bytes (64 B per node-pair visit + 48 B per triangle test + 72 B per
+              traversed ray, exact visit counts from the counting build) / HIP-event time of its launches in the timed region.
+              The working set (110 MB) lives in L2 + Infinity Cache, so HBM is not what binds (hbm.* below: the algorithmic rate
+              exceeds 8 TB/s, the counters show 1-2 TB/s); the resource that binds is the vector-memory path's rate of independent
+              64-B block fetches, so peak = that rate measured on this very box by tools/ubench_lines (4 x 16-B loads per lane to its
+              own random 64-B block, L2-resident set, 32 waves/CU), in the same unit.
+  cpu_baseline = the oracle's CPU port of the same path (all host cores, OpenMP), scene and threads kept warm, on a bounded sample.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,17 +40,36 @@ W, H = 1920, 1080
 N_TRIS = 1_000_000
 RAY_DEPTH = 2
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-STATE_BYTES_PER_TRAVERSED_RAY = 104  # 48 B ray fetch + 4 B index + 20 B hit record + 32 B root node (DESIGN.md "Roofline")
+NODE_PAIR_BYTES, TRI_BYTES, RAY_BYTES = 64, 48, 72     # node pair; triVerts entry; 48 B ray record + 4 B list entry + 20 B hit record
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same flags>`."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
+def view_camera(S, view, w, h):
+    if view == "interior":
+        return S.Camera(w, h, position=(0.0, 0.0, 0.0))       # inside the soup ([-10,10]^3): every primary ray enters the traversal
+    return S.Camera(w, h)                                     # SURVEY 8(d) config 3: z = 25, looking at the soup, FovY 102
 
 
 def main():
     global W, H
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--repeats", type=int, default=7, help="the timed region of --steps steps is repeated this often; the median repetition is reported")
     ap.add_argument("--tris", type=int, default=N_TRIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-frame and interior-view measurements")
+    ap.add_argument("--view", choices=["headline", "interior"], default="headline", help="headline = BASELINE.json configs[2]; interior = camera inside the soup (secondary)")
     ap.add_argument("--depth", type=int, default=RAY_DEPTH, help="RayDepth (headline = 2); other values are secondary-table runs")
     ap.add_argument("--sort", type=int, default=0, help="DoRaySorting (headline = 0)")
     ap.add_argument("--width", type=int, default=W, help="secondary-table runs only (headline = 1920)")
@@ -47,18 +79,18 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 256")
     args = ap.parse_args()
 
-    import numpy as np
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        self_launch(args)                                # does not return
+
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     from idkengine_amd import scenes as S
     from idkengine_amd.bvh import NativeBuilder
     from idkengine_amd import dist as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.batch = max(1, min(256, args.batch * world))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
     # developer smoke test of the N > 1 flow on a single-GPU box: IDKPT_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and uses gloo
@@ -82,7 +114,7 @@ def main():
     if world > 1:
         scene = D.broadcast_scene(scene, src=0, device=device)
     W, H = args.width, args.height
-    cam = S.Camera(W, H)
+    cam = view_camera(S, args.view, W, H)
 
     control = dist.new_group(backend="gloo") if (world > 1 and args.exact_deep_paths) else None   # CPU-side group for the tiny count exchange
     r = D.GpuShardRenderer(W, H, world, rank, local_rank, exact_deep_paths=bool(control), control_group=control)
@@ -111,16 +143,9 @@ def main():
 
     # ---- untimed counter pass over one displayed frame (B samples, one at a time): exact cumulative P (node-pair visits),
     #      T (triangle tests), traversed rays and traced rays after each sample index of this rank's rows
-    pt.enable_counters(True); pt.reset_stats(); pt.ResetAccumulation()
-    cum = [(0, 0, 0, 0)]
-    for _ in range(B):
-        pt.Compute(); pt.synchronize()
-        cs = pt.stats()
-        trav = cs["alive_counts"][0] + sum(cs["alive_counts"][1:depth])   # rays of this sample that entered the traversal kernel
-        cum.append((cs["node_pair_visits"], cs["triangle_tests"], cum[-1][2] + trav, cs["rays_traced"]))
-    pt.enable_counters(False)
+    cum = counter_pass(pt, B, depth)
     q, rem = divmod(args.steps, B)
-    pairs, tri_tests, traversed, rays_expected = (q * cum[B][i] + cum[rem][i] for i in range(4))
+    pairs, tri_tests, traversed, rays_expected = (q * cum[B][i] + cum[rem][i] for i in range(4))   # per repetition
 
     pt.set_max_batch(B)
     step_no[0] = 0
@@ -129,66 +154,181 @@ def main():
     if step_no[0] % B:
         finish_frame()
     pt.synchronize(); pt.reset_stats(); pt.enable_timing(True)
-    step_no[0] = 0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if step_no[0] % B:
-        finish_frame()                               # the last, partial displayed frame is exchanged too
-    pt.synchronize()                                 # launches whatever is still deferred and waits for it
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    repeat_s, rays_rank = [], 0
+    for _rep in range(max(1, args.repeats)):
+        step_no[0] = 0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if step_no[0] % B:
+            finish_frame()                               # the last, partial displayed frame is exchanged too
+        pt.synchronize()                                 # launches whatever is still deferred and waits for it
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        repeat_s.append(tmax.item())
     st = pt.stats()
     pt.enable_timing(False)
-
-    rays_total = torch.tensor([float(st["rays_traced"])], dtype=torch.float64, device=device)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    reps = len(repeat_s)
+    assert st["rays_traced"] == rays_expected * reps, (st["rays_traced"], rays_expected, reps)  # every step traced its complete sample (exact ray count)
+    rays_total = torch.tensor([float(rays_expected), float(traversed)], dtype=torch.float64, device=device)   # per repetition, this rank
     if world > 1:
         dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    rays_total = rays_total.item(); dt = tmax.item()
-    assert st["rays_traced"] == rays_expected, (st["rays_traced"], rays_expected, args.steps)  # every step traced its complete sample (exact ray count)
+    rays_rep, traversed_rep = rays_total.tolist()
+    dt = statistics.median(repeat_s)
 
     if rank == 0:
-        value = rays_total / dt / 1e6
-        # roofline of the traversal kernel (both instantiations of k_trace2: primary + bounce), this rank
-        alg_bytes_total = 64.0 * pairs + 52.0 * tri_tests + STATE_BYTES_PER_TRAVERSED_RAY * traversed   # over all timed steps
-        launches = max(1, st["trace_launches"])
-        alg_bytes_launch = alg_bytes_total / launches
-        avg_launch_s = st["trace_ms_total"] * 1e-3 / launches
-        achieved = alg_bytes_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from the committed PMC summary of this same command
-        headline = (args.tris, depth, args.sort, W, H, args.batch) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world))
-        if os.path.exists(prof) and headline:        # the PMC pass was taken on the headline command only
-            try:
-                traffic = json.load(open(prof)).get(f"n{world}", {}).get("traversal_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        value = rays_rep / dt / 1e6
+        headline = (args.tris, depth, args.sort, W, H, args.batch, args.view) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world), "headline")
+        view_txt = "camera at z = 25 outside the soup (SURVEY 8d config 3)" if args.view == "headline" else "camera INSIDE the soup at the origin"
         out = {
-            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri scene (secondary config)", "value": round(value, 2), "unit": "Mray/s",
+            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri scene, {args.view} view (secondary config)", "value": round(value, 2), "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky",
-                       "rays_per_step": int(rays_total / args.steps), "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather") if world > 1 else "none",
+            "repeats": reps, "repeat_ms": [round(x * 1e3, 3) for x in repeat_s], "statistic": "median repetition of the timed region",
+            "traversed_mray_s": round(traversed_rep / dt / 1e6, 2),
+            "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, {view_txt}",
+                       "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
+                       "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather") if world > 1 else "none",
                        "bvh_build_s": round(build_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": int(launches),
-                         "node_pair_visits_per_step": int(pairs / args.steps), "triangle_tests_per_step": int(tri_tests / args.steps), "traversed_rays_per_step": int(traversed / args.steps),
-                         "hbm_copy_measured_gbs": hbm_copy_gbs(torch, device)},
+            "roofline": roofline(st, pairs * reps, tri_tests * reps, traversed * reps, args, world, B if rem == 0 else (rem if q == 0 else None), torch, device),
         }
+        if world == 1 and not args.no_extras:
+            out["single_frame"] = single_frame(pt, depth)
+            out["interior"] = interior_extras(S, pt, W, H, B)
+            pt.SetCamera(cam); pt.RayDepth = depth; pt.set_max_batch(B)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cam, depth)
+            out["cpu_baseline"] = cpu_baseline(S, scene, depth, args.view)
         print(json.dumps(out), flush=True)
     r.pt.Dispose()
     if world > 1:
         dist.destroy_process_group()
+
+
+def counter_pass(pt, B, depth):
+    """B samples one at a time on the counting build: cumulative (node-pair visits, triangle tests, traversed rays, traced rays)."""
+    pt.set_max_batch(1)
+    pt.enable_counters(True); pt.reset_stats(); pt.ResetAccumulation()
+    cum = [(0, 0, 0, 0)]
+    for _ in range(B):
+        pt.Compute(); pt.synchronize()
+        cs = pt.stats()
+        trav = cs["alive_counts"][0] + sum(cs["alive_counts"][1:depth])   # rays of this sample that entered the traversal kernel
+        cum.append((cs["node_pair_visits"], cs["triangle_tests"], cum[-1][2] + trav, cs["rays_traced"]))
+    pt.enable_counters(False)
+    return cum
+
+
+def gather_ceiling(set_log2_blocks=16):
+    """The chip's rate of independent 64-B block fetches (tools/ubench_lines mode 0: every lane loads 4 x 16 B of its own random 64-B
+    block = the node-pair fetch; 2^16 blocks = 4 MB set = L2 hits, 32 waves/CU), measured now, on this box.  GB/s of 64-B blocks."""
+    exe = os.path.join(ROOT, "tools", "ubench_lines.bin")
+    try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", os.path.join(ROOT, "tools", "ubench_lines.hip"), "-o", exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        txt = subprocess.run([exe, str(set_log2_blocks), "0", "32"], capture_output=True, text=True, timeout=120).stdout
+        for line in txt.splitlines():
+            if line.startswith("RESULT"):
+                kv = dict(p.split("=") for p in line.split()[1:])
+                return float(kv["gbs"])
+    except Exception:
+        pass
+    return None
+
+
+def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, torch, device):
+    """Traversal kernel (both instantiations of k_trace2: primary + bounce), this rank, over all timed repetitions."""
+    alg_bytes_total = float(NODE_PAIR_BYTES) * pairs + float(TRI_BYTES) * tri_tests + float(RAY_BYTES) * traversed
+    launches = max(1, st["trace_launches"])
+    alg_bytes_launch = alg_bytes_total / launches
+    avg_launch_s = st["trace_ms_total"] * 1e-3 / launches
+    achieved = alg_bytes_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    peak_hit = gather_ceiling(16)           # L2-resident set: the hardware ceiling of this access pattern
+    peak_miss = gather_ceiling(21)          # 128 MB set (the scene's working-set size): every block misses L2, served by Infinity Cache
+    # HBM-side bytes per launch from the committed PMC passes of this command (profiles/r02_traffic.json, keyed by view and samples per launch)
+    traffic, l2_hit, l1_miss, l2_miss = None, None, None, None
+    prof = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if os.path.exists(prof) and (args.tris, args.depth, args.sort, args.width, args.height) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080):
+        try:
+            e = json.load(open(prof)).get(f"n{world}", {}).get(args.view, {}).get(f"s{samples_per_launch}")
+            if e:
+                traffic, l2_hit, l1_miss, l2_miss = e.get("traversal_hbm_bytes_per_launch"), e.get("l2_hit_rate"), e.get("l1_miss_requests_per_launch"), e.get("l2_miss_requests_per_launch")
+        except Exception:
+            pass
+    out = {"bound": "vmem-gather", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": peak_hit, "unit": "GB/s",
+           "frac": round(achieved / peak_hit, 4) if peak_hit else None, "traffic": traffic,
+           "peak_source": "tools/ubench_lines.bin 16 0 32, run by this bench: independent random 64-B block fetches (4 x 16-B loads per lane), 4 MB set (L2 hits), 32 waves/CU",
+           "peak_l2_miss_set": peak_miss, "l2_hit_rate_pmc": l2_hit,
+           "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": int(launches), "samples_per_launch": samples_per_launch,
+           "node_pair_visits_per_step": int(pairs / max(1, args.steps * max(1, args.repeats))), "triangle_tests_per_step": int(tri_tests / max(1, args.steps * max(1, args.repeats))),
+           "hbm": {"peak": HBM_PEAK_GBS, "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 4), "counter_gbs": round(traffic / avg_launch_s / 1e9, 1) if traffic else None,
+                   "counter_frac": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None, "copy_measured_gbs": hbm_copy_gbs(torch, device),
+                   "note": "working set (110 MB of nodes + triangles) is L2 / Infinity-Cache resident: HBM does not bind this kernel"}}
+    if peak_hit and peak_miss and l1_miss and l2_miss is not None and avg_launch_s > 0:
+        # counter view of the same bound: the L1 misses of a launch (TCP_TCC_READ_REQ, 64-B blocks), each priced at the measured fetch rate of
+        # where it was served from (L2 hit: peak; L2 miss: peak_l2_miss_set), as a fraction of the launch time.  ~1 = the fill path is saturated.
+        fill_s = (l1_miss - l2_miss) * 64.0 / (peak_hit * 1e9) + l2_miss * 64.0 / (peak_miss * 1e9)
+        out["pmc"] = {"l1_miss_requests_per_launch": l1_miss, "l2_miss_requests_per_launch": l2_miss, "fill_time_frac": round(fill_s / avg_launch_s, 4),
+                      "source": "profiles/r02_traffic.json (rocprofv3 --pmc passes of this command), priced with the two ceilings measured by this run"}
+    return out
+
+
+def single_frame(pt, depth, frames=40):
+    """SURVEY 8(d) protocol: one frame at a time — ResetAccumulation, Compute, wait for it — nothing deferred, nothing batched."""
+    pt.set_max_batch(1)
+    for _ in range(5):
+        pt.ResetAccumulation(); pt.Compute(); pt.synchronize()
+    pt.reset_stats()
+    ts = []
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        pt.ResetAccumulation(); pt.Compute(); pt.synchronize()
+        ts.append(time.perf_counter() - t0)
+    st = pt.stats()
+    rays = st["rays_traced"] / frames
+    trav = st["alive_counts"][0] + sum(st["alive_counts"][1:depth])
+    med = statistics.median(ts)
+    return {"mray_s": round(rays / med / 1e6, 1), "ms_per_frame": round(med * 1e3, 4), "traversed_mray_s": round(trav / med / 1e6, 1), "frames": frames,
+            "protocol": "idkptSetMaxBatch(1); per frame: ResetAccumulation, Compute, Synchronize; median frame"}
+
+
+def timed_batch(pt, B, steps, reps=5):
+    pt.set_max_batch(B)
+    for _ in range(B):
+        pt.Compute()
+    pt.synchronize(); pt.reset_stats()
+    ts = []
+    for _ in range(reps):
+        pt.ResetAccumulation()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pt.Compute()
+        pt.synchronize()
+        ts.append(time.perf_counter() - t0)
+    st = pt.stats()
+    return st["rays_traced"] / reps, statistics.median(ts)
+
+
+def interior_extras(S, pt, w, h, B):
+    """Secondary workload: camera inside the soup, every pixel traverses (>= 95 % of the primary rays hit).  Same library calls."""
+    out = {"workload": "soup-1M interior: camera at the origin inside the soup, 1920x1080, sort off"}
+    pt.SetCamera(view_camera(S, "interior", w, h))
+    for depth in (2, 5):
+        pt.RayDepth = depth
+        rays, dt = timed_batch(pt, B, 2 * B)
+        st = pt.stats()
+        out[f"depth{depth}"] = {"mray_s": round(rays / dt / 1e6, 1), "ms_per_step": round(dt / (2 * B) * 1e3, 4), "rays_per_step": int(rays / (2 * B)), "samples_in_flight": B,
+                                "primary_hit_fraction": round(st["alive_counts"][1] / float(w * h), 4) if depth > 1 else None}
+        if depth == 2:
+            out["depth2"]["single_frame"] = single_frame(pt, depth, frames=20)
+    return out
 
 
 def interactive(args, r, frame, pt, world, rank, device, scene, build_s, dist, torch, S):
@@ -251,36 +391,59 @@ def hbm_copy_gbs(torch, device):
     return round(2.0 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
-def cpu_baseline(scene, cam, depth):
-    """The oracle (CPU port of the reference path, GLSL semantics, OpenMP over all host cores) on a bounded sample of the
-    same frame: every m-th row, m chosen so the run takes roughly 10-30 s."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(S, scene, depth, view):
+    """The oracle (CPU port of the reference path, GLSL semantics, OpenMP over all host cores) on a bounded sample of the same frame:
+    every m-th row, m chosen so the run takes roughly 10-20 s; scene, buffers and thread pool are created once and kept warm.
+    `value` is the whole path; `parallel_section` times only the per-invocation sections (FirstHit / NHit / FinalDraw loops, what
+    the GPU kernels replace) without the serial queue compaction in between."""
     from oracle import oracle as O   # allowed here: cpu_baseline leg only
     cores = os.cpu_count() or 1
 
-    def run(mod):
-        o = O.OraclePathTracer(scene, W, H, row_modulo=mod, row_remainder=0)
-        o.set_camera(cam); o.settings.RayDepth = depth
-        t0 = time.perf_counter(); o.render(); dt = time.perf_counter() - t0
-        rays = o.stats()["rays_traced"]; rows = o.rows
+    def measure(cam, budget_s):
+        probe = O.OraclePathTracer(scene, W, H, row_modulo=32, row_remainder=0); probe.set_camera(cam); probe.settings.RayDepth = depth
+        probe.render(); probe.timing()                      # warm-up (thread pool, page faults)
+        t0 = time.perf_counter(); probe.render(); dt = time.perf_counter() - t0
+        probe.close()
+        full_est = dt * 32
+        mod = 1 if full_est <= 2.0 else max(1, int(full_est / 2.0 + 0.999))       # one repetition ~ <= 2 s
+        o = O.OraclePathTracer(scene, W, H, row_modulo=mod, row_remainder=0); o.set_camera(cam); o.settings.RayDepth = depth
+        o.render(); o.timing(); r0 = o.stats()["rays_traced"]                     # warm-up of this instance
+        tot_dt, reps = 0.0, 0
+        while tot_dt < budget_s and reps < 400:
+            t0 = time.perf_counter(); o.render(); tot_dt += time.perf_counter() - t0; reps += 1
+        par_s, _ = o.timing()
+        rays = o.stats()["rays_traced"] - r0; rows = o.rows
         o.close()
-        return rays, dt, rows
-    rays, dt, rows = run(32)                       # probe: 34 rows
-    full_est = dt * 32
-    mod = 1 if full_est <= 30.0 else max(1, int(full_est / 20.0 + 0.999))
-    # bounded sample of ~10-30 s: the row subset is repeated until at least 10 s of CPU work have been timed
-    tot_rays, tot_dt, reps = 0, 0.0, 0
-    while tot_dt < 10.0 and reps < 400:
-        rays, dt, rows = run(mod)
-        tot_rays += rays; tot_dt += dt; reps += 1
+        return {"value": round(rays / tot_dt / 1e6, 3), "parallel_section": round(rays / par_s / 1e6, 3), "per_core": round(rays / par_s / 1e6 / cores, 4),
+                "sample": f"rows y%{mod}==0 of the {W}x{H} frame ({rows} rows, RayDepth {depth}) x {reps} repetitions = {tot_dt:.1f} s of CPU work ({par_s:.1f} s inside the OpenMP sections)"}
+
+    head = measure(view_camera(S, view, W, H), 10.0)
     # the reference's own CPU path (C# semantics: Gui.Test -> BVH.Intersect -> BLAS.Intersect, Render/Gui.cs:1484-1503): primary rays only
+    cam = view_camera(S, view, W, H)
+    O.cpu_trace_primary(scene, cam, W, H, want_hits=False)
     p_rays, p_dt = 0, 0.0
     while p_dt < 3.0:
-        t0 = time.perf_counter(); r = O.cpu_trace_primary(scene, cam, W, H, want_hits=False); p_dt += time.perf_counter() - t0
-        p_rays += int(r["rays"])
-    return {"value": round(tot_rays / tot_dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
-            "primary_only_csharp_semantics": {"value": round(p_rays / p_dt / 1e6, 3), "unit": "Mray/s", "sample": f"{p_rays // (W * H)} full {W}x{H} frames of centre-of-pixel primary rays, closest hit only (no shading), {p_dt:.1f} s"},
-            "sample": f"rows y%{mod}==0 of the same {W}x{H} frame ({rows} rows, {rays} rays, RayDepth {depth}) x {reps} repetitions = {tot_dt:.1f} s of CPU work; "
-                      "C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET)"}
+        t0 = time.perf_counter(); rr = O.cpu_trace_primary(scene, cam, W, H, want_hits=False); p_dt += time.perf_counter() - t0
+        p_rays += int(rr["rays"])
+    out = {"value": head["value"], "unit": "Mray/s", "cores": cores, "cpu": cpu_model(), "kind": "port", "parallel_section_mray_s": head["parallel_section"],
+           "mray_s_per_core": head["per_core"], "sample": head["sample"] + "; C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET); scene and threads warm",
+           "primary_only_csharp_semantics": {"value": round(p_rays / p_dt / 1e6, 3), "unit": "Mray/s", "per_core": round(p_rays / p_dt / 1e6 / cores, 4),
+                                             "sample": f"{p_rays // (W * H)} full {W}x{H} frames of centre-of-pixel primary rays, closest hit only (no shading), {p_dt:.1f} s"},
+           "note": "a reported baseline, not the target: the GPU/CPU ratio says nothing about kernel quality (roofline.frac does)"}
+    if view == "headline":
+        inter = measure(view_camera(S, "interior", W, H), 6.0)
+        out["interior_view"] = {"value": inter["value"], "parallel_section_mray_s": inter["parallel_section"], "mray_s_per_core": inter["per_core"], "sample": inter["sample"]}
+    return out
 
 
 if __name__ == "__main__":

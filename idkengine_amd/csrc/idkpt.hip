@@ -36,7 +36,7 @@ struct DevBuf {
 
 struct PendingSample { uint32_t accum; int slot; float cam[36]; };   // cam = invProj[16] invView[16] viewPos[3] pad
 
-struct idkpt_ctx {
+struct dev_ctx {
     int device = 0;
     hipStream_t stream = nullptr; bool ownStream = true;
     std::string lastError;
@@ -79,13 +79,13 @@ struct idkpt_ctx {
     float* hCams = nullptr; hipEvent_t evCams[2] = {nullptr, nullptr}; int camHalf = 0;   // pinned, double-buffered staging of the per-sample cameras (frame ring)
 };
 
-static hipEvent_t next_event(idkpt_ctx* ctx)
+static hipEvent_t next_event(dev_ctx* ctx)
 {
     if (ctx->evUsed == ctx->evPool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ctx->evPool.push_back(e); }
     return ctx->evPool[ctx->evUsed++];
 }
 // folds all recorded (start, stop) pairs into the accumulators; requires the stream to be idle
-static void resolve_trace_events(idkpt_ctx* ctx)
+static void resolve_trace_events(dev_ctx* ctx)
 {
     for (size_t i = 0; i + 1 < ctx->evUsed; i += 2) { float ms = 0.0f; if (hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]) == hipSuccess) { ctx->traceMsAcc += ms; ctx->traceLaunchesAcc++; } }
     ctx->evUsed = 0;
@@ -93,7 +93,7 @@ static void resolve_trace_events(idkpt_ctx* ctx)
 #define TRACE_T0() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
 #define TRACE_T1() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
 
-static int fail(idkpt_ctx* c, int code, const std::string& msg) { if (c) c->lastError = msg; return code; }
+static int fail(dev_ctx* c, int code, const std::string& msg) { if (c) c->lastError = msg; return code; }
 // (a failed runtime call leaves its code in the thread's last-error slot: reset it, or the next hipGetLastError() check would report it again)
 #define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
 #define REQUIRE(cond, msg) do { if (!(cond)) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
@@ -101,7 +101,7 @@ static int fail(idkpt_ctx* c, int code, const std::string& msg) { if (c) c->last
 static int local_rows(int H, int mod, int rem) { int n = 0; for (int y = rem; y < H; y += mod) n++; return n; }
 
 template <bool PRIMARY>
-static void launch_trace2(idkpt_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
+static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
                           const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters)
 {
     if (f.useTlas) {                // TLAS walk inside the kernel
@@ -122,7 +122,7 @@ static void launch_trace2(idkpt_ctx* ctx, uint32_t grid, size_t lds, hipStream_t
     }
 }
 
-static int alloc_frame_impl(idkpt_ctx* ctx)
+static int alloc_frame_impl(dev_ctx* ctx)
 {
     const size_t N = (size_t)ctx->W * ctx->rows;
     ctx->Npad = (uint32_t)((N + 63) / 64 * 64);
@@ -151,10 +151,10 @@ static int alloc_frame_impl(idkpt_ctx* ctx)
 }
 
 // a failed allocation leaves the context without a usable frame (idkptRender refuses) until a later idkptSetSize / idkptSetMaxBatch succeeds
-static int alloc_frame(idkpt_ctx* ctx) { int rc = alloc_frame_impl(ctx); ctx->frameOk = rc == IDKPT_OK; return rc; }
+static int alloc_frame(dev_ctx* ctx) { int rc = alloc_frame_impl(ctx); ctx->frameOk = rc == IDKPT_OK; return rc; }
 
 // maxBatch changed: the wavefront buffers grow, the accumulation images (and their contents) stay
-static int alloc_frame_keep_images(idkpt_ctx* ctx)
+static int alloc_frame_keep_images(dev_ctx* ctx)
 {
     const size_t N = (size_t)ctx->W * ctx->rows;
     DevBuf saved[3];
@@ -171,11 +171,11 @@ static int alloc_frame_keep_images(idkpt_ctx* ctx)
     return rc;
 }
 
-static int flush_batch(idkpt_ctx* ctx);
+static int flush_batch(dev_ctx* ctx);
 // After a stream synchronisation: did any traversal drop a stack push?  (Cannot happen for scenes that passed idkptUploadScene's
 // validation with BlasStackSize >= the computed need; the flag is the safety net for buffers patched later with idkptUpdateBuffer
 // and for device-built TLASes deeper than TLAS_STACK_SIZE.)  The results of the affected batch are invalid: report, never return them silently.
-static int check_overflow(idkpt_ctx* ctx)
+static int check_overflow(dev_ctx* ctx)
 {
     if (!ctx->hOverflow || *(volatile uint32_t*)ctx->hOverflow == 0u) return IDKPT_OK;
     *(volatile uint32_t*)ctx->hOverflow = 0u;
@@ -214,18 +214,18 @@ static int tlas_validate(const GpuTlasNode* nodes, int nodeCount, int instanceCo
     return need[0];
 }
 
-extern "C" {
+// ---- single-device implementation of the C-ABI (dev_*); the exported entry points and the multi-device group layer are in idkpt_api.hpp
 
-const char* idkptGetVersionString(void) { return "idkpt 0.1 (gfx950)"; }
+static const char* dev_GetVersionString(void) { return "idkpt 0.1 (gfx950)"; }
 
-int32_t idkptGetDeviceCount(int32_t* outCount)
+static int32_t dev_GetDeviceCount(int32_t* outCount)
 {
     int n = 0; hipError_t e = hipGetDeviceCount(&n);
     if (outCount) *outCount = (e == hipSuccess) ? n : 0;
     return e == hipSuccess ? IDKPT_OK : IDKPT_ERR_NO_DEVICE;
 }
 
-int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** outCtx)
+static int32_t dev_Create(int32_t deviceCount, const int32_t* deviceIds, dev_ctx** outCtx)
 {
     if (!outCtx) return IDKPT_ERR_INVALID_ARGUMENT;
     *outCtx = nullptr;
@@ -235,7 +235,7 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
     int dev = deviceIds ? deviceIds[0] : 0;
     if (dev < 0 || dev >= n) return IDKPT_ERR_INVALID_ARGUMENT;
     if (hipSetDevice(dev) != hipSuccess) return IDKPT_ERR_HIP;
-    idkpt_ctx* ctx = new idkpt_ctx();
+    dev_ctx* ctx = new dev_ctx();
     ctx->device = dev;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->numCUs = prop.multiProcessorCount;
@@ -259,7 +259,7 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
     return IDKPT_OK;
 }
 
-int32_t idkptDestroy(idkpt_ctx* ctx)
+static int32_t dev_Destroy(dev_ctx* ctx)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(ctx->device);
@@ -284,14 +284,14 @@ int32_t idkptDestroy(idkpt_ctx* ctx)
     return IDKPT_OK;
 }
 
-int32_t idkptGetLastError(idkpt_ctx* ctx, const char** outMessage)
+static int32_t dev_GetLastError(dev_ctx* ctx, const char** outMessage)
 {
     if (!ctx || !outMessage) return IDKPT_ERR_INVALID_ARGUMENT;
     *outMessage = ctx->lastError.c_str();
     return IDKPT_OK;
 }
 
-int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height)
+static int32_t dev_SetSize(dev_ctx* ctx, int32_t width, int32_t height)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
@@ -303,7 +303,7 @@ int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height)
     return alloc_frame(ctx);
 }
 
-int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemainder)
+static int32_t dev_SetRowSharding(dev_ctx* ctx, int32_t rowModulo, int32_t rowRemainder)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(rowModulo >= 1 && rowRemainder >= 0 && rowRemainder < rowModulo, "idkptSetRowSharding: need 0 <= remainder < modulo");
@@ -314,7 +314,7 @@ int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemain
     return IDKPT_OK;
 }
 
-int32_t idkptSetRowRange(idkpt_ctx* ctx, int32_t firstRow, int32_t rowCount)
+static int32_t dev_SetRowRange(dev_ctx* ctx, int32_t firstRow, int32_t rowCount)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(firstRow >= 0 && rowCount >= 1, "idkptSetRowRange: need firstRow >= 0 and rowCount >= 1");
@@ -325,7 +325,7 @@ int32_t idkptSetRowRange(idkpt_ctx* ctx, int32_t firstRow, int32_t rowCount)
     return IDKPT_OK;
 }
 
-int32_t idkptSetBounceExchange(idkpt_ctx* ctx, idkpt_bounce_exchange_fn fn, void* user)
+static int32_t dev_SetBounceExchange(dev_ctx* ctx, idkpt_bounce_exchange_fn fn, void* user)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     FLUSH();
@@ -333,7 +333,7 @@ int32_t idkptSetBounceExchange(idkpt_ctx* ctx, idkpt_bounce_exchange_fn fn, void
     return IDKPT_OK;
 }
 
-int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* s)
+static int32_t dev_SetSettings(dev_ctx* ctx, const idkpt_settings* s)
 {
     if (!ctx || !s) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(s->RayDepth >= 1 && s->RayDepth < MAX_DEPTH_SLOTS - 1, "idkptSetSettings: RayDepth out of range");
@@ -353,9 +353,9 @@ int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* s)
     if (reset) std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
     return IDKPT_OK;
 }
-int32_t idkptGetSettings(idkpt_ctx* ctx, idkpt_settings* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->st; return IDKPT_OK; }
+static int32_t dev_GetSettings(dev_ctx* ctx, idkpt_settings* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->st; return IDKPT_OK; }
 
-int32_t idkptSetPerFrame(idkpt_ctx* ctx, const float invProjection[16], const float invView[16], const float viewPos[3])
+static int32_t dev_SetPerFrame(dev_ctx* ctx, const float invProjection[16], const float invView[16], const float viewPos[3])
 {
     if (!ctx || !invProjection || !invView || !viewPos) return IDKPT_ERR_INVALID_ARGUMENT;
     // one camera per batch unless a frame ring is active (then every queued sample carries its own camera)
@@ -363,9 +363,9 @@ int32_t idkptSetPerFrame(idkpt_ctx* ctx, const float invProjection[16], const fl
     memcpy(ctx->invProj, invProjection, 64); memcpy(ctx->invView, invView, 64); memcpy(ctx->viewPos, viewPos, 12);
     return IDKPT_OK;
 }
-int32_t idkptSetPerFrameData(idkpt_ctx* ctx, const GpuPerFrameData* p) { if (!ctx || !p) return IDKPT_ERR_INVALID_ARGUMENT; return idkptSetPerFrame(ctx, p->InvProjection, p->InvView, p->ViewPos); }
+static int32_t dev_SetPerFrameData(dev_ctx* ctx, const GpuPerFrameData* p) { if (!ctx || !p) return IDKPT_ERR_INVALID_ARGUMENT; return dev_SetPerFrame(ctx, p->InvProjection, p->InvView, p->ViewPos); }
 
-static int regather_triverts(idkpt_ctx* ctx, uint32_t first, uint32_t count)
+static int regather_triverts(dev_ctx* ctx, uint32_t first, uint32_t count)
 {
     if (count == 0) return IDKPT_OK;
     hipLaunchKernelGGL(k_gather_triverts, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, ctx->tris.as<uint4>(), ctx->positions.as<float>(), ctx->triVerts.as<float4>(), first, count);
@@ -373,7 +373,7 @@ static int regather_triverts(idkpt_ctx* ctx, uint32_t first, uint32_t count)
     return IDKPT_OK;
 }
 
-static int upload(idkpt_ctx* ctx, DevBuf& b, const void* src, size_t bytes)
+static int upload(dev_ctx* ctx, DevBuf& b, const void* src, size_t bytes)
 {
     HIPC(b.ensure(std::max<size_t>(bytes, 16)));
     if (bytes) HIPC(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -383,8 +383,8 @@ static int upload(idkpt_ctx* ctx, DevBuf& b, const void* src, size_t bytes)
 // The fast path stores nothing but a flag for pre-culled pixels of the most recent sample; this completes their ray state (origin,
 // direction, miss radiance) from the frame constants of that batch.  Must run while the scene the batch was rendered with is still
 // resident (the sky decides the miss radiance): called by idkptDownloadRays and before a new scene replaces the old one.
-static DScene make_dscene(idkpt_ctx* ctx);
-static int materialize_culled_rays(idkpt_ctx* ctx)
+static DScene make_dscene(dev_ctx* ctx);
+static int materialize_culled_rays(dev_ctx* ctx)
 {
     if (!ctx->lastNeedsRegen) return IDKPT_OK;
     const size_t N = (size_t)ctx->W * ctx->rows;
@@ -395,7 +395,7 @@ static int materialize_culled_rays(idkpt_ctx* ctx)
     return IDKPT_OK;
 }
 
-int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
+static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
 {
     if (!ctx || !sc) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(sc->BlasNodes && sc->BlasNodeCount >= 4, "idkptUploadScene: BlasNodes missing");
@@ -491,7 +491,7 @@ int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* sc)
     return IDKPT_OK;
 }
 
-int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count)
+static int32_t dev_SetLightCount(dev_ctx* ctx, int32_t count)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(count >= 0 && count <= IDKPT_MAX_LIGHTS, "idkptSetLightCount: out of range");
@@ -499,7 +499,7 @@ int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count)
     ctx->lightCount = count; return IDKPT_OK;
 }
 
-static DevBuf* which_buffer(idkpt_ctx* ctx, int which, size_t* cap)
+static DevBuf* which_buffer(dev_ctx* ctx, int which, size_t* cap)
 {
     switch (which) {
         case IDKPT_BUF_MESH_TRANSFORMS: *cap = (size_t)ctx->xformCount * sizeof(GpuMeshTransform); return &ctx->xforms;
@@ -515,7 +515,7 @@ static DevBuf* which_buffer(idkpt_ctx* ctx, int which, size_t* cap)
     }
 }
 
-int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, const void* data)
+static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, const void* data)
 {
     if (!ctx || !data) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptUpdateBuffer: no scene uploaded");
@@ -531,7 +531,7 @@ int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, siz
     return IDKPT_OK;
 }
 
-int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst)
+static int32_t dev_DownloadBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst)
 {
     if (!ctx || !dst) return IDKPT_ERR_INVALID_ARGUMENT;
     size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
@@ -543,7 +543,7 @@ int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, s
     return IDKPT_OK;
 }
 
-int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCount)
+static int32_t dev_BuildTlas(dev_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCount)
 {
     if (!ctx || !nodes || nodeCount <= 0) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptBuildTlas: no scene uploaded");
@@ -559,7 +559,7 @@ int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCou
     return IDKPT_OK;
 }
 
-int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius)
+static int32_t dev_BuildTlasOnDevice(dev_ctx* ctx, int32_t searchRadius)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptBuildTlasOnDevice: no scene uploaded");
@@ -579,9 +579,9 @@ int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius)
     return IDKPT_OK;
 }
 
-static DScene make_dscene(idkpt_ctx* ctx);
+static DScene make_dscene(dev_ctx* ctx);
 // frame constants for the ray-query / shadow kernels: only the traversal-related fields are read
-static int query_frame(idkpt_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& grid)
+static int query_frame(dev_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& grid)
 {
     memset(&f, 0, sizeof(f));
     f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;
@@ -594,7 +594,7 @@ static int query_frame(idkpt_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& gri
     return IDKPT_OK;
 }
 
-int32_t idkptTraceRays(idkpt_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
+static int32_t dev_TraceRays(dev_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceRays: no scene uploaded");
@@ -622,7 +622,7 @@ int32_t idkptTraceRays(idkpt_ctx* ctx, const idkpt_ray* rays, size_t count, uint
     return IDKPT_OK;
 }
 
-int32_t idkptTraceShadows(idkpt_ctx* ctx, const idkpt_shadow_params* p, const float* depth, const float* normalOct, float* visibility)
+static int32_t dev_TraceShadows(dev_ctx* ctx, const idkpt_shadow_params* p, const float* depth, const float* normalOct, float* visibility)
 {
     if (!ctx || !p) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceShadows: no scene uploaded");
@@ -651,7 +651,7 @@ int32_t idkptTraceShadows(idkpt_ctx* ctx, const idkpt_shadow_params* p, const fl
     return IDKPT_OK;
 }
 
-int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId)
+static int32_t dev_RefitBlas(dev_ctx* ctx, int32_t blasId)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRefitBlas: no scene uploaded");
@@ -673,7 +673,7 @@ int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId)
     return IDKPT_OK;
 }
 
-int32_t idkptUploadUnskinnedVertices(idkpt_ctx* ctx, const GpuUnskinnedVertex* verts, int32_t count)
+static int32_t dev_UploadUnskinnedVertices(dev_ctx* ctx, const GpuUnskinnedVertex* verts, int32_t count)
 {
     if (!ctx || !verts || count <= 0) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
@@ -683,7 +683,7 @@ int32_t idkptUploadUnskinnedVertices(idkpt_ctx* ctx, const GpuUnskinnedVertex* v
     return IDKPT_OK;
 }
 
-int32_t idkptSkin(idkpt_ctx* ctx, uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count)
+static int32_t dev_Skin(dev_ctx* ctx, uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene || ctx->unskinnedCount == 0 || ctx->joints.bytes == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptSkin: needs scene, unskinned vertices and joint matrices");
@@ -697,10 +697,10 @@ int32_t idkptSkin(idkpt_ctx* ctx, uint32_t inOff, uint32_t outOff, uint32_t join
     return IDKPT_OK;
 }
 
-int32_t idkptResetAccumulation(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->accum[ctx->curSlot] = 0; return IDKPT_OK; }
-int32_t idkptGetAccumulatedSamples(idkpt_ctx* ctx, uint32_t* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->accum[ctx->curSlot]; return IDKPT_OK; }
+static int32_t dev_ResetAccumulation(dev_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->accum[ctx->curSlot] = 0; return IDKPT_OK; }
+static int32_t dev_GetAccumulatedSamples(dev_ctx* ctx, uint32_t* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->accum[ctx->curSlot]; return IDKPT_OK; }
 
-static DScene make_dscene(idkpt_ctx* ctx)
+static DScene make_dscene(dev_ctx* ctx)
 {
     DScene s;
     s.nodes = ctx->nodes.as<float4>(); s.tris = ctx->tris.as<uint4>(); s.triVerts = ctx->triVerts.as<float4>();
@@ -713,16 +713,16 @@ static DScene make_dscene(idkpt_ctx* ctx)
     return s;
 }
 
-static float4* image_ptr(idkpt_ctx* ctx, int i, int slot) { return ctx->img[i].as<float4>() + (size_t)slot * ((size_t)ctx->W * ctx->rows); }
+static float4* image_ptr(dev_ctx* ctx, int i, int slot) { return ctx->img[i].as<float4>() + (size_t)slot * ((size_t)ctx->W * ctx->rows); }
 
 // fast path = persistent while-while traversal (one BLAS, instance list or TLAS); only the debug traversal-cost view uses the general kernel
-static bool fast_path(idkpt_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
+static bool fast_path(dev_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
 
 // One batch of B deferred samples: FirstHit -> [sort ->] NHit x (RayDepth-1) -> FinalDraw (PathTracer.cs:218-270), every
 // stage launched once for all B samples.  Sample k owns ray ids [k*Npad, k*Npad+N); alive queues are batch-wide but stay
 // grouped by sample (stable compaction / sort with the sample index above the key), and every ray's NHit slot is its
 // position inside its own sample's queue, so each sample gets exactly the RNG streams of a stand-alone frame.
-static int flush_batch(idkpt_ctx* ctx)
+static int flush_batch(dev_ctx* ctx)
 {
     const int B = (int)ctx->pending.size();
     if (B == 0) return IDKPT_OK;
@@ -892,7 +892,7 @@ static int flush_batch(idkpt_ctx* ctx)
     return IDKPT_OK;
 }
 
-int32_t idkptRender(idkpt_ctx* ctx)
+static int32_t dev_Render(dev_ctx* ctx)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRender: no scene uploaded");
@@ -912,12 +912,12 @@ int32_t idkptRender(idkpt_ctx* ctx)
     return IDKPT_OK;
 }
 
-int32_t idkptSynchronize(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); SYNC_CHECKED(); return IDKPT_OK; }
+static int32_t dev_Synchronize(dev_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); SYNC_CHECKED(); return IDKPT_OK; }
 
 // Launches whatever is pending without waiting for it (lets a host overlap its own work with the GPU).
-int32_t idkptFlush(idkpt_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); return IDKPT_OK; }
+static int32_t dev_Flush(dev_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); return IDKPT_OK; }
 
-int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
+static int32_t dev_SetMaxBatch(dev_ctx* ctx, int32_t maxBatch)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..256");
@@ -941,7 +941,7 @@ int32_t idkptSetMaxBatch(idkpt_ctx* ctx, int32_t maxBatch)
     return IDKPT_OK;
 }
 
-int32_t idkptSetFrameRing(idkpt_ctx* ctx, int32_t frames)
+static int32_t dev_SetFrameRing(dev_ctx* ctx, int32_t frames)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(frames >= 1 && frames <= 128, "idkptSetFrameRing: 1..128 frames");
@@ -955,7 +955,7 @@ int32_t idkptSetFrameRing(idkpt_ctx* ctx, int32_t frames)
     return IDKPT_OK;
 }
 
-int32_t idkptBeginFrame(idkpt_ctx* ctx, int32_t* outSlot)
+static int32_t dev_BeginFrame(dev_ctx* ctx, int32_t* outSlot)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (ctx->ringStarted) ctx->curSlot = (ctx->curSlot + 1) % ctx->ringSize;   // the first frame after idkptSetFrameRing / idkptSetSize uses slot 0
@@ -965,7 +965,7 @@ int32_t idkptBeginFrame(idkpt_ctx* ctx, int32_t* outSlot)
     return IDKPT_OK;
 }
 
-int32_t idkptDownloadFrame(idkpt_ctx* ctx, int32_t slot, int32_t image, float* rgba, size_t bytes)
+static int32_t dev_DownloadFrame(dev_ctx* ctx, int32_t slot, int32_t image, float* rgba, size_t bytes)
 {
     if (!ctx || !rgba) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(image >= 0 && image < 3, "idkptDownloadFrame: bad image id");
@@ -979,7 +979,7 @@ int32_t idkptDownloadFrame(idkpt_ctx* ctx, int32_t slot, int32_t image, float* r
     return IDKPT_OK;
 }
 
-int32_t idkptGetFrameDevicePtr(idkpt_ctx* ctx, int32_t slot, int32_t image, void** outPtr, size_t* outBytes)
+static int32_t dev_GetFrameDevicePtr(dev_ctx* ctx, int32_t slot, int32_t image, void** outPtr, size_t* outBytes)
 {
     if (!ctx || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(image >= 0 && image < 3, "idkptGetFrameDevicePtr: bad image id");
@@ -991,7 +991,7 @@ int32_t idkptGetFrameDevicePtr(idkpt_ctx* ctx, int32_t slot, int32_t image, void
     return IDKPT_OK;
 }
 
-int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes)
+static int32_t dev_Download(dev_ctx* ctx, int32_t image, float* rgba, size_t bytes)
 {
     if (!ctx || !rgba) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(image >= 0 && image < 3, "idkptDownload: bad image id");
@@ -1004,7 +1004,7 @@ int32_t idkptDownload(idkpt_ctx* ctx, int32_t image, float* rgba, size_t bytes)
     return IDKPT_OK;
 }
 
-int32_t idkptDownloadRays(idkpt_ctx* ctx, GpuWavefrontRay* out, size_t bytes)
+static int32_t dev_DownloadRays(dev_ctx* ctx, GpuWavefrontRay* out, size_t bytes)
 {
     if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT;
     size_t N = (size_t)ctx->W * ctx->rows;
@@ -1027,7 +1027,7 @@ int32_t idkptDownloadRays(idkpt_ctx* ctx, GpuWavefrontRay* out, size_t bytes)
     return IDKPT_OK;
 }
 
-int32_t idkptDownloadAliveQueue(idkpt_ctx* ctx, uint32_t* indices, size_t capacity, uint32_t* outCount)
+static int32_t dev_DownloadAliveQueue(dev_ctx* ctx, uint32_t* indices, size_t capacity, uint32_t* outCount)
 {
     if (!ctx || !outCount) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
@@ -1046,9 +1046,9 @@ int32_t idkptDownloadAliveQueue(idkpt_ctx* ctx, uint32_t* indices, size_t capaci
     return IDKPT_OK;
 }
 
-int32_t idkptEnablePrimaryHitCapture(idkpt_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->capturePrimary = enable != 0; return IDKPT_OK; }
+static int32_t dev_EnablePrimaryHitCapture(dev_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->capturePrimary = enable != 0; return IDKPT_OK; }
 
-int32_t idkptDownloadPrimaryHits(idkpt_ctx* ctx, float* t, uint32_t* triangleId, float* baryXY, size_t pixelCount)
+static int32_t dev_DownloadPrimaryHits(dev_ctx* ctx, float* t, uint32_t* triangleId, float* baryXY, size_t pixelCount)
 {
     if (!ctx || !t || !triangleId || !baryXY) return IDKPT_ERR_INVALID_ARGUMENT;
     size_t N = (size_t)ctx->W * ctx->rows;
@@ -1063,7 +1063,7 @@ int32_t idkptDownloadPrimaryHits(idkpt_ctx* ctx, float* t, uint32_t* triangleId,
     return IDKPT_OK;
 }
 
-int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* out)
+static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
 {
     if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
@@ -1087,7 +1087,7 @@ int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* out)
     return IDKPT_OK;
 }
 
-int32_t idkptResetStats(idkpt_ctx* ctx)
+static int32_t dev_ResetStats(dev_ctx* ctx)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
@@ -1100,10 +1100,10 @@ int32_t idkptResetStats(idkpt_ctx* ctx)
     return IDKPT_OK;
 }
 
-int32_t idkptEnableCounters(idkpt_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->counters = enable != 0; return IDKPT_OK; }
-int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->timing = enable != 0; return IDKPT_OK; }
+static int32_t dev_EnableCounters(dev_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->counters = enable != 0; return IDKPT_OK; }
+static int32_t dev_EnableTiming(dev_ctx* ctx, int32_t enable) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->timing = enable != 0; return IDKPT_OK; }
 
-int32_t idkptGetImageDevicePtr(idkpt_ctx* ctx, int32_t image, void** outPtr, size_t* outBytes)
+static int32_t dev_GetImageDevicePtr(dev_ctx* ctx, int32_t image, void** outPtr, size_t* outBytes)
 {
     if (!ctx || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(image >= 0 && image < 3 && ctx->W > 0, "idkptGetImageDevicePtr: bad image / no size");
@@ -1114,7 +1114,7 @@ int32_t idkptGetImageDevicePtr(idkpt_ctx* ctx, int32_t image, void** outPtr, siz
     return IDKPT_OK;
 }
 
-int32_t idkptSetStream(idkpt_ctx* ctx, void* hipStream)
+static int32_t dev_SetStream(dev_ctx* ctx, void* hipStream)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
@@ -1124,6 +1124,7 @@ int32_t idkptSetStream(idkpt_ctx* ctx, void* hipStream)
     else if (!ctx->ownStream) { HIPC(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->ownStream = true; }
     return IDKPT_OK;
 }
-int32_t idkptGetStream(idkpt_ctx* ctx, void** out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = (void*)ctx->stream; return IDKPT_OK; }
+static int32_t dev_GetStream(dev_ctx* ctx, void** out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = (void*)ctx->stream; return IDKPT_OK; }
 
-} // extern "C"
+
+#include "idkpt_api.hpp"

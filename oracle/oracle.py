@@ -53,6 +53,7 @@ def lib():
         L.ref_pt_get_alive.restype = C.c_uint32; L.ref_pt_get_alive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ref_pt_get_stats.argtypes = [C.c_void_p] * 5
         L.ref_pt_accumulated.restype = C.c_uint32; L.ref_pt_accumulated.argtypes = [C.c_void_p]
+        L.ref_pt_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.ref_cpu_trace_primary.restype = C.c_uint64
         L.ref_cpu_trace_primary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_pcg_hash.restype = C.c_uint32; L.ref_pcg_hash.argtypes = [C.POINTER(C.c_uint32)]
@@ -243,6 +244,16 @@ class OraclePathTracer:
         rays = C.c_uint64(); pairs = C.c_uint64(); tris = C.c_uint64(); alive = (C.c_uint32 * 16)()
         lib().ref_pt_get_stats(self._pt, C.byref(rays), C.byref(pairs), C.byref(tris), alive)
         return {"rays_traced": rays.value, "node_pair_visits": pairs.value, "triangle_tests": tris.value, "alive_counts": list(alive)}
+
+
+def _timing(self, reset=True):
+    """(seconds inside the per-invocation OpenMP sections, seconds inside RenderSample) accumulated since the last reset."""
+    a = C.c_double(); b = C.c_double()
+    lib().ref_pt_get_timing(self._pt, C.byref(a), C.byref(b), 1 if reset else 0)
+    return a.value, b.value
+
+
+OraclePathTracer.timing = _timing
 
 
 def cpu_trace_primary(scene, cam, width, height, y0=0, y1=None, threads=0, want_hits=True, count=False):

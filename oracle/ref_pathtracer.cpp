@@ -11,6 +11,7 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 #include "ref_math.h"
 #include "../include/idkpt.h"
 
@@ -387,6 +388,7 @@ struct PT {
     idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // multi-context exact mode (idkptSetBounceExchange)
     Counters counters; bool countersOn = false;
     uint64_t raysTraced = 0;
+    double parallelSec = 0.0, totalSec = 0.0;   // cpu_baseline leg of bench.py: time inside the per-invocation (OpenMP) sections / whole RenderSample
 };
 
 // gl_GlobalInvocationID of the FirstHit invocation that shades pixel (px,py): inverse of ReorderInvocations(20)
@@ -524,6 +526,10 @@ static void RenderSample(PT& pt)
     std::vector<uint8_t> cont(N);
     std::vector<Counters> rowCnt(rows);
     memset(pt.aliveCounts, 0, sizeof(pt.aliveCounts));
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const clk::time_point tStart = clk::now();
+    clk::time_point tp = tStart;
     // ---- FirstHit main (FirstHit/compute.glsl:44-98), one invocation per pixel ----
     #pragma omp parallel for schedule(dynamic, 4)
     for (int ly = 0; ly < rows; ly++) {
@@ -554,6 +560,7 @@ static void RenderSample(PT& pt)
         }
     }
     pt.raysTraced += N;
+    pt.parallelSec += secs(tp, clk::now());
     // canonical enqueue: increasing pixel index (FirstHit:88-97)
     pt.alive.clear();
     for (size_t i = 0; i < N; i++) if (cont[i]) pt.alive.push_back((uint32_t)i);
@@ -575,6 +582,7 @@ static void RenderSample(PT& pt)
         std::vector<uint8_t> cont2(A); std::vector<uint32_t> keyOut(A, 0u);
         std::vector<Counters> chunkCnt((A + 255) / 256);
         // ---- NHit main (NHit/compute.glsl:40-89), one invocation per queue slot ----
+        tp = clk::now();
         #pragma omp parallel for schedule(dynamic, 1)
         for (long long chunk = 0; chunk < (long long)((A + 255) / 256); chunk++) {
             for (size_t slot = (size_t)chunk * 256; slot < std::min(A, (size_t)(chunk + 1) * 256); slot++) {
@@ -589,6 +597,7 @@ static void RenderSample(PT& pt)
                 cont2[slot] = c; keyOut[slot] = key & ((1u << IDKPT_SORT_KEY_BITS) - 1u);
             }
         }
+        pt.parallelSec += secs(tp, clk::now());
         for (auto& c : chunkCnt) { pt.counters.pairs += c.pairs; pt.counters.tris += c.tris; }
         pt.raysTraced += A;
         // canonical enqueue: increasing old slot (NHit:69-88)
@@ -599,7 +608,9 @@ static void RenderSample(PT& pt)
     for (auto& c : rowCnt) { pt.counters.pairs += c.pairs; pt.counters.tris += c.tris; }
     // ---- FinalDraw (FinalDraw/compute.glsl:24-62) ----
     float w = 1.0f / ((float)pt.accumulated + 1.0f);
-    for (size_t i = 0; i < N; i++) {
+    tp = clk::now();
+    #pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)N; i++) {          // one invocation per pixel, independent
         const GpuWavefrontRay& wr = pt.rays[i];
         v3 nr = V3(wr.Radiance[0], wr.Radiance[1], wr.Radiance[2]);
         if (g.DoDebugBVHTraversal) nr = TurboColormap(wr.PreviousIOROrTraverseCost / 150.0f);
@@ -611,6 +622,8 @@ static void RenderSample(PT& pt)
             float* on = &pt.img[2][4 * i]; v3 rn = gmix(V3(on[0], on[1], on[2]), V3(a.Normal[0], a.Normal[1], a.Normal[2]), w); on[0] = rn.x; on[1] = rn.y; on[2] = rn.z; on[3] = 1.0f;
         }
     }
+    pt.parallelSec += secs(tp, clk::now());
+    pt.totalSec += secs(tStart, clk::now());
     pt.accumulated++;
 }
 
@@ -790,6 +803,7 @@ void ref_pt_get_primary_hits(void* p, float* t, uint32_t* tri, float* bary) { PT
 uint32_t ref_pt_get_alive(void* p, uint32_t* out, uint32_t cap) { PT* pt = (PT*)p; uint32_t n = (uint32_t)pt->alive.size(); if (out) memcpy(out, pt->alive.data(), 4 * (size_t)std::min(n, cap)); return n; }
 void ref_pt_get_stats(void* p, uint64_t* raysTraced, uint64_t* pairs, uint64_t* tris, uint32_t* aliveCounts16) { PT* pt = (PT*)p; *raysTraced = pt->raysTraced; *pairs = pt->counters.pairs; *tris = pt->counters.tris; memcpy(aliveCounts16, pt->aliveCounts, 64); }
 uint32_t ref_pt_accumulated(void* p) { return ((PT*)p)->accumulated; }
+void ref_pt_get_timing(void* p, double* parallelSec, double* totalSec, int reset) { PT* pt = (PT*)p; *parallelSec = pt->parallelSec; *totalSec = pt->totalSec; if (reset) { pt->parallelSec = 0.0; pt->totalSec = 0.0; } }
 
 // ---- KAT helpers (tests/test_oracle_kats.py) ----
 uint32_t ref_pcg_hash(uint32_t* seed) { return pcg_hash(seed); }

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(64) void k(const float4* __restrict__ buf, uint32_t
 int main(int argc, char** argv)
 {
     int logBlocks = argc > 1 ? atoi(argv[1]) : 20;   // 2^20 x 64 B = 64 MB
+    const int onlyMode = argc > 2 ? atoi(argv[2]) : -1, onlyWaves = argc > 3 ? atoi(argv[3]) : -1;   // bench.py: "<log2 blocks> 0 32" = the node-pair pattern at full occupancy
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     int cus = prop.multiProcessorCount;
     size_t nBlocks = (size_t)1 << logBlocks;
@@ -44,6 +45,7 @@ int main(int argc, char** argv)
     uint32_t* out; CHECK(hipMalloc(&out, 4));
     printf("CUs %d, set %zu MB\n", cus, nBlocks * 64 >> 20);
     for (int wavesPerCU : {16, 32}) for (int mode = 0; mode < 5; mode++) {
+        if ((onlyMode >= 0 && mode != onlyMode) || (onlyWaves >= 0 && wavesPerCU != onlyWaves)) continue;
         int iters = 4000;
         dim3 grid(cus * wavesPerCU), block(64);
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -66,6 +68,8 @@ int main(int argc, char** argv)
         const double clk = ms * 1e-3 * 2.4e9;
         printf("waves/CU %2d mode %d: %8.3f ms | %6.1f clk per wave-instr per CU | %6.3f blocks/clk/CU | %6.3f lane-requests/clk/CU\n", wavesPerCU, mode, ms,
                clk / (waveIters / cus * instrPerIter), waveIters * blocksPerIter / cus / clk, waveIters * instrPerIter * 64 / cus / clk);
+        // machine-readable (bench.py): distinct 64-B blocks fetched per second, as GB/s of 64-B blocks
+        printf("RESULT set_mb=%zu waves_per_cu=%d mode=%d ms=%.4f blocks_per_s=%.6e gbs=%.2f\n", nBlocks * 64 >> 20, wavesPerCU, mode, ms, waveIters * blocksPerIter / (ms * 1e-3), waveIters * blocksPerIter * 64.0 / (ms * 1e-3) / 1e9);
     }
     return 0;
 }
