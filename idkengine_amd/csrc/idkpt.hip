@@ -53,7 +53,7 @@ struct dev_ctx {
     // scene
     bool haveScene = false, frameOk = false;
     DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;   // (+ camTab below)
-    std::vector<DevBuf> texData;
+    std::vector<DevBuf> texData; std::vector<std::pair<int, int>> texDims;
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
     std::vector<uint32_t> levelBase;                 // per BLAS base into levelNodes
@@ -76,7 +76,11 @@ struct dev_ctx {
     double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
     int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false, lastNeedsRegen = false; int lastBatch = 1; Frame lastFrame;
     int maxBatch = 1; uint32_t Npad = 0; std::vector<PendingSample> pending; DevBuf bases; uint32_t* hBases = nullptr;
-    float* hCams = nullptr; hipEvent_t evCams[2] = {nullptr, nullptr}; int camHalf = 0;   // pinned, double-buffered staging of the per-sample cameras (frame ring)
+    float* hCams = nullptr; hipEvent_t evCams[2] = {nullptr, nullptr}; int camHalf = 0;   // pinned, double-buffered staging of the per-sample cameras (frame ring)    // member of a multi-device context (idkpt_api.hpp): samples are only queued (the group launches all members together), per-bounce events tell
+    // the members that own later rows when this member's alive counts of a bounce are final, and the group supplies the slot bases
+    bool grouped = false, inGroupFlush = false; int groupIndex = 0;
+    hipEvent_t* evBounce = nullptr;                              // [MAX_DEPTH_SLOTS]; evBounce[j] = bases[j] (alive counts entering bounce j) written
+    int (*groupExchange)(void* user, dev_ctx* member, int bounce, int samples, const uint32_t** outBases) = nullptr; void* groupUser = nullptr;
 };
 
 static hipEvent_t next_event(dev_ctx* ctx)
@@ -229,7 +233,7 @@ static int32_t dev_Create(int32_t deviceCount, const int32_t* deviceIds, dev_ctx
 {
     if (!outCtx) return IDKPT_ERR_INVALID_ARGUMENT;
     *outCtx = nullptr;
-    if (deviceCount != 1) return IDKPT_ERR_INVALID_ARGUMENT; // one context per process per GPU
+    if (deviceCount != 1) return IDKPT_ERR_INVALID_ARGUMENT; // one member per device (several devices: the group layer, idkpt_api.hpp)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return IDKPT_ERR_NO_DEVICE;
     int dev = deviceIds ? deviceIds[0] : 0;
@@ -300,6 +304,19 @@ static int32_t dev_SetSize(dev_ctx* ctx, int32_t width, int32_t height)
     REQUIRE(ctx->rowLimit == 0x7fffffff || ctx->rowRem + ctx->rowLimit <= height, "idkptSetSize: the strip set by idkptSetRowRange exceeds the new image height (set a new range first)");
     REQUIRE(ctx->rowRem < height, "idkptSetSize: this context's row remainder (idkptSetRowSharding) is outside the new image height");
     ctx->W = width; ctx->H = height; ctx->rows = std::min(ctx->rowLimit, local_rows(height, ctx->rowMod, ctx->rowRem));
+    return alloc_frame(ctx);
+}
+
+// size and row layout in one step (group layer): rows y with y % rowMod == rowRem (rowLimit = 0x7fffffff) or the strip [rowRem, rowRem + rowLimit) (rowMod = 1)
+static int32_t dev_SetLayout(dev_ctx* ctx, int32_t width, int32_t height, int32_t rowMod, int32_t rowRem, int32_t rowLimit)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
+    REQUIRE(rowMod >= 1 && rowRem >= 0 && rowRem < height && rowLimit >= 1 && (rowMod == 1 || rowRem < rowMod), "internal: bad row layout");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    ctx->W = width; ctx->H = height; ctx->rowMod = rowMod; ctx->rowRem = rowRem; ctx->rowLimit = rowLimit;
+    ctx->rows = std::min(rowLimit, local_rows(height, rowMod, rowRem));
     return alloc_frame(ctx);
 }
 
@@ -452,7 +469,7 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     ctx->skySize = (sc->SkyFaces && sc->SkyFaceSize > 0) ? sc->SkyFaceSize : 0;
     if ((rc = upload(ctx, ctx->sky, sc->SkyFaces, (size_t)6 * ctx->skySize * ctx->skySize * 16))) return rc;
     for (auto& t : ctx->texData) t.release();
-    ctx->texData.clear();
+    ctx->texData.clear(); ctx->texDims.clear();
     std::vector<TexDesc> td;
     for (int i = 0; i < sc->TextureCount; i++) {
         const idkpt_texture& t = sc->Textures[i];
@@ -460,6 +477,7 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
         ctx->texData.emplace_back();
         if ((rc = upload(ctx, ctx->texData.back(), t.rgba, (size_t)t.width * t.height * 16))) return rc;
         td.push_back({ctx->texData.back().as<float4>(), t.width, t.height});
+        ctx->texDims.push_back({t.width, t.height});
     }
     if ((rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)))) return rc;
     HIPC(ctx->triVerts.ensure((size_t)sc->BlasTriangleCount * 48));
@@ -486,6 +504,43 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     if ((rc = upload(ctx, ctx->levelNodes, allLevels.data(), allLevels.size() * 4))) return rc;
     if ((rc = regather_triverts(ctx, 0, (uint32_t)sc->BlasTriangleCount))) return rc;
     HIPC(hipStreamSynchronize(ctx->stream)); // host arrays are only borrowed for the duration of the call
+    ctx->haveScene = true;
+    std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
+    return IDKPT_OK;
+}
+
+// Multi-device contexts: the scene one member uploaded (validated, derived layouts built) is replicated to another member device-to-device
+// (hipMemcpyPeerAsync: xGMI between MI355X GPUs) instead of crossing PCIe once per GPU — the "broadcast of the BVH" of the group layer.
+static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
+{
+    if (!ctx || !src || !src->haveScene) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    { int rc = materialize_culled_rays(ctx); if (rc) return rc; }   // while the old sky is still resident
+    DevBuf* d[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->vertices, &ctx->meshes,
+                   &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->levelNodes};
+    DevBuf* f[] = {&src->nodes, &src->tris, &src->triVerts, &src->descs, &src->instances, &src->tlas, &src->parents, &src->leaves, &src->positions, &src->vertices, &src->meshes,
+                   &src->materials, &src->xforms, &src->lights, &src->sky, &src->levelNodes};
+    for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++) {
+        if (!f[i]->p || f[i]->bytes == 0) continue;
+        HIPC(d[i]->ensure(f[i]->bytes));
+        HIPC(hipMemcpyPeerAsync(d[i]->p, ctx->device, f[i]->p, src->device, f[i]->bytes, ctx->stream));
+    }
+    for (auto& t : ctx->texData) t.release();
+    ctx->texData.clear(); ctx->texDims = src->texDims;
+    std::vector<TexDesc> td;
+    for (size_t i = 0; i < src->texData.size(); i++) {
+        ctx->texData.emplace_back();
+        HIPC(ctx->texData.back().ensure(src->texData[i].bytes));
+        HIPC(hipMemcpyPeerAsync(ctx->texData.back().p, ctx->device, src->texData[i].p, src->device, src->texData[i].bytes, ctx->stream));
+        td.push_back({ctx->texData.back().as<float4>(), src->texDims[i].first, src->texDims[i].second});
+    }
+    { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
+    ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
+    ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
+    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed;
+    ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase;
+    HIPC(hipStreamSynchronize(ctx->stream));           // td is a stack vector
     ctx->haveScene = true;
     std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
     return IDKPT_OK;
@@ -594,7 +649,8 @@ static int query_frame(dev_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& grid)
     return IDKPT_OK;
 }
 
-static int32_t dev_TraceRays(dev_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
+// issue only (H2D, kernel, D2H on the context's stream); the caller synchronises.  hits must stay valid until then.
+static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceRays: no scene uploaded");
@@ -618,6 +674,12 @@ static int32_t dev_TraceRays(dev_ctx* ctx, const idkpt_ray* rays, size_t count, 
     else hipLaunchKernelGGL((k_trace_query<false>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, ctx->queryIn.as<idkpt_ray>(), ctx->queryOut.as<idkpt_hit>(), (uint32_t)count, lights, work);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(hits, ctx->queryOut.p, count * sizeof(idkpt_hit), hipMemcpyDeviceToHost, st));
+    return IDKPT_OK;
+}
+static int32_t dev_TraceRays(dev_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
+{
+    int rc = dev_TraceRaysIssue(ctx, rays, count, flags, hits); if (rc) return rc;
+    if (count == 0) return IDKPT_OK;
     SYNC_CHECKED();
     return IDKPT_OK;
 }
@@ -726,6 +788,7 @@ static int flush_batch(dev_ctx* ctx)
 {
     const int B = (int)ctx->pending.size();
     if (B == 0) return IDKPT_OK;
+    if (ctx->grouped && !ctx->inGroupFlush) return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: a member of a multi-device context was flushed on its own");
     const uint32_t N = (uint32_t)((size_t)ctx->W * ctx->rows);
     const uint32_t Npad = ctx->Npad;
     const uint32_t total = (uint32_t)B * Npad;
@@ -826,6 +889,7 @@ static int flush_batch(dev_ctx* ctx)
         }
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, (const uint32_t*)nullptr, total, blockSums, (const uint32_t*)waveLocal, counts + 1, (unsigned long long*)(1 < depth ? counters + 2 : nullptr),
                            (const unsigned long long*)contMask, (const uint32_t*)nullptr, Npad, B, bases + 1 * BS);
+        if (ctx->evBounce) HIPC(hipEventRecord(ctx->evBounce[1], st));      // bases[1] (alive counts entering bounce 1) are final
         hipLaunchKernelGGL((k_compact<true>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const unsigned long long*)contMask, (const uint32_t*)waveLocal, (const uint32_t*)blockSums,
                            (const uint32_t*)keysTmp, ctx->queue[1].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
     }
@@ -835,7 +899,9 @@ static int flush_batch(dev_ctx* ctx)
         const uint32_t* cnt = counts + j;
         // exact multi-GPU deep paths: the host tells every sample how many alive rays the contexts above this strip hold (idkpt.h)
         const uint32_t* gbase = nullptr;
-        if (ctx->exchangeFn) {
+        if (ctx->groupExchange) {   // member of a multi-device context: the group sums the counts of the members that own earlier rows, on the device (idkpt_api.hpp)
+            int rc = ctx->groupExchange(ctx->groupUser, ctx, j, B, &gbase); if (rc) { ctx->pending.clear(); return rc; }
+        } else if (ctx->exchangeFn) {
             std::vector<uint32_t> hb(B + 1), local(B), outBases(B, 0u);
             HIPC(hipMemcpyAsync(hb.data(), bases + j * BS, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, st));
             HIPC(hipStreamSynchronize(st));
@@ -875,6 +941,7 @@ static int flush_batch(dev_ctx* ctx)
         hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, cnt, 0u, blockSums, (const uint32_t*)waveLocal, counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr),
                            (const unsigned long long*)contMask, (const uint32_t*)(bases + j * BS), Npad, B, bases + (j + 1) * BS);
+        if (ctx->evBounce) HIPC(hipEventRecord(ctx->evBounce[j + 1], st));
         hipLaunchKernelGGL((k_compact<false>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)q, cnt, 0u, (const unsigned long long*)contMask, (const uint32_t*)waveLocal, (const uint32_t*)blockSums,
                            (const uint32_t*)keysTmp, ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
         side = 1 - side;
@@ -907,7 +974,7 @@ static int32_t dev_Render(dev_ctx* ctx)
         PendingSample ps; ps.accum = ctx->accum[ctx->curSlot]++; ps.slot = ctx->curSlot;
         memcpy(ps.cam, ctx->invProj, 64); memcpy(ps.cam + 16, ctx->invView, 64); memcpy(ps.cam + 32, ctx->viewPos, 12); ps.cam[35] = 0.0f;
         ctx->pending.push_back(ps);
-        if ((int)ctx->pending.size() >= limit) { int rc = flush_batch(ctx); if (rc) return rc; }
+        if (!ctx->grouped && (int)ctx->pending.size() >= limit) { int rc = flush_batch(ctx); if (rc) return rc; }   // (members of a multi-device context: the group launches)
     }
     return IDKPT_OK;
 }

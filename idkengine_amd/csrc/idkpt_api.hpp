@@ -1,0 +1,534 @@
+// idkpt_api.hpp — the exported C-ABI of include/idkpt.h and the multi-device ("group") layer behind idkptCreate(deviceCount = N).
+// Included at the end of idkpt.hip (one translation unit); the single-device implementation is the dev_* functions above.
+//
+// One handle, N GPUs (north_star: "tiles of the framebuffer optionally sharded across the 8 GPUs of one node ... broadcast of the BVH +
+// gather of tiles over xGMI"; the reference itself is single-GPU, Source/EntryPoint.cs:10-33):
+//   * every device gets a member context (dev_ctx: own stream, own wavefront buffers, its rows of the frame);
+//   * the scene crosses PCIe once (member 0) and is replicated device-to-device with hipMemcpyPeerAsync — point-to-point copies are what
+//     xGMI is; no collective library is needed inside one process;
+//   * rows: interleaved (y % N == d: balances sky rows against geometry rows; N-device output == 1-device output bit for bit at RayDepth <= 2,
+//     where radiance does not depend on the queue slot) or contiguous strips with a device-side exchange of the per-sample alive counts
+//     at every bounce (exact at any depth with sorting off: NHit seeds its RNG from the queue slot, NHit/compute.glsl:54) — "auto" picks
+//     by RayDepth; no host synchronisation in either mode: members wait on each other's per-bounce events, counts travel by peer copies;
+//   * results: idkptDownload writes every member's rows straight into the host image (N PCIe links in parallel); idkptGetImageDevicePtr
+//     gathers the rows into a full frame on device 0 (peer copies + one interleave kernel).
+// With deviceCount == 1 every entry point forwards to the single member: no behavioural change, no overhead.
+#pragma once
+#include <array>
+
+struct idkpt_ctx {
+    std::vector<dev_ctx*> dev;
+    std::string lastError; bool groupError = false;
+    int W = 0, H = 0;
+    int shardMode = IDKPT_SHARD_AUTO; bool strips = false;
+    idkpt_settings st;
+    int maxBatch = 1, pending = 0;
+    std::vector<int> firstRow, rowCount;                    // strips: member d renders rows [firstRow[d], firstRow[d] + rowCount[d])
+    std::vector<std::array<hipEvent_t, MAX_DEPTH_SLOTS>> evBounce;
+    std::vector<hipEvent_t> evFlushDone, evGather; std::vector<char> flushDoneValid;
+    std::vector<DevBuf> peerStage, gbase;                   // on member d: the lower members' per-sample bases of the current bounce; the summed slot bases
+    DevBuf full[3], gatherStage, rowOffDev;                 // on device 0: gathered full-frame images; landing zone of the interleaved rows; first landing row of every member
+    size_t n() const { return dev.size(); }
+};
+
+// gbase[k] = sum over the members that own earlier rows of their alive count of sample k (count = bases[k+1] - bases[k])
+__global__ void k_group_bases(const uint32_t* stage, int lower, int stride, int samples, uint32_t* gbase)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= samples) return;
+    uint32_t sum = 0;
+    for (int d = 0; d < lower; d++) sum += stage[(size_t)d * stride + k + 1] - stage[(size_t)d * stride + k];
+    gbase[k] = sum;
+}
+// full[y][x] = rows of member y % n, landed contiguously per member in `stage` (member d at rowOffset[d] rows)
+__global__ void k_interleave_rows(const float4* stage, float4* full, int W, int H, int n, const int* rowOffset)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)W * H) return;
+    const int y = (int)(i / W), x = (int)(i % W), d = y % n, ly = y / n;
+    full[i] = stage[((size_t)rowOffset[d] + ly) * W + x];
+}
+
+static int gfail(idkpt_ctx* c, int code, const std::string& msg) { c->lastError = msg; c->groupError = true; return code; }
+static int mfail(idkpt_ctx* c, dev_ctx* m, int rc) { c->lastError = m->lastError; c->groupError = true; return rc; }
+#define GREQ(cond, msg) do { if (!(cond)) return gfail(c, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
+#define GHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return gfail(c, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+#define ONE(call) do { if (c->n() == 1) { dev_ctx* m = c->dev[0]; return call; } } while (0)
+#define ALL(call) do { for (dev_ctx* m : c->dev) { int _rc = call; if (_rc) return mfail(c, m, _rc); } } while (0)
+
+static void strip_of(int H, int n, int d, int* first, int* count) { const int base = H / n, extra = H % n; *first = d * base + std::min(d, extra); *count = base + (d < extra ? 1 : 0); }
+
+// the hook every member calls at the start of a bounce (flush_batch): slot bases of its samples = alive rays of the members above it
+static int group_exchange(void* user, dev_ctx* m, int bounce, int samples, const uint32_t** outBases)
+{
+    idkpt_ctx* c = (idkpt_ctx*)user;
+    *outBases = nullptr;
+    if (!c->strips || m->groupIndex == 0) return IDKPT_OK;               // interleaved rows: no exchange (exact at RayDepth <= 2); member 0 starts at slot 0
+    const int d = m->groupIndex, BS = MAX_BATCH + 1;
+    dev_ctx* ctx = m;                                                      // (HIPC reports into the member)
+    HIPC(c->peerStage[d].ensure((size_t)d * BS * 4)); HIPC(c->gbase[d].ensure((size_t)MAX_BATCH * 4));
+    for (int d2 = 0; d2 < d; d2++) {
+        dev_ctx* lo = c->dev[d2];
+        HIPC(hipStreamWaitEvent(m->stream, c->evBounce[d2][bounce], 0));  // the lower member's counts of this bounce are final (it was enqueued first)
+        HIPC(hipMemcpyPeerAsync(c->peerStage[d].as<uint32_t>() + (size_t)d2 * BS, m->device, lo->bases.as<uint32_t>() + (size_t)bounce * BS, lo->device, (size_t)(samples + 1) * 4, m->stream));
+    }
+    hipLaunchKernelGGL(k_group_bases, dim3((samples + 63) / 64), dim3(64), 0, m->stream, (const uint32_t*)c->peerStage[d].as<uint32_t>(), d, BS, samples, c->gbase[d].as<uint32_t>());
+    HIPC(hipGetLastError());
+    *outBases = c->gbase[d].as<uint32_t>();
+    return IDKPT_OK;
+}
+
+// launches what the members have queued.  Members are enqueued in row order, so a member only ever waits for members enqueued before it.
+static int group_flush(idkpt_ctx* c)
+{
+    if (c->pending == 0) return IDKPT_OK;
+    for (size_t d = 0; d < c->n(); d++) {
+        dev_ctx* m = c->dev[d];
+        GHIP(hipSetDevice(m->device));
+        // the next batch of this member must not overwrite the per-bounce tables that members below it may still be copying from the last one
+        if (c->strips) for (size_t d2 = d + 1; d2 < c->n(); d2++) if (c->flushDoneValid[d2]) GHIP(hipStreamWaitEvent(m->stream, c->evFlushDone[d2], 0));
+        m->inGroupFlush = true;
+        const int rc = flush_batch(m);
+        m->inGroupFlush = false;
+        if (rc) { for (dev_ctx* o : c->dev) o->pending.clear(); c->pending = 0; return mfail(c, m, rc); }
+        if (c->strips) { GHIP(hipEventRecord(c->evFlushDone[d], m->stream)); c->flushDoneValid[d] = 1; }
+    }
+    c->pending = 0;
+    return IDKPT_OK;
+}
+#define GFLUSH() do { int _rc = group_flush(c); if (_rc) return _rc; } while (0)
+
+static int group_sync(idkpt_ctx* c)
+{
+    for (dev_ctx* m : c->dev) {
+        GHIP(hipSetDevice(m->device)); GHIP(hipStreamSynchronize(m->stream));
+        int rc = check_overflow(m); if (rc) return mfail(c, m, rc);
+    }
+    return IDKPT_OK;
+}
+
+// (re)applies size + row layout to every member.  Strips for deep paths (exact slot numbering), interleaved rows otherwise.
+static int group_layout(idkpt_ctx* c)
+{
+    const int n = (int)c->n();
+    c->strips = c->shardMode == IDKPT_SHARD_STRIPS || (c->shardMode == IDKPT_SHARD_AUTO && c->st.RayDepth > 2);
+    if (c->W <= 0) return IDKPT_OK;
+    GREQ(c->H >= n, "idkptSetSize: a multi-device context needs at least one image row per device");
+    for (int d = 0; d < n; d++) {
+        int rc;
+        if (c->strips) { strip_of(c->H, n, d, &c->firstRow[d], &c->rowCount[d]); rc = dev_SetLayout(c->dev[d], c->W, c->H, 1, c->firstRow[d], c->rowCount[d]); }
+        else { c->firstRow[d] = d; c->rowCount[d] = local_rows(c->H, n, d); rc = dev_SetLayout(c->dev[d], c->W, c->H, n, d, 0x7fffffff); }
+        if (rc) return mfail(c, c->dev[d], rc);
+        c->flushDoneValid[d] = 0;
+    }
+    // where member d's rows land in the gather staging area (interleaved layout), kept on device 0 for k_interleave_rows
+    std::vector<int> rowOff(n, 0);
+    for (int d = 1; d < n; d++) rowOff[d] = rowOff[d - 1] + c->dev[d - 1]->rows;
+    dev_ctx* m0 = c->dev[0];
+    GHIP(hipSetDevice(m0->device));
+    GHIP(c->rowOffDev.ensure((size_t)n * 4));
+    GHIP(hipMemcpyAsync(c->rowOffDev.p, rowOff.data(), (size_t)n * 4, hipMemcpyHostToDevice, m0->stream));
+    GHIP(hipStreamSynchronize(m0->stream));
+    return IDKPT_OK;
+}
+
+// member rows -> host image (every member copies its rows itself: one PCIe link per GPU)
+static int group_download_image(idkpt_ctx* c, int image, int slot, float* rgba, size_t bytes)
+{
+    GREQ(image >= 0 && image < 3, "idkptDownload: bad image id");
+    const size_t rowBytes = (size_t)c->W * 16;
+    GREQ(c->W > 0 && bytes == rowBytes * c->H, "idkptDownload: bytes must equal height*width*16 (the whole frame of a multi-device context)");
+    GREQ(slot >= 0 && slot < c->dev[0]->ringSize, "idkptDownloadFrame: slot outside the frame ring");
+    GFLUSH();
+    const int n = (int)c->n();
+    for (int d = 0; d < n; d++) {
+        dev_ctx* m = c->dev[d];
+        GHIP(hipSetDevice(m->device));
+        const float4* src = image_ptr(m, image, slot);
+        if (c->strips) GHIP(hipMemcpyAsync((char*)rgba + (size_t)c->firstRow[d] * rowBytes, src, (size_t)m->rows * rowBytes, hipMemcpyDeviceToHost, m->stream));
+        else GHIP(hipMemcpy2DAsync((char*)rgba + (size_t)d * rowBytes, (size_t)n * rowBytes, src, rowBytes, rowBytes, (size_t)m->rows, hipMemcpyDeviceToHost, m->stream));
+    }
+    return group_sync(c);
+}
+
+// member rows -> full frame on device 0 (peer copies; interleaved rows land in a staging area and are woven together by one kernel)
+static int group_gather_device(idkpt_ctx* c, int image, int slot, void** outPtr, size_t* outBytes)
+{
+    GREQ(image >= 0 && image < 3 && c->W > 0, "idkptGetImageDevicePtr: bad image / no size");
+    GREQ(slot >= 0 && slot < c->dev[0]->ringSize, "idkptGetFrameDevicePtr: slot outside the frame ring");
+    GFLUSH();
+    const int n = (int)c->n();
+    const size_t rowBytes = (size_t)c->W * 16, frameBytes = rowBytes * c->H;
+    dev_ctx* m0 = c->dev[0];
+    GHIP(hipSetDevice(m0->device));
+    GHIP(c->full[image].ensure(frameBytes));
+    std::vector<int> rowOff(n + 1, 0);
+    for (int d = 0; d < n; d++) rowOff[d + 1] = rowOff[d] + c->dev[d]->rows;
+    if (!c->strips) GHIP(c->gatherStage.ensure(frameBytes));
+    for (int d = 0; d < n; d++) {
+        dev_ctx* m = c->dev[d];
+        GHIP(hipSetDevice(m->device));
+        char* dst = c->strips ? (char*)c->full[image].p + (size_t)c->firstRow[d] * rowBytes : (char*)c->gatherStage.p + (size_t)rowOff[d] * rowBytes;
+        GHIP(hipMemcpyPeerAsync(dst, m0->device, image_ptr(m, image, slot), m->device, (size_t)m->rows * rowBytes, m->stream));   // ordered behind the member's FinalDraw
+        GHIP(hipEventRecord(c->evGather[d], m->stream));
+    }
+    GHIP(hipSetDevice(m0->device));
+    for (int d = 1; d < n; d++) GHIP(hipStreamWaitEvent(m0->stream, c->evGather[d], 0));
+    if (!c->strips) {
+        const size_t px = (size_t)c->W * c->H;
+        hipLaunchKernelGGL(k_interleave_rows, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, m0->stream, (const float4*)c->gatherStage.p, (float4*)c->full[image].p, c->W, c->H, n, (const int*)c->rowOffDev.p);
+        GHIP(hipGetLastError());
+    }
+    *outPtr = c->full[image].p;
+    if (outBytes) *outBytes = frameBytes;
+    return IDKPT_OK;
+}
+
+// local pixel index of member d -> pixel index of the whole frame
+static inline uint32_t global_pixel(const idkpt_ctx* c, int d, uint32_t local)
+{
+    const uint32_t W = (uint32_t)c->W, ly = local / W, x = local % W;
+    const uint32_t y = c->strips ? (uint32_t)c->firstRow[d] + ly : ly * (uint32_t)c->n() + (uint32_t)d;
+    return y * W + x;
+}
+
+extern "C" {
+
+const char* idkptGetVersionString(void) { return "idkpt 0.2 (gfx950)"; }
+int32_t idkptGetDeviceCount(int32_t* outCount) { return dev_GetDeviceCount(outCount); }
+
+int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** outCtx)
+{
+    if (!outCtx) return IDKPT_ERR_INVALID_ARGUMENT;
+    *outCtx = nullptr;
+    if (deviceCount < 1 || deviceCount > 64) return IDKPT_ERR_INVALID_ARGUMENT;
+    idkpt_ctx* c = new idkpt_ctx();
+    memset(&c->st, 0, sizeof(c->st));
+    for (int d = 0; d < deviceCount; d++) {
+        int32_t id = deviceIds ? deviceIds[d] : d;
+        dev_ctx* m = nullptr;
+        int rc = dev_Create(1, &id, &m);
+        if (rc) { for (dev_ctx* o : c->dev) dev_Destroy(o); delete c; return rc; }
+        c->dev.push_back(m);
+    }
+    c->st = c->dev[0]->st;
+    const int n = deviceCount;
+    if (n > 1) {
+        c->firstRow.assign(n, 0); c->rowCount.assign(n, 0); c->evBounce.resize(n); c->evFlushDone.assign(n, nullptr); c->evGather.assign(n, nullptr);
+        c->flushDoneValid.assign(n, 0); c->peerStage.resize(n); c->gbase.resize(n);
+        bool ok = true;
+        for (int d = 0; d < n && ok; d++) {
+            dev_ctx* m = c->dev[d];
+            ok = hipSetDevice(m->device) == hipSuccess;
+            for (int j = 0; j < MAX_DEPTH_SLOTS && ok; j++) ok = hipEventCreateWithFlags(&c->evBounce[d][j], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&c->evFlushDone[d], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->evGather[d], hipEventDisableTiming) == hipSuccess;
+            m->grouped = true; m->groupIndex = d; m->evBounce = c->evBounce[d].data(); m->groupExchange = group_exchange; m->groupUser = c;
+            // direct xGMI access between the members' devices (copies work without it through staging; a refusal is not an error)
+            for (int d2 = 0; d2 < n; d2++) if (c->dev[d2]->device != m->device) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->device, c->dev[d2]->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(c->dev[d2]->device, 0); (void)hipGetLastError(); }
+        }
+        if (!ok) { (void)hipGetLastError(); for (dev_ctx* o : c->dev) dev_Destroy(o); delete c; return IDKPT_ERR_HIP; }
+    }
+    *outCtx = c;
+    return IDKPT_OK;
+}
+
+int32_t idkptDestroy(idkpt_ctx* c)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    for (dev_ctx* m : c->dev) { (void)hipSetDevice(m->device); (void)hipStreamSynchronize(m->stream); }
+    if (c->n() > 1) {
+        for (size_t d = 0; d < c->n(); d++) {
+            (void)hipSetDevice(c->dev[d]->device);
+            for (hipEvent_t e : c->evBounce[d]) if (e) (void)hipEventDestroy(e);
+            if (c->evFlushDone[d]) (void)hipEventDestroy(c->evFlushDone[d]);
+            if (c->evGather[d]) (void)hipEventDestroy(c->evGather[d]);
+            c->peerStage[d].release(); c->gbase[d].release();
+        }
+        (void)hipSetDevice(c->dev[0]->device);
+        for (int i = 0; i < 3; i++) c->full[i].release();
+        c->gatherStage.release(); c->rowOffDev.release();
+    }
+    for (dev_ctx* m : c->dev) dev_Destroy(m);
+    delete c;
+    return IDKPT_OK;
+}
+
+int32_t idkptGetLastError(idkpt_ctx* c, const char** outMessage)
+{
+    if (!c || !outMessage) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (c->n() == 1 && !c->groupError) return dev_GetLastError(c->dev[0], outMessage);
+    *outMessage = c->lastError.c_str();
+    return IDKPT_OK;
+}
+
+int32_t idkptGetContextDeviceCount(idkpt_ctx* c, int32_t* outCount) { if (!c || !outCount) return IDKPT_ERR_INVALID_ARGUMENT; *outCount = (int32_t)c->n(); return IDKPT_OK; }
+
+int32_t idkptSetGroupSharding(idkpt_ctx* c, int32_t mode)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    GREQ(mode == IDKPT_SHARD_AUTO || mode == IDKPT_SHARD_ROWS || mode == IDKPT_SHARD_STRIPS, "idkptSetGroupSharding: unknown mode");
+    if (c->n() == 1) { c->shardMode = mode; return IDKPT_OK; }
+    GFLUSH();
+    const bool was = c->strips;
+    c->shardMode = mode;
+    const bool now = mode == IDKPT_SHARD_STRIPS || (mode == IDKPT_SHARD_AUTO && c->st.RayDepth > 2);
+    return now != was ? group_layout(c) : IDKPT_OK;
+}
+
+int32_t idkptSetSize(idkpt_ctx* c, int32_t width, int32_t height)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetSize(m, width, height));
+    GREQ(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
+    GFLUSH();
+    c->W = width; c->H = height;
+    return group_layout(c);
+}
+int32_t idkptSetRowSharding(idkpt_ctx* c, int32_t rowModulo, int32_t rowRemainder)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetRowSharding(m, rowModulo, rowRemainder));
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetRowSharding: a multi-device context deals its rows itself (idkptSetGroupSharding)");
+}
+int32_t idkptSetRowRange(idkpt_ctx* c, int32_t firstRow, int32_t rowCount)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetRowRange(m, firstRow, rowCount));
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetRowRange: a multi-device context deals its rows itself (idkptSetGroupSharding)");
+}
+int32_t idkptSetBounceExchange(idkpt_ctx* c, idkpt_bounce_exchange_fn fn, void* user)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetBounceExchange(m, fn, user));
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetBounceExchange: a multi-device context exchanges its alive counts on the devices");
+}
+
+int32_t idkptSetSettings(idkpt_ctx* c, const idkpt_settings* s)
+{
+    if (!c || !s) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetSettings(m, s));
+    if (memcmp(&c->st, s, sizeof(*s)) == 0) return IDKPT_OK;
+    GFLUSH();
+    const bool wantStrips = c->shardMode == IDKPT_SHARD_STRIPS || (c->shardMode == IDKPT_SHARD_AUTO && s->RayDepth > 2);
+    ALL(dev_SetSettings(m, s));                       // (validates; nothing is changed when it fails on the first member)
+    c->st = *s;
+    if (wantStrips != c->strips) { int rc = group_layout(c); if (rc) return rc; }   // the RayDepth setter resets the accumulation anyway (PathTracer.cs:16-25)
+    return IDKPT_OK;
+}
+int32_t idkptGetSettings(idkpt_ctx* c, idkpt_settings* out) { if (!c || !out) return IDKPT_ERR_INVALID_ARGUMENT; return dev_GetSettings(c->dev[0], out); }
+
+int32_t idkptSetPerFrame(idkpt_ctx* c, const float invProjection[16], const float invView[16], const float viewPos[3])
+{
+    if (!c || !invProjection || !invView || !viewPos) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetPerFrame(m, invProjection, invView, viewPos));
+    dev_ctx* m0 = c->dev[0];
+    if (m0->ringSize == 1 && (memcmp(m0->invProj, invProjection, 64) || memcmp(m0->invView, invView, 64) || memcmp(m0->viewPos, viewPos, 12))) GFLUSH();   // one camera per batch
+    ALL(dev_SetPerFrame(m, invProjection, invView, viewPos));
+    return IDKPT_OK;
+}
+int32_t idkptSetPerFrameData(idkpt_ctx* c, const GpuPerFrameData* p) { if (!c || !p) return IDKPT_ERR_INVALID_ARGUMENT; return idkptSetPerFrame(c, p->InvProjection, p->InvView, p->ViewPos); }
+
+int32_t idkptUploadScene(idkpt_ctx* c, const idkpt_scene_desc* scene)
+{
+    if (!c || !scene) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_UploadScene(m, scene));
+    GFLUSH();
+    { int rc = dev_UploadScene(c->dev[0], scene); if (rc) return mfail(c, c->dev[0], rc); }          // host -> device 0 (validated there)
+    for (size_t d = 1; d < c->n(); d++) { int rc = dev_CloneSceneFrom(c->dev[d], c->dev[0]); if (rc) return mfail(c, c->dev[d], rc); }   // device 0 -> device d
+    return IDKPT_OK;
+}
+#define REPLICATE(name, ...) do { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; ONE(dev_##name(m, ##__VA_ARGS__)); GFLUSH(); ALL(dev_##name(m, ##__VA_ARGS__)); return IDKPT_OK; } while (0)
+int32_t idkptUpdateBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, const void* data) { REPLICATE(UpdateBuffer, which, offsetBytes, bytes, data); }
+int32_t idkptSetLightCount(idkpt_ctx* c, int32_t count) { REPLICATE(SetLightCount, count); }
+int32_t idkptBuildTlas(idkpt_ctx* c, const GpuTlasNode* nodes, int32_t nodeCount) { REPLICATE(BuildTlas, nodes, nodeCount); }
+int32_t idkptBuildTlasOnDevice(idkpt_ctx* c, int32_t searchRadius) { REPLICATE(BuildTlasOnDevice, searchRadius); }      // every member rebuilds its own copy (0.1 ms; cheaper than shipping it)
+int32_t idkptRefitBlas(idkpt_ctx* c, int32_t blasId) { REPLICATE(RefitBlas, blasId); }
+int32_t idkptUploadUnskinnedVertices(idkpt_ctx* c, const GpuUnskinnedVertex* verts, int32_t count) { REPLICATE(UploadUnskinnedVertices, verts, count); }
+int32_t idkptSkin(idkpt_ctx* c, uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count) { REPLICATE(Skin, inOff, outOff, jointOff, count); }
+int32_t idkptDownloadBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, void* dst)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_DownloadBuffer(m, which, offsetBytes, bytes, dst));
+    GFLUSH();
+    int rc = dev_DownloadBuffer(c->dev[0], which, offsetBytes, bytes, dst);       // the scene is replicated: any member's copy
+    return rc ? mfail(c, c->dev[0], rc) : IDKPT_OK;
+}
+
+// ray queries are independent: the array is cut into one contiguous piece per device
+int32_t idkptTraceRays(idkpt_ctx* c, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_TraceRays(m, rays, count, flags, hits));
+    GREQ(count == 0 || (rays && hits), "idkptTraceRays: null rays/hits");
+    GFLUSH();
+    const size_t n = c->n(), per = (count + n - 1) / n;
+    for (size_t d = 0; d < n; d++) {
+        const size_t first = std::min(count, d * per), cnt = std::min(count, first + per) - first;
+        if (cnt == 0) continue;
+        int rc = dev_TraceRaysIssue(c->dev[d], rays + first, cnt, flags, hits + first); if (rc) { (void)group_sync(c); return mfail(c, c->dev[d], rc); }
+    }
+    return group_sync(c);
+}
+int32_t idkptTraceShadows(idkpt_ctx* c, const idkpt_shadow_params* p, const float* depth, const float* normalOct, float* visibility)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_TraceShadows(m, p, depth, normalOct, visibility));
+    GFLUSH();
+    int rc = dev_TraceShadows(c->dev[0], p, depth, normalOct, visibility);          // one shadow map: runs on the first device
+    return rc ? mfail(c, c->dev[0], rc) : IDKPT_OK;
+}
+
+int32_t idkptSetFrameRing(idkpt_ctx* c, int32_t frames) { REPLICATE(SetFrameRing, frames); }
+int32_t idkptBeginFrame(idkpt_ctx* c, int32_t* outSlot)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_BeginFrame(m, outSlot));
+    int32_t slot = 0;
+    for (dev_ctx* m : c->dev) { int rc = dev_BeginFrame(m, &slot); if (rc) return mfail(c, m, rc); }
+    if (outSlot) *outSlot = slot;
+    return IDKPT_OK;
+}
+int32_t idkptDownloadFrame(idkpt_ctx* c, int32_t slot, int32_t image, float* rgba, size_t bytes)
+{
+    if (!c || !rgba) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_DownloadFrame(m, slot, image, rgba, bytes));
+    return group_download_image(c, image, slot, rgba, bytes);
+}
+int32_t idkptGetFrameDevicePtr(idkpt_ctx* c, int32_t slot, int32_t image, void** outPtr, size_t* outBytes)
+{
+    if (!c || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_GetFrameDevicePtr(m, slot, image, outPtr, outBytes));
+    return group_gather_device(c, image, slot, outPtr, outBytes);
+}
+
+int32_t idkptResetAccumulation(idkpt_ctx* c) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; for (dev_ctx* m : c->dev) dev_ResetAccumulation(m); return IDKPT_OK; }
+int32_t idkptGetAccumulatedSamples(idkpt_ctx* c, uint32_t* out) { if (!c || !out) return IDKPT_ERR_INVALID_ARGUMENT; return dev_GetAccumulatedSamples(c->dev[0], out); }
+
+int32_t idkptRender(idkpt_ctx* c)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_Render(m));
+    if (c->W <= 0) return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptRender: no frame buffers (idkptSetSize not called)");
+    // every member queues the same samples for its rows; the batch is launched on all of them together.  The general path (debug
+    // traversal-cost view) is never batched.
+    const int limit = fast_path(c->dev[0]) ? c->maxBatch : 1;
+    for (int i = 0; i < c->st.SamplesPerPixel; i++) {
+        for (dev_ctx* m : c->dev) {                   // one sample per member and round, so that the batch limit is honoured between the samples of one call
+            const int spp = m->st.SamplesPerPixel; m->st.SamplesPerPixel = 1;
+            const int rc = dev_Render(m);
+            m->st.SamplesPerPixel = spp;
+            if (rc) { for (dev_ctx* o : c->dev) o->pending.clear(); c->pending = 0; return mfail(c, m, rc); }
+        }
+        if (++c->pending >= limit) GFLUSH();
+    }
+    return IDKPT_OK;
+}
+int32_t idkptFlush(idkpt_ctx* c) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; ONE(dev_Flush(m)); return group_flush(c); }
+int32_t idkptSynchronize(idkpt_ctx* c) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; ONE(dev_Synchronize(m)); GFLUSH(); return group_sync(c); }
+int32_t idkptSetMaxBatch(idkpt_ctx* c, int32_t maxBatch)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetMaxBatch(m, maxBatch));
+    GREQ(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..256");
+    GFLUSH();
+    ALL(dev_SetMaxBatch(m, maxBatch));
+    c->maxBatch = maxBatch;
+    return IDKPT_OK;
+}
+
+int32_t idkptDownload(idkpt_ctx* c, int32_t image, float* rgba, size_t bytes)
+{
+    if (!c || !rgba) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_Download(m, image, rgba, bytes));
+    return group_download_image(c, image, c->dev[0]->curSlot, rgba, bytes);
+}
+int32_t idkptGetImageDevicePtr(idkpt_ctx* c, int32_t image, void** outPtr, size_t* outBytes)
+{
+    if (!c || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_GetImageDevicePtr(m, image, outPtr, outBytes));
+    return group_gather_device(c, image, c->dev[0]->curSlot, outPtr, outBytes);
+}
+
+// parity accessors: per-pixel state of the whole frame, reassembled from the members' rows
+int32_t idkptDownloadRays(idkpt_ctx* c, GpuWavefrontRay* out, size_t bytes)
+{
+    if (!c || !out) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_DownloadRays(m, out, bytes));
+    GREQ(bytes == (size_t)c->W * c->H * sizeof(GpuWavefrontRay) && bytes > 0, "idkptDownloadRays: bytes must equal pixelCount*48");
+    GFLUSH();
+    for (size_t d = 0; d < c->n(); d++) {
+        dev_ctx* m = c->dev[d];
+        const size_t N = (size_t)c->W * m->rows;
+        std::vector<GpuWavefrontRay> tmp(N);
+        int rc = dev_DownloadRays(m, tmp.data(), N * sizeof(GpuWavefrontRay)); if (rc) return mfail(c, m, rc);
+        for (size_t i = 0; i < N; i++) out[global_pixel(c, (int)d, (uint32_t)i)] = tmp[i];
+    }
+    return IDKPT_OK;
+}
+int32_t idkptDownloadAliveQueue(idkpt_ctx* c, uint32_t* indices, size_t capacityElems, uint32_t* outCount)
+{
+    if (!c || !outCount) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_DownloadAliveQueue(m, indices, capacityElems, outCount));
+    GFLUSH();
+    // the one-device queue is in increasing pixel order (sorting off): strips concatenate, interleaved rows merge
+    if (c->st.DoRaySorting && c->st.RayDepth > 2) return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptDownloadAliveQueue: with DoRaySorting every device sorts its own queue; there is no single queue to return");
+    std::vector<uint32_t> all;
+    for (size_t d = 0; d < c->n(); d++) {
+        uint32_t cnt = 0;
+        int rc = dev_DownloadAliveQueue(c->dev[d], nullptr, 0, &cnt); if (rc) return mfail(c, c->dev[d], rc);
+        std::vector<uint32_t> q(cnt);
+        if (cnt) { rc = dev_DownloadAliveQueue(c->dev[d], q.data(), cnt, &cnt); if (rc) return mfail(c, c->dev[d], rc); }
+        for (uint32_t v : q) all.push_back(global_pixel(c, (int)d, v));
+    }
+    if (!c->strips) std::sort(all.begin(), all.end());
+    *outCount = (uint32_t)all.size();
+    if (indices && !all.empty()) { GREQ(capacityElems >= all.size(), "idkptDownloadAliveQueue: capacity too small"); memcpy(indices, all.data(), all.size() * 4); }
+    return IDKPT_OK;
+}
+int32_t idkptEnablePrimaryHitCapture(idkpt_ctx* c, int32_t enable) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; for (dev_ctx* m : c->dev) dev_EnablePrimaryHitCapture(m, enable); return IDKPT_OK; }
+int32_t idkptDownloadPrimaryHits(idkpt_ctx* c, float* t, uint32_t* triangleId, float* baryXY, size_t pixelCount)
+{
+    if (!c || !t || !triangleId || !baryXY) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_DownloadPrimaryHits(m, t, triangleId, baryXY, pixelCount));
+    GREQ(pixelCount == (size_t)c->W * c->H, "idkptDownloadPrimaryHits: pixelCount mismatch");
+    GFLUSH();
+    for (size_t d = 0; d < c->n(); d++) {
+        dev_ctx* m = c->dev[d];
+        const size_t N = (size_t)c->W * m->rows;
+        std::vector<float> tt(N), bb(2 * N); std::vector<uint32_t> ii(N);
+        int rc = dev_DownloadPrimaryHits(m, tt.data(), ii.data(), bb.data(), N); if (rc) return mfail(c, m, rc);
+        for (size_t i = 0; i < N; i++) { const uint32_t g = global_pixel(c, (int)d, (uint32_t)i); t[g] = tt[i]; triangleId[g] = ii[i]; baryXY[2 * (size_t)g] = bb[2 * i]; baryXY[2 * (size_t)g + 1] = bb[2 * i + 1]; }
+    }
+    return IDKPT_OK;
+}
+
+int32_t idkptGetStats(idkpt_ctx* c, idkpt_stats* out)
+{
+    if (!c || !out) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_GetStats(m, out));
+    GFLUSH();
+    idkpt_stats sum; memset(&sum, 0, sizeof(sum));
+    for (size_t d = 0; d < c->n(); d++) {
+        idkpt_stats s; int rc = dev_GetStats(c->dev[d], &s); if (rc) return mfail(c, c->dev[d], rc);
+        sum.RaysTraced += s.RaysTraced; sum.PrimaryRays += s.PrimaryRays; sum.NodePairVisits += s.NodePairVisits; sum.TriangleTests += s.TriangleTests;
+        for (int j = 0; j < 16; j++) sum.LastAliveCounts[j] += s.LastAliveCounts[j];
+        sum.LastFrameMs = std::max(sum.LastFrameMs, s.LastFrameMs); sum.LastTraceMs = std::max(sum.LastTraceMs, s.LastTraceMs);       // the devices run side by side
+        sum.TraceMsTotal = std::max(sum.TraceMsTotal, s.TraceMsTotal);
+        if (d == 0) { sum.Frames = s.Frames; sum.TraceLaunches = s.TraceLaunches; }
+    }
+    *out = sum;
+    return IDKPT_OK;
+}
+int32_t idkptResetStats(idkpt_ctx* c) { REPLICATE(ResetStats); }
+int32_t idkptEnableCounters(idkpt_ctx* c, int32_t enable) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; ONE(dev_EnableCounters(m, enable)); GFLUSH(); for (dev_ctx* m : c->dev) dev_EnableCounters(m, enable); return IDKPT_OK; }
+int32_t idkptEnableTiming(idkpt_ctx* c, int32_t enable) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; for (dev_ctx* m : c->dev) dev_EnableTiming(m, enable); return IDKPT_OK; }
+
+int32_t idkptSetStream(idkpt_ctx* c, void* hipStream)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetStream(m, hipStream));
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetStream: a multi-device context owns one stream per device");
+}
+int32_t idkptGetStream(idkpt_ctx* c, void** out) { if (!c || !out) return IDKPT_ERR_INVALID_ARGUMENT; return dev_GetStream(c->dev[0], out); }   // device 0's stream: work on it is ordered behind idkptGetImageDevicePtr's gather
+
+} // extern "C"

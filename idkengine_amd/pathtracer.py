@@ -14,15 +14,21 @@ from ._lib import IdkPtError
 
 
 class PathTracer:
-    def __init__(self, width, height, settings=None, device=0, row_modulo=1, row_remainder=0):
+    def __init__(self, width, height, settings=None, device=0, row_modulo=1, row_remainder=0, devices=None):
+        """devices: list of HIP device ids for ONE context that renders on several GPUs (idkptCreate(deviceCount = N)); an id may repeat
+        (two members on one GPU).  Otherwise one device (`device`), optionally one row shard of a process-per-GPU run (row_modulo/remainder)."""
         self._L = _lib.load()
         n = C.c_int32(0)
         self._L.idkptGetDeviceCount(C.byref(n))
         if n.value <= 0:
             raise IdkPtError("no HIP device visible: the path tracer has no CPU fallback")
         ctx = C.c_void_p()
-        dev = (C.c_int32 * 1)(device)
-        rc = self._L.idkptCreate(1, dev, C.byref(ctx))
+        ids = list(devices) if devices else [device]
+        self.device_count = len(ids)
+        if self.device_count > 1 and (row_modulo, row_remainder) != (1, 0):
+            raise IdkPtError("a multi-device context deals its rows itself")
+        dev = (C.c_int32 * len(ids))(*ids)
+        rc = self._L.idkptCreate(len(ids), dev, C.byref(ctx))
         if rc != 0:
             raise IdkPtError(f"idkptCreate failed with status {rc}")
         self._ctx = ctx
@@ -32,7 +38,8 @@ class PathTracer:
         self.width, self.height = width, height
         self.row_modulo, self.row_remainder = row_modulo, row_remainder
         self._row_limit = None
-        self._check(self._L.idkptSetRowSharding(ctx, row_modulo, row_remainder))
+        if self.device_count == 1:
+            self._check(self._L.idkptSetRowSharding(ctx, row_modulo, row_remainder))
         self._check(self._L.idkptSetSize(ctx, width, height))
         self._push_settings()
 
@@ -183,6 +190,10 @@ class PathTracer:
 
     def Skin(self, input_offset, output_offset, joint_offset, count):
         self._check(self._L.idkptSkin(self._ctx, input_offset, output_offset, joint_offset, count))
+
+    def SetGroupSharding(self, mode):
+        """idkptSetGroupSharding: 0 auto (rows for RayDepth <= 2, strips + device-side count exchange beyond), 1 rows, 2 strips."""
+        self._check(self._L.idkptSetGroupSharding(self._ctx, int(mode)))
 
     def SetRowRange(self, first_row, row_count):
         """idkptSetRowRange: this context renders the contiguous strip [first_row, first_row + row_count)."""

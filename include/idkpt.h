@@ -135,9 +135,26 @@ typedef struct idkpt_stats {
 } idkpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
-/* new PathTracer(w,h,settings) (PathTracer.cs:170-212). deviceCount must be 1: one process per GPU;
- * multi-GPU runs use one context per process and idkptSetRowSharding (DESIGN.md "Multi-GPU"). */
+/* new PathTracer(w,h,settings) (PathTracer.cs:170-212).  deviceCount = 1: the reference's situation, one GPU.
+ * deviceCount = N > 1 (no reference equivalent: Source/EntryPoint.cs:10-33 is single-GPU): ONE handle that renders every frame on N GPUs of
+ * the node — the host keeps calling the same entry points.  The scene crosses PCIe once and is replicated device-to-device over xGMI
+ * (hipMemcpyPeerAsync), every device renders its rows of the frame (idkptSetGroupSharding), idkptDownload returns the whole frame (each
+ * device copies its rows into the host image itself) and idkptGetImageDevicePtr gathers it on the first device.  Results are identical
+ * to a one-device context bit for bit (RayDepth <= 2: always; deeper paths: with DoRaySorting off).  deviceIds may be NULL (devices
+ * 0..N-1); an id may appear twice (two members on one GPU: how the multi-device code is exercised on a one-GPU box).
+ * A process-per-GPU host (torch.distributed / MPI) can instead create one 1-device context per process and use idkptSetRowSharding /
+ * idkptSetRowRange + idkptSetBounceExchange (idkengine_amd/dist.py). */
 IDKPT_API int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** outCtx);
+IDKPT_API int32_t idkptGetContextDeviceCount(idkpt_ctx* ctx, int32_t* outCount);
+/* How a multi-device context deals the image rows to its devices (ignored by a one-device context):
+ *   IDKPT_SHARD_ROWS    row y -> device y % N.  Balances sky rows against geometry rows; exact for RayDepth <= 2 (radiance does not depend on
+ *                       the queue slot there), statistically equivalent beyond.
+ *   IDKPT_SHARD_STRIPS  contiguous strips + a device-side exchange of the per-sample alive counts at every bounce (peer copies ordered by
+ *                       events, no host synchronisation): every strip numbers its NHit queue slots after the alive rays of the strips above
+ *                       it (NHit seeds its RNG from the slot, NHit/compute.glsl:54), so N devices == 1 device at any RayDepth with DoRaySorting off.
+ *   IDKPT_SHARD_AUTO    (default) rows for RayDepth <= 2, strips beyond.  A change of layout restarts the accumulation (like idkptSetSize). */
+enum idkpt_group_sharding { IDKPT_SHARD_AUTO = 0, IDKPT_SHARD_ROWS = 1, IDKPT_SHARD_STRIPS = 2 };
+IDKPT_API int32_t idkptSetGroupSharding(idkpt_ctx* ctx, int32_t mode);
 /* PathTracer.Dispose (PathTracer.cs:344-365) */
 IDKPT_API int32_t idkptDestroy(idkpt_ctx* ctx);
 /* OIDN.GetDeviceError style (OIDN/OIDN.cs:108-112): pointer stays valid until the next call on ctx */
@@ -255,6 +272,8 @@ IDKPT_API int32_t idkptEnableCounters(idkpt_ctx* ctx, int32_t enable);
 IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
 
 /* ---- interop (device pointers as void*, for RCCL gather of row shards by the host process) -- */
+/* Launches what is still deferred and returns the image of the current slot (ordered on the context's stream, idkptGetStream).  Multi-device
+ * context: the rows of all devices are gathered into a full frame on the first device (peer copies; valid until the next call). */
 IDKPT_API int32_t idkptGetImageDevicePtr(idkpt_ctx* ctx, int32_t image, void** outPtr, size_t* outBytes);
 /* Use an externally created hipStream_t (e.g. torch's current stream) for all work; NULL = library stream */
 IDKPT_API int32_t idkptSetStream(idkpt_ctx* ctx, void* hipStream);

@@ -3,7 +3,9 @@
  * renders it through the C-ABI exactly like the reference's PathTracer would be driven (ctor -> uploads -> Compute -> read-back,
  * Source/Render/PathTracer.cs:170-271) and writes the Result image + stats for the test to compare bit for bit.
  *
- *   abi_driver <dir> <width> <height> <rayDepth> <samples> <useTlas>
+ *   abi_driver <dir> <width> <height> <rayDepth> <samples> <useTlas> [devices]
+ * devices > 1: ONE context on that many devices (idkptCreate(deviceCount = N)); ids wrap around the visible GPUs, so on a one-GPU box the
+ * members share the GPU and the very same multi-device code runs.  The frame that comes back is the whole frame either way.
  * <dir>/manifest.txt: "<name> <count>" per line; <dir>/<name>.bin: raw bytes of that array.
  * Build (tests do this): gcc -std=c11 -O1 -I include tests/c_driver/abi_driver.c -L idkengine_amd -lidkpt -Wl,-rpath,idkengine_amd -o abi_driver
  */
@@ -56,7 +58,11 @@ int main(int argc, char** argv)
     idkpt_ctx* ctx = NULL;
     int32_t devCount = 0;
     if (idkptGetDeviceCount(&devCount) != IDKPT_OK || devCount < 1) { fprintf(stderr, "no HIP device\n"); return 4; }
-    if (idkptCreate(1, NULL, &ctx) != IDKPT_OK || !ctx) { fprintf(stderr, "idkptCreate failed\n"); return 4; }
+    const int devices = argc > 7 ? atoi(argv[7]) : 1;
+    int32_t ids[64];
+    if (devices < 1 || devices > 64) { fprintf(stderr, "bad device count\n"); return 1; }
+    for (int d = 0; d < devices; d++) ids[d] = d % devCount;
+    if (idkptCreate(devices, ids, &ctx) != IDKPT_OK || !ctx) { fprintf(stderr, "idkptCreate failed\n"); return 4; }
     CHECK(idkptSetSize(ctx, w, h));
     idkpt_settings st;
     CHECK(idkptGetSettings(ctx, &st));

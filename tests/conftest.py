@@ -13,6 +13,12 @@ def pytest_configure(config):
 
 def _gpu_count():
     try:
+        # torch first: it ships its own copy of the HIP runtime, and the process must end up with ONE runtime — the copy that is
+        # loaded first wins (libidkpt.so's dependency then resolves to it by soname); the other order leaves torch without devices
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         import ctypes
         from idkengine_amd import _lib
         n = ctypes.c_int32(0)

@@ -60,3 +60,16 @@ def _queries(n, seed, extent, max_dist=3.4028235e+38):
     d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
     r["Direction"] = d.astype(np.float32); r["MaxDist"] = max_dist
     return r
+
+
+def read_device_image(pt, ptr, nbytes, shape):
+    """Reads `nbytes` at device pointer `ptr` through the context's own stream (idkptGetStream) — what a consumer that is ordered behind
+    the library's work does.  Uses torch as the HIP front end (one HIP runtime per process: conftest imports torch first)."""
+    import ctypes as C
+    import torch
+    stream = C.c_void_p(); pt._check(pt._L.idkptGetStream(pt._ctx, C.byref(stream)))
+    ext = torch.cuda.ExternalStream(stream.value)
+    holder = type("DevArray", (), {"__cuda_array_interface__": {"shape": (nbytes // 4,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}})()
+    with torch.cuda.stream(ext):
+        t = torch.as_tensor(holder, device="cuda").to("cpu", non_blocking=False)
+    return t.numpy().reshape(shape).copy()

@@ -64,8 +64,10 @@ def test_no_gpu_means_loud_failure_not_fallback():
     n = C.c_int32(-1)
     L.idkptGetDeviceCount(C.byref(n))
     ctx = C.c_void_p()
-    assert L.idkptCreate(2, None, C.byref(ctx)) == 2            # only one device per context (one process per GPU)
+    assert L.idkptCreate(0, None, C.byref(ctx)) == 2 and L.idkptCreate(65, None, C.byref(ctx)) == 2     # 1..64 devices per context
     assert L.idkptCreate(1, None, None) == 2
+    if n.value <= 0:
+        assert L.idkptCreate(2, None, C.byref(ctx)) == 5 and not ctx.value                              # a multi-device context needs devices too
     if n.value <= 0:
         assert L.idkptCreate(1, None, C.byref(ctx)) == 5 and not ctx.value
         from idkengine_amd.pathtracer import PathTracer, IdkPtError

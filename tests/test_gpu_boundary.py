@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 sys.path.insert(0, HERE)
 import configs  # noqa: E402,F401
 from idkengine_amd import scenes as S  # noqa: E402,F401
-from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402,F401
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal, read_device_image  # noqa: E402,F401
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,17 @@ def test_plain_c_host_matches_python_host(native_builder, tmp_path):
         out = subprocess.run([exe, str(tmp_path), str(w), str(h), "4", "2", str(use_tlas)], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
         assert out.stdout.startswith("ok ")
+        got = np.fromfile(str(tmp_path / "result.bin"), np.float32).reshape(h, w, 4)
+        rays, pairs, tris, acc = (int(x) for x in open(str(tmp_path / "stats.txt")).read().split())
+        pt = gpu_render(sc, cam, w, h, RayDepth=4, SamplesPerPixel=2, UseTlas=use_tlas)
+        st = pt.stats()
+        assert (bits(got) == bits(pt.Result)).all()
+        assert (rays, pairs, tris, acc) == (st["rays_traced"], st["node_pair_visits"], st["triangle_tests"], pt.AccumulatedSamples)
+        pt.Dispose()
+    # the same host, ONE context on two devices (ids wrap around the visible GPUs): the whole frame comes back through the same calls
+    for use_tlas in (0, 1):
+        out = subprocess.run([exe, str(tmp_path), str(w), str(h), "4", "2", str(use_tlas), "2"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
         got = np.fromfile(str(tmp_path / "result.bin"), np.float32).reshape(h, w, 4)
         rays, pairs, tris, acc = (int(x) for x in open(str(tmp_path / "stats.txt")).read().split())
         pt = gpu_render(sc, cam, w, h, RayDepth=4, SamplesPerPixel=2, UseTlas=use_tlas)
@@ -165,7 +176,6 @@ def test_strip_is_revalidated_on_resize_and_settings_repush_is_idempotent(native
 def test_device_pointer_getters_launch_deferred_samples(native_builder):
     """idkpt.h: idkptGetImageDevicePtr / idkptGetFrameDevicePtr launch what is still deferred, so a consumer ordered behind the
     context's stream reads the finished image (they used to hand out a stale image)."""
-    import ctypes as C
     from idkengine_amd.pathtracer import PathTracer
     sc = S.cornell_scene(native_builder); w, h = 64, 48; cam = S.cornell_camera(w, h)
     a = PathTracer(w, h); a.UploadScene(sc); a.SetCamera(cam); a.RayDepth = 3; a.set_max_batch(8)
@@ -174,10 +184,6 @@ def test_device_pointer_getters_launch_deferred_samples(native_builder):
         for _ in range(3):
             p.Compute()
     ptr, nbytes = a.image_device_ptr(0)               # 3 samples were pending: this call launches them
-    hip = C.CDLL("libamdhip64.so")
-    stream = C.c_void_p(); a._check(a._L.idkptGetStream(a._ctx, C.byref(stream)))
-    out = np.zeros((h, w, 4), np.float32)
-    assert hip.hipMemcpyAsync(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2, stream) == 0   # 2 = hipMemcpyDeviceToHost
-    assert hip.hipStreamSynchronize(stream) == 0
+    out = read_device_image(a, ptr, nbytes, (h, w, 4))
     assert (bits(out) == bits(b.Result)).all()
     a.Dispose(); b.Dispose()

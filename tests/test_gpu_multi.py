@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 sys.path.insert(0, HERE)
 import configs  # noqa: E402,F401
 from idkengine_amd import scenes as S  # noqa: E402,F401
-from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402,F401
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal, _queries, read_device_image  # noqa: E402,F401
 
 pytestmark = pytest.mark.gpu
 
@@ -114,3 +114,114 @@ def test_sharded_frame_over_rccl_world1(native_builder):
         ref.Dispose(); r.pt.Dispose()
     finally:
         dist.destroy_process_group()
+
+
+def _device_ids(members):
+    import ctypes as C
+    from idkengine_amd import _lib
+    n = C.c_int32(0); _lib.load().idkptGetDeviceCount(C.byref(n))
+    return [i % max(1, n.value) for i in range(members)]      # wraps around the visible GPUs: on a one-GPU box the members share it
+
+
+@pytest.mark.parametrize("members", [2, 3])
+def test_multi_device_context_equals_one_device(native_builder, oracle_mod, members):
+    """idkptCreate(deviceCount = N): ONE handle rendering every frame on N members (rows for RayDepth <= 2, strips + device-side alive-count
+    exchange beyond) must return what a one-device context returns, bit for bit: the three images, the per-pixel ray state, primary hits,
+    the alive queue, the ray and visit counters — batched or not, several samples per call, a size no member count divides."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    sc = S.soup_scene(30000, native_builder, seed=21, extent=3.0); w, h = 200, 117; cam = S.Camera(w, h, position=(0.0, 0.0, 8.0))
+    ids = _device_ids(members)
+    for depth, sort, batch, spp, aov in ((2, 0, 1, 1, 0), (2, 1, 4, 2, 1), (5, 0, 3, 1, 0), (4, 0, 1, 3, 1), (7, 0, 8, 1, 0)):
+        st = configs.apply_settings(T.Settings.default(), dict(RayDepth=depth, DoRaySorting=sort, SamplesPerPixel=spp, OutputAOVs=aov))
+        a = PathTracer(w, h, settings=st, devices=ids); b = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), dict(RayDepth=depth, DoRaySorting=sort, SamplesPerPixel=spp, OutputAOVs=aov)))
+        for p in (a, b):
+            p.UploadScene(sc); p.SetCamera(cam); p.enable_counters(True); p.enable_primary_hit_capture(True); p.set_max_batch(batch)
+            for _ in range(3):
+                p.Compute()
+        assert a.rows == h and a.Result.shape == (h, w, 4)
+        assert (bits(a.Result) == bits(b.Result)).all(), (depth, sort, batch)
+        if aov:
+            assert (bits(a.AlbedoTexture) == bits(b.AlbedoTexture)).all() and (bits(a.NormalTexture) == bits(b.NormalTexture)).all()
+        assert a.AccumulatedSamples == b.AccumulatedSamples == 3 * spp
+        ta, ia, ba = a.primary_hits(); tb, ib, bb = b.primary_hits()
+        assert (ia == ib).all() and (bits(ta) == bits(tb)).all() and (bits(ba) == bits(bb)).all()
+        if depth > 2:
+            # strips + count exchange: every queue slot, hence every RNG stream, is the one-device one -> the internal state matches too.
+            # (Interleaved rows, RayDepth <= 2: the images are exact because radiance never depends on the slot there, but what the LAST
+            # bounce leaves behind for a bounce that is not traced — new direction, roulette survivors — is drawn from slot-seeded streams.)
+            assert a.rays().tobytes() == b.rays().tobytes(), (depth, sort, batch)
+            assert (a.alive_queue() == b.alive_queue()).all()
+        sa, sb = a.stats(), b.stats()
+        for k in ("rays_traced", "primary_rays", "node_pair_visits", "triangle_tests", "frames"):
+            assert sa[k] == sb[k], k
+        assert sa["alive_counts"][:depth] == sb["alive_counts"][:depth]
+        a.Dispose(); b.Dispose()
+    # explicit strips at RayDepth 2: full internal state parity there as well
+    a = PathTracer(w, h, devices=ids); b = PathTracer(w, h)
+    a.SetGroupSharding(2)
+    for p in (a, b):
+        p.UploadScene(sc); p.SetCamera(cam); p.RayDepth = 2; p.set_max_batch(2); p.Compute(); p.Compute()
+    assert (bits(a.Result) == bits(b.Result)).all() and a.rays().tobytes() == b.rays().tobytes() and (a.alive_queue() == b.alive_queue()).all()
+    a.Dispose(); b.Dispose()
+    # ... and the oracle agrees with the group directly (deep paths, strips)
+    st = configs.apply_settings(T.Settings.default(), dict(RayDepth=5))
+    a = PathTracer(w, h, settings=st, devices=ids); a.UploadScene(sc); a.SetCamera(cam); a.set_max_batch(2)
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=2, RayDepth=5)
+    a.Compute(); a.Compute()
+    assert (bits(a.Result) == bits(o.image(0))).all() and a.rays().tobytes() == o.rays().tobytes()
+    a.Dispose(); o.close()
+
+
+def test_multi_device_context_api_surface(native_builder, oracle_mod):
+    """The rest of the boundary on a multi-device context: resize, explicit sharding modes, frame gather on the first device
+    (idkptGetImageDevicePtr), sharded ray queries, replicated scene updates (refit), frame ring, and the calls a group refuses."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd._lib import IdkPtError
+    from idkengine_amd import gputypes as T
+    ids = _device_ids(2)
+    sc = S.soup_scene(8000, native_builder, seed=4, extent=2.5, refittable=True); cam = lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 7.0))   # noqa: E731
+    a = PathTracer(96, 64, devices=ids); b = PathTracer(96, 64)
+    for p in (a, b):
+        p.UploadScene(sc); p.SetCamera(cam(96, 64)); p.RayDepth = 3; p.Compute()
+    assert (bits(a.Result) == bits(b.Result)).all()
+    # resize + explicit strips at depth 2 / explicit rows
+    for mode, depth in ((2, 2), (1, 2), (0, 4)):
+        a.SetGroupSharding(mode)
+        for p in (a, b):
+            p.SetSize(123, 45); p.SetCamera(cam(123, 45)); p.RayDepth = depth; p.set_max_batch(2); p.Compute(); p.Compute()
+        assert (bits(a.Result) == bits(b.Result)).all(), (mode, depth)
+        # gather on the first device: the pointer addresses the whole frame, ordered on the context's stream
+        ptr, nbytes = a.image_device_ptr(0)
+        assert nbytes == 123 * 45 * 16
+        out = read_device_image(a, ptr, nbytes, (45, 123, 4))
+        assert (bits(out) == bits(b.Result)).all(), mode
+    # ray queries are cut into one piece per device
+    rays = _queries(5001, 3, 3.0)
+    assert a.TraceRays(rays).tobytes() == b.TraceRays(rays).tobytes() == oracle_mod.trace_rays(sc, rays).tobytes()
+    assert a.TraceRays(rays, any_hit=True).tobytes() == b.TraceRays(rays, any_hit=True).tobytes()
+    # replicated scene update: every member refits its own copy
+    moved = (sc.vertex_positions + np.float32(0.03) * np.sin(sc.vertex_positions[:, ::-1] * 2.1).astype(np.float32)).astype(np.float32)
+    for p in (a, b):
+        p.UpdateBuffer(1, moved); p.RefitBlas(0); p.ResetAccumulation(); p.Compute()
+    assert (bits(a.Result) == bits(b.Result)).all()
+    assert a.DownloadBuffer(6, T.GpuBlasNode, len(sc.blas_nodes)).tobytes() == b.DownloadBuffer(6, T.GpuBlasNode, len(sc.blas_nodes)).tobytes()
+    # frame ring
+    for p in (a, b):
+        p.SetFrameRing(3); p.set_max_batch(3)
+        slots = []
+        for k in range(3):
+            slots.append(p.BeginFrame()); p.SetCamera(S.Camera(123, 45, position=(0.2 * k, 0.0, 7.0))); p.Compute()
+        p._slots = slots
+    for k in range(3):
+        assert (bits(a.FrameResult(a._slots[k])) == bits(b.FrameResult(b._slots[k]))).all(), k
+    # what a group does not take
+    with pytest.raises(IdkPtError, match="multi-device"):
+        a._check(a._L.idkptSetRowSharding(a._ctx, 2, 0))
+    with pytest.raises(IdkPtError, match="multi-device"):
+        a.set_stream(0)
+    with pytest.raises(IdkPtError):
+        a.SetSize(64, 1)                              # fewer rows than devices
+    a.SetSize(64, 32); a.SetCamera(cam(64, 32)); a.Compute()     # still usable
+    assert a.Result.shape == (32, 64, 4)
+    a.Dispose(); b.Dispose()
