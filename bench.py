@@ -76,12 +76,14 @@ def main():
     ap.add_argument("--height", type=int, default=H, help="secondary-table runs only (headline = 1080)")
     ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: contiguous strips + per-bounce count exchange (gloo control group) so that RayDepth > 2 output equals the 1-GPU output bit for bit; default = interleaved rows (exact at RayDepth 2)")
     ap.add_argument("--interactive", type=int, default=0, metavar="F", help="secondary mode: every step is a NEW frame (own camera, own image, ResetAccumulation semantics) with F frames in flight through the frame ring; every finished frame is exchanged when N > 1")
+    ap.add_argument("--spawn", action="store_true", help="--gpus N without a launcher: start N processes (torch.distributed.run, one rank per GPU, RCCL) instead of the default ONE process driving ONE multi-device context (idkptCreate(deviceCount = N))")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 256")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
+    if world == 1 and args.gpus > 1 and args.spawn:
         self_launch(args)                                # does not return
+    group = args.gpus if (world == 1 and args.gpus > 1) else 1     # one process, one multi-device context (the C-ABI's own N-GPU mode)
 
     import numpy as np  # noqa: F401
     import torch
@@ -90,7 +92,7 @@ def main():
     from idkengine_amd.bvh import NativeBuilder
     from idkengine_amd import dist as D
 
-    args.batch = max(1, min(256, args.batch * world))
+    args.batch = max(1, min(256, args.batch * world * group))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
     # developer smoke test of the N > 1 flow on a single-GPU box: IDKPT_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and uses gloo
@@ -116,13 +118,26 @@ def main():
     W, H = args.width, args.height
     cam = view_camera(S, args.view, W, H)
 
-    control = dist.new_group(backend="gloo") if (world > 1 and args.exact_deep_paths) else None   # CPU-side group for the tiny count exchange
-    r = D.GpuShardRenderer(W, H, world, rank, local_rank, exact_deep_paths=bool(control), control_group=control)
-    r.upload_scene(scene); r.set_camera(cam)
-    pt = r.pt
     depth = args.depth
+    if group > 1:
+        # ONE context on `group` devices: the library replicates the scene over xGMI, deals the rows and gathers the frame itself
+        from idkengine_amd.pathtracer import PathTracer
+        ndev = torch.cuda.device_count()
+        pt = PathTracer(W, H, devices=[d % ndev for d in range(group)])
+        pt.UploadScene(scene); pt.SetCamera(cam)
+        r = type("Single", (), {"pt": pt})()
+
+        class _GroupFrame:                                   # the displayed frame's exchange: rows of all devices gathered on the first one
+            def gather(self):
+                return pt.image_device_ptr(0)
+        frame = _GroupFrame()
+    else:
+        control = dist.new_group(backend="gloo") if (world > 1 and args.exact_deep_paths) else None   # CPU-side group for the tiny count exchange
+        r = D.GpuShardRenderer(W, H, world, rank, local_rank, exact_deep_paths=bool(control), control_group=control)
+        r.upload_scene(scene); r.set_camera(cam)
+        pt = r.pt
+        frame = D.ShardedFrame(r, W, H) if world > 1 else None
     pt.RayDepth = depth; pt.SamplesPerPixel = 1; pt.DoRaySorting = args.sort
-    frame = D.ShardedFrame(r, W, H) if world > 1 else None
 
     if args.interactive > 0:
         return interactive(args, r, frame, pt, world, rank, device, scene, build_s, dist, torch, S)
@@ -186,25 +201,25 @@ def main():
 
     if rank == 0:
         value = rays_rep / dt / 1e6
-        headline = (args.tris, depth, args.sort, W, H, args.batch, args.view) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world), "headline")
+        headline = (args.tris, depth, args.sort, W, H, args.batch, args.view) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world * group), "headline")
         view_txt = "camera at z = 25 outside the soup (SURVEY 8d config 3)" if args.view == "headline" else "camera INSIDE the soup at the origin"
         out = {
             "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri scene, {args.view} view (secondary config)", "value": round(value, 2), "unit": "Mray/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "n_gpus": world * group, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": reps, "repeat_ms": [round(x * 1e3, 3) for x in repeat_s], "statistic": "median repetition of the timed region",
             "traversed_mray_s": round(traversed_rep / dt / 1e6, 2),
             "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, {view_txt}",
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
-                       "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather") if world > 1 else "none",
+                       "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather") if world > 1 else "none")),
                        "bvh_build_s": round(build_s, 2)},
-            "roofline": roofline(st, pairs * reps, tri_tests * reps, traversed * reps, args, world, B if rem == 0 else (rem if q == 0 else None), torch, device),
+            "roofline": roofline(st, pairs * reps / group, tri_tests * reps / group, traversed * reps / group, args, world * group, B if rem == 0 else (rem if q == 0 else None), torch, device),
         }
-        if world == 1 and not args.no_extras:
+        if world * group == 1 and not args.no_extras:
             out["single_frame"] = single_frame(pt, depth)
             out["interior"] = interior_extras(S, pt, W, H, B)
             pt.SetCamera(cam); pt.RayDepth = depth; pt.set_max_batch(B)
-        if world == 1 and not args.no_cpu_baseline:
+        if world * group == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, scene, depth, args.view)
         print(json.dumps(out), flush=True)
     r.pt.Dispose()
