@@ -388,3 +388,19 @@ def presplit_scene(builder, n_small=5000, seed=3, refittable=False):
 
 def presplit_camera(width, height):
     return Camera(width, height, position=(0.5, 0.8, 6.0), fovy_deg=60.0)
+
+
+# ----------------------------------------------------------------------------------------------- glTF-accessor meshes (fixtures)
+
+
+def mesh_scene(npz_path, builder, material=None, refittable=False, sky_color=(0.6, 0.7, 0.9), transform=None):
+    """One indexed mesh (positions / normals / uvs / uint16 indices as extracted by tests/golden/make_models.py from the glTF files the
+    reference ships) as one BLAS: shared vertices, sliver triangles and real PreSplit priorities that the generated scenes do not have.
+    Tangents are not stored in those files; a unit vector orthogonal to the normal stands in (NormalMapStrength is 0)."""
+    d = np.load(npz_path)
+    pos, nrm, uv, idx = d["positions"], d["normals"].astype(np.float64), d["uvs"], d["indices"].astype(np.uint32)
+    nl = np.linalg.norm(nrm, axis=1, keepdims=True); nl[nl == 0] = 1.0; nrm = nrm / nl
+    axis = np.where(np.abs(nrm[:, :1]) > 0.9, np.float64([[0.0, 1.0, 0.0]]), np.float64([[1.0, 0.0, 0.0]]))
+    tan = np.cross(nrm, axis); tan /= np.linalg.norm(tan, axis=1, keepdims=True)
+    mat = material if material is not None else make_material((0.8, 0.78, 0.7, 1.0), roughness=0.55)
+    return assemble([{"meshes": [MeshInput(pos, idx, mat, nrm.astype(np.float32), tan.astype(np.float32), uv)], "refittable": refittable, "transform": transform}], builder, sky_color=sky_color)

@@ -36,7 +36,7 @@ def main():
         bvh[name] = {
             "nodes_sha256": hashlib.sha256(sc.blas_nodes.tobytes()).hexdigest(), "tris_sha256": hashlib.sha256(sc.blas_triangles.tobytes()).hexdigest(),
             "tlas_sha256": hashlib.sha256(sc.tlas_nodes.tobytes()).hexdigest(), "node_count": int(len(sc.blas_nodes)), "tri_count": int(len(sc.blas_triangles)),
-            "stack": [int(x) for x in sc.blas_descs["RequiredStackSize"]],
+            "stack": [int(x) for x in sc.blas_descs["RequiredStackSize"]], "sah": configs.sah_cost(sc),
         }
     json.dump(bvh, open(os.path.join(HERE, "bvh.json"), "w"), indent=1, sort_keys=True)
     print("bvh.json written")

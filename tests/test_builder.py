@@ -1,8 +1,15 @@
 """Native builder (product, libidkbvh.so) vs the oracle's independent restatement: bit-exact nodes / triangle order /
 stack sizes ("BVH node indices bit-exact"), plus the structural invariants documented at Bvh/BLAS.cs:12-22."""
+import hashlib
+import json
+import os
+import sys
 import numpy as np
 import pytest
 from idkengine_amd import scenes as S
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import configs  # noqa: E402
 
 FIELDS = ("blas_nodes", "blas_triangles", "blas_descs", "tlas_nodes", "blas_parent_indices", "blas_leaf_indices")
 
@@ -25,12 +32,37 @@ CASES = [
     ("soup1000_refit", lambda b: S.soup_scene(1000, b, seed=3, refittable=True)),
     ("soup60000", lambda b: S.soup_scene(60000, b, seed=4)),             # stack optimisation kicks in (>= 16)
     ("presplit", lambda b: S.presplit_scene(b)),
+    # the two meshes the reference ships: shared vertices, slivers, deep stacks (RequiredStackSize >= 16 -> OptimizeStackSize, Bvh/BLAS.cs:875-937)
+    ("lucy", configs.lucy_scene),
+    ("helmet", configs.helmet_scene),
+    ("helmet_refit", lambda b: configs.helmet_scene(b, refittable=True)),
 ]
 
 
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
 def test_native_builder_bit_exact_vs_oracle(name, make, native_builder, oracle_builder):
     assert_same(make(native_builder), make(oracle_builder))
+
+
+@pytest.mark.parametrize("name", list(configs.BVH_CASES))
+def test_native_builder_matches_committed_goldens(name, native_builder):
+    """No oracle involved: node / triangle / TLAS hashes, counts, RequiredStackSize and the SAH cost of the product builder against
+    tests/golden/bvh.json."""
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bvh.json")))[name]
+    sc = configs.BVH_CASES[name](native_builder)
+    assert hashlib.sha256(sc.blas_nodes.tobytes()).hexdigest() == g["nodes_sha256"] and hashlib.sha256(sc.blas_triangles.tobytes()).hexdigest() == g["tris_sha256"]
+    assert hashlib.sha256(sc.tlas_nodes.tobytes()).hexdigest() == g["tlas_sha256"]
+    assert (len(sc.blas_nodes), len(sc.blas_triangles)) == (g["node_count"], g["tri_count"]) and [int(x) for x in sc.blas_descs["RequiredStackSize"]] == g["stack"]
+    assert abs(configs.sah_cost(sc) - g["sah"]) <= 1e-9 * abs(g["sah"])
+
+
+def test_real_meshes_exercise_what_the_soup_does_not(native_builder):
+    lucy, helmet = configs.lucy_scene(native_builder), configs.helmet_scene(native_builder)
+    assert len(lucy.blas_triangles) >= 8954 and len(helmet.blas_triangles) >= 15452          # PreSplit may add fragments
+    assert len(np.unique(helmet.blas_triangles["X"])) < len(helmet.blas_triangles)           # shared vertices
+    assert int(lucy.blas_descs["RequiredStackSize"][0]) >= 8 and int(helmet.blas_descs["RequiredStackSize"][0]) >= 8
+    for sc in (lucy, helmet, configs.helmet_scene(native_builder, refittable=True)):
+        _check_invariants(sc)
 
 
 def test_threaded_build_is_deterministic():

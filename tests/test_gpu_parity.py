@@ -38,6 +38,14 @@ MATRIX = [
      lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 3.0), fovy_deg=50.0), 48, 48, dict(RayDepth=4)),
     ("primary_only_d1", lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 100, 60, dict(RayDepth=1, SamplesPerPixel=2)),
     ("sub_tile_5x3", lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 5, 3, dict(RayDepth=6, DoRaySorting=1)),
+    # real geometry: the two glTF meshes the reference ships (tests/golden/make_models.py), PreSplit on (builder default)
+    ("lucy_d2", configs.lucy_scene, configs.lucy_camera, 240, 320, dict(RayDepth=2)),
+    ("lucy_d5_sort", configs.lucy_scene, configs.lucy_camera, 240, 320, dict(RayDepth=5, DoRaySorting=1)),
+    ("lucy_d9", configs.lucy_scene, configs.lucy_camera, 150, 200, dict(RayDepth=9, SamplesPerPixel=2)),
+    ("helmet_d2_sort", configs.helmet_scene, configs.helmet_camera, 320, 256, dict(RayDepth=2, DoRaySorting=1)),
+    ("helmet_d5", configs.helmet_scene, configs.helmet_camera, 320, 256, dict(RayDepth=5)),
+    ("helmet_d9_sort_aov", configs.helmet_scene, configs.helmet_camera, 160, 128, dict(RayDepth=9, DoRaySorting=1, OutputAOVs=1)),
+    ("helmet_refittable_lens_d4", lambda b: configs.helmet_scene(b, refittable=True), configs.helmet_camera, 160, 128, dict(RayDepth=4, FocalLength=2.8, LenseRadius=0.03)),
 ]
 
 
