@@ -277,9 +277,20 @@ def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, t
                 traffic, l2_hit, l1_miss, l2_miss = e.get("traversal_hbm_bytes_per_launch"), e.get("l2_hit_rate"), e.get("l1_miss_requests_per_launch"), e.get("l2_miss_requests_per_launch")
         except Exception:
             pass
-    out = {"bound": "vmem-gather", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": peak_hit, "unit": "GB/s",
-           "frac": round(achieved / peak_hit, 4) if peak_hit else None, "traffic": traffic,
-           "peak_source": "tools/ubench_lines.bin 16 0 32, run by this bench: independent random 64-B block fetches (4 x 16-B loads per lane), 4 MB set (L2 hits), 32 waves/CU",
+    # Two ceilings of the vector-memory path, both in GB/s of bytes delivered to the lanes:
+    #   gather  the rate at which the chip fetches INDEPENDENT 64-B blocks (every block an L1 miss served by L2), measured now by the ubench:
+    #           what binds incoherent traversal (bounce rays, the headline frame);
+    #   l1      the L1 -> register return path, 64 B/clk/CU at the 2.4 GHz maximum clock (MI355X_MICROARCH.md): nothing exceeds it, but only rays
+    #           that share cache lines (camera inside the scene: L1 hit rate 98 % on the primary launch) get beyond the gather ceiling.
+    # frac is taken against the tightest ceiling the kernel does not exceed, and says which one that is.
+    l1_peak = 64.0 * 256 * 2.4                       # GB/s
+    use_gather = bool(peak_hit) and achieved <= peak_hit
+    peak = peak_hit if use_gather else l1_peak
+    out = {"bound": "vmem-gather" if use_gather else "vmem-l1", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s",
+           "frac": round(achieved / peak, 4), "traffic": traffic,
+           "peak_source": ("tools/ubench_lines.bin 16 0 32, run by this bench: independent random 64-B block fetches (4 x 16-B loads per lane), 4 MB set (L2 hits), 32 waves/CU" if use_gather else
+                           "L1 return path 64 B/clk/CU x 256 CUs x 2.4 GHz (the measured gather ceiling is exceeded: the launch is L1-hit dominated)"),
+           "gather_ceiling": peak_hit, "frac_of_gather_ceiling": round(achieved / peak_hit, 4) if peak_hit else None, "l1_ceiling": round(l1_peak, 1), "frac_of_l1_ceiling": round(achieved / l1_peak, 4),
            "peak_l2_miss_set": peak_miss, "l2_hit_rate_pmc": l2_hit,
            "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": int(launches), "samples_per_launch": samples_per_launch,
            "node_pair_visits_per_step": int(pairs / max(1, args.steps * max(1, args.repeats))), "triangle_tests_per_step": int(tri_tests / max(1, args.steps * max(1, args.repeats))),

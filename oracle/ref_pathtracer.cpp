@@ -531,7 +531,7 @@ static void RenderSample(PT& pt)
     const clk::time_point tStart = clk::now();
     clk::time_point tp = tStart;
     // ---- FirstHit main (FirstHit/compute.glsl:44-98), one invocation per pixel ----
-    #pragma omp parallel for schedule(dynamic, 4)
+    #pragma omp parallel for schedule(dynamic, 1)
     for (int ly = 0; ly < rows; ly++) {
         int y = ly * pt.rowMod + pt.rowRem;
         for (int x = 0; x < W; x++) {
@@ -764,7 +764,7 @@ void ref_trace_rays(void* scene, int useTlas, const idkpt_ray* rays, size_t coun
 void ref_trace_shadows(void* scene, int useTlas, const idkpt_shadow_params* p, const float* depth, const float* normalOct, float* visibility)
 {
     const Scene& s = *(Scene*)scene;
-    #pragma omp parallel for schedule(dynamic, 4)
+    #pragma omp parallel for schedule(dynamic, 1)
     for (int y = 0; y < p->Height; y++) for (int x = 0; x < p->Width; x++) ShadowPixel(s, useTlas != 0, *p, x, y, depth, normalOct, visibility);
 }
 
