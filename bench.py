@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-frame and interior-view measurements")
     ap.add_argument("--view", choices=["headline", "interior"], default="headline", help="headline = BASELINE.json configs[2]; interior = camera inside the soup (secondary)")
+    ap.add_argument("--scene", choices=["soup", "atrium"], default="soup", help="soup = BASELINE.json configs[2] (headline); atrium = procedural Sponza-class hall of --tris triangles, camera inside (secondary)")
     ap.add_argument("--depth", type=int, default=RAY_DEPTH, help="RayDepth (headline = 2); other values are secondary-table runs")
     ap.add_argument("--sort", type=int, default=0, help="DoRaySorting (headline = 0)")
     ap.add_argument("--width", type=int, default=W, help="secondary-table runs only (headline = 1920)")
@@ -111,12 +112,12 @@ def main():
 
     # ---- scene: rank 0 builds (native SweepSAH + PreSplit builder), RCCL broadcast to the others
     t0 = time.time()
-    scene = S.soup_scene(args.tris, NativeBuilder(), seed=1) if rank == 0 else None
+    scene = (S.soup_scene(args.tris, NativeBuilder(), seed=1) if args.scene == "soup" else S.atrium_scene(args.tris, NativeBuilder())) if rank == 0 else None
     build_s = time.time() - t0
     if world > 1:
         scene = D.broadcast_scene(scene, src=0, device=device)
     W, H = args.width, args.height
-    cam = view_camera(S, args.view, W, H)
+    cam = view_camera(S, args.view, W, H) if args.scene == "soup" else S.atrium_camera(W, H)
 
     depth = args.depth
     if group > 1:
@@ -201,15 +202,16 @@ def main():
 
     if rank == 0:
         value = rays_rep / dt / 1e6
-        headline = (args.tris, depth, args.sort, W, H, args.batch, args.view) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world * group), "headline")
+        headline = (args.tris, depth, args.sort, W, H, args.batch, args.view, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world * group), "headline", "soup")
         view_txt = "camera at z = 25 outside the soup (SURVEY 8d config 3)" if args.view == "headline" else "camera INSIDE the soup at the origin"
         out = {
-            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri scene, {args.view} view (secondary config)", "value": round(value, 2), "unit": "Mray/s",
+            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri {args.scene} scene, {args.view if args.scene == 'soup' else 'interior'} view (secondary config)", "value": round(value, 2), "unit": "Mray/s",
             "n_gpus": world * group, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": reps, "repeat_ms": [round(x * 1e3, 3) for x in repeat_s], "statistic": "median repetition of the timed region",
             "traversed_mray_s": round(traversed_rep / dt / 1e6, 2),
-            "config": {"workload": f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, {view_txt}",
+            "config": {"workload": (f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, {view_txt}" if args.scene == "soup" else
+                                     f"atrium-{args.tris} (procedural two-storey colonnaded hall, connected surfaces, {len(scene.blas_triangles)} BLAS triangles, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, camera inside looking down the hall"),
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
                        "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather") if world > 1 else "none")),
                        "bvh_build_s": round(build_s, 2)},
@@ -217,7 +219,10 @@ def main():
         }
         if world * group == 1 and not args.no_extras:
             out["single_frame"] = single_frame(pt, depth)
-            out["interior"] = interior_extras(S, pt, W, H, B)
+            if args.scene == "soup":
+                out["interior"] = interior_extras(S, pt, W, H, B)
+                out["atrium"] = atrium_extras(S, NativeBuilder, pt, W, H, B)
+                pt.UploadScene(scene)
             pt.SetCamera(cam); pt.RayDepth = depth; pt.set_max_batch(B)
         if world * group == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, scene, depth, args.view)
@@ -270,7 +275,7 @@ def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, t
     # HBM-side bytes per launch from the committed PMC passes of this command (profiles/r02_traffic.json, keyed by view and samples per launch)
     traffic, l2_hit, l1_miss, l2_miss = None, None, None, None
     prof = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(prof) and (args.tris, args.depth, args.sort, args.width, args.height) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080):
+    if os.path.exists(prof) and (args.tris, args.depth, args.sort, args.width, args.height, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, "soup"):
         try:
             e = json.load(open(prof)).get(f"n{world}", {}).get(args.view, {}).get(f"s{samples_per_launch}")
             if e:
@@ -354,6 +359,23 @@ def interior_extras(S, pt, w, h, B):
                                 "primary_hit_fraction": round(st["alive_counts"][1] / float(w * h), 4) if depth > 1 else None}
         if depth == 2:
             out["depth2"]["single_frame"] = single_frame(pt, depth, frames=20)
+    return out
+
+
+def atrium_extras(S, NativeBuilder, pt, w, h, B):
+    """Secondary workload, the "Sponza-class" stand-in proper: a procedural colonnaded hall (connected surfaces, empty space, occlusion; the
+    reference's Sponza.gltf comes without its geometry buffer), camera inside, 1M triangles at RayDepth 2 and ~262 k triangles at RayDepth 5
+    (BASELINE.json configs[1]: Sponza ~260k tris, 1 spp, 4 bounces)."""
+    out = {"workload": "procedural atrium (idkengine_amd/scenes.py:atrium_scene), 1920x1080, camera inside looking down the hall, sort off"}
+    for tris, depth in ((1_000_000, 2), (262_000, 5)):
+        sc = S.atrium_scene(tris, NativeBuilder())
+        pt.UploadScene(sc); pt.SetCamera(S.atrium_camera(w, h)); pt.RayDepth = depth
+        rays, dt = timed_batch(pt, B, 2 * B)
+        st = pt.stats()
+        e = {"blas_triangles": int(len(sc.blas_triangles)), "mray_s": round(rays / dt / 1e6, 1), "ms_per_step": round(dt / (2 * B) * 1e3, 4), "rays_per_step": int(rays / (2 * B)),
+             "samples_in_flight": B, "primary_hit_fraction": round(st["alive_counts"][1] / float(w * h), 4)}
+        e["single_frame"] = single_frame(pt, depth, frames=20)
+        out[f"atrium_{tris // 1000}k_depth{depth}"] = e
     return out
 
 

@@ -404,3 +404,76 @@ def mesh_scene(npz_path, builder, material=None, refittable=False, sky_color=(0.
     tan = np.cross(nrm, axis); tan /= np.linalg.norm(tan, axis=1, keepdims=True)
     mat = material if material is not None else make_material((0.8, 0.78, 0.7, 1.0), roughness=0.55)
     return assemble([{"meshes": [MeshInput(pos, idx, mat, nrm.astype(np.float32), tan.astype(np.float32), uv)], "refittable": refittable, "transform": transform}], builder, sky_color=sky_color)
+
+
+# ----------------------------------------------------------------------------------------------- procedural atrium ("Sponza-class" stand-in)
+
+
+def _grid_mesh(fn, nu, nv, material, flip=False):
+    """Indexed (nu+1) x (nv+1) grid of the parametric surface fn(u, v) -> (x, y, z), u, v in [0, 1]; per-vertex normals / tangents from finite
+    differences; shared vertices like a real asset (Utils/ModelLoader.cs meshes)."""
+    u, v = np.meshgrid(np.linspace(0.0, 1.0, nu + 1), np.linspace(0.0, 1.0, nv + 1), indexing="ij")
+    P = np.stack(fn(u, v), -1).astype(np.float64)
+    du = np.gradient(P, axis=0); dv = np.gradient(P, axis=1)
+    n = np.cross(du, dv)
+    if flip:
+        n = -n
+    nl = np.linalg.norm(n, axis=-1, keepdims=True); nl[nl == 0] = 1.0; n = n / nl
+    t = du / np.maximum(np.linalg.norm(du, axis=-1, keepdims=True), 1e-12)
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    tri = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)]) if not flip else np.concatenate([np.stack([a, c, b], 1), np.stack([a, d, c], 1)])
+    uv = np.stack([u, v], -1).reshape(-1, 2).astype(np.float32)
+    return MeshInput(P.reshape(-1, 3).astype(np.float32), tri.astype(np.uint32), material, n.reshape(-1, 3).astype(np.float32), t.reshape(-1, 3).astype(np.float32), uv)
+
+
+def atrium_scene(target_tris, builder, seed=7, sky_color=(1.0, 1.0, 1.0)):
+    """A procedural two-storey colonnaded atrium (floor, outer walls with relief, two rows of columns on two levels, arches, gallery slabs,
+    hanging drapes, vases) tessellated to about `target_tris` triangles in ONE BLAS: the layout of the Sponza atrium BASELINE.json's configs[1]
+    and north_star's "Sponza-class scene" refer to (the reference checkout ships Sponza.gltf without its geometry buffer, so the real mesh is not
+    available).  Unlike the random soup, surfaces are connected 2-manifolds with shared vertices, large empty spaces and occlusion.
+    Hall: x in [-18, 18] (long axis), z in [-7, 7], y in [0, 12]; open to the sky."""
+    rng = np.random.default_rng(seed)
+    k = max(1.0, (target_tris / 42000.0) ** 0.5)                      # linear tessellation factor (the base model below has ~42 k triangles at k = 1)
+
+    def q(n):
+        return max(2, int(round(n * k)))
+    stone = make_material((0.72, 0.68, 0.6, 1.0)); floor_m = make_material((0.55, 0.5, 0.45, 1.0), roughness=0.6, metallic=0.05)
+    red = make_material((0.6, 0.12, 0.1, 1.0)); green = make_material((0.15, 0.45, 0.2, 1.0)); blue = make_material((0.15, 0.25, 0.6, 1.0))
+    bronze = make_material((0.8, 0.55, 0.3, 1.0), metallic=0.9, roughness=0.35)
+    meshes = []
+    bump = lambda u, v, a, f: a * np.sin(f * 6.28318 * u) * np.sin(f * 6.28318 * v)          # noqa: E731  (relief so that the walls are not two giant coplanar sheets)
+    # floor and gallery slabs
+    meshes.append(_grid_mesh(lambda u, v: (-18 + 36 * u, bump(u, v, 0.03, 9.0), -7 + 14 * v), q(64), q(28), floor_m, flip=True))
+    for zs in (-1, 1):
+        meshes.append(_grid_mesh(lambda u, v, zs=zs: (-18 + 36 * u, 6.0 + bump(u, v, 0.02, 7.0), zs * (4.2 + 2.8 * v)), q(64), q(8), stone, flip=zs > 0))   # gallery floor (seen from below)
+    # outer walls (long sides, two ends) with shallow relief and window-like recesses
+    for zs in (-1, 1):
+        meshes.append(_grid_mesh(lambda u, v, zs=zs: (-18 + 36 * u, 12 * v, zs * (7.0 - 0.25 * (np.sin(25.1327 * u) > 0.6) * (np.abs(v - 0.3) < 0.12) - bump(u, v, 0.04, 5.0))), q(72), q(30), stone, flip=zs < 0))
+    for xs in (-1, 1):
+        meshes.append(_grid_mesh(lambda u, v, xs=xs: (xs * (18.0 - bump(u, v, 0.05, 3.0)), 12 * v, -7 + 14 * u), q(30), q(30), stone, flip=xs > 0))
+    # columns (two rows, two levels) and arches between them
+    cols_x = np.linspace(-15.0, 15.0, 9)
+    for level, (y0, hgt, rad) in enumerate(((0.0, 5.2, 0.45), (6.0, 4.6, 0.35))):
+        for zs in (-1, 1):
+            for cx in cols_x:
+                meshes.append(_grid_mesh(lambda u, v, cx=cx, zs=zs, y0=y0, hgt=hgt, rad=rad: (cx + rad * (1 + 0.06 * np.cos(50.2655 * u)) * (1.0 - 0.12 * v) * np.cos(6.28318 * u), y0 + hgt * v,
+                                                                                            zs * 4.2 + rad * (1 + 0.06 * np.cos(50.2655 * u)) * (1.0 - 0.12 * v) * np.sin(6.28318 * u)), q(20), q(10), stone))
+            for cx0, cx1 in zip(cols_x[:-1], cols_x[1:]):
+                mid, half = 0.5 * (cx0 + cx1), 0.5 * (cx1 - cx0)
+                meshes.append(_grid_mesh(lambda u, v, mid=mid, half=half, zs=zs, y0=y0, hgt=hgt: (mid - half * np.cos(3.14159 * u), y0 + hgt + 0.8 * np.sin(3.14159 * u) * (0.55 + 0.45 * v),
+                                                                                              zs * (4.2 - 0.3 + 0.6 * v)), q(14), q(3), stone, flip=zs > 0))
+    # drapes hanging from the gallery (wavy sheets) and a row of vases (displaced spheres)
+    for i, cx in enumerate(np.linspace(-12.0, 12.0, 5)):
+        m = (red, green, blue)[i % 3]
+        ph = rng.uniform(0, 6.28)
+        meshes.append(_grid_mesh(lambda u, v, cx=cx, ph=ph: (cx - 1.6 + 3.2 * u, 5.8 - 4.2 * v, (-1) ** i * 3.6 + 0.25 * np.sin(18.85 * u + ph) * (0.3 + v)), q(26), q(22), m))
+    for cx in np.linspace(-13.5, 13.5, 7):
+        meshes.append(_grid_mesh(lambda u, v, cx=cx: (cx + (0.35 + 0.2 * np.sin(3.14159 * v) ** 2) * np.sin(3.14159 * v) ** 0.5 * np.cos(6.28318 * u), 0.05 + 1.3 * v,
+                                                     (0.35 + 0.2 * np.sin(3.14159 * v) ** 2) * np.sin(3.14159 * v) ** 0.5 * np.sin(6.28318 * u)), q(16), q(10), bronze))
+    return assemble([{"meshes": meshes}], builder, sky_color=sky_color)
+
+
+def atrium_camera(width, height):
+    """Standing in the courtyard near one end, looking down the hall and slightly up (the classic Sponza view)."""
+    return Camera(width, height, position=(-15.5, 2.2, 0.6), view_dir=(1.0, 0.12, -0.05), fovy_deg=70.0)

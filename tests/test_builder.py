@@ -36,6 +36,7 @@ CASES = [
     ("lucy", configs.lucy_scene),
     ("helmet", configs.helmet_scene),
     ("helmet_refit", lambda b: configs.helmet_scene(b, refittable=True)),
+    ("atrium", lambda b: S.atrium_scene(50000, b)),
 ]
 
 

@@ -45,6 +45,8 @@ MATRIX = [
     ("helmet_d2_sort", configs.helmet_scene, configs.helmet_camera, 320, 256, dict(RayDepth=2, DoRaySorting=1)),
     ("helmet_d5", configs.helmet_scene, configs.helmet_camera, 320, 256, dict(RayDepth=5)),
     ("helmet_d9_sort_aov", configs.helmet_scene, configs.helmet_camera, 160, 128, dict(RayDepth=9, DoRaySorting=1, OutputAOVs=1)),
+    ("atrium60k_d4", lambda b: S.atrium_scene(60000, b), S.atrium_camera, 256, 144, dict(RayDepth=4)),          # procedural Sponza-class hall: many meshes / materials, shared vertices
+    ("atrium60k_d6_sort_aov", lambda b: S.atrium_scene(60000, b), S.atrium_camera, 192, 108, dict(RayDepth=6, DoRaySorting=1, OutputAOVs=1)),
     ("helmet_refittable_lens_d4", lambda b: configs.helmet_scene(b, refittable=True), configs.helmet_camera, 160, 128, dict(RayDepth=4, FocalLength=2.8, LenseRadius=0.03)),
 ]
 
