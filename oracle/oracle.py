@@ -54,6 +54,7 @@ def lib():
         L.ref_pt_get_stats.argtypes = [C.c_void_p] * 5
         L.ref_pt_accumulated.restype = C.c_uint32; L.ref_pt_accumulated.argtypes = [C.c_void_p]
         L.ref_pt_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.ref_set_num_threads.argtypes = [C.c_int]; L.ref_get_max_threads.restype = C.c_int
         L.ref_cpu_trace_primary.restype = C.c_uint64
         L.ref_cpu_trace_primary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_pcg_hash.restype = C.c_uint32; L.ref_pcg_hash.argtypes = [C.POINTER(C.c_uint32)]
@@ -254,6 +255,11 @@ def _timing(self, reset=True):
 
 
 OraclePathTracer.timing = _timing
+
+
+def set_num_threads(n):
+    """OpenMP thread count of the oracle's parallel sections (bench.py's cpu_baseline picks the count the host scales to)."""
+    lib().ref_set_num_threads(int(n))
 
 
 def cpu_trace_primary(scene, cam, width, height, y0=0, y1=None, threads=0, want_hits=True, count=False):

@@ -12,6 +12,7 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <omp.h>
 #include "ref_math.h"
 #include "../include/idkpt.h"
 
@@ -803,6 +804,8 @@ void ref_pt_get_primary_hits(void* p, float* t, uint32_t* tri, float* bary) { PT
 uint32_t ref_pt_get_alive(void* p, uint32_t* out, uint32_t cap) { PT* pt = (PT*)p; uint32_t n = (uint32_t)pt->alive.size(); if (out) memcpy(out, pt->alive.data(), 4 * (size_t)std::min(n, cap)); return n; }
 void ref_pt_get_stats(void* p, uint64_t* raysTraced, uint64_t* pairs, uint64_t* tris, uint32_t* aliveCounts16) { PT* pt = (PT*)p; *raysTraced = pt->raysTraced; *pairs = pt->counters.pairs; *tris = pt->counters.tris; memcpy(aliveCounts16, pt->aliveCounts, 64); }
 uint32_t ref_pt_accumulated(void* p) { return ((PT*)p)->accumulated; }
+void ref_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }   // cpu_baseline leg of bench.py: pick the thread count the host actually scales to
+int ref_get_max_threads(void) { return omp_get_max_threads(); }
 void ref_pt_get_timing(void* p, double* parallelSec, double* totalSec, int reset) { PT* pt = (PT*)p; *parallelSec = pt->parallelSec; *totalSec = pt->totalSec; if (reset) { pt->parallelSec = 0.0; pt->totalSec = 0.0; } }
 
 // ---- KAT helpers (tests/test_oracle_kats.py) ----
