@@ -1,0 +1,145 @@
+"""Mint tests/golden/glref/*.npz: outputs of the REFERENCE's own GLSL shaders (run by oracle/glref/glref.py on Mesa
+llvmpipe) for every case of tests/golden/glref_cases.py.  Runs only in the build container (/root/reference + Mesa
+swrast); the fixtures travel to the GPU box, this script's inputs do not.
+
+    python oracle/glref/make_vectors.py [case ...]            (re)generate fixtures + summary
+    python oracle/glref/make_vectors.py --check [case ...]    regenerate in memory, compare with the committed fixtures bit for bit
+    python oracle/glref/make_vectors.py --defect-d1           demonstrate reference defect D1 (glref.py ADAPTATIONS A7), JSON on stdout
+
+Per case the fixture holds
+  * stage vectors ("forced"): FirstHit's full output (ray records + alive queue), and for every bounce j the output of
+    ONE NHit dispatch of the reference started from the ORACLE's state after j-1 bounces (sha256 of that input state is
+    stored, so a drifting oracle is detected) — every bounce is compared from identical inputs;
+  * free-run vectors: the reference's whole frame(s) (Result image, AOV images, alive counts per bounce), queue kept in
+    the canonical order between dispatches (glref.py docstring).
+A summary (bit-equal fractions, worst deviations, flipped decisions vs the oracle) goes to tests/golden/glref/summary.json.
+"""
+import hashlib
+import json
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+OUT = os.path.join(ROOT, "tests", "golden", "glref")
+
+
+def state_hash(rays, queue):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(rays).tobytes() + np.ascontiguousarray(queue, np.uint32).tobytes()).digest(), np.uint8)
+
+
+def defect_d1():
+    """Runs the reference's RaySorting exactly in the reference's host order (no A7) and reports what Reorder does."""
+    from oracle.glref import glref as G
+    from oracle import oracle as O
+    from idkengine_amd import gputypes as T
+    import configs
+    import glref_cases
+    fac, camf, w, h, ov = glref_cases.GLREF_CASES["presplit_sort_d4"]
+    sc = fac(O.OracleBuilder()); cam = camf(w, h)
+    st = configs.apply_settings(T.Settings.default(), ov); st.RayDepth = 3
+    rep = {}
+    for fix in (False, True):
+        pt = G.ReferencePathTracer(sc, w, h, st, sort_count_fix=fix); pt.set_camera(cam)
+        seen = {}
+        inner = pt._ray_sorting
+
+        def spy():
+            hdr = pt.header()
+            new = 1 - hdr["pingpong"] if not fix else hdr["pingpong"]
+            cnt = int(hdr["counts"][new])
+            before = pt.alive_queue(cnt); keys = pt._u32(pt.b_keys, 0, cnt)
+            item_count_seen_by_reorder = int(hdr["counts"][hdr["pingpong"]])
+            inner()
+            after = pt.alive_queue(cnt)
+            seen.update(alive=cnt, reorder_item_count=item_count_seen_by_reorder, dispatched_invocations=int(hdr["groups"][0]) * 32,
+                        is_permutation=bool(np.array_equal(np.sort(before), np.sort(after))),
+                        equals_stable_sort=bool(np.array_equal(after, before[np.argsort(keys, kind="stable")])))
+        pt._ray_sorting = spy
+        pt.render()
+        rep["with_A7" if fix else "reference_order"] = seen
+        pt.close()
+    print(json.dumps(rep))
+
+
+def main(names, check=False):
+    from oracle.glref import glref as G
+    from oracle import oracle as O
+    from idkengine_amd import gputypes as T
+    import configs
+    import glref_cases
+    import glref_check
+    os.makedirs(OUT, exist_ok=True)
+    B = O.OracleBuilder()
+    summary_path = os.path.join(OUT, "summary.json")
+    summary = json.load(open(summary_path)) if os.path.exists(summary_path) else {}
+    failed = []
+    for name in names or list(glref_cases.GLREF_CASES):
+        fac, camf, w, h, ov = glref_cases.GLREF_CASES[name]
+        sc = fac(B); cam = camf(w, h)
+        st = configs.apply_settings(T.Settings.default(), ov)
+        depth, spp = int(st.RayDepth), int(st.SamplesPerPixel)
+        out = {"mesa": np.frombuffer(G.gl().glref_info(), np.uint8), "depth": depth, "spp": spp, "width": w, "height": h}
+        # ---- free run: the reference's own frame(s)
+        pt = G.ReferencePathTracer(sc, w, h, st); pt.set_camera(cam)
+        for _ in range(spp):
+            pt.render()
+        out["free_image"] = pt.image(0)
+        if st.OutputAOVs:
+            out["free_albedo"] = pt.image(1); out["free_normal"] = pt.image(2)
+        out["free_counts"] = np.array(pt.alive_counts, np.uint32)
+        out["free_final_alive"] = pt.final_alive
+        pt.close()
+        # ---- stage vectors (sample 0)
+        def oracle_state(d):
+            o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov)
+            o.settings.RayDepth = d; o.settings.SamplesPerPixel = 1
+            o.render()
+            r, q = o.rays(), o.alive_queue(); o.close()
+            return r, q
+        st1 = configs.apply_settings(T.Settings.default(), ov); st1.RayDepth = 1; st1.SamplesPerPixel = 1
+        pt = G.ReferencePathTracer(sc, w, h, st1); pt.set_camera(cam)
+        pt.render()
+        out["fh_rays"] = pt.rays(T.GpuWavefrontRay); out["fh_queue"] = pt.final_alive
+        pt.accumulated = 0                                   # the stage vectors are all of sample 0
+        if not st.Gpu.DoDebugBVHTraversal:
+            prev_out = None
+            for j in range(1, depth):
+                rin, qin = oracle_state(j)
+                if st.DoRaySorting and j > 1 and not np.array_equal(prev_out, qin):
+                    print(f"  {name}: bounce {j} not comparable from forced inputs (the reference's bounce {j - 1} queue differs; no sort keys for it)")
+                    break
+                rout, qout = pt.run_nhit_from(rin, qin, j, sort_first=bool(st.DoRaySorting))
+                prev_out = qout
+                out[f"in_hash_{j}"] = state_hash(rin, qin)
+                out[f"out_rays_{j}"] = rout[qin]; out[f"out_queue_{j}"] = qout
+        pt.close()
+        if check:
+            fx = np.load(os.path.join(OUT, name + ".npz"))
+            bad = [k for k in out if k != "mesa" and not (k in fx and np.asarray(out[k]).tobytes() == np.asarray(fx[k]).tobytes())]
+            bad += [k for k in fx.files if k not in out]
+            print(name, "reproduced" if not bad else f"DIFFERS in {bad}", flush=True)
+            if bad:
+                failed.append(name)
+            continue
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        # ---- summary against the oracle of today
+        fx = np.load(os.path.join(OUT, name + ".npz"))
+        o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.render()
+        rep = glref_check.check_case(fx, oracle_state, dict(image=o.image(0), counts=o.stats()["alive_counts"], albedo=o.image(1) if st.OutputAOVs else None,
+                                                           normal=o.image(2) if st.OutputAOVs else None), strict=False)
+        o.close()
+        summary[name] = rep
+        print(name, json.dumps(rep), flush=True)
+    if check:
+        sys.exit(1 if failed else 0)
+    json.dump(summary, open(summary_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    if "--defect-d1" in args:
+        defect_d1()
+    else:
+        main([a for a in args if not a.startswith("--")], check="--check" in args)

@@ -1,7 +1,8 @@
 """ctypes front-end of the CPU oracle (oracle/liboracle.so).
 
 TEST INFRASTRUCTURE ONLY — may be imported from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
-never from the product package.  PARITY UNPINNED (see ref_math.h): the reference has no golden vectors for this path.
+never from the product package.  The GLSL half (path tracer, ray queries) is pinned against the reference's own shaders run on
+llvmpipe (oracle/glref/, tests/golden/glref/); the C# half (BVH builder, CPU tracer) is unpinned (see ref_math.h).
 """
 import ctypes as C
 import os

@@ -1,4 +1,4 @@
-// ORACLE (test infrastructure only; PARITY UNPINNED, see ref_math.h header).
+// ORACLE (test infrastructure only; PARITY UNPINNED for this C# half, see ref_math.h header).
 // Sequential restatement of the reference's CPU BVH builder.  All citations relative to
 // /root/reference/IDKEngine/Source.  Arithmetic notes:
 //   * Box min/max follow x86 minps/maxps (Vector128.MinNative/MaxNative, Shapes/Box.cs:40-50): r = a<b ? a : b.

@@ -1,4 +1,4 @@
-// ORACLE (test infrastructure only; PARITY UNPINNED, see ref_math.h header).
+// ORACLE (test infrastructure only; PARITY UNPINNED for this C# half, see ref_math.h header).
 // C++ stand-in for the reference's "C# CPU BVH traverse path" (BASELINE.json configs[0]):
 //   Gui.Test (Source/Render/Gui.cs:1484-1503) -> BVH.Intersect (Source/Bvh/BVH.cs:162-193, no TLAS)
 //   -> BLAS.Intersect (Source/Bvh/BLAS.cs:313-386) -> Intersections.RayVsBox / RayVsTriangle

@@ -1,8 +1,13 @@
 // ORACLE (test infrastructure, never shipped, never on the product path).
-// PARITY UNPINNED: the reference has no tests/golden vectors for this path and neither
-// .NET nor an OpenGL/GLSL implementation exists in this environment, so this restatement cannot be checked
-// against reference outputs.  It is pinned only by published known-answers of the third-party algorithms it
-// contains (tests/test_oracle_kats.py) and by self-consistency checks.
+// PARITY: the GLSL half of the path (FirstHit / NHit / FinalDraw / CountingSort and everything they include —
+// ref_math.h, ref_pathtracer.cpp) is PINNED against the reference itself: the reference's own shaders, read from
+// /root/reference and executed by Mesa llvmpipe (oracle/glref/), produce the vectors under tests/golden/glref/, and
+// tests/test_glref.py holds this restatement to them (every bounce from identical inputs: no flipped decision, every
+// value within 1e-4 relative, ~97 % of the words bit-identical; llvmpipe's own `/`, inversesqrt and transcendentals
+// are the remainder).  The C# half (ref_bvh_build.cpp, ref_cpu_baseline.cpp) stays UNPINNED: no .NET here, and the
+// reference has no tests or golden vectors; it is anchored by published known-answers of the
+// third-party algorithms it contains (tests/test_oracle_kats.py), by the brute-force / metamorphic second opinion
+// (tests/test_metamorphic.py) and by the fact that the reference's shaders traverse the trees it builds to the same hits.
 //
 // ref_math.h — the arithmetic contract shared by every oracle function: IEEE-754 binary32, one rounding per
 // written operation, NO contraction (compile with -ffp-contract=off), left-to-right evaluation of GLSL

@@ -1,4 +1,4 @@
-// ORACLE (test infrastructure only; PARITY UNPINNED, see ref_math.h header).
+// ORACLE (test infrastructure only).  PINNED against the reference's own shaders run on llvmpipe (oracle/glref/, tests/test_glref.py; see ref_math.h header).
 // Sequential CPU restatement of the reference's wavefront path tracer in GLSL semantics, executed in the canonical
 // order SURVEY.md §8c fixes (the reference itself is order-nondeterministic through atomicAdd slots):
 //   FirstHit enqueues in increasing pixel index, NHit in increasing old slot, Reorder is a stable counting sort.

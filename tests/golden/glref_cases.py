@@ -1,0 +1,51 @@
+"""Cases the oracle (and through it the HIP path) is PINNED on against the reference's own GLSL shaders executed
+by Mesa llvmpipe (oracle/glref/).  Shared by the generator (oracle/glref/make_vectors.py, runs only where
+/root/reference exists), the CPU tests (oracle vs fixtures) and the GPU tests (HIP path vs fixtures).
+
+name: (scene factory(builder), camera factory(w, h), w, h, settings overrides)
+"""
+import numpy as np
+from idkengine_amd import scenes as S
+import configs
+
+
+def _lights_scene(b):
+    from idkengine_amd import gputypes as T
+    sc = S.cornell_scene(b, "mixed")
+    lights = np.zeros(2, T.GpuLight)
+    lights[0]["Position"] = (0.3, 0.2, 0.4); lights[0]["Radius"] = 0.18; lights[0]["Color"] = (6.0, 5.0, 3.0); lights[0]["PointShadowIndex"] = -1
+    lights[1]["Position"] = (-0.5, -0.4, 0.1); lights[1]["Radius"] = 0.1; lights[1]["Color"] = (1.0, 2.0, 8.0); lights[1]["PointShadowIndex"] = -1
+    sc.lights = lights
+    return sc
+
+
+def _alpha_scene(b):
+    m = S.cornell_meshes("mixed")
+    m["short"].material = S.make_material((0.9, 0.3, 0.3, 0.4), alpha_cutoff=2.0)     # stochastic blend
+    m["tall"].material = S.make_material((0.3, 0.9, 0.3, 0.3), alpha_cutoff=0.5)      # cut-off: passes through
+    return S.assemble([{"meshes": m["walls"] + [m["short"], m["tall"]]}], b, sky_color=(0.2, 0.2, 0.2))
+
+
+def _textured_scene(b):
+    rng = np.random.default_rng(5)
+    m = S.cornell_meshes("diffuse")
+    for part, scale in (("tall", 1.0), ("short", 3.0)):                                  # uv > 1 on "short": repeat wrap
+        m[part].uvs = (rng.uniform(0, 1, (len(m[part].positions), 2)) * scale).astype(np.float32)
+    m["tall"].material["BaseColorTexture"] = 1; m["tall"].material["EmissiveTexture"] = 2; m["tall"].material["EmissiveFactor"] = (0.5, 0.5, 0.5)
+    m["short"].material["BaseColorTexture"] = 3; m["short"].material["MetallicRoughnessTexture"] = 1
+    m["short"].material["MetallicFactor"] = 0.8; m["short"].material["RoughnessFactor"] = 0.6
+    sc = S.assemble([{"meshes": m["walls"] + [m["short"], m["tall"]]}], b, sky_color=(0.3, 0.4, 0.6))
+    sc.textures = [rng.uniform(0.2, 1.0, (8, 8, 4)).astype(np.float32), np.float32([[[0.2, 0.7, 0.1, 1.0]]]),
+                   rng.uniform(0.0, 1.0, (5, 3, 4)).astype(np.float32)]
+    return sc
+
+
+GLREF_CASES = dict(configs.CASES)
+GLREF_CASES.update({
+    "cornell_lights_d5": (_lights_scene, S.cornell_camera, 64, 64, dict(RayDepth=5, DoTraceLights=1)),
+    "cornell_lights_sort_d4": (_lights_scene, S.cornell_camera, 64, 64, dict(RayDepth=4, DoTraceLights=1, DoRaySorting=1)),
+    "cornell_alpha_d6": (_alpha_scene, S.cornell_camera, 64, 64, dict(RayDepth=6)),
+    "cornell_textured_aov_d5": (_textured_scene, S.cornell_camera, 64, 64, dict(RayDepth=5, OutputAOVs=1)),
+    "cornell_odd_size_d3": (lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 53, 37, dict(RayDepth=3)),
+    "soup_multi_tlas_d3": (lambda b: S.soup_scene_multi(6000, b, parts=3, seed=4), lambda w, h: S.Camera(w, h), 96, 54, dict(RayDepth=3, UseTlas=1)),
+})

@@ -1,0 +1,96 @@
+"""The oracle PINNED against the reference itself: tests/golden/glref/*.npz hold outputs of the reference's own GLSL
+path-tracer shaders (FirstHit / NHit / FinalDraw / CountingSort, read from /root/reference and executed by Mesa llvmpipe
+through oracle/glref/).  Here the CPU oracle is compared with them — every bounce from identical inputs, plus the
+reference's free-running frame; tests/test_gpu_glref.py does the same for the HIP path.
+
+The fixtures travel; the generator needs /root/reference + Mesa swrast and is exercised by the `live` tests, which skip
+elsewhere (e.g. on the GPU box)."""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden")); sys.path.insert(0, HERE)
+import configs  # noqa: E402
+import glref_cases  # noqa: E402
+import glref_check  # noqa: E402
+
+FIXTURES = os.path.join(HERE, "golden", "glref")
+
+
+def _live():
+    return os.path.isdir("/root/reference/IDKEngine/Resource/Shaders") and os.path.exists("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")
+
+
+live = pytest.mark.skipif(not _live(), reason="needs /root/reference and Mesa llvmpipe (build container only)")
+
+
+def test_every_case_has_a_fixture():
+    have = {f[:-4] for f in os.listdir(FIXTURES) if f.endswith(".npz")}
+    assert have == set(glref_cases.GLREF_CASES)
+    summary = json.load(open(os.path.join(FIXTURES, "summary.json")))
+    assert set(summary) == have
+
+
+@pytest.mark.parametrize("name", list(glref_cases.GLREF_CASES))
+def test_oracle_matches_reference_shaders(name, oracle_mod):
+    from idkengine_amd import gputypes as T
+    O = oracle_mod
+    fac, camf, w, h, ov = glref_cases.GLREF_CASES[name]
+    sc = fac(O.OracleBuilder()); cam = camf(w, h)
+    fx = np.load(os.path.join(FIXTURES, name + ".npz"))
+    assert (int(fx["width"]), int(fx["height"])) == (w, h)
+
+    def state_at(d):
+        o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov)
+        o.settings.RayDepth = d; o.settings.SamplesPerPixel = 1
+        o.render()
+        r, q = o.rays(), o.alive_queue(); o.close()
+        return r, q
+    o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.render()
+    aov = bool(configs.apply_settings(T.Settings.default(), ov).OutputAOVs)
+    final = dict(image=o.image(0), counts=o.stats()["alive_counts"], albedo=o.image(1) if aov else None, normal=o.image(2) if aov else None)
+    o.close()
+    rep = glref_check.check_case(fx, state_at, final, strict=True)
+    # what the committed fixtures show today (tests/golden/glref/summary.json): not one flipped decision, not one value beyond tolerance
+    assert all(s["flips"] == 0 and s["beyond_tol"] == 0 and s["queue_identical"] for s in rep["stages"]), rep
+
+
+@live
+def test_live_fixtures_are_reproducible():
+    """Re-runs the reference's shaders on llvmpipe for three cases and demands the committed fixtures bit for bit
+    (separate process: Mesa brings its own LLVM, keep it away from this one)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "make_vectors.py"), "--check", "cornell_mixed_d5", "helmet_sort_d4", "cornell_textured_aov_d5"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@live
+def test_live_reference_defect_d1_reorder_item_count():
+    """Reference defect D1 (oracle/glref/glref.py ADAPTATIONS A7): in the reference's host order Reorder bounds-checks against the
+    PREVIOUS bounce's count, so its tail invocations re-insert stale entries and the 'sorted' queue is not a permutation of the alive
+    queue.  With PingPongIndex uploaded first (A7) the reference's shaders produce exactly the stable counting sort the oracle states."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "make_vectors.py"), "--defect-d1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    bug, fixed = rep["reference_order"], rep["with_A7"]
+    assert bug["reorder_item_count"] > bug["alive"] and bug["dispatched_invocations"] > bug["alive"] and not bug["is_permutation"]
+    assert fixed["reorder_item_count"] == fixed["alive"] and fixed["is_permutation"] and fixed["equals_stable_sort"]
+
+
+@live
+def test_live_preprocessor_follows_the_reference():
+    """AppInclude is include-once, AppInsert falls back to 0, unreferenced storage blocks are dropped (BBG/Source/Objects/Shader.cs:177-335)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from oracle.glref import glref as G\n"
+            "s = G.preprocess('PathTracing/NHit/compute.glsl', {'USE_TLAS': '1', 'BLAS_STACK_SIZE': '17'})\n"
+            "assert s.count('struct GpuBlasNode') == 1 and 'AppInclude' not in s and 'AppInsert' not in s\n"
+            "assert '#define USE_TLAS 1' in s and 'max(17, 1)' in s and '#define PATH_TRACER_DO_RAY_SORTING 0' in s\n"
+            "assert 'drawElementsCmdSSBO' not in s and 'wavefrontPTSSBO' in s and 'tlasSSBO' in s\n"
+            "assert s.startswith('#version 460 core') and '#define APP_SHADER_STAGE_COMPUTE 1' in s\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

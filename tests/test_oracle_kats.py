@@ -1,5 +1,6 @@
 """Known-answer / property tests that pin the oracle's third-party building blocks (the reference ships no tests, so
-these published algorithms are the only external anchors; see oracle/ref_math.h "PARITY UNPINNED")."""
+these published algorithms anchor the pieces individually; the path as a whole is pinned against the reference's own shaders in
+tests/test_glref.py, see oracle/ref_math.h)."""
 import ctypes as C
 import math
 import numpy as np
