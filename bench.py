@@ -497,7 +497,17 @@ def cpu_baseline(S, scene, depth, view):
     while p_dt < 3.0:
         t0 = time.perf_counter(); rr = O.cpu_trace_primary(scene, cam, W, H, threads=cores, want_hits=False); p_dt += time.perf_counter() - t0
         p_rays += int(rr["rays"])
-    out = {"value": head["value"], "unit": "Mray/s", "cores": cores, "hw_threads": hw_threads, "cpu": cpu_model(), "kind": "port", "parallel_section_mray_s": head["parallel_section"],
+    quota = None
+    try:                                                    # a container CPU quota explains a host that stops scaling early
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = None
+    out = {"value": head["value"], "unit": "Mray/s", "cores": cores, "hw_threads": hw_threads, "cgroup_cpu_quota": quota, "sched_affinity": affinity, "cpu": cpu_model(), "kind": "port", "parallel_section_mray_s": head["parallel_section"],
            "mray_s_per_core": head["per_core"], "sample": head["sample"] + f"; {cores} OpenMP threads (the fastest of 16/32/64/128/{hw_threads} on a probe: this host does not scale beyond that); C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET); scene and threads warm",
            "primary_only_csharp_semantics": {"value": round(p_rays / p_dt / 1e6, 3), "unit": "Mray/s", "per_core": round(p_rays / p_dt / 1e6 / cores, 4),
                                              "sample": f"{p_rays // (W * H)} full {W}x{H} frames of centre-of-pixel primary rays, closest hit only (no shading), {p_dt:.1f} s"},

@@ -348,6 +348,39 @@ DEV float4 SampleTex(const DScene& s, uint64_t handle, float u, float v)
     return make_float4(gmix(gmix(a.x, b.x, ax), gmix(c.x, d.x, ax), ay), gmix(gmix(a.y, b.y, ax), gmix(c.y, d.y, ax), ay),
                        gmix(gmix(a.z, b.z, ax), gmix(c.z, d.z, ax), ay), gmix(gmix(a.w, b.w, ax), gmix(c.w, d.w, ax), ay));
 }
+// texture(skyBoxUBO.Albedo, dir) on the reference's GL_LINEAR, seamless cube map (Render/SkyBoxManager.cs:44,74): table 8.19 face
+// selection, linear filter at LOD 0; a texel one step beyond a face edge is the adjacent face's texel it folds onto (integer lattice,
+// exact), the ownerless texel beyond a corner is the mean of the footprint's other three.  S == 1 = constant colour per face, unfiltered.
+DEV void SkyFold(int S, int& face, int& x, int& y)
+{
+    int sc = 2 * x + 1 - S, tc = 2 * y + 1 - S;
+    int px, py, pz;
+    switch (face) {
+        case 0: px = S; py = -tc; pz = -sc; break;
+        case 1: px = -S; py = -tc; pz = sc; break;
+        case 2: py = S; px = sc; pz = tc; break;
+        case 3: py = -S; px = sc; pz = -tc; break;
+        case 4: pz = S; px = sc; py = -tc; break;
+        default: pz = -S; px = -sc; py = -tc; break;
+    }
+    const int m = face >> 1;
+    const bool ox = m != 0 && (px > S || px < -S), oy = m != 1 && (py > S || py < -S), oz = m != 2 && (pz > S || pz < -S);
+    if (!(ox || oy || oz)) return;
+    const int in = S - 1;
+    if (m == 0) px = px > 0 ? in : -in; else if (m == 1) py = py > 0 ? in : -in; else pz = pz > 0 ? in : -in;
+    if (oz) { pz = pz > 0 ? S : -S; face = pz > 0 ? 4 : 5; }          // (at most one axis overflows: corners never get here)
+    else if (oy) { py = py > 0 ? S : -S; face = py > 0 ? 2 : 3; }
+    else { px = px > 0 ? S : -S; face = px > 0 ? 0 : 1; }
+    switch (face) {
+        case 0: sc = -pz; tc = -py; break;
+        case 1: sc = pz; tc = -py; break;
+        case 2: sc = px; tc = pz; break;
+        case 3: sc = px; tc = -pz; break;
+        case 4: sc = px; tc = -py; break;
+        default: sc = -px; tc = -py; break;
+    }
+    x = (sc + S - 1) / 2; y = (tc + S - 1) / 2;
+}
 DEV f3 SampleSky(const DScene& s, f3 d)
 {
     if (s.skySize <= 0) return splat3(0.0f);
@@ -356,13 +389,35 @@ DEV f3 SampleSky(const DScene& s, f3 d)
     if (ax >= ay && ax >= az) { face = d.x >= 0.0f ? 0 : 1; sc = d.x >= 0.0f ? -d.z : d.z; tc = -d.y; ma = ax; }
     else if (ay >= az) { face = d.y >= 0.0f ? 2 : 3; sc = d.x; tc = d.y >= 0.0f ? d.z : -d.z; ma = ay; }
     else { face = d.z >= 0.0f ? 4 : 5; sc = d.z >= 0.0f ? d.x : -d.x; tc = -d.y; ma = az; }
-    int S = s.skySize, x = 0, y = 0;
-    if (S > 1) {
-        float u = 0.5f * (sc / ma + 1.0f), v = 0.5f * (tc / ma + 1.0f);
-        x = (int)gmin(gmax(gfloor(u * (float)S), 0.0f), (float)(S - 1)); y = (int)gmin(gmax(gfloor(v * (float)S), 0.0f), (float)(S - 1));
+    const int S = s.skySize;
+    if (S == 1) { float4 p = s.sky[face]; return mk3(p.x, p.y, p.z); }
+    float u = 0.5f * (sc / ma + 1.0f), v = 0.5f * (tc / ma + 1.0f);
+    float fx = u * (float)S - 0.5f, fy = v * (float)S - 0.5f;
+    float x0f = gfloor(fx), y0f = gfloor(fy);
+    float wx = fx - x0f, wy = fy - y0f;
+    const int x0 = (int)gmin(gmax(x0f, -1.0f), (float)(S - 1)), y0 = (int)gmin(gmax(y0f, -1.0f), (float)(S - 1));
+    f3 t[4]; bool corner[4]; bool anyCorner = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int x = x0 + (k & 1), y = y0 + (k >> 1), f2 = face;
+        corner[k] = (x < 0 || x >= S) && (y < 0 || y >= S);
+        t[k] = splat3(0.0f);
+        if (corner[k]) { anyCorner = true; continue; }
+        SkyFold(S, f2, x, y);
+        float4 p = s.sky[((size_t)f2 * S + y) * S + x];
+        t[k] = mk3(p.x, p.y, p.z);
     }
-    float4 p = s.sky[((size_t)face * S + y) * S + x];
-    return mk3(p.x, p.y, p.z);
+    if (anyCorner) {
+        f3 sum = splat3(0.0f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (!corner[k]) sum = sum + t[k];
+        const f3 mean = mk3(sum.x / 3.0f, sum.y / 3.0f, sum.z / 3.0f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (corner[k]) t[k] = mean;
+    }
+    return mk3(gmix(gmix(t[0].x, t[1].x, wx), gmix(t[2].x, t[3].x, wx), wy),
+               gmix(gmix(t[0].y, t[1].y, wx), gmix(t[2].y, t[3].y, wx), wy),
+               gmix(gmix(t[0].z, t[1].z, wx), gmix(t[2].z, t[3].z, wx), wy));
 }
 
 // ---------------------------------------------------------------------------------------------------------------

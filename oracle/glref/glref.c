@@ -80,6 +80,7 @@ GLFN(void, glFinish, void);
 GLFN(GLint, glGetUniformLocation, GLuint, const GLchar *);
 GLFN(void, glProgramUniform1i, GLuint, GLint, GLint);
 GLFN(void, glPixelStorei, GLenum, GLint);
+GLFN(void, glEnable, GLenum);
 
 #define LOAD(name) do { p_##name = gpa(#name); if (!p_##name) { snprintf(g_info, sizeof g_info, "missing GL entry point %s", #name); return -4; } } while (0)
 
@@ -120,9 +121,10 @@ int glref_init(void)
     LOAD(glCreateTextures); LOAD(glDeleteTextures); LOAD(glTextureStorage2D); LOAD(glTextureSubImage2D); LOAD(glTextureSubImage3D);
     LOAD(glTextureParameteri); LOAD(glGetTextureImage); LOAD(glBindTextureUnit); LOAD(glBindImageTexture);
     LOAD(glDispatchCompute); LOAD(glDispatchComputeIndirect); LOAD(glMemoryBarrier); LOAD(glFinish);
-    LOAD(glGetUniformLocation); LOAD(glProgramUniform1i); LOAD(glPixelStorei);
+    LOAD(glGetUniformLocation); LOAD(glProgramUniform1i); LOAD(glPixelStorei); LOAD(glEnable);
     snprintf(g_info, sizeof g_info, "%s | %s", (const char *)p_glGetString(GL_VERSION), (const char *)p_glGetString(GL_RENDERER));
     p_glPixelStorei(GL_UNPACK_ALIGNMENT, 1); p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+    p_glEnable(GL_TEXTURE_CUBE_MAP_SEAMLESS);        /* Texture.TryEnableSeamlessCubemap (Render/SkyBoxManager.cs:74) */
     g_ready = 1;
     return 0;
 }

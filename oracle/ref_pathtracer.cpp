@@ -256,7 +256,40 @@ static RGBA SampleTex(const Scene& s, uint64_t handle, v2 uv)
     }
     RGBA o = {c[0], c[1], c[2], c[3]}; return o;
 }
-// Cube map lookup (GL 4.6 spec table 8.19 face selection, nearest texel; S=1 gives the constant face colour)
+// Sky lookup = texture(skyBoxUBO.Albedo, dir) on a GL_LINEAR, seamless cube map (Render/SkyBoxManager.cs:44,74; FirstHit:227, NHit:208).
+// Face selection and (s,t): GL 4.6 spec table 8.19.  Linear filter at LOD 0: texel centres at (i+0.5)/S, weights frac(u*S-0.5).
+// Seamless: a texel one step beyond a face edge is the texel of the adjacent face it folds onto (SkyFold, exact integer lattice);
+// the one texel beyond a face CORNER has no owner and is the mean of the three other texels of the footprint (the behaviour the GL
+// spec recommends, section 8.14.1).  S = 1 is this library's "constant colour per face" stand-in and stays unfiltered.
+static inline void SkyFold(int S, int& face, int& x, int& y)
+{
+    int sc = 2 * x + 1 - S, tc = 2 * y + 1 - S;          // lattice coordinates of the texel centre: the face spans (-S, S), centres 2 apart
+    int p[3];
+    switch (face) {                                       // inverse of table 8.19: (face, sc, tc) -> point on the cube of half-size S
+        case 0: p[0] = S; p[1] = -tc; p[2] = -sc; break;
+        case 1: p[0] = -S; p[1] = -tc; p[2] = sc; break;
+        case 2: p[1] = S; p[0] = sc; p[2] = tc; break;
+        case 3: p[1] = -S; p[0] = sc; p[2] = -tc; break;
+        case 4: p[2] = S; p[0] = sc; p[1] = -tc; break;
+        default: p[2] = -S; p[0] = -sc; p[1] = -tc; break;
+    }
+    const int m = face >> 1;
+    int o = -1;
+    for (int k = 0; k < 3; k++) if (k != m && (p[k] > S || p[k] < -S)) o = k;
+    if (o < 0) return;                                     // inside the face
+    p[m] = p[m] > 0 ? S - 1 : -(S - 1);                    // one step beyond the edge folds to the outermost row of the neighbour
+    p[o] = p[o] > 0 ? S : -S;
+    face = 2 * o + (p[o] > 0 ? 0 : 1);
+    switch (face) {
+        case 0: sc = -p[2]; tc = -p[1]; break;
+        case 1: sc = p[2]; tc = -p[1]; break;
+        case 2: sc = p[0]; tc = p[2]; break;
+        case 3: sc = p[0]; tc = -p[2]; break;
+        case 4: sc = p[0]; tc = -p[1]; break;
+        default: sc = -p[0]; tc = -p[1]; break;
+    }
+    x = (sc + S - 1) / 2; y = (tc + S - 1) / 2;
+}
 static v3 SampleSky(const Scene& s, v3 d)
 {
     if (s.skySize <= 0) return V3s(0.0f);
@@ -265,13 +298,30 @@ static v3 SampleSky(const Scene& s, v3 d)
     if (ax >= ay && ax >= az) { face = d.x >= 0.0f ? 0 : 1; sc = d.x >= 0.0f ? -d.z : d.z; tc = -d.y; ma = ax; }
     else if (ay >= az) { face = d.y >= 0.0f ? 2 : 3; sc = d.x; tc = d.y >= 0.0f ? d.z : -d.z; ma = ay; }
     else { face = d.z >= 0.0f ? 4 : 5; sc = d.z >= 0.0f ? d.x : -d.x; tc = -d.y; ma = az; }
-    int S = s.skySize; int x = 0, y = 0;
-    if (S > 1) {
-        float u = 0.5f * (sc / ma + 1.0f), v = 0.5f * (tc / ma + 1.0f);
-        x = (int)gmin(gmax(gfloor(u * (float)S), 0.0f), (float)(S - 1)); y = (int)gmin(gmax(gfloor(v * (float)S), 0.0f), (float)(S - 1));
+    const int S = s.skySize;
+    if (S == 1) { const float* p = &s.sky[4 * (size_t)face]; return V3(p[0], p[1], p[2]); }
+    float u = 0.5f * (sc / ma + 1.0f), v = 0.5f * (tc / ma + 1.0f);
+    float fx = u * (float)S - 0.5f, fy = v * (float)S - 0.5f;
+    float x0f = gfloor(fx), y0f = gfloor(fy);
+    float wx = fx - x0f, wy = fy - y0f;
+    int x0 = (int)gmin(gmax(x0f, -1.0f), (float)(S - 1)), y0 = (int)gmin(gmax(y0f, -1.0f), (float)(S - 1));
+    v3 t[4]; bool corner[4]; int nCorner = 0;
+    for (int k = 0; k < 4; k++) {                          // footprint order: (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+        int x = x0 + (k & 1), y = y0 + (k >> 1), f = face;
+        corner[k] = (x < 0 || x >= S) && (y < 0 || y >= S);
+        if (corner[k]) { nCorner++; continue; }
+        SkyFold(S, f, x, y);
+        const float* p = &s.sky[4 * (((size_t)f * S + y) * S + x)];
+        t[k] = V3(p[0], p[1], p[2]);
     }
-    const float* p = &s.sky[4 * (((size_t)face * S + y) * S + x)];
-    return V3(p[0], p[1], p[2]);
+    if (nCorner) {
+        v3 sum = V3s(0.0f);
+        for (int k = 0; k < 4; k++) if (!corner[k]) sum = sum + t[k];
+        for (int k = 0; k < 4; k++) if (corner[k]) t[k] = sum / 3.0f;
+    }
+    return V3(gmix(gmix(t[0].x, t[1].x, wx), gmix(t[2].x, t[3].x, wx), wy),
+              gmix(gmix(t[0].y, t[1].y, wx), gmix(t[2].y, t[3].y, wx), wy),
+              gmix(gmix(t[0].z, t[1].z, wx), gmix(t[2].z, t[3].z, wx), wy));
 }
 
 // include/Surface.glsl

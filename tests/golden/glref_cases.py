@@ -40,6 +40,15 @@ def _textured_scene(b):
     return sc
 
 
+def _sky_scene(b):
+    """Every face a different 5x5 image: the seamless GL_LINEAR cube-map filter across face edges and corners."""
+    rng = np.random.default_rng(9)
+    sc = S.soup_scene(3000, b, seed=5, sky_color=None)
+    sky = np.zeros((6, 5, 5, 4), np.float32); sky[..., :3] = rng.uniform(0, 2, (6, 5, 5, 3)); sky[..., 3] = 1.0
+    sc.sky_faces = sky
+    return sc
+
+
 GLREF_CASES = dict(configs.CASES)
 GLREF_CASES.update({
     "cornell_lights_d5": (_lights_scene, S.cornell_camera, 64, 64, dict(RayDepth=5, DoTraceLights=1)),
@@ -47,5 +56,6 @@ GLREF_CASES.update({
     "cornell_alpha_d6": (_alpha_scene, S.cornell_camera, 64, 64, dict(RayDepth=6)),
     "cornell_textured_aov_d5": (_textured_scene, S.cornell_camera, 64, 64, dict(RayDepth=5, OutputAOVs=1)),
     "cornell_odd_size_d3": (lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 53, 37, dict(RayDepth=3)),
+    "soup_sky_linear_aov_d3": (_sky_scene, lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(1.0, 0.8, 0.9), fovy_deg=110.0), 96, 72, dict(RayDepth=3, OutputAOVs=1)),
     "soup_multi_tlas_d3": (lambda b: S.soup_scene_multi(6000, b, parts=3, seed=4), lambda w, h: S.Camera(w, h), 96, 54, dict(RayDepth=3, UseTlas=1)),
 })
