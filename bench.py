@@ -456,6 +456,7 @@ def cpu_baseline(S, scene, depth, view):
     the GPU kernels replace) without the serial queue compaction in between."""
     from oracle import oracle as O   # allowed here: cpu_baseline leg only
     cores = os.cpu_count() or 1
+    eff = [cores]                                           # cores the process can actually occupy (set below: min(threads, cgroup quota))
 
     def measure(cam, budget_s):
         probe = O.OraclePathTracer(scene, W, H, row_modulo=32, row_remainder=0); probe.set_camera(cam); probe.settings.RayDepth = depth
@@ -472,13 +473,22 @@ def cpu_baseline(S, scene, depth, view):
         par_s, _ = o.timing()
         rays = o.stats()["rays_traced"] - r0; rows = o.rows
         o.close()
-        return {"value": round(rays / tot_dt / 1e6, 3), "parallel_section": round(rays / par_s / 1e6, 3), "per_core": round(rays / par_s / 1e6 / cores, 4),
+        return {"value": round(rays / tot_dt / 1e6, 3), "parallel_section": round(rays / par_s / 1e6, 3), "per_core": round(rays / par_s / 1e6 / eff[0], 4),
                 "sample": f"rows y%{mod}==0 of the {W}x{H} frame ({rows} rows, RayDepth {depth}) x {reps} repetitions = {tot_dt:.1f} s of CPU work ({par_s:.1f} s inside the OpenMP sections)"}
 
     # the host may expose more hardware threads than it lets a process use well (cgroup quota, SMT, 2 sockets): pick the OpenMP thread count
     # that is fastest on a short probe and report THAT count as the cores used
+    quota = None
+    try:                                                    # a container CPU quota (cgroup v2 cpu.max) is the real core count of this process
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
+    cand = {16, 32, 64, 128, cores}
+    if quota:
+        cand |= {max(1, int(quota)), max(1, int(2 * quota))}
     best = (0.0, cores)
-    for nthr in sorted({t for t in (16, 32, 64, 128, cores) if t <= cores}):
+    for nthr in sorted(t for t in cand if t <= cores):
         O.set_num_threads(nthr)
         probe = O.OraclePathTracer(scene, W, H, row_modulo=8, row_remainder=0); probe.set_camera(view_camera(S, view, W, H)); probe.settings.RayDepth = depth
         probe.render(); r0 = probe.stats()["rays_traced"]
@@ -488,6 +498,7 @@ def cpu_baseline(S, scene, depth, view):
         if rate > best[0]:
             best = (rate, nthr)
     hw_threads, cores = cores, best[1]
+    eff[0] = min(cores, int(quota)) if quota else cores
     O.set_num_threads(cores)
     head = measure(view_camera(S, view, W, H), 10.0)
     # the reference's own CPU path (C# semantics: Gui.Test -> BVH.Intersect -> BLAS.Intersect, Render/Gui.cs:1484-1503): primary rays only
@@ -497,19 +508,13 @@ def cpu_baseline(S, scene, depth, view):
     while p_dt < 3.0:
         t0 = time.perf_counter(); rr = O.cpu_trace_primary(scene, cam, W, H, threads=cores, want_hits=False); p_dt += time.perf_counter() - t0
         p_rays += int(rr["rays"])
-    quota = None
-    try:                                                    # a container CPU quota explains a host that stops scaling early
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        quota = None if q == "max" else round(int(q) / int(per), 2)
-    except Exception:
-        pass
     try:
         affinity = len(os.sched_getaffinity(0))
     except Exception:
         affinity = None
-    out = {"value": head["value"], "unit": "Mray/s", "cores": cores, "hw_threads": hw_threads, "cgroup_cpu_quota": quota, "sched_affinity": affinity, "cpu": cpu_model(), "kind": "port", "parallel_section_mray_s": head["parallel_section"],
-           "mray_s_per_core": head["per_core"], "sample": head["sample"] + f"; {cores} OpenMP threads (the fastest of 16/32/64/128/{hw_threads} on a probe: this host does not scale beyond that); C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET); scene and threads warm",
-           "primary_only_csharp_semantics": {"value": round(p_rays / p_dt / 1e6, 3), "unit": "Mray/s", "per_core": round(p_rays / p_dt / 1e6 / cores, 4),
+    out = {"value": head["value"], "unit": "Mray/s", "cores": eff[0], "omp_threads": cores, "hw_threads": hw_threads, "cgroup_cpu_quota": quota, "sched_affinity": affinity, "cpu": cpu_model(), "kind": "port", "parallel_section_mray_s": head["parallel_section"],
+           "mray_s_per_core": head["per_core"], "sample": head["sample"] + f"; {cores} OpenMP threads (the fastest on a probe of 16/32/64/128/{hw_threads} and 1x/2x the container's CPU quota of {quota}; `cores` = min(threads, quota): what the process can actually occupy); C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET); scene and threads warm",
+           "primary_only_csharp_semantics": {"value": round(p_rays / p_dt / 1e6, 3), "unit": "Mray/s", "per_core": round(p_rays / p_dt / 1e6 / eff[0], 4),
                                              "sample": f"{p_rays // (W * H)} full {W}x{H} frames of centre-of-pixel primary rays, closest hit only (no shading), {p_dt:.1f} s"},
            "note": "a reported baseline, not the target: the GPU/CPU ratio says nothing about kernel quality (roofline.frac does)"}
     if view == "headline":
