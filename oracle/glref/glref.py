@@ -41,6 +41,8 @@ ADAPTATIONS = """
  A6  GL_KHR_shader_subgroup_arithmetic (CountingSort/BlellochScan/GroupWise only): if absent, subgroupExclusiveAdd /
      subgroupAdd are emulated through shared memory over groups of MIN_SUBGROUP_SIZE invocations (integer sums: the
      result does not depend on the subgroup size).
+ A8  (ShadowsRayTraced only) `texelFetch(gBufferDataUBO.Depth/Normal, ..)` read bound sampler2D units and
+     `image2D(pointShadow.RayTracedShadowMapImage)` is a bound rgba32f image (llvmpipe has no bindless images either).
  A7  (host order, only with DoRaySorting; sort_count_fix=True) PingPongIndex is uploaded BEFORE RaySorting() instead of
      after it.  Reference defect D1: PathTracer.cs:232-244 runs Reorder while the buffer still holds the previous
      bounce's PingPongIndex, so Reorder's GetItemCount() (Reorder/compute.glsl:44-47) returns the PREVIOUS bounce's
@@ -91,6 +93,7 @@ def gl():
     L.glref_dispatch.argtypes = [C.c_uint] * 4
     L.glref_dispatch_indirect.argtypes = [C.c_uint, C.c_uint, C.c_size_t]
     L.glref_has_extension.argtypes = [C.c_char_p]
+    L.glref_set_uniform_1i.argtypes = [C.c_uint, C.c_char_p, C.c_int]
     L.glref_get_integer.argtypes = [C.c_uint]; L.glref_get_integer_i.argtypes = [C.c_uint, C.c_uint]
     L.glref_delete_buffer.argtypes = [C.c_uint]; L.glref_delete_texture.argtypes = [C.c_uint]; L.glref_delete_program.argtypes = [C.c_uint]
     rc = L.glref_init()
@@ -119,8 +122,9 @@ def _next_keyword(source, start):
         return m
 
 
-def preprocess(local_path, insertions, stage="COMPUTE", vendor="UNKNOWN", min_subgroup=8):
-    """The reference's Preprocessor.PreProcess (BBG/Source/Objects/Shader.cs:177-285) on a shader of REF_SHADERS."""
+def preprocess(local_path, insertions, stage="COMPUTE", vendor="UNKNOWN", min_subgroup=8, source=None):
+    """The reference's Preprocessor.PreProcess (BBG/Source/Objects/Shader.cs:177-285) on a shader of REF_SHADERS
+    (or on `source`, a driver shader of ours that AppIncludes the reference's files)."""
     included = []
 
     def resolve(source):
@@ -149,8 +153,10 @@ def preprocess(local_path, insertions, stage="COMPUTE", vendor="UNKNOWN", min_su
             pos = m.end()
         return "".join(out)
 
-    with open(os.path.join(REF_SHADERS, local_path), "r", encoding="utf-8-sig") as f:
-        text = resolve(f.read())
+    if source is None:
+        with open(os.path.join(REF_SHADERS, local_path), "r", encoding="utf-8-sig") as f:
+            source = f.read()
+    text = resolve(source)
     text = _remove_unused_ssbos(text)
     m = re.search(r"#version .*\n*", text)
     after = m.end() if m else 0
@@ -260,73 +266,63 @@ GL_MAX_SHADER_STORAGE_BUFFER_BINDINGS = 0x90DD
 GL_MAX_COMPUTE_SHADER_STORAGE_BLOCKS = 0x90DB
 
 
-class ReferencePathTracer:
-    """Source/Render/PathTracer.cs driven over llvmpipe.  `scene` is idkengine_amd.gputypes.Scene (whose arrays are
-    byte-exact mirrors of the reference's GPU structs, include/idkpt_types.h), `settings` is gputypes.Settings."""
+class _ReferenceHost:
+    """Scene buffers / uniform blocks / textures at the reference's binding points (include/StaticStorageBuffers.glsl,
+    include/StaticUniformBuffers.glsl), shared by the hosts below.  `scene` is idkengine_amd.gputypes.Scene, whose arrays are
+    byte-exact mirrors of the reference's GPU structs (include/idkpt_types.h)."""
 
-    def __init__(self, scene, width, height, settings, canonical_order=True, sort_count_fix=True):
+    def _init_host(self, scene, use_tlas, blas_stack_size, extra_insertions=None):
         L = gl()
-        self.L, self.W, self.H = L, width, height
-        self.canonical = canonical_order
-        self.sort_count_fix = sort_count_fix
-        self.st = settings
-        self.accumulated = 0
-        self.alive_counts = []
+        self.L = L
         self._bufs, self._texs, self._progs = [], [], []
-        max_b = L.glref_get_integer(GL_MAX_SHADER_STORAGE_BUFFER_BINDINGS)
-        img_fmt = bool(L.glref_has_extension(b"GL_EXT_shader_image_load_formatted"))
-        subgroup = bool(L.glref_has_extension(b"GL_KHR_shader_subgroup"))
-        stack = int(settings.BlasStackSize) if settings.BlasStackSize > 0 else int(scene.blas_stack_size)
-        ins = {"USE_TLAS": "1" if settings.UseTlas else "0", "BLAS_STACK_SIZE": str(stack),                 # Bvh/BVH.cs:25,43
-               "PATH_TRACER_DO_RAY_SORTING": "1" if settings.DoRaySorting else "0",                          # PathTracer.cs:111
-               "PATH_TRACER_OUTPUT_AOVS": "1" if settings.OutputAOVs else "0"}                               # PathTracer.cs:123
-        self.insertions = ins
-        ntex = len(scene.textures)
+        self._max_b = L.glref_get_integer(GL_MAX_SHADER_STORAGE_BUFFER_BINDINGS)
+        self._img_fmt = bool(L.glref_has_extension(b"GL_EXT_shader_image_load_formatted"))
+        self._subgroup = bool(L.glref_has_extension(b"GL_KHR_shader_subgroup"))
+        stack = int(blas_stack_size) if blas_stack_size and blas_stack_size > 0 else int(scene.blas_stack_size)
+        self.insertions = {"USE_TLAS": "1" if use_tlas else "0", "BLAS_STACK_SIZE": str(stack)}               # Bvh/BVH.cs:25,43
+        self.insertions.update(extra_insertions or {})
+        self._ntex = len(scene.textures)
         self.remap = {}
         self.sources = {}
 
-        def prog(path):
-            src, remap = adapt_for_llvmpipe(preprocess(path, ins), ntex, max_b, img_fmt, subgroup)
-            self.remap.update(remap)
-            self.sources[path] = src
-            p = compile_compute(src, path)
-            self._progs.append(p)
-            return p
-        self.first_hit = prog("PathTracing/FirstHit/compute.glsl")
-        self.n_hit = prog("PathTracing/NHit/compute.glsl")
-        self.final_draw = prog("PathTracing/FinalDraw/compute.glsl")
-        if settings.DoRaySorting:
-            self.reorder = prog("PathTracing/CountingSort/Reorder/compute.glsl")
-            self.down_up = prog("PathTracing/CountingSort/BlellochScan/DownUpSweep/compute.glsl")
-            self.group_wise = prog("PathTracing/CountingSort/BlellochScan/GroupWise/compute.glsl")
+    def _program(self, path, source=None, post=None):
+        src = preprocess(path, self.insertions, source=source)
+        src, remap = adapt_for_llvmpipe(src, self._ntex, self._max_b, self._img_fmt, self._subgroup)
+        if post:
+            src = post(src)
+        self.remap.update(remap)
+        self.sources[path] = src
+        p = compile_compute(src, path)
+        self._progs.append(p)
+        return p
 
-        # scene buffers at the reference's binding points (include/StaticStorageBuffers.glsl)
-        def ssbo(binding, arr):
-            arr = np.ascontiguousarray(arr)
-            b = L.glref_buffer(arr.ctypes.data if arr.nbytes else None, arr.nbytes)
-            self._bufs.append(b)
-            L.glref_bind_ssbo(self.remap.get(binding, binding), b)
-            return b
-        self.b_mesh = ssbo(2, scene.meshes); self.b_mat = ssbo(3, scene.materials); self.b_xf = ssbo(4, scene.mesh_transforms)
-        self.b_vert = ssbo(7, scene.vertices); self.b_pos = ssbo(8, np.ascontiguousarray(scene.vertex_positions, np.float32))
-        self.b_desc = ssbo(20, scene.blas_descs); self.b_inst = ssbo(21, scene.blas_instances)
-        self.b_nodes = ssbo(22, scene.blas_nodes); self.b_tris = ssbo(23, scene.blas_triangles)
-        self.b_tlas = ssbo(27, scene.tlas_nodes)
-        n = width * height
-        self.b_rays = ssbo(30, np.zeros(n * 48, np.uint8)); self.b_aov = ssbo(31, np.zeros(n * 32, np.uint8))
-        hdr = np.zeros(HEADER_BYTES // 4 + n, np.uint32); hdr[1] = 1; hdr[2] = 1     # NumGroups = (0,1,1) (PathTracer.cs:323-326)
-        self.b_pt = ssbo(32, hdr)
-        self.b_sorted = ssbo(33, np.zeros(n, np.uint32)); self.b_keys = ssbo(34, np.zeros(n, np.uint32))
-        self.b_wg_prefix = ssbo(35, np.zeros(PREFIX_SUM_CAPACITY, np.uint32))
-        self.b_wg_sums = ssbo(36, np.zeros(PREFIX_SUM_CAPACITY >> GROUP_WISE_PROGRAM_STEPS, np.uint32))
-        # UBO 0 settings (std140: float float bool bool bool), UBO 1 per-frame, UBO 2 lights (StaticUniformBuffers.glsl)
-        self.b_settings = L.glref_buffer(None, 32); self._bufs.append(self.b_settings); L.glref_bind_ubo(0, self.b_settings)
-        self.b_frame = L.glref_buffer(None, 576); self._bufs.append(self.b_frame); L.glref_bind_ubo(1, self.b_frame)
+    def _ssbo(self, binding, arr):
+        arr = np.ascontiguousarray(arr)
+        b = self.L.glref_buffer(arr.ctypes.data if arr.nbytes else None, arr.nbytes)
+        self._bufs.append(b)
+        self.L.glref_bind_ssbo(self.remap.get(binding, binding), b)
+        return b
+
+    def _ubo(self, binding, nbytes, data=None):
+        b = self.L.glref_buffer(data.ctypes.data if data is not None else None, nbytes)
+        self._bufs.append(b)
+        self.L.glref_bind_ubo(binding, b)
+        return b
+
+    def _bind_scene(self, scene):
+        L = self.L
+        self.b_mesh = self._ssbo(2, scene.meshes); self.b_mat = self._ssbo(3, scene.materials); self.b_xf = self._ssbo(4, scene.mesh_transforms)
+        self.b_vert = self._ssbo(7, scene.vertices); self.b_pos = self._ssbo(8, np.ascontiguousarray(scene.vertex_positions, np.float32))
+        self.b_desc = self._ssbo(20, scene.blas_descs); self.b_inst = self._ssbo(21, scene.blas_instances)
+        self.b_nodes = self._ssbo(22, scene.blas_nodes); self.b_tris = self._ssbo(23, scene.blas_triangles)
+        self.b_tlas = self._ssbo(27, scene.tlas_nodes)
+        # UBO 1 per-frame, UBO 2 lights (StaticUniformBuffers.glsl)
+        self.b_frame = self._ubo(1, 576)
         lights = np.zeros(256 * 48 + 16, np.uint8)
         lb = np.ascontiguousarray(scene.lights).view(np.uint8).reshape(-1)
         lights[:lb.size] = lb
         lights[256 * 48:256 * 48 + 4] = np.array([len(scene.lights)], np.int32).view(np.uint8)
-        self.b_lights = L.glref_buffer(lights.ctypes.data, lights.nbytes); self._bufs.append(self.b_lights); L.glref_bind_ubo(2, self.b_lights)
+        self.b_lights = self._ubo(2, lights.nbytes, lights)
         # textures: unit 0 sky cube, unit 1 the 1x1 white default (handle 0), units 2.. the scene's texture table
         sky = scene.sky_faces if scene.sky_faces is not None else np.zeros((6, 1, 1, 4), np.float32)
         sky = np.ascontiguousarray(sky, np.float32)
@@ -334,14 +330,59 @@ class ReferencePathTracer:
         white = np.ones((1, 1, 4), np.float32)
         for i, tex in enumerate([white] + [np.ascontiguousarray(x, np.float32) for x in scene.textures]):
             t = L.glref_texture2d(tex.shape[1], tex.shape[0], tex.ctypes.data, 1, 1); self._texs.append(t); L.glref_bind_texture(1 + i, t)
+
+    def _check_gl(self, what):
+        err = self.L.glref_error()
+        if err:
+            raise RuntimeError(f"GL error 0x{err:x} during {what}")
+
+    def close(self):
+        for b in self._bufs:
+            self.L.glref_delete_buffer(b)
+        for t in self._texs:
+            self.L.glref_delete_texture(t)
+        for p in self._progs:
+            self.L.glref_delete_program(p)
+        self._bufs, self._texs, self._progs = [], [], []
+
+
+class ReferencePathTracer(_ReferenceHost):
+    """Source/Render/PathTracer.cs driven over llvmpipe.  `scene` is idkengine_amd.gputypes.Scene (whose arrays are
+    byte-exact mirrors of the reference's GPU structs, include/idkpt_types.h), `settings` is gputypes.Settings."""
+
+    def __init__(self, scene, width, height, settings, canonical_order=True, sort_count_fix=True):
+        self._init_host(scene, settings.UseTlas, settings.BlasStackSize,
+                        {"PATH_TRACER_DO_RAY_SORTING": "1" if settings.DoRaySorting else "0",                 # PathTracer.cs:111
+                         "PATH_TRACER_OUTPUT_AOVS": "1" if settings.OutputAOVs else "0"})                      # PathTracer.cs:123
+        L = self.L
+        self.W, self.H = width, height
+        self.canonical = canonical_order
+        self.sort_count_fix = sort_count_fix
+        self.st = settings
+        self.accumulated = 0
+        self.alive_counts = []
+        self.first_hit = self._program("PathTracing/FirstHit/compute.glsl")
+        self.n_hit = self._program("PathTracing/NHit/compute.glsl")
+        self.final_draw = self._program("PathTracing/FinalDraw/compute.glsl")
+        if settings.DoRaySorting:
+            self.reorder = self._program("PathTracing/CountingSort/Reorder/compute.glsl")
+            self.down_up = self._program("PathTracing/CountingSort/BlellochScan/DownUpSweep/compute.glsl")
+            self.group_wise = self._program("PathTracing/CountingSort/BlellochScan/GroupWise/compute.glsl")
+        self._bind_scene(scene)
+        n = width * height
+        self.b_rays = self._ssbo(30, np.zeros(n * 48, np.uint8)); self.b_aov = self._ssbo(31, np.zeros(n * 32, np.uint8))
+        hdr = np.zeros(HEADER_BYTES // 4 + n, np.uint32); hdr[1] = 1; hdr[2] = 1     # NumGroups = (0,1,1) (PathTracer.cs:323-326)
+        self.b_pt = self._ssbo(32, hdr)
+        self.b_sorted = self._ssbo(33, np.zeros(n, np.uint32)); self.b_keys = self._ssbo(34, np.zeros(n, np.uint32))
+        self.b_wg_prefix = self._ssbo(35, np.zeros(PREFIX_SUM_CAPACITY, np.uint32))
+        self.b_wg_sums = self._ssbo(36, np.zeros(PREFIX_SUM_CAPACITY >> GROUP_WISE_PROGRAM_STEPS, np.uint32))
+        self.b_settings = self._ubo(0, 32)                                            # UBO 0 settings (std140: float float bool bool bool)
         # Result / Albedo / Normal images (PathTracer.cs:301-318)
         zero = np.zeros((height, width, 4), np.float32)
         self.img = []
         for _ in range(3):
             t = L.glref_texture2d(width, height, zero.ctypes.data, 1, 0); self._texs.append(t); self.img.append(t)
-        err = L.glref_error()
-        if err:
-            raise RuntimeError(f"GL error 0x{err:x} during set-up")
+        self._check_gl("set-up")
 
     # ---- state ----
     def set_camera(self, cam):
@@ -493,11 +534,118 @@ class ReferencePathTracer:
         L.glref_dispatch_indirect(self.reorder, self.b_pt, 0); L.glref_barrier()
         L.glref_buffer_copy(self.b_sorted, self.b_pt, 0, HEADER_BYTES, self.W * self.H * 4)
 
-    def close(self):
-        for b in self._bufs:
-            self.L.glref_delete_buffer(b)
-        for t in self._texs:
-            self.L.glref_delete_texture(t)
-        for p in self._progs:
-            self.L.glref_delete_program(p)
-        self._bufs, self._texs, self._progs = [], [], []
+
+# ------------------------------------------------------------------------------------------------ ray queries (BVHIntersect.glsl)
+
+_QUERY_DRIVER = """#version 460 core
+// glref driver (ours): one invocation per query calls the REFERENCE's TraceRay / TraceRayAny (include/BVHIntersect.glsl:183-411).
+AppInclude(include/Ray.glsl)
+AppInclude(include/StaticStorageBuffers.glsl)
+AppInclude(include/StaticUniformBuffers.glsl)
+#define TRAVERSAL_STACK_USE_SHARED_STACK_SIZE 64
+AppInclude(include/BVHIntersect.glsl)
+layout(local_size_x = 64, local_size_y = 1, local_size_z = 1) in;
+struct GlrefQuery { float ox, oy, oz, maxDist, dx, dy, dz; uint pad; };
+struct GlrefHit { float t, bx, by; uint tri, xform, hit, p0, p1; };
+layout(std430, binding = 18) restrict readonly buffer GlrefQuerySSBO { GlrefQuery q[]; } glrefQuerySSBO;
+layout(std430, binding = 19) restrict writeonly buffer GlrefHitSSBO { GlrefHit h[]; } glrefHitSSBO;
+uniform int GlrefCount;
+uniform int GlrefAnyHit;
+uniform int GlrefTraceLights;
+void main()
+{
+    uint i = gl_GlobalInvocationID.x;
+    if (i >= uint(GlrefCount)) return;
+    GlrefQuery q = glrefQuerySSBO.q[i];
+    Ray ray = Ray(vec3(q.ox, q.oy, q.oz), vec3(q.dx, q.dy, q.dz));
+    HitInfo hitInfo;
+    bool hit;
+    if (GlrefAnyHit != 0) hit = TraceRayAny(ray, hitInfo, GlrefTraceLights != 0, q.maxDist);
+    else hit = TraceRay(ray, hitInfo, GlrefTraceLights != 0, q.maxDist);
+    GlrefHit o;
+    o.t = hitInfo.T; o.bx = hitInfo.BaryXY.x; o.by = hitInfo.BaryXY.y; o.tri = hitInfo.TriangleId; o.xform = hitInfo.MeshTransformId;
+    o.hit = hit ? 1u : 0u; o.p0 = 0u; o.p1 = 0u;
+    glrefHitSSBO.h[i] = o;
+}
+"""
+
+
+class ReferenceRayQuery(_ReferenceHost):
+    """The reference's TraceRay / TraceRayAny (maxDist, traceLights, USE_TLAS on/off) on arbitrary rays: what idkptTraceRays restates."""
+
+    def __init__(self, scene, use_tlas=False, blas_stack_size=0):
+        self._init_host(scene, use_tlas, blas_stack_size)
+        self.prog = self._program("glref/RayQuery/compute.glsl", source=_QUERY_DRIVER)
+        self._bind_scene(scene)
+        self._check_gl("set-up")
+
+    def trace(self, rays, any_hit=False, trace_lights=False):
+        """rays: gputypes.RayQuery records.  Returns gputypes.RayHit-shaped records; fields the reference leaves undefined on a miss
+        (barycentrics, ids) carry whatever the shader's uninitialised `out` struct held."""
+        L = self.L
+        rays = np.ascontiguousarray(rays)
+        n = len(rays)
+        out = np.zeros(n, np.dtype([("T", "<f4"), ("BaryX", "<f4"), ("BaryY", "<f4"), ("TriangleId", "<u4"), ("MeshTransformId", "<u4"), ("Hit", "<u4"), ("_pad0", "<u4"), ("_pad1", "<u4")]))
+        bq = self._ssbo(18, rays); bh = self._ssbo(19, out)
+        L.glref_set_uniform_1i(self.prog, b"GlrefCount", n); L.glref_set_uniform_1i(self.prog, b"GlrefAnyHit", int(bool(any_hit)))
+        L.glref_set_uniform_1i(self.prog, b"GlrefTraceLights", int(bool(trace_lights)))
+        L.glref_dispatch(self.prog, (n + 63) // 64, 1, 1); L.glref_barrier()
+        L.glref_buffer_read(bh, 0, out.nbytes, out.ctypes.data)
+        self._check_gl("ray query")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ ShadowsRayTraced/compute.glsl
+
+def _adapt_shadows(src):
+    """A8 (this shader only): the G-buffer samplers of GBufferDataUBO and the bindless shadow image become bound units."""
+    src = src.replace("texelFetch(gBufferDataUBO.Depth,", "texelFetch(glrefGBufferDepth,").replace("texelFetch(gBufferDataUBO.Normal,", "texelFetch(glrefGBufferNormal,")
+    src = src.replace("image2D(pointShadow.RayTracedShadowMapImage)", "glrefShadowImage")
+    decl = ("layout(binding = 30) uniform sampler2D glrefGBufferDepth;\nlayout(binding = 31) uniform sampler2D glrefGBufferNormal;\n"
+            "layout(binding = 3, rgba32f) restrict uniform image2D glrefShadowImage;\n")
+    at = src.index("vec4 glrefMaterialTexture(")
+    return src[:at] + decl + src[at:]
+
+
+class ReferenceShadows(_ReferenceHost):
+    """Shaders/ShadowsRayTraced/compute.glsl (one point shadow, PointShadowManager.cs) over a caller-supplied G-buffer: what
+    idkptTraceShadows restates.  params: gputypes.ShadowParams; NoiseIndex must be a multiple of RayTracingSamples (it is
+    (Frame % SampleCount) * RayTracingSamples in the shader)."""
+
+    def __init__(self, scene, use_tlas=False, blas_stack_size=0):
+        self._init_host(scene, use_tlas, blas_stack_size)
+        self.prog = self._program("ShadowsRayTraced/compute.glsl", post=_adapt_shadows)
+        self._bind_scene(scene)
+        self.b_shadows = self._ubo(3, 128 * 432 + 16)       # GpuPointShadow[128] (std140, 432 B each with 8-byte handles) + Count
+        self.b_taa = self._ubo(4, 32)
+        self._check_gl("set-up")
+
+    def trace(self, p, depth, normal_oct, visibility=None):
+        L = self.L
+        w, h, rts = int(p.Width), int(p.Height), int(p.RayTracingSamples)
+        assert int(p.NoiseIndex) % rts == 0
+        pf = np.zeros(576 // 4, np.float32)
+        pf[100:116] = np.frombuffer(bytes(p.InvProjView), np.float32)                       # InvProjView @400
+        pf.view(np.uint32)[67] = int(p.NoiseIndex) // rts                                    # Frame @268
+        L.glref_buffer_write(self.b_frame, 0, pf.nbytes, pf.ctypes.data)
+        taa = np.zeros(8, np.uint32)
+        taa[0:2] = np.array([p.TaaJitter[0], p.TaaJitter[1]], np.float32).view(np.uint32)
+        taa[2] = 1 << 20; taa[4] = 1 if int(p.NoiseIndex) else 0                             # SampleCount, TemporalAntiAliasingMode (TAA / none)
+        L.glref_buffer_write(self.b_taa, 0, 32, taa.ctypes.data)
+        sh = np.zeros(432 // 4, np.uint32); sh[428 // 4] = np.uint32(int(p.LightIndex))      # PointShadows[0].LightIndex
+        L.glref_buffer_write(self.b_shadows, 0, 432, sh.ctypes.data)
+        cnt = np.array([1], np.int32); L.glref_buffer_write(self.b_shadows, 128 * 432, 4, cnt.ctypes.data)
+        d4 = np.zeros((h, w, 4), np.float32); d4[..., 0] = np.asarray(depth, np.float32).reshape(h, w)
+        n4 = np.zeros((h, w, 4), np.float32); n4[..., 0:2] = np.asarray(normal_oct, np.float32).reshape(h, w, 2)
+        v4 = np.zeros((h, w, 4), np.float32)
+        if visibility is not None:
+            v4[...] = np.asarray(visibility, np.float32).reshape(h, w, 1)
+        td = L.glref_texture2d(w, h, d4.ctypes.data, 0, 0); tn = L.glref_texture2d(w, h, n4.ctypes.data, 0, 0); tv = L.glref_texture2d(w, h, v4.ctypes.data, 0, 0)
+        self._texs += [td, tn, tv]
+        L.glref_bind_texture(30, td); L.glref_bind_texture(31, tn); L.glref_bind_image(3, tv)
+        L.glref_set_uniform_1i(self.prog, b"RayTracingSamples", rts)
+        L.glref_dispatch(self.prog, (w + 7) // 8, (h + 7) // 8, 1); L.glref_barrier()
+        out = np.zeros((h, w, 4), np.float32)
+        L.glref_texture_read(tv, w, h, out.ctypes.data)
+        self._check_gl("shadows")
+        return out[..., 0].copy()

@@ -4,6 +4,7 @@ swrast); the fixtures travel to the GPU box, this script's inputs do not.
 
     python oracle/glref/make_vectors.py [case ...]            (re)generate fixtures + summary
     python oracle/glref/make_vectors.py --check [case ...]    regenerate in memory, compare with the committed fixtures bit for bit
+    python oracle/glref/make_vectors.py --queries [--check]   ray-query (TraceRay / TraceRayAny) and ShadowsRayTraced vectors
     python oracle/glref/make_vectors.py --defect-d1           demonstrate reference defect D1 (glref.py ADAPTATIONS A7), JSON on stdout
 
 Per case the fixture holds
@@ -61,6 +62,76 @@ def defect_d1():
         rep["with_A7" if fix else "reference_order"] = seen
         pt.close()
     print(json.dumps(rep))
+
+
+def query_scene(builder):
+    from idkengine_amd import scenes as S
+    sc = S.cornell_scene(builder, "mixed", True)
+    sc.lights = S.make_lights([((0.0, 0.55, 0.2), 0.12, (20.0, 20.0, 20.0)), ((-0.5, -0.2, 0.6), 0.08, (5.0, 2.0, 2.0))])
+    return sc
+
+
+def shadow_scene(builder, variant):
+    sc = query_scene(builder)
+    if variant == "blend":   # short box alpha-blended, tall box alpha-tested: the continue-through-surface loop of the shader
+        sc.materials["AlphaCutoff"][-2] = 2.0; sc.materials["BaseColorFactor"][-2] = (sc.materials["BaseColorFactor"][-2] & 0x00FFFFFF) | (0x60 << 24)
+        sc.materials["AlphaCutoff"][-1] = 0.5; sc.materials["BaseColorFactor"][-1] = (sc.materials["BaseColorFactor"][-1] & 0x00FFFFFF) | (0x40 << 24)
+    return sc
+
+
+SHADOW_CONFIGS = [("mixed", 0), ("mixed", 1), ("blend", 0)]
+SHADOW_PARAMS = [(0, 1, 0), (0, 4, 8), (1, 3, 6)]          # (light, RayTracingSamples, NoiseIndex = k * samples)
+SHADOW_SIZE = (96, 80)
+
+
+def make_query_and_shadow_vectors(check=False):
+    """queries.npz: the reference's TraceRay / TraceRayAny (BVHIntersect.glsl) on 4000 random rays x {closest, any} x {lights} x {TLAS};
+    shadows.npz: Shaders/ShadowsRayTraced/compute.glsl on a G-buffer of the Cornell scene, 3 scene/TLAS configs x 3 parameter sets."""
+    from oracle.glref import glref as G
+    from oracle import oracle as O
+    from idkengine_amd import scenes as S, gputypes as T
+    B = O.OracleBuilder()
+    out = {}
+    sc = query_scene(B)
+    rng = np.random.default_rng(11)
+    rays = np.zeros(4000, T.RayQuery)
+    rays["Origin"] = rng.uniform(-1.1, 1.1, (len(rays), 3)).astype(np.float32)
+    d = rng.normal(size=(len(rays), 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["Direction"] = d.astype(np.float32); rays["MaxDist"] = 3.4028235e+38
+    rays["MaxDist"][::3] = rng.uniform(0.05, 2.0, len(rays[::3])).astype(np.float32)      # a third of the rays are range-limited
+    out["rays"] = rays
+    for tlas in (0, 1):
+        rq = G.ReferenceRayQuery(sc, use_tlas=bool(tlas))
+        for any_hit in (0, 1):
+            for lights in (0, 1):
+                out[f"hits_tlas{tlas}_any{any_hit}_lights{lights}"] = rq.trace(rays, bool(any_hit), bool(lights))
+        rq.close()
+    sh = {}
+    w, h = SHADOW_SIZE
+    cam = S.cornell_camera(w, h)
+    prim = S.primary_ray_queries(cam, w, h)
+    for variant, tlas in SHADOW_CONFIGS:
+        scs = shadow_scene(B, variant)
+        hits = O.trace_rays(scs, prim, use_tlas=bool(tlas))
+        depth, normal = S.gbuffer_from_hits(scs, cam, w, h, prim, hits)
+        sh[f"depth_{variant}_{tlas}"] = depth; sh[f"normal_{variant}_{tlas}"] = normal
+        rs = G.ReferenceShadows(scs, use_tlas=bool(tlas))
+        for light, samples, noise in SHADOW_PARAMS:
+            p = T.ShadowParams.make(cam.inv_proj_view, w, h, light_index=light, samples=samples, noise_index=noise, jitter=(0.0005, -0.0003))
+            sh[f"vis_{variant}_{tlas}_{light}_{samples}_{noise}"] = rs.trace(p, depth, normal, visibility=np.full((h, w), np.float32(-3.0)))
+        rs.close()
+    failed = []
+    for fname, data in (("queries.npz", out), ("shadows.npz", sh)):
+        path = os.path.join(OUT, fname)
+        if check:
+            fx = np.load(path)
+            bad = [k for k in data if not (k in fx and np.asarray(data[k]).tobytes() == np.asarray(fx[k]).tobytes())] + [k for k in fx.files if k not in data]
+            print(fname, "reproduced" if not bad else f"DIFFERS in {bad}", flush=True)
+            failed += bad
+        else:
+            np.savez_compressed(path, **data)
+            print(fname, "written", os.path.getsize(path), "bytes", flush=True)
+    return failed
 
 
 def main(names, check=False):
@@ -141,5 +212,8 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     if "--defect-d1" in args:
         defect_d1()
+    elif "--queries" in args:
+        os.makedirs(OUT, exist_ok=True)
+        sys.exit(1 if make_query_and_shadow_vectors(check="--check" in args) else 0)
     else:
         main([a for a in args if not a.startswith("--")], check="--check" in args)

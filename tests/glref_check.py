@@ -114,3 +114,29 @@ def check_case(fx, state_at, final, strict=True):
         else:
             assert free["mean_abs_diff"] <= 0.05 * max(free["mean_ref"], 1e-3), free
     return rep
+
+
+def check_query_hits(got, ref):
+    """got: RayHit records of the implementation under test; ref: what the reference's TraceRay / TraceRayAny returned on llvmpipe.
+    Hit/miss, triangle and instance identity must agree for every ray; T and the barycentrics of triangle hits are compared bit for
+    bit (the traversal and Moeller-Trumbore use only + - * and one division whose result llvmpipe rounds like IEEE here: observed 100 %
+    identical); sphere-light hits (sqrt) and misses (T = maxDist) to REL_TOL.  Fields the reference leaves undefined are skipped."""
+    hit = ref["Hit"] != 0
+    assert ((got["Hit"] != 0) == hit).all()
+    tri = hit & (ref["TriangleId"] != 0xFFFFFFFF)
+    assert (got["TriangleId"][hit] == ref["TriangleId"][hit]).all()
+    assert (got["MeshTransformId"][hit] == ref["MeshTransformId"][hit]).all()
+    for f in ("T", "BaryX", "BaryY"):
+        assert (got[f][tri].view(np.uint32) == ref[f][tri].view(np.uint32)).all(), f
+    light = hit & ~tri
+    np.testing.assert_allclose(got["T"][light], ref["T"][light], rtol=REL_TOL)
+    assert (got["T"][~hit].view(np.uint32) == ref["T"][~hit].view(np.uint32)).all()
+    return {"rays": int(len(ref)), "hits": int(hit.sum()), "triangle_hits": int(tri.sum()), "light_hits": int(light.sum())}
+
+
+def check_shadow_image(got, ref):
+    """Visibility images of ShadowsRayTraced: sums of 0 / 1 / (1 - alpha) products over the samples, divided by the count."""
+    got = np.asarray(got, np.float32); ref = np.asarray(ref, np.float32)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= REL_TOL
+    assert (got.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.999

@@ -30,8 +30,9 @@ live = pytest.mark.skipif(not _live(), reason="needs /root/reference and Mesa ll
 
 
 def test_every_case_has_a_fixture():
-    have = {f[:-4] for f in os.listdir(FIXTURES) if f.endswith(".npz")}
+    have = {f[:-4] for f in os.listdir(FIXTURES) if f.endswith(".npz")} - {"queries", "shadows"}
     assert have == set(glref_cases.GLREF_CASES)
+    assert os.path.exists(os.path.join(FIXTURES, "queries.npz")) and os.path.exists(os.path.join(FIXTURES, "shadows.npz"))
     summary = json.load(open(os.path.join(FIXTURES, "summary.json")))
     assert set(summary) == have
 
@@ -58,6 +59,48 @@ def test_oracle_matches_reference_shaders(name, oracle_mod):
     rep = glref_check.check_case(fx, state_at, final, strict=True)
     # what the committed fixtures show today (tests/golden/glref/summary.json): not one flipped decision, not one value beyond tolerance
     assert all(s["flips"] == 0 and s["beyond_tol"] == 0 and s["queue_identical"] for s in rep["stages"]), rep
+
+
+def _mv():
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "glref"))
+    import make_vectors
+    return make_vectors
+
+
+@pytest.mark.parametrize("use_tlas", [0, 1])
+@pytest.mark.parametrize("any_hit", [0, 1])
+@pytest.mark.parametrize("lights", [0, 1])
+def test_oracle_ray_queries_match_reference_functions(oracle_mod, use_tlas, any_hit, lights):
+    """oracle.trace_rays (what idkptTraceRays is held to) vs the reference's own TraceRay / TraceRayAny (BVHIntersect.glsl:183-411)."""
+    fx = np.load(os.path.join(FIXTURES, "queries.npz"))
+    sc = _mv().query_scene(oracle_mod.OracleBuilder())
+    got = oracle_mod.trace_rays(sc, fx["rays"], any_hit=bool(any_hit), trace_lights=bool(lights), use_tlas=bool(use_tlas))
+    rep = glref_check.check_query_hits(got, fx[f"hits_tlas{use_tlas}_any{any_hit}_lights{lights}"])
+    assert rep["triangle_hits"] > 1000 and (not lights or rep["light_hits"] > 20)
+
+
+def test_oracle_rt_shadows_match_reference_shader(oracle_mod):
+    """oracle.trace_shadows (what idkptTraceShadows is held to) vs Shaders/ShadowsRayTraced/compute.glsl run on llvmpipe."""
+    from idkengine_amd import scenes as S, gputypes as T
+    mv = _mv()
+    fx = np.load(os.path.join(FIXTURES, "shadows.npz"))
+    w, h = mv.SHADOW_SIZE
+    cam = S.cornell_camera(w, h)
+    for variant, tlas in mv.SHADOW_CONFIGS:
+        sc = mv.shadow_scene(oracle_mod.OracleBuilder(), variant)
+        depth, normal = fx[f"depth_{variant}_{tlas}"], fx[f"normal_{variant}_{tlas}"]
+        for light, samples, noise in mv.SHADOW_PARAMS:
+            p = T.ShadowParams.make(cam.inv_proj_view, w, h, light_index=light, samples=samples, noise_index=noise, jitter=(0.0005, -0.0003))
+            got = oracle_mod.trace_shadows(sc, p, depth, normal, visibility=np.full((h, w), np.float32(-3.0)), use_tlas=bool(tlas))
+            ref = fx[f"vis_{variant}_{tlas}_{light}_{samples}_{noise}"]
+            glref_check.check_shadow_image(got, ref)
+            assert (ref == 1.0).any() and (ref == 0.0).any() and (ref == -3.0).any()
+
+
+@live
+def test_live_query_and_shadow_fixtures_are_reproducible():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "make_vectors.py"), "--queries", "--check"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 @live

@@ -34,3 +34,43 @@ def test_hip_path_matches_reference_shaders(name, native_builder):
     rep = glref_check.check_case(fx, state_at, final, strict=True)
     pt.Dispose()
     assert all(s["flips"] == 0 and s["beyond_tol"] == 0 and s["queue_identical"] for s in rep["stages"]), rep
+
+
+def _mv():
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle", "glref"))
+    import make_vectors
+    return make_vectors
+
+
+def test_hip_ray_queries_match_reference_functions(native_builder):
+    """idkptTraceRays vs the reference's own TraceRay / TraceRayAny (BVHIntersect.glsl:183-411) run on llvmpipe."""
+    from idkengine_amd.pathtracer import PathTracer
+    fx = np.load(os.path.join(FIXTURES, "queries.npz"))
+    sc = _mv().query_scene(native_builder)
+    pt = PathTracer(8, 8); pt.UploadScene(sc)
+    for tlas in (0, 1):
+        pt.UseTlas = tlas
+        for any_hit in (0, 1):
+            for lights in (0, 1):
+                got = pt.TraceRays(fx["rays"], any_hit=bool(any_hit), trace_lights=bool(lights))
+                glref_check.check_query_hits(got, fx[f"hits_tlas{tlas}_any{any_hit}_lights{lights}"])
+    pt.Dispose()
+
+
+def test_hip_rt_shadows_match_reference_shader(native_builder):
+    """idkptTraceShadows vs Shaders/ShadowsRayTraced/compute.glsl run on llvmpipe."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import scenes as S, gputypes as T
+    mv = _mv()
+    fx = np.load(os.path.join(FIXTURES, "shadows.npz"))
+    w, h = mv.SHADOW_SIZE
+    cam = S.cornell_camera(w, h)
+    for variant, tlas in mv.SHADOW_CONFIGS:
+        sc = mv.shadow_scene(native_builder, variant)
+        pt = PathTracer(8, 8); pt.UploadScene(sc); pt.UseTlas = tlas
+        depth, normal = fx[f"depth_{variant}_{tlas}"], fx[f"normal_{variant}_{tlas}"]
+        for light, samples, noise in mv.SHADOW_PARAMS:
+            p = T.ShadowParams.make(cam.inv_proj_view, w, h, light_index=light, samples=samples, noise_index=noise, jitter=(0.0005, -0.0003))
+            got = pt.TraceShadows(p, depth, normal, visibility=np.full((h, w), np.float32(-3.0)))
+            glref_check.check_shadow_image(got, fx[f"vis_{variant}_{tlas}_{light}_{samples}_{noise}"])
+        pt.Dispose()
