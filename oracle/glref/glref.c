@@ -79,6 +79,7 @@ GLFN(void, glMemoryBarrier, GLbitfield);
 GLFN(void, glFinish, void);
 GLFN(GLint, glGetUniformLocation, GLuint, const GLchar *);
 GLFN(void, glProgramUniform1i, GLuint, GLint, GLint);
+GLFN(void, glProgramUniform1ui, GLuint, GLint, GLuint);
 GLFN(void, glPixelStorei, GLenum, GLint);
 GLFN(void, glEnable, GLenum);
 
@@ -121,7 +122,7 @@ int glref_init(void)
     LOAD(glCreateTextures); LOAD(glDeleteTextures); LOAD(glTextureStorage2D); LOAD(glTextureSubImage2D); LOAD(glTextureSubImage3D);
     LOAD(glTextureParameteri); LOAD(glGetTextureImage); LOAD(glBindTextureUnit); LOAD(glBindImageTexture);
     LOAD(glDispatchCompute); LOAD(glDispatchComputeIndirect); LOAD(glMemoryBarrier); LOAD(glFinish);
-    LOAD(glGetUniformLocation); LOAD(glProgramUniform1i); LOAD(glPixelStorei); LOAD(glEnable);
+    LOAD(glGetUniformLocation); LOAD(glProgramUniform1i); LOAD(glProgramUniform1ui); LOAD(glPixelStorei); LOAD(glEnable);
     snprintf(g_info, sizeof g_info, "%s | %s", (const char *)p_glGetString(GL_VERSION), (const char *)p_glGetString(GL_RENDERER));
     p_glPixelStorei(GL_UNPACK_ALIGNMENT, 1); p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
     p_glEnable(GL_TEXTURE_CUBE_MAP_SEAMLESS);        /* Texture.TryEnableSeamlessCubemap (Render/SkyBoxManager.cs:74) */
@@ -164,6 +165,14 @@ int glref_set_uniform_1i(unsigned prog, const char *name, int v)
     GLint loc = p_glGetUniformLocation(prog, name);
     if (loc < 0) return -1;
     p_glProgramUniform1i(prog, loc, v);
+    return 0;
+}
+
+int glref_set_uniform_1ui(unsigned prog, const char *name, unsigned v)
+{
+    GLint loc = p_glGetUniformLocation(prog, name);
+    if (loc < 0) return -1;
+    p_glProgramUniform1ui(prog, loc, v);
     return 0;
 }
 

@@ -94,6 +94,7 @@ def gl():
     L.glref_dispatch_indirect.argtypes = [C.c_uint, C.c_uint, C.c_size_t]
     L.glref_has_extension.argtypes = [C.c_char_p]
     L.glref_set_uniform_1i.argtypes = [C.c_uint, C.c_char_p, C.c_int]
+    L.glref_set_uniform_1ui.argtypes = [C.c_uint, C.c_char_p, C.c_uint]
     L.glref_get_integer.argtypes = [C.c_uint]; L.glref_get_integer_i.argtypes = [C.c_uint, C.c_uint]
     L.glref_delete_buffer.argtypes = [C.c_uint]; L.glref_delete_texture.argtypes = [C.c_uint]; L.glref_delete_program.argtypes = [C.c_uint]
     rc = L.glref_init()
@@ -649,3 +650,54 @@ class ReferenceShadows(_ReferenceHost):
         L.glref_texture_read(tv, w, h, out.ctypes.data)
         self._check_gl("shadows")
         return out[..., 0].copy()
+
+
+# ------------------------------------------------------------------------------------------------ BLASRefit / Skinning
+
+class ReferenceSceneUpdates(_ReferenceHost):
+    """Shaders/BLASRefit/compute.glsl (Bvh/BVH.cs GpuBlasesRefit) and Shaders/Skinning/compute.glsl (ModelManager.cs) — what
+    idkptRefitBlas and idkptSkin restate.  The refit shader synchronises parents with atomicExchange locks; its result does not
+    depend on the order the leaves arrive in."""
+
+    def __init__(self, scene):
+        self._init_host(scene, False, 0)
+        self.refit_prog = self._program("BLASRefit/compute.glsl")
+        self.skin_prog = self._program("Skinning/compute.glsl")
+        self._bind_scene(scene)
+        self.b_parents = self._ssbo(24, np.ascontiguousarray(scene.blas_parent_indices, np.int32))
+        self.b_leaves = self._ssbo(25, np.ascontiguousarray(scene.blas_leaf_indices, np.int32).view(np.uint32))
+        self.b_locks = self._ssbo(26, np.zeros(max(len(scene.blas_nodes), 1), np.uint32))
+        self.n_nodes = len(scene.blas_nodes); self.n_verts = len(scene.vertices)
+        self.node_dtype = scene.blas_nodes.dtype; self.vertex_dtype = scene.vertices.dtype
+        self.descs = scene.blas_descs
+        self.b_prev = self._ssbo(17, np.zeros((self.n_verts, 3), np.float32))
+        self._check_gl("set-up")
+
+    def set_positions(self, positions):
+        p = np.ascontiguousarray(positions, np.float32)
+        self.L.glref_buffer_write(self.b_pos, 0, p.nbytes, p.ctypes.data)
+
+    def refit(self, blas_index):
+        L = self.L
+        z = np.zeros(max(self.n_nodes, 1), np.uint32); L.glref_buffer_write(self.b_locks, 0, z.nbytes, z.ctypes.data)
+        L.glref_set_uniform_1ui(self.refit_prog, b"BlasIndex", int(blas_index))
+        leaves = int(self.descs[blas_index]["LeafIndicesCount"])
+        L.glref_dispatch(self.refit_prog, (leaves + 63) // 64, 1, 1); L.glref_barrier()
+        out = np.zeros(self.n_nodes, self.node_dtype)
+        L.glref_buffer_read(self.b_nodes, 0, out.nbytes, out.ctypes.data)
+        self._check_gl("refit")
+        return out
+
+    def skin(self, unskinned, joints, input_offset, output_offset, joint_offset, count):
+        """Returns (positions, previous positions, vertex records) after the dispatch."""
+        L = self.L
+        un = np.ascontiguousarray(unskinned); jm = np.ascontiguousarray(joints, np.float32)
+        self._ssbo(16, un); self._ssbo(15, jm)
+        for name, v in ((b"InputVertexOffset", input_offset), (b"OutputVertexOffset", output_offset), (b"JointMatricesOffset", joint_offset), (b"VertexCount", count)):
+            L.glref_set_uniform_1ui(self.skin_prog, name, int(v))
+        L.glref_dispatch(self.skin_prog, (int(count) + 63) // 64, 1, 1); L.glref_barrier()
+        pos = np.zeros((self.n_verts, 3), np.float32); prev = np.zeros((self.n_verts, 3), np.float32); verts = np.zeros(self.n_verts, self.vertex_dtype)
+        L.glref_buffer_read(self.b_pos, 0, pos.nbytes, pos.ctypes.data); L.glref_buffer_read(self.b_prev, 0, prev.nbytes, prev.ctypes.data)
+        L.glref_buffer_read(self.b_vert, 0, verts.nbytes, verts.ctypes.data)
+        self._check_gl("skinning")
+        return pos, prev, verts

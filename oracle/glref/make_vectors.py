@@ -84,9 +84,30 @@ SHADOW_PARAMS = [(0, 1, 0), (0, 4, 8), (1, 3, 6)]          # (light, RayTracingS
 SHADOW_SIZE = (96, 80)
 
 
+def update_inputs(builder):
+    """Scene + inputs of the refit / skinning vectors (deterministic; shared with the tests)."""
+    from idkengine_amd import scenes as S, gputypes as T
+    sc = S.soup_scene(5000, builder, seed=12, refittable=True)
+    rng = np.random.default_rng(3)
+    moved = (sc.vertex_positions + np.sin(sc.vertex_positions[:, ::-1] * 1.7).astype(np.float32) * np.float32(0.05) + rng.normal(0, 0.01, sc.vertex_positions.shape)).astype(np.float32)
+    n = 600
+    un = np.zeros(n, T.GpuUnskinnedVertex)
+    un["Position"] = sc.vertex_positions[:n]
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tng = np.cross(nrm, rng.normal(size=(n, 3))); tng /= np.linalg.norm(tng, axis=1, keepdims=True)
+    un["Normal"] = S.compress_sr11g11b10(nrm.astype(np.float32)); un["Tangent"] = S.compress_sr11g11b10(tng.astype(np.float32))
+    un["JointIndices"] = rng.integers(0, 3, (n, 4)); wts = rng.uniform(0, 1, (n, 4)).astype(np.float32); un["JointWeights"] = wts / wts.sum(1, keepdims=True)
+    joints = np.zeros((5, 3, 4), np.float32)                        # joint 0/1 unused by offset 2: JointMatricesOffset is exercised
+    joints[2, :, :3] = np.eye(3); joints[2, :, 3] = (0.1, 0.0, -0.2)
+    c, s_ = np.cos(0.3), np.sin(0.3); joints[3, :, :3] = [[c, 0, s_], [0, 1, 0], [-s_, 0, c]]; joints[3, :, 3] = (0, 0.3, 0)
+    joints[4, :, :3] = np.diag([1.2, 0.8, 1.0]); joints[4, :, 3] = (-0.05, 0.02, 0.3)
+    return sc, moved, un, joints, dict(input_offset=0, output_offset=40, joint_offset=2, count=n - 10)
+
+
 def make_query_and_shadow_vectors(check=False):
     """queries.npz: the reference's TraceRay / TraceRayAny (BVHIntersect.glsl) on 4000 random rays x {closest, any} x {lights} x {TLAS};
-    shadows.npz: Shaders/ShadowsRayTraced/compute.glsl on a G-buffer of the Cornell scene, 3 scene/TLAS configs x 3 parameter sets."""
+    shadows.npz: Shaders/ShadowsRayTraced/compute.glsl on a G-buffer of the Cornell scene, 3 scene/TLAS configs x 3 parameter sets;
+    updates.npz: Shaders/BLASRefit/compute.glsl on a displaced refittable soup and Shaders/Skinning/compute.glsl with offsets."""
     from oracle.glref import glref as G
     from oracle import oracle as O
     from idkengine_amd import scenes as S, gputypes as T
@@ -120,8 +141,18 @@ def make_query_and_shadow_vectors(check=False):
             p = T.ShadowParams.make(cam.inv_proj_view, w, h, light_index=light, samples=samples, noise_index=noise, jitter=(0.0005, -0.0003))
             sh[f"vis_{variant}_{tlas}_{light}_{samples}_{noise}"] = rs.trace(p, depth, normal, visibility=np.full((h, w), np.float32(-3.0)))
         rs.close()
+    # ---- BLASRefit / Skinning
+    sc_u, moved, un, joints, sk = update_inputs(B)
+    up = G.ReferenceSceneUpdates(sc_u)
+    up.set_positions(moved)
+    upd = {"refit_nodes": up.refit(0)}
+    pos, prev, verts = up.skin(un, joints, sk["input_offset"], sk["output_offset"], sk["joint_offset"], sk["count"])
+    lo, hi = sk["output_offset"], sk["output_offset"] + sk["count"]
+    upd["skin_positions"] = pos[lo:hi]; upd["skin_prev_positions"] = prev[lo:hi]; upd["skin_normals"] = verts["Normal"][lo:hi]; upd["skin_tangents"] = verts["Tangent"][lo:hi]
+    upd["skin_untouched_ok"] = np.array([np.array_equal(pos[:lo], moved[:lo]) and np.array_equal(pos[hi:], moved[hi:])])
+    up.close()
     failed = []
-    for fname, data in (("queries.npz", out), ("shadows.npz", sh)):
+    for fname, data in (("queries.npz", out), ("shadows.npz", sh), ("updates.npz", upd)):
         path = os.path.join(OUT, fname)
         if check:
             fx = np.load(path)

@@ -30,7 +30,7 @@ live = pytest.mark.skipif(not _live(), reason="needs /root/reference and Mesa ll
 
 
 def test_every_case_has_a_fixture():
-    have = {f[:-4] for f in os.listdir(FIXTURES) if f.endswith(".npz")} - {"queries", "shadows"}
+    have = {f[:-4] for f in os.listdir(FIXTURES) if f.endswith(".npz")} - {"queries", "shadows", "updates"}
     assert have == set(glref_cases.GLREF_CASES)
     assert os.path.exists(os.path.join(FIXTURES, "queries.npz")) and os.path.exists(os.path.join(FIXTURES, "shadows.npz"))
     summary = json.load(open(os.path.join(FIXTURES, "summary.json")))
@@ -95,6 +95,21 @@ def test_oracle_rt_shadows_match_reference_shader(oracle_mod):
             ref = fx[f"vis_{variant}_{tlas}_{light}_{samples}_{noise}"]
             glref_check.check_shadow_image(got, ref)
             assert (ref == 1.0).any() and (ref == 0.0).any() and (ref == -3.0).any()
+
+
+def test_oracle_refit_and_skinned_positions_match_reference_shaders(oracle_mod):
+    """BLAS.Refit restatement vs Shaders/BLASRefit/compute.glsl (node arrays bit for bit) and the binary32 restatement of
+    Shaders/Skinning/compute.glsl's position path vs the shader (bit for bit)."""
+    from test_gpu_scene_updates import _skin_numpy
+    mv = _mv()
+    fx = np.load(os.path.join(FIXTURES, "updates.npz"))
+    B = oracle_mod.OracleBuilder()
+    sc, moved, un, joints, sk = mv.update_inputs(B)
+    assert B.refit(sc.blas_nodes, moved, sc.blas_triangles).tobytes() == fx["refit_nodes"].tobytes()
+    n = sk["count"]
+    want = _skin_numpy(un[sk["input_offset"]:sk["input_offset"] + n], joints[sk["joint_offset"]:])
+    assert want.tobytes() == fx["skin_positions"].tobytes()
+    assert fx["skin_prev_positions"].tobytes() == moved[sk["output_offset"]:sk["output_offset"] + n].tobytes() and bool(fx["skin_untouched_ok"][0])
 
 
 @live

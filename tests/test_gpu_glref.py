@@ -74,3 +74,32 @@ def test_hip_rt_shadows_match_reference_shader(native_builder):
             got = pt.TraceShadows(p, depth, normal, visibility=np.full((h, w), np.float32(-3.0)))
             glref_check.check_shadow_image(got, fx[f"vis_{variant}_{tlas}_{light}_{samples}_{noise}"])
         pt.Dispose()
+
+
+def test_hip_refit_and_skinning_match_reference_shaders(native_builder):
+    """idkptRefitBlas vs Shaders/BLASRefit/compute.glsl (every node, bit for bit); idkptSkin vs Shaders/Skinning/compute.glsl: positions and the
+    previous-position copy bit for bit; the re-compressed 11/11/10-bit normals and tangents identical up to one quantisation step where llvmpipe's
+    inversesqrt rounds the other way."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    mv = _mv()
+    fx = np.load(os.path.join(FIXTURES, "updates.npz"))
+    sc, moved, un, joints, sk = mv.update_inputs(native_builder)
+    pt = PathTracer(8, 8); pt.UploadScene(sc)
+    pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, moved)
+    pt.RefitBlas(0)
+    assert pt.DownloadBuffer(T.IDKPT_BUF_BLAS_NODES, T.GpuBlasNode, len(sc.blas_nodes)).tobytes() == fx["refit_nodes"].tobytes()
+    pt.UploadUnskinnedVertices(un); pt.UpdateBuffer(T.IDKPT_BUF_JOINT_MATRICES, joints)
+    pt.Skin(sk["input_offset"], sk["output_offset"], sk["joint_offset"], sk["count"]); pt.synchronize()
+    lo, hi = sk["output_offset"], sk["output_offset"] + sk["count"]
+    pos = pt.DownloadBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, np.float32, 3 * len(moved)).reshape(-1, 3)
+    assert pos[lo:hi].tobytes() == fx["skin_positions"].tobytes()
+    assert pos[:lo].tobytes() == moved[:lo].tobytes() and pos[hi:].tobytes() == moved[hi:].tobytes()
+    verts = pt.DownloadBuffer(T.IDKPT_BUF_VERTICES, T.GpuVertex, len(sc.vertices))
+    for field, key in (("Normal", "skin_normals"), ("Tangent", "skin_tangents")):
+        got, ref = verts[field][lo:hi].astype(np.int64), fx[key].astype(np.int64)
+        same = got == ref
+        assert same.mean() >= 0.98, (field, same.mean())
+        for shift, mask in ((0, 2047), (11, 2047), (22, 1023)):
+            assert np.abs(((got >> shift) & mask) - ((ref >> shift) & mask)).max() <= 1, field
+    pt.Dispose()
