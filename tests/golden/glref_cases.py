@@ -40,6 +40,26 @@ def _textured_scene(b):
     return sc
 
 
+def _bias_normalmap_scene(b):
+    """The Surface.glsl / Shading.glsl branches the other cases leave out: thin-walled (non-volumetric) transmission without tint,
+    every GpuMesh bias (SurfaceApplyModificatons), a tangent-space normal map blended by NormalMapStrength, a transmission texture."""
+    rng = np.random.default_rng(21)
+    m = S.cornell_meshes("mixed")
+    m["short"].material = S.make_material((0.85, 0.9, 0.6, 1.0), transmission=0.9, roughness=0.15, ior=1.3, absorbance=(0.2, 0.4, 0.1), volumetric=False)
+    m["short"].mesh_kwargs = dict(TintOnTransmissive=0, IORBias=0.2, RoughnessBias=0.1, TransmissionBias=-0.15, AbsorbanceBias=(0.05, -0.5, 0.1), EmissiveBias=0.02)
+    m["short"].uvs = rng.uniform(0, 1, (len(m["short"].positions), 2)).astype(np.float32)
+    m["short"].material["TransmissionTexture"] = 2
+    m["tall"].material = S.make_material((0.8, 0.7, 0.7, 1.0), metallic=0.3, roughness=0.5)
+    m["tall"].mesh_kwargs = dict(NormalMapStrength=0.7, SpecularBias=0.25, RoughnessBias=-0.2)
+    m["tall"].uvs = (rng.uniform(0, 1, (len(m["tall"].positions), 2)) * 2.0).astype(np.float32)
+    m["tall"].material["NormalTexture"] = 1
+    sc = S.assemble([{"meshes": m["walls"] + [m["short"], m["tall"]]}], b, sky_color=(0.25, 0.3, 0.4))
+    nm = np.zeros((6, 6, 4), np.float32); nm[..., 0:2] = rng.uniform(0.3, 0.7, (6, 6, 2)); nm[..., 2] = 1.0; nm[..., 3] = 1.0
+    tr = np.ones((4, 4, 4), np.float32); tr[..., 0] = rng.uniform(0.2, 1.0, (4, 4))
+    sc.textures = [nm, tr]
+    return sc
+
+
 def _sky_scene(b):
     """Every face a different 5x5 image: the seamless GL_LINEAR cube-map filter across face edges and corners."""
     rng = np.random.default_rng(9)
@@ -55,6 +75,7 @@ GLREF_CASES.update({
     "cornell_lights_sort_d4": (_lights_scene, S.cornell_camera, 64, 64, dict(RayDepth=4, DoTraceLights=1, DoRaySorting=1)),
     "cornell_alpha_d6": (_alpha_scene, S.cornell_camera, 64, 64, dict(RayDepth=6)),
     "cornell_textured_aov_d5": (_textured_scene, S.cornell_camera, 64, 64, dict(RayDepth=5, OutputAOVs=1)),
+    "cornell_bias_normalmap_d6": (_bias_normalmap_scene, S.cornell_camera, 64, 64, dict(RayDepth=6)),
     "cornell_odd_size_d3": (lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 53, 37, dict(RayDepth=3)),
     "soup_sky_linear_aov_d3": (_sky_scene, lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(1.0, 0.8, 0.9), fovy_deg=110.0), 96, 72, dict(RayDepth=3, OutputAOVs=1)),
     "soup_multi_tlas_d3": (lambda b: S.soup_scene_multi(6000, b, parts=3, seed=4), lambda w, h: S.Camera(w, h), 96, 54, dict(RayDepth=3, UseTlas=1)),
