@@ -8,6 +8,9 @@
 // Node ids do not depend on scheduling: a subtree with L fragments owns the id range reserved for it up front
 // (Bvh/BLAS.cs:221-241), which is what makes the threaded build deterministic.
 #include <stdint.h>
+#include <stdio.h>
+#include <sys/resource.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <float.h>
@@ -15,6 +18,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "../../include/idkbvh.h"
@@ -23,6 +28,7 @@ namespace {
 
 constexpr int kThreadedRecursionThreshold = 1 << 13; // BLAS.cs:28
 constexpr int kThreadedSortingThreshold = 1 << 16;   // BLAS.cs:29
+constexpr int kParallelSweepThreshold = 1 << 15;     // ours: nodes this large sweep their three axes on three threads
 constexpr float kTraversalCost = 1.0f;               // BLAS.cs:26
 constexpr float kTriangleCost = 1.1f;                // BuildSettings defaults, BLAS.cs:31-48
 constexpr int kStopSplittingThreshold = 1;
@@ -84,7 +90,7 @@ struct Builder {
     std::vector<int> sorted[3]; std::vector<float> rightCosts; std::vector<uint8_t> leftTable;
     std::vector<HNode> nodes;
     int requiredStack = 0;
-    std::atomic<int> liveThreads{1};
+    std::atomic<int> liveThreads{0};   // workers inside buildSubtree (+2 while a node sweeps its axes on extra threads)
     int maxThreads = 1;
     // outputs
     std::vector<GpuBlasTriangle> outTris; std::vector<int> parents, leaves;
@@ -103,21 +109,35 @@ struct Builder {
     }
     float priority(int i) const { __m128 a, b, c; triPoints(i, a, b, c); SBox bx = SBox::point(a); bx.grow(b); bx.grow(c); float e = bx.largestExtent(); return cbrtf((e * e) * (bx.area() - triArea(a, b, c))); }
     static int splitCount(float prio, float total, int n, float factor) { float share = prio / total * (float)n; return 1 + satInt(share * factor); }
+    template <class F> void parallelFor(int n, F&& body) const   // body(begin, end) over contiguous chunks; chunks are independent
+    {
+        const int t = std::max(1, std::min(maxThreads, n / 4096));
+        if (t == 1) { body(0, n); return; }
+        std::vector<std::thread> pool;
+        for (int k = 1; k < t; k++) pool.emplace_back([&, k] { body((int)((long long)n * k / t), (int)((long long)n * (k + 1) / t)); });
+        body(0, (int)((long long)n / t));
+        for (auto& th : pool) th.join();
+    }
     void preSplit(float factor)
     {
         std::vector<float> prio(triCount);
+        parallelFor(triCount, [&](int b, int e) { for (int i = b; i < e; i++) prio[i] = priority(i); });
         float total = 0.0f;
-        for (int i = 0; i < triCount; i++) { prio[i] = priority(i); total += prio[i]; }
+        for (int i = 0; i < triCount; i++) total += prio[i];                       // binary32 running sum in index order (PreSplitting.cs:40-48)
+        std::vector<size_t> first((size_t)triCount + 1);
         size_t count = 0;
-        for (int i = 0; i < triCount; i++) count += (size_t)splitCount(prio[i], total, triCount, factor);
+        for (int i = 0; i < triCount; i++) { first[i] = count; count += (size_t)splitCount(prio[i], total, triCount, factor); }
+        first[triCount] = count;
         frag.resize(count); origTri.resize(count);
         SBox global = SBox::empty();
         for (int i = 0; i < triCount; i++) { __m128 a, b, c; triPoints(i, a, b, c); global.grow(a); global.grow(b); global.grow(c); }
         float gsz[4]; global.size(gsz);
-        size_t w = 0;
         struct Item { SBox box; int splits; };
+        // every triangle writes its own fragment range [first[i], first[i+1]) in the order the serial loop emits them
+        parallelFor(triCount, [&](int tb0, int te0) {
         Item stack[64];
-        for (int i = 0; i < triCount; i++) {
+        for (int i = tb0; i < te0; i++) {
+            size_t w = first[i];
             __m128 pa, pb, pc; triPoints(i, pa, pb, pc);
             float P[3][4]; _mm_storeu_ps(P[0], pa); _mm_storeu_ps(P[1], pb); _mm_storeu_ps(P[2], pc);
             __m128 PV[3] = {pa, pb, pc};
@@ -157,6 +177,7 @@ struct Builder {
                 stack[sp++] = {lb, lc};
             }
         }
+        });
     }
 
     // ---------------- build
@@ -168,55 +189,95 @@ struct Builder {
         memcpy(src + l, aux, sizeof(int) * (size_t)r);
         return l;
     }
+    // One axis of the sweep of BLAS.TrySplit (BLAS.cs:760-821): right-to-left accumulation of the right costs, then the left sweep.
+    // `bestCost` carries the best cost found so far (the reference prunes both sweeps against it); on return it, bestIndex and the
+    // return value (true = this axis improved on it) are updated.
+    bool sweepAxis(int axis, int start, int end, float* rc, float& bestCost, int& bestIndex) const
+    {
+        bool improved = false;
+        const int* ids = sorted[axis].data();
+        int firstRight = start + 1;
+        SBox acc = SBox::empty(); float cnt = 0.0f;
+        for (int i = end - 1; i >= firstRight; i--) {
+            cnt++; acc.grow(frag[ids[i]]);
+            float c = acc.halfArea() * cnt;
+            rc[i] = c;
+            if (c >= bestCost) { firstRight = i + 1; break; }
+        }
+        SBox lacc = SBox::empty(); float lcnt = (float)(firstRight - start) - 1.0f;
+        for (int i = start; i < firstRight - 1; i++) lacc.grow(frag[ids[i]]);
+        for (int i = firstRight - 1; i < end - 1; i++) {
+            lcnt++; lacc.grow(frag[ids[i]]);
+            float lcost = lacc.halfArea() * lcnt;
+            float cost = lcost + rc[i + 1];
+            if (cost < bestCost) { bestIndex = i + 1; bestCost = cost; improved = true; }
+            else if (lcost >= bestCost) break;
+        }
+        return improved;
+    }
     // BLAS.TrySplit (BLAS.cs:730-873). Returns split index or -1.
+    // Large nodes sweep the three axes on three threads, each pruning only against its own running best.  The outcome is the one of the
+    // serial sweep: both prune only positions whose cost cannot be strictly below the final best (the partial costs are monotone), so
+    // each axis reports (its minimum, the first index reaching it) and the axes are then compared in order with the reference's strict '<'.
     int trySplit(const HNode& parent)
     {
         if (parent.count <= kStopSplittingThreshold) return -1;
         const int start = parent.startOrChild, end = start + parent.count;
+        const int n = (int)frag.size();
         int bestAxis = 0, bestIndex = 0; float bestCost = FLT_MAX;
-        float* rc = rightCosts.data();
-        for (int axis = 0; axis < 3; axis++) {
-            const int* ids = sorted[axis].data();
-            int firstRight = start + 1;
-            SBox acc = SBox::empty(); float cnt = 0.0f;
-            for (int i = end - 1; i >= firstRight; i--) {
-                cnt++; acc.grow(frag[ids[i]]);
-                float c = acc.halfArea() * cnt;
-                rc[i] = c;
-                if (c >= bestCost) { firstRight = i + 1; break; }
-            }
-            SBox lacc = SBox::empty(); float lcnt = (float)(firstRight - start) - 1.0f;
-            for (int i = start; i < firstRight - 1; i++) lacc.grow(frag[ids[i]]);
-            for (int i = firstRight - 1; i < end - 1; i++) {
-                lcnt++; lacc.grow(frag[ids[i]]);
-                float lcost = lacc.halfArea() * lcnt;
-                float cost = lcost + rc[i + 1];
-                if (cost < bestCost) { bestIndex = i + 1; bestAxis = axis; bestCost = cost; }
-                else if (lcost >= bestCost) break;
-            }
+        float* rcAxis[3] = {rightCosts.data(), rightCosts.data() + n, rightCosts.data() + 2 * (size_t)n};
+        bool wide = false;
+        if (parent.count >= kParallelSweepThreshold && maxThreads > 2) {
+            int cur = liveThreads.load();
+            while (cur + 2 <= maxThreads && !wide) wide = liveThreads.compare_exchange_weak(cur, cur + 2);
         }
+        if (wide) {
+            float c[3] = {FLT_MAX, FLT_MAX, FLT_MAX}; int ix[3] = {0, 0, 0}; bool ok[3] = {false, false, false};
+            std::thread t1([&] { ok[1] = sweepAxis(1, start, end, rcAxis[1], c[1], ix[1]); }), t2([&] { ok[2] = sweepAxis(2, start, end, rcAxis[2], c[2], ix[2]); });
+            ok[0] = sweepAxis(0, start, end, rcAxis[0], c[0], ix[0]);
+            t1.join(); t2.join();
+            for (int axis = 0; axis < 3; axis++) if (ok[axis] && c[axis] < bestCost) { bestCost = c[axis]; bestIndex = ix[axis]; bestAxis = axis; }
+        } else {
+            for (int axis = 0; axis < 3; axis++) if (sweepAxis(axis, start, end, rcAxis[0], bestCost, bestIndex)) bestAxis = axis;
+        }
+        auto release = [&] { if (wide) liveThreads -= 2; };
         if (parent.count <= kMaxLeafTriangleCount) {
             float notSplit = kTriangleCost * (float)parent.count;
             float newCost = kTraversalCost + (kTriangleCost * bestCost / nodeHalfArea(parent));
-            if (newCost >= notSplit) return -1;
+            if (newCost >= notSplit) { release(); return -1; }
         }
-        SBox lb = boundsOf(start, bestIndex - start, bestAxis), rb = boundsOf(bestIndex, end - bestIndex, bestAxis);
+        SBox lb, rb;
+        if (wide) { std::thread t([&] { rb = boundsOf(bestIndex, end - bestIndex, bestAxis); }); lb = boundsOf(start, bestIndex - start, bestAxis); t.join(); }
+        else { lb = boundsOf(start, bestIndex - start, bestAxis); rb = boundsOf(bestIndex, end - bestIndex, bestAxis); }
         const bool swap = lb.halfArea() < rb.halfArea();
         int* ids = sorted[bestAxis].data();
         for (int i = start; i < bestIndex; i++) leftTable[ids[i]] = !swap;
         for (int i = bestIndex; i < end; i++) leftTable[ids[i]] = swap;
-        int* aux = reinterpret_cast<int*>(rc + start);
-        if (swap) bestIndex = start + stablePartition(ids + start, parent.count, aux, leftTable.data());
-        stablePartition(sorted[(bestAxis + 1) % 3].data() + start, parent.count, aux, leftTable.data());
-        stablePartition(sorted[(bestAxis + 2) % 3].data() + start, parent.count, aux, leftTable.data());
+        const int a1 = (bestAxis + 1) % 3, a2 = (bestAxis + 2) % 3;
+        if (wide) {
+            // the three id arrays are partitioned independently (each with its own scratch: the right-cost rows are free again)
+            std::thread t1([&] { stablePartition(sorted[a1].data() + start, parent.count, reinterpret_cast<int*>(rcAxis[1] + start), leftTable.data()); });
+            std::thread t2([&] { stablePartition(sorted[a2].data() + start, parent.count, reinterpret_cast<int*>(rcAxis[2] + start), leftTable.data()); });
+            if (swap) bestIndex = start + stablePartition(ids + start, parent.count, reinterpret_cast<int*>(rcAxis[0] + start), leftTable.data());
+            t1.join(); t2.join();
+        } else {
+            int* aux = reinterpret_cast<int*>(rcAxis[0] + start);
+            if (swap) bestIndex = start + stablePartition(ids + start, parent.count, aux, leftTable.data());
+            stablePartition(sorted[a1].data() + start, parent.count, aux, leftTable.data());
+            stablePartition(sorted[a2].data() + start, parent.count, aux, leftTable.data());
+        }
+        release();
         return bestIndex;
     }
-    void buildSubtree(int parentId, int newNodesId)
+    // Subtrees are independent once their id range is reserved (BLAS.cs:221-241), so they are built by a pool of workers fed from one
+    // shared list: a worker walks its subtree depth-first and hands every right child that is still large to the list.  Which worker
+    // builds what does not matter for the result.
+    struct Task { int parent, fresh; };
+    std::vector<Task> shared; std::mutex mtx; std::condition_variable cv; int pendingTasks = 0;
+    void pushShared(Task t) { { std::lock_guard<std::mutex> lk(mtx); shared.push_back(t); pendingTasks++; } cv.notify_one(); }
+    void buildSubtree(Task first)
     {
-        // explicit stack instead of recursion; big subtrees are handed to new threads like BLAS.cs:221-231
-        struct Task { int parent, fresh; };
-        std::vector<Task> todo; todo.push_back({parentId, newNodesId});
-        std::vector<std::thread> spawned;
+        std::vector<Task> todo; todo.push_back(first);
         while (!todo.empty()) {
             Task t = todo.back(); todo.pop_back();
             HNode& p = nodes[t.parent];
@@ -230,16 +291,37 @@ struct Builder {
             nodes[lid] = l; nodes[rid] = r;
             p.startOrChild = lid; p.count = 0;
             const int leftFresh = rid + 1, rightFresh = rid + (2 * l.count - 1);
-            if (std::min(l.count, r.count) >= kThreadedRecursionThreshold && liveThreads.load() < maxThreads) {
-                liveThreads++;
-                spawned.emplace_back([this, lid, leftFresh]() { buildSubtree(lid, leftFresh); liveThreads--; });
-                todo.push_back({rid, rightFresh});
-            } else {
-                todo.push_back({rid, rightFresh});
-                todo.push_back({lid, leftFresh}); // left first (order is irrelevant for the result, ids are pre-reserved)
-            }
+            if (maxThreads > 1 && std::min(l.count, r.count) >= kThreadedRecursionThreshold) pushShared({rid, rightFresh});
+            else todo.push_back({rid, rightFresh});
+            todo.push_back({lid, leftFresh}); // left first (order is irrelevant for the result, ids are pre-reserved)
         }
-        for (auto& th : spawned) th.join();
+    }
+    void worker()
+    {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mtx);
+                cv.wait(lk, [&] { return !shared.empty() || pendingTasks == 0; });
+                if (shared.empty()) return;
+                t = shared.back(); shared.pop_back();
+            }
+            liveThreads++;
+            buildSubtree(t);
+            liveThreads--;
+            bool done;
+            { std::lock_guard<std::mutex> lk(mtx); done = --pendingTasks == 0; }
+            if (done) cv.notify_all();
+        }
+    }
+    void buildAll()
+    {
+        liveThreads = 0;
+        pushShared({1, 2});
+        std::vector<std::thread> pool;
+        for (int i = 1; i < maxThreads; i++) pool.emplace_back([this] { worker(); });
+        worker();
+        for (auto& th : pool) th.join();
     }
     int requiredStackSize(int nodeId = 2) const // BLAS.cs:672-702
     {
@@ -357,13 +439,26 @@ struct Builder {
     void run(bool refittable, float factor, int threads)
     {
         auto t0 = std::chrono::steady_clock::now();
+        const bool timing = getenv("IDKBVH_TIMING") != nullptr;   // developer knob: phase times on stderr
+        auto tp = t0;
+        struct rusage ru0; getrusage(RUSAGE_SELF, &ru0);
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            auto t = std::chrono::steady_clock::now();
+            struct rusage ru; getrusage(RUSAGE_SELF, &ru);
+            auto tv = [](const timeval& a) { return a.tv_sec * 1e3 + a.tv_usec * 1e-3; };
+            fprintf(stderr, "[idkbvh] %-18s %8.2f ms   cpu user %8.2f sys %8.2f ms   minor faults %ld\n", what, std::chrono::duration<double, std::milli>(t - tp).count(),
+                    tv(ru.ru_utime) - tv(ru0.ru_utime), tv(ru.ru_stime) - tv(ru0.ru_stime), ru.ru_minflt - ru0.ru_minflt);
+            tp = t; ru0 = ru;
+        };
         maxThreads = threads <= 0 ? std::max(1u, std::thread::hardware_concurrency()) : threads;
         const bool doPreSplit = !refittable;
         if (doPreSplit) preSplit(factor);
         else { frag.resize(triCount); for (int i = 0; i < triCount; i++) frag[i] = triBox(i); }
+        lap("presplit");
         const int n = (int)frag.size();
         nodes.assign((size_t)std::max(2 * n, 4), HNode{});
-        leftTable.assign(n, 0); rightCosts.assign(n, 0.0f);
+        leftTable.assign(n, 0); rightCosts.assign(3 * (size_t)n, 0.0f);   // one right-cost / scratch row per axis
         // BLAS.GetBuildData (BLAS.cs:128-157): ids sorted by FloatToKey(min+max) per axis
         {
             auto sortAxis = [&](int axis) {
@@ -375,12 +470,17 @@ struct Builder {
             if (n >= kThreadedSortingThreshold && maxThreads > 1) { std::thread a(sortAxis, 0), b(sortAxis, 1); sortAxis(2); a.join(); b.join(); }
             else for (int a = 0; a < 3; a++) sortAxis(a);
         }
+        lap("sort");
         nodes[1].startOrChild = 0; nodes[1].count = n;
-        buildSubtree(1, 2);
+        buildAll();
+        lap("build");
         if (isLeaf(nodes[1])) { nodes[2] = nodes[1]; nodes[3] = nodes[1]; nodes[1].startOrChild = 2; nodes[1].count = 0; } // BLAS.cs:173-183
         optimizeStackSize();
+        lap("stack-opt");
         nodes.resize((size_t)compactNodes());
+        lap("compact");
         if (doPreSplit) unindexPreSplit(); else unindexPlain();
+        lap("unindex");
         if (refittable) {
             const int nn = (int)nodes.size();
             parents.assign(nn, -1);
@@ -388,6 +488,7 @@ struct Builder {
             for (int i = 2; i < nn; i++) if (isLeaf(nodes[i])) leaves.push_back(i);
         }
         sah = globalSAH();
+        lap("parents+sah");
         buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 };
