@@ -7,7 +7,7 @@ from . import gputypes as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libidkbvh.so")
-SYMBOLS = ["idkbvhBuildBlas", "idkbvhBlasGetInfo", "idkbvhBlasCopy", "idkbvhBlasFree", "idkbvhInstanceWorldBounds", "idkbvhBuildTlas", "idkbvhRefitBlas"]
+SYMBOLS = ["idkbvhBuildBlas", "idkbvhBlasBegin", "idkbvhBlasFragments", "idkbvhBlasCoreCpu", "idkbvhBlasCoreGet", "idkbvhBlasCoreSet", "idkbvhBlasFinish", "idkbvhBlasGetInfo", "idkbvhBlasCopy", "idkbvhBlasFree", "idkbvhInstanceWorldBounds", "idkbvhBuildTlas", "idkbvhRefitBlas"]
 _lib = None
 
 
@@ -23,6 +23,12 @@ def load():
             raise RuntimeError("libidkbvh.so not built: run __graft_entry__.build()")
         L = C.CDLL(LIB_PATH)
         L.idkbvhBuildBlas.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.POINTER(C.c_void_p)]
+        L.idkbvhBlasBegin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.POINTER(C.c_void_p)]
+        L.idkbvhBlasFragments.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.idkbvhBlasCoreCpu.argtypes = [C.c_void_p]
+        L.idkbvhBlasCoreGet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.idkbvhBlasCoreSet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.idkbvhBlasFinish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.idkbvhBlasGetInfo.argtypes = [C.c_void_p, C.c_void_p]
         L.idkbvhBlasCopy.argtypes = [C.c_void_p] * 5
         L.idkbvhBlasFree.argtypes = [C.c_void_p]; L.idkbvhBlasFree.restype = None
@@ -57,6 +63,24 @@ class NativeBuilder:
         finally:
             L.idkbvhBlasFree(h)
 
+    def core_arrays(self, positions, tris, refittable):
+        """(fragment boxes, node array before compaction, final x-sorted id order) of the CPU core: what idkptBuildBlasCore must reproduce."""
+        L = load()
+        positions = np.ascontiguousarray(positions, np.float32); tris = np.ascontiguousarray(tris)
+        h = C.c_void_p()
+        if L.idkbvhBlasBegin(positions.ctypes.data, tris.ctypes.data, len(tris), 1 if refittable else 0, self.presplit_factor, self.threads, C.byref(h)) != 0:
+            raise RuntimeError("idkbvhBlasBegin failed")
+        try:
+            bp = C.c_void_p(); n = C.c_int32()
+            L.idkbvhBlasFragments(h, C.byref(bp), C.byref(n))
+            boxes = np.ctypeslib.as_array(C.cast(bp, C.POINTER(C.c_float)), shape=(n.value, 8)).copy()
+            L.idkbvhBlasCoreCpu(h)
+            nodes = np.zeros(max(2 * n.value, 4), T.GpuBlasNode); order = np.zeros(n.value, np.int32)
+            L.idkbvhBlasCoreGet(h, nodes.ctypes.data, order.ctypes.data)
+            return boxes, nodes, order
+        finally:
+            L.idkbvhBlasFree(h)
+
     def instance_world_bounds(self, root_node, xform):
         out = np.zeros(6, np.float32)
         root_node = np.ascontiguousarray(root_node); xform = np.ascontiguousarray(xform)
@@ -75,3 +99,47 @@ class NativeBuilder:
         nodes = np.ascontiguousarray(nodes).copy(); positions = np.ascontiguousarray(positions, np.float32); tris = np.ascontiguousarray(tris)
         load().idkbvhRefitBlas(nodes.ctypes.data, len(nodes), positions.ctypes.data, tris.ctypes.data)
         return nodes
+
+
+class GpuBuilder(NativeBuilder):
+    """BLAS build with the SweepSAH core on the GPU: idkbvhBlasBegin (fragments / PreSplit, host) -> idkptBuildBlasCore (sort + recursion,
+    libidkpt.so on the context's device) -> idkbvhBlasFinish (stack-size optimisation, compaction, un-indexing, host).  Same bytes as
+    NativeBuilder.  `pt` is any idkengine_amd.pathtracer.PathTracer (only its context handle is used; no scene is needed)."""
+
+    def __init__(self, pt, presplit_factor=0.3, threads=0):
+        super().__init__(presplit_factor, threads)
+        self._pt = pt
+        self.last_levels = 0; self.last_core_ms = 0.0
+
+    def core_on_gpu(self, boxes):
+        import time
+        boxes = np.ascontiguousarray(boxes, np.float32)
+        n = len(boxes)
+        nodes = np.zeros(max(2 * n, 4), T.GpuBlasNode); order = np.zeros(n, np.int32); lv = C.c_int32()
+        t0 = time.perf_counter()
+        self._pt._check(self._pt._L.idkptBuildBlasCore(self._pt._ctx, boxes.ctypes.data, n, nodes.ctypes.data, order.ctypes.data, C.byref(lv)))
+        self.last_core_ms = (time.perf_counter() - t0) * 1e3; self.last_levels = lv.value
+        return nodes, order
+
+    def build_blas(self, positions, tris, refittable):
+        L = load()
+        positions = np.ascontiguousarray(positions, np.float32); tris = np.ascontiguousarray(tris)
+        h = C.c_void_p()
+        if L.idkbvhBlasBegin(positions.ctypes.data, tris.ctypes.data, len(tris), 1 if refittable else 0, self.presplit_factor, self.threads, C.byref(h)) != 0:
+            raise RuntimeError("idkbvhBlasBegin failed")
+        try:
+            bp = C.c_void_p(); n = C.c_int32()
+            L.idkbvhBlasFragments(h, C.byref(bp), C.byref(n))
+            boxes = np.ctypeslib.as_array(C.cast(bp, C.POINTER(C.c_float)), shape=(n.value, 8))
+            nodes, order = self.core_on_gpu(boxes)
+            if L.idkbvhBlasCoreSet(h, nodes.ctypes.data, order.ctypes.data) != 0 or L.idkbvhBlasFinish(h, positions.ctypes.data, tris.ctypes.data) != 0:
+                raise RuntimeError("idkbvhBlasCoreSet / idkbvhBlasFinish failed")
+            info = BlasInfo(); L.idkbvhBlasGetInfo(h, C.addressof(info))
+            out_nodes = np.zeros(info.NodeCount, T.GpuBlasNode); out_tris = np.zeros(info.TriangleCount, T.GpuBlasTriangle)
+            parents = np.zeros(info.ParentIndexCount, np.int32); leaves = np.zeros(info.LeafIndexCount, np.int32)
+            L.idkbvhBlasCopy(h, out_nodes.ctypes.data, out_tris.ctypes.data, parents.ctypes.data if len(parents) else None, leaves.ctypes.data if len(leaves) else None)
+            self.last_build_ms = info.BuildMs
+            return {"nodes": out_nodes, "triangles": out_tris, "parents": parents, "leaves": leaves, "required_stack_size": info.RequiredStackSize,
+                    "sah": info.Sah, "fragments": info.FragmentCount, "build_ms": info.BuildMs}
+        finally:
+            L.idkbvhBlasFree(h)

@@ -436,26 +436,36 @@ struct Builder {
         outTris.resize(g);
     }
 
-    void run(bool refittable, float factor, int threads)
+    // The build in three steps, so that a host can run the middle one elsewhere (libidkpt's idkptBuildBlasCore on the GPU):
+    //   begin  — fragments (PreSplit or one box per triangle);
+    //   core   — BLAS.GetBuildData + the SweepSAH recursion: the node array (ids reserved per subtree, no compaction yet) and the final
+    //            order of the x-sorted id array, which is all the later steps read;
+    //   finish — single-leaf root, OptimizeStackSize, RemoveEmptySubtrees, GetUnindexedTriangles, parent / leaf indices, SAH.
+    bool refit = false; bool timing = false;
+    std::chrono::steady_clock::time_point t0, tp; struct rusage ru0;
+    void lap(const char* what)
     {
-        auto t0 = std::chrono::steady_clock::now();
-        const bool timing = getenv("IDKBVH_TIMING") != nullptr;   // developer knob: phase times on stderr
-        auto tp = t0;
-        struct rusage ru0; getrusage(RUSAGE_SELF, &ru0);
-        auto lap = [&](const char* what) {
-            if (!timing) return;
-            auto t = std::chrono::steady_clock::now();
-            struct rusage ru; getrusage(RUSAGE_SELF, &ru);
-            auto tv = [](const timeval& a) { return a.tv_sec * 1e3 + a.tv_usec * 1e-3; };
-            fprintf(stderr, "[idkbvh] %-18s %8.2f ms   cpu user %8.2f sys %8.2f ms   minor faults %ld\n", what, std::chrono::duration<double, std::milli>(t - tp).count(),
-                    tv(ru.ru_utime) - tv(ru0.ru_utime), tv(ru.ru_stime) - tv(ru0.ru_stime), ru.ru_minflt - ru0.ru_minflt);
-            tp = t; ru0 = ru;
-        };
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        struct rusage ru; getrusage(RUSAGE_SELF, &ru);
+        auto tv = [](const timeval& a) { return a.tv_sec * 1e3 + a.tv_usec * 1e-3; };
+        fprintf(stderr, "[idkbvh] %-18s %8.2f ms   cpu user %8.2f sys %8.2f ms   minor faults %ld\n", what, std::chrono::duration<double, std::milli>(t - tp).count(),
+                tv(ru.ru_utime) - tv(ru0.ru_utime), tv(ru.ru_stime) - tv(ru0.ru_stime), ru.ru_minflt - ru0.ru_minflt);
+        tp = t; ru0 = ru;
+    }
+    void begin(bool refittable, float factor, int threads)
+    {
+        t0 = tp = std::chrono::steady_clock::now();
+        timing = getenv("IDKBVH_TIMING") != nullptr;   // developer knob: phase times on stderr
+        getrusage(RUSAGE_SELF, &ru0);
         maxThreads = threads <= 0 ? std::max(1u, std::thread::hardware_concurrency()) : threads;
-        const bool doPreSplit = !refittable;
-        if (doPreSplit) preSplit(factor);
+        refit = refittable;
+        if (!refit) preSplit(factor);
         else { frag.resize(triCount); for (int i = 0; i < triCount; i++) frag[i] = triBox(i); }
         lap("presplit");
+    }
+    void coreCpu()
+    {
         const int n = (int)frag.size();
         nodes.assign((size_t)std::max(2 * n, 4), HNode{});
         leftTable.assign(n, 0); rightCosts.assign(3 * (size_t)n, 0.0f);   // one right-cost / scratch row per axis
@@ -474,14 +484,24 @@ struct Builder {
         nodes[1].startOrChild = 0; nodes[1].count = n;
         buildAll();
         lap("build");
+    }
+    void coreSet(const HNode* coreNodes, const int32_t* sorted0)
+    {
+        const int n = (int)frag.size();
+        nodes.assign(coreNodes, coreNodes + (size_t)std::max(2 * n, 4));
+        sorted[0].assign(sorted0, sorted0 + n);
+        lap("core (external)");
+    }
+    void finish()
+    {
         if (isLeaf(nodes[1])) { nodes[2] = nodes[1]; nodes[3] = nodes[1]; nodes[1].startOrChild = 2; nodes[1].count = 0; } // BLAS.cs:173-183
         optimizeStackSize();
         lap("stack-opt");
         nodes.resize((size_t)compactNodes());
         lap("compact");
-        if (doPreSplit) unindexPreSplit(); else unindexPlain();
+        if (!refit) unindexPreSplit(); else unindexPlain();
         lap("unindex");
-        if (refittable) {
+        if (refit) {
             const int nn = (int)nodes.size();
             parents.assign(nn, -1);
             for (int i = 1; i < nn; i++) if (!isLeaf(nodes[i])) { parents[nodes[i].startOrChild] = i; parents[nodes[i].startOrChild + 1] = i; }
@@ -491,6 +511,7 @@ struct Builder {
         lap("parents+sah");
         buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    void run(bool refittable, float factor, int threads) { begin(refittable, factor, threads); coreCpu(); finish(); }
 };
 
 uint32_t spread3(uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; }
@@ -510,6 +531,45 @@ int32_t idkbvhBuildBlas(const float* positions, const GpuBlasTriangle* tris, int
     h->fragmentCount = (int)h->b.frag.size();
     h->b.positions = nullptr; h->b.tris = nullptr; // inputs are only borrowed during the call
     *out = h;
+    return 0;
+}
+int32_t idkbvhBlasBegin(const float* positions, const GpuBlasTriangle* tris, int32_t triCount, int32_t isRefittable, float preSplitFactor, int32_t threads, idkbvh_blas** out)
+{
+    if (!positions || !tris || triCount <= 0 || !out) return 2;
+    idkbvh_blas* h = new idkbvh_blas();
+    h->b.positions = positions; h->b.tris = tris; h->b.triCount = triCount;
+    h->b.begin(isRefittable != 0, preSplitFactor, threads);
+    h->fragmentCount = (int)h->b.frag.size();
+    h->b.positions = nullptr; h->b.tris = nullptr;
+    *out = h;
+    return 0;
+}
+int32_t idkbvhBlasFragments(const idkbvh_blas* h, const float** boxes, int32_t* count)
+{
+    if (!h || !boxes || !count) return 2;
+    *boxes = reinterpret_cast<const float*>(h->b.frag.data()); *count = (int32_t)h->b.frag.size();
+    return 0;
+}
+int32_t idkbvhBlasCoreCpu(idkbvh_blas* h) { if (!h || h->b.frag.empty()) return 2; h->b.coreCpu(); return 0; }
+int32_t idkbvhBlasCoreGet(const idkbvh_blas* h, GpuBlasNode* nodes, int32_t* sorted0)
+{
+    if (!h || h->b.nodes.empty() || h->b.sorted[0].empty()) return 2;
+    if (nodes) memcpy(nodes, h->b.nodes.data(), h->b.nodes.size() * sizeof(HNode));
+    if (sorted0) memcpy(sorted0, h->b.sorted[0].data(), h->b.sorted[0].size() * 4);
+    return 0;
+}
+int32_t idkbvhBlasCoreSet(idkbvh_blas* h, const GpuBlasNode* nodes, const int32_t* sorted0)
+{
+    if (!h || h->b.frag.empty() || !nodes || !sorted0) return 2;
+    h->b.coreSet(reinterpret_cast<const HNode*>(nodes), sorted0);
+    return 0;
+}
+int32_t idkbvhBlasFinish(idkbvh_blas* h, const float* positions, const GpuBlasTriangle* tris)
+{
+    if (!h || !positions || !tris || h->b.nodes.empty() || h->b.sorted[0].empty()) return 2;
+    h->b.positions = positions; h->b.tris = tris;
+    h->b.finish();
+    h->b.positions = nullptr; h->b.tris = nullptr;
     return 0;
 }
 int32_t idkbvhBlasGetInfo(const idkbvh_blas* h, idkbvh_blas_info* o)

@@ -24,6 +24,7 @@ using namespace ptd;
 #include "kernels_queue.hpp"
 #include "kernels_frame.hpp"
 #include "kernels_scene.hpp"
+#include "bvh_gpu.hpp"
 
 // =================================================================================================== host side
 
@@ -631,6 +632,96 @@ static int32_t dev_BuildTlasOnDevice(dev_ctx* ctx, int32_t searchRadius)
                        ctx->xforms.as<float4>(), n, (int)searchRadius, ctx->tlas.as<float4>(), (float4*)(sc + tempOff), (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff));
     HIPC(hipGetLastError());
     ctx->tlasCount = nodeCount; ctx->tlasNeed = std::min(TLAS_STACK_SIZE, std::max(1, n));   // depth unknown on the host: all rows a tree over n leaves can need, up to the limit (beyond it: overflow flag)
+    return IDKPT_OK;
+}
+
+// idkptBuildBlasCore (bvh_gpu.hpp): fragment boxes in, node array (2 * n entries, reference id scheme, not compacted) + final x-sorted id
+// order out.  Stateless apart from the device and stream of the context: no scene is needed and none is touched.
+static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n, GpuBlasNode* outNodes, int32_t* outSortedX, int32_t* outLevels)
+{
+    using namespace bvhgpu;
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(fragBoxes && outNodes && outSortedX && n >= 1, "idkptBuildBlasCore: null argument or no fragments");
+    REQUIRE(n <= (1 << 27), "idkptBuildBlasCore: too many fragments");
+    HIPC(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t nodeCount = (size_t)std::max(2 * n, 4);
+    const int Cmax = n / CH + n + 2;                             // chunks of a level: at most one per CH positions plus one per active node
+    struct Bufs { DevBuf fb, ids[3][2], keys[2], vals[2], hist, nodes, act[2], cnt, nodeChunk0, chunkNode, chunkBegin, cboxL, cboxR, carryL, carryR, rc, cbestCost, cbestPos, dec, sideL, sideR, freshOf,
+                  swapOf, leftCountOf, startOf, countOf, leftTable, pcnt, poff;
+                  ~Bufs() { DevBuf* all[] = {&fb, &ids[0][0], &ids[0][1], &ids[1][0], &ids[1][1], &ids[2][0], &ids[2][1], &keys[0], &keys[1], &vals[0], &vals[1], &hist, &nodes, &act[0], &act[1], &cnt, &nodeChunk0,
+                                             &chunkNode, &chunkBegin, &cboxL, &cboxR, &carryL, &carryR, &rc, &cbestCost, &cbestPos, &dec, &sideL, &sideR, &freshOf, &swapOf, &leftCountOf, &startOf, &countOf,
+                                             &leftTable, &pcnt, &poff}; for (DevBuf* b : all) b->release(); } } B;
+    HIPC(B.fb.ensure((size_t)n * 32));
+    for (int a = 0; a < 3; a++) for (int k = 0; k < 2; k++) HIPC(B.ids[a][k].ensure((size_t)n * 4));
+    for (int k = 0; k < 2; k++) { HIPC(B.keys[k].ensure((size_t)n * 4)); HIPC(B.vals[k].ensure((size_t)n * 4)); HIPC(B.act[k].ensure(nodeCount * 4)); }
+    const uint32_t nTiles = ((uint32_t)n + SORT_TILE - 1) / SORT_TILE;
+    HIPC(B.hist.ensure(((size_t)SORT_RADIX * nTiles + SORT_RADIX) * 4));
+    HIPC(B.nodes.ensure(nodeCount * 32)); HIPC(B.cnt.ensure(64));
+    HIPC(B.nodeChunk0.ensure((nodeCount + 1) * 4)); HIPC(B.chunkNode.ensure((size_t)Cmax * 4)); HIPC(B.chunkBegin.ensure((size_t)Cmax * 4));
+    HIPC(B.cboxL.ensure((size_t)3 * Cmax * sizeof(BBox))); HIPC(B.cboxR.ensure((size_t)3 * Cmax * sizeof(BBox))); HIPC(B.carryL.ensure((size_t)3 * Cmax * sizeof(BBox))); HIPC(B.carryR.ensure((size_t)3 * Cmax * sizeof(BBox)));
+    HIPC(B.rc.ensure((size_t)3 * n * 4)); HIPC(B.cbestCost.ensure((size_t)3 * Cmax * 4)); HIPC(B.cbestPos.ensure((size_t)3 * Cmax * 4));
+    HIPC(B.dec.ensure(nodeCount * sizeof(Decision))); HIPC(B.sideL.ensure((size_t)Cmax * sizeof(BBox))); HIPC(B.sideR.ensure((size_t)Cmax * sizeof(BBox)));
+    HIPC(B.freshOf.ensure(nodeCount * 4)); HIPC(B.swapOf.ensure(nodeCount * 4)); HIPC(B.leftCountOf.ensure(nodeCount * 4)); HIPC(B.startOf.ensure(nodeCount * 4)); HIPC(B.countOf.ensure(nodeCount * 4));
+    HIPC(B.leftTable.ensure((size_t)n)); HIPC(B.pcnt.ensure((size_t)3 * Cmax * 4)); HIPC(B.poff.ensure((size_t)3 * Cmax * 4));
+    HIPC(hipMemcpyAsync(B.fb.p, fragBoxes, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    // device words: [0] = n (count for the sort kernels), [1] = chunk count of the level, [2] = next level's node count
+    uint32_t* cnt = B.cnt.as<uint32_t>();
+    { uint32_t h[3] = {(uint32_t)n, 0u, 0u}; HIPC(hipMemcpyAsync(cnt, h, 12, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }
+    // ---- BLAS.GetBuildData: per axis a stable sort of the ids by FloatToKey(min + max) (five 7-bit LSD passes over the 32-bit key)
+    uint32_t* digitTotals = B.hist.as<uint32_t>() + (size_t)SORT_RADIX * nTiles;
+    for (int axis = 0; axis < 3; axis++) {
+        hipLaunchKernelGGL(k_keys, dim3((n + 255) / 256), dim3(256), 0, st, (const float4*)B.fb.as<float4>(), n, axis, B.keys[0].as<uint32_t>(), B.vals[0].as<uint32_t>());
+        int cur = 0;
+        for (int pass = 0; pass < 5; pass++) {
+            hipLaunchKernelGGL(k_sort_hist, dim3(nTiles), dim3(SORT_BLOCK), 0, st, (const uint32_t*)B.keys[cur].as<uint32_t>(), (const uint32_t*)cnt, (uint32_t)(7 * pass), B.hist.as<uint32_t>(), nTiles);
+            hipLaunchKernelGGL(k_sort_scan, dim3(SORT_RADIX), dim3(1024), 0, st, (const uint32_t*)cnt, B.hist.as<uint32_t>(), nTiles, digitTotals);
+            hipLaunchKernelGGL(k_sort_scatter, dim3(nTiles), dim3(SORT_BLOCK), 0, st, (const uint32_t*)B.keys[cur].as<uint32_t>(), (const uint32_t*)B.vals[cur].as<uint32_t>(), (const uint32_t*)cnt, (uint32_t)(7 * pass),
+                               (const uint32_t*)B.hist.as<uint32_t>(), nTiles, (const uint32_t*)digitTotals, B.keys[1 - cur].as<uint32_t>(), B.vals[1 - cur].as<uint32_t>());
+            cur = 1 - cur;
+        }
+        HIPC(hipMemcpyAsync(B.ids[axis][0].p, B.vals[cur].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    // ---- the recursion, one level at a time
+    HIPC(hipMemsetAsync(B.nodes.p, 0, nodeCount * 32, st));
+    { HNodeG root = {}; root.startOrChild = 0; root.count = n; HIPC(hipMemcpyAsync(B.nodes.as<HNodeG>() + 1, &root, 32, hipMemcpyHostToDevice, st));
+      int one = 1, two = 2; HIPC(hipMemcpyAsync(B.act[0].p, &one, 4, hipMemcpyHostToDevice, st)); HIPC(hipMemcpyAsync(B.freshOf.as<int>() + 1, &two, 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }
+    HNodeG* nodes = B.nodes.as<HNodeG>();
+    int A = 1, curAct = 0, pp = 0, levels = 0;
+    while (A > 0) {
+        Level L; L.act = B.act[curAct].as<int>(); L.A = A; L.nodeChunk0 = B.nodeChunk0.as<int>(); L.chunkNode = B.chunkNode.as<int>(); L.chunkBegin = B.chunkBegin.as<int>(); L.chunkCount = (int*)(cnt + 1);
+        const int Cl = std::min(Cmax, n / CH + A + 1);            // grid bound for this level's chunks (workgroups beyond the real count exit)
+        const int gA = (A + 255) / 256;
+        const int* i0 = B.ids[0][pp].as<int>(); const int* i1 = B.ids[1][pp].as<int>(); const int* i2 = B.ids[2][pp].as<int>();
+        int* o0 = B.ids[0][1 - pp].as<int>(); int* o1 = B.ids[1][1 - pp].as<int>(); int* o2 = B.ids[2][1 - pp].as<int>();
+        const float4* fb = B.fb.as<float4>();
+        HIPC(hipMemsetAsync(cnt + 2, 0, 4, st));
+        hipLaunchKernelGGL(k_chunks, dim3(1), dim3(1024), 0, st, (const HNodeG*)nodes, L);
+        hipLaunchKernelGGL(k_snapshot_ranges, dim3(gA), dim3(256), 0, st, (const HNodeG*)nodes, L, B.startOf.as<int>(), B.countOf.as<int>());
+        hipLaunchKernelGGL(k_chunk_box, dim3(Cl, 3), dim3(CH), 0, st, (const HNodeG*)nodes, L, fb, i0, i1, i2, B.cboxL.as<BBox>(), B.cboxR.as<BBox>(), Cmax);
+        hipLaunchKernelGGL(k_node_carry, dim3(gA), dim3(256), 0, st, nodes, L, (const BBox*)B.cboxL.as<BBox>(), (const BBox*)B.cboxR.as<BBox>(), B.carryL.as<BBox>(), B.carryR.as<BBox>(), Cmax);
+        hipLaunchKernelGGL(k_chunk_rc, dim3(Cl, 3), dim3(CH), 0, st, (const HNodeG*)nodes, L, fb, i0, i1, i2, (const BBox*)B.carryR.as<BBox>(), B.rc.as<float>(), n, Cmax);
+        hipLaunchKernelGGL(k_chunk_cost, dim3(Cl, 3), dim3(CH), 0, st, (const HNodeG*)nodes, L, fb, i0, i1, i2, (const BBox*)B.carryL.as<BBox>(), (const float*)B.rc.as<float>(), B.cbestCost.as<float>(), B.cbestPos.as<int>(), n, Cmax);
+        hipLaunchKernelGGL(k_node_decide, dim3(gA), dim3(256), 0, st, (const HNodeG*)nodes, L, (const float*)B.cbestCost.as<float>(), (const int*)B.cbestPos.as<int>(), B.dec.as<Decision>(), Cmax);
+        hipLaunchKernelGGL(k_chunk_sides, dim3(Cl), dim3(CH), 0, st, (const HNodeG*)nodes, L, (const Decision*)B.dec.as<Decision>(), fb, i0, i1, i2, B.sideL.as<BBox>(), B.sideR.as<BBox>());
+        hipLaunchKernelGGL(k_node_finalize, dim3(gA), dim3(256), 0, st, nodes, L, B.dec.as<Decision>(), (const BBox*)B.sideL.as<BBox>(), (const BBox*)B.sideR.as<BBox>(), B.freshOf.as<int>(), B.swapOf.as<int>(), B.leftCountOf.as<int>(),
+                           B.act[1 - curAct].as<int>(), (int*)(cnt + 2));
+        hipLaunchKernelGGL(k_mark, dim3(Cl), dim3(CH), 0, st, (const HNodeG*)nodes, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.swapOf.as<int>(), (const int*)B.startOf.as<int>(), (const int*)B.countOf.as<int>(), i0, i1, i2, B.leftTable.as<uint8_t>());
+        for (int a = 0; a < 3; a++) HIPC(hipMemcpyAsync(B.ids[a][1 - pp].p, B.ids[a][pp].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_part_count, dim3(Cl, 3), dim3(CH), 0, st, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.startOf.as<int>(), (const int*)B.countOf.as<int>(), i0, i1, i2, (const uint8_t*)B.leftTable.as<uint8_t>(), B.pcnt.as<int>(), Cmax);
+        hipLaunchKernelGGL(k_part_offsets, dim3(gA), dim3(256), 0, st, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.pcnt.as<int>(), B.poff.as<int>(), Cmax);
+        hipLaunchKernelGGL(k_part_scatter, dim3(Cl, 3), dim3(CH), 0, st, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.startOf.as<int>(), (const int*)B.countOf.as<int>(), (const int*)B.leftCountOf.as<int>(), i0, i1, i2, o0, o1, o2,
+                           (const uint8_t*)B.leftTable.as<uint8_t>(), (const int*)B.poff.as<int>(), Cmax);
+        HIPC(hipGetLastError());
+        uint32_t next = 0;
+        HIPC(hipMemcpyAsync(&next, cnt + 2, 4, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st));
+        A = (int)next; curAct = 1 - curAct; pp = 1 - pp; levels++;
+        if (levels > 4096) return fail(ctx, IDKPT_ERR_UNKNOWN, "idkptBuildBlasCore: recursion does not terminate");
+    }
+    HIPC(hipMemcpyAsync(outNodes, B.nodes.p, nodeCount * 32, hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(outSortedX, B.ids[0][pp].p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (outLevels) *outLevels = levels;
     return IDKPT_OK;
 }
 

@@ -343,6 +343,13 @@ int32_t idkptSetLightCount(idkpt_ctx* c, int32_t count) { REPLICATE(SetLightCoun
 int32_t idkptBuildTlas(idkpt_ctx* c, const GpuTlasNode* nodes, int32_t nodeCount) { REPLICATE(BuildTlas, nodes, nodeCount); }
 int32_t idkptBuildTlasOnDevice(idkpt_ctx* c, int32_t searchRadius) { REPLICATE(BuildTlasOnDevice, searchRadius); }      // every member rebuilds its own copy (0.1 ms; cheaper than shipping it)
 int32_t idkptRefitBlas(idkpt_ctx* c, int32_t blasId) { REPLICATE(RefitBlas, blasId); }
+int32_t idkptBuildBlasCore(idkpt_ctx* c, const float* fragmentBoxes, int32_t fragmentCount, GpuBlasNode* outNodes, int32_t* outSortedIdsX, int32_t* outLevels)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    dev_ctx* m = c->dev[0];                                     // a host-side service: runs on the first device, touches no scene state
+    const int rc = dev_BuildBlasCore(m, fragmentBoxes, fragmentCount, outNodes, outSortedIdsX, outLevels);
+    return rc ? mfail(c, m, rc) : IDKPT_OK;
+}
 int32_t idkptUploadUnskinnedVertices(idkpt_ctx* c, const GpuUnskinnedVertex* verts, int32_t count) { REPLICATE(UploadUnskinnedVertices, verts, count); }
 int32_t idkptSkin(idkpt_ctx* c, uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count) { REPLICATE(Skin, inOff, outOff, jointOff, count); }
 int32_t idkptDownloadBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, void* dst)

@@ -41,6 +41,19 @@ typedef struct idkbvh_blas_info {
  * sort axis >= 65536 fragments; results do not depend on the thread count). */
 IDKBVH_API int32_t idkbvhBuildBlas(const float* positions, const GpuBlasTriangle* tris, int32_t triCount, int32_t isRefittable,
                                    float preSplitFactor, int32_t threads, idkbvh_blas** outBlas);
+/* The same build in three steps, for hosts that run the middle one elsewhere (idkptBuildBlasCore of libidkpt.so: the SweepSAH recursion on
+ * the GPU).  Begin = fragments (PreSplit, or one box per triangle when refittable).  The CORE consumes the fragment boxes (8 floats each:
+ * min.xyz, pad, max.xyz, pad) and produces (a) the node array of 2 * fragmentCount entries in the builder's id scheme — a subtree's ids are
+ * reserved from its fragment count (Bvh/BLAS.cs:221-241), unused entries zero, no compaction yet — and (b) the final order of the x-sorted id
+ * array (leaves index into it).  Finish = single-leaf root, OptimizeStackSize, RemoveEmptySubtrees, GetUnindexedTriangles, parent / leaf
+ * indices, SAH; afterwards idkbvhBlasGetInfo / idkbvhBlasCopy work as after idkbvhBuildBlas.  idkbvhBuildBlas == Begin + CoreCpu + Finish. */
+IDKBVH_API int32_t idkbvhBlasBegin(const float* positions, const GpuBlasTriangle* tris, int32_t triCount, int32_t isRefittable,
+                                   float preSplitFactor, int32_t threads, idkbvh_blas** outBlas);
+IDKBVH_API int32_t idkbvhBlasFragments(const idkbvh_blas* blas, const float** outBoxes, int32_t* outCount);   /* borrowed until idkbvhBlasFree */
+IDKBVH_API int32_t idkbvhBlasCoreCpu(idkbvh_blas* blas);
+IDKBVH_API int32_t idkbvhBlasCoreGet(const idkbvh_blas* blas, GpuBlasNode* nodes /* 2 * fragments, may be NULL */, int32_t* sortedIdsX /* fragments, may be NULL */);
+IDKBVH_API int32_t idkbvhBlasCoreSet(idkbvh_blas* blas, const GpuBlasNode* nodes, const int32_t* sortedIdsX);
+IDKBVH_API int32_t idkbvhBlasFinish(idkbvh_blas* blas, const float* positions, const GpuBlasTriangle* tris);
 IDKBVH_API int32_t idkbvhBlasGetInfo(const idkbvh_blas* blas, idkbvh_blas_info* outInfo);
 /* Copies the results into caller arrays sized from idkbvhBlasGetInfo (parents/leaves may be NULL). */
 IDKBVH_API int32_t idkbvhBlasCopy(const idkbvh_blas* blas, GpuBlasNode* nodes, GpuBlasTriangle* triangles, int32_t* parentIndices, int32_t* leafIndices);

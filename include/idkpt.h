@@ -203,6 +203,13 @@ IDKPT_API int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32
  * and mesh transforms (after idkptUpdateBuffer(MESH_TRANSFORMS)/idkptRefitBlas): no host round trip per animated frame.
  * Node array is bit-identical to the serial host build.  searchRadius: TLAS.BuildSettings.SearchRadius (reference: 15). */
 IDKPT_API int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius);
+/* The SweepSAH core of the BLAS build on the GPU: BLAS.GetBuildData + the recursion of BLAS.Build / TrySplit
+ * (Bvh/BLAS.cs:128-243, 730-873) over `fragmentCount` boxes (8 floats each: min.xyz, pad, max.xyz, pad — what libidkbvh's idkbvhBlasFragments
+ * returns after idkbvhBlasBegin).  outNodes receives max(2 * fragmentCount, 4) nodes in the builder's id scheme (a subtree's ids are reserved
+ * from its fragment count; unused entries zero; not compacted), outSortedIdsX the final order of the x-sorted fragment ids (leaves index
+ * into it): exactly the two arrays idkbvhBlasCoreSet takes, byte-identical to idkbvhBlasCoreCpu's.  A host-side service: it uses the context's
+ * first device and stream, needs no uploaded scene and changes none.  outLevels (may be NULL): depth of the recursion. */
+IDKPT_API int32_t idkptBuildBlasCore(idkpt_ctx* ctx, const float* fragmentBoxes, int32_t fragmentCount, GpuBlasNode* outNodes, int32_t* outSortedIdsX, int32_t* outLevels);
 /* BVH.GpuBlasesRefit(blasId,1) (Bvh/BVH.cs:472-489, Shaders/BLASRefit/compute.glsl) */
 IDKPT_API int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId);
 /* ModelManager skinning dispatch (ModelManager.cs:326-353, Shaders/Skinning/compute.glsl):
