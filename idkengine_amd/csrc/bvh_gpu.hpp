@@ -114,22 +114,6 @@ __global__ __launch_bounds__(CH) void k_chunk_box(const HNodeG* nodes, Level L, 
     if (threadIdx.x == 0) { cboxL[(size_t)axis * Cmax + k] = l; cboxR[(size_t)axis * Cmax + k] = r; }
 }
 
-// per node: boxes of the chunks before (prefix rule) / after (suffix rule) every chunk, per axis; the node's bounds (x-sorted order)
-__global__ void k_node_carry(HNodeG* nodes, Level L, const BBox* cboxL, const BBox* cboxR, BBox* carryL, BBox* carryR, int Cmax)
-{
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= L.A) return;
-    const int c0 = L.nodeChunk0[a], c1 = L.nodeChunk0[a + 1];
-    for (int axis = 0; axis < 3; axis++) {
-        const size_t o = (size_t)axis * Cmax;
-        BBox acc = box_empty();
-        for (int k = c0; k < c1; k++) { carryL[o + k] = acc; acc = join_lr(acc, cboxL[o + k]); }
-        if (axis == 0) { HNodeG& nd = nodes[L.act[a]]; for (int d = 0; d < 3; d++) { nd.mn[d] = acc.mn[d]; nd.mx[d] = acc.mx[d]; } }   // setBounds(boundsOf(.., axis 0)), BLAS.cs:206
-        acc = box_empty();
-        for (int k = c1 - 1; k >= c0; k--) { carryR[o + k] = acc; acc = join_rl(cboxR[o + k], acc); }
-    }
-}
-
 // inclusive in-order scan of the chunk's boxes (Hillis-Steele over shared memory).  RL: from the right end (suffix), else from the left (prefix).
 template <bool RL>
 DEV BBox block_scan(BBox v, BBox* sh)
@@ -148,6 +132,43 @@ DEV BBox block_scan(BBox v, BBox* sh)
     BBox r = sh[t];
     __syncthreads();
     return r;
+}
+
+// per node (one workgroup): boxes of the chunks before (prefix rule) / after (suffix rule) every chunk, per axis; the node's bounds (x-sorted order)
+__global__ __launch_bounds__(CH) void k_node_carry(HNodeG* nodes, Level L, const BBox* cboxL, const BBox* cboxR, BBox* carryL, BBox* carryR, int Cmax)
+{
+    __shared__ BBox sh[CH];
+    __shared__ BBox shPrev[CH];
+    const int a = blockIdx.x, t = threadIdx.x;
+    if (a >= L.A) return;
+    const int c0 = L.nodeChunk0[a], c1 = L.nodeChunk0[a + 1];
+    for (int axis = 0; axis < 3; axis++) {
+        const size_t o = (size_t)axis * Cmax;
+        BBox run = box_empty();                                                  // union of the tiles already done
+        for (int base = c0; base < c1; base += CH) {                             // prefix direction
+            const int k = base + t; const bool valid = k < c1;
+            BBox incl = block_scan<false>(valid ? cboxL[o + k] : box_empty(), sh);
+            shPrev[t] = incl;
+            __syncthreads();
+            if (valid) carryL[o + k] = t == 0 ? run : join_lr(run, shPrev[t - 1]);
+            const BBox tileAll = shPrev[CH - 1];
+            __syncthreads();
+            run = join_lr(run, tileAll);
+        }
+        if (axis == 0 && t == 0) { HNodeG& nd = nodes[L.act[a]]; for (int d = 0; d < 3; d++) { nd.mn[d] = run.mn[d]; nd.mx[d] = run.mx[d]; } }   // setBounds(boundsOf(.., axis 0)), BLAS.cs:206
+        run = box_empty();
+        const int tiles = (c1 - c0 + CH - 1) / CH;
+        for (int tile = tiles - 1; tile >= 0; tile--) {                          // suffix direction
+            const int base = c0 + tile * CH, k = base + t; const bool valid = k < c1;
+            BBox incl = block_scan<true>(valid ? cboxR[o + k] : box_empty(), sh);
+            shPrev[t] = incl;
+            __syncthreads();
+            if (valid) carryR[o + k] = t == CH - 1 ? run : join_rl(shPrev[t + 1], run);
+            const BBox tileAll = shPrev[0];
+            __syncthreads();
+            run = join_rl(tileAll, run);
+        }
+    }
 }
 
 // right costs: rc[axis][pos] = HalfArea(union of [pos, end)) * (end - pos)   (BLAS.cs:768-782)
@@ -199,20 +220,29 @@ __global__ __launch_bounds__(CH) void k_chunk_cost(const HNodeG* nodes, Level L,
 
 struct Decision { int split; int axis; int index; };           // split: 0 = leaf
 
-// TrySplit's verdict per node (BLAS.cs:733-736, 806-829)
-__global__ void k_node_decide(const HNodeG* nodes, Level L, const float* cbestCost, const int* cbestPos, Decision* dec, int Cmax)
+// TrySplit's verdict per node (BLAS.cs:733-736, 806-829); one workgroup per node reduces the chunk minima in (axis, position) order
+__global__ __launch_bounds__(CH) void k_node_decide(const HNodeG* nodes, Level L, const float* cbestCost, const int* cbestPos, Decision* dec, int Cmax)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float shc[CH]; __shared__ int shp[CH];
+    const int a = blockIdx.x, t = threadIdx.x;
     if (a >= L.A) return;
     const HNodeG nd = nodes[L.act[a]];
     Decision d = {0, 0, 0};
     if (nd.count > 1) {                                        // kStopSplittingThreshold = 1
         float best = 3.402823466e+38f; int bi = 0, ba = 0;
-        for (int axis = 0; axis < 3; axis++)
-            for (int k = L.nodeChunk0[a]; k < L.nodeChunk0[a + 1]; k++) {
-                const float c = cbestCost[(size_t)axis * Cmax + k];
-                if (c < best) { best = c; bi = cbestPos[(size_t)axis * Cmax + k]; ba = axis; }
+        const int c0 = L.nodeChunk0[a], c1 = L.nodeChunk0[a + 1];
+        for (int axis = 0; axis < 3; axis++) {
+            float c = 3.402823466e+38f; int p = 0x7fffffff;
+            for (int k = c0 + t; k < c1; k += CH) { const float c2 = cbestCost[(size_t)axis * Cmax + k]; const int p2 = cbestPos[(size_t)axis * Cmax + k]; if (c2 < c || (c2 == c && p2 < p)) { c = c2; p = p2; } }
+            shc[t] = c; shp[t] = p;
+            __syncthreads();
+            for (int s2 = CH / 2; s2 > 0; s2 >>= 1) {
+                if (t < s2) { const float c2 = shc[t + s2]; const int p2 = shp[t + s2]; if (c2 < shc[t] || (c2 == shc[t] && p2 < shp[t])) { shc[t] = c2; shp[t] = p2; } }
+                __syncthreads();
             }
+            if (shc[0] < best) { best = shc[0]; bi = shp[0]; ba = axis; }
+            __syncthreads();
+        }
         d.split = 1; d.axis = ba; d.index = bi;
         if (nd.count <= 2) {                                   // kMaxLeafTriangleCount = 2: a leaf unless splitting is cheaper
             const float x = nd.mx[0] - nd.mn[0], y = nd.mx[1] - nd.mn[1], z = nd.mx[2] - nd.mn[2];
@@ -222,7 +252,7 @@ __global__ void k_node_decide(const HNodeG* nodes, Level L, const float* cbestCo
             if (newCost >= notSplit) d.split = 0;
         }
     }
-    dec[a] = d;
+    if (t == 0) dec[a] = d;
 }
 
 // boxes of the two sides of the chosen split, per chunk of the chosen axis (BLAS.cs:831-833: boundsOf both halves)
@@ -245,16 +275,24 @@ __global__ __launch_bounds__(CH) void k_chunk_sides(const HNodeG* nodes, Level L
 }
 
 // swap rule, children, next level's list (BLAS.cs:208-241, 833-835)
-__global__ void k_node_finalize(HNodeG* nodes, Level L, Decision* dec, const BBox* sideL, const BBox* sideR, int* freshOf, int* swapOf, int* leftCountOf, int* nextAct, int* nextCount)
+__global__ __launch_bounds__(CH) void k_node_finalize(HNodeG* nodes, Level L, Decision* dec, const BBox* sideL, const BBox* sideR, int* freshOf, int* swapOf, int* leftCountOf, int* nextAct, int* nextCount, int* smallList, int* smallCount, int smallMax)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ BBox sh[CH];
+    const int a = blockIdx.x, t = threadIdx.x;
     if (a >= L.A) return;
     const Decision d = dec[a];
     if (!d.split) return;
     const int v = L.act[a];
     HNodeG nd = nodes[v];
     BBox lb = box_empty(), rb = box_empty();
-    for (int k = L.nodeChunk0[a]; k < L.nodeChunk0[a + 1]; k++) { lb = join_lr(lb, sideL[k]); rb = join_lr(rb, sideR[k]); }
+    {   // in-order union over the node's chunks: every thread folds a contiguous run, the runs are then folded in order
+        const int c0 = L.nodeChunk0[a], c1 = L.nodeChunk0[a + 1], per = (c1 - c0 + CH - 1) / CH;
+        const int b0 = min(c0 + t * per, c1), b1 = min(b0 + per, c1);
+        BBox l = box_empty(), r = box_empty();
+        for (int k = b0; k < b1; k++) { l = join_lr(l, sideL[k]); r = join_lr(r, sideR[k]); }
+        lb = block_reduce<false>(l, true, sh); rb = block_reduce<false>(r, true, sh);
+    }
+    if (t != 0) return;
     const int start = nd.startOrChild, end = start + nd.count;
     const int swap = half_area(lb) < half_area(rb) ? 1 : 0;
     const int lcount = swap ? end - d.index : d.index - start;
@@ -266,8 +304,9 @@ __global__ void k_node_finalize(HNodeG* nodes, Level L, Decision* dec, const BBo
     nodes[lid] = l; nodes[rid] = r;
     freshOf[lid] = rid + 1; freshOf[rid] = rid + (2 * lcount - 1);
     nodes[v].startOrChild = lid; nodes[v].count = 0;
-    const int o = atomicAdd(nextCount, 2);
-    nextAct[o] = lid; nextAct[o + 1] = rid;
+    // children with few fragments leave the level-synchronous scheme: one thread each finishes their subtree (k_small_subtrees)
+    if (l.count <= smallMax) smallList[atomicAdd(smallCount, 1)] = lid; else nextAct[atomicAdd(nextCount, 1)] = lid;
+    if (r.count <= smallMax) smallList[atomicAdd(smallCount, 1)] = rid; else nextAct[atomicAdd(nextCount, 1)] = rid;
 }
 
 // leftTable (BLAS.cs:837-846) along the chosen axis
@@ -300,14 +339,25 @@ __global__ __launch_bounds__(CH) void k_part_count(Level L, const Decision* dec,
     for (int s = CH / 2; s > 0; s >>= 1) { if (t < s) sh[t] += sh[t + s]; __syncthreads(); }
     if (t == 0) pcnt[(size_t)axis * Cmax + k] = sh[0];
 }
-// step 2: flagged positions before every chunk, per node and axis
-__global__ void k_part_offsets(Level L, const Decision* dec, const int* pcnt, int* poff, int Cmax)
+// step 2: flagged positions before every chunk, per node and axis (one workgroup per node)
+__global__ __launch_bounds__(CH) void k_part_offsets(Level L, const Decision* dec, const int* pcnt, int* poff, int Cmax)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int sh[CH];
+    const int a = blockIdx.x, t = threadIdx.x;
     if (a >= L.A || !dec[a].split) return;
+    const int c0 = L.nodeChunk0[a], c1 = L.nodeChunk0[a + 1];
     for (int axis = 0; axis < 3; axis++) {
         int run = 0;
-        for (int k = L.nodeChunk0[a]; k < L.nodeChunk0[a + 1]; k++) { poff[(size_t)axis * Cmax + k] = run; run += pcnt[(size_t)axis * Cmax + k]; }
+        for (int base = c0; base < c1; base += CH) {
+            const int k = base + t; const int v = k < c1 ? pcnt[(size_t)axis * Cmax + k] : 0;
+            sh[t] = v;
+            __syncthreads();
+            for (int s2 = 1; s2 < CH; s2 <<= 1) { int w = t >= s2 ? sh[t - s2] : 0; __syncthreads(); sh[t] += w; __syncthreads(); }
+            if (k < c1) poff[(size_t)axis * Cmax + k] = run + sh[t] - v;
+            const int tileAll = sh[CH - 1];
+            __syncthreads();
+            run += tileAll;
+        }
     }
 }
 // step 3: scatter (stable on both sides).  `out` was pre-filled with a copy of `in`, so ranges of nodes that do not split stay as they are.
@@ -341,6 +391,77 @@ __global__ void k_snapshot_ranges(const HNodeG* nodes, Level L, int* startOf, in
     if (a >= L.A) return;
     const HNodeG nd = nodes[L.act[a]];
     startOf[a] = nd.startOrChild; countOf[a] = nd.count;
+}
+
+// ---- subtrees of at most `smallMax` fragments: BLAS.Build / TrySplit as the reference runs them (Bvh/BLAS.cs:193-243, 730-873), one thread per subtree.
+// The id arrays are partitioned in place (positions of different subtrees are disjoint), `rc` / `aux` are per-position scratch.
+DEV void grow(BBox& a, const BBox& x) { for (int k = 0; k < 3; k++) { a.mn[k] = sse_min(a.mn[k], x.mn[k]); a.mx[k] = sse_max(a.mx[k], x.mx[k]); } }   // Box.GrowToFit: minps / maxps (acc, x)
+DEV BBox bounds_of(const float4* fb, const int* ids, int start, int count) { BBox b = box_empty(); for (int i = 0; i < count; i++) grow(b, frag_box(fb, ids[start + i])); return b; }
+DEV int stable_partition(int* src, int n, int* aux, const uint8_t* table)
+{
+    int l = 0, r = 0;
+    for (int i = 0; i < n; i++) { const int id = src[i]; if (table[id]) src[l++] = id; else aux[r++] = id; }
+    for (int i = 0; i < r; i++) src[l + i] = aux[i];
+    return l;
+}
+__global__ void k_small_subtrees(HNodeG* nodes, const int* smallList, const int* smallCount, const float4* fb, int* ids0, int* ids1, int* ids2, float* rc, int* aux, uint8_t* leftTable, const int* freshOf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *smallCount) return;
+    int* idsA[3] = {ids0, ids1, ids2};
+    int stackNode[136], stackFresh[136]; int sp = 0;              // a subtree over <= smallMax (<= 128) fragments never holds more entries than it has fragments
+    stackNode[0] = smallList[i]; stackFresh[0] = freshOf[smallList[i]]; sp = 1;
+    while (sp > 0) {
+        sp--;
+        const int pid = stackNode[sp], fresh = stackFresh[sp];
+        HNodeG p = nodes[pid];
+        const int start = p.startOrChild, count = p.count, end = start + count;
+        { const BBox b = bounds_of(fb, ids0, start, count); for (int d = 0; d < 3; d++) { p.mn[d] = b.mn[d]; p.mx[d] = b.mx[d]; } nodes[pid] = p; }
+        if (count <= 1) continue;
+        int bestAxis = 0, bestIndex = 0; float bestCost = 3.402823466e+38f;
+        for (int axis = 0; axis < 3; axis++) {
+            const int* ids = idsA[axis];
+            int firstRight = start + 1;
+            BBox acc = box_empty(); float cnt = 0.0f;
+            for (int k = end - 1; k >= firstRight; k--) {
+                cnt += 1.0f; grow(acc, frag_box(fb, ids[k]));
+                const float c = half_area(acc) * cnt;
+                rc[k] = c;
+                if (c >= bestCost) { firstRight = k + 1; break; }
+            }
+            BBox lacc = box_empty(); float lcnt = (float)(firstRight - start) - 1.0f;
+            for (int k = start; k < firstRight - 1; k++) grow(lacc, frag_box(fb, ids[k]));
+            for (int k = firstRight - 1; k < end - 1; k++) {
+                lcnt += 1.0f; grow(lacc, frag_box(fb, ids[k]));
+                const float lcost = half_area(lacc) * lcnt;
+                const float cost = lcost + rc[k + 1];
+                if (cost < bestCost) { bestIndex = k + 1; bestAxis = axis; bestCost = cost; }
+                else if (lcost >= bestCost) break;
+            }
+        }
+        if (count <= 2) {
+            const float x = p.mx[0] - p.mn[0], y = p.mx[1] - p.mn[1], z = p.mx[2] - p.mn[2];
+            const float notSplit = 1.1f * (float)count;
+            const float newCost = 1.0f + (1.1f * bestCost / __builtin_fmaf(x + y, z, x * y));
+            if (newCost >= notSplit) continue;
+        }
+        const BBox lb = bounds_of(fb, idsA[bestAxis], start, bestIndex - start), rb = bounds_of(fb, idsA[bestAxis], bestIndex, end - bestIndex);
+        const bool swap = half_area(lb) < half_area(rb);
+        int* ids = idsA[bestAxis];
+        for (int k = start; k < bestIndex; k++) leftTable[ids[k]] = (uint8_t)!swap;
+        for (int k = bestIndex; k < end; k++) leftTable[ids[k]] = (uint8_t)swap;
+        if (swap) bestIndex = start + stable_partition(ids + start, count, aux + start, leftTable);
+        stable_partition(idsA[(bestAxis + 1) % 3] + start, count, aux + start, leftTable);
+        stable_partition(idsA[(bestAxis + 2) % 3] + start, count, aux + start, leftTable);
+        HNodeG l = {}, r = {};
+        l.startOrChild = start; l.count = bestIndex - start;
+        r.startOrChild = bestIndex; r.count = count - l.count;
+        const int lid = fresh, rid = lid + 1;
+        nodes[lid] = l; nodes[rid] = r;
+        p.startOrChild = lid; p.count = 0; nodes[pid] = p;
+        stackNode[sp] = rid; stackFresh[sp] = rid + (2 * l.count - 1); sp++;
+        stackNode[sp] = lid; stackFresh[sp] = rid + 1; sp++;
+    }
 }
 
 } // namespace bvhgpu

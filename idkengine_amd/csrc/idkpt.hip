@@ -648,10 +648,10 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
     const size_t nodeCount = (size_t)std::max(2 * n, 4);
     const int Cmax = n / CH + n + 2;                             // chunks of a level: at most one per CH positions plus one per active node
     struct Bufs { DevBuf fb, ids[3][2], keys[2], vals[2], hist, nodes, act[2], cnt, nodeChunk0, chunkNode, chunkBegin, cboxL, cboxR, carryL, carryR, rc, cbestCost, cbestPos, dec, sideL, sideR, freshOf,
-                  swapOf, leftCountOf, startOf, countOf, leftTable, pcnt, poff;
+                  swapOf, leftCountOf, startOf, countOf, leftTable, pcnt, poff, smallList, aux;
                   ~Bufs() { DevBuf* all[] = {&fb, &ids[0][0], &ids[0][1], &ids[1][0], &ids[1][1], &ids[2][0], &ids[2][1], &keys[0], &keys[1], &vals[0], &vals[1], &hist, &nodes, &act[0], &act[1], &cnt, &nodeChunk0,
                                              &chunkNode, &chunkBegin, &cboxL, &cboxR, &carryL, &carryR, &rc, &cbestCost, &cbestPos, &dec, &sideL, &sideR, &freshOf, &swapOf, &leftCountOf, &startOf, &countOf,
-                                             &leftTable, &pcnt, &poff}; for (DevBuf* b : all) b->release(); } } B;
+                                             &leftTable, &pcnt, &poff, &smallList, &aux}; for (DevBuf* b : all) b->release(); } } B;
     HIPC(B.fb.ensure((size_t)n * 32));
     for (int a = 0; a < 3; a++) for (int k = 0; k < 2; k++) HIPC(B.ids[a][k].ensure((size_t)n * 4));
     for (int k = 0; k < 2; k++) { HIPC(B.keys[k].ensure((size_t)n * 4)); HIPC(B.vals[k].ensure((size_t)n * 4)); HIPC(B.act[k].ensure(nodeCount * 4)); }
@@ -664,10 +664,12 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
     HIPC(B.dec.ensure(nodeCount * sizeof(Decision))); HIPC(B.sideL.ensure((size_t)Cmax * sizeof(BBox))); HIPC(B.sideR.ensure((size_t)Cmax * sizeof(BBox)));
     HIPC(B.freshOf.ensure(nodeCount * 4)); HIPC(B.swapOf.ensure(nodeCount * 4)); HIPC(B.leftCountOf.ensure(nodeCount * 4)); HIPC(B.startOf.ensure(nodeCount * 4)); HIPC(B.countOf.ensure(nodeCount * 4));
     HIPC(B.leftTable.ensure((size_t)n)); HIPC(B.pcnt.ensure((size_t)3 * Cmax * 4)); HIPC(B.poff.ensure((size_t)3 * Cmax * 4));
+    HIPC(B.smallList.ensure(nodeCount * 4)); HIPC(B.aux.ensure((size_t)n * 4));
+    int smallMax = 32; if (const char* e = getenv("IDKPT_BVH_SMALL")) smallMax = std::max(0, std::min(128, atoi(e)));   // subtrees of at most this many fragments are finished by one thread each
     HIPC(hipMemcpyAsync(B.fb.p, fragBoxes, (size_t)n * 32, hipMemcpyHostToDevice, st));
-    // device words: [0] = n (count for the sort kernels), [1] = chunk count of the level, [2] = next level's node count
+    // device words: [0] = n (count for the sort kernels), [1] = chunk count of the level, [2] = next level's node count, [3] = small subtrees
     uint32_t* cnt = B.cnt.as<uint32_t>();
-    { uint32_t h[3] = {(uint32_t)n, 0u, 0u}; HIPC(hipMemcpyAsync(cnt, h, 12, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }
+    { uint32_t h[4] = {(uint32_t)n, 0u, 0u, 0u}; HIPC(hipMemcpyAsync(cnt, h, 16, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }
     // ---- BLAS.GetBuildData: per axis a stable sort of the ids by FloatToKey(min + max) (five 7-bit LSD passes over the 32-bit key)
     uint32_t* digitTotals = B.hist.as<uint32_t>() + (size_t)SORT_RADIX * nTiles;
     for (int axis = 0; axis < 3; axis++) {
@@ -688,6 +690,7 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
       int one = 1, two = 2; HIPC(hipMemcpyAsync(B.act[0].p, &one, 4, hipMemcpyHostToDevice, st)); HIPC(hipMemcpyAsync(B.freshOf.as<int>() + 1, &two, 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }
     HNodeG* nodes = B.nodes.as<HNodeG>();
     int A = 1, curAct = 0, pp = 0, levels = 0;
+    if (n <= smallMax) { A = 0; int one = 1; HIPC(hipMemcpyAsync(B.smallList.p, &one, 4, hipMemcpyHostToDevice, st)); HIPC(hipMemcpyAsync(cnt + 3, &one, 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }
     while (A > 0) {
         Level L; L.act = B.act[curAct].as<int>(); L.A = A; L.nodeChunk0 = B.nodeChunk0.as<int>(); L.chunkNode = B.chunkNode.as<int>(); L.chunkBegin = B.chunkBegin.as<int>(); L.chunkCount = (int*)(cnt + 1);
         const int Cl = std::min(Cmax, n / CH + A + 1);            // grid bound for this level's chunks (workgroups beyond the real count exit)
@@ -699,17 +702,17 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
         hipLaunchKernelGGL(k_chunks, dim3(1), dim3(1024), 0, st, (const HNodeG*)nodes, L);
         hipLaunchKernelGGL(k_snapshot_ranges, dim3(gA), dim3(256), 0, st, (const HNodeG*)nodes, L, B.startOf.as<int>(), B.countOf.as<int>());
         hipLaunchKernelGGL(k_chunk_box, dim3(Cl, 3), dim3(CH), 0, st, (const HNodeG*)nodes, L, fb, i0, i1, i2, B.cboxL.as<BBox>(), B.cboxR.as<BBox>(), Cmax);
-        hipLaunchKernelGGL(k_node_carry, dim3(gA), dim3(256), 0, st, nodes, L, (const BBox*)B.cboxL.as<BBox>(), (const BBox*)B.cboxR.as<BBox>(), B.carryL.as<BBox>(), B.carryR.as<BBox>(), Cmax);
+        hipLaunchKernelGGL(k_node_carry, dim3(A), dim3(CH), 0, st, nodes, L, (const BBox*)B.cboxL.as<BBox>(), (const BBox*)B.cboxR.as<BBox>(), B.carryL.as<BBox>(), B.carryR.as<BBox>(), Cmax);
         hipLaunchKernelGGL(k_chunk_rc, dim3(Cl, 3), dim3(CH), 0, st, (const HNodeG*)nodes, L, fb, i0, i1, i2, (const BBox*)B.carryR.as<BBox>(), B.rc.as<float>(), n, Cmax);
         hipLaunchKernelGGL(k_chunk_cost, dim3(Cl, 3), dim3(CH), 0, st, (const HNodeG*)nodes, L, fb, i0, i1, i2, (const BBox*)B.carryL.as<BBox>(), (const float*)B.rc.as<float>(), B.cbestCost.as<float>(), B.cbestPos.as<int>(), n, Cmax);
-        hipLaunchKernelGGL(k_node_decide, dim3(gA), dim3(256), 0, st, (const HNodeG*)nodes, L, (const float*)B.cbestCost.as<float>(), (const int*)B.cbestPos.as<int>(), B.dec.as<Decision>(), Cmax);
+        hipLaunchKernelGGL(k_node_decide, dim3(A), dim3(CH), 0, st, (const HNodeG*)nodes, L, (const float*)B.cbestCost.as<float>(), (const int*)B.cbestPos.as<int>(), B.dec.as<Decision>(), Cmax);
         hipLaunchKernelGGL(k_chunk_sides, dim3(Cl), dim3(CH), 0, st, (const HNodeG*)nodes, L, (const Decision*)B.dec.as<Decision>(), fb, i0, i1, i2, B.sideL.as<BBox>(), B.sideR.as<BBox>());
-        hipLaunchKernelGGL(k_node_finalize, dim3(gA), dim3(256), 0, st, nodes, L, B.dec.as<Decision>(), (const BBox*)B.sideL.as<BBox>(), (const BBox*)B.sideR.as<BBox>(), B.freshOf.as<int>(), B.swapOf.as<int>(), B.leftCountOf.as<int>(),
-                           B.act[1 - curAct].as<int>(), (int*)(cnt + 2));
+        hipLaunchKernelGGL(k_node_finalize, dim3(A), dim3(CH), 0, st, nodes, L, B.dec.as<Decision>(), (const BBox*)B.sideL.as<BBox>(), (const BBox*)B.sideR.as<BBox>(), B.freshOf.as<int>(), B.swapOf.as<int>(), B.leftCountOf.as<int>(),
+                           B.act[1 - curAct].as<int>(), (int*)(cnt + 2), B.smallList.as<int>(), (int*)(cnt + 3), smallMax);
         hipLaunchKernelGGL(k_mark, dim3(Cl), dim3(CH), 0, st, (const HNodeG*)nodes, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.swapOf.as<int>(), (const int*)B.startOf.as<int>(), (const int*)B.countOf.as<int>(), i0, i1, i2, B.leftTable.as<uint8_t>());
         for (int a = 0; a < 3; a++) HIPC(hipMemcpyAsync(B.ids[a][1 - pp].p, B.ids[a][pp].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_part_count, dim3(Cl, 3), dim3(CH), 0, st, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.startOf.as<int>(), (const int*)B.countOf.as<int>(), i0, i1, i2, (const uint8_t*)B.leftTable.as<uint8_t>(), B.pcnt.as<int>(), Cmax);
-        hipLaunchKernelGGL(k_part_offsets, dim3(gA), dim3(256), 0, st, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.pcnt.as<int>(), B.poff.as<int>(), Cmax);
+        hipLaunchKernelGGL(k_part_offsets, dim3(A), dim3(CH), 0, st, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.pcnt.as<int>(), B.poff.as<int>(), Cmax);
         hipLaunchKernelGGL(k_part_scatter, dim3(Cl, 3), dim3(CH), 0, st, L, (const Decision*)B.dec.as<Decision>(), (const int*)B.startOf.as<int>(), (const int*)B.countOf.as<int>(), (const int*)B.leftCountOf.as<int>(), i0, i1, i2, o0, o1, o2,
                            (const uint8_t*)B.leftTable.as<uint8_t>(), (const int*)B.poff.as<int>(), Cmax);
         HIPC(hipGetLastError());
@@ -718,6 +721,9 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
         A = (int)next; curAct = 1 - curAct; pp = 1 - pp; levels++;
         if (levels > 4096) return fail(ctx, IDKPT_ERR_UNKNOWN, "idkptBuildBlasCore: recursion does not terminate");
     }
+    hipLaunchKernelGGL(k_small_subtrees, dim3((unsigned)((nodeCount + 63) / 64)), dim3(64), 0, st, nodes, (const int*)B.smallList.as<int>(), (const int*)(cnt + 3), (const float4*)B.fb.as<float4>(), B.ids[0][pp].as<int>(), B.ids[1][pp].as<int>(), B.ids[2][pp].as<int>(),
+                       B.rc.as<float>(), B.aux.as<int>(), B.leftTable.as<uint8_t>(), (const int*)B.freshOf.as<int>());
+    HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(outNodes, B.nodes.p, nodeCount * 32, hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(outSortedX, B.ids[0][pp].p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
