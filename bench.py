@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: contiguous strips + per-bounce count exchange (gloo control group) so that RayDepth > 2 output equals the 1-GPU output bit for bit; default = interleaved rows (exact at RayDepth 2)")
     ap.add_argument("--interactive", type=int, default=0, metavar="F", help="secondary mode: every step is a NEW frame (own camera, own image, ResetAccumulation semantics) with F frames in flight through the frame ring; every finished frame is exchanged when N > 1")
     ap.add_argument("--spawn", action="store_true", help="--gpus N without a launcher: start N processes (torch.distributed.run, one rank per GPU, RCCL) instead of the default ONE process driving ONE multi-device context (idkptCreate(deviceCount = N))")
+    ap.add_argument("--cpu-build", action="store_true", help="build the BLAS entirely on the host (libidkbvh) instead of running the SweepSAH core on the GPU; the result is the same bytes")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 256")
     args = ap.parse_args()
 
@@ -112,7 +113,18 @@ def main():
 
     # ---- scene: rank 0 builds (native SweepSAH + PreSplit builder), RCCL broadcast to the others
     t0 = time.time()
-    scene = (S.soup_scene(args.tris, NativeBuilder(), seed=1) if args.scene == "soup" else S.atrium_scene(args.tris, NativeBuilder())) if rank == 0 else None
+    scene, builder_kind, blas_build_ms = None, "cpu", None
+    if rank == 0:
+        if args.cpu_build:
+            builder = NativeBuilder()
+        else:   # SweepSAH core on the GPU (idkptBuildBlasCore), PreSplit and the tail passes in libidkbvh: same bytes as the CPU build
+            from idkengine_amd.bvh import GpuBuilder
+            from idkengine_amd.pathtracer import PathTracer as _PT
+            _bpt = _PT(8, 8); builder = GpuBuilder(_bpt); builder_kind = "gpu-core"
+        scene = S.soup_scene(args.tris, builder, seed=1) if args.scene == "soup" else S.atrium_scene(args.tris, builder)
+        blas_build_ms = round(builder.last_build_ms, 1)
+        if not args.cpu_build:
+            _bpt.Dispose()
     build_s = time.time() - t0
     if world > 1:
         scene = D.broadcast_scene(scene, src=0, device=device)
@@ -214,7 +226,7 @@ def main():
                                      f"atrium-{args.tris} (procedural two-storey colonnaded hall, connected surfaces, {len(scene.blas_triangles)} BLAS triangles, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, camera inside looking down the hall"),
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
                        "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather") if world > 1 else "none")),
-                       "bvh_build_s": round(build_s, 2)},
+                       "bvh_build_s": round(build_s, 2), "blas_build_ms": blas_build_ms, "bvh_builder": builder_kind},
             "roofline": roofline(st, pairs * reps / group, tri_tests * reps / group, traversed * reps / group, args, world * group, B if rem == 0 else (rem if q == 0 else None), torch, device),
         }
         if world * group == 1 and not args.no_extras:

@@ -7,7 +7,7 @@ from . import gputypes as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libidkbvh.so")
-SYMBOLS = ["idkbvhBuildBlas", "idkbvhBlasBegin", "idkbvhBlasFragments", "idkbvhBlasCoreCpu", "idkbvhBlasCoreGet", "idkbvhBlasCoreSet", "idkbvhBlasFinish", "idkbvhBlasGetInfo", "idkbvhBlasCopy", "idkbvhBlasFree", "idkbvhInstanceWorldBounds", "idkbvhBuildTlas", "idkbvhRefitBlas"]
+SYMBOLS = ["idkbvhBuildBlas", "idkbvhBlasBegin", "idkbvhBlasFragments", "idkbvhBlasCoreCpu", "idkbvhBlasCoreGet", "idkbvhBlasCoreSet", "idkbvhBlasCoreBuffers", "idkbvhBlasFinish", "idkbvhBlasGetInfo", "idkbvhBlasCopy", "idkbvhBlasFree", "idkbvhInstanceWorldBounds", "idkbvhBuildTlas", "idkbvhRefitBlas"]
 _lib = None
 
 
@@ -28,6 +28,7 @@ def load():
         L.idkbvhBlasCoreCpu.argtypes = [C.c_void_p]
         L.idkbvhBlasCoreGet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.idkbvhBlasCoreSet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.idkbvhBlasCoreBuffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.idkbvhBlasFinish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.idkbvhBlasGetInfo.argtypes = [C.c_void_p, C.c_void_p]
         L.idkbvhBlasCopy.argtypes = [C.c_void_p] * 5
@@ -130,10 +131,14 @@ class GpuBuilder(NativeBuilder):
         try:
             bp = C.c_void_p(); n = C.c_int32()
             L.idkbvhBlasFragments(h, C.byref(bp), C.byref(n))
-            boxes = np.ctypeslib.as_array(C.cast(bp, C.POINTER(C.c_float)), shape=(n.value, 8))
-            nodes, order = self.core_on_gpu(boxes)
-            if L.idkbvhBlasCoreSet(h, nodes.ctypes.data, order.ctypes.data) != 0 or L.idkbvhBlasFinish(h, positions.ctypes.data, tris.ctypes.data) != 0:
-                raise RuntimeError("idkbvhBlasCoreSet / idkbvhBlasFinish failed")
+            # the GPU core writes straight into the builder's own arrays
+            pn = C.c_void_p(); po = C.c_void_p(); lv = C.c_int32()
+            if L.idkbvhBlasCoreBuffers(h, C.byref(pn), C.byref(po)) != 0:
+                raise RuntimeError("idkbvhBlasCoreBuffers failed")
+            self._pt._check(self._pt._L.idkptBuildBlasCore(self._pt._ctx, bp, n.value, pn, po, C.byref(lv)))
+            self.last_levels = lv.value
+            if L.idkbvhBlasFinish(h, positions.ctypes.data, tris.ctypes.data) != 0:
+                raise RuntimeError("idkbvhBlasFinish failed")
             info = BlasInfo(); L.idkbvhBlasGetInfo(h, C.addressof(info))
             out_nodes = np.zeros(info.NodeCount, T.GpuBlasNode); out_tris = np.zeros(info.TriangleCount, T.GpuBlasTriangle)
             parents = np.zeros(info.ParentIndexCount, np.int32); leaves = np.zeros(info.LeafIndexCount, np.int32)

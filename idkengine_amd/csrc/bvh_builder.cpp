@@ -564,10 +564,19 @@ int32_t idkbvhBlasCoreSet(idkbvh_blas* h, const GpuBlasNode* nodes, const int32_
     h->b.coreSet(reinterpret_cast<const HNode*>(nodes), sorted0);
     return 0;
 }
+int32_t idkbvhBlasCoreBuffers(idkbvh_blas* h, GpuBlasNode** nodes, int32_t** sorted0)
+{
+    if (!h || h->b.frag.empty() || !nodes || !sorted0) return 2;
+    const size_t n = h->b.frag.size();
+    h->b.nodes.resize(std::max<size_t>(2 * n, 4)); h->b.sorted[0].resize(n);      // written in full by the external core
+    *nodes = reinterpret_cast<GpuBlasNode*>(h->b.nodes.data()); *sorted0 = h->b.sorted[0].data();
+    return 0;
+}
 int32_t idkbvhBlasFinish(idkbvh_blas* h, const float* positions, const GpuBlasTriangle* tris)
 {
     if (!h || !positions || !tris || h->b.nodes.empty() || h->b.sorted[0].empty()) return 2;
     h->b.positions = positions; h->b.tris = tris;
+    h->b.lap("core");
     h->b.finish();
     h->b.positions = nullptr; h->b.tris = nullptr;
     return 0;

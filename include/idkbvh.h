@@ -53,6 +53,8 @@ IDKBVH_API int32_t idkbvhBlasFragments(const idkbvh_blas* blas, const float** ou
 IDKBVH_API int32_t idkbvhBlasCoreCpu(idkbvh_blas* blas);
 IDKBVH_API int32_t idkbvhBlasCoreGet(const idkbvh_blas* blas, GpuBlasNode* nodes /* 2 * fragments, may be NULL */, int32_t* sortedIdsX /* fragments, may be NULL */);
 IDKBVH_API int32_t idkbvhBlasCoreSet(idkbvh_blas* blas, const GpuBlasNode* nodes, const int32_t* sortedIdsX);
+/* the builder's own core arrays, sized for the current fragments, for an external core to write into directly (instead of idkbvhBlasCoreSet's copy) */
+IDKBVH_API int32_t idkbvhBlasCoreBuffers(idkbvh_blas* blas, GpuBlasNode** outNodes, int32_t** outSortedIdsX);
 IDKBVH_API int32_t idkbvhBlasFinish(idkbvh_blas* blas, const float* positions, const GpuBlasTriangle* tris);
 IDKBVH_API int32_t idkbvhBlasGetInfo(const idkbvh_blas* blas, idkbvh_blas_info* outInfo);
 /* Copies the results into caller arrays sized from idkbvhBlasGetInfo (parents/leaves may be NULL). */
