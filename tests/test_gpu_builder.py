@@ -72,3 +72,28 @@ def test_signed_zero_bounds_follow_the_sse_tie_rule(native_builder):
         gpu_nodes, gpu_order = gb.core_on_gpu(boxes)
         assert gpu_order.tobytes() == cpu_order.tobytes() and gpu_nodes.tobytes() == cpu_nodes.tobytes()
     pt.Dispose()
+
+
+@pytest.mark.parametrize("small", ["0", "5", "128"])
+def test_level_synchronous_and_per_thread_paths_agree(small, native_builder, monkeypatch):
+    """IDKPT_BVH_SMALL = 0: every node goes through the chunked level-synchronous kernels; 128: subtrees of up to 128 fragments are finished by
+    one thread.  Both must give the CPU core's bytes; so must degenerate inputs (1, 2, 3 fragments; all fragments identical)."""
+    from idkengine_amd.bvh import GpuBuilder
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    monkeypatch.setenv("IDKPT_BVH_SMALL", small)
+    pt = PathTracer(8, 8); gb = GpuBuilder(pt)
+    rng = np.random.default_rng(int(small) + 1)
+    for n in (1, 2, 3, 7, 300, 5000):
+        p = rng.uniform(-3, 3, (n, 3, 3)).astype(np.float32)
+        if n == 7:
+            p[:] = p[0]                                            # identical fragments: every cost ties
+        positions = p.reshape(-1, 3)
+        tris = np.zeros(n, T.GpuBlasTriangle); tris["X"] = np.arange(n) * 3; tris["Y"] = tris["X"] + 1; tris["Z"] = tris["X"] + 2
+        for refittable in (True, False):
+            boxes, cpu_nodes, cpu_order = native_builder.core_arrays(positions, tris, refittable)
+            gpu_nodes, gpu_order = gb.core_on_gpu(boxes)
+            assert gpu_order.tobytes() == cpu_order.tobytes() and gpu_nodes.tobytes() == cpu_nodes.tobytes(), (n, refittable)
+            a = gb.build_blas(positions, tris, refittable); b = native_builder.build_blas(positions, tris, refittable)
+            assert a["nodes"].tobytes() == b["nodes"].tobytes() and a["triangles"].tobytes() == b["triangles"].tobytes()
+    pt.Dispose()
