@@ -7,6 +7,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <algorithm>
 #include "../../include/idkpt.h"
 #include "pt_kernels.hpp"
@@ -645,6 +646,9 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
     REQUIRE(n <= (1 << 27), "idkptBuildBlasCore: too many fragments");
     HIPC(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    const bool timing = getenv("IDKPT_BVH_TIMING") != nullptr;   // developer knob: host-side phase times on stderr
+    auto tq = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; (void)hipStreamSynchronize(st); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[idkpt bvh] %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tq).count()); tq = t; };
     const size_t nodeCount = (size_t)std::max(2 * n, 4);
     const int Cmax = n / CH + n + 2;                             // chunks of a level: at most one per CH positions plus one per active node
     struct Bufs { DevBuf fb, ids[3][2], keys[2], vals[2], hist, nodes, act[2], cnt, nodeChunk0, chunkNode, chunkBegin, cboxL, cboxR, carryL, carryR, rc, cbestCost, cbestPos, dec, sideL, sideR, freshOf,
@@ -666,7 +670,9 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
     HIPC(B.leftTable.ensure((size_t)n)); HIPC(B.pcnt.ensure((size_t)3 * Cmax * 4)); HIPC(B.poff.ensure((size_t)3 * Cmax * 4));
     HIPC(B.smallList.ensure(nodeCount * 4)); HIPC(B.aux.ensure((size_t)n * 4));
     int smallMax = 32; if (const char* e = getenv("IDKPT_BVH_SMALL")) smallMax = std::max(0, std::min(128, atoi(e)));   // subtrees of at most this many fragments are finished by one thread each
+    lap("alloc");
     HIPC(hipMemcpyAsync(B.fb.p, fragBoxes, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    lap("upload");
     // device words: [0] = n (count for the sort kernels), [1] = chunk count of the level, [2] = next level's node count, [3] = small subtrees
     uint32_t* cnt = B.cnt.as<uint32_t>();
     { uint32_t h[4] = {(uint32_t)n, 0u, 0u, 0u}; HIPC(hipMemcpyAsync(cnt, h, 16, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }
@@ -684,6 +690,7 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
         }
         HIPC(hipMemcpyAsync(B.ids[axis][0].p, B.vals[cur].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     }
+    lap("sort");
     // ---- the recursion, one level at a time
     HIPC(hipMemsetAsync(B.nodes.p, 0, nodeCount * 32, st));
     { HNodeG root = {}; root.startOrChild = 0; root.count = n; HIPC(hipMemcpyAsync(B.nodes.as<HNodeG>() + 1, &root, 32, hipMemcpyHostToDevice, st));
@@ -721,12 +728,15 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
         A = (int)next; curAct = 1 - curAct; pp = 1 - pp; levels++;
         if (levels > 4096) return fail(ctx, IDKPT_ERR_UNKNOWN, "idkptBuildBlasCore: recursion does not terminate");
     }
+    lap("levels");
     hipLaunchKernelGGL(k_small_subtrees, dim3((unsigned)((nodeCount + 63) / 64)), dim3(64), 0, st, nodes, (const int*)B.smallList.as<int>(), (const int*)(cnt + 3), (const float4*)B.fb.as<float4>(), B.ids[0][pp].as<int>(), B.ids[1][pp].as<int>(), B.ids[2][pp].as<int>(),
                        B.rc.as<float>(), B.aux.as<int>(), B.leftTable.as<uint8_t>(), (const int*)B.freshOf.as<int>());
     HIPC(hipGetLastError());
+    lap("subtrees");
     HIPC(hipMemcpyAsync(outNodes, B.nodes.p, nodeCount * 32, hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(outSortedX, B.ids[0][pp].p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
+    lap("download");
     if (outLevels) *outLevels = levels;
     return IDKPT_OK;
 }
