@@ -14,9 +14,14 @@ Metric (BASELINE.json): Mray/s (primary + 1 bounce) at 1920x1080 on the syntheti
               others from the root box), `single_frame` (one frame at a time with a synchronisation per frame, SURVEY 8(d)'s
               protocol: what a host sees that cannot keep 32 samples in flight) and `interior` (camera inside the soup: every pixel
               traverses — the stand-in for a Sponza-class view).
-  N GPUs    = image rows dealt round-robin to the ranks (idkengine_amd/dist.py); the only exchange is the RCCL all-gather of
-              the finished row shards, inside the timed region.  Total work per step is fixed -> "strong" scaling.
-              `python bench.py --gpus N` without a launcher starts its own ranks (torch.distributed.run, 127.0.0.1).
+  N GPUs    = one process per GPU (torch.distributed launch, the driver's command): sample-parallel by default (--shard samples) — every rank
+              renders WHOLE frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence), i.e. a step is one full-frame pass
+              on every GPU and `value` counts the rays of all of them; the displayed frame (N x samples_in_flight samples) is the
+              all-reduced mean of the ranks' accumulations, exchanged inside the timed region; nothing crosses xGMI inside a frame.
+              Per-GPU work is fixed -> "weak" scaling.  --shard rows deals the frame's rows over the ranks instead (bit-identical to one
+              GPU, all-gather of the row shards, total work per step fixed -> "strong"; the latency mode).
+              `python bench.py --gpus N` without a launcher drives ONE multi-device context (idkptCreate(deviceCount = N): rows / strips
+              per device, "strong"); --spawn starts ranks instead (torch.distributed.run, 127.0.0.1).
   roofline  = traversal kernel (k_trace2).  achieved = algorithmic bytes (64 B per node-pair visit + 48 B per triangle test + 72 B per
               traversed ray, exact visit counts from the counting build) / HIP-event time of its launches in the timed region.
               The working set (110 MB) lives in L2 + Infinity Cache, so HBM is not what binds (hbm.* below: the algorithmic rate
@@ -78,6 +83,7 @@ def main():
     ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: contiguous strips + per-bounce count exchange (gloo control group) so that RayDepth > 2 output equals the 1-GPU output bit for bit; default = interleaved rows (exact at RayDepth 2)")
     ap.add_argument("--interactive", type=int, default=0, metavar="F", help="secondary mode: every step is a NEW frame (own camera, own image, ResetAccumulation semantics) with F frames in flight through the frame ring; every finished frame is exchanged when N > 1")
     ap.add_argument("--spawn", action="store_true", help="--gpus N without a launcher: start N processes (torch.distributed.run, one rank per GPU, RCCL) instead of the default ONE process driving ONE multi-device context (idkptCreate(deviceCount = N))")
+    ap.add_argument("--shard", choices=["samples", "rows"], default="samples", help="one process per GPU (torch.distributed launch) only.  samples (default): every rank renders WHOLE frames for its own sample indices (idkptSetSampleSequence(rank, N)), one all-reduce per displayed frame, weak scaling — per-GPU work does not shrink with N.  rows: the frame's rows are dealt over the ranks (bit-identical to one GPU, strong scaling, the latency mode)")
     ap.add_argument("--cpu-build", action="store_true", help="build the BLAS entirely on the host (libidkbvh) instead of running the SweepSAH core on the GPU; the result is the same bytes")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 256")
     args = ap.parse_args()
@@ -94,7 +100,8 @@ def main():
     from idkengine_amd.bvh import NativeBuilder
     from idkengine_amd import dist as D
 
-    args.batch = max(1, min(256, args.batch * world * group))
+    sample_parallel = world > 1 and args.shard == "samples" and not args.exact_deep_paths and args.interactive == 0
+    args.batch = max(1, min(256, args.batch * (1 if sample_parallel else world * group)))   # row sharding: a rank holds 1/N of every frame, so N times the samples keep its launches as large
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
     # developer smoke test of the N > 1 flow on a single-GPU box: IDKPT_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and uses gloo
@@ -145,11 +152,17 @@ def main():
                 return pt.image_device_ptr(0)
         frame = _GroupFrame()
     else:
-        control = dist.new_group(backend="gloo") if (world > 1 and args.exact_deep_paths) else None   # CPU-side group for the tiny count exchange
-        r = D.GpuShardRenderer(W, H, world, rank, local_rank, exact_deep_paths=bool(control), control_group=control)
-        r.upload_scene(scene); r.set_camera(cam)
-        pt = r.pt
-        frame = D.ShardedFrame(r, W, H) if world > 1 else None
+        if sample_parallel:
+            r = D.SampleParallelRenderer(W, H, world, rank, 0 if one_device else local_rank)
+            r.upload_scene(scene); r.set_camera(cam)
+            pt = r.pt
+            frame = D.SampleParallelFrame(r)
+        else:
+            control = dist.new_group(backend="gloo") if (world > 1 and args.exact_deep_paths) else None   # CPU-side group for the tiny count exchange
+            r = D.GpuShardRenderer(W, H, world, rank, local_rank, exact_deep_paths=bool(control), control_group=control)
+            r.upload_scene(scene); r.set_camera(cam)
+            pt = r.pt
+            frame = D.ShardedFrame(r, W, H) if world > 1 else None
     pt.RayDepth = depth; pt.SamplesPerPixel = 1; pt.DoRaySorting = args.sort
 
     if args.interactive > 0:
@@ -214,18 +227,18 @@ def main():
 
     if rank == 0:
         value = rays_rep / dt / 1e6
-        headline = (args.tris, depth, args.sort, W, H, args.batch, args.view, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world * group), "headline", "soup")
+        headline = (args.tris, depth, args.sort, W, H, args.batch, args.view, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, 32 if sample_parallel else min(256, 32 * world * group), "headline", "soup")
         view_txt = "camera at z = 25 outside the soup (SURVEY 8d config 3)" if args.view == "headline" else "camera INSIDE the soup at the origin"
         out = {
             "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri {args.scene} scene, {args.view if args.scene == 'soup' else 'interior'} view (secondary config)", "value": round(value, 2), "unit": "Mray/s",
             "n_gpus": world * group, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if sample_parallel else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": reps, "repeat_ms": [round(x * 1e3, 3) for x in repeat_s], "statistic": "median repetition of the timed region",
             "traversed_mray_s": round(traversed_rep / dt / 1e6, 2),
             "config": {"workload": (f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, {view_txt}" if args.scene == "soup" else
                                      f"atrium-{args.tris} (procedural two-storey colonnaded hall, connected surfaces, {len(scene.blas_triangles)} BLAS triangles, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, camera inside looking down the hall"),
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
-                       "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather") if world > 1 else "none")),
+                       "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
                        "bvh_build_s": round(build_s, 2), "blas_build_ms": blas_build_ms, "bvh_builder": builder_kind},
             "roofline": roofline(st, pairs * reps / group, tri_tests * reps / group, traversed * reps / group, args, world * group, B if rem == 0 else (rem if q == 0 else None), torch, device),
         }

@@ -12,7 +12,7 @@ SYMBOLS = [
     "idkptSetSize", "idkptSetRowSharding", "idkptSetRowRange", "idkptSetBounceExchange", "idkptSetSettings", "idkptGetSettings",
     "idkptSetPerFrame", "idkptSetPerFrameData", "idkptUploadScene", "idkptUpdateBuffer", "idkptSetLightCount",
     "idkptBuildTlas", "idkptBuildTlasOnDevice", "idkptBuildBlasCore", "idkptRefitBlas", "idkptUploadUnskinnedVertices", "idkptSkin", "idkptDownloadBuffer",
-    "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptRender", "idkptSynchronize", "idkptDownload",
+    "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptSetSampleSequence", "idkptRender", "idkptSynchronize", "idkptDownload",
     "idkptDownloadRays", "idkptDownloadAliveQueue", "idkptEnablePrimaryHitCapture", "idkptDownloadPrimaryHits",
     "idkptGetStats", "idkptResetStats", "idkptEnableCounters", "idkptEnableTiming", "idkptGetImageDevicePtr",
     "idkptSetStream", "idkptGetStream", "idkptSetMaxBatch", "idkptFlush", "idkptTraceRays", "idkptTraceShadows", "idkptSetFrameRing", "idkptBeginFrame", "idkptDownloadFrame", "idkptGetFrameDevicePtr",
@@ -43,7 +43,7 @@ def load():
         "idkptUpdateBuffer": [vp, i32, sz, sz, vp], "idkptSetLightCount": [vp, i32], "idkptBuildTlas": [vp, vp, i32], "idkptBuildTlasOnDevice": [vp, i32], "idkptBuildBlasCore": [vp, vp, i32, vp, vp, vp], "idkptTraceRays": [vp, vp, sz, u32, vp], "idkptTraceShadows": [vp, vp, vp, vp, vp], "idkptSetFrameRing": [vp, i32], "idkptBeginFrame": [vp, C.POINTER(i32)],
         "idkptDownloadFrame": [vp, i32, i32, vp, sz], "idkptGetFrameDevicePtr": [vp, i32, i32, C.POINTER(vp), C.POINTER(sz)],
         "idkptRefitBlas": [vp, i32], "idkptUploadUnskinnedVertices": [vp, vp, i32], "idkptSkin": [vp, u32, u32, u32, u32],
-        "idkptDownloadBuffer": [vp, i32, sz, sz, vp], "idkptResetAccumulation": [vp], "idkptGetAccumulatedSamples": [vp, C.POINTER(u32)],
+        "idkptDownloadBuffer": [vp, i32, sz, sz, vp], "idkptResetAccumulation": [vp], "idkptSetSampleSequence": [vp, u32, u32], "idkptGetAccumulatedSamples": [vp, C.POINTER(u32)],
         "idkptRender": [vp], "idkptSynchronize": [vp], "idkptDownload": [vp, i32, vp, sz], "idkptDownloadRays": [vp, vp, sz],
         "idkptDownloadAliveQueue": [vp, vp, sz, C.POINTER(u32)], "idkptEnablePrimaryHitCapture": [vp, i32],
         "idkptDownloadPrimaryHits": [vp, vp, vp, vp, sz], "idkptGetStats": [vp, vp], "idkptResetStats": [vp],

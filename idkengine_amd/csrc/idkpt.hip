@@ -52,6 +52,7 @@ struct dev_ctx {
     // AccumulatedSamples index, so several frames (different cameras) can be in flight in one batch
     int ringSize = 1, curSlot = 0; bool ringStarted = false; std::vector<uint32_t> accum = std::vector<uint32_t>(1, 0u);
     bool counters = false, timing = false, capturePrimary = false, forceGeneric = false, noTileCull = false; int traceVariant = 0;
+    uint32_t seqFirst = 0, seqStride = 1;                         // idkptSetSampleSequence
     // scene
     bool haveScene = false, frameOk = false;
     DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;   // (+ camTab below)
@@ -867,6 +868,19 @@ static int32_t dev_Skin(dev_ctx* ctx, uint32_t inOff, uint32_t outOff, uint32_t 
 }
 
 static int32_t dev_ResetAccumulation(dev_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; ctx->accum[ctx->curSlot] = 0; return IDKPT_OK; }
+// Sample-parallel rendering: context r of N renders the reference's samples r, r + N, r + 2N, ... (their RNG streams), each context accumulating
+// its own running mean; the mean of the N accumulations is an accumulation over N * K distinct reference samples.
+static int32_t dev_SetSampleSequence(dev_ctx* ctx, uint32_t first, uint32_t stride)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(stride >= 1, "idkptSetSampleSequence: stride must be >= 1");
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    if (first == ctx->seqFirst && stride == ctx->seqStride) return IDKPT_OK;
+    ctx->seqFirst = first; ctx->seqStride = stride;
+    std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);           // other RNG streams: the accumulation starts over
+    return IDKPT_OK;
+}
 static int32_t dev_GetAccumulatedSamples(dev_ctx* ctx, uint32_t* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->accum[ctx->curSlot]; return IDKPT_OK; }
 
 static DScene make_dscene(dev_ctx* ctx)
@@ -908,7 +922,8 @@ static int flush_batch(dev_ctx* ctx)
     f.outputAovs = ctx->st.OutputAOVs;
     f.batch = B; f.Npad = Npad;
     for (int k = 0; k < MAX_BATCH; k++) { f.accum[k] = k < B ? ctx->pending[k].accum : 0u; f.slotOf[k] = (uint32_t)(k < B ? ctx->pending[k].slot : 0); }
-    f.accumulated = f.accum[0];
+    f.seqFirst = ctx->seqFirst; f.seqStride = ctx->seqStride;
+    f.accumulated = f.seqFirst + f.accum[0] * f.seqStride;
     f.cams = nullptr;
     if (ctx->ringSize > 1) {   // frame ring: every sample renders with the camera it was queued with
         // pinned double-buffered staging: no stream synchronisation per batch (the host may run ahead of the GPU)

@@ -409,6 +409,7 @@ int32_t idkptGetFrameDevicePtr(idkpt_ctx* c, int32_t slot, int32_t image, void**
 }
 
 int32_t idkptResetAccumulation(idkpt_ctx* c) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; for (dev_ctx* m : c->dev) dev_ResetAccumulation(m); return IDKPT_OK; }
+int32_t idkptSetSampleSequence(idkpt_ctx* c, uint32_t first, uint32_t stride) { REPLICATE(SetSampleSequence, first, stride); }
 int32_t idkptGetAccumulatedSamples(idkpt_ctx* c, uint32_t* out) { if (!c || !out) return IDKPT_ERR_INVALID_ARGUMENT; return dev_GetAccumulatedSamples(c->dev[0], out); }
 
 int32_t idkptRender(idkpt_ctx* c)

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_regen_culled(DScene s, Frame f, RayBufs
     const uint8_t flag = contFlag[rid];
     if (flag != 2 && flag != 4) return;                                 // 2: culled per pixel, 4: culled per tile (no ray was generated at all); bit 0 = continues
     f3 origin; f2 pd; uint32_t seed;
-    gen_primary(f, smp, pix, f.accum[smp], origin, pd, seed);
+    gen_primary(f, smp, pix, sample_index(f, smp), origin, pd, seed);
     rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f);
     rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x);
     if (flag == 4) {                                                    // the miss branch of FirstHit (FirstHit:225-233) for a pixel nothing was stored for

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs 
     if (item >= *activeCount) return;
     const uint32_t rid = activeList[item];
     const uint32_t smp = rid / f.Npad, pix = rid - smp * f.Npad;
-    const uint32_t acc = f.accum[smp];
+    const uint32_t acc = sample_index(f, smp);
     float4 a = rays.o_ior[rid], b = rays.thr_px[rid], c = rays.rad_py[rid];
     float4 h = hits.hit[rid];
     HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[rid];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
         if (FIRST && pix >= (uint32_t)f.W * (uint32_t)f.rows) inRange = false; // padding of the sample segment
     }
     if (inRange) {
-        const uint32_t acc = f.accum[smp];
+        const uint32_t acc = sample_index(f, smp);
         float4 a = rays.o_ior[idx], b = rays.thr_px[idx], c = rays.rad_py[idx];
         float4 h = hits.hit[slot];
         HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[slot];

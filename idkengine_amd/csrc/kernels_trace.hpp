@@ -184,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
         contFlag[rid] = 4;                                               // (bit 0 = "continues" must stay clear) origin / direction planes regenerated on demand (k_regen_culled)
     } else if (valid) {
         f3 origin; f2 pd; uint32_t seed;
-        gen_primary(f, smp, pix, f.accum[smp], origin, pd, seed);
+        gen_primary(f, smp, pix, sample_index(f, smp), origin, pd, seed);
         f3 rd = DecodeUnitVec(pd.x, pd.y);
         f3 lo = origin, ld = rd, invDir = splat3(0.0f);   // several instances / TLAS: the traversal kernel transforms the world ray per instance
         float rootT = __builtin_inff();                   // single instance: tMin of the root-box test (+inf = miss), consumed by k_trace2

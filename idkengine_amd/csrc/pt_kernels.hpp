@@ -40,6 +40,7 @@ struct Frame {
     int tlasCap;                // rows of the per-lane TLAS stack (<= TLAS_STACK_SIZE; a TLAS over n instances is never deeper than n)
     // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
     int batch; uint32_t Npad; uint32_t accum[256];   // [MAX_BATCH]
+    uint32_t seqFirst, seqStride;   // idkptSetSampleSequence: sample i of an accumulation draws the RNG streams of AccumulatedSamples = seqFirst + i * seqStride (reference: 0, 1)
     // frame ring (idkptSetFrameRing): sample k renders with camera cams[36*k ..] (null: the one camera above) into result-image slot slotOf[k]
     const float* cams; uint32_t slotOf[256];   // (dwords: scalar loads from the kernel-argument segment; gfx9 has no scalar byte load)
 };
@@ -294,6 +295,8 @@ DEV bool TraceRayAny(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit,
 
 // ---------------------------------------------------------------------------------------------------------------
 // Primary ray generation (FirstHit/compute.glsl:44-77).  `pix` = local pixel index.
+// the value the reference's shaders would read as wavefrontPTSSBO.AccumulatedSamples for sample `smp` of the batch (FinalDraw's weight keeps the plain count)
+DEV uint32_t sample_index(const Frame& f, uint32_t smp) { return f.seqFirst + f.accum[smp] * f.seqStride; }
 DEV void gen_primary(const Frame& f, uint32_t smp, uint32_t pix, uint32_t acc, f3& origin, f2& packedDir, uint32_t& rngSeed)
 {
     const float* cam = f.cams ? f.cams + 36u * smp : f.invProj;      // invProj[16] invView[16] viewPos[3], contiguous in both places

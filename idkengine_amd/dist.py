@@ -219,3 +219,60 @@ class ShardedFrame:
                 n = len(rows_of_rank(self.height, self.world, r))
                 full[r::self.world] = parts[r][:n]
         return full
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Sample-parallel rendering: no sharding of the frame at all.  Rank r of N renders the WHOLE frame for the reference's samples
+# r, r + N, r + 2N, ... (idkptSetSampleSequence(r, N): their RNG streams, own running mean), so a displayed frame of N * K samples
+# costs every GPU K full-frame passes — the same launches, the same cache behaviour as one GPU alone — and ONE all-reduce of the
+# image.  Nothing is exchanged inside a frame.  The displayed image is the mean of the N accumulations: every reference sample
+# 0 .. N*K-1 enters exactly once with weight 1 / (N*K); the summation order differs from a single GPU's running mean, so it equals
+# the 1-GPU accumulation of the same samples up to binary32 rounding (each rank's own accumulation IS bit-exact, tests/test_gpu_samples.py).
+# This is the throughput mode (weak scaling: per-GPU work is fixed); row sharding above is the latency mode (strong scaling, bit-exact).
+
+def combine_accumulations(local, world, group=None):
+    """Mean over the ranks of their accumulated images: all-reduce (sum) of a torch-owned copy, then * (1 / world)."""
+    buf = local.contiguous().clone()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf.mul_(1.0 / float(world))
+
+
+class SampleParallelRenderer:
+    """idkengine_amd.PathTracer on this rank's GPU rendering whole frames for the sample indices rank, rank + world, ..."""
+
+    def __init__(self, width, height, world, rank, device_index):
+        from .pathtracer import PathTracer
+        torch.cuda.set_device(device_index)
+        self.device = torch.device("cuda", device_index)
+        self.pt = PathTracer(width, height, device=device_index)
+        self.pt.SetSampleSequence(rank, world)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.pt.set_stream(self.stream.cuda_stream)
+        self.width, self.height, self.rows, self.world = width, height, height, world
+
+    def upload_scene(self, scene):
+        self.pt.UploadScene(scene)
+
+    def set_camera(self, cam):
+        self.pt.SetCamera(cam)
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
+
+    def local_image(self):
+        self.pt.flush()
+        ptr, nbytes = self.pt.image_device_ptr(0)
+        assert nbytes == self.height * self.width * 16
+        return torch.as_tensor(_DevArray(ptr, (self.height, self.width, 4)), device=self.device)
+
+
+class SampleParallelFrame:
+    """The displayed frame of a sample-parallel group: gather() = mean of the ranks' accumulations, on every rank."""
+
+    def __init__(self, renderer, group=None):
+        self.r, self.group = renderer, group
+        self.world = dist.get_world_size(group)
+
+    def gather(self):
+        with self.r.stream_ctx():
+            return combine_accumulations(self.r.local_image(), self.world, self.group)

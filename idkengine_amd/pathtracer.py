@@ -107,6 +107,10 @@ class PathTracer:
         self.width, self.height = width, height
         self._check(self._L.idkptSetSize(self._ctx, width, height))
 
+    def SetSampleSequence(self, first, stride):
+        """Sample-parallel rendering (idkptSetSampleSequence): this context renders the reference's samples first, first + stride, ..."""
+        self._check(self._L.idkptSetSampleSequence(self._ctx, int(first), int(stride)))
+
     def ResetAccumulation(self):                      # :334-337
         self._check(self._L.idkptResetAccumulation(self._ctx))
 

@@ -248,6 +248,13 @@ IDKPT_API int32_t idkptGetFrameDevicePtr(idkpt_ctx* ctx, int32_t slot, int32_t i
 /* PathTracer.ResetAccumulation (PathTracer.cs:334-337) */
 IDKPT_API int32_t idkptResetAccumulation(idkpt_ctx* ctx);
 IDKPT_API int32_t idkptGetAccumulatedSamples(idkpt_ctx* ctx, uint32_t* outSamples);
+/* Sample-parallel multi-GPU (no reference counterpart; the reference is single-GPU): sample i of an accumulation (i = 0 after
+ * idkptResetAccumulation) draws the RNG streams the reference's shaders draw with AccumulatedSamples = first + i * stride
+ * (FirstHit/compute.glsl:53, NHit/compute.glsl:54, Shading.glsl), while FinalDraw keeps weighting by 1 / (i + 1).  Default (0, 1) is the
+ * reference.  N independent contexts (one per GPU, no sharding, no exchange inside a frame) set (r, N): together they render the reference's
+ * samples 0 .. N*K-1 exactly once, and the mean of their N accumulated images is an accumulation over all of them.  Changing the
+ * sequence restarts the accumulation. */
+IDKPT_API int32_t idkptSetSampleSequence(idkpt_ctx* ctx, uint32_t first, uint32_t stride);
 /* PathTracer.Compute (PathTracer.cs:214-271): SamplesPerPixel x [FirstHit, (sort,) NHit x (RayDepth-1), FinalDraw].
  * Asynchronous on the context's stream; no host read-back inside. */
 IDKPT_API int32_t idkptRender(idkpt_ctx* ctx);

@@ -46,6 +46,7 @@ def lib():
         L.ref_pt_set_settings.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_pt_set_perframe.argtypes = [C.c_void_p] * 4
         L.ref_pt_reset_accumulation.argtypes = [C.c_void_p]
+        L.ref_pt_set_sample_sequence.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.ref_pt_enable_counters.argtypes = [C.c_void_p, C.c_int]
         L.ref_pt_render.argtypes = [C.c_void_p]
         L.ref_pt_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -208,6 +209,10 @@ class OraclePathTracer:
     def set_blas_nodes(self, nodes):
         n = np.ascontiguousarray(nodes)
         lib().ref_scene_set_blas_nodes(self._scene, n.ctypes.data, len(n))
+
+    def set_sample_sequence(self, first, stride):
+        """idkptSetSampleSequence: sample i draws the reference's RNG streams of AccumulatedSamples = first + i * stride."""
+        lib().ref_pt_set_sample_sequence(self._pt, int(first), int(stride))
 
     def reset_accumulation(self):
         lib().ref_pt_reset_accumulation(self._pt)

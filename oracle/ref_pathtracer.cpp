@@ -430,6 +430,8 @@ struct PT {
     idkpt_settings st;
     float invProj[16], invView[16], viewPos[3];
     uint32_t accumulated = 0;
+    uint32_t seqFirst = 0, seqStride = 1;   // idkptSetSampleSequence: AccumulatedSamples the shaders see = seqFirst + accumulated * seqStride
+    uint32_t sampleIndex() const { return seqFirst + accumulated * seqStride; }
     std::vector<GpuWavefrontRay> rays; std::vector<GpuAovRay> aov;
     std::vector<float> img[3];
     std::vector<uint32_t> alive; // queue (local pixel indices)
@@ -521,7 +523,7 @@ static bool ShadeRay(PT& pt, bool first, GpuWavefrontRay& wr, GpuAovRay& ar, Rng
         float cosTheta = dot(-rayDir, surface.Normal);
         if (cosTheta < 0.0f) { surface.Normal = surface.Normal * -1.0f; cosTheta *= -1.0f; }
         radiance = radiance + surface.Emissive * throughput;
-        SampleMaterialResult result = SampleMaterial(rayDir, surface, prevIor, fromInside, rng, gidSeed, pt.accumulated);
+        SampleMaterialResult result = SampleMaterial(rayDir, surface, prevIor, fromInside, rng, gidSeed, pt.sampleIndex());
         throughput = throughput * (result.Bsdf / result.Pdf);
         {
             float weight = GetSurfaceVariance(surface.Metallic, surface.Transmission, surface.Roughness);
@@ -587,7 +589,7 @@ static void RenderSample(PT& pt)
         int y = ly * pt.rowMod + pt.rowRem;
         for (int x = 0; x < W; x++) {
             size_t rayIndex = (size_t)ly * W + x;
-            Rng rng; rng.seed = (uint32_t)(y * 4096 + x) * (pt.accumulated + 1u);
+            Rng rng; rng.seed = (uint32_t)(y * 4096 + x) * (pt.sampleIndex() + 1u);
             float ox = rnd01(&rng), oy = rnd01(&rng);
             v2 ndc = {((float)x + ox) / (float)W * 2.0f - 1.0f, ((float)y + oy) / (float)pt.H * 2.0f - 1.0f};
             v3 camDir = GetWorldSpaceDirection(pt.invProj, pt.invView, ndc);
@@ -639,7 +641,7 @@ static void RenderSample(PT& pt)
             for (size_t slot = (size_t)chunk * 256; slot < std::min(A, (size_t)(chunk + 1) * 256); slot++) {
                 uint32_t rayIndex = pt.alive[slot];
                 uint32_t gslot = slotBase + (uint32_t)slot;
-                Rng rng; rng.seed = gslot * 4096u + pt.accumulated;
+                Rng rng; rng.seed = gslot * 4096u + pt.sampleIndex();
                 GpuWavefrontRay wr = pt.rays[rayIndex]; GpuAovRay ar = pt.aov[rayIndex];
                 uint32_t key = 0;
                 bool c = ShadeRay(pt, false, wr, ar, &rng, gslot, &key, pt.countersOn ? &chunkCnt[chunk] : nullptr, nullptr, nullptr, nullptr);
@@ -846,6 +848,7 @@ void ref_pt_set_bounce_exchange(void* p, idkpt_bounce_exchange_fn fn, void* user
 void ref_pt_set_settings(void* p, const idkpt_settings* s) { ((PT*)p)->st = *s; }
 void ref_pt_set_perframe(void* p, const float* invProj, const float* invView, const float* viewPos) { PT* pt = (PT*)p; memcpy(pt->invProj, invProj, 64); memcpy(pt->invView, invView, 64); memcpy(pt->viewPos, viewPos, 12); }
 void ref_pt_reset_accumulation(void* p) { ((PT*)p)->accumulated = 0; }
+void ref_pt_set_sample_sequence(void* p, uint32_t first, uint32_t stride) { PT* pt = (PT*)p; pt->seqFirst = first; pt->seqStride = stride; pt->accumulated = 0; }
 void ref_pt_enable_counters(void* p, int on) { ((PT*)p)->countersOn = on != 0; }
 void ref_pt_render(void* p) { PT* pt = (PT*)p; for (int i = 0; i < pt->st.SamplesPerPixel; i++) RenderSample(*pt); } // PathTracer.cs:218
 void ref_pt_get_image(void* p, int which, float* out) { PT* pt = (PT*)p; memcpy(out, pt->img[which].data(), pt->img[which].size() * 4); }

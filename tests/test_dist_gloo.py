@@ -154,3 +154,58 @@ def test_rows_of_rank_partition():
         from idkengine_amd.dist import strip_of_rank
         strips = [strip_of_rank(h, world, r) for r in range(world)]
         assert [y for f, n in strips for y in range(f, f + n)] == list(range(h))
+
+
+def _worker_samples(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from idkengine_amd import scenes as S, dist as D
+    from idkengine_amd.bvh import NativeBuilder
+    from oracle import oracle as O
+    scene = S.cornell_scene(NativeBuilder(), "mixed") if rank == 0 else None
+    scene = D.broadcast_scene(scene, src=0)
+    pt = O.OraclePathTracer(scene, W, H); pt.set_camera(S.cornell_camera(W, H)); pt.settings.RayDepth = 4
+    pt.set_sample_sequence(rank, world)                       # this rank renders the reference's samples rank, rank + world, ...
+    for _ in range(3):
+        pt.render()
+    full = D.combine_accumulations(torch.from_numpy(pt.image()), world).numpy()
+    q.put((rank, full, pt.image().copy(), pt.stats()["rays_traced"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sample_parallel_world3_gloo():
+    """Sample-parallel mode (idkengine_amd/dist.py): 3 ranks x 3 whole-frame samples with idkptSetSampleSequence(rank, 3).  Every rank's own
+    accumulation is the running mean of the reference's samples rank, rank + 3, rank + 6 (checked against a plain 9-sample run), and the
+    combined frame is the mean of the three accumulations — the 9-sample accumulation up to binary32 rounding."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_samples, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from idkengine_amd import scenes as S
+    from idkengine_amd.bvh import NativeBuilder
+    from oracle import oracle as O
+    sc = S.cornell_scene(NativeBuilder(), "mixed")
+    ref = O.OraclePathTracer(sc, W, H); ref.set_camera(S.cornell_camera(W, H)); ref.settings.RayDepth = 4
+    radiance = []
+    for _ in range(9):
+        ref.render(); radiance.append(ref.rays()["Radiance"].reshape(H, W, 3).copy())
+    nine = ref.image()[..., :3]
+    f = np.float32
+    for rank, full, own, traced in res:
+        acc = np.zeros((H, W, 3), f)
+        for i in range(3):                                     # FinalDraw's running mean over this rank's three samples
+            wgt = f(1.0) / (f(i) + f(1.0))
+            acc = (acc * (f(1.0) - wgt) + radiance[rank + 3 * i] * wgt).astype(f)
+        assert (own[..., :3].view(np.uint32) == acc.view(np.uint32)).all()
+    for _, full, _, _ in res:
+        assert (full.view(np.uint32) == res[0][1].view(np.uint32)).all()                      # the same combined frame on every rank
+        np.testing.assert_allclose(full[..., :3], nine, rtol=2e-6, atol=1e-6)                  # = the 9-sample accumulation up to rounding

@@ -126,3 +126,27 @@ def test_cpu_csharp_path_agrees_with_glsl_path_on_triangle_ids(oracle_mod, oracl
         ok = (u >= 0) & (v >= 0) & (1 - u - v >= 0) & (tt > 0)
         best = np.where(ok, tt, np.inf).argmin()
         assert abs(np.where(ok, tt, np.inf)[best] - r["t"][i]) < 1e-3
+
+
+def test_sample_sequence_draws_the_reference_streams_of_its_indices(oracle_mod, oracle_builder):
+    """idkptSetSampleSequence(first, stride): sample i of the accumulation is the reference's sample first + i * stride (same rays, same
+    queue), only FinalDraw's weight follows the local count; (0, 1) is the reference."""
+    sc = S.cornell_scene(oracle_builder, "mixed"); w = h = 40; cam = S.cornell_camera(w, h)
+    plain = oracle_mod.OraclePathTracer(sc, w, h); plain.set_camera(cam); plain.settings.RayDepth = 4
+    states = []
+    for _ in range(8):
+        plain.render(); states.append((plain.rays().tobytes(), plain.alive_queue().tobytes()))
+    seq = oracle_mod.OraclePathTracer(sc, w, h); seq.set_camera(cam); seq.settings.RayDepth = 4
+    seq.set_sample_sequence(1, 3)
+    imgs = []
+    for i in range(3):
+        seq.render()
+        assert (seq.rays().tobytes(), seq.alive_queue().tobytes()) == states[1 + 3 * i]
+        imgs.append(seq.rays()["Radiance"].reshape(h, w, 3).copy())
+    # the accumulation is the running mean of exactly these three samples (FinalDraw/compute.glsl:39-41 with the local count)
+    acc = np.zeros((h, w, 3), np.float32)
+    for i, r in enumerate(imgs):
+        wgt = np.float32(1.0) / (np.float32(i) + np.float32(1.0))
+        acc = (acc * (np.float32(1.0) - wgt) + r * wgt).astype(np.float32)
+    assert (seq.image()[..., :3].view(np.uint32) == acc.view(np.uint32)).all()
+    plain.close(); seq.close()
