@@ -5,6 +5,7 @@ swrast); the fixtures travel to the GPU box, this script's inputs do not.
     python oracle/glref/make_vectors.py [case ...]            (re)generate fixtures + summary
     python oracle/glref/make_vectors.py --check [case ...]    regenerate in memory, compare with the committed fixtures bit for bit
     python oracle/glref/make_vectors.py --queries [--check]   ray-query (TraceRay / TraceRayAny) and ShadowsRayTraced vectors
+    python oracle/glref/make_vectors.py --extended            three larger live comparisons (no fixtures), JSON on stdout
     python oracle/glref/make_vectors.py --defect-d1           demonstrate reference defect D1 (glref.py ADAPTATIONS A7), JSON on stdout
 
 Per case the fixture holds
@@ -165,6 +166,51 @@ def make_query_and_shadow_vectors(check=False):
     return failed
 
 
+def extended():
+    """Larger live comparisons (no fixtures): every bounce of three bigger frames, the reference's shaders on llvmpipe against the oracle from
+    identical inputs.  JSON on stdout: per case the rays compared, flipped decisions, values beyond tolerance, worst deviation."""
+    from oracle.glref import glref as G
+    from oracle import oracle as O
+    from idkengine_amd import scenes as S, gputypes as T
+    import configs
+    import glref_check
+    B = O.OracleBuilder()
+    cases = {
+        "soup50k_256x144_d5": (lambda b: S.soup_scene(50000, b, seed=9), lambda w, h: S.Camera(w, h, position=(0, 0, 0), view_dir=(0.2, 0.1, -1), fovy_deg=90), 256, 144, dict(RayDepth=5)),
+        "atrium40k_192x108_d4": (lambda b: S.atrium_scene(40000, b), S.atrium_camera, 192, 108, dict(RayDepth=4)),
+        "lucy_256x320_d4_sort": (configs.lucy_scene, configs.lucy_camera, 256, 320, dict(RayDepth=4, DoRaySorting=1)),
+    }
+    rep = {}
+    for name, (fac, camf, w, h, ov) in cases.items():
+        sc = fac(B); cam = camf(w, h)
+        st = configs.apply_settings(T.Settings.default(), ov); depth = int(st.RayDepth)
+
+        def oracle_state(d):
+            o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.settings.RayDepth = d; o.settings.SamplesPerPixel = 1
+            o.render(); r, q = o.rays(), o.alive_queue(); o.close()
+            return r, q
+        st1 = configs.apply_settings(T.Settings.default(), ov); st1.RayDepth = 1
+        pt = G.ReferencePathTracer(sc, w, h, st1); pt.set_camera(cam); pt.render()
+        fh_rays, fh_q = pt.rays(T.GpuWavefrontRay), pt.final_alive; pt.accumulated = 0
+        r1, q1 = oracle_state(1)
+        beyond, eq, worst = glref_check._compare_records(r1, fh_rays)
+        tot = {"rays": len(r1), "flips": int(len(np.setxor1d(fh_q, q1))), "beyond_tol": int(beyond.sum()), "max_rel": worst, "stages": 1}
+        prev_out, prev = None, (r1, q1)
+        for j in range(1, depth):
+            rin, qin = prev
+            if st.DoRaySorting and j > 1 and not np.array_equal(prev_out, qin):
+                break
+            rout, qout = pt.run_nhit_from(rin, qin, j, sort_first=bool(st.DoRaySorting)); prev_out = qout
+            cur = oracle_state(j + 1)
+            fl = np.setxor1d(cur[1], qout); keep = ~np.isin(qin, fl)
+            beyond, eq, worst = glref_check._compare_records(cur[0][qin][keep], rout[qin][keep])
+            tot["rays"] += len(qin); tot["flips"] += int(len(fl)); tot["beyond_tol"] += int(beyond.sum()); tot["max_rel"] = max(tot["max_rel"], worst); tot["stages"] += 1
+            prev = cur
+        pt.close()
+        rep[name] = tot
+    print(json.dumps(rep))
+
+
 def main(names, check=False):
     from oracle.glref import glref as G
     from oracle import oracle as O
@@ -243,6 +289,8 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     if "--defect-d1" in args:
         defect_d1()
+    elif "--extended" in args:
+        extended()
     elif "--queries" in args:
         os.makedirs(OUT, exist_ok=True)
         sys.exit(1 if make_query_and_shadow_vectors(check="--check" in args) else 0)

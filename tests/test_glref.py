@@ -128,6 +128,18 @@ def test_live_fixtures_are_reproducible():
 
 
 @live
+def test_live_extended_frames_have_no_flipped_decision():
+    """Three larger frames that are not stored as fixtures (interior soup 256x144 depth 5, atrium 192x108 depth 4, Lucy 256x320 depth 4 with ray
+    sorting): about 210 000 rays compared bounce by bounce from identical inputs, reference shaders on llvmpipe against the oracle."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "make_vectors.py"), "--extended"], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(rep) == 3
+    for name, t in rep.items():
+        assert t["rays"] > 20000 and t["flips"] == 0 and t["beyond_tol"] == 0 and t["max_rel"] < glref_check.REL_TOL, (name, t)
+
+
+@live
 def test_live_reference_defect_d1_reorder_item_count():
     """Reference defect D1 (oracle/glref/glref.py ADAPTATIONS A7): in the reference's host order Reorder bounds-checks against the
     PREVIOUS bounce's count, so its tail invocations re-insert stale entries and the 'sorted' queue is not a permutation of the alive
