@@ -959,7 +959,8 @@ static int flush_batch(dev_ctx* ctx)
     // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
     wavesPerCU = std::max(1, wavesPerCU);
-    const uint32_t traceGrid = (uint32_t)(ctx->numCUs * wavesPerCU);
+    // (a launch never needs more waves than it can have rays: small frames would otherwise spend their time dispatching idle workgroups)
+    const uint32_t traceGrid = std::min<uint32_t>((uint32_t)(ctx->numCUs * wavesPerCU), std::max<uint32_t>(1u, (uint32_t)(((size_t)B * N + 63) / 64)));
     const bool debug = f.g.DoDebugBVHTraversal != 0;
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);
@@ -1052,7 +1053,12 @@ static int flush_batch(dev_ctx* ctx)
             if (va != q) HIPC(hipMemcpyAsync(q, va, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
         }
         TRACE_T0();
-        if (fast) launch_trace2<false>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)q, cnt, work + j, counters);
+        // grid of the bounce launch: its queue length is only known on the device; the length the same bounce had in the previous batch (pinned copy,
+        // possibly one batch stale) is a good predictor, and a grid that is too small or too large only costs time (the waves are persistent)
+        uint32_t gridj = traceGrid;
+        static const int hintMul = getenv("IDKPT_GRID_HINT") ? atoi(getenv("IDKPT_GRID_HINT")) : 2;
+        if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) { const uint32_t prev = ctx->hBases[(size_t)j * BS + B]; if (prev > 0) gridj = std::min<uint32_t>(traceGrid, std::max<uint32_t>(256u, (uint32_t)(((uint64_t)hintMul * prev + 63) / 64))); }
+        if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)q, cnt, work + j, counters);
         else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
