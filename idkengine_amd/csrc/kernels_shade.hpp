@@ -30,19 +30,25 @@ DEV void write_trace_ready(const DScene& s, const Frame& f, const TraceBufs& tr,
 // Fast-path FirstHit shading: only the rays that entered the traversal (active list, any order).  The continue decision
 // goes to a per-ray byte (pre-zeroed), which the ordered compaction turns back into pixel order.
 __global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* activeList, const uint32_t* activeCount,
-                                                     uint8_t* contFlag, uint32_t* seedsAndKeys)
+                                                     uint8_t* contFlag, uint32_t* seedsAndKeys, int lean /* k_gen_primary stored nothing but the trace-ready record of this ray */)
 {
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= *activeCount) return;
     const uint32_t rid = activeList[item];
     const uint32_t smp = rid / f.Npad, pix = rid - smp * f.Npad;
     const uint32_t acc = sample_index(f, smp);
-    float4 a = rays.o_ior[rid], b = rays.thr_px[rid], c = rays.rad_py[rid];
     float4 h = hits.hit[rid];
     HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[rid];
-    RayState r; r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;
+    RayState r; uint32_t rng, key = 0;
+    if (lean) {   // the state FirstHit:44-77 starts a primary ray with, recomputed (same arithmetic, same bits) instead of 52 B written and read back
+        f2 pd; gen_primary(f, smp, pix, acc, r.origin, pd, rng);
+        r.prevIor = 1.0f; r.throughput = splat3(1.0f); r.pdx = pd.x; r.radiance = splat3(0.0f); r.pdy = pd.y;
+    } else {
+        float4 a = rays.o_ior[rid], b = rays.thr_px[rid], c = rays.rad_py[rid];
+        r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;
+        rng = seedsAndKeys[rid];
+    }
     AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
-    uint32_t rng = seedsAndKeys[rid], key = 0;
     int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
     uint32_t gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
     f3 rd = DecodeUnitVec(r.pdx, r.pdy);

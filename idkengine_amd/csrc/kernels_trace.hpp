@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
 // record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
 // wave) to an unordered active list; results are stored per pixel, so the list order is free.
 __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut, uint8_t* contFlag,
-                                                     const uint8_t* tileClass /* null: no tile pre-classification */)
+                                                     const uint8_t* tileClass /* null: no tile pre-classification */,
+                                                     int lean /* the traversal reads only the trace-ready record: k_shade_first regenerates the state of a surviving ray instead of reading it back */)
 {
     __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase;
     // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
         f3 radiance = splat3(0.0f);
         if (keep) {
             tr.rec[4 * (size_t)rid] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)rid + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.rec[4 * (size_t)rid + 2] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f);
-            seedOut[rid] = seed;                                        // RNG state after ray generation, consumed by k_shade_first
+            if (!lean) seedOut[rid] = seed;                             // RNG state after ray generation, consumed by k_shade_first
         } else {
             // miss branch of FirstHit TraceRay (FirstHit/compute.glsl:225-233), evaluated right here
             f3 albedo = SampleSky(s, rd);
@@ -233,9 +234,10 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
         }
         // A culled pixel's ray is finished: FinalDraw only needs its radiance.  Origin/throughput planes (32 of the 48 B) are not
         // written; the flag lets idkptDownloadRays regenerate them on demand (k_regen_culled).
-        if (keep) { rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f); rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x); }
+        // A surviving ray's planes are a function of (pixel, sample): in lean mode (52 of its 105 B) k_shade_first recomputes them.
+        if (keep && !lean) { rays.o_ior[rid] = make_float4(origin.x, origin.y, origin.z, 1.0f); rays.thr_px[rid] = make_float4(1.0f, 1.0f, 1.0f, pd.x); }
         contFlag[rid] = keep ? 0 : 2;       // also resets the continue flag of this ray id (k_shade_first sets 1); pad ids stay 0 from allocation
-        rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, pd.y);
+        if (!(keep && lean)) rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, pd.y);
     }
     // append the survivors: one atomic per 16-wave workgroup (a single counter word saturates at ~88 atomics/us)
     const unsigned long long m = __ballot(keep);

@@ -5,6 +5,7 @@
 //   mode 2: quads share a block: each lane 16 B (1 instr, 16 lines)                                       -> 16 blocks/wave-step
 //   mode 3: every lane its own block, ONE dwordx4 (request-rate probe)
 //   mode 4: every lane its own block, ONE dword
+//   mode 5: every lane its own random 128-B LINE (two adjacent blocks), 8 x dwordx4: does the second half of a line come for free?
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_lines.hip -o tools/ubench_lines.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -28,6 +29,8 @@ __global__ __launch_bounds__(64) void k(const float4* __restrict__ buf, uint32_t
         if (MODE == 1) { const float4* q = p + 2 * (lane & 1); float4 a = q[0], b = q[1]; acc += __float_as_uint(a.x) ^ __float_as_uint(b.y); }
         if (MODE == 2) { float4 a = p[lane & 3]; acc += __float_as_uint(a.x); }
         if (MODE == 3) { float4 a = p[0]; acc += __float_as_uint(a.x) ^ __float_as_uint(a.w); }
+        if (MODE == 5) { const float4* q = buf + (size_t)(idx & ~1u) * 4; float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6], h = q[7];
+                         acc += __float_as_uint(a.x) ^ __float_as_uint(b.y) ^ __float_as_uint(c.z) ^ __float_as_uint(d.w) ^ __float_as_uint(e.x) ^ __float_as_uint(f.y) ^ __float_as_uint(g.z) ^ __float_as_uint(h.w); }
         if (MODE == 4) { acc += __float_as_uint(((const float*)p)[0]); }
     }
     if (acc == 0x12345678u) out[0] = acc;
@@ -44,7 +47,7 @@ int main(int argc, char** argv)
     CHECK(hipMemset(buf, 1, nBlocks * 64));
     uint32_t* out; CHECK(hipMalloc(&out, 4));
     printf("CUs %d, set %zu MB\n", cus, nBlocks * 64 >> 20);
-    for (int wavesPerCU : {16, 32}) for (int mode = 0; mode < 5; mode++) {
+    for (int wavesPerCU : {16, 32}) for (int mode = 0; mode < 6; mode++) {
         if ((onlyMode >= 0 && mode != onlyMode) || (onlyWaves >= 0 && wavesPerCU != onlyWaves)) continue;
         int iters = 4000;
         dim3 grid(cus * wavesPerCU), block(64);
@@ -57,12 +60,13 @@ int main(int argc, char** argv)
                 case 1: hipLaunchKernelGGL(k<1>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out); break;
                 case 2: hipLaunchKernelGGL(k<2>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out); break;
                 case 3: hipLaunchKernelGGL(k<3>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out); break;
+                case 5: hipLaunchKernelGGL(k<5>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out); break;
                 case 4: hipLaunchKernelGGL(k<4>, grid, block, 0, 0, buf, (uint32_t)(nBlocks - 1), iters, out); break;
             }
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             CHECK(hipEventElapsedTime(&ms, e0, e1));
         }
-        const double instrPerIter = mode == 0 ? 4 : mode == 1 ? 2 : 1;
+        const double instrPerIter = mode == 5 ? 8 : mode == 0 ? 4 : mode == 1 ? 2 : 1;
         const double blocksPerIter = mode == 1 ? 32 : mode == 2 ? 16 : 64;
         const double waveIters = (double)grid.x * iters;
         const double clk = ms * 1e-3 * 2.4e9;
