@@ -22,6 +22,10 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <memory>
+#include <utility>
+#include <sched.h>
+#include <new>
 #include "../../include/idkbvh.h"
 
 namespace {
@@ -33,6 +37,25 @@ constexpr float kTraversalCost = 1.0f;               // BLAS.cs:26
 constexpr float kTriangleCost = 1.1f;                // BuildSettings defaults, BLAS.cs:31-48
 constexpr int kStopSplittingThreshold = 1;
 constexpr int kMaxLeafTriangleCount = 2;
+// Threads a build may use by default: the hardware threads this process may run on (affinity mask), capped by the container's CPU quota
+// (cgroup v2 cpu.max / v1 cfs quota).  More runnable threads than the quota get the whole process throttled for the rest of the scheduler period.
+static int defaultThreadCount()
+{
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) n = std::min(n, a); }
+    double quota = 0.0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[32] = {0}; long long per = 0; if (fscanf(f, "%31s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / (double)per; fclose(f); }
+    else {
+        long long q = -1, per = 0;
+        if (FILE* a = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(a, "%lld", &q) != 1) q = -1; fclose(a); }
+        if (FILE* b = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(b, "%lld", &per) != 1) per = 0; fclose(b); }
+        if (q > 0 && per > 0) quota = (double)q / (double)per;
+    }
+    if (quota > 0.0) n = std::min(n, std::max(1, (int)(quota + 0.5)));
+    return n;
+}
+
 constexpr int kStackOptThreshold = 16;
 constexpr float kStackOptSahIncreaseAcceptance = 0.0009745f;
 
@@ -54,6 +77,19 @@ struct alignas(16) SBox {
 inline __m128 load3(const float* p) { return _mm_set_ps(0.0f, p[2], p[1], p[0]); }
 
 struct HNode { float mn[3]; int32_t startOrChild; float mx[3]; int32_t count; };
+// Allocator of the build's large arrays: with NoInit, resize() / the sized constructor leave new elements uninitialised (they are overwritten in
+// full, by several threads or by a device copy: value-initialising 85 MB first would be a serial pass that also puts every page on the calling
+// thread); assign(n, v) and copies behave as usual.  (Transparent huge pages were tried for these blocks — 43 faults instead of 21 000 for the
+// node array — and dropped: with defrag = madvise a 2 MB fault can stall for milliseconds in compaction, 5 ms each on the development container.)
+template <class T, bool NoInit = false> struct BigAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = BigAlloc<U, NoInit>; };
+    template <class U, class... A> void construct(U* p, A&&... a)
+    {
+        if constexpr (NoInit && sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using BigVec = std::vector<T, BigAlloc<T>>;
+using NodeVec = std::vector<HNode, BigAlloc<HNode, true>>;
 static_assert(sizeof(HNode) == sizeof(GpuBlasNode), "node layout");
 inline bool isLeaf(const HNode& n) { return n.count > 0; }
 inline float nodeHalfArea(const HNode& n) { float x = n.mx[0] - n.mn[0], y = n.mx[1] - n.mn[1], z = n.mx[2] - n.mn[2]; return fmaf(x + y, z, x * y); }
@@ -85,15 +121,15 @@ struct Builder {
     // inputs
     const float* positions; const GpuBlasTriangle* tris; int triCount;
     // fragments
-    std::vector<SBox> frag; std::vector<int> origTri;
+    BigVec<SBox> frag; BigVec<int> origTri;
     // build state
-    std::vector<int> sorted[3]; std::vector<float> rightCosts; std::vector<uint8_t> leftTable;
-    std::vector<HNode> nodes;
+    BigVec<int> sorted[3]; BigVec<float> rightCosts; BigVec<uint8_t> leftTable;
+    NodeVec nodes;
     int requiredStack = 0;
     std::atomic<int> liveThreads{0};   // workers inside buildSubtree (+2 while a node sweeps its axes on extra threads)
     int maxThreads = 1;
     // outputs
-    std::vector<GpuBlasTriangle> outTris; std::vector<int> parents, leaves;
+    BigVec<GpuBlasTriangle> outTris; std::vector<int> parents, leaves;
     double sah = 0.0, buildMs = 0.0;
 
     void triPoints(int i, __m128& a, __m128& b, __m128& c) const { const GpuBlasTriangle& t = tris[i]; a = load3(positions + 3 * (size_t)t.X); b = load3(positions + 3 * (size_t)t.Y); c = load3(positions + 3 * (size_t)t.Z); }
@@ -323,6 +359,29 @@ struct Builder {
         worker();
         for (auto& th : pool) th.join();
     }
+    // ---- whole-tree walks (RequiredStackSize, GlobalSAH, CollapseDeepest).  Each is a depth-first walk whose binary64 sums depend on the visiting
+    // order.  They run in parallel without changing a bit: the tree is cut at depth kCutDepth, every subtree below the cut is walked by a task
+    // that records its terms IN ORDER instead of adding them, and the part above the cut is then walked serially, splicing the recorded
+    // sequences in where the serial walk would have produced them; the additions happen once, in the serial order.
+    static constexpr int kCutDepth = 9;
+    void cutTree(int parentId, int depth, std::vector<int>& roots) const   // internal nodes at depth kCutDepth, in left-first order
+    {
+        if (depth == kCutDepth) { roots.push_back(parentId); return; }
+        const int c = nodes[parentId].startOrChild;
+        if (!isLeaf(nodes[c])) cutTree(c, depth + 1, roots);
+        if (!isLeaf(nodes[c + 1])) cutTree(c + 1, depth + 1, roots);
+    }
+    template <class F> void runTasks(int n, F&& task) const   // dynamic: subtrees of an SAH tree differ widely in size
+    {
+        const int t = std::max(1, std::min(maxThreads, n));
+        if (t == 1) { for (int i = 0; i < n; i++) task(i); return; }
+        std::atomic<int> next{0};
+        auto loop = [&] { for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) task(i); };
+        std::vector<std::thread> pool;
+        for (int k = 1; k < t; k++) pool.emplace_back(loop);
+        loop();
+        for (auto& th : pool) th.join();
+    }
     int requiredStackSize(int nodeId = 2) const // BLAS.cs:672-702
     {
         const HNode& l = nodes[nodeId]; const HNode& r = nodes[nodeId + 1];
@@ -331,24 +390,59 @@ struct Builder {
         if (tl || tr) return requiredStackSize(tl ? l.startOrChild : r.startOrChild);
         return 0;
     }
-    double globalSAH() const // BLAS.cs:629-657
+    int requiredStackTop(int parentId, int depth, const std::vector<int>& below, size_t& next) const
     {
-        double cost = 0.0, rootArea = 1.0 / (double)nodeHalfArea(nodes[1]);
-        std::vector<int> st; st.push_back(1);
+        if (depth == kCutDepth) return below[next++];
+        const int c = nodes[parentId].startOrChild;
+        const bool tl = !isLeaf(nodes[c]), tr = !isLeaf(nodes[c + 1]);
+        const int a = tl ? requiredStackTop(c, depth + 1, below, next) : 0;
+        const int b = tr ? requiredStackTop(c + 1, depth + 1, below, next) : 0;
+        return (tl && tr) ? std::max(a, b) + 1 : (tl ? a : b);
+    }
+    int requiredStackSizeAll() const
+    {
+        std::vector<int> roots; cutTree(1, 0, roots);
+        std::vector<int> below(roots.size());
+        runTasks((int)roots.size(), [&](int k) { below[k] = requiredStackSize(nodes[roots[k]].startOrChild); });
+        size_t next = 0;
+        return requiredStackTop(1, 0, below, next);
+    }
+    template <class Add> void sahTerms(int rootId, double rootArea, Add&& add) const // BLAS.cs:629-657: pre-order, left subtree first
+    {
+        std::vector<int> st; st.push_back(rootId);
         while (!st.empty()) {
             const HNode& n = nodes[st.back()]; st.pop_back();
             double prob = (double)nodeHalfArea(n) * rootArea;
-            if (isLeaf(n)) cost += (double)(kTriangleCost * (float)n.count) * prob;
-            else { cost += (double)kTraversalCost * prob; st.push_back(n.startOrChild + 1); st.push_back(n.startOrChild); }
+            if (isLeaf(n)) add((double)(kTriangleCost * (float)n.count) * prob);
+            else { add((double)kTraversalCost * prob); st.push_back(n.startOrChild + 1); st.push_back(n.startOrChild); }
         }
+    }
+    void sahTop(int nodeId, int depth, double rootArea, const std::vector<std::vector<double>>& below, size_t& next, double& cost) const
+    {
+        const HNode& n = nodes[nodeId];
+        if (!isLeaf(n) && depth == kCutDepth) { for (double t : below[next]) cost += t; next++; return; }
+        double prob = (double)nodeHalfArea(n) * rootArea;
+        if (isLeaf(n)) { cost += (double)(kTriangleCost * (float)n.count) * prob; return; }
+        cost += (double)kTraversalCost * prob;
+        sahTop(n.startOrChild, depth + 1, rootArea, below, next, cost);
+        sahTop(n.startOrChild + 1, depth + 1, rootArea, below, next, cost);
+    }
+    double globalSAH() const
+    {
+        const double rootArea = 1.0 / (double)nodeHalfArea(nodes[1]);
+        std::vector<int> roots; cutTree(1, 0, roots);
+        std::vector<std::vector<double>> below(roots.size());
+        runTasks((int)roots.size(), [&](int k) { sahTerms(roots[k], rootArea, [&](double t) { below[k].push_back(t); }); });
+        double cost = 0.0; size_t next = 0;
+        sahTop(1, 0, rootArea, below, next, cost);
         return cost;
     }
-    void collapseDeepest(int newStackSize, bool firstPass, double& nextCost, int parentId = 1, int depth = 0) // BLAS.cs:897-936
+    template <class Add> void collapseDeepest(int newStackSize, bool firstPass, Add&& add, int parentId, int depth) // BLAS.cs:897-936
     {
         HNode& p = nodes[parentId];
         const int c = p.startOrChild;
-        if (!isLeaf(nodes[c])) collapseDeepest(newStackSize, firstPass, nextCost, c, depth + 1);
-        if (!isLeaf(nodes[c + 1])) collapseDeepest(newStackSize, firstPass, nextCost, c + 1, depth + 1);
+        if (!isLeaf(nodes[c])) collapseDeepest(newStackSize, firstPass, add, c, depth + 1);
+        if (!isLeaf(nodes[c + 1])) collapseDeepest(newStackSize, firstPass, add, c + 1, depth + 1);
         const HNode& l = nodes[c]; const HNode& r = nodes[c + 1];
         if (isLeaf(l) && isLeaf(r)) {
             if (depth > newStackSize && !firstPass) { p.startOrChild = l.startOrChild; p.count = l.count + r.count; }
@@ -356,84 +450,174 @@ struct Builder {
                 // StackOptMaxLeafTriangleCount = int.MaxValue: the guard at BLAS.cs:924-928 can never fire
                 double leavesCost = (double)kTriangleCost * ((double)l.count * (double)nodeHalfArea(l) + (double)r.count * (double)nodeHalfArea(r));
                 double newParentLeafCost = (double)kTriangleCost * (double)(l.count + r.count);
-                nextCost += ((double)nodeHalfArea(p) * (newParentLeafCost - (double)kTraversalCost) - leavesCost) / (double)nodeHalfArea(nodes[1]);
+                add(((double)nodeHalfArea(p) * (newParentLeafCost - (double)kTraversalCost) - leavesCost) / rootHalfArea);
             }
         }
     }
+    void collapseTop(int parentId, int depth, const std::vector<std::vector<double>>& below, size_t& next, double& nextCost) const
+    {
+        if (depth == kCutDepth) { for (double t : below[next]) nextCost += t; next++; return; }
+        const int c = nodes[parentId].startOrChild;   // above the cut a node is never deep enough to be touched (newStackSize > kCutDepth): only the order matters
+        if (!isLeaf(nodes[c])) collapseTop(c, depth + 1, below, next, nextCost);
+        if (!isLeaf(nodes[c + 1])) collapseTop(c + 1, depth + 1, below, next, nextCost);
+    }
+    double rootHalfArea = 0.0;
+    void collapseDeepestAll(int newStackSize, bool firstPass, double& nextCost)
+    {
+        rootHalfArea = (double)nodeHalfArea(nodes[1]);   // the root is never collapsed
+        if (newStackSize <= kCutDepth) { collapseDeepest(newStackSize, firstPass, [&](double t) { nextCost += t; }, 1, 0); return; }
+        std::vector<int> roots; cutTree(1, 0, roots);
+        std::vector<std::vector<double>> below(roots.size());
+        runTasks((int)roots.size(), [&](int k) { collapseDeepest(newStackSize, firstPass, [&](double t) { below[k].push_back(t); }, roots[k], kCutDepth); });
+        size_t next = 0;
+        collapseTop(1, 0, below, next, nextCost);
+    }
     void optimizeStackSize() // BLAS.cs:875-895
     {
-        requiredStack = requiredStackSize();
+        requiredStack = requiredStackSizeAll();
+        if (timing) fprintf(stderr, "[idkbvh] required stack before optimisation %d\n", requiredStack);
         if (requiredStack < kStackOptThreshold) return;
         double current = globalSAH(), added = 0.0;
-        collapseDeepest(requiredStack - 1, true, added);
+        collapseDeepestAll(requiredStack - 1, true, added);
         double inc = added / current;
-        while (inc <= (double)kStackOptSahIncreaseAcceptance && requiredStack > 0) { collapseDeepest(--requiredStack, false, added); inc = added / current; }
+        while (inc <= (double)kStackOptSahIncreaseAcceptance && requiredStack > 0) { collapseDeepestAll(--requiredStack, false, added); inc = added / current; }
     }
-    int compactNodes() // RemoveEmptySubtrees, BLAS.cs:245-273
+    // RemoveEmptySubtrees, BLAS.cs:245-273: child pairs renumbered in pre-order of their parents (left first), pair k at slot 2 + 2k.
+    // Out of place and by subtree: internal-node counts below the cut give every subtree its first slot, then the subtrees copy themselves.
+    int countInternal(int rootId) const
     {
-        int counter = 2;
-        std::vector<int> st; st.push_back(1);
+        int n = 0;
+        std::vector<int> st; st.push_back(rootId);
         while (!st.empty()) {
-            int pid = st.back(); st.pop_back();
-            HNode l = nodes[nodes[pid].startOrChild], r = nodes[nodes[pid].startOrChild + 1];
-            nodes[counter] = l; nodes[counter + 1] = r;
-            nodes[pid].startOrChild = counter;
-            if (!isLeaf(r)) st.push_back(counter + 1);
-            if (!isLeaf(l)) st.push_back(counter);
+            const int c = nodes[st.back()].startOrChild; st.pop_back(); n++;
+            if (!isLeaf(nodes[c + 1])) st.push_back(c + 1);
+            if (!isLeaf(nodes[c])) st.push_back(c);
+        }
+        return n;
+    }
+    void compactSubtree(NodeVec& out, int oldRoot, int newRoot, int counter) const
+    {
+        std::vector<std::pair<int, int>> st; st.push_back({oldRoot, newRoot});
+        while (!st.empty()) {
+            const int o = st.back().first, nw = st.back().second; st.pop_back();
+            const int c = nodes[o].startOrChild;
+            out[counter] = nodes[c]; out[counter + 1] = nodes[c + 1];
+            out[nw].startOrChild = counter;
+            if (!isLeaf(nodes[c + 1])) st.push_back({c + 1, counter + 1});
+            if (!isLeaf(nodes[c])) st.push_back({c, counter});
             counter += 2;
         }
-        return counter;
     }
+    struct CutSlot { int newId, firstPair; };
+    void compactTop(NodeVec& out, int oldId, int newId, int depth, const std::vector<int>& internal, std::vector<CutSlot>& slots, int& pre) const
+    {
+        if (depth == kCutDepth) { slots.push_back({newId, pre}); pre += internal[slots.size() - 1]; return; }
+        const int c = nodes[oldId].startOrChild, slot = 2 + 2 * pre++;
+        out[slot] = nodes[c]; out[slot + 1] = nodes[c + 1];
+        out[newId].startOrChild = slot;
+        if (!isLeaf(nodes[c])) compactTop(out, c, slot, depth + 1, internal, slots, pre);
+        if (!isLeaf(nodes[c + 1])) compactTop(out, c + 1, slot + 1, depth + 1, internal, slots, pre);
+    }
+    int compactNodes()
+    {
+        std::vector<int> roots; cutTree(1, 0, roots);
+        std::vector<int> internal(roots.size());
+        runTasks((int)roots.size(), [&](int k) { internal[k] = countInternal(roots[k]); });
+        int total = 0; for (int v : internal) total += v;
+        int top = 0;   // internal nodes above the cut
+        { std::vector<std::pair<int, int>> st; st.push_back({1, 0});
+          while (!st.empty()) { const int o = st.back().first, d = st.back().second; st.pop_back(); if (d == kCutDepth) continue; top++;
+                                const int c = nodes[o].startOrChild; if (!isLeaf(nodes[c])) st.push_back({c, d + 1}); if (!isLeaf(nodes[c + 1])) st.push_back({c + 1, d + 1}); } }
+        NodeVec out((size_t)2 + 2 * (size_t)(total + top));
+        out[0] = nodes[0]; out[1] = nodes[1];
+        std::vector<CutSlot> slots; slots.reserve(roots.size());
+        int pre = 0;
+        compactTop(out, 1, 1, 0, internal, slots, pre);
+        runTasks((int)roots.size(), [&](int k) { compactSubtree(out, roots[k], slots[k].newId, 2 + 2 * slots[k].firstPair); });
+        nodes.swap(out);
+        return (int)nodes.size();
+    }
+    // Both un-indexing passes walk the compacted tree in the order RemoveEmptySubtrees numbered it (pre-order over the parents, left first), so
+    // "the next leaf / sibling pair of the walk" is simply the next one in memory: sizes per pair -> running offsets -> independent writes.
     void unindexPlain() // BLAS.GetUnindexedTriangles, BLAS.cs:441-466
     {
         // single-leaf root: its leaf is duplicated into nodes 2 and 3 (BLAS.cs:173-183; the reference throws here) ->
         // size by the sum of leaf counts so the duplicated triangles are simply stored twice
-        size_t total = 0;
-        for (size_t i = 2; i < nodes.size(); i++) if (isLeaf(nodes[i])) total += (size_t)nodes[i].count;
-        outTris.resize(std::max(total, frag.size()));
-        int w = 0;
-        for (size_t i = 2; i < nodes.size(); i++) {
-            HNode& n = nodes[i];
-            if (!isLeaf(n)) continue;
-            for (int j = 0; j < n.count; j++) outTris[w + j] = tris[sorted[0][n.startOrChild + j]];
-            n.startOrChild = w; w += n.count;
-        }
-        outTris.resize((size_t)w);
+        const int nn = (int)nodes.size();
+        std::vector<int> at((size_t)nn + 1, 0);
+        for (int i = 2; i < nn; i++) at[i + 1] = at[i] + (isLeaf(nodes[i]) ? nodes[i].count : 0);
+        outTris.resize((size_t)at[nn]);
+        parallelFor(nn, [&](int b, int e) {
+            for (int i = std::max(b, 2); i < e; i++) {
+                HNode& n = nodes[i];
+                if (!isLeaf(n)) continue;
+                const int w = at[i];
+                for (int j = 0; j < n.count; j++) outTris[w + j] = tris[sorted[0][n.startOrChild + j]];
+                n.startOrChild = w;
+            }
+        });
     }
-    void uniqueIds(const HNode& leaf, std::vector<int>& ids) const
+    // sorted distinct original-triangle ids of a leaf, written over the leaf's own (disjoint) range of `uniq`; returns how many
+    int uniqueIds(const HNode& leaf, int* uniq) const
     {
-        ids.resize(leaf.count);
+        int* ids = uniq + leaf.startOrChild;
         for (int i = 0; i < leaf.count; i++) ids[i] = origTri[sorted[0][leaf.startOrChild + i]];
-        std::sort(ids.begin(), ids.end());
-        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        std::sort(ids, ids + leaf.count);
+        return (int)(std::unique(ids, ids + leaf.count) - ids);
     }
     void unindexPreSplit() // PreSplitting.GetUnindexedTriangles, PreSplitting.cs:169-273
     {
-        outTris.assign(frag.size(), GpuBlasTriangle{});
-        int g = 0;
-        std::vector<int> st, lu, ru; st.push_back(2);
-        while (!st.empty()) {
-            int top = st.back(); st.pop_back();
-            HNode& l = nodes[top]; HNode& r = nodes[top + 1];
-            if (isLeaf(l) && isLeaf(r)) {
-                uniqueIds(l, lu); uniqueIds(r, ru);
-                int onlyLeft = 0, back = 0, nl = (int)lu.size();
-                for (int id : lu) { if (std::binary_search(ru.begin(), ru.end(), id)) outTris[g + nl - back++ - 1] = tris[id]; else outTris[g + onlyLeft++] = tris[id]; }
-                int onlyRight = 0;
-                for (int id : ru) if (!std::binary_search(lu.begin(), lu.end(), id)) outTris[g + nl + onlyRight++] = tris[id];
-                l.startOrChild = g; l.count = nl;
-                r.startOrChild = g + onlyLeft; r.count = (int)ru.size();
-                g += (r.startOrChild + r.count) - l.startOrChild;
-            } else if (isLeaf(l) || isLeaf(r)) {
-                HNode& leaf = isLeaf(l) ? l : r;
-                uniqueIds(leaf, lu);
-                for (size_t i = 0; i < lu.size(); i++) outTris[g + (int)i] = tris[lu[i]];
-                leaf.startOrChild = g; leaf.count = (int)lu.size(); g += (int)lu.size();
+        const int pairs = ((int)nodes.size() - 2) / 2;
+        std::vector<int, BigAlloc<int, true>> uniq(frag.size()); BigVec<int> ucount(nodes.size(), 0), at((size_t)pairs + 1, 0);
+        const bool twins = pairs == 1 && isLeaf(nodes[2]) && isLeaf(nodes[3]) && nodes[2].startOrChild == nodes[3].startOrChild;   // single-leaf root: both leaves are the same range
+        std::vector<int> twinIds;
+        // pass 1: distinct ids per leaf and how far the pair advances the output cursor (PreSplitting.cs:200-262)
+        parallelFor(pairs, [&](int b, int e) {
+            for (int p = b; p < e; p++) {
+                const int top = 2 + 2 * p;
+                const HNode& l = nodes[top]; const HNode& r = nodes[top + 1];
+                int adv = 0;
+                if (isLeaf(l) && isLeaf(r)) {
+                    const int nl = ucount[top] = uniqueIds(l, uniq.data());
+                    if (twins) twinIds.assign(uniq.begin() + l.startOrChild, uniq.begin() + l.startOrChild + nl);
+                    const int nr = ucount[top + 1] = twins ? nl : uniqueIds(r, uniq.data());
+                    const int* lu = uniq.data() + l.startOrChild; const int* ru = twins ? twinIds.data() : uniq.data() + r.startOrChild;
+                    int shared = 0;
+                    for (int i = 0; i < nl; i++) if (std::binary_search(ru, ru + nr, lu[i])) shared++;
+                    adv = (nl - shared) + nr;                       // l = [g, g + nl), r = [g + onlyLeft, g + onlyLeft + nr): they overlap in the shared ids
+                } else if (isLeaf(l) || isLeaf(r)) {
+                    const int leaf = isLeaf(l) ? top : top + 1;
+                    adv = ucount[leaf] = uniqueIds(nodes[leaf], uniq.data());
+                }
+                at[p + 1] = adv;
             }
-            if (!isLeaf(r)) st.push_back(r.startOrChild);
-            if (!isLeaf(l)) st.push_back(l.startOrChild);
-        }
-        outTris.resize(g);
+        });
+        for (int p = 0; p < pairs; p++) at[p + 1] += at[p];
+        outTris.assign(frag.size(), GpuBlasTriangle{});
+        // pass 2: every pair writes its own output range
+        parallelFor(pairs, [&](int b, int e) {
+            for (int p = b; p < e; p++) {
+                const int top = 2 + 2 * p, g = at[p];
+                HNode& l = nodes[top]; HNode& r = nodes[top + 1];
+                if (isLeaf(l) && isLeaf(r)) {
+                    const int nl = ucount[top], nr = ucount[top + 1];
+                    const int* lu = uniq.data() + l.startOrChild; const int* ru = twins ? twinIds.data() : uniq.data() + r.startOrChild;
+                    int onlyLeft = 0, back = 0;
+                    for (int i = 0; i < nl; i++) { const int id = lu[i]; if (std::binary_search(ru, ru + nr, id)) outTris[g + nl - back++ - 1] = tris[id]; else outTris[g + onlyLeft++] = tris[id]; }
+                    int onlyRight = 0;
+                    for (int i = 0; i < nr; i++) if (!std::binary_search(lu, lu + nl, ru[i])) outTris[g + nl + onlyRight++] = tris[ru[i]];
+                    l.startOrChild = g; l.count = nl;
+                    r.startOrChild = g + onlyLeft; r.count = nr;
+                } else if (isLeaf(l) || isLeaf(r)) {
+                    HNode& leaf = isLeaf(l) ? l : r;
+                    const int n = ucount[isLeaf(l) ? top : top + 1];
+                    const int* lu = uniq.data() + leaf.startOrChild;
+                    for (int i = 0; i < n; i++) outTris[g + i] = tris[lu[i]];
+                    leaf.startOrChild = g; leaf.count = n;
+                }
+            }
+        });
+        outTris.resize((size_t)at[pairs]);
     }
 
     // The build in three steps, so that a host can run the middle one elsewhere (libidkpt's idkptBuildBlasCore on the GPU):
@@ -458,7 +642,7 @@ struct Builder {
         t0 = tp = std::chrono::steady_clock::now();
         timing = getenv("IDKBVH_TIMING") != nullptr;   // developer knob: phase times on stderr
         getrusage(RUSAGE_SELF, &ru0);
-        maxThreads = threads <= 0 ? std::max(1u, std::thread::hardware_concurrency()) : threads;
+        maxThreads = threads <= 0 ? defaultThreadCount() : threads;
         refit = refittable;
         if (!refit) preSplit(factor);
         else { frag.resize(triCount); for (int i = 0; i < triCount; i++) frag[i] = triBox(i); }
