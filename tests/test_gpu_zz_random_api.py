@@ -14,7 +14,7 @@ from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IDKPT_RANDOM_API_SEEDS", "6"))))   # soak: IDKPT_RANDOM_API_SEEDS=100
 def test_random_api_sequences_match_unbatched_replay(native_builder, seed):
     """State-machine check of the deferral logic: a random sequence of host calls (camera moves, Compute, ResetAccumulation, settings,
     SetMaxBatch, SetSize, scene swap, reads in between) must leave the same image as the same logical sequence replayed on a context
