@@ -10,7 +10,7 @@ timeout 200 python bench.py $S --depth 5 --sort 1 > $OUT/sec_d5_sort.json 2>> $O
 timeout 200 python bench.py $S --depth 9 > $OUT/sec_d9.json 2>> $OUT/err.log
 timeout 200 python bench.py $S --depth 2 --sort 1 > $OUT/sec_d2_sort.json 2>> $OUT/err.log
 timeout 200 python bench.py $S --tris 260000 --depth 5 > $OUT/sec_260k_d5.json 2>> $OUT/err.log
-timeout 300 python bench.py $S --tris 4000000 --width 3840 --height 2160 --depth 9 --batch 8 --steps 16 --warmup 8 > $OUT/sec_4m_4k_d9.json 2>> $OUT/err.log
+timeout 300 python bench.py $S --tris 4000000 --width 3840 --height 2160 --depth 9 --steps 32 --warmup 32 > $OUT/sec_4m_4k_d9.json 2>> $OUT/err.log
 timeout 200 python bench.py $S --view interior --depth 2 > $OUT/sec_interior_d2.json 2>> $OUT/err.log
 timeout 200 python bench.py $S --view interior --depth 5 > $OUT/sec_interior_d5.json 2>> $OUT/err.log
 timeout 200 python bench.py $S --gpus 2 > $OUT/group2_shared_gpu.json 2>> $OUT/err.log
