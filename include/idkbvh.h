@@ -37,7 +37,7 @@ typedef struct idkbvh_blas_info {
 /* BVH.BlasesBuild body for one BLAS (Bvh/BVH.cs:315-375).  `tris` is this BLAS' slice of BVH.BlasTriangles as filled
  * by BVH.Add (global vertex ids + MeshId, Bvh/BVH.cs:236-276); `positions` the global packed-float3 vertex array.
  * PreSplitting (factor `preSplitFactor`, reference default 0.3) runs iff !isRefittable (Bvh/BVH.cs:325).
- * threads <= 0: use all hardware threads (the reference spawns a thread per subtree >= 8192 triangles and a task per
+ * threads <= 0: use the hardware threads this process may occupy (affinity mask, capped by the container's cgroup CPU quota) (the reference spawns a thread per subtree >= 8192 triangles and a task per
  * sort axis >= 65536 fragments; results do not depend on the thread count). */
 IDKBVH_API int32_t idkbvhBuildBlas(const float* positions, const GpuBlasTriangle* tris, int32_t triCount, int32_t isRefittable,
                                    float preSplitFactor, int32_t threads, idkbvh_blas** outBlas);

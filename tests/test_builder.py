@@ -73,6 +73,18 @@ def test_threaded_build_is_deterministic():
     assert_same(a, b)
 
 
+@pytest.mark.parametrize("make", [lambda b: S.soup_scene(70000, b, seed=11), lambda b: S.soup_scene(70000, b, seed=11, refittable=True), lambda b: S.atrium_scene(60000, b)],
+                         ids=["soup_presplit", "soup_refit", "atrium"])
+def test_parallel_tail_passes_keep_the_serial_result(make):
+    """Stack-size optimisation, GlobalSAH, RemoveEmptySubtrees and un-indexing run as subtree tasks whose binary64 terms are added in the serial
+    order (csrc/bvh_builder.cpp): trees deep enough for the cut (depth 9) and for OptimizeStackSize (>= 16) must not depend on the thread count."""
+    from idkengine_amd.bvh import NativeBuilder
+    ref = make(NativeBuilder(threads=1))
+    assert int(ref.blas_descs["RequiredStackSize"][0]) >= 14
+    for t in (2, 3, 16):
+        assert_same(ref, make(NativeBuilder(threads=t)))
+
+
 def _check_invariants(sc):
     nodes, tris, pos = sc.blas_nodes, sc.blas_triangles, sc.vertex_positions
     for d in sc.blas_descs:
