@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libidkpt.so")
+LIB_PATH = os.environ.get("IDKPT_LIB_PATH") or os.path.join(_HERE, "libidkpt.so")   # (the override is a developer knob: A/B runs of two builds on one box)
 
 # every symbol include/idkpt.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [

@@ -16,6 +16,7 @@ using namespace ptd;
 
 #define WAVE 64
 #define MAX_DEPTH_SLOTS 64
+#define WORK_WORDS ((GRAB_SLICES + 1) * GRAB_STRIDE)   // work counters: launch j uses word j of every 512-B line (k_trace2: one line per work-list slice, kernels_trace.hpp)
 
 // =================================================================================================== kernels (one translation unit)
 #include "kernels_common.hpp"
@@ -145,7 +146,7 @@ static int alloc_frame_impl(dev_ctx* ctx)
     HIPC(ctx->keysTmp.ensure(cap * 4)); HIPC(ctx->sortKeys.ensure(cap * 4)); HIPC(ctx->sortVals.ensure(cap * 4));
     size_t nW = (cap + 63) / 64;
     HIPC(ctx->contMask.ensure(nW * 8)); HIPC(ctx->waveCounts.ensure(nW * 4));
-    HIPC(ctx->counts.ensure(MAX_DEPTH_SLOTS * 4)); HIPC(ctx->work.ensure(4 * MAX_DEPTH_SLOTS * 4)); HIPC(ctx->counters64.ensure(128));
+    HIPC(ctx->counts.ensure(MAX_DEPTH_SLOTS * 4)); HIPC(ctx->work.ensure(WORK_WORDS * 4)); HIPC(ctx->counters64.ensure(128));
     HIPC(ctx->bases.ensure((size_t)MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4));
     size_t nTiles = (cap + SORT_TILE - 1) / SORT_TILE;
     HIPC(ctx->sortHist.ensure((SORT_RADIX * nTiles + SORT_RADIX) * 4));
@@ -750,7 +751,7 @@ static int query_frame(dev_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& grid)
     f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;
     f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
     f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->tlasNeed));
-    ldsBytes = (size_t)(f.stackCap + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;
+    ldsBytes = (size_t)(f.stackCap + 1 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the spare row of k_trace2's branch-free step
     if (ldsBytes > 64 * 1024) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack");
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
     grid = (uint32_t)(ctx->numCUs * std::max(1, wavesPerCU));
@@ -949,16 +950,21 @@ static int flush_batch(dev_ctx* ctx)
     const int depth = ctx->st.RayDepth;
     hipStream_t st = ctx->stream;
     if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[0], st));
-    HIPC(hipMemsetAsync(work, 0, 4 * MAX_DEPTH_SLOTS * 4, st));
+    HIPC(hipMemsetAsync(work, 0, WORK_WORDS * 4, st));
     HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
 
     f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->tlasNeed));
-    size_t ldsBytes = (size_t)(f.stackCap + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;
+    f.grabUnitLog2 = 10; f.grabFixed = 0; f.grabDummy = 0;
+    if (const char* e = getenv("IDKPT_GRAB_UNIT_LOG2")) f.grabUnitLog2 = std::min(16, std::max(6, atoi(e)));
+    if (const char* e = getenv("IDKPT_GRAB_FIXED")) f.grabFixed = std::max(0, atoi(e));   // developer knobs (kernels_trace.hpp, work-list hand-out)
+    if (const char* e = getenv("IDKPT_GRAB_DUMMY")) f.grabDummy = std::max(0, atoi(e));
+    size_t ldsBytes = (size_t)(f.stackCap + 1 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the spare row of k_trace2's branch-free step
     if (const char* e = getenv("IDKPT_LDS_PAD")) ldsBytes += (size_t)atoi(e);   // developer knob: caps the waves per CU (occupancy experiments)
     if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }
     // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
     wavesPerCU = std::max(1, wavesPerCU);
+    if (const char* e = getenv("IDKPT_TRACE_WAVES")) wavesPerCU = std::max(1, atoi(e));   // developer knob: one-wave workgroups per CU in the persistent grid
     // (a launch never needs more waves than it can have rays: small frames would otherwise spend their time dispatching idle workgroups)
     const uint32_t traceGrid = std::min<uint32_t>((uint32_t)(ctx->numCUs * wavesPerCU), std::max<uint32_t>(1u, (uint32_t)(((size_t)B * N + 63) / 64)));
     const bool debug = f.g.DoDebugBVHTraversal != 0;

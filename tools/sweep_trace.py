@@ -20,8 +20,6 @@ def run(sc, cam, variant, batch, frames, depth=2, sort=0, env=None):
     for k, v in (env or {}).items():
         os.environ[k] = str(v)
     pt = PathTracer(W, H)
-    for k in (env or {}):
-        os.environ.pop(k, None)
     pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = depth; pt.DoRaySorting = sort; pt.set_max_batch(batch)
     for _ in range(max(batch, 4)):
         pt.Compute()
@@ -38,16 +36,19 @@ def run(sc, cam, variant, batch, frames, depth=2, sort=0, env=None):
     st = pt.stats()
     img = pt.Result; rays = pt.rays()
     pt.Dispose()
+    for k in (env or {}):          # (some knobs are read at launch time, not at context creation)
+        os.environ.pop(k, None)
     return {"ms_per_frame": dt / frames * 1e3, "mray_s": st["rays_traced"] / dt / 1e6, "trace_ms_per_launch": st["trace_ms_total"] / max(1, st["trace_launches"]),
             "trace_ms_per_frame": st["trace_ms_total"] / frames, "rays_per_frame": st["rays_traced"] / frames}, img, rays
 
 
 if __name__ == "__main__":
-    variants = [int(v) for v in sys.argv[1:]] or [100, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]
-    sc = S.soup_scene(1000000, NativeBuilder(), seed=1)
-    views = {"headline": S.Camera(W, H), "interior": S.Camera(W, H, position=(0.0, 0.0, 0.0))}
+    variants = [int(v) for v in sys.argv[1:]] or [100, 208, 216, 232, 308, 316, 332, 408]
+    soup = S.soup_scene(1000000, NativeBuilder(), seed=1)
+    atrium = S.atrium_scene(1000000, NativeBuilder())
+    views = {"atrium": (atrium, S.atrium_camera(W, H)), "headline": (soup, S.Camera(W, H)), "interior": (soup, S.Camera(W, H, position=(0.0, 0.0, 0.0)))}
     report = {}
-    for vname, cam in views.items():
+    for vname, (sc, cam) in views.items():
         ref = {}
         for batch, frames in ((32, 96), (1, 40)):
             for v in variants:
@@ -61,4 +62,4 @@ if __name__ == "__main__":
                 report[f"{vname}/b{batch}/v{v}"] = r
                 print(f"{vname:9s} batch {batch:2d} variant {v:3d}: {r['mray_s']:8.1f} Mray/s  {r['ms_per_frame']:.3f} ms/frame  trace {r['trace_ms_per_frame']:.3f} ms/frame  parity {r['parity']}", flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(report, open("gpurun_out/sweep_trace.json", "w"), indent=1)
+    json.dump(report, open(os.environ.get("SWEEP_OUT", "gpurun_out/sweep_trace.json"), "w"), indent=1)
