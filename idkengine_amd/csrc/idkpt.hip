@@ -16,7 +16,7 @@ using namespace ptd;
 
 #define WAVE 64
 #define MAX_DEPTH_SLOTS 64
-#define WORK_WORDS ((GRAB_SLICES + 1) * GRAB_STRIDE)   // work counters: launch j uses word j of every 512-B line (k_trace2: one line per work-list slice, kernels_trace.hpp)
+#define WORK_WORDS (GRAB_SLICES * GRAB_STRIDE)   // work counters: launch j uses word j of every 512-B line (k_trace2: one line per work-list slice, kernels_trace.hpp)
 
 // =================================================================================================== kernels (one translation unit)
 #include "kernels_common.hpp"
@@ -126,6 +126,9 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
     switch (ctx->traceVariant) {   // developer knob (IDKPT_TRACE_VARIANT): s_memtime-instrumented builds; results are bit-identical
         case 107: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 65>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;   // instrumented, old policy
         case 113: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;  // instrumented, default policy
+#define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+        case 901: T2V(32, 20); break; case 902: T2V(40, 16); break;
+#undef T2V
         default: hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
     }
 }
@@ -954,10 +957,11 @@ static int flush_batch(dev_ctx* ctx)
     HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
 
     f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->tlasNeed));
-    f.grabUnitLog2 = 10; f.grabFixed = 0; f.grabDummy = 0;
+    f.grabUnitLog2 = 10; f.grabFixed = 0;
+    f.leafMin = B >= 4 ? 16 : 12;        // (measured: 16-20 with many samples in flight, 12 for a frame traced alone; tools/sweep_sched.py)
+    if (const char* e = getenv("IDKPT_LEAF_MIN")) f.leafMin = std::max(1, atoi(e));
     if (const char* e = getenv("IDKPT_GRAB_UNIT_LOG2")) f.grabUnitLog2 = std::min(16, std::max(6, atoi(e)));
     if (const char* e = getenv("IDKPT_GRAB_FIXED")) f.grabFixed = std::max(0, atoi(e));   // developer knobs (kernels_trace.hpp, work-list hand-out)
-    if (const char* e = getenv("IDKPT_GRAB_DUMMY")) f.grabDummy = std::max(0, atoi(e));
     size_t ldsBytes = (size_t)(f.stackCap + 1 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the spare row of k_trace2's branch-free step
     if (const char* e = getenv("IDKPT_LDS_PAD")) ldsBytes += (size_t)atoi(e);   // developer knob: caps the waves per CU (occupancy experiments)
     if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }

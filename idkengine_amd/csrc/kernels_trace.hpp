@@ -328,7 +328,6 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                     len = ((nBlocks + GRAB_SLICES - 1u - slice) / GRAB_SLICES) << unitLog2;   // entries of this slice (the list's last run may be partial)
                     fresh = wave_grab(workCounter + GRAB_STRIDE * slice, want);
                     if (PROF) pn[0]++;
-                    for (int k = 0; k < f.grabDummy; k++) (void)wave_grab(workCounter + GRAB_STRIDE * GRAB_SLICES, 1u);   // (developer experiment: extra atomics on another line)
                     if (fresh < len) { got = true; break; }
                     slice = (slice + 1u) & (GRAB_SLICES - 1u); slicesDone++;                  // handed out: try the next one
                 }
@@ -424,7 +423,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             const bool canStep = active && !leafPending && top != 0u;
             const unsigned long long stepMask = __builtin_amdgcn_ballot_w64(canStep);
             if (stepMask == 0ull) break;
-            if (LEAF_MIN <= 64 && __builtin_popcountll(__builtin_amdgcn_ballot_w64(active && leafPending)) >= LEAF_MIN) break;
+            if (LEAF_MIN <= 64 && __builtin_popcountll(__builtin_amdgcn_ballot_w64(active && leafPending)) >= (LEAF_MIN == 24 ? f.leafMin : LEAF_MIN)) break;   // (24 = "the host's choice")
             if (PROF) { pn[2]++; pn[3] += (unsigned long long)__builtin_popcountll(stepMask); }
             if (canStep) {
                 if (COUNT) nPairs++;

@@ -38,7 +38,8 @@ struct Frame {
     uint32_t accumulated;       // AccumulatedSamples of sample 0 of the batch (== accum[0])
     int useTlas, stackCap, outputAovs;
     int tlasCap;                // rows of the per-lane TLAS stack (<= TLAS_STACK_SIZE; a TLAS over n instances is never deeper than n)
-    int grabUnitLog2, grabFixed, grabDummy;   // developer knobs of k_trace2's work-list hand-out: entries reserved per atomic (0: what the refill needs), extra atomics per grab
+    int leafMin;                // k_trace2 leaves its node phase when this many lanes are parked on a leaf
+    int grabUnitLog2, grabFixed;   // k_trace2's work-list hand-out: a slice owns runs of 2^grabUnitLog2 entries; developer knob: entries reserved per atomic (0: what the refill needs)
     // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
     int batch; uint32_t Npad; uint32_t accum[256];   // [MAX_BATCH]
     uint32_t seqFirst, seqStride;   // idkptSetSampleSequence: sample i of an accumulation draws the RNG streams of AccumulatedSamples = seqFirst + i * seqStride (reference: 0, 1)

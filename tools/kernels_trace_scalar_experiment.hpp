@@ -1,3 +1,5 @@
+// Parked experiment (round 2): kernels_trace.hpp with the scalar-cache fetch of wave-uniform node pairs (template parameter SCALAR_MIN of k_trace2,
+// IDKPT_TRACE_VARIANT 208 / 216 / 232).  Bit-identical, no gain: see profiles/r02_trace_variants.md.  Not part of the build.
 // kernels_trace.hpp — traversal kernels: thread-per-ray general kernels (k_trace_primary / k_trace_queue), coherent primary-ray generation with pre-cull (k_gen_primary) and the persistent while-while kernel k_trace2 (BVHIntersect.glsl:27-105, 183-291).
 // Part of the single translation unit idkpt.hip (included there, in this order); see DESIGN.md §4 for the kernel table.
 #pragma once
@@ -260,33 +262,17 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
 //         instance list itself; the trace-ready planes hold the WORLD-space ray and the per-instance RayTransform happens here.
 // MODE 2: USE_TLAS (BVHIntersect.glsl:205-272): every lane walks the TLAS with its own stack (LDS rows after the BLAS rows); a
 //         TLAS leaf hands its instance to the same node/leaf phases (no root test, :32), then the TLAS walk resumes.
-//
-// SCALAR_MIN > 0 (wave-uniform fetches): the vector-memory path — one lane request per 16 B, whether or not the lanes want the same bytes —
-// is what binds this kernel, and coherent rays (the primary rays of an 8x8 tile) spend most of their node steps on the SAME
-// node pair as their neighbours (tools/sim_wave_sharing.py: 72 % of the lane-steps of the atrium's primary launch, 40 % inside the soup).
-// So every node step first asks which node the wave's first stepping lane wants and which lanes want the same one; when at least
-// SCALAR_MIN do, that pair is fetched ONCE through the scalar cache (s_load_dwordx16: 64 B per wave instead of 64 B per lane) and handed
-// to those lanes in registers; the other lanes fetch theirs as before.  SLEAF does the same for the triangle records of the leaf phase.
-// Same bytes, same arithmetic per ray: results stay bit-identical.
+// The node step is branch-free: the entry a pop would return is read from the LDS stack together with the node pair, the far child is
+// stored unconditionally into the row above the stack top (it only joins the stack when sp moves), and every decision of
+// BVHIntersect.glsl:81-101 is a select — no nested exec-mask regions (15 branches and 20 instructions fewer per step than the
+// if/else form; +2.5 to +6 % on every view).  One spare LDS row (index cap) takes the store of a full stack.
+#define GRAB_SLICES 8u          // work-list counters of k_trace2 (power of two)
+#define GRAB_STRIDE 128u        // words between them (512 B: separate cache lines and memory channels)
+// SCALAR_MIN > 0 (experiment): when at least that many stepping lanes want the node pair the wave's first stepping lane wants, the pair is
+// fetched once through the scalar cache (s_load_dwordx16) and handed to those lanes in registers; the others fetch theirs as before.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// (the wait sits in the same wave-uniform block as the load: the data must stay in SGPRs, and a wait placed in the lanes' divergent code would make it a per-lane value)
 DEV u32x16 sload64(const void* p) { u32x16 v; asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p)); return v; }
-DEV void sload48(const void* p, u32x8& a, u32x4& b) { asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p)); }
-
-// SROUNDS 1 / 2 (experimental form): the scalar load is only ISSUED before the other lanes' vector loads and waited for after them, and a
-// second group (the first stepping lane outside the first group and its sharers) may be served the same way.  The 16 per-lane registers are
-// "defined" by an empty asm at the top of the step so that the compiler does not carry the lanes that were not written around the loops.
-DEV void sload64_issue(u32x16& v, const void* p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p)); }
-DEV void sload_wait(u32x16& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); }
-DEV void free_def(float4& v) { asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
-#define ND_TO_LANES(nd) do { lmin = make_float4(__uint_as_float(nd[0]), __uint_as_float(nd[1]), __uint_as_float(nd[2]), __uint_as_float(nd[3])); \
-                             lmax = make_float4(__uint_as_float(nd[4]), __uint_as_float(nd[5]), __uint_as_float(nd[6]), __uint_as_float(nd[7])); \
-                             rmin = make_float4(__uint_as_float(nd[8]), __uint_as_float(nd[9]), __uint_as_float(nd[10]), __uint_as_float(nd[11])); \
-                             rmax = make_float4(__uint_as_float(nd[12]), __uint_as_float(nd[13]), __uint_as_float(nd[14]), __uint_as_float(nd[15])); } while (0)
-
-template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int SCALAR_MIN = 0, bool SLEAF = false, int SROUNDS = 0>
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int SCALAR_MIN = 0>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
     constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
@@ -294,7 +280,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     const uint32_t lane = threadIdx.x;
     uint32_t* stk = lds + lane;
     const int cap = f.stackCap;
-    uint32_t* tstk = stk + cap * WAVE;     // TLAS only
+    uint32_t* tstk = stk + (cap + 1) * WAVE;     // TLAS only (row cap is the spare row of the branch-free step)
     const uint32_t N = *countPtr;
     // wave-uniform scene constants
     const GpuBlasInstance inst = s.instances[0];
@@ -303,6 +289,13 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
 
     bool active = false, leafPending = false, workLeft = true;
+    // work-list state of this wave (wave-uniform): the slice it grabs from, how many slices it has seen handed out, and the positions
+    // [chunkNext, chunkEnd) of slice chunkSlice it has reserved but not yet given to lanes (only with a reservation size grabChunk > 0)
+    uint32_t slice = blockIdx.x & (GRAB_SLICES - 1u), slicesDone = 0, chunkNext = 0, chunkEnd = 0, chunkSlice = 0;
+    const uint32_t unitLog2 = (uint32_t)f.grabUnitLog2;           // a slice owns runs of 2^unitLog2 consecutive entries
+    const uint32_t nBlocks = (N + (1u << unitLog2) - 1u) >> unitLog2;
+    const uint32_t grabChunk = f.grabFixed > 0 ? (uint32_t)f.grabFixed : 0u;
+    if (N == 0u) workLeft = false;
     uint32_t top = 0, slot = 0, leafFirst = 0, leafEnd = 0;
     uint32_t instIdx = 0, rayId = 0, nodeOff = 0, triOff = 0, xformId = 0;   // MULTI only: per-lane instance cursor (TLAS: next TLAS node) and BLAS offsets
     int tsp = 0; bool moreInst = false;                                       // TLAS stack pointer; "there are instances / TLAS nodes left for this ray"
@@ -310,6 +303,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
     float hitT = 0.0f, hbx = 0.0f, hby = 0.0f; uint32_t hitTri = ~0u, hitXform = 0;
     uint32_t nPairs = 0, nTris = 0;
+    bool ovf = false;                      // a push found the stack full (reported once, when the wave ends)
     // PROF: per-wave cycle buckets [refill, node, leaf, other], step counts and active-lane sums (developer instrumentation)
     unsigned long long pc[4] = {0, 0, 0, 0}, pn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tPrev = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -321,10 +315,37 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         unsigned long long idle = __ballot(!active);
         if (workLeft && ((uint32_t)__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
             const uint32_t n = (uint32_t)__popcll(idle);
-            if (PROF) { pn[0]++; pn[1] += n; }
-            const uint32_t base = wave_grab(workCounter, n);      // (chunked grabbing was measured: no gain, worse balance at small N)
-            const uint32_t item = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (base + n >= N) workLeft = false;
+            if (PROF) { pn[1] += n; }
+            // Handing out the work list.  One counter word takes about 88 atomics per microsecond on this chip (any single address does), and
+            // coherent short rays ask for more: an atrium's primary rays (33 node steps, a wave refills ~50 lanes at a time) ran at exactly
+            // 87 refills per microsecond whatever the traversal did.  So the list is dealt over GRAB_SLICES counters on different cache lines:
+            // slice k owns the runs k, k + K, k + 2K, ... of 2^grabUnitLog2 consecutive entries and hands out positions of that sub-list.  All slices advance at the same
+            // rate, so the entries in flight are the same contiguous window of the list as with one counter (reserving big chunks instead
+            // costs incoherent scenes 2-13 %: neighbouring entries share nodes, and tails get longer); a wave starts at slice blockIdx % K
+            // and moves on to the next slice when its own is handed out.  Which lane traces which entry is free.
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t avail = chunkEnd - chunkNext;          // wave-uniform: what is left of this wave's last reservation
+            uint32_t q, sl; bool valid = true;                    // per lane: position inside a slice, the slice
+            if (avail >= n) { q = chunkNext + rank; sl = chunkSlice; chunkNext += n; }
+            else {
+                const uint32_t need = n - avail, want = grabChunk > need ? grabChunk : need;   // (grabChunk 0: exactly what this refill needs)
+                uint32_t fresh = 0, len = 0; bool got = false;
+                while (slicesDone < GRAB_SLICES) {
+                    len = ((nBlocks + GRAB_SLICES - 1u - slice) / GRAB_SLICES) << unitLog2;   // entries of this slice (the list's last run may be partial)
+                    fresh = wave_grab(workCounter + GRAB_STRIDE * slice, want);
+                    if (PROF) pn[0]++;
+                    for (int k = 0; k < f.grabDummy; k++) (void)wave_grab(workCounter + GRAB_STRIDE * GRAB_SLICES, 1u);   // (developer experiment: extra atomics on another line)
+                    if (fresh < len) { got = true; break; }
+                    slice = (slice + 1u) & (GRAB_SLICES - 1u); slicesDone++;                  // handed out: try the next one
+                }
+                q = rank < avail ? chunkNext + rank : fresh + (rank - avail); sl = rank < avail ? chunkSlice : slice;
+                valid = rank < avail || (got && q < len);
+                const uint32_t end = got ? (fresh + want < len ? fresh + want : len) : 0u;
+                chunkNext = got ? (fresh + need < end ? fresh + need : end) : 0u; chunkEnd = end; chunkSlice = slice;
+                if (got && fresh + want >= len) { slice = (slice + 1u) & (GRAB_SLICES - 1u); slicesDone++; }   // this reservation reached the slice's end
+            }
+            const uint32_t item = valid ? ((((q >> unitLog2) * GRAB_SLICES + sl) << unitLog2) | (q & ((1u << unitLog2) - 1u))) : N;
+            if (slicesDone >= GRAB_SLICES && chunkNext >= chunkEnd) workLeft = false;
             if (!active && item < N) {
                 const uint32_t idx = list[item];
                 slot = PRIMARY ? idx : item;
@@ -404,116 +425,62 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             }
         }
 
-        // ---- node phase
+        // ---- node phase (branch-free step: see the kernel's header comment)
         while (true) {
             const bool canStep = active && !leafPending && top != 0u;
-            const unsigned long long stepMask = __ballot(canStep);
+            const unsigned long long stepMask = __builtin_amdgcn_ballot_w64(canStep);
             if (stepMask == 0ull) break;
-            // enough lanes are parked on a leaf: test those leaves now instead of letting the stragglers run on alone
-            if (LEAF_MIN <= 64 && (int)__popcll(__ballot(active && leafPending)) >= LEAF_MIN) break;
-            if (PROF) { pn[2]++; pn[3] += (unsigned long long)__popcll(stepMask); }
-            bool viaScalar = false;                                 // this lane's pair arrives through the scalar cache
+            if (LEAF_MIN <= 64 && __builtin_popcountll(__builtin_amdgcn_ballot_w64(active && leafPending)) >= (LEAF_MIN == 24 ? f.leafMin : LEAF_MIN)) break;   // (24 = "the host's choice")
+            if (PROF) { pn[2]++; pn[3] += (unsigned long long)__builtin_popcountll(stepMask); }
+            bool viaScalar = false;                                 // SCALAR_MIN > 0: this lane's pair arrives through the scalar cache
             u32x16 nd;
-            float4 lmin, lmax, rmin, rmax;
-            if (SCALAR_MIN > 0 && SROUNDS == 0) {
+            if (SCALAR_MIN > 0) {
                 const uint32_t key = MULTI ? nodeOff + top : top;   // pair index in the node array
                 const uint32_t leadKey = __builtin_amdgcn_readlane(key, __ffsll((long long)stepMask) - 1);
                 const bool mine = canStep && key == leadKey;
-                if ((int)__popcll(__builtin_amdgcn_ballot_w64(mine)) >= SCALAR_MIN) {  // wave-uniform branch
-                    if (PROF) { pn[6]++; pn[7] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(mine)); }
+                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine)) >= SCALAR_MIN) {   // wave-uniform branch
                     nd = sload64((MULTI ? s.nodes : nodes) + 2 * (size_t)leadKey);
                     viaScalar = mine;
                 }
             }
-            if (SCALAR_MIN > 0 && SROUNDS > 0) {
-                free_def(lmin); free_def(lmax); free_def(rmin); free_def(rmax);
-                const float4* base = MULTI ? s.nodes : nodes;
-                const uint32_t key = MULTI ? nodeOff + top : top;
-                const uint32_t lead1 = __builtin_amdgcn_readlane(key, __ffsll((long long)stepMask) - 1);
-                const bool mine1 = canStep && key == lead1;
-                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(mine1);
-                const bool shared1 = (int)__popcll(m1) >= SCALAR_MIN;                     // wave-uniform
-                bool mine2 = false, shared2 = false; uint32_t lead2 = 0;
-                if (SROUNDS > 1 && shared1 && (stepMask & ~m1) != 0ull) {
-                    lead2 = __builtin_amdgcn_readlane(key, __ffsll((long long)(stepMask & ~m1)) - 1);
-                    mine2 = canStep && key == lead2;
-                    shared2 = (int)__popcll(__builtin_amdgcn_ballot_w64(mine2)) >= SCALAR_MIN;
-                }
-                viaScalar = (shared1 && mine1) || (shared2 && mine2);
-                if (shared1) sload64_issue(nd, base + 2 * (size_t)lead1);
-                if (canStep && !viaScalar) {                        // in flight while the scalar loads are waited for
-                    const float4* p = base + 2 * (size_t)key;
-                    lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3];
-                }
-                if (shared1) { sload_wait(nd); if (mine1) ND_TO_LANES(nd); }
-                if (SROUNDS > 1 && shared2) { nd = sload64(base + 2 * (size_t)lead2); if (mine2) ND_TO_LANES(nd); }
-            }
             if (canStep) {
                 if (COUNT) nPairs++;
-                if (SCALAR_MIN <= 0 || SROUNDS == 0) {
-                    if (!viaScalar) {
-                        const float4* p = MULTI ? s.nodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top;
-                        lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3];
-                    } else ND_TO_LANES(nd);
+                const float4* p = MULTI ? s.nodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top;
+                const int below = sp > 0 ? sp - 1 : 0;
+                const uint32_t popped = stk[(below < cap ? below : cap) * WAVE];   // what a pop would return (in flight with the node pair)
+                float4 lmin, lmax, rmin, rmax;
+                if (!viaScalar) { lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3]; }
+                else {
+                    lmin = make_float4(__uint_as_float(nd[0]), __uint_as_float(nd[1]), __uint_as_float(nd[2]), __uint_as_float(nd[3]));
+                    lmax = make_float4(__uint_as_float(nd[4]), __uint_as_float(nd[5]), __uint_as_float(nd[6]), __uint_as_float(nd[7]));
+                    rmin = make_float4(__uint_as_float(nd[8]), __uint_as_float(nd[9]), __uint_as_float(nd[10]), __uint_as_float(nd[11]));
+                    rmax = make_float4(__uint_as_float(nd[12]), __uint_as_float(nd[13]), __uint_as_float(nd[14]), __uint_as_float(nd[15]));
                 }
                 const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
                 float tMinLeft, tMinRight;
                 const bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= hitT;
                 const bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hitT;
                 const bool intersectLeft = hitLeft && lCount > 0, intersectRight = hitRight && rCount > 0;
-                if (intersectLeft || intersectRight) {
-                    const uint32_t tOff = MULTI ? triOff : triOffset;
-                    leafFirst = (intersectLeft ? lStart : rStart) + tOff;
-                    leafEnd = (!intersectRight ? (lStart + lCount) : (rStart + rCount)) + tOff;
-                    leafPending = true;
-                    if (COUNT) nTris += leafEnd - leafFirst;
-                }
+                const bool anyLeaf = intersectLeft || intersectRight;
+                const uint32_t tOff = MULTI ? triOff : triOffset;
+                const uint32_t lf = (intersectLeft ? lStart : rStart) + tOff, le = (!intersectRight ? (lStart + lCount) : (rStart + rCount)) + tOff;
+                leafFirst = anyLeaf ? lf : leafFirst; leafEnd = anyLeaf ? le : leafEnd; leafPending = anyLeaf;
+                if (COUNT) nTris += anyLeaf ? le - lf : 0u;
                 const bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
-                if (traverseLeft || traverseRight) {
-                    if (traverseLeft && traverseRight) {
-                        const bool leftCloser = tMinLeft < tMinRight;
-                        top = leftCloser ? lStart : rStart;
-                        if (sp < cap) stk[sp * WAVE] = leftCloser ? rStart : lStart; else *s.overflow = 1u;
-                        sp++;
-                    } else top = traverseLeft ? lStart : rStart;
-                } else {
-                    if (sp == 0) top = 0u;
-                    else { sp--; top = sp < cap ? stk[sp * WAVE] : 0u; }   // (sp >= cap: the matching push was dropped and flagged)
-                }
+                const bool both = traverseLeft && traverseRight, none = !(traverseLeft || traverseRight);
+                const bool leftCloser = tMinLeft < tMinRight;
+                const uint32_t nearChild = both ? (leftCloser ? lStart : rStart) : (traverseLeft ? lStart : rStart);
+                stk[(sp < cap ? sp : cap) * WAVE] = leftCloser ? rStart : lStart;   // the far child, above the top: part of the stack only if sp moves
+                ovf = ovf || (both && sp >= cap);
+                const bool canPop = sp > 0 && sp <= cap;               // (sp > cap: the matching push was dropped and flagged)
+                top = none ? (canPop ? popped : 0u) : nearChild;
+                sp += both ? 1 : ((none && sp > 0) ? -1 : 0);
             }
         }
         PROF_MARK(1);
         if (PROF) { unsigned long long lm = __ballot(leafPending); if (lm) { pn[4]++; pn[5] += (unsigned long long)__popcll(lm); } }
         // ---- leaf phase
-        if (SLEAF) {
-            // the same loop, wave-wide, with the triangle record of the first testing lane fetched once when enough lanes test the same one
-            uint32_t i = leafFirst;
-            bool inLeaf = leafPending;                              // (a parked leaf holds at least one triangle)
-            while (true) {
-                const unsigned long long lm = __ballot(inLeaf);
-                if (lm == 0ull) break;
-                bool viaScalar = false;
-                u32x8 t8; u32x4 t4;
-                const uint32_t leadI = __builtin_amdgcn_readlane(i, __ffsll((long long)lm) - 1);
-                const bool mine = inLeaf && i == leadI;
-                if ((int)__popcll(__builtin_amdgcn_ballot_w64(mine)) >= SCALAR_MIN) { sload48(s.triVerts + 3 * (size_t)leadI, t8, t4); viaScalar = mine; }
-                if (inLeaf) {
-                    float4 a, b, c;
-                    if (!viaScalar) { const float4* tv = s.triVerts + 3 * (size_t)i; a = tv[0]; b = tv[1]; c = tv[2]; }
-                    else {
-                        a = make_float4(__uint_as_float(t8[0]), __uint_as_float(t8[1]), __uint_as_float(t8[2]), __uint_as_float(t8[3]));
-                        b = make_float4(__uint_as_float(t8[4]), __uint_as_float(t8[5]), __uint_as_float(t8[6]), __uint_as_float(t8[7]));
-                        c = make_float4(__uint_as_float(t4[0]), __uint_as_float(t4[1]), __uint_as_float(t4[2]), __uint_as_float(t4[3]));
-                    }
-                    float by, bz, t;
-                    if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hitT) {
-                        hitTri = i; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = MULTI ? xformId : inst.MeshTransformId;
-                    }
-                    i++; inLeaf = i < leafEnd;
-                }
-            }
-            leafPending = false;
-        } else if (leafPending) {
+        if (leafPending) {
             for (uint32_t i = leafFirst; i < leafEnd; i++) {
                 const float4* tv = s.triVerts + 3 * (size_t)i;
                 float4 a = tv[0], b = tv[1], c = tv[2];
@@ -532,6 +499,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             active = false;
         }
     }
+    if (ovf) *s.overflow = 1u;
     if (COUNT) flush_counters(counters, nPairs, nTris);
     if (PROF && lane == 0) { for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)&counters[4 + i], pc[i]); for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&counters[8 + i], pn[i]); }
 #undef PROF_MARK
