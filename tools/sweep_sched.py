@@ -9,8 +9,9 @@ from idkengine_amd import scenes as S  # noqa: E402
 from idkengine_amd.bvh import NativeBuilder  # noqa: E402
 from sweep_trace import run, W, H  # noqa: E402
 
-CONFIGS = [("default (leafMin by batch)", 100, {}), ("leafMin 16", 100, {"IDKPT_LEAF_MIN": 16}), ("leafMin 12", 100, {"IDKPT_LEAF_MIN": 12}), ("leafMin 20", 100, {"IDKPT_LEAF_MIN": 20}), ("leafMin 24", 100, {"IDKPT_LEAF_MIN": 24}),
-           ("scalar >= 8", 208, {}), ("scalar >= 16", 216, {}), ("scalar >= 32", 232, {})]
+CONFIGS = [("default", 100, {})] + [(f"leafMin {l}", 100, {"IDKPT_LEAF_MIN": l}) for l in (8, 12, 16, 20, 24)] + [("R32 L20 (template)", 901, {}), ("R40 L16 (template)", 902, {})] + \
+          [(f"grid {w} waves/CU", 100, {"IDKPT_TRACE_WAVES": w}) for w in (12, 16, 20, 24, 28, 40)]
+SORT = int(os.environ.get("SWEEP_SORT", 0))
 
 if __name__ == "__main__":
     names = sys.argv[1:] or ["atrium", "headline", "interior"]
@@ -22,7 +23,7 @@ if __name__ == "__main__":
         for batch, frames in ((32, 96), (1, 40)):
             ref = None
             for label, variant, env in CONFIGS:
-                r, img, rays = run(sc, cam, variant, batch, frames, env=env)
+                r, img, rays = run(sc, cam, variant, batch, frames, env=env, sort=SORT)
                 if ref is None:
                     ref = (img, rays); par = "ref"
                 else:
