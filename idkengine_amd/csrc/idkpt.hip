@@ -960,7 +960,7 @@ static int flush_batch(dev_ctx* ctx)
     f.grabUnitLog2 = 10; f.grabFixed = 0;
     f.leafMin = B >= 4 ? 16 : 12;        // (measured: 16-20 with many samples in flight, 12 for a frame traced alone; tools/sweep_sched.py)
     if (const char* e = getenv("IDKPT_LEAF_MIN")) f.leafMin = std::max(1, atoi(e));
-    if (const char* e = getenv("IDKPT_GRAB_UNIT_LOG2")) f.grabUnitLog2 = std::min(16, std::max(6, atoi(e)));
+    if (const char* e = getenv("IDKPT_GRAB_UNIT_LOG2")) f.grabUnitLog2 = std::min(24, std::max(6, atoi(e)));
     if (const char* e = getenv("IDKPT_GRAB_FIXED")) f.grabFixed = std::max(0, atoi(e));   // developer knobs (kernels_trace.hpp, work-list hand-out)
     size_t ldsBytes = (size_t)(f.stackCap + 1 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the spare row of k_trace2's branch-free step
     if (const char* e = getenv("IDKPT_LDS_PAD")) ldsBytes += (size_t)atoi(e);   // developer knob: caps the waves per CU (occupancy experiments)
