@@ -128,6 +128,9 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         case 113: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;  // instrumented, default policy
 #define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         case 901: T2V(32, 20); break; case 902: T2V(40, 16); break;
+#define T2D(D) hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, D>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+        case 951: T2D(1); break; case 952: T2D(2); break; case 953: T2D(3); break; case 954: T2D(4); break;   // bottleneck probes: +16 VALU / +16 SALU / +48 SALU / +48 VALU instructions per node step
+#undef T2D
 #undef T2V
         default: hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
     }
@@ -754,7 +757,7 @@ static int query_frame(dev_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& grid)
     f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;
     f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
     f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->tlasNeed));
-    ldsBytes = (size_t)(f.stackCap + 1 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the spare row of k_trace2's branch-free step
+    ldsBytes = (size_t)(f.stackCap + 2 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the dummy and the spare row of k_trace2's stack (kernels_trace.hpp)
     if (ldsBytes > 64 * 1024) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack");
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
     grid = (uint32_t)(ctx->numCUs * std::max(1, wavesPerCU));
@@ -962,7 +965,7 @@ static int flush_batch(dev_ctx* ctx)
     if (const char* e = getenv("IDKPT_LEAF_MIN")) f.leafMin = std::max(1, atoi(e));
     if (const char* e = getenv("IDKPT_GRAB_UNIT_LOG2")) f.grabUnitLog2 = std::min(24, std::max(6, atoi(e)));
     if (const char* e = getenv("IDKPT_GRAB_FIXED")) f.grabFixed = std::max(0, atoi(e));   // developer knobs (kernels_trace.hpp, work-list hand-out)
-    size_t ldsBytes = (size_t)(f.stackCap + 1 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the spare row of k_trace2's branch-free step
+    size_t ldsBytes = (size_t)(f.stackCap + 2 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the dummy and the spare row of k_trace2's stack (kernels_trace.hpp)
     if (const char* e = getenv("IDKPT_LDS_PAD")) ldsBytes += (size_t)atoi(e);   // developer knob: caps the waves per CU (occupancy experiments)
     if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }
     // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)

@@ -263,18 +263,22 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
 // The node step is branch-free: the entry a pop would return is read from the LDS stack together with the node pair, the far child is
 // stored unconditionally into the row above the stack top (it only joins the stack when sp moves), and every decision of
 // BVHIntersect.glsl:81-101 is a select — no nested exec-mask regions (15 branches and 20 instructions fewer per step than the
-// if/else form; +2.5 to +6 % on every view).  One spare LDS row (index cap) takes the store of a full stack.
+// if/else form; +2.5 to +6 % on every view).  The stack pointer is the LDS address itself (pop = [sp], push = [sp + one row]: no index arithmetic).
 #define GRAB_SLICES 8u          // work-list counters of k_trace2 (power of two)
 #define GRAB_STRIDE 128u        // words between them (512 B: separate cache lines and memory channels)
-template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0>
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
     constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    uint32_t* stk = lds + lane;
+    // LDS rows of this wave, one word per lane: row 0 = dummy (what a pop of the empty stack reads), rows 1 .. cap = stack entries 0 .. cap-1,
+    // row cap + 1 = spare (takes the store of a full stack), then the TLAS rows.  The stack pointer IS an LDS address (stkBase + sp rows).
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* const stkBase = (lds_u32*)lds + lane;
     const int cap = f.stackCap;
-    uint32_t* tstk = stk + (cap + 1) * WAVE;     // TLAS only (row cap is the spare row of the branch-free step)
+    lds_u32* const stkFull = stkBase + cap * WAVE;
+    uint32_t* tstk = lds + lane + (cap + 2) * WAVE;     // TLAS only
     const uint32_t N = *countPtr;
     // wave-uniform scene constants
     const GpuBlasInstance inst = s.instances[0];
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     uint32_t top = 0, slot = 0, leafFirst = 0, leafEnd = 0;
     uint32_t instIdx = 0, rayId = 0, nodeOff = 0, triOff = 0, xformId = 0;   // MULTI only: per-lane instance cursor (TLAS: next TLAS node) and BLAS offsets
     int tsp = 0; bool moreInst = false;                                       // TLAS stack pointer; "there are instances / TLAS nodes left for this ray"
-    int sp = 0;
+    lds_u32* sp = stkBase;
     f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
     float hitT = 0.0f, hbx = 0.0f, hby = 0.0f; uint32_t hitTri = ~0u, hitXform = 0;
     uint32_t nPairs = 0, nTris = 0;
@@ -352,13 +356,13 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         if (RaySphereIntersect(wo, wd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hitT) { hitT = tMin < 0.0f ? tMax : tMin; hitXform = (uint32_t)i; hitTri = ~0u; }
                     }
                 }
-                if (MULTI) { rayId = idx; instIdx = 0; tsp = 0; moreInst = TLAS ? s.tlasCount > 0 : true; active = true; leafPending = false; sp = 0; top = 0u; }
+                if (MULTI) { rayId = idx; instIdx = 0; tsp = 0; moreInst = TLAS ? s.tlasCount > 0 : true; active = true; leafPending = false; sp = stkBase; top = 0u; }
                 else {
                     // local-space ray and 1/dir were prepared by the (coherent, full-lane) kernel that produced this ray
                     float rootT;
                     { float4 a = tr.rec[4 * (size_t)idx], b = tr.rec[4 * (size_t)idx + 1], c = tr.rec[4 * (size_t)idx + 2]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z); rootT = a.w; }
                     const bool enter = rootT < hitT;   // root test (:32-39): the box arithmetic ran in the kernel that produced the ray (record[0].w = tMin, +inf = miss)
-                    active = true; leafPending = false; sp = 0; top = enter ? 2u : 0u;
+                    active = true; leafPending = false; sp = stkBase; top = enter ? 2u : 0u;
                 }
             }
         }
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                         invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
-                        sp = 0; top = 2u;                                                   // no root test under USE_TLAS (:32)
+                        sp = stkBase; top = 2u;                                             // no root test under USE_TLAS (:32)
                         if (tsp == 0 || tsp > f.tlasCap) moreInst = false; else instIdx = tstk[--tsp * WAVE];  // the pop the reference does after the BLAS; order-independent
                     } else {
                         const uint32_t l = id, r = id + 1;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                     const float4* root = s.nodes + 2 * (size_t)nodeOff + 2;
                     float t1;
                     const bool enter = RayBoxIntersect(ro, invDir, root[0], root[1], &t1) && t1 < hitT;
-                    sp = 0; top = enter ? 2u : 0u;
+                    sp = stkBase; top = enter ? 2u : 0u;
                     instIdx++;
                 }
                 adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
@@ -428,35 +432,41 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             if (canStep) {
                 if (COUNT) nPairs++;
                 const float4* p = MULTI ? s.nodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top;
-                const int below = sp > 0 ? sp - 1 : 0;
-                const uint32_t popped = stk[(below < cap ? below : cap) * WAVE];   // what a pop would return (in flight with the node pair)
+                if (DBG == 1) { uint32_t x0 = lane, x1 = lane, x2 = lane, x3 = lane;       // (bottleneck probe: 16 extra VALU instructions per step, four independent chains)
+                    for (int k = 0; k < 4; k++) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)); }
+                if (DBG == 2) { uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;                   // (16 extra SALU instructions per step)
+                    for (int k = 0; k < 4; k++) asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1" : "+s"(y0), "+s"(y1), "+s"(y2), "+s"(y3)); }
+                if (DBG == 3) { uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;                   // (48 extra SALU instructions per step)
+                    for (int k = 0; k < 12; k++) asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1" : "+s"(y0), "+s"(y1), "+s"(y2), "+s"(y3)); }
+                if (DBG == 4) { uint32_t x0 = lane, x1 = lane, x2 = lane, x3 = lane;       // (48 extra VALU instructions per step)
+                    for (int k = 0; k < 12; k++) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)); }
+                const uint32_t popped = sp[0];                          // what a pop would return (in flight with the node pair; row 0 for an empty stack)
                 float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
                 const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
                 float tMinLeft, tMinRight;
                 const bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= hitT;
                 const bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hitT;
                 const bool intersectLeft = hitLeft && lCount > 0, intersectRight = hitRight && rCount > 0;
-                const bool anyLeaf = intersectLeft || intersectRight;
-                const uint32_t tOff = MULTI ? triOff : triOffset;
-                const uint32_t lf = (intersectLeft ? lStart : rStart) + tOff, le = (!intersectRight ? (lStart + lCount) : (rStart + rCount)) + tOff;
-                leafFirst = anyLeaf ? lf : leafFirst; leafEnd = anyLeaf ? le : leafEnd; leafPending = anyLeaf;
-                if (COUNT) nTris += anyLeaf ? le - lf : 0u;
+                // (a lane that steps has no parked leaf, so its leaf registers are free: written unconditionally, BLAS-local; the leaf phase adds the offset)
+                leafFirst = intersectLeft ? lStart : rStart; leafEnd = !intersectRight ? lStart + lCount : rStart + rCount; leafPending = intersectLeft || intersectRight;
+                if (COUNT) nTris += leafPending ? leafEnd - leafFirst : 0u;
                 const bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
                 const bool both = traverseLeft && traverseRight, none = !(traverseLeft || traverseRight);
                 const bool leftCloser = tMinLeft < tMinRight;
                 const uint32_t nearChild = both ? (leftCloser ? lStart : rStart) : (traverseLeft ? lStart : rStart);
-                stk[(sp < cap ? sp : cap) * WAVE] = leftCloser ? rStart : lStart;   // the far child, above the top: part of the stack only if sp moves
-                ovf = ovf || (both && sp >= cap);
-                const bool canPop = sp > 0 && sp <= cap;               // (sp > cap: the matching push was dropped and flagged)
-                top = none ? (canPop ? popped : 0u) : nearChild;
-                sp += both ? 1 : ((none && sp > 0) ? -1 : 0);
+                sp[WAVE] = leftCloser ? rStart : lStart;                // the far child, above the top: part of the stack only if sp moves
+                const bool full = sp == stkFull, nonEmpty = sp != stkBase;
+                ovf = ovf || (both && full);                            // (the push is dropped and flagged: the upload-time validation makes this unreachable)
+                top = none ? (nonEmpty ? popped : 0u) : nearChild;
+                sp += (both && !full) ? (int)WAVE : ((none && nonEmpty) ? -(int)WAVE : 0);
             }
         }
         PROF_MARK(1);
         if (PROF) { unsigned long long lm = __ballot(leafPending); if (lm) { pn[4]++; pn[5] += (unsigned long long)__popcll(lm); } }
         // ---- leaf phase
         if (leafPending) {
-            for (uint32_t i = leafFirst; i < leafEnd; i++) {
+            const uint32_t tOff = MULTI ? triOff : triOffset;
+            for (uint32_t i = leafFirst + tOff, e = leafEnd + tOff; i < e; i++) {
                 const float4* tv = s.triVerts + 3 * (size_t)i;
                 float4 a = tv[0], b = tv[1], c = tv[2];
                 float by, bz, t;
