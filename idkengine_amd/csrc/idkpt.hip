@@ -128,6 +128,8 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         case 113: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;  // instrumented, default policy
 #define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         case 901: T2V(32, 20); break; case 902: T2V(40, 16); break;
+        case 961: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;   // occupancy probes: 7 / 8 waves per SIMD forced (launch bounds)
+        case 962: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 8, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
 #define T2D(D) hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, D>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         case 951: T2D(1); break; case 952: T2D(2); break; case 953: T2D(3); break; case 954: T2D(4); break;   // bottleneck probes: +16 VALU / +16 SALU / +48 SALU / +48 VALU instructions per node step
 #undef T2D
