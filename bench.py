@@ -25,9 +25,11 @@ Metric (BASELINE.json): Mray/s (primary + 1 bounce) at 1920x1080 on the syntheti
   roofline  = traversal kernel (k_trace2).  achieved = algorithmic bytes (64 B per node-pair visit + 48 B per triangle test + 72 B per
               traversed ray, exact visit counts from the counting build) / HIP-event time of its launches in the timed region.
               The working set (110 MB) lives in L2 + Infinity Cache, so HBM is not what binds (hbm.* below: the algorithmic rate
-              exceeds 8 TB/s, the counters show 1-2 TB/s); the resource that binds is the vector-memory path's rate of independent
-              64-B block fetches, so peak = that rate measured on this very box by tools/ubench_lines (4 x 16-B loads per lane to its
-              own random 64-B block, L2-resident set, 32 waves/CU), in the same unit.
+              exceeds 8 TB/s, the counters show 1-2 TB/s); what bounds the INCOHERENT launches (this headline view, every bounce
+              launch) is the vector-memory path's rate of independent 64-B block fetches, so peak = that rate measured on this very
+              box by tools/ubench_lines (4 x 16-B loads per lane to its own random 64-B block, L2-resident set, 32 waves/CU), in the
+              same unit.  Coherent launches (camera inside the scene) exceed that ceiling in algorithmic bytes - their rays share
+              cache lines - and are then priced against the L1 return path; nothing in the memory system binds them.
   cpu_baseline = the oracle's CPU port of the same path (all host cores, OpenMP), scene and threads kept warm, on a bounded sample.
 """
 import argparse
