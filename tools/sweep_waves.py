@@ -16,7 +16,7 @@ if __name__ == "__main__":
     for vname in names:
         sc, cam = views[vname]
         for batch, frames in ((32, 96), (1, 40)):
-            for variant in (100, 801):
+            for variant in (100,):
                 for waves, pad in ((12, 0), (16, 0), (20, 0), (22, 0), (24, 0), (26, 0), (28, 0), (30, 0), (32, 0), (40, 0), (24, 1536), (32, 1536)):
                     r, _, _ = run(sc, cam, variant, batch, frames, env={"IDKPT_TRACE_WAVES": waves, "IDKPT_LDS_PAD": pad})
                     print(f"{vname:9s} batch {batch:2d} variant {variant} waves/CU {waves:2d} pad {pad:4d}: {r['mray_s']:8.1f} Mray/s  {r['ms_per_frame']:.3f} ms/frame  trace {r['trace_ms_per_frame']:.3f} ms/frame", flush=True)
