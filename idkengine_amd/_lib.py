@@ -15,7 +15,7 @@ SYMBOLS = [
     "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptSetSampleSequence", "idkptRender", "idkptSynchronize", "idkptDownload",
     "idkptDownloadRays", "idkptDownloadAliveQueue", "idkptEnablePrimaryHitCapture", "idkptDownloadPrimaryHits",
     "idkptGetStats", "idkptResetStats", "idkptEnableCounters", "idkptEnableTiming", "idkptGetImageDevicePtr",
-    "idkptSetStream", "idkptGetStream", "idkptSetMaxBatch", "idkptFlush", "idkptTraceRays", "idkptTraceShadows", "idkptSetFrameRing", "idkptBeginFrame", "idkptDownloadFrame", "idkptGetFrameDevicePtr",
+    "idkptSetStream", "idkptGetStream", "idkptSetDeveloperOption", "idkptSetMaxBatch", "idkptFlush", "idkptTraceRays", "idkptTraceShadows", "idkptSetFrameRing", "idkptBeginFrame", "idkptDownloadFrame", "idkptGetFrameDevicePtr",
 ]
 
 _lib = None
@@ -48,7 +48,7 @@ def load():
         "idkptDownloadAliveQueue": [vp, vp, sz, C.POINTER(u32)], "idkptEnablePrimaryHitCapture": [vp, i32],
         "idkptDownloadPrimaryHits": [vp, vp, vp, vp, sz], "idkptGetStats": [vp, vp], "idkptResetStats": [vp],
         "idkptEnableCounters": [vp, i32], "idkptEnableTiming": [vp, i32], "idkptGetImageDevicePtr": [vp, i32, C.POINTER(vp), C.POINTER(sz)],
-        "idkptSetStream": [vp, vp], "idkptGetStream": [vp, C.POINTER(vp)], "idkptSetMaxBatch": [vp, i32], "idkptFlush": [vp],
+        "idkptSetStream": [vp, vp], "idkptGetStream": [vp, C.POINTER(vp)], "idkptSetDeveloperOption": [vp, C.c_char_p, i32], "idkptSetMaxBatch": [vp, i32], "idkptFlush": [vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

@@ -29,11 +29,13 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force=False, verbose=False):
-    out = os.path.join(_HERE, "libidkpt.so")
+def build_hip(force=False, verbose=False, developer=False):
+    """libidkpt.so: the product.  developer=True: libidkpt_dev.so, the same source with -DIDKPT_DEVELOPER — additionally carries the instrumented
+    and probe instantiations of the traversal kernel (option "trace_variant"); used by tools/ through IDKPT_LIB_PATH, never by the product path."""
+    out = os.path.join(_HERE, "libidkpt_dev.so" if developer else "libidkpt.so")
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [os.path.join(INCLUDE, f) for f in ("idkpt.h", "idkpt_types.h")]
     if force or _stale(out, srcs):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", out, os.path.join(CSRC, "idkpt.hip")]
+        cmd = [_hipcc()] + HIPCC_FLAGS + (["-DIDKPT_DEVELOPER"] if developer else []) + ["-o", out, os.path.join(CSRC, "idkpt.hip")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include "../../include/idkpt.h"
 #include "pt_kernels.hpp"
+#include "node_layout.hpp"
 
 using namespace ptd;
 
@@ -37,6 +38,24 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Tuning / test options (idkptSetDeveloperOption; none is part of the reference's interface and results are bit-identical under all of them:
+// tests/test_gpu_worklist.py, test_gpu_layout.py).  The library itself never reads the environment; the Python host mirror forwards IDKPT_<NAME>.
+struct DevOptions {
+    int forceGeneric = 0;        // thread-per-ray kernels instead of k_trace2 (the cross-check of the tests)
+    int noTileCull = 0;          // per-pixel root-box cull only
+    int noLeanPrimary = 0;       // k_gen_primary stores the full ray state of surviving rays
+    int leafMin = 0;             // k_trace2: lanes parked on a leaf before the node phase is left (0: 16 for batches of >= 4 samples, 12 below)
+    int grabUnitLog2 = 10, grabFixed = 0;   // work-list hand-out: run length of a slice, entries reserved per atomic (0: what the refill needs)
+    int ldsPad = 0;              // bytes of LDS added per workgroup of k_trace2 (caps the resident waves)
+    int traceWaves = 0;          // one-wave workgroups per CU in the persistent grid (0: what LDS allows, at most 32)
+    int gridHint = 2;            // bounce launches: grid = gridHint x the queue length the same bounce had in the previous batch (0: full grid)
+    int nodeLayout = 1;          // derived node order (node_layout.hpp): 0 = reference order, 1 = line couples depth-first, 2 = line couples in treelets
+    int treeletDepth = 3;
+    int traceOrder = 1;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order, 1 = batches of >= 4 samples, 2 = always
+    int traceVariant = 0;        // IDKPT_DEVELOPER builds only: instrumented / probe instantiations of k_trace2
+    int bvhTiming = 0, bvhSmall = 32;   // idkptBuildBlasCore: phase times on stderr; subtrees of at most this many fragments are finished by one thread
+};
+
 struct PendingSample { uint32_t accum; int slot; float cam[36]; };   // cam = invProj[16] invView[16] viewPos[3] pad
 
 struct dev_ctx {
@@ -52,19 +71,21 @@ struct dev_ctx {
     // frame ring (idkptSetFrameRing): ringSize result-image sets; every queued sample remembers its slot, its camera and its
     // AccumulatedSamples index, so several frames (different cameras) can be in flight in one batch
     int ringSize = 1, curSlot = 0; bool ringStarted = false; std::vector<uint32_t> accum = std::vector<uint32_t>(1, 0u);
-    bool counters = false, timing = false, capturePrimary = false, forceGeneric = false, noTileCull = false; int traceVariant = 0;
+    bool counters = false, timing = false, capturePrimary = false;
+    DevOptions opt;
     uint32_t seqFirst = 0, seqStride = 1;                         // idkptSetSampleSequence
     // scene
     bool haveScene = false, frameOk = false;
-    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;   // (+ camTab below)
+    DevBuf nodes, tnodes, nodeSlot, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;   // (+ camTab below)
     std::vector<DevBuf> texData; std::vector<std::pair<int, int>> texDims;
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
     std::vector<uint32_t> levelBase;                 // per BLAS base into levelNodes
     int nodeCount = 0, triCount = 0, instanceCount = 0, tlasCount = 0, vertexCount = 0, meshCount = 0, materialCount = 0, xformCount = 0, lightCount = 0, skySize = 0, textureCount = 0, unskinnedCount = 0;
     int sceneStack = 1;
+    bool layoutActive = false;                       // tnodes holds the derived order (else the traversal reads `nodes`)
     // wavefront state
-    DevBuf trRec, contFlag, blockSums, rayO, rayT, rayR, aovA, aovN, hit, hitX, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, contMask, waveCounts, counts, work, sortHist, counters64;
+    DevBuf trRec, contFlag, blockSums, rayO, rayT, rayR, aovA, aovN, hit, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, ordKeys[2], ordVals[2], ordIdx, contMask, waveCounts, counts, work, sortHist, counters64;
     DevBuf img[3];
     DevBuf camTab;                                       // per-sample cameras of the batch being launched (ring mode)
     int rowLimit = 0x7fffffff;                           // idkptSetRowRange: at most this many local rows
@@ -123,19 +144,22 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         return;
     }
     if (ctx->counters) { hipLaunchKernelGGL((k_trace2<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return; }
-    switch (ctx->traceVariant) {   // developer knob (IDKPT_TRACE_VARIANT): s_memtime-instrumented builds; results are bit-identical
-        case 107: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 65>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;   // instrumented, old policy
-        case 113: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;  // instrumented, default policy
+#ifdef IDKPT_DEVELOPER
+    switch (ctx->opt.traceVariant) {   // developer builds (libidkpt_dev.so, option "trace_variant"): s_memtime-instrumented and probe instantiations; results are bit-identical
+        case 107: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 65>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // instrumented, old policy
+        case 113: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // instrumented, default policy
 #define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
-        case 901: T2V(32, 20); break; case 902: T2V(40, 16); break;
-        case 961: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;   // occupancy probes: 7 / 8 waves per SIMD forced (launch bounds)
-        case 962: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 8, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        case 901: T2V(32, 20); return; case 902: T2V(40, 16); return;
+        case 961: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // occupancy probes: 7 / 8 waves per SIMD forced (launch bounds)
+        case 962: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 8, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;
 #define T2D(D) hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, D>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
-        case 951: T2D(1); break; case 952: T2D(2); break; case 953: T2D(3); break; case 954: T2D(4); break;   // bottleneck probes: +16 VALU / +16 SALU / +48 SALU / +48 VALU instructions per node step
+        case 951: T2D(1); return; case 952: T2D(2); return; case 953: T2D(3); return; case 954: T2D(4); return;   // bottleneck probes: +16 VALU / +16 SALU / +48 SALU / +48 VALU instructions per node step
 #undef T2D
 #undef T2V
-        default: hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); break;
+        default: break;
     }
+#endif
+    hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
 }
 
 static int alloc_frame_impl(dev_ctx* ctx)
@@ -149,9 +173,10 @@ static int alloc_frame_impl(dev_ctx* ctx)
     HIPC(ctx->aovA.ensure(cap * 16)); HIPC(ctx->aovN.ensure(cap * 16));
     HIPC(ctx->trRec.ensure(cap * 64)); HIPC(ctx->contFlag.ensure(cap));
     HIPC(ctx->blockSums.ensure(((cap + 63) / 64 + SCAN_WAVES_PER_BLOCK - 1) / SCAN_WAVES_PER_BLOCK * 4 + 16));
-    HIPC(ctx->hit.ensure(cap * 16)); HIPC(ctx->hitX.ensure(cap * 4)); HIPC(ctx->hitCost.ensure(cap * 4));
+    HIPC(ctx->hit.ensure(cap * 32)); HIPC(ctx->hitCost.ensure(cap * 4));
     for (int i = 0; i < 2; i++) { HIPC(ctx->queue[i].ensure(cap * 4)); HIPC(ctx->keys[i].ensure(cap * 4)); }
     HIPC(ctx->keysTmp.ensure(cap * 4)); HIPC(ctx->sortKeys.ensure(cap * 4)); HIPC(ctx->sortVals.ensure(cap * 4));
+    if (ctx->opt.traceOrder) { for (int i = 0; i < 2; i++) { HIPC(ctx->ordKeys[i].ensure(cap * 4)); HIPC(ctx->ordVals[i].ensure(cap * 4)); } HIPC(ctx->ordIdx.ensure(cap * 4)); }
     size_t nW = (cap + 63) / 64;
     HIPC(ctx->contMask.ensure(nW * 8)); HIPC(ctx->waveCounts.ensure(nW * 4));
     HIPC(ctx->counts.ensure(MAX_DEPTH_SLOTS * 4)); HIPC(ctx->work.ensure(WORK_WORDS * 4)); HIPC(ctx->counters64.ensure(128));
@@ -230,6 +255,64 @@ static int tlas_validate(const GpuTlasNode* nodes, int nodeCount, int instanceCo
     return need[0];
 }
 
+// BLAS node arrays a host hands over (idkptUploadScene, idkptUpdateBuffer on IDKPT_BUF_BLAS_NODES): index validation so that a bad array cannot
+// fault the GPU, plus the traversal stack the trees need.  Returns null when valid, else the reason.
+static const char* validate_blas_nodes(const GpuBlasNode* nodes, int nodeCount, const GpuBlasDesc* descs, int descCount, int triangleCount, bool checkClaim, int* outMaxStack)
+{
+    int maxStack = 1;
+    for (int i = 0; i < descCount; i++) {
+        const GpuBlasDesc& d = descs[i];
+        if (!(d.NodeOffset >= 0 && d.NodeCount >= 4 && d.NodeOffset + d.NodeCount <= nodeCount && d.TriangleOffset >= 0 && d.TriangleOffset + d.TriangleCount <= triangleCount)) return "BlasDesc range out of bounds";
+        for (int n = 1; n < d.NodeCount; n++) {
+            const GpuBlasNode& nd = nodes[d.NodeOffset + n];
+            if (nd.TriCount > 0) { if (!((uint64_t)nd.TriStartOrChild + nd.TriCount <= (uint64_t)d.TriangleCount)) return "leaf triangle range out of bounds"; }
+            else if (n == 1 || nd.TriStartOrChild != 0) { if (!(nd.TriStartOrChild >= 2 && nd.TriStartOrChild > (uint32_t)n && nd.TriStartOrChild + 1 < (uint32_t)d.NodeCount)) return "child index out of bounds (children must lie behind their parent)"; }
+        }
+        // the traversal stack is sized from what the tree really needs (BLAS.ComputeRequiredStackSize, Bvh/BLAS.cs:672-702); a host that
+        // claims less in RequiredStackSize would have compiled the reference's shaders with too small a BLAS_STACK_SIZE (Bvh/BVH.cs:559-567)
+        const int need = blas_stack_need(nodes + d.NodeOffset, d.NodeCount);
+        if (checkClaim && d.RequiredStackSize < need) return "BlasDesc.RequiredStackSize is smaller than the stack the BLAS needs";
+        maxStack = std::max(maxStack, need);
+    }
+    *outMaxStack = maxStack;
+    return nullptr;
+}
+
+static int derive_nodes(dev_ctx* ctx, int blasId)
+{
+    if (!ctx->layoutActive) return IDKPT_OK;
+    const GpuBlasDesc& d = ctx->hDescs[blasId];
+    const uint32_t pairs = (uint32_t)d.NodeCount / 2;
+    hipLaunchKernelGGL(k_derive_nodes, dim3((pairs + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->nodes.as<float4>(), (const uint32_t*)ctx->nodeSlot.as<uint32_t>(), ctx->tnodes.as<float4>(), (uint32_t)d.NodeOffset, pairs);
+    HIPC(hipGetLastError());
+    return IDKPT_OK;
+}
+
+// The derived node order of the whole scene (node_layout.hpp), from a host copy of the (validated) reference nodes: one permutation per BLAS, the
+// slots on the device, then k_derive_nodes per BLAS.  Scenes whose BLAS ranges are not disjoint, pair-aligned pieces of the node array keep the
+// reference order (the traversal then reads `nodes`): never produced by the reference's builder, legal for the traversal.
+static int rebuild_node_layout(dev_ctx* ctx, const GpuBlasNode* hostNodes)
+{
+    ctx->layoutActive = false;
+    if (ctx->opt.nodeLayout == 0) { ctx->tnodes.release(); ctx->nodeSlot.release(); return IDKPT_OK; }
+    const size_t pairsTotal = (size_t)ctx->nodeCount / 2;
+    std::vector<std::pair<int, int>> ranges;
+    for (const GpuBlasDesc& d : ctx->hDescs) { if ((d.NodeOffset & 1) || (d.NodeCount & 1)) return IDKPT_OK; ranges.push_back({d.NodeOffset, d.NodeCount}); }
+    std::sort(ranges.begin(), ranges.end());
+    for (size_t i = 1; i < ranges.size(); i++) if (ranges[i].first < ranges[i - 1].first + ranges[i - 1].second) return IDKPT_OK;   // shared / overlapping node ranges
+    std::vector<uint32_t> slots(pairsTotal + 1, 0u), one;
+    for (const GpuBlasDesc& d : ctx->hDescs) {
+        nodelayout::compute((const nodelayout::Node*)(hostNodes + d.NodeOffset), d.NodeCount, (uint32_t)d.NodeOffset / 2, ctx->opt.nodeLayout, ctx->opt.treeletDepth, one);
+        std::copy(one.begin(), one.end(), slots.begin() + d.NodeOffset / 2);
+    }
+    HIPC(ctx->nodeSlot.ensure(slots.size() * 4)); HIPC(ctx->tnodes.ensure(std::max<size_t>((size_t)ctx->nodeCount * 32, 64)));
+    HIPC(hipMemcpyAsync(ctx->nodeSlot.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->layoutActive = true;
+    for (int b = 0; b < (int)ctx->hDescs.size(); b++) { int rc = derive_nodes(ctx, b); if (rc) { ctx->layoutActive = false; return rc; } }
+    HIPC(hipStreamSynchronize(ctx->stream));            // `slots` is a stack vector
+    return IDKPT_OK;
+}
+
 // ---- single-device implementation of the C-ABI (dev_*); the exported entry points and the multi-device group layer are in idkpt_api.hpp
 
 static const char* dev_GetVersionString(void) { return "idkpt 0.1 (gfx950)"; }
@@ -268,9 +351,6 @@ static int32_t dev_Create(int32_t deviceCount, const int32_t* deviceIds, dev_ctx
     if (hipHostMalloc((void**)&ctx->hBases, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     memset(ctx->hBases, 0, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4);
     (void)hipEventCreate(&ctx->evFrame[0]); (void)hipEventCreate(&ctx->evFrame[1]);
-    if (const char* e = getenv("IDKPT_FORCE_GENERIC")) ctx->forceGeneric = atoi(e) != 0;
-    if (const char* e = getenv("IDKPT_TRACE_VARIANT")) ctx->traceVariant = atoi(e);
-    if (const char* e = getenv("IDKPT_NO_TILE_CULL")) ctx->noTileCull = atoi(e) != 0;   // developer/test knob: per-pixel cull only
     *outCtx = ctx;
     return IDKPT_OK;
 }
@@ -281,8 +361,8 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* all[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit, &ctx->hitX,
+    DevBuf* all[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -438,20 +518,7 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     for (int i = 0; i < sc->MeshCount; i++) REQUIRE(sc->Meshes[i].MaterialId >= 0 && sc->Meshes[i].MaterialId < sc->MaterialCount, "idkptUploadScene: Mesh.MaterialId out of range");
     for (int i = 0; i < sc->BlasInstanceCount; i++) REQUIRE(sc->BlasInstances[i].BlasId < (uint32_t)sc->BlasDescCount && sc->BlasInstances[i].MeshTransformId < (uint32_t)sc->MeshTransformCount, "idkptUploadScene: BlasInstance out of range");
     int maxStack = 1;
-    for (int i = 0; i < sc->BlasDescCount; i++) {
-        const GpuBlasDesc& d = sc->BlasDescs[i];
-        REQUIRE(d.NodeOffset >= 0 && d.NodeCount >= 4 && d.NodeOffset + d.NodeCount <= sc->BlasNodeCount && d.TriangleOffset >= 0 && d.TriangleOffset + d.TriangleCount <= sc->BlasTriangleCount, "idkptUploadScene: BlasDesc range out of bounds");
-        for (int n = 1; n < d.NodeCount; n++) {
-            const GpuBlasNode& nd = sc->BlasNodes[d.NodeOffset + n];
-            if (nd.TriCount > 0) REQUIRE((uint64_t)nd.TriStartOrChild + nd.TriCount <= (uint64_t)d.TriangleCount, "idkptUploadScene: leaf triangle range out of bounds");
-            else if (n == 1 || nd.TriStartOrChild != 0) REQUIRE(nd.TriStartOrChild >= 2 && nd.TriStartOrChild > (uint32_t)n && nd.TriStartOrChild + 1 < (uint32_t)d.NodeCount, "idkptUploadScene: child index out of bounds (children must lie behind their parent)");
-        }
-        // the traversal stack is sized from what the tree really needs (BLAS.ComputeRequiredStackSize, Bvh/BLAS.cs:672-702); a host that
-        // claims less in RequiredStackSize would have compiled the reference's shaders with too small a BLAS_STACK_SIZE (Bvh/BVH.cs:559-567)
-        const int need = blas_stack_need(sc->BlasNodes + d.NodeOffset, d.NodeCount);
-        REQUIRE(d.RequiredStackSize >= need, "idkptUploadScene: BlasDesc.RequiredStackSize is smaller than the stack the BLAS needs");
-        maxStack = std::max(maxStack, need);
-    }
+    { const char* why = validate_blas_nodes(sc->BlasNodes, sc->BlasNodeCount, sc->BlasDescs, sc->BlasDescCount, sc->BlasTriangleCount, true, &maxStack); REQUIRE(why == nullptr, std::string("idkptUploadScene: ") + (why ? why : "")); }
     REQUIRE(ctx->st.BlasStackSize == 0 || ctx->st.BlasStackSize >= maxStack, "idkptUploadScene: the BlasStackSize set with idkptSetSettings is smaller than this scene's maximum RequiredStackSize");
     int tlasNeed = 1;
     if (sc->TlasNodes && sc->TlasNodeCount > 0) {
@@ -515,6 +582,7 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     }
     if ((rc = upload(ctx, ctx->levelNodes, allLevels.data(), allLevels.size() * 4))) return rc;
     if ((rc = regather_triverts(ctx, 0, (uint32_t)sc->BlasTriangleCount))) return rc;
+    if ((rc = rebuild_node_layout(ctx, sc->BlasNodes))) return rc;
     HIPC(hipStreamSynchronize(ctx->stream)); // host arrays are only borrowed for the duration of the call
     ctx->haveScene = true;
     std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
@@ -529,9 +597,9 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     { int rc = materialize_culled_rays(ctx); if (rc) return rc; }   // while the old sky is still resident
-    DevBuf* d[] = {&ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->vertices, &ctx->meshes,
+    DevBuf* d[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->vertices, &ctx->meshes,
                    &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->levelNodes};
-    DevBuf* f[] = {&src->nodes, &src->tris, &src->triVerts, &src->descs, &src->instances, &src->tlas, &src->parents, &src->leaves, &src->positions, &src->vertices, &src->meshes,
+    DevBuf* f[] = {&src->nodes, &src->tnodes, &src->nodeSlot, &src->tris, &src->triVerts, &src->descs, &src->instances, &src->tlas, &src->parents, &src->leaves, &src->positions, &src->vertices, &src->meshes,
                    &src->materials, &src->xforms, &src->lights, &src->sky, &src->levelNodes};
     for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++) {
         if (!f[i]->p || f[i]->bytes == 0) continue;
@@ -550,7 +618,7 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
     ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
     ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
-    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed;
+    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
     ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase;
     HIPC(hipStreamSynchronize(ctx->stream));           // td is a stack vector
     ctx->haveScene = true;
@@ -592,9 +660,82 @@ static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes,
     size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
     REQUIRE(b != nullptr, "idkptUpdateBuffer: unknown buffer");
     REQUIRE(offsetBytes + bytes <= cap, "idkptUpdateBuffer: range exceeds buffer");
+    if (which == IDKPT_BUF_BLAS_NODES || which == IDKPT_BUF_TLAS_NODES) {
+        // Patched tree nodes are validated like uploaded ones BEFORE they reach the device (a bad child index must not fault the GPU, a deeper tree must
+        // not overflow the traversal stack), on a host copy of the array with the patch applied; BLAS nodes: the derived order is rebuilt from that copy.
+        std::vector<char> h(cap);
+        HIPC(hipMemcpyAsync(h.data(), b->p, cap, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
+        memcpy(h.data() + offsetBytes, data, bytes);
+        if (which == IDKPT_BUF_BLAS_NODES) {
+            int maxStack = 1;
+            const char* why = validate_blas_nodes((const GpuBlasNode*)h.data(), ctx->nodeCount, ctx->hDescs.data(), (int)ctx->hDescs.size(), ctx->triCount, false, &maxStack);
+            REQUIRE(why == nullptr, std::string("idkptUpdateBuffer: ") + (why ? why : ""));
+            REQUIRE(ctx->st.BlasStackSize == 0 || ctx->st.BlasStackSize >= maxStack, "idkptUpdateBuffer: the patched BLAS needs a deeper traversal stack than the BlasStackSize set with idkptSetSettings");
+            HIPC(hipMemcpyAsync((char*)b->p + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+            ctx->sceneStack = maxStack;
+            int rc = rebuild_node_layout(ctx, (const GpuBlasNode*)h.data()); if (rc) return rc;
+        } else {
+            const char* why = nullptr;
+            const int need = tlas_validate((const GpuTlasNode*)h.data(), ctx->tlasCount, ctx->instanceCount, &why);
+            REQUIRE(need >= 0, std::string("idkptUpdateBuffer: ") + (why ? why : "bad TLAS"));
+            REQUIRE(need <= TLAS_STACK_SIZE, "idkptUpdateBuffer: TLAS deeper than TLAS_STACK_SIZE (32)");
+            HIPC(hipMemcpyAsync((char*)b->p + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+            ctx->tlasNeed = std::max(1, need);
+        }
+        HIPC(hipStreamSynchronize(ctx->stream));
+        return IDKPT_OK;
+    }
     HIPC(hipMemcpyAsync((char*)b->p + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (which == IDKPT_BUF_VERTEX_POSITIONS) { int rc = regather_triverts(ctx, 0, (uint32_t)ctx->triCount); if (rc) return rc; }
     HIPC(hipStreamSynchronize(ctx->stream));
+    return IDKPT_OK;
+}
+
+// idkptSetDeveloperOption: tuning / test hooks (DevOptions above).  Unknown names are an error, so that a typo cannot silently test nothing.
+static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
+{
+    if (!ctx || !name) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    DevOptions& o = ctx->opt;
+    const std::string n(name);
+    if (n == "force_generic") o.forceGeneric = value != 0;
+    else if (n == "no_tile_cull") o.noTileCull = value != 0;
+    else if (n == "no_lean_primary") o.noLeanPrimary = value != 0;
+    else if (n == "leaf_min") o.leafMin = std::max(0, value);
+    else if (n == "grab_unit_log2") o.grabUnitLog2 = value;
+    else if (n == "grab_fixed") o.grabFixed = value;
+    else if (n == "lds_pad") o.ldsPad = value;
+    else if (n == "trace_waves") o.traceWaves = std::max(0, value);
+    else if (n == "grid_hint") o.gridHint = std::max(0, value);
+    else if (n == "bvh_timing") o.bvhTiming = value != 0;
+    else if (n == "bvh_small") o.bvhSmall = value;
+    else if (n == "force_no_peer") { }                 // (multi-device contexts: idkpt_api.hpp; nothing to stage on one device)
+    else if (n == "trace_variant") {
+#ifdef IDKPT_DEVELOPER
+        o.traceVariant = value;
+#else
+        REQUIRE(value == 0 || value == 100, "idkptSetDeveloperOption: trace_variant needs the developer build of the library (libidkpt_dev.so)");
+#endif
+    }
+    else if (n == "trace_order") {
+        REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: trace_order is 0, 1 or 2");
+        o.traceOrder = value;
+        if (value && ctx->W > 0 && !ctx->ordIdx.p) {       // the permutation buffers of the current frame size
+            const size_t cap = (size_t)ctx->maxBatch * ctx->Npad;
+            for (int i = 0; i < 2; i++) { HIPC(ctx->ordKeys[i].ensure(cap * 4)); HIPC(ctx->ordVals[i].ensure(cap * 4)); } HIPC(ctx->ordIdx.ensure(cap * 4));
+        }
+    }
+    else if (n == "node_layout" || n == "treelet_depth") {
+        if (n == "node_layout") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: node_layout is 0, 1 or 2"); o.nodeLayout = value; }
+        else { REQUIRE(value >= 1 && value <= 16, "idkptSetDeveloperOption: treelet_depth is 1..16"); o.treeletDepth = value; }
+        if (ctx->haveScene) {                               // re-derive the resident scene
+            std::vector<GpuBlasNode> h((size_t)ctx->nodeCount);
+            HIPC(hipMemcpyAsync(h.data(), ctx->nodes.p, h.size() * 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
+            int rc = rebuild_node_layout(ctx, h.data()); if (rc) return rc;
+        }
+    }
+    else return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "idkptSetDeveloperOption: unknown option '" + n + "'");
     return IDKPT_OK;
 }
 
@@ -656,7 +797,7 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
     REQUIRE(n <= (1 << 27), "idkptBuildBlasCore: too many fragments");
     HIPC(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const bool timing = getenv("IDKPT_BVH_TIMING") != nullptr;   // developer knob: host-side phase times on stderr
+    const bool timing = ctx->opt.bvhTiming != 0;   // option "bvh_timing": host-side phase times on stderr
     auto tq = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; (void)hipStreamSynchronize(st); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[idkpt bvh] %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tq).count()); tq = t; };
     const size_t nodeCount = (size_t)std::max(2 * n, 4);
@@ -679,7 +820,7 @@ static int32_t dev_BuildBlasCore(dev_ctx* ctx, const float* fragBoxes, int32_t n
     HIPC(B.freshOf.ensure(nodeCount * 4)); HIPC(B.swapOf.ensure(nodeCount * 4)); HIPC(B.leftCountOf.ensure(nodeCount * 4)); HIPC(B.startOf.ensure(nodeCount * 4)); HIPC(B.countOf.ensure(nodeCount * 4));
     HIPC(B.leftTable.ensure((size_t)n)); HIPC(B.pcnt.ensure((size_t)3 * Cmax * 4)); HIPC(B.poff.ensure((size_t)3 * Cmax * 4));
     HIPC(B.smallList.ensure(nodeCount * 4)); HIPC(B.aux.ensure((size_t)n * 4));
-    int smallMax = 32; if (const char* e = getenv("IDKPT_BVH_SMALL")) smallMax = std::max(0, std::min(128, atoi(e)));   // subtrees of at most this many fragments are finished by one thread each
+    const int smallMax = std::max(0, std::min(128, ctx->opt.bvhSmall));   // subtrees of at most this many fragments are finished by one thread each (option "bvh_small")
     lap("alloc");
     HIPC(hipMemcpyAsync(B.fb.p, fragBoxes, (size_t)n * 32, hipMemcpyHostToDevice, st));
     lap("upload");
@@ -849,7 +990,7 @@ static int32_t dev_RefitBlas(dev_ctx* ctx, int32_t blasId)
         hipLaunchKernelGGL(k_refit_level, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->levelNodes.as<int32_t>() + ctx->levelBase[blasId] + off[l], cnt, (uint32_t)d.NodeOffset);
     }
     HIPC(hipGetLastError());
-    return IDKPT_OK;
+    return derive_nodes(ctx, blasId);          // the refitted boxes, in the order the traversal fetches them
 }
 
 static int32_t dev_UploadUnskinnedVertices(dev_ctx* ctx, const GpuUnskinnedVertex* verts, int32_t count)
@@ -895,7 +1036,7 @@ static int32_t dev_GetAccumulatedSamples(dev_ctx* ctx, uint32_t* out) { if (!ctx
 static DScene make_dscene(dev_ctx* ctx)
 {
     DScene s;
-    s.nodes = ctx->nodes.as<float4>(); s.tris = ctx->tris.as<uint4>(); s.triVerts = ctx->triVerts.as<float4>();
+    s.nodes = ctx->nodes.as<float4>(); s.tnodes = ctx->layoutActive ? ctx->tnodes.as<float4>() : ctx->nodes.as<float4>(); s.tris = ctx->tris.as<uint4>(); s.triVerts = ctx->triVerts.as<float4>();
     s.descs = ctx->descs.as<GpuBlasDesc>(); s.instances = ctx->instances.as<GpuBlasInstance>(); s.instanceCount = ctx->instanceCount;
     s.tlas = ctx->tlas.as<float4>(); s.tlasCount = ctx->tlasCount; s.vertices = ctx->vertices.as<uint4>();
     s.meshes = ctx->meshes.as<GpuMesh>(); s.materials = ctx->materials.as<GpuMaterial>(); s.xforms = ctx->xforms.as<float4>();
@@ -908,7 +1049,7 @@ static DScene make_dscene(dev_ctx* ctx)
 static float4* image_ptr(dev_ctx* ctx, int i, int slot) { return ctx->img[i].as<float4>() + (size_t)slot * ((size_t)ctx->W * ctx->rows); }
 
 // fast path = persistent while-while traversal (one BLAS, instance list or TLAS); only the debug traversal-cost view uses the general kernel
-static bool fast_path(dev_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->forceGeneric; }
+static bool fast_path(dev_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st.Gpu.DoDebugBVHTraversal && !ctx->opt.forceGeneric; }
 
 // One batch of B deferred samples: FirstHit -> [sort ->] NHit x (RayDepth-1) -> FinalDraw (PathTracer.cs:218-270), every
 // stage launched once for all B samples.  Sample k owns ray ids [k*Npad, k*Npad+N); alive queues are batch-wide but stay
@@ -950,7 +1091,7 @@ static int flush_batch(dev_ctx* ctx)
         f.cams = ctx->camTab.as<float>();
     }
     RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
-    HitBufs hits = {ctx->hit.as<float4>(), ctx->hitX.as<uint32_t>(), ctx->hitCost.as<float>()};
+    HitBufs hits = {ctx->hit.as<float4>(), ctx->hitCost.as<float>()};
     uint32_t* counts = ctx->counts.as<uint32_t>();
     uint32_t* bases = ctx->bases.as<uint32_t>();             // [MAX_DEPTH_SLOTS][MAX_BATCH+1]
     uint32_t* work = ctx->work.as<uint32_t>();
@@ -962,18 +1103,15 @@ static int flush_batch(dev_ctx* ctx)
     HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
 
     f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->tlasNeed));
-    f.grabUnitLog2 = 10; f.grabFixed = 0;
-    f.leafMin = B >= 4 ? 16 : 12;        // (measured: 16-20 with many samples in flight, 12 for a frame traced alone; tools/sweep_sched.py)
-    if (const char* e = getenv("IDKPT_LEAF_MIN")) f.leafMin = std::max(1, atoi(e));
-    if (const char* e = getenv("IDKPT_GRAB_UNIT_LOG2")) f.grabUnitLog2 = std::min(24, std::max(6, atoi(e)));
-    if (const char* e = getenv("IDKPT_GRAB_FIXED")) f.grabFixed = std::max(0, atoi(e));   // developer knobs (kernels_trace.hpp, work-list hand-out)
+    f.grabUnitLog2 = std::min(24, std::max(6, ctx->opt.grabUnitLog2)); f.grabFixed = std::max(0, ctx->opt.grabFixed);   // work-list hand-out (kernels_trace.hpp)
+    f.leafMin = ctx->opt.leafMin > 0 ? ctx->opt.leafMin : (B >= 4 ? 16 : 12);        // (measured: 16-20 with many samples in flight, 12 for a frame traced alone; tools/sweep_sched.py)
     size_t ldsBytes = (size_t)(f.stackCap + 2 + (f.useTlas ? f.tlasCap : 0)) * WAVE * 4;   // + the dummy and the spare row of k_trace2's stack (kernels_trace.hpp)
-    if (const char* e = getenv("IDKPT_LDS_PAD")) ldsBytes += (size_t)atoi(e);   // developer knob: caps the waves per CU (occupancy experiments)
+    ldsBytes += (size_t)std::max(0, ctx->opt.ldsPad);   // option "lds_pad": caps the waves per CU (occupancy experiments)
     if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }
     // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)
     int wavesPerCU = (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
     wavesPerCU = std::max(1, wavesPerCU);
-    if (const char* e = getenv("IDKPT_TRACE_WAVES")) wavesPerCU = std::max(1, atoi(e));   // developer knob: one-wave workgroups per CU in the persistent grid
+    if (ctx->opt.traceWaves > 0) wavesPerCU = ctx->opt.traceWaves;   // option "trace_waves": one-wave workgroups per CU in the persistent grid
     // (a launch never needs more waves than it can have rays: small frames would otherwise spend their time dispatching idle workgroups)
     const uint32_t traceGrid = std::min<uint32_t>((uint32_t)(ctx->numCUs * wavesPerCU), std::max<uint32_t>(1u, (uint32_t)(((size_t)B * N + 63) / 64)));
     const bool debug = f.g.DoDebugBVHTraversal != 0;
@@ -988,8 +1126,8 @@ static int flush_batch(dev_ctx* ctx)
     // ---- FirstHit
     uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (capacity uints), free until the first sort
     uint32_t* activeCount = counts + (MAX_DEPTH_SLOTS - 1);
-    TraceBufs tr = {ctx->trRec.as<float4>()};
-    TraceBufs trNone = {nullptr};
+    TraceBufs tr = {ctx->trRec.as<float4>(), nullptr, nullptr};
+    TraceBufs trNone = {nullptr, nullptr, nullptr};
     uint32_t* waveLocal = waveCounts;                     // per-wave exclusive offset inside its 256-wave scan block
     uint32_t* blockSums = ctx->blockSums.as<uint32_t>();
     const uint32_t scanBlocks = ((total + 63) / 64 + SCAN_WAVES_PER_BLOCK - 1) / SCAN_WAVES_PER_BLOCK;
@@ -1000,11 +1138,11 @@ static int flush_batch(dev_ctx* ctx)
             const uint32_t genWaves = tilesX * tilesY;
             const int cull = f.g.DoTraceLights ? 0 : 1;
             // single instance without lights: k_trace2 reads nothing but the trace-ready record, so the planes of a surviving primary ray need not exist before k_shade_first
-            static const bool noLean = getenv("IDKPT_NO_LEAN_PRIMARY") != nullptr;
+            const bool noLean = ctx->opt.noLeanPrimary != 0;
             const int lean = (cull && !f.useTlas && s.instanceCount == 1 && !noLean) ? 1 : 0;
-            if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits.hit + (size_t)(B - 1) * Npad, hits.xformId + (size_t)(B - 1) * Npad, N);
+            if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N);
             tileClass = nullptr;
-            if (cull && !ctx->noTileCull) {   // sample-independent pre-classification of the 8x8 tiles (conservative whole-tile miss test)
+            if (cull && !ctx->opt.noTileCull) {   // sample-independent pre-classification of the 8x8 tiles (conservative whole-tile miss test)
                 const uint32_t classSets = f.cams ? (uint32_t)B : 1u;       // one classification per camera
                 HIPC(ctx->tileClass.ensure((size_t)genWaves * classSets));
                 hipLaunchKernelGGL(k_classify_tiles, dim3((genWaves + 255) / 256, classSets), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
@@ -1014,7 +1152,7 @@ static int flush_batch(dev_ctx* ctx)
             TRACE_T0();
             launch_trace2<true>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
-            if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.as<float4>() + (size_t)(B - 1) * Npad, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
+            if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
             hipLaunchKernelGGL(k_shade_first, dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
             hipLaunchKernelGGL((k_scan_local<true>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)ctx->contFlag.as<uint8_t>(), contMask, waveLocal, blockSums);
         } else {
@@ -1023,7 +1161,7 @@ static int flush_batch(dev_ctx* ctx)
             if (ctx->counters) { if (debug) hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<true, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
             else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
             TRACE_T1();
-            if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); HIPC(hipMemcpyAsync(ctx->primHit.p, ctx->hit.p, (size_t)N * 16, hipMemcpyDeviceToDevice, st)); }
+            if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)0, N, ctx->primHit.as<float4>()); }
             hipLaunchKernelGGL((k_shade<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, trNone, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                                contMask, waveCounts, keysTmp);
             hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
@@ -1038,6 +1176,7 @@ static int flush_batch(dev_ctx* ctx)
     for (int j = 1; j < depth; j++) {
         uint32_t* q = ctx->queue[side].as<uint32_t>(); uint32_t* k = ctx->keys[side].as<uint32_t>();
         const uint32_t* cnt = counts + j;
+        const uint32_t* kq = k;                                           // keys of the queue entries, position by position
         // exact multi-GPU deep paths: the host tells every sample how many alive rays the contexts above this strip hold (idkpt.h)
         const uint32_t* gbase = nullptr;
         if (ctx->groupExchange) {   // member of a multi-device context: the group sums the counts of the members that own earlier rows, on the device (idkpt_api.hpp)
@@ -1069,14 +1208,35 @@ static int flush_batch(dev_ctx* ctx)
             }
             // odd pass count: the sorted data sits in (sortKeys, sortVals) -> copy the indices back (the reference copies W*H*4 B too, PathTracer.cs:296)
             if (va != q) HIPC(hipMemcpyAsync(q, va, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+            kq = ka;                                                      // the keys that line up with the sorted queue
+        }
+        // trace order (kernels_queue.hpp k_order_*): the bounce launch is handed out by the triangle its rays start on, all samples of the batch together
+        TraceBufs trj = tr;
+        if (fast && ctx->opt.traceOrder && (ctx->opt.traceOrder >= 2 || B >= 4) && ctx->ordIdx.p) {
+            int bits = 1; while (bits < 31 && (1u << bits) < (uint32_t)std::max(2, ctx->triCount)) bits++;
+            bits = std::min(bits, IDKPT_SORT_KEY_BITS);                  // (the key holds the low 21 bits of the triangle id, NHit/compute.glsl:81)
+            const int shiftLo = std::max(0, bits - 14), nPass = bits > 7 ? 2 : 1;
+            const uint32_t nTiles = (total + SORT_TILE - 1) / SORT_TILE;
+            uint32_t* digitTotals = ctx->sortHist.as<uint32_t>() + (size_t)SORT_RADIX * nTiles;
+            const uint32_t* kin = kq; const uint32_t* vin = nullptr;     // (first pass: value = the item's own index = its slot)
+            for (int pass = 0; pass < nPass; pass++) {
+                uint32_t* kout = ctx->ordKeys[pass].as<uint32_t>(); uint32_t* vout = ctx->ordVals[pass].as<uint32_t>();
+                const uint32_t shift = (uint32_t)(shiftLo + 7 * pass);
+                hipLaunchKernelGGL(k_sort_hist, dim3(nTiles), dim3(SORT_BLOCK), 0, st, kin, cnt, shift, ctx->sortHist.as<uint32_t>(), nTiles);
+                hipLaunchKernelGGL(k_sort_scan, dim3(SORT_RADIX), dim3(1024), 0, st, cnt, ctx->sortHist.as<uint32_t>(), nTiles, digitTotals);
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nTiles), dim3(SORT_BLOCK), 0, st, kin, vin, cnt, shift, (const uint32_t*)ctx->sortHist.as<uint32_t>(), nTiles, (const uint32_t*)digitTotals, kout, vout);
+                kin = kout; vin = vout;
+            }
+            hipLaunchKernelGGL(k_order_gather, dim3(gridTotal), dim3(256), 0, st, vin, (const uint32_t*)q, cnt, ctx->ordIdx.as<uint32_t>());
+            trj.order = vin; trj.orderIdx = ctx->ordIdx.as<uint32_t>();
         }
         TRACE_T0();
         // grid of the bounce launch: its queue length is only known on the device; the length the same bounce had in the previous batch (pinned copy,
         // possibly one batch stale) is a good predictor, and a grid that is too small or too large only costs time (the waves are persistent)
         uint32_t gridj = traceGrid;
-        static const int hintMul = getenv("IDKPT_GRID_HINT") ? atoi(getenv("IDKPT_GRID_HINT")) : 2;
+        const int hintMul = ctx->opt.gridHint;
         if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) { const uint32_t prev = ctx->hBases[(size_t)j * BS + B]; if (prev > 0) gridj = std::min<uint32_t>(traceGrid, std::max<uint32_t>(256u, (uint32_t)(((uint64_t)hintMul * prev + 63) / 64))); }
-        if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)q, cnt, work + j, counters);
+        if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, trj, hits, (const uint32_t*)q, cnt, work + j, counters);
         else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
@@ -1294,7 +1454,7 @@ static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
     uint64_t c[4] = {0, 0, 0, 0};
     HIPC(hipMemcpyAsync(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
-    if (ctx->traceVariant == 107 || ctx->traceVariant == 113) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13]); }
+    if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13]); }
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
     *out = s;
     return IDKPT_OK;

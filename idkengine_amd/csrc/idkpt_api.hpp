@@ -340,6 +340,7 @@ int32_t idkptUploadScene(idkpt_ctx* c, const idkpt_scene_desc* scene)
 #define REPLICATE(name, ...) do { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; ONE(dev_##name(m, ##__VA_ARGS__)); GFLUSH(); ALL(dev_##name(m, ##__VA_ARGS__)); return IDKPT_OK; } while (0)
 int32_t idkptUpdateBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, const void* data) { REPLICATE(UpdateBuffer, which, offsetBytes, bytes, data); }
 int32_t idkptSetLightCount(idkpt_ctx* c, int32_t count) { REPLICATE(SetLightCount, count); }
+int32_t idkptSetDeveloperOption(idkpt_ctx* c, const char* name, int32_t value) { REPLICATE(SetOption, name, value); }
 int32_t idkptBuildTlas(idkpt_ctx* c, const GpuTlasNode* nodes, int32_t nodeCount) { REPLICATE(BuildTlas, nodes, nodeCount); }
 int32_t idkptBuildTlasOnDevice(idkpt_ctx* c, int32_t searchRadius) { REPLICATE(BuildTlasOnDevice, searchRadius); }      // every member rebuilds its own copy (0.1 ms; cheaper than shipping it)
 int32_t idkptRefitBlas(idkpt_ctx* c, int32_t blasId) { REPLICATE(RefitBlas, blasId); }

@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void k_regen_culled(DScene s, Frame f, RayBufs
 }
 
 // test support (idkptEnablePrimaryHitCapture): miss records for the pixels the pre-cull removes before the traversal
-__global__ void k_fill_miss(float4* hit, uint32_t* xform, uint32_t n)
+__global__ void k_fill_miss(HitBufs hits, size_t first, uint32_t n)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { hit[i] = make_float4(PT_FLOAT_MAX, 0.0f, 0.0f, __uint_as_float(~0u)); xform[i] = 0; }
+    if (i < n) store_hit(hits, first + i, PT_FLOAT_MAX, 0.0f, 0.0f, ~0u, 0u);
 }
 
 // derived layout: positions of each BLAS triangle's vertices, in leaf order (48 B/triangle, one contiguous fetch in the leaf loop)
@@ -84,4 +84,28 @@ __global__ void k_gather_triverts(const uint4* tris, const float* positions, flo
     const float* a = positions + 3 * (size_t)t.x; const float* b = positions + 3 * (size_t)t.y; const float* c = positions + 3 * (size_t)t.z;
     float4* o = triVerts + 3 * (size_t)(first + i);
     o[0] = make_float4(a[0], a[1], a[2], 0.0f); o[1] = make_float4(b[0], b[1], b[2], 0.0f); o[2] = make_float4(c[0], c[1], c[2], 0.0f);
+}
+
+// test support (idkptEnablePrimaryHitCapture): the first half of `n` consecutive 32-B hit records -> a dense float4 array
+__global__ void k_capture_primary(HitBufs hits, size_t first, uint32_t n, float4* out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hits.hit[2 * (first + i)];
+}
+
+// derived layout: the node pairs of one BLAS in the order k_trace2 fetches them (node_layout.hpp).  Pair k of the reference array (nodes 2k, 2k+1,
+// BLAS-local) goes to slot[k]; an internal node's child index c becomes 2 * slot[c / 2]; boxes, leaf ranges and empty nodes are copied as they are.
+// Re-run whenever the reference array changes (upload, idkptRefitBlas, idkptUpdateBuffer): the permutation depends on the topology only.
+__global__ void k_derive_nodes(const float4* nodes, const uint32_t* slot, float4* tnodes, uint32_t nodeOffset, uint32_t pairCount)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= pairCount) return;
+    const float4* src = nodes + 2 * ((size_t)nodeOffset + 2 * (size_t)k);
+    const uint32_t* sl = slot + nodeOffset / 2;
+    float4 a0 = src[0], a1 = src[1], b0 = src[2], b1 = src[3];
+    const uint32_t ac = __float_as_uint(a0.w), an = __float_as_uint(a1.w), bc = __float_as_uint(b0.w), bn = __float_as_uint(b1.w);
+    if (an == 0u && ac != 0u && !(k == 0u)) a0.w = __uint_as_float(2u * sl[ac >> 1]);          // (node 0 of a BLAS is unused)
+    if (bn == 0u && bc != 0u) b0.w = __uint_as_float(2u * sl[bc >> 1]);
+    float4* dst = tnodes + 2 * ((size_t)nodeOffset + 2 * (size_t)sl[k]);
+    dst[0] = a0; dst[1] = a1; dst[2] = b0; dst[3] = b1;
 }

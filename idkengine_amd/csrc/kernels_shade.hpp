@@ -37,8 +37,7 @@ __global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs 
     const uint32_t rid = activeList[item];
     const uint32_t smp = rid / f.Npad, pix = rid - smp * f.Npad;
     const uint32_t acc = sample_index(f, smp);
-    float4 h = hits.hit[rid];
-    HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[rid];
+    const HitRec hit = load_hit(hits, rid);
     RayState r; uint32_t rng, key = 0;
     if (lean) {   // the state FirstHit:44-77 starts a primary ray with, recomputed (same arithmetic, same bits) instead of 52 B written and read back
         f2 pd; gen_primary(f, smp, pix, acc, r.origin, pd, rng);
@@ -82,8 +81,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
     if (inRange) {
         const uint32_t acc = sample_index(f, smp);
         float4 a = rays.o_ior[idx], b = rays.thr_px[idx], c = rays.rad_py[idx];
-        float4 h = hits.hit[slot];
-        HitRec hit; hit.T = h.x; hit.bx = h.y; hit.by = h.z; hit.tri = __float_as_uint(h.w); hit.xform = hits.xformId[slot];
+        const HitRec hit = load_hit(hits, slot);
         if (FIRST && f.g.DoDebugBVHTraversal) {
             rays.o_ior[idx] = make_float4(a.x, a.y, a.z, hits.cost[slot]); // FirstHit:108-112
         } else {

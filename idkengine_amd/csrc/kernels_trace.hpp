@@ -24,8 +24,7 @@ __global__ __launch_bounds__(WAVE) void k_trace_primary(DScene s, Frame f, RayBu
             f3 rd = DecodeUnitVec(pd.x, pd.y);
             HitRec hit; float cost;
             TraceRay<COUNT, COST>(s, f, origin, rd, hit, cost, stk, WAVE, nPairs, nTris);
-            hits.hit[pix] = make_float4(hit.T, hit.bx, hit.by, __uint_as_float(hit.tri));
-            hits.xformId[pix] = hit.xform;
+            store_hit(hits, pix, hit.T, hit.bx, hit.by, hit.tri, hit.xform);
             if (COST) hits.cost[pix] = cost;
         }
     }
@@ -52,8 +51,7 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
             f3 rd = DecodeUnitVec(pdx, pdy);
             HitRec hit; float cost;
             TraceRay<COUNT, false>(s, f, mk3(o.x, o.y, o.z), rd, hit, cost, stk, WAVE, nPairs, nTris);
-            hits.hit[slot] = make_float4(hit.T, hit.bx, hit.by, __uint_as_float(hit.tri));
-            hits.xformId[slot] = hit.xform;
+            store_hit(hits, slot, hit.T, hit.bx, hit.by, hit.tri, hit.xform);
         }
     }
     if (COUNT) flush_counters(counters, nPairs, nTris);
@@ -284,7 +282,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     const GpuBlasInstance inst = s.instances[0];
     const int nodeOffset = s.descs[inst.BlasId].NodeOffset;
     const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
-    const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
+    const float4* nodes = s.tnodes + 2 * (size_t)nodeOffset;      // the derived order (node_layout.hpp): same pairs, same child relations, other positions
 
     bool active = false, leafPending = false, workLeft = true;
     // work-list state of this wave (wave-uniform): the slice it grabs from, how many slices it has seen handed out, and the positions
@@ -344,8 +342,10 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             const uint32_t item = valid ? ((((q >> unitLog2) * GRAB_SLICES + sl) << unitLog2) | (q & ((1u << unitLog2) - 1u))) : N;
             if (slicesDone >= GRAB_SLICES && chunkNext >= chunkEnd) workLeft = false;
             if (!active && item < N) {
-                const uint32_t idx = list[item];
-                slot = PRIMARY ? idx : item;
+                // (bounce launches may be handed out in trace order, kernels_queue.hpp: position -> slot and ray id; the slot a hit is stored at does not change)
+                const bool ordered = !PRIMARY && tr.order != nullptr;
+                const uint32_t idx = ordered ? tr.orderIdx[item] : list[item];
+                slot = PRIMARY ? idx : (ordered ? tr.order[item] : item);
                 hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f;
                 if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203 (world-space ray)
                     float4 o = rays.o_ior[idx];
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             if (PROF) { pn[2]++; pn[3] += (unsigned long long)__builtin_popcountll(stepMask); }
             if (canStep) {
                 if (COUNT) nPairs++;
-                const float4* p = MULTI ? s.nodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top;
+                const float4* p = MULTI ? s.tnodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top;
                 if (DBG == 1) { uint32_t x0 = lane, x1 = lane, x2 = lane, x3 = lane;       // (bottleneck probe: 16 extra VALU instructions per step, four independent chains)
                     for (int k = 0; k < 4; k++) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)); }
                 if (DBG == 2) { uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;                   // (16 extra SALU instructions per step)
@@ -479,8 +479,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         PROF_MARK(2);
         // ---- retire finished rays (MULTI: only after the last instance)
         if (active && top == 0u && (!MULTI || (TLAS ? !moreInst : instIdx >= (uint32_t)s.instanceCount))) {
-            hits.hit[slot] = make_float4(hitT, hbx, hby, __uint_as_float(hitTri));
-            hits.xformId[slot] = hitXform;
+            store_hit(hits, slot, hitT, hbx, hby, hitTri, hitXform);
             active = false;
         }
     }

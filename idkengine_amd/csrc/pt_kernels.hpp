@@ -16,6 +16,7 @@ struct TexDesc { const float4* data; int w, h; };
 
 struct DScene {
     const float4* nodes;        // 2 x float4 per GpuBlasNode: {Min.xyz, TriStartOrChild}, {Max.xyz, TriCount}
+    const float4* tnodes;       // derived: the same node pairs in the order k_trace2 fetches them (node_layout.hpp; child indices rewritten, pairs 0 and 1 of every BLAS in place); == nodes when no derived order is in use
     const uint4* tris;          // GpuBlasTriangle
     const float4* triVerts;     // derived: 3 x float4 per BLAS triangle (leaf order): positions of X,Y,Z (w unused)
     const GpuBlasDesc* descs;
@@ -57,15 +58,29 @@ struct RayBufs {                // SoA planes of the reference's GpuWavefrontRay
 };
 struct TraceBufs {              // derived, per ray id: the ray ready for the traversal kernel, one 64-B record (the size and alignment of a node pair, so
     float4* rec;                // that a refill touches one cache line per ray instead of three): [0] RayTransform(origin) (Ray.glsl:7-12), .w = tMin of
-};                              // the root-box test (+inf = miss), so that the traversal kernel's root test is one compare; [1] RayTransform(direction), not renormalised; [2] 1 / [1] (IntersectionRoutines.glsl:29); [3] unused.
+                                // the root-box test (+inf = miss), so that the traversal kernel's root test is one compare; [1] RayTransform(direction), not renormalised; [2] 1 / [1] (IntersectionRoutines.glsl:29); [3] unused.
                                 // Several instances / TLAS: [0],[1] hold the WORLD-space ray, [2] the world 1/dir (TLAS only).
-struct HitBufs {                // indexed by queue slot
-    float4* hit;                // T, BaryXY.x, BaryXY.y, TriangleId (bits)
-    uint32_t* xformId;          // MeshTransformId or light index
+    // trace order of a bounce launch (null: queue order): the launch hands out positions of `order`; order[i] = queue slot, orderIdx[i] = the ray id in that
+    // slot.  The slots — which seed NHit's RNG (NHit/compute.glsl:54) — stay what they are; only WHEN a slot is traced changes (kernels_queue.hpp, k_order_*).
+    const uint32_t* order; const uint32_t* orderIdx;
+};
+struct HitBufs {                // indexed by queue slot: one 32-B record per slot (one aligned store sector instead of a 16-B and a 4-B partial write)
+    float4* hit;                // [2*slot] = T, BaryXY.x, BaryXY.y, TriangleId (bits); [2*slot+1].x = MeshTransformId or light index (bits)
     float* cost;                // debugCost (only written in DoDebugBVHTraversal mode)
 };
 
 struct HitRec { float T, bx, by; uint32_t tri, xform; };
+DEV void store_hit(const HitBufs& h, size_t slot, float T, float bx, float by, uint32_t tri, uint32_t xform)
+{
+    h.hit[2 * slot] = make_float4(T, bx, by, __uint_as_float(tri));
+    h.hit[2 * slot + 1] = make_float4(__uint_as_float(xform), 0.0f, 0.0f, 0.0f);
+}
+DEV HitRec load_hit(const HitBufs& h, size_t slot)
+{
+    const float4 a = h.hit[2 * slot]; const float x = h.hit[2 * slot + 1].x;
+    HitRec r; r.T = a.x; r.bx = a.y; r.by = a.z; r.tri = __float_as_uint(a.w); r.xform = __float_as_uint(x);
+    return r;
+}
 
 #define TLAS_STACK_SIZE 32
 

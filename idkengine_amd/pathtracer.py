@@ -7,10 +7,16 @@ entry points through LibraryImport is shown in INTEGRATION.md.
 No CPU fallback: construction raises when libidkpt.so or a GPU is missing.
 """
 import ctypes as C
+import os
 import numpy as np
 from . import _lib
 from . import gputypes as T
 from ._lib import IdkPtError
+
+
+# idkptSetDeveloperOption names; IDKPT_<NAME> in the environment is forwarded when a PathTracer is created (test / tuning hooks only)
+_OPTION_NAMES = ("force_generic", "no_tile_cull", "no_lean_primary", "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves", "grid_hint",
+                 "node_layout", "treelet_depth", "trace_order", "bvh_timing", "bvh_small", "force_no_peer", "trace_variant")
 
 
 class PathTracer:
@@ -32,6 +38,11 @@ class PathTracer:
         if rc != 0:
             raise IdkPtError(f"idkptCreate failed with status {rc}")
         self._ctx = ctx
+        # tuning / test options: the library reads no environment; this host mirror forwards IDKPT_<NAME> (tests, tools) to idkptSetDeveloperOption
+        for name in _OPTION_NAMES:
+            v = os.environ.get("IDKPT_" + name.upper())
+            if v is not None and v != "":
+                self.set_option(name, int(v))
         self._settings = settings if settings is not None else T.Settings.default()
         self._cached_ray_depth = self._settings.RayDepth
         self._scene = None
@@ -298,6 +309,10 @@ class PathTracer:
 
     def flush(self):
         self._check(self._L.idkptFlush(self._ctx))
+
+    def set_option(self, name, value):
+        """idkptSetDeveloperOption: tuning / test hooks (include/idkpt.h); results are bit-identical under all of them."""
+        self._check(self._L.idkptSetDeveloperOption(self._ctx, name.encode(), int(value)))
 
     def set_stream(self, hip_stream_handle):
         self._check(self._L.idkptSetStream(self._ctx, C.c_void_p(hip_stream_handle)))

@@ -285,6 +285,16 @@ IDKPT_API int32_t idkptEnableCounters(idkpt_ctx* ctx, int32_t enable);
 /* enable=1: record HIP events (on the context's stream) around each idkptRender and around every traversal-kernel launch */
 IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
 
+/* Tuning / test hooks — not part of the reference's interface (PathTracer.cs has no counterpart) and never needed for correct results: every option
+ * leaves every output bit-identical (tests/test_gpu_worklist.py, tests/test_gpu_layout.py).  The library itself reads no environment variables; the
+ * Python host mirror forwards IDKPT_<NAME> for the tests and tools.  Names (value): "force_generic" (0/1: thread-per-ray kernels instead of the
+ * persistent traversal kernel), "no_tile_cull", "no_lean_primary" (0/1), "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves",
+ * "grid_hint" (scheduling of the traversal kernel), "node_layout" (0 reference order, 1 line couples depth-first [default], 2 line couples in
+ * treelets of "treelet_depth" levels), "trace_order" (0 queue order, 1 spatial order for batches of >= 4 samples [default], 2 always),
+ * "bvh_timing", "bvh_small" (idkptBuildBlasCore), "force_no_peer" (0/1, multi-device contexts: stage every device-to-device copy through pinned
+ * host memory, as on a node whose GPUs refuse peer access), "trace_variant" (developer build of the library only).  Unknown names fail. */
+IDKPT_API int32_t idkptSetDeveloperOption(idkpt_ctx* ctx, const char* name, int32_t value);
+
 /* ---- interop (device pointers as void*, for RCCL gather of row shards by the host process) -- */
 /* Launches what is still deferred and returns the image of the current slot (ordered on the context's stream, idkptGetStream).  Multi-device
  * context: the rows of all devices are gathered into a full frame on the first device (peer copies; valid until the next call). */

@@ -1,0 +1,158 @@
+"""Where a node pair lies in memory (derived node order, csrc/node_layout.hpp + k_derive_nodes) and when a queue slot is traced (trace order of a
+bounce launch, kernels_queue.hpp k_order_*) are free choices of the implementation: neither may change one bit of the output.  Every combination
+must give the oracle's frame — image, primary hits, every ray record, the alive queue, and the visit counters (a permuted array that is the
+same tree visits the same number of pairs and triangles) — on one instance, on an instance list, under a TLAS, batched with and without the
+reference's own ray sorting, and after the tree changed on the device (refit) or was patched by the host."""
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden")); sys.path.insert(0, HERE)
+import configs  # noqa: E402
+from idkengine_amd import scenes as S  # noqa: E402
+from idkengine_amd import gputypes as T  # noqa: E402
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+COMBOS = [(0, 0), (1, 0), (2, 0), (0, 2), (1, 2), (2, 2), (1, 1)]     # (node_layout, trace_order)
+
+
+def _env(layout, order, depth=None):
+    e = {"IDKPT_NODE_LAYOUT": str(layout), "IDKPT_TRACE_ORDER": str(order)}
+    if depth is not None:
+        e["IDKPT_TREELET_DEPTH"] = str(depth)
+    return e
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("layout,order", COMBOS)
+def test_single_frame_is_bit_exact_under_every_layout_and_order(layout, order, oracle_mod, native_builder):
+    cases = [(S.cornell_scene(native_builder, variant="mixed"), S.cornell_camera(97, 61), 97, 61, 4),
+             (S.soup_scene(20000, native_builder, seed=5), S.Camera(320, 200, position=(0.0, 0.0, 0.0), view_dir=(0.2, 0.1, -1.0)), 320, 200, 4)]
+    for sc, cam, w, h, depth in cases:
+        o = oracle_render(oracle_mod, sc, cam, w, h, RayDepth=depth)
+        pt = _with_env(_env(layout, order, 2 + layout), lambda: gpu_render(sc, cam, w, h, RayDepth=depth))
+        assert_equal(pt, o)
+        pt.Dispose(); o.close()
+
+
+@pytest.mark.parametrize("sort", [0, 1])
+@pytest.mark.parametrize("layout,order", [(1, 1), (2, 2), (0, 1)])
+def test_batched_samples_in_trace_order(layout, order, sort, oracle_mod, native_builder):
+    """Five samples in one batch (trace_order 1 = "batches of >= 4 samples"): the permutation mixes the samples of the batch, the slots and with them
+    every sample's RNG streams must stay those of five stand-alone frames; with DoRaySorting the permutation is built from the SORTED queue's keys."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.soup_scene(20000, native_builder, seed=9); w, h = 250, 130
+    cam = S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(-0.3, 0.2, -1.0))
+    ov = dict(RayDepth=4, DoRaySorting=sort)
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=5, **ov)
+
+    def run():
+        pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov))
+        pt.UploadScene(sc); pt.SetCamera(cam); pt.enable_counters(True); pt.enable_primary_hit_capture(True); pt.set_max_batch(5)
+        for _ in range(5):
+            pt.Compute()
+        return pt
+    pt = _with_env(_env(layout, order), run)
+    assert_equal(pt, o)
+    pt.Dispose(); o.close()
+
+
+@pytest.mark.parametrize("tlas", [0, 1])
+def test_instances_and_tlas_read_the_derived_order(tlas, oracle_mod, native_builder):
+    sc = S.soup_scene_multi(30000, native_builder, parts=3, seed=4); w, h = 240, 135
+    cam = S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(0.1, -0.2, -1.0))
+    ov = dict(RayDepth=3, UseTlas=tlas)
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=4, **ov)
+    from idkengine_amd.pathtracer import PathTracer
+
+    def run():
+        pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov))
+        pt.UploadScene(sc); pt.SetCamera(cam); pt.enable_counters(True); pt.enable_primary_hit_capture(True); pt.set_max_batch(4)
+        for _ in range(4):
+            pt.Compute()
+        return pt
+    pt = _with_env(_env(2, 2, 3), run)
+    assert_equal(pt, o)
+    pt.Dispose(); o.close()
+
+
+def test_switching_layout_and_order_on_a_resident_scene(native_builder):
+    """idkptSetDeveloperOption re-derives the resident scene; accumulating across the switches must equal an accumulation without them."""
+    sc = S.soup_scene(20000, native_builder, seed=12); w, h = 200, 120
+    cam = S.Camera(w, h, position=(0.0, 0.0, 0.0))
+    ref = gpu_render(sc, cam, w, h, frames=6, RayDepth=3)
+    from idkengine_amd.pathtracer import PathTracer
+    pt = PathTracer(w, h); pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = 3; pt.set_max_batch(2)
+    for i, (layout, order) in enumerate([(1, 2), (0, 0), (2, 2), (2, 0), (0, 2), (1, 1)]):
+        pt.set_option("node_layout", layout); pt.set_option("trace_order", order); pt.set_option("treelet_depth", 2 + i)
+        pt.Compute()
+    assert (bits(pt.Result) == bits(ref.Result)).all() and pt.rays().tobytes() == ref.rays().tobytes()
+    with pytest.raises(Exception):
+        pt.set_option("no_such_option", 1)
+    pt.Dispose(); ref.Dispose()
+
+
+def test_refit_rebuilds_the_derived_order(oracle_mod, native_builder):
+    """idkptRefitBlas writes the reference array; the traversal reads the derived one: it must follow (layout 2, the most scrambled one)."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.soup_scene(6000, native_builder, seed=31, refittable=True); w, h = 160, 100
+    cam = S.Camera(w, h, position=(0.0, 0.0, 0.0))
+
+    def run():
+        pt = PathTracer(w, h); pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = 3; pt.enable_counters(True); pt.enable_primary_hit_capture(True)
+        return pt
+    pt = _with_env(_env(2, 2, 3), run)
+    rng = np.random.default_rng(5)
+    pos = sc.vertex_positions.reshape(-1, 3) + rng.uniform(-0.05, 0.05, (len(sc.vertex_positions.reshape(-1, 3)), 3)).astype(np.float32)
+    pos = np.ascontiguousarray(pos, np.float32)
+    pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, pos)
+    pt.RefitBlas(0)
+    pt.Compute()
+    import copy
+    sc2 = copy.copy(sc)
+    sc2.vertex_positions = pos.reshape(sc.vertex_positions.shape)
+    sc2.blas_nodes = native_builder.refit(sc.blas_nodes, sc2.vertex_positions, sc.blas_triangles)
+    assert pt.DownloadBuffer(T.IDKPT_BUF_BLAS_NODES, T.GpuBlasNode, len(sc.blas_nodes)).tobytes() == sc2.blas_nodes.tobytes()
+    o = oracle_render(oracle_mod, sc2, cam, w, h, RayDepth=3)
+    assert_equal(pt, o)
+    pt.Dispose(); o.close()
+
+
+def test_patched_blas_nodes_are_validated_and_rederived(oracle_mod, native_builder):
+    """idkptUpdateBuffer(IDKPT_BUF_BLAS_NODES): a patch is validated like an upload before it reaches the device (a patched tree must not
+    fault the GPU or overflow the stack), and the derived order is rebuilt from the patched array."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd._lib import IdkPtError
+    a = S.soup_scene(5000, native_builder, seed=41); b = S.soup_scene(5000, native_builder, seed=41, edge=0.15)
+    w, h = 128, 96
+    cam = S.Camera(w, h, position=(0.0, 0.0, 0.0))
+    pt = PathTracer(w, h); pt.UploadScene(a); pt.SetCamera(cam); pt.RayDepth = 3; pt.enable_counters(True); pt.enable_primary_hit_capture(True)
+    pt.Compute()
+    bad = a.blas_nodes[2:4].copy()
+    k = 0 if bad["TriCount"][0] == 0 else 1
+    bad["TriStartOrChild"][k] = 2                                    # a child that lies in front of its parent: a cycle
+    if bad["TriCount"][k] == 0:
+        with pytest.raises(IdkPtError):
+            pt.UpdateBuffer(T.IDKPT_BUF_BLAS_NODES, bad, offset_bytes=2 * 32)
+    # the rejected patch changed nothing; the same bytes patched back in keep the frame
+    pt.UpdateBuffer(T.IDKPT_BUF_BLAS_NODES, np.ascontiguousarray(b.blas_nodes[100:300]), offset_bytes=100 * 32)
+    pt.ResetAccumulation(); pt.reset_stats(); pt.Compute()
+    o = oracle_render(oracle_mod, b, cam, w, h, RayDepth=3)
+    assert_equal(pt, o)
+    pt.Dispose(); o.close()
