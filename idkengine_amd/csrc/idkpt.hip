@@ -49,9 +49,9 @@ struct DevOptions {
     int ldsPad = 0;              // bytes of LDS added per workgroup of k_trace2 (caps the resident waves)
     int traceWaves = 0;          // one-wave workgroups per CU in the persistent grid (0: what LDS allows, at most 32)
     int gridHint = 2;            // bounce launches: grid = gridHint x the queue length the same bounce had in the previous batch (0: full grid)
-    int nodeLayout = 1;          // derived node order (node_layout.hpp): 0 = reference order, 1 = line couples depth-first, 2 = line couples in treelets
+    int nodeLayout = 0;          // derived node order (node_layout.hpp): 0 = reference order (default: the derived orders raise the L2 hit rate, not the speed — profiles/r03_layout_order_pmc.json), 1 = line couples depth-first, 2 = line couples in treelets
     int treeletDepth = 3;
-    int traceOrder = 1;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order, 1 = batches of >= 4 samples, 2 = always
+    int traceOrder = 0;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order (default: L2 hit rate 0.62 -> 0.88, launch -7 %, the permutation costs more), 1 = batches of >= 4 samples, 2 = always
     int traceVariant = 0;        // IDKPT_DEVELOPER builds only: instrumented / probe instantiations of k_trace2
     int bvhTiming = 0, bvhSmall = 32;   // idkptBuildBlasCore: phase times on stderr; subtrees of at most this many fragments are finished by one thread
 };

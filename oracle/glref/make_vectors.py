@@ -211,6 +211,38 @@ def extended():
     print(json.dumps(rep))
 
 
+def summary_only(names):
+    """Recomputes tests/golden/glref/summary.json from the COMMITTED fixtures and today's oracle (no llvmpipe needed): what the gate of
+    tests/glref_check.py measures — pure relative errors, flips, pixels beyond tolerance — per case and stage."""
+    from oracle import oracle as O
+    from idkengine_amd import gputypes as T
+    import configs
+    import glref_cases
+    import glref_check
+    B = O.OracleBuilder()
+    summary = {}
+    for name in names or list(glref_cases.GLREF_CASES):
+        fac, camf, w, h, ov = glref_cases.GLREF_CASES[name]
+        sc = fac(B); cam = camf(w, h)
+        st = configs.apply_settings(T.Settings.default(), ov)
+        fx = np.load(os.path.join(OUT, name + ".npz"))
+
+        def oracle_state(d):
+            o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov)
+            o.settings.RayDepth = d; o.settings.SamplesPerPixel = 1
+            o.render()
+            r, q = o.rays(), o.alive_queue(); o.close()
+            return r, q
+        o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.render()
+        rep = glref_check.check_case(fx, oracle_state, dict(image=o.image(0), counts=o.stats()["alive_counts"], albedo=o.image(1) if st.OutputAOVs else None,
+                                                           normal=o.image(2) if st.OutputAOVs else None), strict=False, name=name)
+        o.close()
+        rep["gate"] = {"rel_tol": glref_check.REL_TOL, "abs_floor": glref_check.ABS_FLOOR, "max_outlier_frac": glref_check.MAX_OUTLIER_FRAC, "allow": glref_check.FREE_RUN_ALLOW.get(name)}
+        summary[name] = rep
+        print(name, json.dumps(rep), flush=True)
+    json.dump(summary, open(os.path.join(OUT, "summary.json"), "w"), indent=1, sort_keys=True)
+
+
 def main(names, check=False):
     from oracle.glref import glref as G
     from oracle import oracle as O
@@ -291,6 +323,8 @@ if __name__ == "__main__":
         defect_d1()
     elif "--extended" in args:
         extended()
+    elif "--summary" in args:
+        summary_only([a for a in args if not a.startswith("--")])
     elif "--queries" in args:
         os.makedirs(OUT, exist_ok=True)
         sys.exit(1 if make_query_and_shadow_vectors(check="--check" in args) else 0)

@@ -1,16 +1,48 @@
 """Checker shared by tests/test_glref.py (oracle vs the reference's llvmpipe outputs), tests/test_gpu_glref.py (HIP path vs
 the same) and oracle/glref/make_vectors.py (summary).  The fixtures under tests/golden/glref/ are outputs of the
 REFERENCE's own shaders; llvmpipe's float arithmetic is IEEE for + - * but its division, inverse square root and
-transcendental functions are approximations of its own, so agreement is demanded to the tolerance north_star states
-(1e-4 relative) — bit equality is reported, not required — and the handful of rays whose discrete decision (hit/miss at
-an edge, Russian roulette, BSDF lobe) flips under a last-place difference are counted and bounded."""
+transcendental functions are approximations of its own, so agreement is demanded to the tolerance north_star states —
+"within 1e-4 relative per-pixel" — as a PURE relative error, with no outliers; bit equality is reported, not required.
+
+The gate, stated once:
+  * radiance, throughput, previous IOR and every pixel of the frames: |candidate - reference| / |reference| <= REL_TOL per component; only where
+    |reference| < ABS_FLOOR (1e-6: black, or a value that is itself rounding noise) the denominator is ABS_FLOOR instead (an exact 0 has no
+    relative error);
+  * positions (Origin): relative to the vector, max|diff| / max|component| — one coordinate of a hit point can be arbitrarily close to zero
+    while its error is set by the magnitudes that cancelled;
+  * PackedDirectionX/Y: components of an octahedron-encoded UNIT vector: absolute difference <= REL_TOL (relative to the unit length);
+  * discrete decisions (alive queue after every stage): identical, no exception;
+  * free-running frames: alive counts identical and every pixel within tolerance — except the cases named in FREE_RUN_ALLOW, each with its
+    reason and its bound."""
 import hashlib
-import math
 import numpy as np
 
-REL_TOL = 1e-4            # BASELINE.json north_star tolerance
-MAX_OUTLIER_FRAC = 0.003  # rays per stage allowed beyond REL_TOL or with a flipped discrete decision (observed: 0 - 0.1 %)
+REL_TOL = 1e-4            # BASELINE.json north_star tolerance ("within 1e-4 relative per-pixel")
+ABS_FLOOR = 1e-6          # denominators below this are replaced by it (a reference value of exactly 0 has no relative error)
+MAX_OUTLIER_FRAC = 0.0    # no ray and no pixel beyond the tolerance, no flipped decision
+# Free-running frames that may differ, and why.  lucy_d5: llvmpipe rounds one primary ray's FirstHit output differently in the last place,
+# that ray's Russian-roulette decision at bounce 2 flips (stage vectors, which start every bounce from identical inputs, show 0 flips), and
+# because NHit seeds its RNG from the queue slot (NHit/compute.glsl:54) every later ray of that bounce draws another stream: 24 of 12 288 pixels.
+# Observed: alive counts 4261 / 331 / 96 / 25 here against the reference's 4261 / 330 / 93 / 25, 23 pixels beyond tolerance.
+FREE_RUN_ALLOW = {"lucy_d5": {"max_count_diff": 4, "max_pixels_beyond": 32,
+                              "reason": "one llvmpipe last-place rounding flips one ray at bounce 2; slot-seeded RNG streams shift behind it"}}
 FIELDS = ("Origin", "Throughput", "Radiance", "PackedDirectionX", "PackedDirectionY", "PreviousIOROrTraverseCost")
+
+
+def rel_err(x, y, field=None):
+    """Error of candidate x against reference y (float64 arrays of shape (n, k)) under the gate above, per record."""
+    d = np.abs(x - y)
+    if field == "Origin":
+        return d.max(axis=1) / np.maximum(np.abs(y).max(axis=1), ABS_FLOOR)
+    if field in ("PackedDirectionX", "PackedDirectionY"):
+        return d.max(axis=1)
+    return (d / np.maximum(np.abs(y), ABS_FLOOR)).max(axis=1)
+
+
+def pixel_rel_err(img, ref):
+    """Per-pixel pure relative error of an RGBA32F image against the reference's (largest component)."""
+    img = np.asarray(img, np.float64); ref = np.asarray(ref, np.float64)
+    return (np.abs(img - ref) / np.maximum(np.abs(ref), ABS_FLOOR)).max(axis=-1)
 
 
 def state_hash(rays, queue):
@@ -34,10 +66,10 @@ def _compare_records(a, b):
         same = x.view(np.uint32) == y.view(np.uint32)
         eq_words += int(same.sum()); words += same.size
         with np.errstate(invalid="ignore", over="ignore"):
-            rel = np.abs(x.astype(np.float64) - y.astype(np.float64)) / np.maximum(np.abs(y.astype(np.float64)), 1.0)
-        rel = np.where(same, 0.0, rel)
+            rel = rel_err(x.astype(np.float64), y.astype(np.float64), f)
+        rel = np.where(same.all(axis=1), 0.0, rel)
         rel = np.where(np.isnan(rel), np.inf, rel)
-        beyond |= (rel > REL_TOL).any(axis=1)
+        beyond |= rel > REL_TOL
         fin = rel[np.isfinite(rel) & (rel <= REL_TOL)]
         if fin.size:
             worst = max(worst, float(fin.max()))
@@ -45,10 +77,10 @@ def _compare_records(a, b):
 
 
 def _limit(n):
-    return max(1, int(math.ceil(MAX_OUTLIER_FRAC * n)))
+    return int(MAX_OUTLIER_FRAC * n)
 
 
-def check_case(fx, state_at, final, strict=True):
+def check_case(fx, state_at, final, strict=True, name=None):
     """fx: loaded fixture; state_at(d) -> (ray records of the whole image, alive queue) of the implementation under test
     after a frame of RayDepth d (one sample); final: dict(image, counts, albedo, normal) of the case's own settings.
     Returns a report; with strict=True asserts the bounds."""
@@ -91,28 +123,28 @@ def check_case(fx, state_at, final, strict=True):
     img = np.asarray(final["image"], np.float32); ref_img = np.asarray(fx["free_image"], np.float32)
     ref_counts = [int(c) for c in fx["free_counts"]]
     counts = [int(c) for c in list(final["counts"])[1:1 + len(ref_counts)]]
-    rel = np.abs(img.astype(np.float64) - ref_img) / np.maximum(np.abs(ref_img), 1.0)
-    px_beyond = float((rel.max(axis=2) > REL_TOL).mean())
+    rel = pixel_rel_err(img, ref_img)
+    px_beyond = int((rel > REL_TOL).sum())
     free = {"counts": counts, "ref_counts": ref_counts, "counts_identical": counts == ref_counts,
-            "pixels_bit_equal": round(float((img.view(np.uint32) == ref_img.view(np.uint32)).all(axis=2).mean()), 4), "pixels_beyond_tol": round(px_beyond, 5),
+            "pixels_bit_equal": round(float((img.view(np.uint32) == ref_img.view(np.uint32)).all(axis=2).mean()), 4), "pixels_beyond_tol": px_beyond, "pixels": int(rel.size),
+            "max_rel_within_tol": float(rel[rel <= REL_TOL].max()) if (rel <= REL_TOL).any() else 0.0,
             "mean_abs_diff": float(np.abs(img - ref_img).mean()), "mean_ref": float(np.abs(ref_img).mean())}
     for k in ("albedo", "normal"):
         if final.get(k) is not None and ("free_" + k) in fx:
-            a = np.asarray(final[k], np.float32); b = np.asarray(fx["free_" + k], np.float32)
-            free[k + "_pixels_beyond_tol"] = round(float(((np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), 1.0)).max(axis=2) > REL_TOL).mean()), 5)
+            free[k + "_pixels_beyond_tol"] = int((pixel_rel_err(final[k], fx["free_" + k]) > REL_TOL).sum())
     rep["free_run"] = free
     if strict:
-        # alive counts may differ by the few flipped rays; a flip reshuffles every later slot-seeded RNG stream of its bounce, so pixel equality
-        # is only demanded while the counts agree
-        for a, b in zip(counts, ref_counts):
-            assert abs(a - b) <= max(2, _limit(b) * 4), free
-        if counts == ref_counts:
-            assert px_beyond <= 0.005, free
+        allow = FREE_RUN_ALLOW.get(name)
+        if allow is None:
+            assert counts == ref_counts, free
+            assert px_beyond == 0, free
             for k in ("albedo", "normal"):
                 if k + "_pixels_beyond_tol" in free:
-                    assert free[k + "_pixels_beyond_tol"] <= 0.005, free
-        else:
-            assert free["mean_abs_diff"] <= 0.05 * max(free["mean_ref"], 1e-3), free
+                    assert free[k + "_pixels_beyond_tol"] == 0, free
+        else:   # a named exception: bounded, with its reason (FREE_RUN_ALLOW)
+            for a, b in zip(counts, ref_counts):
+                assert abs(a - b) <= allow["max_count_diff"], (free, allow)
+            assert px_beyond <= allow["max_pixels_beyond"], (free, allow)
     return rep
 
 

@@ -56,7 +56,7 @@ def test_oracle_matches_reference_shaders(name, oracle_mod):
     aov = bool(configs.apply_settings(T.Settings.default(), ov).OutputAOVs)
     final = dict(image=o.image(0), counts=o.stats()["alive_counts"], albedo=o.image(1) if aov else None, normal=o.image(2) if aov else None)
     o.close()
-    rep = glref_check.check_case(fx, state_at, final, strict=True)
+    rep = glref_check.check_case(fx, state_at, final, strict=True, name=name)
     # what the committed fixtures show today (tests/golden/glref/summary.json): not one flipped decision, not one value beyond tolerance
     assert all(s["flips"] == 0 and s["beyond_tol"] == 0 and s["queue_identical"] for s in rep["stages"]), rep
 

@@ -31,7 +31,7 @@ def test_hip_path_matches_reference_shaders(name, native_builder):
     pt = gpu_render(sc, cam, w, h, **ov)
     aov = bool(configs.apply_settings(T.Settings.default(), ov).OutputAOVs)
     final = dict(image=pt.Result, counts=pt.stats()["alive_counts"], albedo=pt.AlbedoTexture if aov else None, normal=pt.NormalTexture if aov else None)
-    rep = glref_check.check_case(fx, state_at, final, strict=True)
+    rep = glref_check.check_case(fx, state_at, final, strict=True, name=name)
     pt.Dispose()
     assert all(s["flips"] == 0 and s["beyond_tol"] == 0 and s["queue_identical"] for s in rep["stages"]), rep
 
