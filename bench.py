@@ -14,22 +14,22 @@ Metric (BASELINE.json): Mray/s (primary + 1 bounce) at 1920x1080 on the syntheti
               others from the root box), `single_frame` (one frame at a time with a synchronisation per frame, SURVEY 8(d)'s
               protocol: what a host sees that cannot keep 32 samples in flight) and `interior` (camera inside the soup: every pixel
               traverses — the stand-in for a Sponza-class view).
-  N GPUs    = one process per GPU (torch.distributed launch, the driver's command): sample-parallel by default (--shard samples) — every rank
-              renders WHOLE frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence), i.e. a step is one full-frame pass
-              on every GPU and `value` counts the rays of all of them; the displayed frame (N x samples_in_flight samples) is the
-              all-reduced mean of the ranks' accumulations, exchanged inside the timed region; nothing crosses xGMI inside a frame.
-              Per-GPU work is fixed -> "weak" scaling.  --shard rows deals the frame's rows over the ranks instead (bit-identical to one
-              GPU, all-gather of the row shards, total work per step fixed -> "strong"; the latency mode).
-              `python bench.py --gpus N` without a launcher drives ONE multi-device context (idkptCreate(deviceCount = N): rows / strips
-              per device, "strong"); --spawn starts ranks instead (torch.distributed.run, 127.0.0.1).
-  roofline  = traversal kernel (k_trace2).  achieved = algorithmic bytes (64 B per node-pair visit + 48 B per triangle test + 72 B per
-              traversed ray, exact visit counts from the counting build) / HIP-event time of its launches in the timed region.
-              The working set (110 MB) lives in L2 + Infinity Cache, so HBM is not what binds (hbm.* below: the algorithmic rate
-              exceeds 8 TB/s, the counters show 1-2 TB/s); what bounds the INCOHERENT launches (this headline view, every bounce
-              launch) is the vector-memory path's rate of independent 64-B block fetches, so peak = that rate measured on this very
-              box by tools/ubench_lines (4 x 16-B loads per lane to its own random 64-B block, L2-resident set, 32 waves/CU), in the
-              same unit.  Coherent launches (camera inside the scene) exceed that ceiling in algorithmic bytes - their rays share
-              cache lines - and are then priced against the L1 return path; nothing in the memory system binds them.
+  N GPUs    = the FRAME is sharded (BASELINE.json's metric: one 1920x1080 frame on 1/2/4/8 GPUs; total work per step fixed -> "strong" scaling),
+              whichever way the run is started: one process per GPU (torch.distributed launch, the driver's command; --shard rows, the default):
+              the frame's rows are dealt over the ranks (bit-identical to one GPU), the displayed frame's row shards are all-gathered over
+              RCCL inside the timed region; `python bench.py --gpus N` without a launcher drives ONE multi-device context
+              (idkptCreate(deviceCount = N): rows / strips per device, scene replicated by peer copies, frame gathered on device 0); --spawn starts
+              ranks instead (torch.distributed.run, 127.0.0.1).  Both print the same metric string and "scaling": "strong".
+              --shard samples (explicit, never under the headline metric string): every rank renders WHOLE frames for the sample indices rank,
+              rank + N, ... (idkptSetSampleSequence); per-GPU work is fixed -> "weak"; a secondary mode for hosts that want samples per second.
+  roofline  = traversal kernel (k_trace2), fixed denominators from /opt/skills/guides/MI355X_MICROARCH.md.  achieved = algorithmic bytes (64 B per
+              node-pair visit + 48 B per triangle test + 72 B per traversed ray, exact visit counts from the counting build) / HIP-event time of
+              its launches in the timed region.  `frac` = achieved / 34.5 TB/s (aggregate L2, `bound: "l2"`): the 110 MB working set lives in L2 +
+              Infinity Cache, so HBM does not bind and the algorithmic rate can exceed 8 TB/s — both HBM fractions (algorithmic, and from the
+              FETCH_SIZE + WRITE_SIZE counters) are reported beside it under `hbm`.  `gather_measured` is a third, separately labelled figure: the
+              rate at which THIS box fetches independent 64-B blocks (tools/ubench_lines), the access pattern of incoherent traversal.
+              `traffic` and `pmc` are measured for THIS run: the timed region is re-executed under rocprofv3 --pmc (separate passes for
+              FETCH_SIZE, WRITE_SIZE and the L2/L1 request counters; --kernel-trace only beside them) and the timed launches are averaged.
   cpu_baseline = the oracle's CPU port of the same path (all host cores, OpenMP), scene and threads kept warm, on a bounded sample.
 """
 import argparse
@@ -47,6 +47,7 @@ W, H = 1920, 1080
 N_TRIS = 1_000_000
 RAY_DEPTH = 2
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0          # same guide, "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
 NODE_PAIR_BYTES, TRI_BYTES, RAY_BYTES = 64, 48, 72     # node pair; triVerts entry; 48 B ray record + 4 B list entry + 20 B hit record
 
 
@@ -85,7 +86,9 @@ def main():
     ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: contiguous strips + per-bounce count exchange (gloo control group) so that RayDepth > 2 output equals the 1-GPU output bit for bit; default = interleaved rows (exact at RayDepth 2)")
     ap.add_argument("--interactive", type=int, default=0, metavar="F", help="secondary mode: every step is a NEW frame (own camera, own image, ResetAccumulation semantics) with F frames in flight through the frame ring; every finished frame is exchanged when N > 1")
     ap.add_argument("--spawn", action="store_true", help="--gpus N without a launcher: start N processes (torch.distributed.run, one rank per GPU, RCCL) instead of the default ONE process driving ONE multi-device context (idkptCreate(deviceCount = N))")
-    ap.add_argument("--shard", choices=["samples", "rows"], default="samples", help="one process per GPU (torch.distributed launch) only.  samples (default): every rank renders WHOLE frames for its own sample indices (idkptSetSampleSequence(rank, N)), one all-reduce per displayed frame, weak scaling — per-GPU work does not shrink with N.  rows: the frame's rows are dealt over the ranks (bit-identical to one GPU, strong scaling, the latency mode)")
+    ap.add_argument("--shard", choices=["rows", "samples"], default="rows", help="one process per GPU (torch.distributed launch) only.  rows (default): the frame's rows are dealt over the ranks (bit-identical to one GPU, strong scaling: BASELINE.json's metric).  samples: every rank renders WHOLE frames for its own sample indices (idkptSetSampleSequence(rank, N)), one all-reduce per displayed frame, weak scaling — a secondary mode, never reported under the headline metric string")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic / roofline.pmc for this run (N = 1 only)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the re-execution of the timed region under rocprofv3
     ap.add_argument("--cpu-build", action="store_true", help="build the BLAS entirely on the host (libidkbvh) instead of running the SweepSAH core on the GPU; the result is the same bytes")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU-frame-equivalent the library may defer and trace together (idkptSetMaxBatch; results are bit-identical); multiplied by the GPU count because each rank only holds 1/N of every frame, capped at 256")
     args = ap.parse_args()
@@ -229,10 +232,10 @@ def main():
 
     if rank == 0:
         value = rays_rep / dt / 1e6
-        headline = (args.tris, depth, args.sort, W, H, args.batch, args.view, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, 32 if sample_parallel else min(256, 32 * world * group), "headline", "soup")
+        headline = (not sample_parallel) and (args.tris, depth, args.sort, W, H, args.batch, args.view, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world * group), "headline", "soup")
         view_txt = "camera at z = 25 outside the soup (SURVEY 8d config 3)" if args.view == "headline" else "camera INSIDE the soup at the origin"
         out = {
-            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri {args.scene} scene, {args.view if args.scene == 'soup' else 'interior'} view (secondary config)", "value": round(value, 2), "unit": "Mray/s",
+            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri {args.scene} scene, {args.view if args.scene == 'soup' else 'interior'} view (secondary config{', sample-parallel: whole frames per GPU' if sample_parallel else ''})", "value": round(value, 2), "unit": "Mray/s",
             "n_gpus": world * group, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if sample_parallel else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": reps, "repeat_ms": [round(x * 1e3, 3) for x in repeat_s], "statistic": "median repetition of the timed region",
@@ -241,9 +244,12 @@ def main():
                                      f"atrium-{args.tris} (procedural two-storey colonnaded hall, connected surfaces, {len(scene.blas_triangles)} BLAS triangles, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, camera inside looking down the hall"),
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
                        "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
-                       "bvh_build_s": round(build_s, 2), "blas_build_ms": blas_build_ms, "bvh_builder": builder_kind},
+                       "bvh_build_s": round(build_s, 2), "blas_build_ms": blas_build_ms, "bvh_builder": builder_kind,
+                       "n_gpu": n_gpu_report(torch, dist, world, group)},
             "roofline": roofline(st, pairs * reps / group, tri_tests * reps / group, traversed * reps / group, args, world * group, B if rem == 0 else (rem if q == 0 else None), torch, device),
         }
+        if args.pmc_child:
+            out = {"pmc_child": True, "trace_launches": int(st["trace_launches"]), "ms_per_step": out["ms_per_step"]}
         if world * group == 1 and not args.no_extras:
             out["single_frame"] = single_frame(pt, depth)
             if args.scene == "soup":
@@ -257,6 +263,21 @@ def main():
     r.pt.Dispose()
     if world > 1:
         dist.destroy_process_group()
+
+
+def n_gpu_report(torch, dist, world, group):
+    """What the N > 1 run actually ran on (tools/scale_selftest.py checks the same things and the bits): devices, peer access, ranks RCCL saw."""
+    if world * group == 1:
+        return None
+    try:
+        ndev = torch.cuda.device_count()
+        ids = sorted({d % ndev for d in range(group)}) if group > 1 else list(range(min(ndev, world)))
+        rep = {"visible_devices": ndev, "devices_used": ids, "peer_access": [[1 if i == j else int(torch.cuda.can_device_access_peer(i, j)) for j in ids] for i in ids]}
+        if world > 1:
+            rep["ranks"] = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size()}
+        return rep
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e)}
 
 
 def counter_pass(pt, B, depth):
@@ -290,51 +311,95 @@ def gather_ceiling(set_log2_blocks=16):
     return None
 
 
+def pmc_passes(args, launches):
+    """Re-executes this run's timed region (same scene, view, depth, steps, warm-up; one repetition, no extras) under rocprofv3 --pmc, one
+    pass per counter set (the guide's HBM/rocprofv3 section: FETCH_SIZE and WRITE_SIZE do not fit one pass; --kernel-trace only beside --pmc),
+    and averages the counters over the timed launches of the non-counting k_trace2 instantiations (the last `launches` dispatches of each
+    child: warm-up comes first, nothing follows).  Returns None when rocprofv3 is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    sets = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "l2": ["TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]}
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--no-pmc", "--no-extras", "--no-cpu-baseline", "--repeats", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+             "--tris", str(args.tris), "--view", args.view, "--scene", args.scene, "--depth", str(args.depth), "--sort", str(args.sort), "--width", str(args.width), "--height", str(args.height),
+             "--batch", str(args.batch)] + (["--cpu-build"] if args.cpu_build else [])
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="idkpt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for name, ctrs in sets.items():
+            d = os.path.join(tmp, name)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "b", "--"] + child, capture_output=True, text=True, timeout=420, env=env, cwd="/tmp")
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            n_child = None
+            for line in r.stdout.splitlines():
+                if line.startswith("{") and "pmc_child" in line:
+                    n_child = json.loads(line)["trace_launches"]
+            if n_child != launches:
+                return None                                    # not the same launch schedule: do not report someone else's numbers
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"]
+                if "k_trace2<" not in k:
+                    continue
+                targs = k.split("k_trace2<")[1].split(">")[0].replace(" ", "").split(",")
+                if targs[1] != "false":
+                    continue                                   # the counting instantiation (untimed counter pass)
+                per.setdefault(row["Counter_Name"], []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+            for c, v in per.items():
+                v.sort()
+                timed = [x for _, x in v[-launches:]]
+                if len(timed) != launches:
+                    return None
+                got[c] = sum(timed) / launches
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return got
+
+
 def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, torch, device):
-    """Traversal kernel (both instantiations of k_trace2: primary + bounce), this rank, over all timed repetitions."""
+    """Traversal kernel (both instantiations of k_trace2: primary + bounce), this rank, over all timed repetitions.  Fixed denominators."""
     alg_bytes_total = float(NODE_PAIR_BYTES) * pairs + float(TRI_BYTES) * tri_tests + float(RAY_BYTES) * traversed
     launches = max(1, st["trace_launches"])
     alg_bytes_launch = alg_bytes_total / launches
     avg_launch_s = st["trace_ms_total"] * 1e-3 / launches
     achieved = alg_bytes_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    peak_hit = gather_ceiling(16)           # L2-resident set: the hardware ceiling of this access pattern
+    peak_hit = gather_ceiling(16)           # 4 MB set: every block an L1 miss served by L2
     peak_miss = gather_ceiling(21)          # 128 MB set (the scene's working-set size): every block misses L2, served by Infinity Cache
-    # HBM-side bytes per launch from the committed PMC passes of this command (profiles/r02_traffic.json, keyed by view and samples per launch)
-    traffic, l2_hit, l1_miss, l2_miss = None, None, None, None
-    prof = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(prof) and (args.tris, args.depth, args.sort, args.width, args.height, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, "soup"):
-        try:
-            e = json.load(open(prof)).get(f"n{world}", {}).get(args.view, {}).get(f"s{samples_per_launch}")
-            if e:
-                traffic, l2_hit, l1_miss, l2_miss = e.get("traversal_hbm_bytes_per_launch"), e.get("l2_hit_rate"), e.get("l1_miss_requests_per_launch"), e.get("l2_miss_requests_per_launch")
-        except Exception:
-            pass
-    # Two ceilings of the vector-memory path, both in GB/s of bytes delivered to the lanes:
-    #   gather  the rate at which the chip fetches INDEPENDENT 64-B blocks (every block an L1 miss served by L2), measured now by the ubench:
-    #           what binds incoherent traversal (bounce rays, the headline frame);
-    #   l1      the L1 -> register return path, 64 B/clk/CU at the 2.4 GHz maximum clock (MI355X_MICROARCH.md): nothing exceeds it, but only rays
-    #           that share cache lines (camera inside the scene: L1 hit rate 98 % on the primary launch) get beyond the gather ceiling.
-    # frac is taken against the tightest ceiling the kernel does not exceed, and says which one that is.
-    l1_peak = 64.0 * 256 * 2.4                       # GB/s
-    use_gather = bool(peak_hit) and achieved <= peak_hit
-    peak = peak_hit if use_gather else l1_peak
-    out = {"bound": "vmem-gather" if use_gather else "vmem-l1", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s",
-           "frac": round(achieved / peak, 4), "traffic": traffic,
-           "peak_source": ("tools/ubench_lines.bin 16 0 32, run by this bench: independent random 64-B block fetches (4 x 16-B loads per lane), 4 MB set (L2 hits), 32 waves/CU" if use_gather else
-                           "L1 return path 64 B/clk/CU x 256 CUs x 2.4 GHz (the measured gather ceiling is exceeded: the launch is L1-hit dominated)"),
-           "gather_ceiling": peak_hit, "frac_of_gather_ceiling": round(achieved / peak_hit, 4) if peak_hit else None, "l1_ceiling": round(l1_peak, 1), "frac_of_l1_ceiling": round(achieved / l1_peak, 4),
-           "peak_l2_miss_set": peak_miss, "l2_hit_rate_pmc": l2_hit,
+    pmc = None
+    if world == 1 and not args.no_pmc and not args.pmc_child:
+        pmc = pmc_passes(args, launches // max(1, args.repeats))
+    traffic = None
+    out = {"bound": "l2", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / L2_PEAK_GBS, 4), "traffic": None,
+           "peak_source": "MI355X_MICROARCH.md: aggregate L2 bandwidth ~34.5 TB/s (8 XCDs x 4 MiB); the working set of this kernel is L2 + Infinity-Cache resident, so HBM (8 TB/s) is not the roof - both HBM fractions are under `hbm`",
            "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": int(launches), "samples_per_launch": samples_per_launch,
+           "alg_bytes_definition": "64 B x node-pair visits + 48 B x triangle tests + 72 B x rays entering the kernel (DESIGN.md 5), exact counts of the counting build",
            "node_pair_visits_per_step": int(pairs / max(1, args.steps * max(1, args.repeats))), "triangle_tests_per_step": int(tri_tests / max(1, args.steps * max(1, args.repeats))),
-           "hbm": {"peak": HBM_PEAK_GBS, "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 4), "counter_gbs": round(traffic / avg_launch_s / 1e9, 1) if traffic else None,
-                   "counter_frac": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None, "copy_measured_gbs": hbm_copy_gbs(torch, device),
-                   "note": "working set (110 MB of nodes + triangles) is L2 / Infinity-Cache resident: HBM does not bind this kernel"}}
-    if peak_hit and peak_miss and l1_miss and l2_miss is not None and avg_launch_s > 0:
-        # counter view of the same bound: the L1 misses of a launch (TCP_TCC_READ_REQ, 64-B blocks), each priced at the measured fetch rate of
-        # where it was served from (L2 hit: peak; L2 miss: peak_l2_miss_set), as a fraction of the launch time.  ~1 = the fill path is saturated.
-        fill_s = (l1_miss - l2_miss) * 64.0 / (peak_hit * 1e9) + l2_miss * 64.0 / (peak_miss * 1e9)
-        out["pmc"] = {"l1_miss_requests_per_launch": l1_miss, "l2_miss_requests_per_launch": l2_miss, "fill_time_frac": round(fill_s / avg_launch_s, 4),
-                      "source": "profiles/r02_traffic.json (rocprofv3 --pmc passes of this command), priced with the two ceilings measured by this run"}
+           "hbm": {"peak": HBM_PEAK_GBS, "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 4), "counter_gbs": None, "counter_frac": None, "copy_measured_gbs": hbm_copy_gbs(torch, device),
+                   "note": "algorithmic_frac > 1 is possible and says only that the bytes are served from cache; counter_* = (FETCH_SIZE + WRITE_SIZE) of this run's launches"},
+           "gather_measured": {"gbs": peak_hit, "frac": round(achieved / peak_hit, 4) if peak_hit else None, "l2_miss_set_gbs": peak_miss,
+                               "what": "not a guide peak: tools/ubench_lines.bin run by this bench - independent random 64-B block fetches (4 x 16-B loads per lane, the node-pair fetch), 32 waves/CU, from a 4 MB set (L2 hits) and from a 128 MB set (L2 misses served by the Infinity Cache)"}}
+    if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # KiB -> bytes; FETCH_SIZE calibrated at 1.03 on this 64-B gather pattern (profiles/r01_bench_pmc_summary.json), no doubling
+        out["traffic"] = int(traffic)
+        out["hbm"]["counter_gbs"] = round(traffic / avg_launch_s / 1e9, 1); out["hbm"]["counter_frac"] = round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4)
+        h, m, rq, ac = pmc.get("TCC_HIT_sum"), pmc.get("TCC_MISS_sum"), pmc.get("TCP_TCC_READ_REQ_sum"), pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum")
+        out["pmc"] = {"source": "this run: its timed region re-executed under rocprofv3 --kernel-trace --pmc (3 passes), mean over the timed k_trace2 launches",
+                      "fetch_bytes_per_launch": int(pmc["FETCH_SIZE"] * 1024.0), "write_bytes_per_launch": int(pmc["WRITE_SIZE"] * 1024.0),
+                      "l1_miss_bytes_per_launch": int(rq * 64.0) if rq is not None else None, "l2_miss_bytes_per_launch": int(m * 128.0) if m is not None else None,
+                      "l1_hit_rate": round(1.0 - rq / ac, 4) if rq is not None and ac else None, "l2_hit_rate": round(h / (h + m), 4) if h is not None and m is not None and h + m > 0 else None,
+                      "units": "L1 misses = TCP_TCC_READ_REQ x 64 B; L2 misses = TCC_MISS x 128-B lines; FETCH/WRITE_SIZE KiB x 1024"}
+    else:
+        out["pmc"] = None
     return out
 
 

@@ -106,6 +106,7 @@ struct dev_ctx {
     bool grouped = false, inGroupFlush = false; int groupIndex = 0;
     hipEvent_t* evBounce = nullptr;                              // [MAX_DEPTH_SLOTS]; evBounce[j] = bases[j] (alive counts entering bounce j) written
     int (*groupExchange)(void* user, dev_ctx* member, int bounce, int samples, const uint32_t** outBases) = nullptr; void* groupUser = nullptr;
+    struct PeerPolicy* peer = nullptr;                           // multi-device contexts: how device-to-device copies are made (member_copy)
 };
 
 static hipEvent_t next_event(dev_ctx* ctx)
@@ -589,6 +590,36 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     return IDKPT_OK;
 }
 
+// Device-to-device copies of a multi-device context.  xGMI peer copies (hipMemcpyPeerAsync, ordered on `st`) where the runtime grants them; on a
+// node whose GPUs refuse peer access — or under the option "force_no_peer" — every copy is staged through pinned host memory instead: wait for
+// `st` (so that what the stream order promised about the source holds), D2H on the source device, H2D on the destination device, both blocking.
+// Slower (two PCIe crossings and a host synchronisation), same results; the first refusal is logged once.
+struct PeerPolicy { bool forceStaged = false, warned = false; void* stage = nullptr; size_t stageBytes = 0; };
+static hipError_t member_copy(PeerPolicy* pol, void* dst, int dstDev, const void* src, int srcDev, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    if (!pol || !pol->forceStaged) {
+        hipError_t e = hipMemcpyPeerAsync(dst, dstDev, src, srcDev, bytes, st);
+        if (e == hipSuccess || !pol) return e;
+        (void)hipGetLastError();
+        if (!pol->warned) { fprintf(stderr, "[idkpt] warning: peer copy GPU %d -> GPU %d refused (%s); staging device-to-device copies through host memory from now on\n", srcDev, dstDev, hipGetErrorString(e)); pol->warned = true; }
+        pol->forceStaged = true;
+    }
+    hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) return e;
+    if (pol->stageBytes < bytes) {
+        if (pol->stage) (void)hipHostFree(pol->stage);
+        pol->stage = nullptr; pol->stageBytes = 0;
+        e = hipHostMalloc(&pol->stage, bytes, hipHostMallocDefault); if (e != hipSuccess) return e;
+        pol->stageBytes = bytes;
+    }
+    int cur = 0; (void)hipGetDevice(&cur);
+    e = hipSetDevice(srcDev); if (e == hipSuccess) e = hipMemcpy(pol->stage, src, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipSetDevice(dstDev);
+    if (e == hipSuccess) e = hipMemcpy(dst, pol->stage, bytes, hipMemcpyHostToDevice);
+    (void)hipSetDevice(cur);
+    return e;
+}
+
 // Multi-device contexts: the scene one member uploaded (validated, derived layouts built) is replicated to another member device-to-device
 // (hipMemcpyPeerAsync: xGMI between MI355X GPUs) instead of crossing PCIe once per GPU — the "broadcast of the BVH" of the group layer.
 static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
@@ -604,7 +635,7 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++) {
         if (!f[i]->p || f[i]->bytes == 0) continue;
         HIPC(d[i]->ensure(f[i]->bytes));
-        HIPC(hipMemcpyPeerAsync(d[i]->p, ctx->device, f[i]->p, src->device, f[i]->bytes, ctx->stream));
+        HIPC(member_copy(ctx->peer, d[i]->p, ctx->device, f[i]->p, src->device, f[i]->bytes, ctx->stream));
     }
     for (auto& t : ctx->texData) t.release();
     ctx->texData.clear(); ctx->texDims = src->texDims;
@@ -612,7 +643,7 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     for (size_t i = 0; i < src->texData.size(); i++) {
         ctx->texData.emplace_back();
         HIPC(ctx->texData.back().ensure(src->texData[i].bytes));
-        HIPC(hipMemcpyPeerAsync(ctx->texData.back().p, ctx->device, src->texData[i].p, src->device, src->texData[i].bytes, ctx->stream));
+        HIPC(member_copy(ctx->peer, ctx->texData.back().p, ctx->device, src->texData[i].p, src->device, src->texData[i].bytes, ctx->stream));
         td.push_back({ctx->texData.back().as<float4>(), src->texDims[i].first, src->texDims[i].second});
     }
     { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
@@ -1359,6 +1390,7 @@ static int32_t dev_GetFrameDevicePtr(dev_ctx* ctx, int32_t slot, int32_t image, 
     REQUIRE(slot >= 0 && slot < ctx->ringSize, "idkptGetFrameDevicePtr: slot outside the frame ring");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();                                        // launches what is still deferred (stream-ordered: a consumer on the context's stream sees the finished image)
+    { int rc = check_overflow(ctx); if (rc) return rc; }   // (no wait: reports an overflow of batches that have already finished; a zero-copy consumer sees the rest at its next idkptSynchronize)
     *outPtr = image_ptr(ctx, image, slot);
     if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
     return IDKPT_OK;
@@ -1482,6 +1514,7 @@ static int32_t dev_GetImageDevicePtr(dev_ctx* ctx, int32_t image, void** outPtr,
     REQUIRE(image >= 0 && image < 3 && ctx->W > 0, "idkptGetImageDevicePtr: bad image / no size");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();                                        // launches what is still deferred
+    { int rc = check_overflow(ctx); if (rc) return rc; }   // (no wait: see idkptGetFrameDevicePtr)
     *outPtr = image_ptr(ctx, image, ctx->curSlot);
     if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
     return IDKPT_OK;

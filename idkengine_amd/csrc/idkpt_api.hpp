@@ -18,7 +18,10 @@
 
 struct idkpt_ctx {
     std::vector<dev_ctx*> dev;
-    std::string lastError; bool groupError = false;
+    std::string lastError;
+    PeerPolicy peer;                                        // how the members copy to each other (xGMI peer copies, or staged through the host)
+    hipEvent_t evGatherStart = nullptr;                     // device 0: what was queued on its stream before a gather (the consumer of the previous frame)
+    bool frameOk = true;                                    // false after a failed re-layout: idkptRender refuses until the next successful idkptSetSize
     int W = 0, H = 0;
     int shardMode = IDKPT_SHARD_AUTO; bool strips = false;
     idkpt_settings st;
@@ -49,8 +52,9 @@ __global__ void k_interleave_rows(const float4* stage, float4* full, int W, int 
     full[i] = stage[((size_t)rowOffset[d] + ly) * W + x];
 }
 
-static int gfail(idkpt_ctx* c, int code, const std::string& msg) { c->lastError = msg; c->groupError = true; return code; }
-static int mfail(idkpt_ctx* c, dev_ctx* m, int rc) { c->lastError = m->lastError; c->groupError = true; return rc; }
+// one place for the last error: the context's string; a one-device context mirrors it into its member (idkptGetLastError reads the member there)
+static int gfail(idkpt_ctx* c, int code, const std::string& msg) { c->lastError = msg; if (c->n() == 1) c->dev[0]->lastError = msg; return code; }
+static int mfail(idkpt_ctx* c, dev_ctx* m, int rc) { c->lastError = m->lastError; return rc; }
 #define GREQ(cond, msg) do { if (!(cond)) return gfail(c, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
 #define GHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return gfail(c, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
 #define ONE(call) do { if (c->n() == 1) { dev_ctx* m = c->dev[0]; return call; } } while (0)
@@ -70,7 +74,7 @@ static int group_exchange(void* user, dev_ctx* m, int bounce, int samples, const
     for (int d2 = 0; d2 < d; d2++) {
         dev_ctx* lo = c->dev[d2];
         HIPC(hipStreamWaitEvent(m->stream, c->evBounce[d2][bounce], 0));  // the lower member's counts of this bounce are final (it was enqueued first)
-        HIPC(hipMemcpyPeerAsync(c->peerStage[d].as<uint32_t>() + (size_t)d2 * BS, m->device, lo->bases.as<uint32_t>() + (size_t)bounce * BS, lo->device, (size_t)(samples + 1) * 4, m->stream));
+        HIPC(member_copy(&c->peer, c->peerStage[d].as<uint32_t>() + (size_t)d2 * BS, m->device, lo->bases.as<uint32_t>() + (size_t)bounce * BS, lo->device, (size_t)(samples + 1) * 4, m->stream));
     }
     hipLaunchKernelGGL(k_group_bases, dim3((samples + 63) / 64), dim3(64), 0, m->stream, (const uint32_t*)c->peerStage[d].as<uint32_t>(), d, BS, samples, c->gbase[d].as<uint32_t>());
     HIPC(hipGetLastError());
@@ -108,17 +112,22 @@ static int group_sync(idkpt_ctx* c)
 }
 
 // (re)applies size + row layout to every member.  Strips for deep paths (exact slot numbering), interleaved rows otherwise.
-static int group_layout(idkpt_ctx* c)
+static int group_layout(idkpt_ctx* c, int W, int H)
 {
     const int n = (int)c->n();
-    c->strips = c->shardMode == IDKPT_SHARD_STRIPS || (c->shardMode == IDKPT_SHARD_AUTO && c->st.RayDepth > 2);
-    if (c->W <= 0) return IDKPT_OK;
-    GREQ(c->H >= n, "idkptSetSize: a multi-device context needs at least one image row per device");
+    const bool strips = c->shardMode == IDKPT_SHARD_STRIPS || (c->shardMode == IDKPT_SHARD_AUTO && c->st.RayDepth > 2);
+    c->strips = strips;
+    if (W <= 0) return IDKPT_OK;
+    GREQ(H >= n, "idkptSetSize: a multi-device context needs at least one image row per device");     // (checked before any member is touched)
+    // A member's allocation can fail half way through the loop; the group then has no usable frame (idkptRender refuses) until a later
+    // idkptSetSize / idkptSetSettings / idkptSetGroupSharding re-layout succeeds — never a mix of members on the old and the new size.
+    c->frameOk = false;
+    std::vector<int> first(n), count(n);
     for (int d = 0; d < n; d++) {
         int rc;
-        if (c->strips) { strip_of(c->H, n, d, &c->firstRow[d], &c->rowCount[d]); rc = dev_SetLayout(c->dev[d], c->W, c->H, 1, c->firstRow[d], c->rowCount[d]); }
-        else { c->firstRow[d] = d; c->rowCount[d] = local_rows(c->H, n, d); rc = dev_SetLayout(c->dev[d], c->W, c->H, n, d, 0x7fffffff); }
-        if (rc) return mfail(c, c->dev[d], rc);
+        if (strips) { strip_of(H, n, d, &first[d], &count[d]); rc = dev_SetLayout(c->dev[d], W, H, 1, first[d], count[d]); }
+        else { first[d] = d; count[d] = local_rows(H, n, d); rc = dev_SetLayout(c->dev[d], W, H, n, d, 0x7fffffff); }
+        if (rc) { for (dev_ctx* o : c->dev) o->frameOk = false; return mfail(c, c->dev[d], rc); }
         c->flushDoneValid[d] = 0;
     }
     // where member d's rows land in the gather staging area (interleaved layout), kept on device 0 for k_interleave_rows
@@ -129,6 +138,7 @@ static int group_layout(idkpt_ctx* c)
     GHIP(c->rowOffDev.ensure((size_t)n * 4));
     GHIP(hipMemcpyAsync(c->rowOffDev.p, rowOff.data(), (size_t)n * 4, hipMemcpyHostToDevice, m0->stream));
     GHIP(hipStreamSynchronize(m0->stream));
+    c->W = W; c->H = H; c->firstRow = first; c->rowCount = count; c->frameOk = true;      // commit
     return IDKPT_OK;
 }
 
@@ -165,11 +175,16 @@ static int group_gather_device(idkpt_ctx* c, int image, int slot, void** outPtr,
     std::vector<int> rowOff(n + 1, 0);
     for (int d = 0; d < n; d++) rowOff[d + 1] = rowOff[d] + c->dev[d]->rows;
     if (!c->strips) GHIP(c->gatherStage.ensure(frameBytes));
+    // The landing buffers on device 0 may still be read by what is queued on device 0's stream (the previous gather's k_interleave_rows, a consumer
+    // the host ordered behind idkptGetStream): no member may write them before that work is done.
+    GHIP(hipEventRecord(c->evGatherStart, m0->stream));
+    if (c->peer.forceStaged) GHIP(hipEventSynchronize(c->evGatherStart));          // (staged copies land from the host, outside any stream order)
     for (int d = 0; d < n; d++) {
         dev_ctx* m = c->dev[d];
         GHIP(hipSetDevice(m->device));
+        GHIP(hipStreamWaitEvent(m->stream, c->evGatherStart, 0));
         char* dst = c->strips ? (char*)c->full[image].p + (size_t)c->firstRow[d] * rowBytes : (char*)c->gatherStage.p + (size_t)rowOff[d] * rowBytes;
-        GHIP(hipMemcpyPeerAsync(dst, m0->device, image_ptr(m, image, slot), m->device, (size_t)m->rows * rowBytes, m->stream));   // ordered behind the member's FinalDraw
+        GHIP(member_copy(&c->peer, dst, m0->device, image_ptr(m, image, slot), m->device, (size_t)m->rows * rowBytes, m->stream));   // ordered behind the member's FinalDraw
         GHIP(hipEventRecord(c->evGather[d], m->stream));
     }
     GHIP(hipSetDevice(m0->device));
@@ -222,10 +237,11 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
             ok = hipSetDevice(m->device) == hipSuccess;
             for (int j = 0; j < MAX_DEPTH_SLOTS && ok; j++) ok = hipEventCreateWithFlags(&c->evBounce[d][j], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&c->evFlushDone[d], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->evGather[d], hipEventDisableTiming) == hipSuccess;
-            m->grouped = true; m->groupIndex = d; m->evBounce = c->evBounce[d].data(); m->groupExchange = group_exchange; m->groupUser = c;
+            m->grouped = true; m->groupIndex = d; m->evBounce = c->evBounce[d].data(); m->groupExchange = group_exchange; m->groupUser = c; m->peer = &c->peer;
             // direct xGMI access between the members' devices (copies work without it through staging; a refusal is not an error)
             for (int d2 = 0; d2 < n; d2++) if (c->dev[d2]->device != m->device) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->device, c->dev[d2]->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(c->dev[d2]->device, 0); (void)hipGetLastError(); }
         }
+        ok = ok && hipSetDevice(c->dev[0]->device) == hipSuccess && hipEventCreateWithFlags(&c->evGatherStart, hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); for (dev_ctx* o : c->dev) dev_Destroy(o); delete c; return IDKPT_ERR_HIP; }
     }
     *outCtx = c;
@@ -247,6 +263,8 @@ int32_t idkptDestroy(idkpt_ctx* c)
         (void)hipSetDevice(c->dev[0]->device);
         for (int i = 0; i < 3; i++) c->full[i].release();
         c->gatherStage.release(); c->rowOffDev.release();
+        if (c->evGatherStart) (void)hipEventDestroy(c->evGatherStart);
+        if (c->peer.stage) (void)hipHostFree(c->peer.stage);
     }
     for (dev_ctx* m : c->dev) dev_Destroy(m);
     delete c;
@@ -256,7 +274,7 @@ int32_t idkptDestroy(idkpt_ctx* c)
 int32_t idkptGetLastError(idkpt_ctx* c, const char** outMessage)
 {
     if (!c || !outMessage) return IDKPT_ERR_INVALID_ARGUMENT;
-    if (c->n() == 1 && !c->groupError) return dev_GetLastError(c->dev[0], outMessage);
+    if (c->n() == 1) return dev_GetLastError(c->dev[0], outMessage);      // (gfail mirrors group-level messages into the member)
     *outMessage = c->lastError.c_str();
     return IDKPT_OK;
 }
@@ -272,7 +290,7 @@ int32_t idkptSetGroupSharding(idkpt_ctx* c, int32_t mode)
     const bool was = c->strips;
     c->shardMode = mode;
     const bool now = mode == IDKPT_SHARD_STRIPS || (mode == IDKPT_SHARD_AUTO && c->st.RayDepth > 2);
-    return now != was ? group_layout(c) : IDKPT_OK;
+    return now != was ? group_layout(c, c->W, c->H) : IDKPT_OK;
 }
 
 int32_t idkptSetSize(idkpt_ctx* c, int32_t width, int32_t height)
@@ -281,8 +299,7 @@ int32_t idkptSetSize(idkpt_ctx* c, int32_t width, int32_t height)
     ONE(dev_SetSize(m, width, height));
     GREQ(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
     GFLUSH();
-    c->W = width; c->H = height;
-    return group_layout(c);
+    return group_layout(c, width, height);
 }
 int32_t idkptSetRowSharding(idkpt_ctx* c, int32_t rowModulo, int32_t rowRemainder)
 {
@@ -312,7 +329,7 @@ int32_t idkptSetSettings(idkpt_ctx* c, const idkpt_settings* s)
     const bool wantStrips = c->shardMode == IDKPT_SHARD_STRIPS || (c->shardMode == IDKPT_SHARD_AUTO && s->RayDepth > 2);
     ALL(dev_SetSettings(m, s));                       // (validates; nothing is changed when it fails on the first member)
     c->st = *s;
-    if (wantStrips != c->strips) { int rc = group_layout(c); if (rc) return rc; }   // the RayDepth setter resets the accumulation anyway (PathTracer.cs:16-25)
+    if (wantStrips != c->strips) { int rc = group_layout(c, c->W, c->H); if (rc) return rc; }   // the RayDepth setter resets the accumulation anyway (PathTracer.cs:16-25)
     return IDKPT_OK;
 }
 int32_t idkptGetSettings(idkpt_ctx* c, idkpt_settings* out) { if (!c || !out) return IDKPT_ERR_INVALID_ARGUMENT; return dev_GetSettings(c->dev[0], out); }
@@ -340,7 +357,12 @@ int32_t idkptUploadScene(idkpt_ctx* c, const idkpt_scene_desc* scene)
 #define REPLICATE(name, ...) do { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; ONE(dev_##name(m, ##__VA_ARGS__)); GFLUSH(); ALL(dev_##name(m, ##__VA_ARGS__)); return IDKPT_OK; } while (0)
 int32_t idkptUpdateBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, const void* data) { REPLICATE(UpdateBuffer, which, offsetBytes, bytes, data); }
 int32_t idkptSetLightCount(idkpt_ctx* c, int32_t count) { REPLICATE(SetLightCount, count); }
-int32_t idkptSetDeveloperOption(idkpt_ctx* c, const char* name, int32_t value) { REPLICATE(SetOption, name, value); }
+int32_t idkptSetDeveloperOption(idkpt_ctx* c, const char* name, int32_t value)
+{
+    if (!c || !name) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (c->n() > 1 && std::string(name) == "force_no_peer") { GFLUSH(); c->peer.forceStaged = value != 0; return IDKPT_OK; }   // device-to-device copies through pinned host memory
+    REPLICATE(SetOption, name, value);
+}
 int32_t idkptBuildTlas(idkpt_ctx* c, const GpuTlasNode* nodes, int32_t nodeCount) { REPLICATE(BuildTlas, nodes, nodeCount); }
 int32_t idkptBuildTlasOnDevice(idkpt_ctx* c, int32_t searchRadius) { REPLICATE(BuildTlasOnDevice, searchRadius); }      // every member rebuilds its own copy (0.1 ms; cheaper than shipping it)
 int32_t idkptRefitBlas(idkpt_ctx* c, int32_t blasId) { REPLICATE(RefitBlas, blasId); }
@@ -417,7 +439,7 @@ int32_t idkptRender(idkpt_ctx* c)
 {
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
     ONE(dev_Render(m));
-    if (c->W <= 0) return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptRender: no frame buffers (idkptSetSize not called)");
+    if (c->W <= 0 || !c->frameOk) return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptRender: no frame buffers (idkptSetSize not called, or the last re-layout of the devices failed)");
     // every member queues the same samples for its rows; the batch is launched on all of them together.  The general path (debug
     // traversal-cost view) is never batched.
     const int limit = fast_path(c->dev[0]) ? c->maxBatch : 1;

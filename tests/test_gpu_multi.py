@@ -225,3 +225,32 @@ def test_multi_device_context_api_surface(native_builder, oracle_mod):
     a.SetSize(64, 32); a.SetCamera(cam(64, 32)); a.Compute()     # still usable
     assert a.Result.shape == (32, 64, 4)
     a.Dispose(); b.Dispose()
+
+
+@pytest.mark.parametrize("members", [2, 3])
+def test_multi_device_context_without_peer_access(native_builder, members, monkeypatch):
+    """A node whose GPUs refuse peer access (or the option "force_no_peer"): every device-to-device copy of the group layer — scene replication,
+    the per-bounce alive-count exchange of the strips, the frame gather on device 0 — is staged through pinned host memory instead.  Same bits."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    monkeypatch.setenv("IDKPT_FORCE_NO_PEER", "1")
+    sc = S.soup_scene(20000, native_builder, seed=33, extent=3.0, refittable=True); w, h = 160, 101; cam = S.Camera(w, h, position=(0.0, 0.0, 8.0))
+    ids = _device_ids(members)
+    for depth, batch in ((2, 2), (5, 3)):
+        st = lambda: configs.apply_settings(T.Settings.default(), dict(RayDepth=depth))   # noqa: E731
+        a = PathTracer(w, h, settings=st(), devices=ids); b = PathTracer(w, h, settings=st())
+        for p in (a, b):
+            p.UploadScene(sc); p.SetCamera(cam); p.set_max_batch(batch)
+            for _ in range(4):
+                p.Compute()
+        assert (bits(a.Result) == bits(b.Result)).all(), depth
+        if depth > 2:
+            assert a.rays().tobytes() == b.rays().tobytes() and (a.alive_queue() == b.alive_queue()).all()
+        assert a.stats()["rays_traced"] == b.stats()["rays_traced"]
+        ptr, nbytes = a.image_device_ptr(0)                       # staged gather on device 0, twice in a row (the second one waits for the first's readers)
+        out = read_device_image(a, ptr, nbytes, (h, w, 4))
+        assert (bits(out) == bits(b.Result)).all()
+        a.Compute(); b.Compute()
+        ptr, nbytes = a.image_device_ptr(0)
+        assert (bits(read_device_image(a, ptr, nbytes, (h, w, 4))) == bits(b.Result)).all()
+        a.Dispose(); b.Dispose()
