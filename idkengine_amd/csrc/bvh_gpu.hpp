@@ -208,6 +208,9 @@ __global__ __launch_bounds__(CH) void k_chunk_cost(const HNodeG* nodes, Level L,
         const float lcost = half_area(p) * (float)(pos - start + 1);
         cost = lcost + rc[(size_t)axis * n + pos + 1];
         cpos = pos + 1;                                        // the split index: first position of the right part
+        // the CPU sweep only ever accepts `cost < bestCost` with bestCost <= FLT_MAX: a NaN (inf - inf of non-finite fragment boxes), +inf or FLT_MAX
+        // cost is never chosen there.  Here a NaN sitting in a reduction slot would never be displaced (c2 < NaN is false): map all of them to "invalid".
+        if (!(cost < 3.402823466e+38f)) { cost = 3.402823466e+38f; cpos = 0x7fffffff; }
     }
     shc[t] = cost; shp[t] = cpos;
     __syncthreads();

@@ -1,0 +1,88 @@
+"""Parity at the scale of BASELINE.json's other configurations (VERDICT r2 "missing 3"): what the 1M-triangle headline tests do not reach.
+
+  * configs[3] "ray-sort on" beyond 2^21 triangles: the reference masks its sort key to 21 bits (NHit/compute.glsl:81, PREFIX_SUM_BIT_CAPACITY), so
+    triangle ids alias — the sort stays a stable counting sort of the ALIASED keys and both sides must agree on it;
+  * configs[4] (Bistro stand-in): 3840x2160, 4 spp, RayDepth 9 on a 4M-triangle scene;
+  * configs[1] (Sponza stand-in): the procedural atrium at the sizes bench.py times it, 1920x1080, RayDepth 5 (262 k triangles) and 2 (1 M).
+
+Whole frames at these sizes would take the CPU oracle minutes, so both sides render the SAME row shard (idkptSetRowSharding: rows y % m == r; the
+reference's slot numbering — and with it every RNG stream beyond the first bounce — is a function of the rows that are rendered, so the shard must
+be rendered as a shard on both sides, not cut out of a full frame).  Everything is compared bit for bit: image, ray state, alive queue, ray and
+visit counters."""
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden")); sys.path.insert(0, HERE)
+import configs  # noqa: E402
+from idkengine_amd import scenes as S  # noqa: E402
+from idkengine_amd import gputypes as T  # noqa: E402
+from gpu_helpers import bits  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _shard_pair(oracle_mod, sc, cam, w, h, mod, rem, frames, batch, counters=True, **ov):
+    from idkengine_amd.pathtracer import PathTracer
+    pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov), row_modulo=mod, row_remainder=rem)
+    pt.UploadScene(sc); pt.SetCamera(cam); pt.enable_counters(counters); pt.enable_primary_hit_capture(True); pt.set_max_batch(batch)
+    o = oracle_mod.OraclePathTracer(sc, w, h, row_modulo=mod, row_remainder=rem); o.set_camera(cam)
+    configs.apply_settings(o.settings, ov); o.enable_counters(True)
+    for _ in range(frames):
+        pt.Compute(); o.render()
+    return pt, o
+
+
+def _assert_shard_equal(pt, o, counters=True):
+    assert (bits(pt.Result) == bits(o.image(0))).all()
+    assert pt.rays().tobytes() == o.rays().tobytes()
+    assert (pt.alive_queue() == o.alive_queue()).all()
+    gs, os_ = pt.stats(), o.stats()
+    assert gs["rays_traced"] == os_["rays_traced"]
+    if counters:
+        assert gs["node_pair_visits"] == os_["node_pair_visits"] and gs["triangle_tests"] == os_["triangle_tests"]
+
+
+def test_ray_sorting_with_aliased_keys_beyond_2_21_triangles(oracle_mod, native_builder):
+    """2.3 M triangles (> 2^21 = 2 097 152): BLAS triangle ids 2^21 ... alias ids 0 ... in the 21-bit sort key.  DoRaySorting on, RayDepth 5,
+    two accumulated samples in one batch (the sample index sits above the 21 key bits), camera inside so that every pixel has a path."""
+    sc = S.soup_scene(2_300_000, native_builder, seed=2)
+    assert len(sc.blas_triangles) > (1 << 21)
+    w, h = 1920, 1080; cam = S.Camera(w, h, position=(0.0, 0.0, 0.0))
+    pt, o = _shard_pair(oracle_mod, sc, cam, w, h, 16, 5, frames=2, batch=2, RayDepth=5, DoRaySorting=1)
+    _, tri, _ = pt.primary_hits()
+    hit = tri[tri != 0xFFFFFFFF]
+    assert (hit >= (1 << 21)).any() and (hit < (1 << 21)).any()          # both halves of the alias classes are actually hit
+    _assert_shard_equal(pt, o)
+    # sorting must have done something: the same shard without sorting ends in another state (slot-seeded RNG streams)
+    pt2, o2 = _shard_pair(oracle_mod, sc, cam, w, h, 16, 5, frames=2, batch=2, RayDepth=5, DoRaySorting=0)
+    _assert_shard_equal(pt2, o2)
+    assert pt2.rays().tobytes() != pt.rays().tobytes()
+    for x in (pt, o, pt2, o2):
+        (x.Dispose if hasattr(x, "Dispose") else x.close)()
+
+
+def test_config4_4k_4spp_depth9_on_4m_triangles(oracle_mod, native_builder):
+    """BASELINE.json configs[4] stand-in (the Bistro mesh is not in the reference checkout): soup-4M, 3840x2160, 4 spp, RayDepth 9; rows y % 32 == 7."""
+    sc = S.soup_scene(4_000_000, native_builder, seed=3)
+    w, h = 3840, 2160; cam = S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(0.3, 0.1, -1.0))
+    pt, o = _shard_pair(oracle_mod, sc, cam, w, h, 32, 7, frames=1, batch=4, RayDepth=9, SamplesPerPixel=4)
+    assert pt.AccumulatedSamples == 4
+    _assert_shard_equal(pt, o)
+    pt.Dispose(); o.close()
+
+
+@pytest.mark.parametrize("tris,depth,mod,rem", [(262_000, 5, 8, 3), (1_000_000, 2, 8, 1)], ids=["atrium262k_d5", "atrium1m_d2"])
+def test_atrium_at_bench_size(tris, depth, mod, rem, oracle_mod, native_builder):
+    """The Sponza-class stand-in at the two sizes bench.py times (configs[1]: ~260 k triangles, 4 bounces; 1 M triangles, RayDepth 2), 1920x1080,
+    the bench's camera; 3 samples traced in one batch, without the counters as well (the timed kernel instantiation)."""
+    sc = S.atrium_scene(tris, native_builder)
+    w, h = 1920, 1080; cam = S.atrium_camera(w, h)
+    pt, o = _shard_pair(oracle_mod, sc, cam, w, h, mod, rem, frames=3, batch=3, RayDepth=depth)
+    _assert_shard_equal(pt, o)
+    pt.Dispose()
+    pt, o2 = _shard_pair(oracle_mod, sc, cam, w, h, mod, rem, frames=3, batch=3, counters=False, RayDepth=depth)
+    _assert_shard_equal(pt, o2, counters=False)
+    pt.Dispose(); o.close(); o2.close()

@@ -37,6 +37,9 @@ def random_material(rng):
 
 
 def random_scene(rng, builder):
+    # now and then (FUZZ_P_BIG, default 1.5 % of the cases; 10+ s each) the first mesh has more than 2^21 triangles: triangle ids beyond the 21 bits
+    # the reference's sort key keeps (NHit/compute.glsl:81) and beyond what most index arithmetic of small scenes ever sees
+    big = rng.random() < float(os.environ.get("FUZZ_P_BIG", "0.015"))
     nb = int(rng.integers(1, 5))
     extent = float(rng.choice([1.5, 4.0, 10.0]))
     use_tex = rng.random() < 0.3
@@ -45,7 +48,10 @@ def random_scene(rng, builder):
         meshes = []
         for _ in range(int(rng.integers(1, 4))):
             n = int(rng.choice([1, 2, 7, 60, 400, 3000]))
-            p, i, nrm, tan = S.flat_shaded(S.soup_triangles(n, int(rng.integers(1, 1 << 30)), extent, float(rng.choice([0.15, 0.6, 2.0]))))
+            edge = float(rng.choice([0.15, 0.6, 2.0]))
+            if big and k == 0 and not meshes:
+                n, edge = 2_150_000, 0.02 * extent
+            p, i, nrm, tan = S.flat_shaded(S.soup_triangles(n, int(rng.integers(1, 1 << 30)), extent, edge))
             mat = random_material(rng)
             uvs = None; kw = None
             if use_tex:
@@ -88,7 +94,11 @@ def one_case(seed, builder):
     if rng.random() < 0.3: ov.update(FocalLength=float(rng.uniform(0.5, 2.0) * extent), LenseRadius=float(rng.uniform(0.005, 0.05) * extent))
     frames = int(rng.integers(1, 6)); batch = int(rng.choice([1, 2, 5, 8]))
     st = configs.apply_settings(T.Settings.default(), ov)
-    pt = PathTracer(w, h, settings=st); pt.UploadScene(sc); pt.SetCamera(cam); pt.enable_primary_hit_capture(True); pt.set_max_batch(batch)
+    opts = {"node_layout": int(rng.choice([0, 0, 1, 2])), "treelet_depth": int(rng.integers(1, 6)), "trace_order": int(rng.choice([0, 0, 1, 2]))}   # free choices of the implementation: never visible in the output
+    pt = PathTracer(w, h, settings=st)
+    for k_, v_ in opts.items():
+        pt.set_option(k_, v_)
+    pt.UploadScene(sc); pt.SetCamera(cam); pt.enable_primary_hit_capture(True); pt.set_max_batch(batch)
     o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov)
     for _ in range(frames):
         pt.Compute(); o.render()
@@ -103,7 +113,7 @@ def one_case(seed, builder):
     if pt.stats()["rays_traced"] != o.stats()["rays_traced"]: bad.append("ray count")
     rays = pt.stats()["rays_traced"]
     pt.Dispose()
-    print(f"seed {seed}: {w}x{h} blases {nb} tris {len(sc.blas_triangles)} {ov} frames {frames} batch {batch} rays {rays}: {'OK' if not bad else 'MISMATCH ' + ', '.join(bad)}", flush=True)
+    print(f"seed {seed}: {w}x{h} blases {nb} tris {len(sc.blas_triangles)} {ov} {opts} frames {frames} batch {batch} rays {rays}: {'OK' if not bad else 'MISMATCH ' + ', '.join(bad)}", flush=True)
     return not bad
 
 
