@@ -129,10 +129,10 @@ def main():
     if rank == 0:
         if args.cpu_build:
             builder = NativeBuilder()
-        else:   # SweepSAH core on the GPU (idkptBuildBlasCore), PreSplit and the tail passes in libidkbvh: same bytes as the CPU build
-            from idkengine_amd.bvh import GpuBuilder
+        else:   # the whole BLAS build on the GPU (idkptBuildBlas: PreSplit, SweepSAH, stack-size optimisation, compaction, un-indexing): same bytes as the CPU build
+            from idkengine_amd.bvh import DeviceBuilder
             from idkengine_amd.pathtracer import PathTracer as _PT
-            _bpt = _PT(8, 8); builder = GpuBuilder(_bpt); builder_kind = "gpu-core"
+            _bpt = _PT(8, 8); builder = DeviceBuilder(_bpt); builder_kind = "device (idkptBuildBlas)"
         scene = S.soup_scene(args.tris, builder, seed=1) if args.scene == "soup" else S.atrium_scene(args.tris, builder)
         blas_build_ms = round(builder.last_build_ms, 1)
         if not args.cpu_build:

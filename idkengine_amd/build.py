@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_HERE, "..", "include")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fvisibility=hidden"]   # (-munsafe-fp-atomics: native f64 atomic adds for the builder's per-depth sums; no other floating-point atomics exist in the library)
 GXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse4.1", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-pthread"]
 
 

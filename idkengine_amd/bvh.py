@@ -148,3 +148,34 @@ class GpuBuilder(NativeBuilder):
                     "sah": info.Sah, "fragments": info.FragmentCount, "build_ms": info.BuildMs}
         finally:
             L.idkbvhBlasFree(h)
+
+
+class BlasBuildInfo(C.Structure):
+    _fields_ = [("NodeCount", C.c_int32), ("TriangleCount", C.c_int32), ("RequiredStackSize", C.c_int32), ("ParentIndexCount", C.c_int32), ("LeafIndexCount", C.c_int32),
+                ("FragmentCount", C.c_int32), ("Levels", C.c_int32), ("_pad", C.c_int32), ("Sah", C.c_double), ("BuildMs", C.c_double)]
+
+
+class DeviceBuilder(NativeBuilder):
+    """The whole BLAS build on the GPU (idkptBuildBlas / idkptBuildBlasFetch, csrc/bvh_gpu_full.hpp): PreSplit, SweepSAH, stack-size optimisation,
+    compaction, un-indexing, parent / leaf indices.  Same bytes as NativeBuilder (tests/test_gpu_builder.py).  TLAS build and refit stay the
+    inherited host routines.  `pt` is any idkengine_amd.pathtracer.PathTracer (only its context handle is used)."""
+
+    def __init__(self, pt, presplit_factor=0.3, threads=0):
+        super().__init__(presplit_factor, threads)
+        self._pt = pt
+        self.last_levels = 0
+
+    def build_blas(self, positions, tris, refittable):
+        import time
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3); tris = np.ascontiguousarray(tris)
+        info = BlasBuildInfo()
+        t0 = time.perf_counter()
+        self._pt._check(self._pt._L.idkptBuildBlas(self._pt._ctx, positions.ctypes.data, len(positions), tris.ctypes.data, len(tris), 1 if refittable else 0,
+                                                   C.c_float(self.presplit_factor), C.addressof(info)))
+        out_nodes = np.empty(info.NodeCount, T.GpuBlasNode); out_tris = np.empty(info.TriangleCount, T.GpuBlasTriangle)
+        parents = np.empty(info.ParentIndexCount, np.int32); leaves = np.empty(info.LeafIndexCount, np.int32)
+        self._pt._check(self._pt._L.idkptBuildBlasFetch(self._pt._ctx, out_nodes.ctypes.data, out_tris.ctypes.data, parents.ctypes.data if len(parents) else None,
+                                                        leaves.ctypes.data if len(leaves) else None))
+        self.last_build_ms = (time.perf_counter() - t0) * 1e3; self.last_levels = info.Levels; self.last_device_ms = info.BuildMs
+        return {"nodes": out_nodes, "triangles": out_tris, "parents": parents, "leaves": leaves, "required_stack_size": info.RequiredStackSize,
+                "sah": info.Sah, "fragments": info.FragmentCount, "build_ms": self.last_build_ms}

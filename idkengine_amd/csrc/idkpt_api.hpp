@@ -373,6 +373,21 @@ int32_t idkptBuildBlasCore(idkpt_ctx* c, const float* fragmentBoxes, int32_t fra
     const int rc = dev_BuildBlasCore(m, fragmentBoxes, fragmentCount, outNodes, outSortedIdsX, outLevels);
     return rc ? mfail(c, m, rc) : IDKPT_OK;
 }
+int32_t idkptBuildBlas(idkpt_ctx* c, const float* positions, int32_t vertexCount, const GpuBlasTriangle* triangles, int32_t triangleCount, int32_t isRefittable, float preSplitFactor, idkpt_blas_build_info* outInfo)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    dev_ctx* m = c->dev[0];                                     // a host-side service like idkptBuildBlasCore: first device, no scene state
+    const int rc = dev_BuildBlas(m, positions, vertexCount, triangles, triangleCount, isRefittable, preSplitFactor, outInfo);
+    return rc ? mfail(c, m, rc) : IDKPT_OK;
+}
+int32_t idkptBuildBlasFetch(idkpt_ctx* c, GpuBlasNode* outNodes, GpuBlasTriangle* outTriangles, int32_t* outParentIndices, int32_t* outLeafIndices)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    dev_ctx* m = c->dev[0];
+    const int rc = dev_BuildBlasFetch(m, outNodes, outTriangles, outParentIndices, outLeafIndices);
+    return rc ? mfail(c, m, rc) : IDKPT_OK;
+}
+int32_t idkptCbrtProbe(idkpt_ctx* c, const float* in, float* out, int32_t n) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; dev_ctx* m = c->dev[0]; const int rc = dev_CbrtProbe(m, in, out, n); return rc ? mfail(c, m, rc) : IDKPT_OK; }
 int32_t idkptUploadUnskinnedVertices(idkpt_ctx* c, const GpuUnskinnedVertex* verts, int32_t count) { REPLICATE(UploadUnskinnedVertices, verts, count); }
 int32_t idkptSkin(idkpt_ctx* c, uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count) { REPLICATE(Skin, inOff, outOff, jointOff, count); }
 int32_t idkptDownloadBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, void* dst)

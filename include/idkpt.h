@@ -210,6 +210,23 @@ IDKPT_API int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius);
  * into it): exactly the two arrays idkbvhBlasCoreSet takes, byte-identical to idkbvhBlasCoreCpu's.  A host-side service: it uses the context's
  * first device and stream, needs no uploaded scene and changes none.  outLevels (may be NULL): depth of the recursion. */
 IDKPT_API int32_t idkptBuildBlasCore(idkpt_ctx* ctx, const float* fragmentBoxes, int32_t fragmentCount, GpuBlasNode* outNodes, int32_t* outSortedIdsX, int32_t* outLevels);
+/* The WHOLE BLAS build of one geometry on the device — what BVH.BlasesBuild does per BLAS on the CPU (Bvh/BVH.cs:311-371):
+ * PreSplitting.PreSplit (or one box per triangle when isRefittable), BLAS.GetBuildData + BLAS.Build incl. OptimizeStackSize and
+ * RemoveEmptySubtrees, GetUnindexedTriangles, GetParentIndices / GetLeafIndices (refittable only), ComputeGlobalSAH.  positions: vertexCount x 3
+ * floats; triangles: vertex ids into positions (+ MeshId, copied through).  The results stay on the device until idkptBuildBlasFetch copies them
+ * into host arrays sized from outInfo (one build per context at a time).  Output bytes are those of libidkbvh's idkbvhBuildBlas (and therefore of
+ * the reference's builder as far as that is pinned); nodes carry BLAS-local indices like BLAS.Build's.  A host-side service like
+ * idkptBuildBlasCore: first device of the context, no scene needed, none touched. */
+typedef struct idkpt_blas_build_info {
+    int32_t NodeCount, TriangleCount, RequiredStackSize, ParentIndexCount, LeafIndexCount, FragmentCount, Levels, _pad;
+    double Sah;      /* ComputeGlobalSAH of the finished tree (parallel binary64 sum: equal to the reference's tree-order sum up to rounding) */
+    double BuildMs;  /* wall time of the call, transfers of the inputs included */
+} idkpt_blas_build_info;
+IDKPT_API int32_t idkptBuildBlas(idkpt_ctx* ctx, const float* positions, int32_t vertexCount, const GpuBlasTriangle* triangles, int32_t triangleCount, int32_t isRefittable,
+                                 float preSplitFactor, idkpt_blas_build_info* outInfo);
+IDKPT_API int32_t idkptBuildBlasFetch(idkpt_ctx* ctx, GpuBlasNode* outNodes, GpuBlasTriangle* outTriangles, int32_t* outParentIndices, int32_t* outLeafIndices);
+/* test hook: the device cbrtf behind PreSplit's priorities (glibc 2.35's algorithm) on n inputs, for comparison with the host's cbrtf */
+IDKPT_API int32_t idkptCbrtProbe(idkpt_ctx* ctx, const float* in, float* out, int32_t n);
 /* BVH.GpuBlasesRefit(blasId,1) (Bvh/BVH.cs:472-489, Shaders/BLASRefit/compute.glsl) */
 IDKPT_API int32_t idkptRefitBlas(idkpt_ctx* ctx, int32_t blasId);
 /* ModelManager skinning dispatch (ModelManager.cs:326-353, Shaders/Skinning/compute.glsl):

@@ -149,3 +149,20 @@ def test_tlas_structure(native_builder):
     leaves = sorted(int(x & 0x7FFFFFFF) for x in t["IsLeafAndChildOrInstanceId"] if x >> 31)
     assert leaves == list(range(len(sc.blas_instances)))
     assert t[0]["IsLeafAndChildOrInstanceId"] >> 31 == 0                     # root = node 0, internal
+
+
+def test_cbrt_twin_of_the_device_equals_the_hosts_cbrtf(tmp_path):
+    """PreSplit's priorities take a cube root (PreSplitting.cs:134, MathF.Cbrt = the C runtime's cbrtf; libidkbvh calls the same function).  The GPU
+    build evaluates glibc 2.35's algorithm itself (csrc/bvh_gpu_full.hpp: dev_cbrtf); tests/c_driver/cbrt_check.c is its CPU twin, held here to the
+    host's cbrtf on every 61st of the 2^32 bit patterns (all of them with IDKPT_CBRT_EXHAUSTIVE=1: 0 mismatches on this image).  A host whose libm
+    rounds cbrtf differently fails here first — and would also make the CPU and GPU builders disagree on split counts."""
+    import ctypes as C
+    import subprocess
+    so = tmp_path / "libcbrtcheck.so"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_driver", "cbrt_check.c"), "-o", str(so), "-lm"])
+    L = C.CDLL(str(so))
+    L.twin_vs_host_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_long, C.POINTER(C.c_uint32)]; L.twin_vs_host_mismatches.restype = C.c_long
+    stride = 1 if os.environ.get("IDKPT_CBRT_EXHAUSTIVE") == "1" else 61
+    first_bad = C.c_uint32(0)
+    bad = L.twin_vs_host_mismatches(0, stride, (1 << 32) // stride, C.byref(first_bad))
+    assert bad == 0, hex(first_bad.value)

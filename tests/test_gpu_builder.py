@@ -97,3 +97,89 @@ def test_level_synchronous_and_per_thread_paths_agree(small, native_builder, mon
             a = gb.build_blas(positions, tris, refittable); b = native_builder.build_blas(positions, tris, refittable)
             assert a["nodes"].tobytes() == b["nodes"].tobytes() and a["triangles"].tobytes() == b["triangles"].tobytes()
     pt.Dispose()
+
+
+# ---- idkptBuildBlas: the whole build on the device (csrc/bvh_gpu_full.hpp)
+
+FULL_CASES = dict(CASES)
+FULL_CASES["soup1"] = lambda b: S.soup_scene(1, b)
+FULL_CASES["soup1_refit"] = lambda b: S.soup_scene(1, b, refittable=True)            # single-leaf root duplicated into nodes 2, 3
+FULL_CASES["soup2"] = lambda b: S.soup_scene(2, b)
+FULL_CASES["soup3"] = lambda b: S.soup_scene(3, b, seed=5)
+FULL_CASES["soup300k_refit"] = lambda b: S.soup_scene(300000, b, seed=12, refittable=True)   # stack optimisation (>= 16) without PreSplit
+FULL_CASES["atrium300k"] = lambda b: S.atrium_scene(300000, b)
+
+
+@pytest.mark.parametrize("name", list(FULL_CASES))
+def test_device_build_equals_native_build(name, native_builder):
+    """PreSplit (device cbrtf, split counts, grid splits), SweepSAH, OptimizeStackSize (parallel sums + the reference's decisions), RemoveEmptySubtrees
+    as a stream compaction, both un-indexing variants, parent / leaf indices: every output array byte for byte, RequiredStackSize and the fragment
+    count exactly, the SAH to rounding (a parallel binary64 sum)."""
+    from idkengine_amd.bvh import DeviceBuilder
+    from idkengine_amd.pathtracer import PathTracer
+    cap = _Capture(native_builder)
+    FULL_CASES[name](cap)
+    pt = PathTracer(8, 8)
+    db = DeviceBuilder(pt)
+    assert cap.calls
+    for positions, tris, refittable in cap.calls:
+        a = db.build_blas(positions, tris, refittable); b = native_builder.build_blas(positions, tris, refittable)
+        assert a["fragments"] == b["fragments"] and a["required_stack_size"] == b["required_stack_size"], (a["fragments"], b["fragments"], a["required_stack_size"], b["required_stack_size"])
+        for k in ("nodes", "triangles", "parents", "leaves"):
+            assert a[k].shape == b[k].shape, (k, a[k].shape, b[k].shape)
+            assert a[k].tobytes() == b[k].tobytes(), k
+        assert abs(a["sah"] - b["sah"]) <= 1e-12 * abs(b["sah"])
+    pt.Dispose()
+
+
+def test_device_cbrtf_equals_host_cbrtf(tmp_path):
+    """The device's cbrtf (glibc 2.35's algorithm in binary64 steps) against the host's, bit for bit, on 6 M inputs: a stride through all bit patterns
+    (every exponent, subnormals, negatives, zeros, infinities, NaNs) and the magnitudes PreSplit priorities have."""
+    import ctypes as C
+    import subprocess
+    from idkengine_amd.pathtracer import PathTracer
+    so = tmp_path / "libcbrtcheck.so"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", os.path.join(HERE, "c_driver", "cbrt_check.c"), "-o", str(so), "-lm"])
+    L = C.CDLL(str(so)); L.host_cbrtf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+    rng = np.random.default_rng(2)
+    x = np.concatenate([np.arange(0, 1 << 32, 1021, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                        (rng.uniform(0, 1, 1 << 21).astype(np.float32) ** 3 * np.float32(1e-3)), np.float32([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, 8.0, 27.0, 1e-45, -1e-45])])
+    x = np.ascontiguousarray(x, np.float32)
+    want = np.empty_like(x); L.host_cbrtf_array(x.ctypes.data, want.ctypes.data, len(x))
+    pt = PathTracer(8, 8)
+    got = np.empty_like(x)
+    pt._check(pt._L.idkptCbrtProbe(pt._ctx, x.ctypes.data, got.ctypes.data, len(x)))
+    pt.Dispose()
+    nan = np.isnan(want)
+    assert (np.isnan(got) == nan).all()
+    assert (got.view(np.uint32)[~nan] == want.view(np.uint32)[~nan]).all()
+
+
+def test_device_build_signed_zeros_and_degenerate_inputs(native_builder):
+    """Signed zeros (minps / maxps tie rule in the scene box, the triangle boxes and the clipped split boxes), identical triangles (every cost ties,
+    the tree degenerates into a chain: deep enough for the stack optimisation), zero-area triangles (priority 0, cbrt(0))."""
+    from idkengine_amd.bvh import DeviceBuilder
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    rng = np.random.default_rng(14)
+    pt = PathTracer(8, 8); db = DeviceBuilder(pt)
+    sets = []
+    n = 3000
+    p = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32)
+    p[::3, :, 0] = np.where(rng.random((len(p[::3]), 3)) < 0.5, np.float32(0.0), np.float32(-0.0))
+    p[1::7, 0, 1] = np.float32(-0.0); p[2::5, 1, 2] = np.float32(0.0)
+    sets.append(p)
+    q = np.repeat(rng.uniform(-1, 1, (1, 3, 3)).astype(np.float32), 40, axis=0)          # 40 identical triangles
+    sets.append(q)
+    z = rng.uniform(-1, 1, (500, 3, 3)).astype(np.float32); z[::4, 2] = z[::4, 1]           # every 4th triangle has zero area
+    z[5] *= np.float32(40.0)                                                                 # and one is large: many splits
+    sets.append(z)
+    for tri_pos in sets:
+        positions = tri_pos.reshape(-1, 3); m = len(tri_pos)
+        tris = np.zeros(m, T.GpuBlasTriangle); tris["X"] = np.arange(m) * 3; tris["Y"] = tris["X"] + 1; tris["Z"] = tris["X"] + 2
+        for refittable in (True, False):
+            a = db.build_blas(positions, tris, refittable); b = native_builder.build_blas(positions, tris, refittable)
+            assert a["fragments"] == b["fragments"] and a["required_stack_size"] == b["required_stack_size"]
+            for k in ("nodes", "triangles", "parents", "leaves"):
+                assert a[k].tobytes() == b[k].tobytes(), (k, m, refittable)
+    pt.Dispose()
