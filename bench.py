@@ -333,7 +333,7 @@ def pmc_passes(args, launches):
     try:
         for name, ctrs in sets.items():
             d = os.path.join(tmp, name)
-            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "b", "--"] + child, capture_output=True, text=True, timeout=420, env=env, cwd="/tmp")
+            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "b", "--"] + child, capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None

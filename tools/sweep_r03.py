@@ -17,6 +17,8 @@ CONFIGS = [("reference order, queue order", {"IDKPT_NODE_LAYOUT": 0, "IDKPT_TRAC
            ("reference order, trace order", {"IDKPT_NODE_LAYOUT": 0, "IDKPT_TRACE_ORDER": 2}),
            ("couples depth-first, trace order", {"IDKPT_NODE_LAYOUT": 1, "IDKPT_TRACE_ORDER": 2}),
            ("couples treelets(3), trace order", {"IDKPT_NODE_LAYOUT": 2, "IDKPT_TREELET_DEPTH": 3, "IDKPT_TRACE_ORDER": 2})]
+if os.environ.get("SWEEP_ONLY_REF") == "1":      # A/B of whole libraries (IDKPT_LIB_PATH): the default configuration only
+    CONFIGS = [("default options", {})]
 DEPTHS = [int(d) for d in os.environ.get("SWEEP_DEPTHS", "2,5").split(",")]
 BATCHES = [int(b) for b in os.environ.get("SWEEP_BATCHES", "32,1").split(",")]
 
@@ -33,7 +35,7 @@ if __name__ == "__main__":
                 frames = (96 if batch > 1 else 30) if depth <= 2 else (64 if batch > 1 else 20)
                 ref = None
                 for label, env in CONFIGS:
-                    if batch == 1 and env["IDKPT_TRACE_ORDER"] and env["IDKPT_NODE_LAYOUT"] == 2:
+                    if batch == 1 and env.get("IDKPT_TRACE_ORDER") and env.get("IDKPT_NODE_LAYOUT") == 2:
                         continue
                     r, img, rays = run(sc, cam, 100, batch, frames, depth=depth, env=env)
                     if ref is None:
