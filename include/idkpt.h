@@ -201,7 +201,11 @@ IDKPT_API int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count);
 IDKPT_API int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCount);
 /* BVH.TlasBuild + TLAS.Build (Bvh/BVH.cs:278-298, Bvh/TLAS.cs:28-141) done on the device from the resident BLAS roots, instances
  * and mesh transforms (after idkptUpdateBuffer(MESH_TRANSFORMS)/idkptRefitBlas): no host round trip per animated frame.
- * Node array is bit-identical to the serial host build.  searchRadius: TLAS.BuildSettings.SearchRadius (reference: 15). */
+ * Node array is bit-identical to the serial host build.  searchRadius: TLAS.BuildSettings.SearchRadius (reference: 15).
+ * The depth of a device-built TLAS is not known to the host: the per-lane TLAS stack gets min(instanceCount, 32) rows (the reference's
+ * TLAS_STACK_SIZE), and a tree deeper than that sets the device-side overflow flag — reported as IDKPT_ERR_INVALID_OPERATION by the next
+ * idkptSynchronize / idkptDownload* / idkptGetStats and, for batches that have already finished, by idkptGetImageDevicePtr /
+ * idkptGetFrameDevicePtr.  A zero-copy consumer of those pointers must call idkptSynchronize once per scene change to see it. */
 IDKPT_API int32_t idkptBuildTlasOnDevice(idkpt_ctx* ctx, int32_t searchRadius);
 /* The SweepSAH core of the BLAS build on the GPU: BLAS.GetBuildData + the recursion of BLAS.Build / TrySplit
  * (Bvh/BLAS.cs:128-243, 730-873) over `fragmentCount` boxes (8 floats each: min.xyz, pad, max.xyz, pad — what libidkbvh's idkbvhBlasFragments
