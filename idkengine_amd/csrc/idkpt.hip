@@ -55,6 +55,7 @@ struct DevOptions {
     int traceOrder = 0;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order (default: L2 hit rate 0.62 -> 0.88, launch -7 %, the permutation costs more), 1 = batches of >= 4 samples, 2 = always
     int traceVariant = 0;        // IDKPT_DEVELOPER builds only: instrumented / probe instantiations of k_trace2
     int bvhTiming = 0, bvhSmall = 32;   // idkptBuildBlasCore: phase times on stderr; subtrees of at most this many fragments are finished by one thread
+    int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
 };
 
 struct PendingSample { uint32_t accum; int slot; float cam[36]; };   // cam = invProj[16] invView[16] viewPos[3] pad
@@ -745,6 +746,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "grid_hint") o.gridHint = std::max(0, value);
     else if (n == "bvh_timing") o.bvhTiming = value != 0;
     else if (n == "bvh_small") o.bvhSmall = value;
+    else if (n == "bvh_stackopt_host") o.bvhStackOptHost = value != 0;
     else if (n == "force_no_peer") { }                 // (multi-device contexts: idkpt_api.hpp; nothing to stage on one device)
     else if (n == "trace_variant") {
 #ifdef IDKPT_DEVELOPER
@@ -1125,7 +1127,7 @@ static int32_t dev_BuildBlas(dev_ctx* ctx, const float* positions, int32_t verte
         // replay of the loop of BLAS.cs:882-894 on the sums.  The reference adds the same terms one by one in tree order; two binary64 summation
         // orders of N terms differ by at most ~2 N u sum|t| (u = 2^-53), so `inc <= acceptance` is decided here only outside that margin (x 8).
         const double accept = (double)0.0009745f, u = 1.1102230246251565e-16;
-        bool certain = maxDepth < OPT_MAX_DEPTH && requiredStack - 1 < OPT_MAX_DEPTH;
+        bool certain = maxDepth < OPT_MAX_DEPTH && requiredStack - 1 < OPT_MAX_DEPTH && !ctx->opt.bvhStackOptHost;
         const double current = bins[0]; double added = bins[1], addedAbs = bins[2], nTerms = (double)nodeCount;
         int rs = requiredStack, sLast = 0x7fffffff;
         auto decide = [&](bool& le) {

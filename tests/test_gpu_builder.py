@@ -183,3 +183,39 @@ def test_device_build_signed_zeros_and_degenerate_inputs(native_builder):
             for k in ("nodes", "triangles", "parents", "leaves"):
                 assert a[k].tobytes() == b[k].tobytes(), (k, m, refittable)
     pt.Dispose()
+
+
+@pytest.mark.parametrize("factor", [0.0, 0.3, 1.0, 2.5])
+def test_device_build_presplit_factors(factor, native_builder):
+    """PreSplitting.Settings.SplitFactor other than the default (the reference suggests 1.0 for Bistro, BLAS.cs:33-35): split counts, and with them every
+    fragment, follow the factor on both builders."""
+    from idkengine_amd.bvh import DeviceBuilder, NativeBuilder
+    from idkengine_amd.pathtracer import PathTracer
+    nb = NativeBuilder(presplit_factor=factor)
+    pt = PathTracer(8, 8); db = DeviceBuilder(pt, presplit_factor=factor)
+    for make in (configs.lucy_scene, configs.helmet_scene, lambda b: S.presplit_scene(b)):
+        cap = _Capture(nb); make(cap)
+        for positions, tris, refittable in cap.calls:
+            a = db.build_blas(positions, tris, refittable); b = nb.build_blas(positions, tris, refittable)
+            assert a["fragments"] == b["fragments"] and a["required_stack_size"] == b["required_stack_size"]
+            for k in ("nodes", "triangles"):
+                assert a[k].tobytes() == b[k].tobytes(), (k, factor)
+    pt.Dispose()
+
+
+def test_device_build_stack_optimisation_fallback_path(native_builder, monkeypatch):
+    """OptimizeStackSize is decided on the device from parallel sums with an error bound; a decision inside the bound would fall back to the reference's own
+    serial walk on a host copy of the tree.  That has never happened, so the path is forced here ("bvh_stackopt_host") on trees that need the optimisation
+    (RequiredStackSize >= 16 before it): same bytes as the normal path and as the host builder."""
+    from idkengine_amd.bvh import DeviceBuilder
+    from idkengine_amd.pathtracer import PathTracer
+    pt = PathTracer(8, 8); db = DeviceBuilder(pt)
+    pt.set_option("bvh_stackopt_host", 1)
+    for make in (lambda b: S.soup_scene(60000, b, seed=4), lambda b: S.soup_scene(200000, b, seed=8, refittable=True), configs.helmet_scene):
+        cap = _Capture(native_builder); make(cap)
+        for positions, tris, refittable in cap.calls:
+            a = db.build_blas(positions, tris, refittable); b = native_builder.build_blas(positions, tris, refittable)
+            assert a["required_stack_size"] == b["required_stack_size"]
+            for k in ("nodes", "triangles", "parents", "leaves"):
+                assert a[k].tobytes() == b[k].tobytes(), k
+    pt.Dispose()
