@@ -1511,7 +1511,7 @@ static int flush_batch(dev_ctx* ctx)
                 hipLaunchKernelGGL(k_classify_tiles, dim3((genWaves + 255) / 256, classSets), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
                 tileClass = ctx->tileClass.as<uint8_t>();
             }
-            hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 16 * GEN_TG - 1) / (16 * GEN_TG)), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
+            hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
             TRACE_T0();
             launch_trace2<true>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();

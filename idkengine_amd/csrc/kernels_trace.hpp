@@ -1,7 +1,6 @@
 // kernels_trace.hpp — traversal kernels: thread-per-ray general kernels (k_trace_primary / k_trace_queue), coherent primary-ray generation with pre-cull (k_gen_primary) and the persistent while-while kernel k_trace2 (BVHIntersect.glsl:27-105, 183-291).
 // Part of the single translation unit idkpt.hip (included there, in this order); see DESIGN.md §4 for the kernel table.
 #pragma once
-#define GEN_TG 4u               // sub-groups of 16 tiles per workgroup of k_gen_primary (one append atomic per workgroup)
 
 // FirstHit part 1: ray generation + closest-hit trace of the primary rays (FirstHit/compute.glsl:44-77,100-106).
 // Persistent waves; each wave pulls packets of 64 consecutive pixels.
@@ -164,16 +163,11 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
                                                      const uint8_t* tileClass /* null: no tile pre-classification */,
                                                      int lean /* the traversal reads only the trace-ready record: k_shade_first regenerates the state of a surviving ray instead of reading it back */)
 {
-    __shared__ uint32_t waveKeep[16 * GEN_TG]; __shared__ uint32_t blockBase;
-    // grid = (samples, groups of GEN_TG x 16 tiles): the samples of one group are dispatched back to back, so the active list keeps
-    // rays of the same screen region (all samples) together -> coherent waves in the traversal kernel.  A workgroup walks its GEN_TG
-    // sub-groups of 16 tiles one after the other and appends all its survivors with ONE atomic (a single counter word takes ~88 atomics
-    // per microsecond: with one atomic per 16 tiles that was 0.7 of this kernel's time on a view where most pixels survive).
+    __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase;
+    // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
+    // rays of the same screen region (all samples) together -> coherent waves in the traversal kernel
     const uint32_t smp = blockIdx.x;                                   // sample of the batch
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t keepBits = 0, rankInWave[GEN_TG];
-    for (uint32_t g = 0; g < GEN_TG; g++) {
-    const uint32_t wave = ((blockIdx.y * GEN_TG + g) * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t wave = (blockIdx.y * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
     const uint32_t tx = wave % tilesX, ty = wave / tilesX;
     const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
@@ -243,20 +237,15 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
         contFlag[rid] = keep ? 0 : 2;       // also resets the continue flag of this ray id (k_shade_first sets 1); pad ids stay 0 from allocation
         if (!(keep && lean)) rays.rad_py[rid] = make_float4(radiance.x, radiance.y, radiance.z, pd.y);
     }
+    // append the survivors: one atomic per 16-wave workgroup (a single counter word saturates at ~88 atomics/us; one atomic per 32 / 64 / 128 waves was
+    // measured in round 3 and changes nothing: this kernel is not bound by its counter, profiles/r03_trace_experiments.md)
     const unsigned long long m = __ballot(keep);
-    if (lane == 0) waveKeep[g * 16 + wv] = (uint32_t)__popcll(m);
-    rankInWave[g] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    keepBits |= (keep ? 1u : 0u) << g;
-    }
-    // append the survivors: one atomic per workgroup, entries in (sub-group, wave, lane) order
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 0) waveKeep[wv] = (uint32_t)__popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t tot = 0; for (int i = 0; i < 16 * GEN_TG; i++) { uint32_t c = waveKeep[i]; waveKeep[i] = tot; tot += c; } blockBase = tot ? atomicAdd(activeCount, tot) : 0u; }
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (int i = 0; i < 16; i++) { uint32_t c = waveKeep[i]; waveKeep[i] = tot; tot += c; } blockBase = tot ? atomicAdd(activeCount, tot) : 0u; }
     __syncthreads();
-    for (uint32_t g = 0; g < GEN_TG; g++) if ((keepBits >> g) & 1u) {
-        const uint32_t wave = ((blockIdx.y * GEN_TG + g) * blockDim.x + threadIdx.x) >> 6, tilesX = ((uint32_t)f.W + 7) / 8;
-        const uint32_t x = (wave % tilesX) * 8 + (lane & 7), y = (wave / tilesX) * 8 + (lane >> 3);
-        activeList[blockBase + waveKeep[g * 16 + wv] + rankInWave[g]] = smp * f.Npad + y * (uint32_t)f.W + x;
-    }
+    if (keep) activeList[blockBase + waveKeep[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rid;
 }
 
 // k_trace2: persistent waves; every lane owns one ray at a time and is refilled from the work list as soon as enough
