@@ -42,6 +42,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC: without it RCCL's hipIpcGetMemHandle fails (multi-process runs)
 
 W, H = 1920, 1080
 N_TRIS = 1_000_000
