@@ -94,7 +94,8 @@ struct dev_ctx {
     idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // exact multi-GPU deep paths (idkptSetBounceExchange)
     // stats
     idkpt_stats stats;
-    uint32_t* hCounts = nullptr; // pinned
+    uint32_t* hCounts = nullptr; uint32_t* dCountsMirror = nullptr;   // host-mapped mirror of the queue lengths (written by k_scan_blocks, read by the host after a sync)
+    bool countersDirty = true;   // the batch counters were not reset by the last k_final_draw (first batch, or a batch that failed half way)
     uint32_t* hOverflow = nullptr; uint32_t* dOverflow = nullptr;   // host-mapped word the kernels set when a traversal-stack push is dropped (checked after every sync)
     int tlasNeed = 1;            // rows the TLAS walk needs (validated for host-built TLAS nodes; min(instances, TLAS_STACK_SIZE) for a device build)
     hipEvent_t evFrame[2] = {nullptr, nullptr};
@@ -102,7 +103,7 @@ struct dev_ctx {
     std::vector<hipEvent_t> evPool; size_t evUsed = 0;
     double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
     int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false, lastNeedsRegen = false; int lastBatch = 1; Frame lastFrame;
-    int maxBatch = 1; uint32_t Npad = 0; std::vector<PendingSample> pending; DevBuf bases; uint32_t* hBases = nullptr;
+    int maxBatch = 1; uint32_t Npad = 0; std::vector<PendingSample> pending; DevBuf bases, qwork; uint32_t* hBases = nullptr; uint32_t* dBasesMirror = nullptr;
     float* hCams = nullptr; hipEvent_t evCams[2] = {nullptr, nullptr}; int camHalf = 0;   // pinned, double-buffered staging of the per-sample cameras (frame ring)    // member of a multi-device context (idkpt_api.hpp): samples are only queued (the group launches all members together), per-bounce events tell
     // the members that own later rows when this member's alive counts of a bounce are final, and the group supplies the slot bases
     bool grouped = false, inGroupFlush = false; int groupIndex = 0;
@@ -189,6 +190,7 @@ static int alloc_frame_impl(dev_ctx* ctx)
     HIPC(ctx->sortHist.ensure((SORT_RADIX * nTiles + SORT_RADIX) * 4));
     for (int i = 0; i < 3; i++) { HIPC(ctx->img[i].ensure(N * 16 * ctx->ringSize)); HIPC(hipMemsetAsync(ctx->img[i].p, 0, N * 16 * ctx->ringSize, ctx->stream)); }   // slot s at offset s*N
     HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream));
+    ctx->countersDirty = true;   // (the first batch resets its counters itself)
     HIPC(hipMemsetAsync(ctx->aovA.p, 0, cap * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, cap * 16, ctx->stream));
     HIPC(hipMemsetAsync(ctx->contFlag.p, 0, cap, ctx->stream));   // per-batch values are written by k_gen_primary; the pad ids [N, Npad) must read 0
     ctx->accum.assign(ctx->ringSize, 0u); ctx->curSlot = 0; ctx->ringStarted = false;
@@ -348,11 +350,11 @@ static int32_t dev_Create(int32_t deviceCount, const int32_t* deviceIds, dev_ctx
     ctx->stCaller = ctx->st;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     memset(ctx->invProj, 0, 64); memset(ctx->invView, 0, 64); memset(ctx->viewPos, 0, 12);
-    if (hipHostMalloc((void**)&ctx->hCounts, MAX_DEPTH_SLOTS * 4 + 16, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
+    if (hipHostMalloc((void**)&ctx->hCounts, MAX_DEPTH_SLOTS * 4 + 16, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&ctx->dCountsMirror, ctx->hCounts, 0) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4 + 16);
     if (hipHostMalloc((void**)&ctx->hOverflow, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&ctx->dOverflow, ctx->hOverflow, 0) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     *ctx->hOverflow = 0;
-    if (hipHostMalloc((void**)&ctx->hBases, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4, hipHostMallocDefault) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
+    if (hipHostMalloc((void**)&ctx->hBases, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&ctx->dBasesMirror, ctx->hBases, 0) != hipSuccess) { delete ctx; return IDKPT_ERR_OUT_OF_MEMORY; }
     memset(ctx->hBases, 0, MAX_DEPTH_SLOTS * (MAX_BATCH + 1) * 4);
     (void)hipEventCreate(&ctx->evFrame[0]); (void)hipEventCreate(&ctx->evFrame[1]);
     *outCtx = ctx;
@@ -369,7 +371,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     DevBuf* all[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
                      &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
-                     &ctx->counts, &ctx->work, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
+                     &ctx->counts, &ctx->work, &ctx->qwork, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
     for (auto& t : ctx->texData) t.release();
     builder_scratch_free(ctx);
@@ -1288,7 +1290,8 @@ static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t co
     HIPC(ctx->queryIn.ensure(count * sizeof(idkpt_ray))); HIPC(ctx->queryOut.ensure(count * sizeof(idkpt_hit)));
     hipStream_t st = ctx->stream;
     HIPC(hipMemcpyAsync(ctx->queryIn.p, rays, count * sizeof(idkpt_ray), hipMemcpyHostToDevice, st));
-    uint32_t* work = ctx->work.as<uint32_t>();
+    HIPC(ctx->qwork.ensure(64));                                           // its own work-list counter: the frame's counters are reset by the frame's last kernel, not per batch
+    uint32_t* work = ctx->qwork.as<uint32_t>();
     HIPC(hipMemsetAsync(work, 0, 4, st));
     const int lights = (flags & IDKPT_TRACE_LIGHTS) ? 1 : 0;
     if (flags & IDKPT_TRACE_ANY_HIT) hipLaunchKernelGGL((k_trace_query<true>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, ctx->queryIn.as<idkpt_ray>(), ctx->queryOut.as<idkpt_hit>(), (uint32_t)count, lights, work);
@@ -1462,8 +1465,9 @@ static int flush_batch(dev_ctx* ctx)
     const int depth = ctx->st.RayDepth;
     hipStream_t st = ctx->stream;
     if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[0], st));
-    HIPC(hipMemsetAsync(work, 0, WORK_WORDS * 4, st));
-    HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st));
+    if (ctx->countersDirty) { HIPC(hipMemsetAsync(work, 0, WORK_WORDS * 4, st)); HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st)); }   // (otherwise the previous batch's k_final_draw has reset them)
+    ctx->countersDirty = true;
+    uint32_t* hostCounts = ctx->dCountsMirror; uint32_t* hostBases = ctx->dBasesMirror;
 
     f.tlasCap = std::min(TLAS_STACK_SIZE, std::max(1, ctx->tlasNeed));
     f.grabUnitLog2 = std::min(24, std::max(6, ctx->opt.grabUnitLog2)); f.grabFixed = std::max(0, ctx->opt.grabFixed);   // work-list hand-out (kernels_trace.hpp)
@@ -1530,7 +1534,8 @@ static int flush_batch(dev_ctx* ctx)
             hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
         }
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, (const uint32_t*)nullptr, total, blockSums, (const uint32_t*)waveLocal, counts + 1, (unsigned long long*)(1 < depth ? counters + 2 : nullptr),
-                           (const unsigned long long*)contMask, (const uint32_t*)nullptr, Npad, B, bases + 1 * BS);
+                           (const unsigned long long*)contMask, (const uint32_t*)nullptr, Npad, B, bases + 1 * BS,
+                           hostCounts + 1, hostBases + 1 * BS, (const uint32_t*)(counts + MAX_DEPTH_SLOTS - 1), hostCounts + MAX_DEPTH_SLOTS - 1);
         if (ctx->evBounce) HIPC(hipEventRecord(ctx->evBounce[1], st));      // bases[1] (alive counts entering bounce 1) are final
         hipLaunchKernelGGL((k_compact<true>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const unsigned long long*)contMask, (const uint32_t*)waveLocal, (const uint32_t*)blockSums,
                            (const uint32_t*)keysTmp, ctx->queue[1].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
@@ -1609,18 +1614,19 @@ static int flush_batch(dev_ctx* ctx)
                            contMask, waveCounts, keysTmp);
         hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, cnt, 0u, blockSums, (const uint32_t*)waveLocal, counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr),
-                           (const unsigned long long*)contMask, (const uint32_t*)(bases + j * BS), Npad, B, bases + (j + 1) * BS);
+                           (const unsigned long long*)contMask, (const uint32_t*)(bases + j * BS), Npad, B, bases + (j + 1) * BS,
+                           hostCounts + j + 1, hostBases + (size_t)(j + 1) * BS, (const uint32_t*)nullptr, (uint32_t*)nullptr);
         if (ctx->evBounce) HIPC(hipEventRecord(ctx->evBounce[j + 1], st));
         hipLaunchKernelGGL((k_compact<false>), dim3(gridTotal), dim3(256), 0, st, (const uint32_t*)q, cnt, 0u, (const unsigned long long*)contMask, (const uint32_t*)waveLocal, (const uint32_t*)blockSums,
                            (const uint32_t*)keysTmp, ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
         side = 1 - side;
     }
     ctx->lastQueueSide = side; ctx->lastQueueCountSlot = depth; ctx->lastFast = fast; ctx->lastNeedsRegen = fast; ctx->lastBatch = B; ctx->lastFrame = f;
-    hipLaunchKernelGGL(k_final_draw, dim3((N + 255) / 256), dim3(256), 0, st, s, f, rays, image_ptr(ctx, 0, 0), image_ptr(ctx, 1, 0), image_ptr(ctx, 2, 0), N, tileClass);
+    hipLaunchKernelGGL(k_final_draw, dim3((N + 255) / 256), dim3(256), 0, st, s, f, rays, image_ptr(ctx, 0, 0), image_ptr(ctx, 1, 0), image_ptr(ctx, 2, 0), N, tileClass,
+                       work, (uint32_t)WORK_WORDS, counts, (uint32_t)MAX_DEPTH_SLOTS);
     HIPC(hipGetLastError());
-    // queue lengths stay on the GPU during the batch; a copy goes to pinned memory for GetStats (no sync here)
-    HIPC(hipMemcpyAsync(ctx->hCounts, counts, MAX_DEPTH_SLOTS * 4, hipMemcpyDeviceToHost, st));
-    HIPC(hipMemcpyAsync(ctx->hBases, bases, MAX_DEPTH_SLOTS * BS * 4, hipMemcpyDeviceToHost, st));
+    ctx->countersDirty = false;
+    // queue lengths stay on the GPU during the batch; k_scan_blocks mirrors them into host-mapped memory for GetStats and the queue downloads (no copy, no sync here)
     if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[1], st));
     ctx->stats.Frames += (uint64_t)B;
     ctx->stats.PrimaryRays += (uint64_t)N * (uint64_t)B;

@@ -13,8 +13,12 @@ DEV f3 TurboColormap(float x)
     float b = (((v0 * 0.10667330f + v1 * 12.64194608f) + v2 * -60.58204836f) + v3 * 110.36276771f) + (w0 * -89.90310912f + w1 * 27.34824973f);
     return mk3(r, g, b);
 }
-__global__ __launch_bounds__(256) void k_final_draw(DScene s, Frame f, RayBufs rays, float4* imgResult, float4* imgAlbedo, float4* imgNormal, uint32_t N, const uint8_t* tileClass)
+__global__ __launch_bounds__(256) void k_final_draw(DScene s, Frame f, RayBufs rays, float4* imgResult, float4* imgAlbedo, float4* imgNormal, uint32_t N, const uint8_t* tileClass,
+                                                    uint32_t* zeroWork, uint32_t nWork, uint32_t* zeroCounts, uint32_t nCounts)
 {
+    // last kernel of a batch: nothing reads this batch's work-list and queue-length counters any more, so they are reset here for the next batch
+    // (two memset launches per batch less: they were 5 % of a frame that is rendered alone)
+    if (blockIdx.x == 0) { for (uint32_t k = threadIdx.x; k < nWork; k += blockDim.x) zeroWork[k] = 0u; for (uint32_t k = threadIdx.x; k < nCounts; k += blockDim.x) zeroCounts[k] = 0u; }
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     // the images of ring slot q start at q*N; samples are accumulated in submission order, exactly like consecutive FinalDraw dispatches,

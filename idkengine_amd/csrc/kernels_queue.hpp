@@ -36,7 +36,9 @@ __global__ __launch_bounds__(SCAN_WAVES_PER_BLOCK) void k_scan_local(const uint3
     if (threadIdx.x == SCAN_WAVES_PER_BLOCK - 1) blockSums[blockIdx.x] = part[threadIdx.x];
 }
 __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* countPtr, uint32_t countImm, uint32_t* blockSums, const uint32_t* waveLocal, uint32_t* nextCount, unsigned long long* tracedRays,
-                                                      const unsigned long long* contMask, const uint32_t* curBase /* null: FIRST (slots are ray ids) */, uint32_t Npad, int batch, uint32_t* nextBase)
+                                                      const unsigned long long* contMask, const uint32_t* curBase /* null: FIRST (slots are ray ids) */, uint32_t Npad, int batch, uint32_t* nextBase,
+                                                      uint32_t* hostNextCount, uint32_t* hostNextBase /* mirrors in host-mapped memory (read by the host after a synchronisation: no copy kernels) */,
+                                                      const uint32_t* activeCount, uint32_t* hostActiveCount /* FIRST only: length of the primary active list */)
 {
     __shared__ uint32_t part[1024];
     const uint32_t N = countPtr ? *countPtr : countImm;
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* countPtr, 
     for (uint32_t off = 1; off < 1024; off <<= 1) { uint32_t v = (t >= off) ? part[t - off] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
     uint32_t run = part[t] - sum;
     for (uint32_t i = b; i < e; i++) { uint32_t c = blockSums[i]; blockSums[i] = run; run += c; }   // blockSums becomes blockBase
-    if (t == 1023) { *nextCount = part[1023]; if (tracedRays) atomicAdd(tracedRays, (unsigned long long)part[1023]); }
+    if (t == 1023) { *nextCount = part[1023]; *hostNextCount = part[1023]; if (tracedRays) atomicAdd(tracedRays, (unsigned long long)part[1023]); }
+    if (t == 0 && hostActiveCount) *hostActiveCount = *activeCount;
     __threadfence_block();
     __syncthreads();
     // first slot of every sample in the NEXT queue = number of survivors in front of the sample's first current slot
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* countPtr, 
         uint32_t w = g >> 6, l = g & 63;
         uint32_t v = part[1023];
         if (w < nW) v = blockSums[w / SCAN_WAVES_PER_BLOCK] + waveLocal[w] + (uint32_t)__popcll(contMask[w] & ((1ull << l) - 1ull));
-        nextBase[t] = v;
+        nextBase[t] = v; hostNextBase[t] = v;
     }
 }
 
