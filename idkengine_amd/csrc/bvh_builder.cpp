@@ -22,6 +22,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <cmath>
 #include <memory>
 #include <utility>
 #include <sched.h>
@@ -128,6 +129,7 @@ struct Builder {
     int requiredStack = 0;
     std::atomic<int> liveThreads{0};   // workers inside buildSubtree (+2 while a node sweeps its axes on extra threads)
     int maxThreads = 1;
+    std::atomic<int> error{0};   // 3: fragment count out of range, 4: PreSplit stack (the reference throws), 5: non-finite vertex position
     // outputs
     BigVec<GpuBlasTriangle> outTris; std::vector<int> parents, leaves;
     double sah = 0.0, buildMs = 0.0;
@@ -162,8 +164,9 @@ struct Builder {
         for (int i = 0; i < triCount; i++) total += prio[i];                       // binary32 running sum in index order (PreSplitting.cs:40-48)
         std::vector<size_t> first((size_t)triCount + 1);
         size_t count = 0;
-        for (int i = 0; i < triCount; i++) { first[i] = count; count += (size_t)splitCount(prio[i], total, triCount, factor); }
+        for (int i = 0; i < triCount; i++) { first[i] = count; count += (size_t)(uint32_t)splitCount(prio[i], total, triCount, factor); }
         first[triCount] = count;
+        if (count > ((size_t)1 << 27)) { error = 3; return; }                     // (a split factor or priorities that ask for more fragments than any array here can hold)
         frag.resize(count); origTri.resize(count);
         SBox global = SBox::empty();
         for (int i = 0; i < triCount; i++) { __m128 a, b, c; triPoints(i, a, b, c); global.grow(a); global.grow(b); global.grow(c); }
@@ -209,6 +212,7 @@ struct Builder {
                 float le = lb.largestExtent(), re = rb.largestExtent();
                 int lc = satInt((float)it.splits * (le / (le + re)));
                 lc = std::min(std::max(lc, 1), it.splits - 1);
+                if (sp + 2 > 64) { error = 4; sp = 0; break; }                    // the reference's stackalloc of 64 entries (PreSplitting.cs:57) would have thrown
                 stack[sp++] = {rb, it.splits - lc};
                 stack[sp++] = {lb, lc};
             }
@@ -644,7 +648,10 @@ struct Builder {
         getrusage(RUSAGE_SELF, &ru0);
         maxThreads = threads <= 0 ? defaultThreadCount() : threads;
         refit = refittable;
-        if (!refit) preSplit(factor);
+        // non-finite positions: the reference's builder has no defined result for them (NaN boxes, int conversions of NaN); refused here
+        parallelFor(triCount, [&](int b, int e) { for (int i = b; i < e; i++) { __m128 p[3]; triPoints(i, p[0], p[1], p[2]); for (int v = 0; v < 3; v++) { float f[4]; _mm_storeu_ps(f, p[v]); if (!std::isfinite(f[0]) || !std::isfinite(f[1]) || !std::isfinite(f[2])) error = 5; } } });
+        if (error) return;
+        if (!refit) { preSplit(factor); if (error) return; }
         else { frag.resize(triCount); for (int i = 0; i < triCount; i++) frag[i] = triBox(i); }
         lap("presplit");
     }
@@ -695,7 +702,7 @@ struct Builder {
         lap("parents+sah");
         buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    void run(bool refittable, float factor, int threads) { begin(refittable, factor, threads); coreCpu(); finish(); }
+    void run(bool refittable, float factor, int threads) { begin(refittable, factor, threads); if (error) return; coreCpu(); finish(); }
 };
 
 uint32_t spread3(uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; }
@@ -712,6 +719,7 @@ int32_t idkbvhBuildBlas(const float* positions, const GpuBlasTriangle* tris, int
     idkbvh_blas* h = new idkbvh_blas();
     h->b.positions = positions; h->b.tris = tris; h->b.triCount = triCount;
     h->b.run(isRefittable != 0, preSplitFactor, threads);
+    if (h->b.error) { const int32_t rc = h->b.error; delete h; return rc; }
     h->fragmentCount = (int)h->b.frag.size();
     h->b.positions = nullptr; h->b.tris = nullptr; // inputs are only borrowed during the call
     *out = h;
@@ -723,6 +731,7 @@ int32_t idkbvhBlasBegin(const float* positions, const GpuBlasTriangle* tris, int
     idkbvh_blas* h = new idkbvh_blas();
     h->b.positions = positions; h->b.tris = tris; h->b.triCount = triCount;
     h->b.begin(isRefittable != 0, preSplitFactor, threads);
+    if (h->b.error) { const int32_t rc = h->b.error; delete h; return rc; }
     h->fragmentCount = (int)h->b.frag.size();
     h->b.positions = nullptr; h->b.tris = nullptr;
     *out = h;

@@ -78,12 +78,19 @@ __global__ void k_tri_prio(const float* pos, const uint4* tris, int n, float* pr
     const float triArea = __builtin_sqrtf((cx * cx) + (cy * cy) + (cz * cz)) * 0.5f;
     prio[i] = dev_cbrtf((e * e) * (area - triArea));
 }
-__global__ void k_split_count(const float* prio, float total, int n, float factor, uint32_t* cnt)   // GetSplitCount, PreSplitting.cs:116-122
+__global__ void k_split_count(const float* prio, float total, int n, float factor, uint32_t* cnt, unsigned long long* sum64)   // GetSplitCount, PreSplitting.cs:116-122
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float share = prio[i] / total * (float)n;
-    cnt[i] = (uint32_t)(1 + sat_int(share * factor));
+    uint32_t c = 0;
+    if (i < n) {
+        const float share = prio[i] / total * (float)n;
+        c = 1u + (uint32_t)sat_int(share * factor);
+        cnt[i] = c;
+    }
+    // the exact total (the 32-bit scan of the counts wraps for absurd split factors: the host refuses the build then)
+    unsigned long long w = c;
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(sum64, w);
 }
 // scene box (BLAS.ComputeBoundingBox over the geometry): grown point by point in triangle order with minps/maxps -> an in-order reduction
 __global__ __launch_bounds__(CH) void k_global_box_partial(const float* pos, const uint4* tris, int n, BBox* part)
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(CH) void k_global_box_final(const BBox* part, int m
 }
 // the recursive grid split of one triangle (PreSplitting.cs:57-112, Triangle.Split Shapes/Triangle.cs:48-97), fragments in the order the
 // reference's stack emits them, into the triangle's own range
-__global__ __launch_bounds__(64) void k_presplit(const float* pos, const uint4* tris, int n, const uint32_t* cnt, const uint32_t* first, const BBox* globalBox, float4* fb, int* origTri)
+__global__ __launch_bounds__(64) void k_presplit(const float* pos, const uint4* tris, int n, const uint32_t* cnt, const uint32_t* first, const BBox* globalBox, float4* fb, int* origTri, uint32_t* stackOverflow)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(64) void k_presplit(const float* pos, const uint4* 
         const float le = largest_extent(lb), re = largest_extent(rb);
         int lc = sat_int((float)splits * (le / (le + re)));
         lc = min(max(lc, 1), splits - 1);
-        if (sp + 2 > 64) { sp = 0; break; }                                                       // (the reference's stackalloc of 64 would have thrown)
+        if (sp + 2 > 64) { *stackOverflow = 1u; sp = 0; break; }                                  // (the reference's stackalloc of 64 would have thrown: the host reports it)
         stackBox[sp] = rb; stackSplits[sp] = splits - lc; sp++;
         stackBox[sp] = lb; stackSplits[sp] = lc; sp++;
     }

@@ -833,7 +833,7 @@ struct BuilderScratch {
            swapOf, leftCountOf, startOf, countOf, leftTable, pcnt, poff, smallList, aux;
     // whole build
     DevBuf pos, tris, prio, splitCnt, first, scanTmp[3], gboxPart, gbox, origTri, parent, jump[2], dist[2], arrived, need, aggStart, aggCount, bins, maxDepth, used, rank, outNodes, leafCnt, at, uniq, ucount,
-           outTris, parents, leafFlag, leaves, sahPart;
+           outTris, parents, leafFlag, leaves, sahPart, status;
     // results of the last idkptBuildBlas, for idkptBuildBlasFetch
     int outNodeCount = 0, outTriCount = 0, outParentCount = 0, outLeafCount = 0; bool haveResult = false;
     void release()
@@ -841,7 +841,7 @@ struct BuilderScratch {
         DevBuf* all[] = {&fb, &ids[0][0], &ids[0][1], &ids[1][0], &ids[1][1], &ids[2][0], &ids[2][1], &keys[0], &keys[1], &vals[0], &vals[1], &hist, &nodes, &act[0], &act[1], &cnt, &nodeChunk0, &chunkNode, &chunkBegin,
                          &cboxL, &cboxR, &carryL, &carryR, &rc, &cbestCost, &cbestPos, &dec, &sideL, &sideR, &freshOf, &swapOf, &leftCountOf, &startOf, &countOf, &leftTable, &pcnt, &poff, &smallList, &aux,
                          &pos, &tris, &prio, &splitCnt, &first, &scanTmp[0], &scanTmp[1], &scanTmp[2], &gboxPart, &gbox, &origTri, &parent, &jump[0], &jump[1], &dist[0], &dist[1], &arrived, &need, &aggStart, &aggCount,
-                         &bins, &maxDepth, &used, &rank, &outNodes, &leafCnt, &at, &uniq, &ucount, &outTris, &parents, &leafFlag, &leaves, &sahPart};
+                         &bins, &maxDepth, &used, &rank, &outNodes, &leafCnt, &at, &uniq, &ucount, &outTris, &parents, &leafFlag, &leaves, &sahPart, &status};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -1038,6 +1038,11 @@ static int32_t dev_BuildBlas(dev_ctx* ctx, const float* positions, int32_t verte
     REQUIRE(positions && tris && info && vertexCount > 0 && triCount > 0, "idkptBuildBlas: null argument or empty geometry");
     REQUIRE(triCount <= (1 << 26), "idkptBuildBlas: too many triangles");
     for (int i = 0; i < triCount; i++) REQUIRE(tris[i].X < (uint32_t)vertexCount && tris[i].Y < (uint32_t)vertexCount && tris[i].Z < (uint32_t)vertexCount, "idkptBuildBlas: triangle index out of range");
+    {   // non-finite positions: the reference's builder has no defined result for them (NaN boxes, integer conversions of NaN) — refused, like idkbvhBuildBlas does
+        const uint32_t* pb = reinterpret_cast<const uint32_t*>(positions); uint32_t bad = 0;
+        for (size_t i = 0, e = (size_t)vertexCount * 3; i < e; i++) bad |= (uint32_t)((pb[i] & 0x7f800000u) == 0x7f800000u);
+        REQUIRE(!bad, "idkptBuildBlas: a vertex position is not finite");
+    }
     HIPC(hipSetDevice(ctx->device));
     BuilderScratch& B = builder_scratch(ctx);
     B.haveResult = false;
@@ -1066,19 +1071,24 @@ static int32_t dev_BuildBlas(dev_ctx* ctx, const float* positions, int32_t verte
         HIPC(hipMemcpyAsync(hp.data(), B.prio.p, (size_t)nT * 4, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st));
         float total = 0.0f;
         for (int i = 0; i < nT; i++) total += hp[i];
-        hipLaunchKernelGGL(k_split_count, dim3(gT), dim3(256), 0, st, (const float*)B.prio.as<float>(), total, nT, preSplitFactor, B.splitCnt.as<uint32_t>());
+        HIPC(B.status.ensure(16)); HIPC(hipMemsetAsync(B.status.p, 0, 16, st));      // [0..7] exact fragment count, [8..11] PreSplit stack flag
+        hipLaunchKernelGGL(k_split_count, dim3(gT), dim3(256), 0, st, (const float*)B.prio.as<float>(), total, nT, preSplitFactor, B.splitCnt.as<uint32_t>(), B.status.as<unsigned long long>());
         HIPC(hipMemsetAsync(B.splitCnt.as<uint32_t>() + nT, 0, 4, st));
         { int rc = scan_u32(ctx, B, B.splitCnt.as<uint32_t>(), B.first.as<uint32_t>(), (uint32_t)nT + 1u); if (rc) return rc; }
-        uint32_t hF = 0;
-        HIPC(hipMemcpyAsync(&hF, B.first.as<uint32_t>() + nT, 4, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st));
-        REQUIRE(hF >= (uint32_t)nT && hF <= (1u << 27), "idkptBuildBlas: PreSplit produced an implausible fragment count");
+        uint32_t hF = 0; unsigned long long hSum = 0;
+        HIPC(hipMemcpyAsync(&hF, B.first.as<uint32_t>() + nT, 4, hipMemcpyDeviceToHost, st)); HIPC(hipMemcpyAsync(&hSum, B.status.p, 8, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st));
+        REQUIRE(hSum <= (1ull << 27), "idkptBuildBlas: PreSplit asks for more than 2^27 fragments (split factor / priorities)");
+        REQUIRE(hF == (uint32_t)hSum && hF >= (uint32_t)nT, "idkptBuildBlas: PreSplit produced an implausible fragment count");
         F = (int)hF;
         const int parts = (nT + CH - 1) / CH;
         HIPC(B.gboxPart.ensure((size_t)parts * sizeof(BBox))); HIPC(B.gbox.ensure(sizeof(BBox)));
         hipLaunchKernelGGL(k_global_box_partial, dim3(parts), dim3(CH), 0, st, dPos, dTris, nT, B.gboxPart.as<BBox>());
         hipLaunchKernelGGL(k_global_box_final, dim3(1), dim3(CH), 0, st, (const BBox*)B.gboxPart.as<BBox>(), parts, B.gbox.as<BBox>());
         HIPC(B.fb.ensure((size_t)F * 32)); HIPC(B.origTri.ensure((size_t)F * 4));
-        hipLaunchKernelGGL(k_presplit, dim3((unsigned)((nT + 63) / 64)), dim3(64), 0, st, dPos, dTris, nT, (const uint32_t*)B.splitCnt.as<uint32_t>(), (const uint32_t*)B.first.as<uint32_t>(), (const BBox*)B.gbox.as<BBox>(), B.fb.as<float4>(), B.origTri.as<int>());
+        hipLaunchKernelGGL(k_presplit, dim3((unsigned)((nT + 63) / 64)), dim3(64), 0, st, dPos, dTris, nT, (const uint32_t*)B.splitCnt.as<uint32_t>(), (const uint32_t*)B.first.as<uint32_t>(), (const BBox*)B.gbox.as<BBox>(), B.fb.as<float4>(), B.origTri.as<int>(), B.status.as<uint32_t>() + 2);
+        uint32_t hOvf = 0;
+        HIPC(hipMemcpyAsync(&hOvf, B.status.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st));
+        REQUIRE(!hOvf, "idkptBuildBlas: a triangle's PreSplit recursion needs more than 64 stack entries (the reference throws here, PreSplitting.cs:57)");
     }
     HIPC(hipGetLastError());
     lap("fragments");

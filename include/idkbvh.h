@@ -38,7 +38,10 @@ typedef struct idkbvh_blas_info {
  * by BVH.Add (global vertex ids + MeshId, Bvh/BVH.cs:236-276); `positions` the global packed-float3 vertex array.
  * PreSplitting (factor `preSplitFactor`, reference default 0.3) runs iff !isRefittable (Bvh/BVH.cs:325).
  * threads <= 0: use the hardware threads this process may occupy (affinity mask, capped by the container's cgroup CPU quota) (the reference spawns a thread per subtree >= 8192 triangles and a task per
- * sort axis >= 65536 fragments; results do not depend on the thread count). */
+ * sort axis >= 65536 fragments; results do not depend on the thread count).
+ * Returns 0, or: 2 null / empty argument, 3 PreSplit asks for more than 2^27 fragments (split factor / priorities), 4 a triangle's split recursion needs more
+ * than the 64 stack entries the reference allocates (PreSplitting.cs:57: it throws there), 5 a referenced vertex position is not finite (the reference's
+ * builder has no defined result for NaN / infinite boxes).  On an error no handle is returned. */
 IDKBVH_API int32_t idkbvhBuildBlas(const float* positions, const GpuBlasTriangle* tris, int32_t triCount, int32_t isRefittable,
                                    float preSplitFactor, int32_t threads, idkbvh_blas** outBlas);
 /* The same build in three steps, for hosts that run the middle one elsewhere (idkptBuildBlasCore of libidkpt.so: the SweepSAH recursion on

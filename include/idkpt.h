@@ -220,7 +220,10 @@ IDKPT_API int32_t idkptBuildBlasCore(idkpt_ctx* ctx, const float* fragmentBoxes,
  * floats; triangles: vertex ids into positions (+ MeshId, copied through).  The results stay on the device until idkptBuildBlasFetch copies them
  * into host arrays sized from outInfo (one build per context at a time).  Output bytes are those of libidkbvh's idkbvhBuildBlas (and therefore of
  * the reference's builder as far as that is pinned); nodes carry BLAS-local indices like BLAS.Build's.  A host-side service like
- * idkptBuildBlasCore: first device of the context, no scene needed, none touched. */
+ * idkptBuildBlasCore: first device of the context, no scene needed, none touched.
+ * IDKPT_ERR_INVALID_ARGUMENT (nothing built) for: a vertex id out of range, a vertex position that is not finite (the reference's builder has no defined
+ * result for NaN / infinite boxes), a PreSplit that asks for more than 2^27 fragments, a triangle whose split recursion needs more than the 64 stack
+ * entries the reference allocates (PreSplitting.cs:57: it throws there).  idkbvhBuildBlas refuses the same inputs. */
 typedef struct idkpt_blas_build_info {
     int32_t NodeCount, TriangleCount, RequiredStackSize, ParentIndexCount, LeafIndexCount, FragmentCount, Levels, _pad;
     double Sah;      /* ComputeGlobalSAH of the finished tree (parallel binary64 sum: equal to the reference's tree-order sum up to rounding) */

@@ -166,3 +166,24 @@ def test_cbrt_twin_of_the_device_equals_the_hosts_cbrtf(tmp_path):
     first_bad = C.c_uint32(0)
     bad = L.twin_vs_host_mismatches(0, stride, (1 << 32) // stride, C.byref(first_bad))
     assert bad == 0, hex(first_bad.value)
+
+
+def test_builder_refuses_inputs_the_reference_has_no_defined_result_for(native_builder):
+    """Non-finite vertex positions (NaN boxes, integer conversions of NaN) and a PreSplit that asks for more fragments than any array can hold are refused
+    with a status (include/idkbvh.h: 5 / 3) instead of producing garbage or running out of memory; the same geometry builds once it is repaired."""
+    from idkengine_amd import gputypes as T
+    from idkengine_amd.bvh import NativeBuilder
+    rng = np.random.default_rng(3)
+    pos = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+    tris = np.zeros(100, T.GpuBlasTriangle); tris["X"] = np.arange(100) * 3; tris["Y"] = tris["X"] + 1; tris["Z"] = tris["X"] + 2
+    for bad in (np.nan, np.inf, -np.inf):
+        p = pos.copy(); p[151, 1] = bad
+        for refittable in (False, True):
+            with pytest.raises(RuntimeError, match="5"):
+                native_builder.build_blas(p, tris, refittable)
+    p = pos.copy(); p[299, 2] = np.nan                      # a vertex no triangle refers to is nobody's business
+    tris2 = tris[:99]
+    assert native_builder.build_blas(p, tris2, False)["nodes"].tobytes() == native_builder.build_blas(pos, tris2, False)["nodes"].tobytes()
+    with pytest.raises(RuntimeError, match="3"):
+        NativeBuilder(presplit_factor=1e9).build_blas(pos, tris, False)
+    assert NativeBuilder(presplit_factor=1e9).build_blas(pos, tris, True)["fragments"] == 100     # (refittable: no PreSplit, the factor is not looked at)

@@ -219,3 +219,31 @@ def test_device_build_stack_optimisation_fallback_path(native_builder, monkeypat
             for k in ("nodes", "triangles", "parents", "leaves"):
                 assert a[k].tobytes() == b[k].tobytes(), k
     pt.Dispose()
+
+
+def test_device_build_refuses_what_the_host_builder_refuses(native_builder):
+    """include/idkpt.h: non-finite vertex positions, vertex ids out of range and a PreSplit that asks for more than 2^27 fragments are refused with
+    IDKPT_ERR_INVALID_ARGUMENT before anything is built (idkbvhBuildBlas refuses the same: tests/test_builder.py); the context keeps working."""
+    from idkengine_amd.bvh import DeviceBuilder
+    from idkengine_amd.pathtracer import PathTracer, IdkPtError
+    from idkengine_amd import gputypes as T
+    rng = np.random.default_rng(3)
+    pos = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+    tris = np.zeros(100, T.GpuBlasTriangle); tris["X"] = np.arange(100) * 3; tris["Y"] = tris["X"] + 1; tris["Z"] = tris["X"] + 2
+    pt = PathTracer(8, 8); db = DeviceBuilder(pt)
+    for bad in (np.nan, np.inf, -np.inf):
+        p = pos.copy(); p[151, 1] = bad
+        for refittable in (False, True):
+            with pytest.raises(IdkPtError, match="not finite"):
+                db.build_blas(p, tris, refittable)
+    t2 = tris.copy(); t2["Z"][7] = 300
+    with pytest.raises(IdkPtError, match="out of range"):
+        db.build_blas(pos, t2, False)
+    big = DeviceBuilder(pt, presplit_factor=1e9)
+    with pytest.raises(IdkPtError, match="2\\^27"):
+        big.build_blas(pos, tris, False)
+    a = big.build_blas(pos, tris, True); b = native_builder.build_blas(pos, tris, True)              # refittable: no PreSplit, the factor is not looked at
+    assert a["nodes"].tobytes() == b["nodes"].tobytes()
+    a = db.build_blas(pos, tris, False); b = native_builder.build_blas(pos, tris, False)             # and the context still builds
+    assert a["fragments"] == b["fragments"] and a["nodes"].tobytes() == b["nodes"].tobytes() and a["triangles"].tobytes() == b["triangles"].tobytes()
+    pt.Dispose()
