@@ -50,6 +50,7 @@ struct DevOptions {
     int ldsPad = 0;              // bytes of LDS added per workgroup of k_trace2 (caps the resident waves)
     int traceWaves = 0;          // one-wave workgroups per CU in the persistent grid (0: what LDS allows, at most 32)
     int gridHint = 2;            // bounce launches: grid = gridHint x the queue length the same bounce had in the previous batch (0: full grid)
+    int gridRaysX4 = 6;          // small launches: quarter-rays per lane the persistent grid is sized for (from the previous batch's counts; 0: gridHint's rule alone)
     int nodeLayout = 0;          // derived node order (node_layout.hpp): 0 = reference order (default: the derived orders raise the L2 hit rate, not the speed — profiles/r03_layout_order_pmc.json), 1 = line couples depth-first, 2 = line couples in treelets
     int treeletDepth = 3;
     int traceOrder = 0;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order (default: L2 hit rate 0.62 -> 0.88, launch -7 %, the permutation costs more), 1 = batches of >= 4 samples, 2 = always
@@ -746,6 +747,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "lds_pad") o.ldsPad = value;
     else if (n == "trace_waves") o.traceWaves = std::max(0, value);
     else if (n == "grid_hint") o.gridHint = std::max(0, value);
+    else if (n == "grid_rays_x4") o.gridRaysX4 = std::max(0, value);
     else if (n == "bvh_timing") o.bvhTiming = value != 0;
     else if (n == "bvh_small") o.bvhSmall = value;
     else if (n == "bvh_stackopt_host") o.bvhStackOptHost = value != 0;
@@ -1431,6 +1433,21 @@ static bool fast_path(dev_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st
 // stage launched once for all B samples.  Sample k owns ray ids [k*Npad, k*Npad+N); alive queues are batch-wide but stay
 // grouped by sample (stable compaction / sort with the sample index above the key), and every ray's NHit slot is its
 // position inside its own sample's queue, so each sample gets exactly the RNG streams of a stand-alone frame.
+// Grid of a traversal launch whose ray count is only known on the device: `prev` = the count the same launch had in the previous batch (host-mapped mirror,
+// possibly one batch stale; 0 = unknown -> full grid).  Any grid >= 1 is correct (the waves are persistent); the size only costs or saves time:
+//   * never more than hintMul x the waves that hold all rays at once (tiny frames would otherwise spend their time dispatching idle workgroups), at least 256;
+//   * launches below ~1.5 rays per lane of the full grid run faster on FEWER, fuller waves — every wave instruction costs the same whatever its exec mask, and a
+//     launch this small lasts as long as its longest rays, whose steps get faster when fewer waves share a SIMD: raysX4 / 4 rays per lane, but not below
+//     1024 waves where the first rule allows them (round 3, same box: headline one frame at a time +6 %, Cornell 1080p RayDepth 5 +12 %; profiles/r03_trace_experiments.md 7).
+static uint32_t small_launch_grid(uint32_t fullGrid, uint32_t prev, int hintMul, int raysX4)
+{
+    if (prev == 0u || hintMul <= 0) return fullGrid;
+    const uint32_t cap = std::max<uint32_t>(256u, (uint32_t)(((uint64_t)hintMul * prev + 63) / 64));
+    uint32_t g = cap;
+    if (raysX4 > 0) g = std::max<uint32_t>((uint32_t)(((uint64_t)prev * 4u / (uint32_t)raysX4 + 63) / 64), std::min<uint32_t>(cap, 1024u));
+    return std::min(fullGrid, std::min(g, cap));
+}
+
 static int flush_batch(dev_ctx* ctx)
 {
     const int B = (int)ctx->pending.size();
@@ -1527,7 +1544,9 @@ static int flush_batch(dev_ctx* ctx)
             }
             hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
             TRACE_T0();
-            launch_trace2<true>(ctx, traceGrid, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
+            uint32_t grid0 = traceGrid;
+            if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4);
+            launch_trace2<true>(ctx, grid0, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
             hipLaunchKernelGGL(k_shade_first, dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
@@ -1613,7 +1632,7 @@ static int flush_batch(dev_ctx* ctx)
         // possibly one batch stale) is a good predictor, and a grid that is too small or too large only costs time (the waves are persistent)
         uint32_t gridj = traceGrid;
         const int hintMul = ctx->opt.gridHint;
-        if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) { const uint32_t prev = ctx->hBases[(size_t)j * BS + B]; if (prev > 0) gridj = std::min<uint32_t>(traceGrid, std::max<uint32_t>(256u, (uint32_t)(((uint64_t)hintMul * prev + 63) / 64))); }
+        if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) gridj = small_launch_grid(traceGrid, ctx->hBases[(size_t)j * BS + B], hintMul, ctx->opt.gridRaysX4);
         if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, trj, hits, (const uint32_t*)q, cnt, work + j, counters);
         else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);

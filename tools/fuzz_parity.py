@@ -94,7 +94,8 @@ def one_case(seed, builder):
     if rng.random() < 0.3: ov.update(FocalLength=float(rng.uniform(0.5, 2.0) * extent), LenseRadius=float(rng.uniform(0.005, 0.05) * extent))
     frames = int(rng.integers(1, 6)); batch = int(rng.choice([1, 2, 5, 8]))
     st = configs.apply_settings(T.Settings.default(), ov)
-    opts = {"node_layout": int(rng.choice([0, 0, 1, 2])), "treelet_depth": int(rng.integers(1, 6)), "trace_order": int(rng.choice([0, 0, 1, 2]))}   # free choices of the implementation: never visible in the output
+    opts = {"node_layout": int(rng.choice([0, 0, 1, 2])), "treelet_depth": int(rng.integers(1, 6)), "trace_order": int(rng.choice([0, 0, 1, 2])),
+            "grid_rays_x4": int(rng.choice([6, 6, 0, 1, 64])), "grid_hint": int(rng.choice([2, 2, 0, 1])), "trace_waves": int(rng.choice([0, 0, 1, 7]))}   # free choices of the implementation: never visible in the output
     pt = PathTracer(w, h, settings=st)
     for k_, v_ in opts.items():
         pt.set_option(k_, v_)

@@ -19,6 +19,9 @@ CONFIGS = [("reference order, queue order", {"IDKPT_NODE_LAYOUT": 0, "IDKPT_TRAC
            ("couples treelets(3), trace order", {"IDKPT_NODE_LAYOUT": 2, "IDKPT_TREELET_DEPTH": 3, "IDKPT_TRACE_ORDER": 2})]
 if os.environ.get("SWEEP_ONLY_REF") == "1":      # A/B of whole libraries (IDKPT_LIB_PATH): the default configuration only
     CONFIGS = [("default options", {})]
+if os.environ.get("SWEEP_OPT"):                  # one library option swept: SWEEP_OPT=GRAB_UNIT_LOG2:10,13,16 (run length of the work-list slices), TRACE_WAVES:8,12,24 ...
+    _name, _vals = os.environ["SWEEP_OPT"].split(":")
+    CONFIGS = [(f"{_name.lower()} {v}", {"IDKPT_" + _name: int(v)}) for v in _vals.split(",")]
 DEPTHS = [int(d) for d in os.environ.get("SWEEP_DEPTHS", "2,5").split(",")]
 BATCHES = [int(b) for b in os.environ.get("SWEEP_BATCHES", "32,1").split(",")]
 
