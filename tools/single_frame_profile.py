@@ -12,8 +12,12 @@ from idkengine_amd.pathtracer import PathTracer
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 W, H = 1920, 1080
-sc = S.soup_scene(1000000, NativeBuilder(), seed=1)
-pt = PathTracer(W, H); pt.UploadScene(sc); pt.SetCamera(S.Camera(W, H)); pt.RayDepth = 2
+view = sys.argv[2] if len(sys.argv) > 2 else "headline"      # headline | interior | atrium
+if view == "atrium":
+    sc = S.atrium_scene(1000000, NativeBuilder()); cam = S.atrium_camera(W, H)
+else:
+    sc = S.soup_scene(1000000, NativeBuilder(), seed=1); cam = S.Camera(W, H) if view == "headline" else S.Camera(W, H, position=(0.0, 0.0, 0.0))
+pt = PathTracer(W, H); pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = 2
 pt.set_max_batch(1)
 if os.environ.get("SFP_NO_TIMING"):
     pt.enable_timing(False) if hasattr(pt, "enable_timing") else None
