@@ -1,0 +1,126 @@
+"""Mint tests/golden/glref_full/*.npz: the REFERENCE's own GLSL shaders (oracle/glref/glref.py on Mesa llvmpipe) on WHOLE frames at BASELINE size —
+1920x1080 on the 1M-triangle scenes bench.py times (tests/golden/glref_cases.py FULL_CASES) — compared with the oracle ray by ray, stage by stage.
+Test infrastructure; runs only in the build container (/root/reference + Mesa swrast).
+
+    python oracle/glref/make_full_vectors.py [case ...]
+
+Method (the one of make_vectors.py): FirstHit is run by the reference on the whole frame; every bounce j is ONE NHit dispatch of the reference started from
+the ORACLE's state after j-1 bounces, so every stage is compared from identical inputs.  All rays of a stage are compared here, under the gate of
+tests/glref_check.py; the fixture keeps
+  * `state_hash_<j>`: sha256 of the oracle's state (ray records + alive queue) after stage j — the state that was compared.  A test that finds the same hash
+    on its candidate (the oracle again, or the HIP path, which equals it bit for bit) inherits this comparison of every ray;
+  * `idx_<j>`, `ref_<j>`: the reference's records on every FULL_SAMPLE_STRIDE-th ray of the stage, for a direct comparison wherever the fixture travels;
+  * `exc_ids_<j>`, `exc_ref_<j>`, `exc_cand_<j>`: EVERY ray on which the reference's run and the oracle differ beyond the gate (tolerance or alive decision),
+    with both results; `exc_bf_<j>`: what a binary64 brute force over all triangles says about that ray (tests/c_driver/brute_force.c): [closest t, runner-up t,
+    distance of the oracle's result, distance of the reference's result];
+  * the reference's alive queue as a hash plus its symmetric difference with the oracle's (`ref_queue_hash_<j>`, `flips_<j>`).
+tests/golden/glref_full/summary.json holds the whole-stage statistics (rays, flips, beyond tolerance, worst deviation)."""
+import hashlib
+import json
+import os
+import sys
+import time
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+OUT = os.path.join(ROOT, "tests", "golden", "glref_full")
+
+
+def queue_hash(q):
+    return np.frombuffer(hashlib.sha256(np.sort(np.asarray(q, np.uint32)).tobytes()).digest(), np.uint8)      # the alive SET (sorted ids)
+
+
+def brute_force_exceptions(sc, origins, dirs, cand_pts, ref_pts):
+    """binary64 closest hit of the given rays against every triangle; per ray [t closest, t runner-up, |candidate point - origin|, |reference point - origin|]."""
+    import test_metamorphic as M
+    tris, _ = M.world_triangles(sc)
+    t, _, t2 = M.brute_force(tris, origins, dirs)
+    return np.stack([t, t2, np.linalg.norm(cand_pts - origins, axis=1), np.linalg.norm(ref_pts - origins, axis=1)], 1)
+
+
+def main(names):
+    from oracle.glref import glref as G
+    from oracle import oracle as O
+    from idkengine_amd import gputypes as T
+    from idkengine_amd.bvh import NativeBuilder
+    import configs
+    import glref_cases
+    import glref_check
+    os.makedirs(OUT, exist_ok=True)
+    spath = os.path.join(OUT, "summary.json")
+    summary = json.load(open(spath)) if os.path.exists(spath) else {}
+    scenes = {}
+    for name in names or list(glref_cases.FULL_CASES):
+        skey, camf, w, h, ov = glref_cases.FULL_CASES[name]
+        stride = glref_cases.FULL_SAMPLE_STRIDE.get(name, glref_cases.FULL_SAMPLE_STRIDE[None])
+        if skey not in scenes:
+            scenes[skey] = glref_cases.FULL_SCENES[skey](NativeBuilder())     # (the product builder: same bytes as the oracle's, tests/test_builder.py; minutes faster at this size)
+        sc = scenes[skey]; cam = camf(w, h)
+        st = configs.apply_settings(T.Settings.default(), ov)
+        depth = int(st.RayDepth)
+        t0 = time.time()
+
+        def oracle_state(d):
+            o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.settings.RayDepth = d; o.settings.SamplesPerPixel = 1
+            o.render(); r, q = o.rays().copy(), o.alive_queue().copy(); o.close()
+            return r, q
+        out = {"mesa": np.frombuffer(G.gl().glref_info(), np.uint8), "depth": depth, "width": w, "height": h, "stride": stride}
+        rep = {"stages": []}
+        st1 = configs.apply_settings(T.Settings.default(), ov); st1.RayDepth = 1; st1.SamplesPerPixel = 1
+        pt = G.ReferencePathTracer(sc, w, h, st1); pt.set_camera(cam); pt.render()
+        ref_rays, ref_q = pt.rays(T.GpuWavefrontRay), np.asarray(pt.final_alive, np.uint32); pt.accumulated = 0
+        cur = oracle_state(1)
+        campos = np.asarray(cam.position, np.float64)
+
+        def record_stage(j, ids, cand, ref, cand_q, ref_q, in_origins, in_dirs):
+            """ids: ray ids compared in this stage (all pixels for FirstHit, the queue entering bounce j otherwise); cand / ref: records of those rays."""
+            flips = np.setxor1d(cand_q, ref_q)
+            beyond, eq, worst = glref_check._compare_records(cand, ref)
+            exc = beyond | np.isin(ids, flips)
+            pos = np.nonzero(exc)[0]
+            out[f"state_hash_{j}"] = glref_check.state_hash(cur[0], cur[1])
+            out[f"ref_queue_hash_{j}"] = queue_hash(ref_q); out[f"flips_{j}"] = flips.astype(np.uint32)
+            samp = np.arange(0, len(ids), stride)
+            out[f"idx_{j}"] = ids[samp].astype(np.uint32); out[f"ref_{j}"] = ref[samp]
+            out[f"exc_ids_{j}"] = ids[pos].astype(np.uint32); out[f"exc_ref_{j}"] = ref[pos]; out[f"exc_cand_{j}"] = cand[pos]
+            bf = np.zeros((0, 4))
+            if len(pos):
+                bf = brute_force_exceptions(sc, in_origins[pos], in_dirs[pos], cand["Origin"][pos].astype(np.float64), ref["Origin"][pos].astype(np.float64))
+            out[f"exc_bf_{j}"] = bf
+            stage = {"stage": "FirstHit" if j == 0 else f"NHit{j}", "rays": int(len(ids)), "flips": int(len(flips)), "beyond_tol": int(beyond.sum()), "exceptions": int(len(pos)),
+                     "bit_equal_words": round(eq, 4), "max_rel_within_tol": worst,
+                     "exceptions_where_oracle_is_the_binary64_closest_hit": int(sum(1 for r in bf if np.isfinite(r[0]) and abs(r[2] - r[0]) <= 3e-3 + 1e-4 * r[0])),
+                     "exceptions_where_reference_is_the_binary64_closest_hit": int(sum(1 for r in bf if np.isfinite(r[0]) and abs(r[3] - r[0]) <= 3e-3 + 1e-4 * r[0]))}
+            rep["stages"].append(stage)
+            print("  ", name, json.dumps(stage), flush=True)
+
+        # ---- FirstHit: all pixels; the primary ray of a pixel leaves the camera position (no lens in these cases) through the hit point
+        ids = np.arange(w * h, dtype=np.uint32)
+        d0 = cur[0]["Origin"].astype(np.float64) - campos; nrm = np.linalg.norm(d0, axis=1, keepdims=True); d0 = d0 / np.maximum(nrm, 1e-30)
+        record_stage(0, ids, cur[0], ref_rays, cur[1], ref_q, np.broadcast_to(campos, d0.shape).copy(), d0)
+        prev_out = None
+        for j in range(1, depth):
+            rin, qin = cur
+            if st.DoRaySorting and j > 1 and not np.array_equal(prev_out, qin):
+                print(f"  {name}: bounce {j} not comparable from forced inputs (the reference's bounce {j - 1} queue differs; no sort keys for it)")
+                break
+            rout, qout = pt.run_nhit_from(rin, qin, j, sort_first=bool(st.DoRaySorting)); prev_out = qout
+            nxt = oracle_state(j + 1)
+            o_in = rin["Origin"][qin].astype(np.float64)
+            d_in = glref_check.decode_unit_vec(rin["PackedDirectionX"][qin], rin["PackedDirectionY"][qin])
+            cur = nxt
+            record_stage(j, qin.astype(np.uint32), nxt[0][qin], rout[qin], nxt[1], np.asarray(qout, np.uint32), o_in, d_in)
+        pt.close()
+        rep["seconds"] = round(time.time() - t0, 1)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **out)
+        rep["fixture_bytes"] = os.path.getsize(path)
+        rep["gate"] = {"rel_tol": glref_check.REL_TOL, "abs_floor": glref_check.ABS_FLOOR, "max_listed_exceptions_per_stage": glref_check.FULL_ALLOW.get(name), "reason": glref_check.FULL_EXCEPTION_REASON}
+        summary[name] = rep
+        json.dump(summary, open(spath, "w"), indent=1, sort_keys=True)
+        print(name, "written", rep["fixture_bytes"], "bytes in", rep["seconds"], "s", flush=True)
+
+
+if __name__ == "__main__":
+    main([a for a in sys.argv[1:] if not a.startswith("--")])

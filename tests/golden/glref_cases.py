@@ -80,3 +80,23 @@ GLREF_CASES.update({
     "soup_sky_linear_aov_d3": (_sky_scene, lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(1.0, 0.8, 0.9), fovy_deg=110.0), 96, 72, dict(RayDepth=3, OutputAOVs=1)),
     "soup_multi_tlas_d3": (lambda b: S.soup_scene_multi(6000, b, parts=3, seed=4), lambda w, h: S.Camera(w, h), 96, 54, dict(RayDepth=3, UseTlas=1)),
 })
+
+
+# ---- BASELINE-size cases (tests/golden/glref_full/, minted by oracle/glref/make_full_vectors.py): the reference's own shaders on llvmpipe on WHOLE frames of
+# the workloads bench.py times.  A whole frame's ray records are 100 MB, so the fixture keeps (a) the sha256 of the state that was compared with the reference
+# ray by ray at generation (the oracle's — and, bit for bit, the HIP path's), (b) the reference's records on a fixed sample of the rays for a direct comparison
+# wherever the fixture travels, (c) every ray on which the reference's run and the oracle differ, with both results (glref_check.FULL_ALLOW names them).
+# name: (scene key, camera factory(w, h), w, h, settings overrides); scenes by key, built once per test session.
+FULL_SCENES = {
+    "soup1m": lambda b: S.soup_scene(1000000, b, seed=1),
+    "atrium262k": lambda b: S.atrium_scene(262000, b),
+    "soup4m": lambda b: S.soup_scene(4000000, b, seed=3),
+}
+FULL_CASES = {
+    "full_headline_d2": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=2)),                                            # BASELINE configs[2], the bench line
+    "full_headline_sort_d5": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=5, DoRaySorting=1)),                       # configs[3] (sort on), 4 bounces
+    "full_interior_d3": ("soup1m", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0)), 1920, 1080, dict(RayDepth=3)),                 # every pixel traverses
+    "full_atrium262k_d5": ("atrium262k", S.atrium_camera, 1920, 1080, dict(RayDepth=5)),                                                   # configs[1] stand-in
+    "full_soup4m_4k_d9": ("soup4m", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(0.3, 0.1, -1.0)), 3840, 2160, dict(RayDepth=9)),   # configs[4] stand-in (sample 0 of its 4 spp)
+}
+FULL_SAMPLE_STRIDE = {None: 127, "full_soup4m_4k_d9": 1016}      # every n-th ray of a stage is kept in the fixture (a 4K frame of nine stages at 127 would be 7 MB)
