@@ -2,7 +2,8 @@
 1920x1080 on the 1M-triangle scenes bench.py times (tests/golden/glref_cases.py FULL_CASES) — compared with the oracle ray by ray, stage by stage.
 Test infrastructure; runs only in the build container (/root/reference + Mesa swrast).
 
-    python oracle/glref/make_full_vectors.py [case ...]
+    python oracle/glref/make_full_vectors.py [case ...]            (re)generate fixtures + summary
+    python oracle/glref/make_full_vectors.py --check [case ...]    regenerate in memory, compare with the committed fixtures bit for bit
 
 Method (the one of make_vectors.py): FirstHit is run by the reference on the whole frame; every bounce j is ONE NHit dispatch of the reference started from
 the ORACLE's state after j-1 bounces, so every stage is compared from identical inputs.  All rays of a stage are compared here, under the gate of
@@ -39,7 +40,7 @@ def brute_force_exceptions(sc, origins, dirs, cand_pts, ref_pts):
     return np.stack([t, t2, np.linalg.norm(cand_pts - origins, axis=1), np.linalg.norm(ref_pts - origins, axis=1)], 1)
 
 
-def main(names):
+def main(names, check=False):
     from oracle.glref import glref as G
     from oracle import oracle as O
     from idkengine_amd import gputypes as T
@@ -114,6 +115,13 @@ def main(names):
         pt.close()
         rep["seconds"] = round(time.time() - t0, 1)
         path = os.path.join(OUT, name + ".npz")
+        if check:       # regenerate in memory and demand the committed fixture bit for bit (tests/test_glref_full.py, `live`)
+            fx = np.load(path)
+            bad = [k for k in out if k != "mesa" and not (k in fx and np.asarray(out[k]).tobytes() == np.asarray(fx[k]).tobytes())] + [k for k in fx.files if k not in out]
+            print(name, "reproduced" if not bad else f"DIFFERS in {bad}", flush=True)
+            if bad:
+                raise SystemExit(1)
+            continue
         np.savez_compressed(path, **out)
         rep["fixture_bytes"] = os.path.getsize(path)
         rep["gate"] = {"rel_tol": glref_check.REL_TOL, "abs_floor": glref_check.ABS_FLOOR, "max_listed_exceptions_per_stage": glref_check.FULL_ALLOW.get(name), "reason": glref_check.FULL_EXCEPTION_REASON}
@@ -123,4 +131,4 @@ def main(names):
 
 
 if __name__ == "__main__":
-    main([a for a in sys.argv[1:] if not a.startswith("--")])
+    main([a for a in sys.argv[1:] if not a.startswith("--")], check="--check" in sys.argv)

@@ -16,6 +16,14 @@ import glref_cases  # noqa: E402
 import glref_check  # noqa: E402
 
 FIXTURES = os.path.join(HERE, "golden", "glref_full")
+ROOT = os.path.dirname(HERE)
+
+
+def _live():
+    return os.path.isdir("/root/reference/IDKEngine/Resource/Shaders") and os.path.exists("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")
+
+
+live = pytest.mark.skipif(not _live(), reason="needs /root/reference and Mesa llvmpipe (build container only)")
 _SCENES = {}
 
 
@@ -56,3 +64,12 @@ def test_oracle_still_produces_the_state_compared_with_the_reference(name, oracl
     # the headline case stage by stage; the others on their last compared stage (one whole-frame oracle render each keeps the CPU suite short)
     rep = glref_check.check_full_case(fx, state_at, strict=True, only_last=(name != "full_headline_d2"), name=name)
     assert all(s["state_is_the_compared_state"] and s["beyond_tol_in_sample"] == 0 for s in rep["stages"]), rep
+
+
+@live
+def test_live_headline_frame_regenerates_the_committed_fixture():
+    """Re-runs the reference's shaders on the whole headline frame (llvmpipe, ~15 s) and demands the committed fixture bit for bit: hashes of the compared
+    states, the sampled reference records, the listed exceptions and their brute-force verdicts."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "make_full_vectors.py"), "--check", "full_headline_d2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "full_headline_d2 reproduced" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
