@@ -100,6 +100,16 @@ def main(names, check=False):
         ids = np.arange(w * h, dtype=np.uint32)
         d0 = cur[0]["Origin"].astype(np.float64) - campos; nrm = np.linalg.norm(d0, axis=1, keepdims=True); d0 = d0 / np.maximum(nrm, 1e-30)
         record_stage(0, ids, cur[0], ref_rays, cur[1], ref_q, np.broadcast_to(campos, d0.shape).copy(), d0)
+        if st.Gpu.DoDebugBVHTraversal:      # the reference's own count of the traversal work of the frame's primary rays, and the oracle's counters for the same rays
+            o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.enable_counters(True); o.render(); cst = o.stats(); o.close()
+            out["ref_cost_sum"] = np.float64(ref_rays["PreviousIOROrTraverseCost"].astype(np.float64).sum())
+            out["cand_cost_sum"] = np.float64(cur[0]["PreviousIOROrTraverseCost"].astype(np.float64).sum())
+            out["cand_pairs"] = np.int64(cst["node_pair_visits"]); out["cand_tri_tests"] = np.int64(cst["triangle_tests"])
+            rep["traversal_cost"] = {"reference_debugCost_sum": float(out["ref_cost_sum"]), "oracle_debugCost_sum": float(out["cand_cost_sum"]),
+                                     "oracle_node_pair_visits": int(out["cand_pairs"]), "oracle_triangle_tests": int(out["cand_tri_tests"]),
+                                     "pairs_plus_1.1_tests": float(out["cand_pairs"] + 1.1 * float(out["cand_tri_tests"])),
+                                     "pixels_with_identical_cost": float((ref_rays["PreviousIOROrTraverseCost"].view(np.uint32) == cur[0]["PreviousIOROrTraverseCost"].view(np.uint32)).mean())}
+            print("  ", name, json.dumps(rep["traversal_cost"]), flush=True)
         prev_out = None
         for j in range(1, depth):
             rin, qin = cur

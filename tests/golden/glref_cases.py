@@ -97,6 +97,9 @@ FULL_CASES = {
     "full_headline_sort_d5": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=5, DoRaySorting=1)),                       # configs[3] (sort on), 4 bounces
     "full_interior_d3": ("soup1m", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0)), 1920, 1080, dict(RayDepth=3)),                 # every pixel traverses
     "full_atrium262k_d5": ("atrium262k", S.atrium_camera, 1920, 1080, dict(RayDepth=5)),                                                   # configs[1] stand-in
+    # the reference's own traversal-cost counter (BVHIntersect.glsl:45,60: +1 per node pair, +1.1 per triangle test) on the headline frame's primary rays:
+    # pins the P and T that the roofline's algorithmic bytes are computed from against the reference's count, pixel by pixel and in total
+    "full_headline_debugcost_d1": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=1, DoDebugBVHTraversal=1)),
     "full_soup4m_4k_d9": ("soup4m", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(0.3, 0.1, -1.0)), 3840, 2160, dict(RayDepth=9)),   # configs[4] stand-in (sample 0 of its 4 spp)
 }
 FULL_SAMPLE_STRIDE = {None: 127, "full_soup4m_4k_d9": 1016}      # every n-th ray of a stage is kept in the fixture (a 4K frame of nine stages at 127 would be 7 MB)

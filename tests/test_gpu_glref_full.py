@@ -29,5 +29,8 @@ def test_hip_whole_frames_are_the_states_compared_with_the_reference(name, nativ
         r, q = pt.rays().copy(), pt.alive_queue().copy(); pt.Dispose()
         return r, q
     rep = glref_check.check_full_case(fx, state_at, strict=True, name=name)
-    assert len(rep["stages"]) >= 2
+    assert len(rep["stages"]) >= (1 if "debugcost" in name else 2)
+    if "ref_cost_sum" in fx:     # the reference's own traversal-cost counter against the HIP path's P / T counters (the numerator of bench.py's roofline)
+        pt = gpu_render(sc, cam, w, h, counters=True, capture=False, **ov); st = pt.stats(); pt.Dispose()
+        glref_check.check_traversal_cost(fx, st["node_pair_visits"], st["triangle_tests"])
     assert all(s["state_is_the_compared_state"] and s["beyond_tol_in_sample"] == 0 for s in rep["stages"]), rep
