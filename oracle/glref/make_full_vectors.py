@@ -4,6 +4,7 @@ Test infrastructure; runs only in the build container (/root/reference + Mesa sw
 
     python oracle/glref/make_full_vectors.py [case ...]            (re)generate fixtures + summary
     python oracle/glref/make_full_vectors.py --check [case ...]    regenerate in memory, compare with the committed fixtures bit for bit
+    python oracle/glref/make_full_vectors.py --updates [--check]   BLASRefit + Skinning shaders on the refittable 1M-triangle scene (config-5 size): updates_1m.npz
 
 Method (the one of make_vectors.py): FirstHit is run by the reference on the whole frame; every bounce j is ONE NHit dispatch of the reference started from
 the ORACLE's state after j-1 bounces, so every stage is compared from identical inputs.  All rays of a stage are compared here, under the gate of
@@ -140,5 +141,65 @@ def main(names, check=False):
         print(name, "written", rep["fixture_bytes"], "bytes in", rep["seconds"], "s", flush=True)
 
 
+
+
+
+# ---- config-5 size: Shaders/BLASRefit/compute.glsl and Shaders/Skinning/compute.glsl on the refittable 1M-triangle scene (3 M vertices) -------------------------
+def full_update_inputs(builder):
+    """The animated stand-in of BASELINE configs[5] at full size (deterministic; shared with the tests): refittable soup-1M, every vertex displaced, and the
+    skinning inputs of tools/bench_animated.py's kind (all 3 M vertices, two joints, weights from the position)."""
+    from idkengine_amd import scenes as S, gputypes as T
+    sc = S.soup_scene(1000000, builder, seed=1, refittable=True)
+    p = sc.vertex_positions
+    moved = (p + np.sin(p[:, ::-1] * np.float32(1.7)).astype(np.float32) * np.float32(0.05)).astype(np.float32)
+    n = len(p)
+    un = np.zeros(n, T.GpuUnskinnedVertex)
+    un["Position"] = p
+    un["Normal"] = sc.vertices["Normal"][:n] if "Normal" in sc.vertices.dtype.names else 0
+    un["Tangent"] = sc.vertices["Tangent"][:n] if "Tangent" in sc.vertices.dtype.names else 0
+    un["JointIndices"][:, 0] = 0; un["JointIndices"][:, 1] = 1
+    w0 = (np.float32(0.5) + np.float32(0.5) * np.sin(p[:, 1] * np.float32(0.3))).astype(np.float32)
+    un["JointWeights"][:, 0] = w0; un["JointWeights"][:, 1] = np.float32(1.0) - w0
+    joints = np.zeros((2, 3, 4), np.float32)
+    c, s_ = np.float32(np.cos(0.05)), np.float32(np.sin(0.05))
+    joints[0, :, :3] = [[c, 0, s_], [0, 1, 0], [-s_, 0, c]]; joints[0, :, 3] = (0.02, 0.0, -0.01)
+    joints[1, :, :3] = np.eye(3); joints[1, :, 3] = (0.0, 0.03, 0.0)
+    return sc, moved, un, joints
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def make_full_updates(check=False):
+    from oracle.glref import glref as G
+    from idkengine_amd.bvh import NativeBuilder
+    t0 = time.time()
+    sc, moved, un, joints = full_update_inputs(NativeBuilder())
+    up = G.ReferenceSceneUpdates(sc)
+    up.set_positions(moved)
+    nodes = up.refit(0)
+    out = {"refit_nodes_hash": sha(nodes), "refit_nodes_sample": nodes[::509], "node_count": np.int64(len(nodes))}
+    up.set_positions(sc.vertex_positions)
+    pos, prev, verts = up.skin(un, joints, 0, 0, 0, len(un))
+    out["skin_positions_hash"] = sha(pos); out["skin_positions_sample"] = pos[::1021]
+    out["skin_prev_is_input"] = np.array([np.array_equal(prev, sc.vertex_positions)])
+    out["skin_normals_sample"] = verts["Normal"][::1021]; out["skin_tangents_sample"] = verts["Tangent"][::1021]
+    up.close()
+    path = os.path.join(OUT, "updates_1m.npz")
+    if check:
+        fx = np.load(path)
+        bad = [k for k in out if not (k in fx and np.asarray(out[k]).tobytes() == np.asarray(fx[k]).tobytes())]
+        print("updates_1m", "reproduced" if not bad else f"DIFFERS in {bad}", flush=True)
+        if bad:
+            raise SystemExit(1)
+        return
+    np.savez_compressed(path, **out)
+    print("updates_1m written", os.path.getsize(path), "bytes in", round(time.time() - t0, 1), "s:", len(nodes), "nodes,", len(un), "vertices", flush=True)
+
+
 if __name__ == "__main__":
-    main([a for a in sys.argv[1:] if not a.startswith("--")], check="--check" in sys.argv)
+    if "--updates" in sys.argv:
+        make_full_updates(check="--check" in sys.argv)
+    else:
+        main([a for a in sys.argv[1:] if not a.startswith("--")], check="--check" in sys.argv)

@@ -34,3 +34,31 @@ def test_hip_whole_frames_are_the_states_compared_with_the_reference(name, nativ
         pt = gpu_render(sc, cam, w, h, counters=True, capture=False, **ov); st = pt.stats(); pt.Dispose()
         glref_check.check_traversal_cost(fx, st["node_pair_visits"], st["triangle_tests"])
     assert all(s["state_is_the_compared_state"] and s["beyond_tol_in_sample"] == 0 for s in rep["stages"]), rep
+
+
+def test_hip_refit_and_skinning_at_config5_size_match_reference_shaders(native_builder):
+    """The device refit (level-synchronous) and the skinning kernel on the refittable 1M-triangle scene / 3 M vertices against the reference's BLASRefit and
+    Skinning shaders run on llvmpipe over the whole scene: all 1.85 M nodes and all 3 M skinned positions bit-identical (sha256), re-compressed normals /
+    tangents within one quantisation step on the sampled vertices (llvmpipe's inversesqrt)."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    from test_glref_full import _mfv, _sha
+    fx = np.load(os.path.join(FIXTURES, "updates_1m.npz"))
+    sc, moved, un, joints = _mfv().full_update_inputs(native_builder)
+    pt = PathTracer(8, 8); pt.UploadScene(sc)
+    pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, moved)
+    pt.RefitBlas(0)
+    nodes = pt.DownloadBuffer(T.IDKPT_BUF_BLAS_NODES, T.GpuBlasNode, len(sc.blas_nodes))
+    assert np.array_equal(_sha(nodes), fx["refit_nodes_hash"]) and nodes[::509].tobytes() == fx["refit_nodes_sample"].tobytes()
+    pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, sc.vertex_positions)
+    pt.UploadUnskinnedVertices(un); pt.UpdateBuffer(T.IDKPT_BUF_JOINT_MATRICES, joints)
+    pt.Skin(0, 0, 0, len(un)); pt.synchronize()
+    pos = pt.DownloadBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, np.float32, 3 * len(moved)).reshape(-1, 3)
+    assert np.array_equal(_sha(pos), fx["skin_positions_hash"]) and pos[::1021].tobytes() == fx["skin_positions_sample"].tobytes()
+    verts = pt.DownloadBuffer(T.IDKPT_BUF_VERTICES, T.GpuVertex, len(sc.vertices))
+    for field, key in (("Normal", "skin_normals_sample"), ("Tangent", "skin_tangents_sample")):
+        got, ref = verts[field][::1021].astype(np.int64), fx[key].astype(np.int64)
+        assert (got == ref).mean() >= 0.98, (field, (got == ref).mean())
+        for shift, mask in ((0, 2047), (11, 2047), (22, 1023)):
+            assert np.abs(((got >> shift) & mask) - ((ref >> shift) & mask)).max() <= 1, field
+    pt.Dispose()
