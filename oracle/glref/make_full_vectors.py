@@ -124,6 +124,26 @@ def main(names, check=False):
             cur = nxt
             record_stage(j, qin.astype(np.uint32), nxt[0][qin], rout[qin], nxt[1], np.asarray(qout, np.uint32), o_in, d_in)
         pt.close()
+        # ---- the reference's own whole frames, free-running (FirstHit, NHit, FinalDraw; two accumulated samples): only where no later bounce can shift RNG slots (RayDepth 2)
+        if depth == 2 and not st.Gpu.DoDebugBVHTraversal:
+            nfree = 2
+            ptf = G.ReferencePathTracer(sc, w, h, st); ptf.set_camera(cam)
+            o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov)
+            for _ in range(nfree):
+                ptf.render(); o.render()
+            rimg = np.asarray(ptf.image(0), np.float32).reshape(-1, 4); oimg = np.asarray(o.image(0), np.float32).reshape(-1, 4)
+            counts_same = [int(c) for c in ptf.alive_counts] == [int(c) for c in list(o.stats()["alive_counts"])[1:1 + len(ptf.alive_counts)]]
+            ptf.close(); o.close()
+            rel = glref_check.pixel_rel_err(oimg, rimg)
+            px = np.nonzero(rel > glref_check.REL_TOL)[0].astype(np.uint32)
+            samp = np.arange(0, w * h, stride)
+            out["free_samples"] = np.int64(nfree); out["free_image_hash"] = sha(oimg)
+            out["free_idx"] = samp.astype(np.uint32); out["free_ref"] = rimg[samp]
+            out["free_exc_px"] = px; out["free_exc_ref"] = rimg[px]; out["free_exc_cand"] = oimg[px]
+            rep["free_run"] = {"samples": nfree, "pixels": int(w * h), "pixels_beyond_tol": int(len(px)), "alive_counts_identical": bool(counts_same),
+                               "pixels_bit_equal": round(float((rimg.view(np.uint32) == oimg.view(np.uint32)).all(axis=1).mean()), 4),
+                               "max_rel_within_tol": float(rel[rel <= glref_check.REL_TOL].max())}
+            print("  ", name, json.dumps(rep["free_run"]), flush=True)
         rep["seconds"] = round(time.time() - t0, 1)
         path = os.path.join(OUT, name + ".npz")
         if check:       # regenerate in memory and demand the committed fixture bit for bit (tests/test_glref_full.py, `live`)

@@ -208,6 +208,25 @@ def check_traversal_cost(fx, pairs, tri_tests):
     return {"pairs_plus_1.1_tests": mine, "reference_debugCost_sum": ref, "relative_difference": abs(mine - ref) / ref}
 
 
+FULL_ALLOW_FREE = {"full_headline_d2": 8}     # pixels of the free-running two-sample frame beyond tolerance: the listed closest-hit rays (4 per sample)
+
+
+def check_full_frame(fx, image, name=None):
+    """The reference's own free-running frame (FirstHit, NHit, FinalDraw; fx["free_samples"] accumulated samples) against the candidate's Result image: the candidate's
+    image must be the one that was compared pixel by pixel at generation (sha256), agree with the reference's on the sampled pixels, and the listed pixels stay bounded."""
+    img = np.asarray(image, np.float32).reshape(-1, 4)
+    import hashlib
+    same = bool(np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(img).tobytes()).digest(), np.uint8), np.asarray(fx["free_image_hash"], np.uint8)))
+    idx = np.asarray(fx["free_idx"], np.int64); exc = np.asarray(fx["free_exc_px"], np.int64)
+    keep = ~np.isin(idx, exc)
+    rel = pixel_rel_err(img[idx][keep], np.asarray(fx["free_ref"], np.float32)[keep])
+    rep = {"image_is_the_compared_image": same, "sampled_pixels": int(keep.sum()), "beyond_tol_in_sample": int((rel > REL_TOL).sum()), "listed_pixels": int(len(exc))}
+    assert same, rep
+    assert rep["beyond_tol_in_sample"] == 0, rep
+    assert name is None or len(exc) <= FULL_ALLOW_FREE[name], (rep, FULL_EXCEPTION_REASON)
+    return rep
+
+
 def check_full_case(fx, state_at, strict=True, only_last=False, name=None):
     """fx: a tests/golden/glref_full fixture; state_at(d) -> (ray records of the whole frame, alive queue) of the implementation under test after a frame of
     RayDepth d.  Per stage: (1) the candidate's state must be, bit for bit, the state that was compared with the reference ray by ray at generation

@@ -64,6 +64,11 @@ def test_oracle_still_produces_the_state_compared_with_the_reference(name, oracl
     # the headline case stage by stage; the others on their last compared stage (one whole-frame oracle render each keeps the CPU suite short)
     rep = glref_check.check_full_case(fx, state_at, strict=True, only_last=(name != "full_headline_d2"), name=name)
     assert all(s["state_is_the_compared_state"] and s["beyond_tol_in_sample"] == 0 for s in rep["stages"]), rep
+    if "free_image_hash" in fx:  # the reference's whole free-running frame (incl. FinalDraw, accumulated samples) against the oracle's Result image
+        o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov)
+        for _ in range(int(fx["free_samples"])):
+            o.render()
+        glref_check.check_full_frame(fx, o.image(0), name=name); o.close()
     if "ref_cost_sum" in fx:     # the reference's own traversal-cost counter against the oracle's P / T counters (the numerator of the roofline)
         o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.enable_counters(True); o.render(); st = o.stats(); o.close()
         glref_check.check_traversal_cost(fx, st["node_pair_visits"], st["triangle_tests"])

@@ -30,6 +30,9 @@ def test_hip_whole_frames_are_the_states_compared_with_the_reference(name, nativ
         return r, q
     rep = glref_check.check_full_case(fx, state_at, strict=True, name=name)
     assert len(rep["stages"]) >= (1 if "debugcost" in name else 2)
+    if "free_image_hash" in fx:  # the reference's whole free-running frame (FirstHit, NHit, FinalDraw; accumulated samples) against the Result image of the C-ABI
+        pt = gpu_render(sc, cam, w, h, counters=False, capture=False, frames=int(fx["free_samples"]), **ov)
+        glref_check.check_full_frame(fx, pt.Result, name=name); pt.Dispose()
     if "ref_cost_sum" in fx:     # the reference's own traversal-cost counter against the HIP path's P / T counters (the numerator of bench.py's roofline)
         pt = gpu_render(sc, cam, w, h, counters=True, capture=False, **ov); st = pt.stats(); pt.Dispose()
         glref_check.check_traversal_cost(fx, st["node_pair_visits"], st["triangle_tests"])
