@@ -451,7 +451,7 @@ class ReferencePathTracer(_ReferenceHost):
                 if j > 1:
                     if self.sort_count_fix:
                         self._w32(self.b_pt, 20, [ping])                                          # A7 (reference defect D1)
-                    self._ray_sorting()
+                    self._ray_sorting(count)
                 self._w32(self.b_wg_prefix, 0, np.zeros(PREFIX_SUM_CAPACITY, np.uint32))          # workGroupPrefixSumBuffer.Fill(0)
             prev_in = self.alive_queue(count)
             self.alive_counts.append(count)
@@ -474,13 +474,16 @@ class ReferencePathTracer(_ReferenceHost):
         if err:
             raise RuntimeError(f"GL error 0x{err:x} during render")
 
-    def run_nhit_from(self, rays, queue, j, aov=None, sort_first=False):
+    def run_nhit_from(self, rays, queue, j, aov=None, sort_first=False, keys=None):
         """One NHit dispatch (bounce j) from a GIVEN state: `rays` (W*H GpuWavefrontRay records) and `queue` (alive ray
         indices in slot order), as left by j-1 completed bounces.  Returns (rays after, surviving queue in canonical order).
         Lets a checker compare every bounce from identical inputs, so that one flipped discrete decision (a 1-ulp
         difference at an edge or at a Russian-roulette threshold) does not shift every later slot-seeded RNG stream.
         sort_first (DoRaySorting, j > 1): run RaySorting() on the queue first, with the keys and histogram the previous
-        run_nhit_from call (bounce j-1, whose surviving queue must be `queue`) left in the buffers."""
+        run_nhit_from call (bounce j-1, whose surviving queue must be `queue`) left in the buffers — or, with `keys` (one per queue entry), with exactly these
+        keys: they are part of the state between two dispatches, and a caller that forces the state forces them too (the cached-key buffer and the histogram NHit
+        j-1 builds with atomicAdd, NHit/compute.glsl:80-85, are rewritten from `keys`).  One ray whose closest hit is a tie between two copies of a pre-split
+        triangle reports another TriangleId under another rounding of 1/dir; its key then moves it to another run and every slot in between shifts by one."""
         L = self.L
         ping = j % 2
         rays = np.ascontiguousarray(rays); queue = np.ascontiguousarray(queue, np.uint32)
@@ -499,7 +502,12 @@ class ReferencePathTracer(_ReferenceHost):
         L.glref_buffer_write(self.b_settings, 0, 32, s.ctypes.data)
         if self.st.DoRaySorting:
             if sort_first and j > 1 and len(queue):
-                self._ray_sorting()
+                if keys is not None:
+                    k = np.ascontiguousarray(keys, np.uint32)
+                    assert len(k) == len(queue) and (k.max() < PREFIX_SUM_CAPACITY if len(k) else True)
+                    self._w32(self.b_keys, 0, k)
+                    self._w32(self.b_wg_prefix, 0, np.bincount(k, minlength=PREFIX_SUM_CAPACITY).astype(np.uint32))
+                self._ray_sorting(len(queue))
                 queue = self.alive_queue(len(queue))
             self._w32(self.b_wg_prefix, 0, np.zeros(PREFIX_SUM_CAPACITY, np.uint32))
         if len(queue):
@@ -509,8 +517,10 @@ class ReferencePathTracer(_ReferenceHost):
         out = self.alive_queue(count)
         rank = np.full(self.W * self.H, -1, np.int64); rank[queue] = np.arange(len(queue))
         order = np.argsort(rank[out], kind="stable")
+        self.last_out_keys = None
         if self.st.DoRaySorting and count:
             k = self._u32(self.b_keys, 0, count); self._w32(self.b_keys, 0, k[order])
+            self.last_out_keys = k[order].copy()               # the keys this dispatch cached, entry by entry of the returned queue
         return self.rays(rays.dtype), out[order]
 
     def _canonicalise(self, j, count, prev_in):
@@ -527,12 +537,27 @@ class ReferencePathTracer(_ReferenceHost):
             k = self._u32(self.b_keys, 0, count)
             self._w32(self.b_keys, 0, k[order])
 
-    def _ray_sorting(self):
-        """PathTracer.RaySorting (PathTracer.cs:273-297)."""
+    def _ray_sorting(self, count=None):
+        """PathTracer.RaySorting (PathTracer.cs:273-297).  Reorder places an entry at blockOffset + atomicAdd(PrefixSum[key], 1) (Reorder/compute.glsl:24-25):
+        WHICH of the entries of one key gets which slot of the key's run is scheduling-dependent in the reference (llvmpipe runs work groups on several threads;
+        with more than 2^21 triangles, where far-apart entries alias to one key, it shows).  Every such order is a valid execution; with canonical_order the host
+        checks that the reference's output is a counting sort of exactly these keys — every entry inside the run of its own key — and rewrites each run into the
+        order the oracle fixes (increasing old slot = the stable sort): again a permutation of the reference's own output, nothing is recomputed."""
         L = self.L
+        q0 = k0 = None
+        if self.canonical and count:
+            q0 = self.alive_queue(count); k0 = self._u32(self.b_keys, 0, count)
         L.glref_dispatch(self.group_wise, PREFIX_SUM_CAPACITY >> GROUP_WISE_PROGRAM_STEPS, 1, 1); L.glref_barrier()
         L.glref_dispatch(self.down_up, 1, 1, 1); L.glref_barrier()
         L.glref_dispatch_indirect(self.reorder, self.b_pt, 0); L.glref_barrier()
+        if q0 is not None and self.sort_count_fix:
+            sq = self._u32(self.b_sorted, 0, count)
+            key_of = np.zeros(self.W * self.H, np.uint32); key_of[q0] = k0
+            order = np.argsort(k0, kind="stable")
+            if not (np.array_equal(key_of[sq], k0[order]) and np.array_equal(np.sort(sq), np.sort(q0))):
+                raise RuntimeError("the reference's Reorder output is not a counting sort of the cached keys")
+            self.sort_entries_moved_inside_their_runs = getattr(self, "sort_entries_moved_inside_their_runs", 0) + int((sq != q0[order]).sum())
+            self._w32(self.b_sorted, 0, q0[order])
         L.glref_buffer_copy(self.b_sorted, self.b_pt, 0, HEADER_BYTES, self.W * self.H * 4)
 
 

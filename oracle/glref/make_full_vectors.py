@@ -65,8 +65,8 @@ def main(names, check=False):
 
         def oracle_state(d):
             o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.settings.RayDepth = d; o.settings.SamplesPerPixel = 1
-            o.render(); r, q = o.rays().copy(), o.alive_queue().copy(); o.close()
-            return r, q
+            o.render(); r, q, k = o.rays().copy(), o.alive_queue().copy(), o.alive_keys().copy(); o.close()
+            return r, q, k
         out = {"mesa": np.frombuffer(G.gl().glref_info(), np.uint8), "depth": depth, "width": w, "height": h, "stride": stride}
         rep = {"stages": []}
         st1 = configs.apply_settings(T.Settings.default(), ov); st1.RayDepth = 1; st1.SamplesPerPixel = 1
@@ -87,7 +87,7 @@ def main(names, check=False):
             out[f"idx_{j}"] = ids[samp].astype(np.uint32); out[f"ref_{j}"] = ref[samp]
             out[f"exc_ids_{j}"] = ids[pos].astype(np.uint32); out[f"exc_ref_{j}"] = ref[pos]; out[f"exc_cand_{j}"] = cand[pos]
             bf = np.zeros((0, 4))
-            if len(pos):
+            if 0 < len(pos) <= 2000:     # (a stage with more listed rays than that has a systematic difference: no point in asking the brute force about each)
                 bf = brute_force_exceptions(sc, in_origins[pos], in_dirs[pos], cand["Origin"][pos].astype(np.float64), ref["Origin"][pos].astype(np.float64))
             out[f"exc_bf_{j}"] = bf
             stage = {"stage": "FirstHit" if j == 0 else f"NHit{j}", "rays": int(len(ids)), "flips": int(len(flips)), "beyond_tol": int(beyond.sum()), "exceptions": int(len(pos)),
@@ -112,17 +112,25 @@ def main(names, check=False):
                                      "pixels_with_identical_cost": float((ref_rays["PreviousIOROrTraverseCost"].view(np.uint32) == cur[0]["PreviousIOROrTraverseCost"].view(np.uint32)).mean())}
             print("  ", name, json.dumps(rep["traversal_cost"]), flush=True)
         prev_out = None
+        key_diffs = {}
         for j in range(1, depth):
-            rin, qin = cur
-            if st.DoRaySorting and j > 1 and not np.array_equal(prev_out, qin):
-                print(f"  {name}: bounce {j} not comparable from forced inputs (the reference's bounce {j - 1} queue differs; no sort keys for it)")
-                break
-            rout, qout = pt.run_nhit_from(rin, qin, j, sort_first=bool(st.DoRaySorting)); prev_out = qout
+            rin, qin = cur[0], cur[1]
+            rout, qout = pt.run_nhit_from(rin, qin, j, sort_first=bool(st.DoRaySorting), keys=(cur[2] if (st.DoRaySorting and j > 1) else None)); prev_out = qout
             nxt = oracle_state(j + 1)
+            if st.DoRaySorting and pt.last_out_keys is not None:
+                # the keys the reference's dispatch cached for the next sort against the oracle's, ray by ray (a key is a TriangleId: a discrete result of the stage)
+                kr = np.zeros(w * h, np.int64) - 1; kr[np.asarray(qout, np.int64)] = pt.last_out_keys
+                ko = np.zeros(w * h, np.int64) - 1; ko[nxt[1].astype(np.int64)] = nxt[2]
+                both = np.intersect1d(qout, nxt[1])
+                kd = both[kr[both] != ko[both]]
+                out[f"key_diff_ids_{j}"] = kd.astype(np.uint32); out[f"key_diff_ref_{j}"] = kr[kd].astype(np.uint32); out[f"key_diff_cand_{j}"] = ko[kd].astype(np.uint32)
+                key_diffs[j] = int(len(kd))
             o_in = rin["Origin"][qin].astype(np.float64)
             d_in = glref_check.decode_unit_vec(rin["PackedDirectionX"][qin], rin["PackedDirectionY"][qin])
             cur = nxt
             record_stage(j, qin.astype(np.uint32), nxt[0][qin], rout[qin], nxt[1], np.asarray(qout, np.uint32), o_in, d_in)
+            if j in key_diffs:
+                rep["stages"][-1]["sort_keys_differing"] = key_diffs[j]
         pt.close()
         # ---- the reference's own whole frames, free-running (FirstHit, NHit, FinalDraw; two accumulated samples): only where no later bounce can shift RNG slots (RayDepth 2)
         if depth == 2 and not st.Gpu.DoDebugBVHTraversal:

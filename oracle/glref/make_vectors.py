@@ -47,13 +47,13 @@ def defect_d1():
         seen = {}
         inner = pt._ray_sorting
 
-        def spy():
+        def spy(count_arg=None):
             hdr = pt.header()
             new = 1 - hdr["pingpong"] if not fix else hdr["pingpong"]
             cnt = int(hdr["counts"][new])
             before = pt.alive_queue(cnt); keys = pt._u32(pt.b_keys, 0, cnt)
             item_count_seen_by_reorder = int(hdr["counts"][hdr["pingpong"]])
-            inner()
+            inner(count_arg)
             after = pt.alive_queue(cnt)
             seen.update(alive=cnt, reorder_item_count=item_count_seen_by_reorder, dispatched_invocations=int(hdr["groups"][0]) * 32,
                         is_permutation=bool(np.array_equal(np.sort(before), np.sort(after))),

@@ -53,6 +53,7 @@ def lib():
         L.ref_pt_get_rays.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_pt_get_primary_hits.argtypes = [C.c_void_p] * 4
         L.ref_pt_get_alive.restype = C.c_uint32; L.ref_pt_get_alive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.ref_pt_get_alive_keys.restype = C.c_uint32; L.ref_pt_get_alive_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ref_pt_get_stats.argtypes = [C.c_void_p] * 5
         L.ref_pt_accumulated.restype = C.c_uint32; L.ref_pt_accumulated.argtypes = [C.c_void_p]
         L.ref_pt_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -245,6 +246,14 @@ class OraclePathTracer:
         out = np.zeros(n, np.uint32)
         if n:
             lib().ref_pt_get_alive(self._pt, out.ctypes.data, n)
+        return out
+
+    def alive_keys(self):
+        """Sort keys of the alive queue's entries (cached by the last NHit; empty after FirstHit or without DoRaySorting in effect)."""
+        n = lib().ref_pt_get_alive_keys(self._pt, None, 0)
+        out = np.zeros(n, np.uint32)
+        if n:
+            lib().ref_pt_get_alive_keys(self._pt, out.ctypes.data, n)
         return out
 
     def stats(self):

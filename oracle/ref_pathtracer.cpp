@@ -855,6 +855,8 @@ void ref_pt_get_image(void* p, int which, float* out) { PT* pt = (PT*)p; memcpy(
 void ref_pt_get_rays(void* p, GpuWavefrontRay* out) { PT* pt = (PT*)p; memcpy(out, pt->rays.data(), pt->rays.size() * sizeof(GpuWavefrontRay)); }
 void ref_pt_get_primary_hits(void* p, float* t, uint32_t* tri, float* bary) { PT* pt = (PT*)p; size_t N = pt->primT.size(); memcpy(t, pt->primT.data(), 4 * N); memcpy(tri, pt->primTri.data(), 4 * N); memcpy(bary, pt->primBary.data(), 8 * N); }
 uint32_t ref_pt_get_alive(void* p, uint32_t* out, uint32_t cap) { PT* pt = (PT*)p; uint32_t n = (uint32_t)pt->alive.size(); if (out) memcpy(out, pt->alive.data(), 4 * (size_t)std::min(n, cap)); return n; }
+// sort keys cached by the last NHit for the alive queue, entry by entry (NHit/compute.glsl:80-85; empty after FirstHit) — the checker forces them as part of a stage's input state
+uint32_t ref_pt_get_alive_keys(void* p, uint32_t* out, uint32_t cap) { PT* pt = (PT*)p; uint32_t n = (uint32_t)pt->keys.size(); if (out) memcpy(out, pt->keys.data(), 4 * (size_t)std::min(n, cap)); return n; }
 void ref_pt_get_stats(void* p, uint64_t* raysTraced, uint64_t* pairs, uint64_t* tris, uint32_t* aliveCounts16) { PT* pt = (PT*)p; *raysTraced = pt->raysTraced; *pairs = pt->counters.pairs; *tris = pt->counters.tris; memcpy(aliveCounts16, pt->aliveCounts, 64); }
 uint32_t ref_pt_accumulated(void* p) { return ((PT*)p)->accumulated; }
 void ref_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }   // cpu_baseline leg of bench.py: pick the thread count the host actually scales to
