@@ -92,6 +92,8 @@ FULL_SCENES = {
     "atrium262k": lambda b: S.atrium_scene(262000, b),
     "soup4m": lambda b: S.soup_scene(4000000, b, seed=3),
     "soup2m3": lambda b: S.soup_scene(2300000, b, seed=2),
+    "lucy": configs.lucy_scene,
+    "helmet": configs.helmet_scene,
 }
 FULL_CASES = {
     "full_headline_d2": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=2)),                                            # BASELINE configs[2], the bench line
@@ -101,6 +103,9 @@ FULL_CASES = {
     # the reference's own traversal-cost counter (BVHIntersect.glsl:45,60: +1 per node pair, +1.1 per triangle test) on the headline frame's primary rays:
     # pins the P and T that the roofline's algorithmic bytes are computed from against the reference's count, pixel by pixel and in total
     "full_headline_debugcost_d1": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=1, DoDebugBVHTraversal=1)),
+    # the two meshes the reference ships (shared vertices, slivers), at full HD
+    "full_lucy_d5": ("lucy", configs.lucy_camera, 1080, 1920, dict(RayDepth=5)),
+    "full_helmet_sort_d4": ("helmet", configs.helmet_camera, 1920, 1080, dict(RayDepth=4, DoRaySorting=1)),
     # more than 2^21 triangles with DoRaySorting: triangle ids alias in the reference's 21-bit sort key (NHit/compute.glsl:81) — the reference's own CountingSort on the aliased keys
     "full_soup2m3_sort_d4": ("soup2m3", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0)), 1920, 1080, dict(RayDepth=4, DoRaySorting=1)),
     "full_soup4m_4k_d9": ("soup4m", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(0.3, 0.1, -1.0)), 3840, 2160, dict(RayDepth=9)),   # configs[4] stand-in (sample 0 of its 4 spp)
