@@ -50,6 +50,7 @@ struct DevOptions {
     int ldsPad = 0;              // bytes of LDS added per workgroup of k_trace2 (caps the resident waves)
     int traceWaves = 0;          // one-wave workgroups per CU in the persistent grid (0: what LDS allows, at most 32)
     int gridHint = 2;            // bounce launches: grid = gridHint x the queue length the same bounce had in the previous batch (0: full grid)
+    int gridMidWaves = 20;       // launches below GRID_MID_RAYS rays: one-wave workgroups per CU (0: off) — see small_launch_grid
     int gridRaysX4 = 6;          // small launches: quarter-rays per lane the persistent grid is sized for (from the previous batch's counts; 0: gridHint's rule alone)
     int nodeLayout = 0;          // derived node order (node_layout.hpp): 0 = reference order (default: the derived orders raise the L2 hit rate, not the speed — profiles/r03_layout_order_pmc.json), 1 = line couples depth-first, 2 = line couples in treelets
     int treeletDepth = 3;
@@ -748,6 +749,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "trace_waves") o.traceWaves = std::max(0, value);
     else if (n == "grid_hint") o.gridHint = std::max(0, value);
     else if (n == "grid_rays_x4") o.gridRaysX4 = std::max(0, value);
+    else if (n == "grid_mid_waves") o.gridMidWaves = std::max(0, value);
     else if (n == "bvh_timing") o.bvhTiming = value != 0;
     else if (n == "bvh_small") o.bvhSmall = value;
     else if (n == "bvh_stackopt_host") o.bvhStackOptHost = value != 0;
@@ -1439,12 +1441,17 @@ static bool fast_path(dev_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st
 //   * launches below ~1.5 rays per lane of the full grid run faster on FEWER, fuller waves — every wave instruction costs the same whatever its exec mask, and a
 //     launch this small lasts as long as its longest rays, whose steps get faster when fewer waves share a SIMD: raysX4 / 4 rays per lane, but not below
 //     1024 waves where the first rule allows them (round 3, same box: headline one frame at a time +6 %, Cornell 1080p RayDepth 5 +12 %; profiles/r03_trace_experiments.md 7).
-static uint32_t small_launch_grid(uint32_t fullGrid, uint32_t prev, int hintMul, int raysX4)
+//   * launches of up to GRID_MID_RAYS rays (the headline frame with up to ~24 samples in flight, one rank's share of an N-GPU frame) run 2-4 % faster on 20 than on 24
+//     waves per CU for the same reason, and views whose launches are that small only with a few samples in flight (every pixel traversing) lose nothing measurable;
+//     above it 24 is never worse (profiles/r03_trace_experiments.md 9).
+#define GRID_MID_RAYS 14000000u
+static uint32_t small_launch_grid(uint32_t fullGrid, uint32_t prev, int hintMul, int raysX4, uint32_t midGrid)
 {
     if (prev == 0u || hintMul <= 0) return fullGrid;
     const uint32_t cap = std::max<uint32_t>(256u, (uint32_t)(((uint64_t)hintMul * prev + 63) / 64));
     uint32_t g = cap;
     if (raysX4 > 0) g = std::max<uint32_t>((uint32_t)(((uint64_t)prev * 4u / (uint32_t)raysX4 + 63) / 64), std::min<uint32_t>(cap, 1024u));
+    if (midGrid > 0u && prev < GRID_MID_RAYS) g = std::min(g, midGrid);
     return std::min(fullGrid, std::min(g, cap));
 }
 
@@ -1508,6 +1515,7 @@ static int flush_batch(dev_ctx* ctx)
     if (ctx->opt.traceWaves > 0) wavesPerCU = ctx->opt.traceWaves;   // option "trace_waves": one-wave workgroups per CU in the persistent grid
     // (a launch never needs more waves than it can have rays: small frames would otherwise spend their time dispatching idle workgroups)
     const uint32_t traceGrid = std::min<uint32_t>((uint32_t)(ctx->numCUs * wavesPerCU), std::max<uint32_t>(1u, (uint32_t)(((size_t)B * N + 63) / 64)));
+    const uint32_t midGrid = (ctx->opt.gridMidWaves > 0 && ctx->opt.traceWaves == 0) ? (uint32_t)(ctx->numCUs * std::min(wavesPerCU, ctx->opt.gridMidWaves)) : 0u;   // (an explicit trace_waves wins)
     const bool debug = f.g.DoDebugBVHTraversal != 0;
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);
@@ -1545,7 +1553,7 @@ static int flush_batch(dev_ctx* ctx)
             hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
             TRACE_T0();
             uint32_t grid0 = traceGrid;
-            if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4);
+            if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4, midGrid);
             launch_trace2<true>(ctx, grid0, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
@@ -1632,7 +1640,7 @@ static int flush_batch(dev_ctx* ctx)
         // possibly one batch stale) is a good predictor, and a grid that is too small or too large only costs time (the waves are persistent)
         uint32_t gridj = traceGrid;
         const int hintMul = ctx->opt.gridHint;
-        if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) gridj = small_launch_grid(traceGrid, ctx->hBases[(size_t)j * BS + B], hintMul, ctx->opt.gridRaysX4);
+        if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) gridj = small_launch_grid(traceGrid, ctx->hBases[(size_t)j * BS + B], hintMul, ctx->opt.gridRaysX4, midGrid);
         if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, trj, hits, (const uint32_t*)q, cnt, work + j, counters);
         else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
@@ -1867,7 +1875,7 @@ static int32_t dev_ResetStats(dev_ctx* ctx)
     HIPC(hipStreamSynchronize(ctx->stream));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;
-    memset(ctx->hCounts, 0, MAX_DEPTH_SLOTS * 4);
+    memset(ctx->hCounts, 0, (MAX_DEPTH_SLOTS - 1) * 4);     // (the last word, the length of the primary active list, is also the grid hint of the next batch: idkptGetStats reports it only once frames were rendered)
     HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
 }

@@ -17,7 +17,10 @@ if __name__ == "__main__" and os.environ.get("SHARD_TWO") != "1":
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     sc = S.soup_scene(1000000, NativeBuilder(), seed=1); cam = S.Camera(W, H)
     for mod in (1, N):
-        for opts in ({}, {"leaf_min": 12}, {"leaf_min": 16}, {"leaf_min": 20}, {"grid_hint": 0}, {"trace_waves": 16}, {"trace_waves": 32}):
+        sets = ({}, {"leaf_min": 12}, {"leaf_min": 16}, {"leaf_min": 20}, {"grid_hint": 0}, {"trace_waves": 16}, {"trace_waves": 32})
+        if os.environ.get("SHARD_OPTS") == "grid":
+            sets = ({}, {"grid_rays_x4": 0}, {"grid_rays_x4": 8}, {"grid_rays_x4": 12}, {"grid_rays_x4": 16}, {"grid_rays_x4": 24}, {"trace_waves": 20}, {"trace_waves": 16}, {"trace_waves": 12})
+        for opts in sets:
             pt = PathTracer(W, H, row_modulo=mod, row_remainder=0)
             for k, v in opts.items():
                 pt.set_option(k, v)
