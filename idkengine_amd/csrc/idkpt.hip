@@ -1516,6 +1516,7 @@ static int flush_batch(dev_ctx* ctx)
     // (a launch never needs more waves than it can have rays: small frames would otherwise spend their time dispatching idle workgroups)
     const uint32_t traceGrid = std::min<uint32_t>((uint32_t)(ctx->numCUs * wavesPerCU), std::max<uint32_t>(1u, (uint32_t)(((size_t)B * N + 63) / 64)));
     const uint32_t midGrid = (ctx->opt.gridMidWaves > 0 && ctx->opt.traceWaves == 0) ? (uint32_t)(ctx->numCUs * std::min(wavesPerCU, ctx->opt.gridMidWaves)) : 0u;   // (an explicit trace_waves wins)
+    f.gridRaysX4 = (uint32_t)std::max(0, ctx->opt.gridRaysX4); f.gridMid = midGrid; f.gridMidRays = GRID_MID_RAYS;   // the same rules inside k_trace2, on the launch's actual ray count
     const bool debug = f.g.DoDebugBVHTraversal != 0;
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);

@@ -279,6 +279,13 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     lds_u32* const stkFull = stkBase + cap * WAVE;
     uint32_t* tstk = lds + lane + (cap + 2) * WAVE;     // TLAS only
     const uint32_t N = *countPtr;
+    {   // How many waves this launch wants is a function of its ray count, which only the device knows for sure (the host sizes the grid from the previous batch's
+        // count when it has one, small_launch_grid in idkpt.hip): waves beyond that retire here, before they touch the work list.  Any number >= 1 is correct.
+        uint32_t want = gridDim.x;
+        if (f.gridRaysX4 > 0u) want = max((uint32_t)(((unsigned long long)N * 4ull / f.gridRaysX4 + 63ull) / 64ull), min(want, 1024u));
+        if (f.gridMid > 0u && N < f.gridMidRays) want = min(want, f.gridMid);
+        if (blockIdx.x >= max(want, 1u)) return;
+    }
     // wave-uniform scene constants
     const GpuBlasInstance inst = s.instances[0];
     const int nodeOffset = s.descs[inst.BlasId].NodeOffset;

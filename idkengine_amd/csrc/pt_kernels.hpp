@@ -40,6 +40,7 @@ struct Frame {
     int useTlas, stackCap, outputAovs;
     int tlasCap;                // rows of the per-lane TLAS stack (<= TLAS_STACK_SIZE; a TLAS over n instances is never deeper than n)
     int leafMin;                // k_trace2 leaves its node phase when this many lanes are parked on a leaf
+    uint32_t gridRaysX4, gridMid, gridMidRays;   // k_trace2: the waves of a launch beyond what its ray count wants retire at once (the rules of small_launch_grid, idkpt.hip, applied on the device to the launch's actual count)
     int grabUnitLog2, grabFixed;   // k_trace2's work-list hand-out: a slice owns runs of 2^grabUnitLog2 entries; developer knob: entries reserved per atomic (0: what the refill needs)
     // batch of independent samples traced together (DESIGN.md "Batching"): sample s owns ray ids [s*Npad, s*Npad+N)
     int batch; uint32_t Npad; uint32_t accum[256];   // [MAX_BATCH]
