@@ -50,6 +50,7 @@ struct DevOptions {
     int ldsPad = 0;              // bytes of LDS added per workgroup of k_trace2 (caps the resident waves)
     int traceWaves = 0;          // one-wave workgroups per CU in the persistent grid (0: what LDS allows, at most 32)
     int gridHint = 2;            // bounce launches: grid = gridHint x the queue length the same bounce had in the previous batch (0: full grid)
+    int graphProbe = 0;          // developer build only: capture the next batch into a hipGraph and time this many replays (tools/graph_probe.py)
     int gridMidWaves = 20;       // launches below GRID_MID_RAYS rays: one-wave workgroups per CU (0: off) — see small_launch_grid
     int gridRaysX4 = 6;          // small launches: quarter-rays per lane the persistent grid is sized for (from the previous batch's counts; 0: gridHint's rule alone)
     int nodeLayout = 0;          // derived node order (node_layout.hpp): 0 = reference order (default: the derived orders raise the L2 hit rate, not the speed — profiles/r03_layout_order_pmc.json), 1 = line couples depth-first, 2 = line couples in treelets
@@ -750,6 +751,9 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "grid_hint") o.gridHint = std::max(0, value);
     else if (n == "grid_rays_x4") o.gridRaysX4 = std::max(0, value);
     else if (n == "grid_mid_waves") o.gridMidWaves = std::max(0, value);
+#ifdef IDKPT_DEVELOPER
+    else if (n == "graph_probe") o.graphProbe = std::max(0, value);
+#endif
     else if (n == "bvh_timing") o.bvhTiming = value != 0;
     else if (n == "bvh_small") o.bvhSmall = value;
     else if (n == "bvh_stackopt_host") o.bvhStackOptHost = value != 0;
@@ -1498,6 +1502,12 @@ static int flush_batch(dev_ctx* ctx)
     uint64_t* counters = ctx->counters64.as<uint64_t>();
     const int depth = ctx->st.RayDepth;
     hipStream_t st = ctx->stream;
+#ifdef IDKPT_DEVELOPER
+    // "graph_probe" (developer build): is a hipGraph of a batch's launches faster than the launches?  The batch is captured instead of executed, then
+    // executed once as a graph and replayed graph_probe times between two events (the replays re-accumulate the same sample: timing only).
+    bool capturing = false;
+    if (ctx->opt.graphProbe > 0 && !ctx->timing) capturing = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+#endif
     if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[0], st));
     if (ctx->countersDirty) { HIPC(hipMemsetAsync(work, 0, WORK_WORDS * 4, st)); HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st)); }   // (otherwise the previous batch's k_final_draw has reset them)
     ctx->countersDirty = true;
@@ -1664,6 +1674,24 @@ static int flush_batch(dev_ctx* ctx)
                        work, (uint32_t)WORK_WORDS, counts, (uint32_t)MAX_DEPTH_SLOTS);
     HIPC(hipGetLastError());
     ctx->countersDirty = false;
+#ifdef IDKPT_DEVELOPER
+    if (capturing) {
+        hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr;
+        const int K = ctx->opt.graphProbe; ctx->opt.graphProbe = 0;
+        if (hipStreamEndCapture(st, &g) == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+            hipEvent_t e0 = nullptr, e1 = nullptr; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            (void)hipGraphLaunch(ex, st); (void)hipStreamSynchronize(st);                       // the batch itself (a capture does not execute)
+            (void)hipEventRecord(e0, st);
+            for (int k = 0; k < K; k++) (void)hipGraphLaunch(ex, st);
+            (void)hipEventRecord(e1, st); (void)hipStreamSynchronize(st);
+            float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1);
+            size_t nodes = 0; (void)hipGraphGetNodes(g, nullptr, &nodes);
+            fprintf(stderr, "[idkpt graph] batch of %d sample(s) captured: %zu graph nodes; %d replays: %.1f us per batch\n", B, nodes, K, ms * 1000.0f / (float)K);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipGraphExecDestroy(ex);
+        } else fprintf(stderr, "[idkpt graph] capture or instantiation failed: %s\n", hipGetErrorString(hipGetLastError()));
+        if (g) (void)hipGraphDestroy(g);
+    }
+#endif
     // queue lengths stay on the GPU during the batch; k_scan_blocks mirrors them into host-mapped memory for GetStats and the queue downloads (no copy, no sync here)
     if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[1], st));
     ctx->stats.Frames += (uint64_t)B;
