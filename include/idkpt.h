@@ -105,7 +105,7 @@ typedef struct idkpt_scene_desc {
     const GpuMaterial*      Materials;        int32_t MaterialCount;        /* SSBO 3 */
     const GpuMeshTransform* MeshTransforms;   int32_t MeshTransformCount;   /* SSBO 4 */
     const GpuLight*         Lights;           int32_t LightCount;           /* UBO 2 (<= 256) */
-    const float*            SkyFaces;         int32_t SkyFaceSize;          /* UBO 5: 6 faces (+X,-X,+Y,-Y,+Z,-Z) x S x S x RGBA32F; NULL => black */
+    const float*            SkyFaces;         int32_t SkyFaceSize;          /* UBO 5: 6 faces (+X,-X,+Y,-Y,+Z,-Z) x S x S x RGBA32F, sampled GL_LINEAR + seamless like the reference's skybox; S = 1: six constant face colours (unfiltered); NULL => black */
     const idkpt_texture*    Textures;         int32_t TextureCount;         /* texture table for GpuMaterial handles */
 } idkpt_scene_desc;
 

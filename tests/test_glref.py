@@ -164,3 +164,14 @@ def test_live_preprocessor_follows_the_reference():
             "assert s.startswith('#version 460 core') and '#define APP_SHADER_STAGE_COMPUTE 1' in s\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@live
+def test_live_reference_fuzz_first_seeds():
+    """oracle/glref/fuzz_reference.py: the random cases of tools/fuzz_parity.py (scenes, materials, textures, instances, lights, sky, lens, settings) through the
+    reference's own shaders, stage by stage from identical inputs.  The first 12 seeds (31 stages, 47 000 rays) here; 400 seeds are in profiles/r03_reference_fuzz.json."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "fuzz_reference.py"), "12", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    tot = json.loads(r.stdout.strip().splitlines()[-1])
+    assert tot["cases"] == 12 and tot["stages"] >= 30 and tot["rays"] > 40000
+    assert tot["flips"] == 0 and tot["beyond_tol"] == 0 and tot["key_diffs"] == 0, tot

@@ -82,7 +82,8 @@ def random_scene(rng, builder):
     return sc, extent, lights is not None, nb
 
 
-def one_case(seed, builder):
+def draw_case(seed, builder):
+    """Everything one_case draws, in the same order (also used by oracle/glref/fuzz_reference.py, which runs the same cases through the reference's shaders)."""
     rng = np.random.default_rng(seed)
     sc, extent, has_lights, nb = random_scene(rng, builder)
     w, h = int(rng.choice([17, 40, 64, 96, 131])), int(rng.choice([9, 33, 48, 77]))
@@ -96,6 +97,11 @@ def one_case(seed, builder):
     st = configs.apply_settings(T.Settings.default(), ov)
     opts = {"node_layout": int(rng.choice([0, 0, 1, 2])), "treelet_depth": int(rng.integers(1, 6)), "trace_order": int(rng.choice([0, 0, 1, 2])),
             "grid_rays_x4": int(rng.choice([6, 6, 0, 1, 64])), "grid_mid_waves": int(rng.choice([20, 20, 0, 3])), "grid_hint": int(rng.choice([2, 2, 0, 1])), "trace_waves": int(rng.choice([0, 0, 1, 7]))}   # free choices of the implementation: never visible in the output
+    return sc, cam, w, h, ov, st, opts, frames, batch, nb
+
+
+def one_case(seed, builder):
+    sc, cam, w, h, ov, st, opts, frames, batch, nb = draw_case(seed, builder)
     pt = PathTracer(w, h, settings=st)
     for k_, v_ in opts.items():
         pt.set_option(k_, v_)
