@@ -50,6 +50,7 @@ struct DevOptions {
     int ldsPad = 0;              // bytes of LDS added per workgroup of k_trace2 (caps the resident waves)
     int traceWaves = 0;          // one-wave workgroups per CU in the persistent grid (0: what LDS allows, at most 32)
     int gridHint = 2;            // bounce launches: grid = gridHint x the queue length the same bounce had in the previous batch (0: full grid)
+    int deferLast = 1;           // the last bounce's continuation (state, queue) on demand instead of every frame, where only radiance of it is visible (kernels_shade.hpp k_shade_last)
     int graphProbe = 0;          // developer build only: capture the next batch into a hipGraph and time this many replays (tools/graph_probe.py)
     int gridMidWaves = 20;       // launches below GRID_MID_RAYS rays: one-wave workgroups per CU (0: off) — see small_launch_grid
     int gridRaysX4 = 6;          // small launches: quarter-rays per lane the persistent grid is sized for (from the previous batch's counts; 0: gridHint's rule alone)
@@ -98,6 +99,9 @@ struct dev_ctx {
     // stats
     idkpt_stats stats;
     uint32_t* hCounts = nullptr; uint32_t* dCountsMirror = nullptr;   // host-mapped mirror of the queue lengths (written by k_scan_blocks, read by the host after a sync)
+    bool sceneNoEmission = false;   // no material / mesh of the uploaded scene emits and every texel is finite: a hit of the last bounce cannot change the radiance (k_shade_last)
+    struct { bool valid = false; int j = 0, side = 0, B = 0; uint32_t total = 0, Npad = 0; } defer;   // the last bounce of the last batch still owes its continuation (finish_deferred)
+    DevBuf radSave, deferCount;
     bool countersDirty = true;   // the batch counters were not reset by the last k_final_draw (first batch, or a batch that failed half way)
     uint32_t* hOverflow = nullptr; uint32_t* dOverflow = nullptr;   // host-mapped word the kernels set when a traversal-stack push is dropped (checked after every sync)
     int tlasNeed = 1;            // rows the TLAS walk needs (validated for host-built TLAS nodes; min(instances, TLAS_STACK_SIZE) for a device build)
@@ -232,7 +236,11 @@ static int check_overflow(dev_ctx* ctx)
     return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "traversal stack overflow: a BLAS/TLAS is deeper than the traversal stack (BlasStackSize / TLAS_STACK_SIZE); results since the last synchronisation are invalid");
 }
 #define SYNC_CHECKED() do { HIPC(hipStreamSynchronize(ctx->stream)); int _rc = check_overflow(ctx); if (_rc) return _rc; } while (0)
-#define FLUSH() do { int _rc = flush_batch(ctx); if (_rc) return _rc; } while (0)
+static int finish_deferred(dev_ctx* ctx);
+// FLUSH: issue the samples still queued, and complete a deferred last bounce (readers of ray state / queues, and everything that changes what its kernels would read).
+// FLUSH_KEEP: issue only (images, synchronisation, camera, statistics, batching knobs: nothing that looks at or invalidates the deferred part).
+#define FLUSH() do { int _rc = flush_batch(ctx); if (_rc) return _rc; _rc = finish_deferred(ctx); if (_rc) return _rc; } while (0)
+#define FLUSH_KEEP() do { int _rc = flush_batch(ctx); if (_rc) return _rc; } while (0)
 
 // Rows a traversal stack needs for one BLAS: BLAS.ComputeRequiredStackSize (Bvh/BLAS.cs:672-702) evaluated bottom-up.  Requires what the
 // validation established first: every child pair lies behind its parent (acyclic), so one reverse sweep over the node array suffices.
@@ -374,7 +382,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     DevBuf* all[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
                      &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
-                     &ctx->counts, &ctx->work, &ctx->qwork, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
+                     &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
     for (auto& t : ctx->texData) t.release();
     builder_scratch_free(ctx);
@@ -479,7 +487,7 @@ static int32_t dev_SetPerFrame(dev_ctx* ctx, const float invProjection[16], cons
 {
     if (!ctx || !invProjection || !invView || !viewPos) return IDKPT_ERR_INVALID_ARGUMENT;
     // one camera per batch unless a frame ring is active (then every queued sample carries its own camera)
-    if (ctx->ringSize == 1 && (memcmp(ctx->invProj, invProjection, 64) || memcmp(ctx->invView, invView, 64) || memcmp(ctx->viewPos, viewPos, 12))) FLUSH();
+    if (ctx->ringSize == 1 && (memcmp(ctx->invProj, invProjection, 64) || memcmp(ctx->invView, invView, 64) || memcmp(ctx->viewPos, viewPos, 12))) FLUSH_KEEP();
     memcpy(ctx->invProj, invProjection, 64); memcpy(ctx->invView, invView, 64); memcpy(ctx->viewPos, viewPos, 12);
     return IDKPT_OK;
 }
@@ -556,6 +564,19 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     if ((rc = upload(ctx, ctx->xforms, sc->MeshTransforms, (size_t)sc->MeshTransformCount * sizeof(GpuMeshTransform)))) return rc;
     HIPC(ctx->lights.ensure(IDKPT_MAX_LIGHTS * sizeof(GpuLight)));
     if (sc->Lights && sc->LightCount) HIPC(hipMemcpyAsync(ctx->lights.p, sc->Lights, (size_t)sc->LightCount * sizeof(GpuLight), hipMemcpyHostToDevice, ctx->stream));
+    {   // can a surface of this scene add radiance?  (k_shade_last: without emission the last bounce's hits leave the radiance alone)
+        bool none = true;
+        for (int i = 0; i < sc->MaterialCount && none; i++) { const GpuMaterial& m = sc->Materials[i]; none = m.EmissiveFactor[0] == 0.0f && m.EmissiveFactor[1] == 0.0f && m.EmissiveFactor[2] == 0.0f; }
+        for (int i = 0; i < sc->MeshCount && none; i++) none = sc->Meshes[i].EmissiveBias == 0.0f;
+        for (int i = 0; i < sc->TextureCount && none; i++) {      // (0 x a texel is only 0 for a finite texel)
+            const idkpt_texture& t = sc->Textures[i];
+            if (!(t.width > 0 && t.height > 0 && t.rgba)) { none = false; break; }
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(t.rgba); uint32_t bad = 0;
+            for (size_t k = 0, e = (size_t)t.width * t.height * 4; k < e; k++) bad |= (uint32_t)((w[k] & 0x7f800000u) == 0x7f800000u);
+            none = !bad;
+        }
+        ctx->sceneNoEmission = none;
+    }
     ctx->skySize = (sc->SkyFaces && sc->SkyFaceSize > 0) ? sc->SkyFaceSize : 0;
     if ((rc = upload(ctx, ctx->sky, sc->SkyFaces, (size_t)6 * ctx->skySize * ctx->skySize * 16))) return rc;
     for (auto& t : ctx->texData) t.release();
@@ -659,7 +680,7 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
     ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
     ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
-    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
+    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
     ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase;
     HIPC(hipStreamSynchronize(ctx->stream));           // td is a stack vector
     ctx->haveScene = true;
@@ -726,6 +747,7 @@ static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes,
         HIPC(hipStreamSynchronize(ctx->stream));
         return IDKPT_OK;
     }
+    if (which == IDKPT_BUF_MESHES || which == IDKPT_BUF_MATERIALS) ctx->sceneNoEmission = false;   // (a patched material may emit: decided again at the next idkptUploadScene)
     HIPC(hipMemcpyAsync((char*)b->p + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (which == IDKPT_BUF_VERTEX_POSITIONS) { int rc = regather_triverts(ctx, 0, (uint32_t)ctx->triCount); if (rc) return rc; }
     HIPC(hipStreamSynchronize(ctx->stream));
@@ -751,6 +773,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "grid_hint") o.gridHint = std::max(0, value);
     else if (n == "grid_rays_x4") o.gridRaysX4 = std::max(0, value);
     else if (n == "grid_mid_waves") o.gridMidWaves = std::max(0, value);
+    else if (n == "defer_last") o.deferLast = value != 0;
 #ifdef IDKPT_DEVELOPER
     else if (n == "graph_probe") o.graphProbe = std::max(0, value);
 #endif
@@ -1301,7 +1324,7 @@ static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t co
     if (ctx->st.UseTlas && ctx->tlasCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceRays: UseTlas set but no TLAS nodes uploaded");
     if (count == 0) return IDKPT_OK;
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     Frame f; size_t ldsBytes; uint32_t grid;
     int rc = query_frame(ctx, f, ldsBytes, grid); if (rc) return rc;
     DScene s = make_dscene(ctx);
@@ -1336,7 +1359,7 @@ static int32_t dev_TraceShadows(dev_ctx* ctx, const idkpt_shadow_params* p, cons
     REQUIRE(p->LightIndex >= 0 && p->LightIndex < ctx->lightCount, "idkptTraceShadows: LightIndex out of range");
     if (ctx->st.UseTlas && ctx->tlasCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceShadows: UseTlas set but no TLAS nodes uploaded");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     Frame f; size_t ldsBytes; uint32_t grid;
     int rc = query_frame(ctx, f, ldsBytes, grid); if (rc) return rc;
     DScene s = make_dscene(ctx);
@@ -1409,7 +1432,7 @@ static int32_t dev_SetSampleSequence(dev_ctx* ctx, uint32_t first, uint32_t stri
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(stride >= 1, "idkptSetSampleSequence: stride must be >= 1");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     if (first == ctx->seqFirst && stride == ctx->seqStride) return IDKPT_OK;
     ctx->seqFirst = first; ctx->seqStride = stride;
     std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);           // other RNG streams: the accumulation starts over
@@ -1457,6 +1480,42 @@ static uint32_t small_launch_grid(uint32_t fullGrid, uint32_t prev, int hintMul,
     if (raysX4 > 0) g = std::max<uint32_t>((uint32_t)(((uint64_t)prev * 4u / (uint32_t)raysX4 + 63) / 64), std::min<uint32_t>(cap, 1024u));
     if (midGrid > 0u && prev < GRID_MID_RAYS) g = std::min(g, midGrid);
     return std::min(fullGrid, std::min(g, cap));
+}
+
+// The continuation of a deferred last bounce (k_shade_last): the radiance k_shade_last replaced goes back, then the ordinary kernels of the bounce run — shading,
+// scan, scatter — on the inputs the batch left untouched (hit records, ray state, the queue entering the bounce, its per-sample bases).  Afterwards ray state, alive
+// queue and counts are what the eager path leaves, bit for bit; the frame was complete before.
+static int finish_deferred(dev_ctx* ctx)
+{
+    if (!ctx->defer.valid) return IDKPT_OK;
+    ctx->defer.valid = false;
+    using namespace ptd;
+    hipStream_t st = ctx->stream;
+    const int j = ctx->defer.j, side = ctx->defer.side, B = ctx->defer.B, BS = MAX_BATCH + 1;
+    const uint32_t total = ctx->defer.total, Npad = ctx->defer.Npad, gridTotal = (total + 255) / 256;
+    const Frame f = ctx->lastFrame;
+    DScene s = make_dscene(ctx);
+    RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
+    HitBufs hits = {ctx->hit.as<float4>(), ctx->hitCost.as<float>()};
+    TraceBufs tr = {ctx->trRec.as<float4>(), nullptr, nullptr};
+    uint32_t* counts = ctx->counts.as<uint32_t>(); uint32_t* bases = ctx->bases.as<uint32_t>();
+    unsigned long long* contMask = ctx->contMask.as<unsigned long long>();
+    uint32_t* waveLocal = ctx->waveCounts.as<uint32_t>(); uint32_t* blockSums = ctx->blockSums.as<uint32_t>(); uint32_t* keysTmp = ctx->keysTmp.as<uint32_t>();
+    const uint32_t scanBlocks = ((total + 63) / 64 + SCAN_WAVES_PER_BLOCK - 1) / SCAN_WAVES_PER_BLOCK;
+    const uint32_t* q = ctx->queue[side].as<uint32_t>();
+    const uint32_t* cnt = ctx->deferCount.as<uint32_t>();            // (counts[j] itself was reset by the batch's last kernel)
+    hipLaunchKernelGGL(k_restore_last, dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>());
+    hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, q, cnt, 0u, (const uint32_t*)(bases + j * BS), (const uint32_t*)nullptr, contMask, waveLocal, keysTmp);
+    hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, cnt, 0u, blockSums, (const uint32_t*)waveLocal, counts + j + 1, (unsigned long long*)nullptr,
+                       (const unsigned long long*)contMask, (const uint32_t*)(bases + j * BS), Npad, B, bases + (j + 1) * BS,
+                       ctx->dCountsMirror + j + 1, ctx->dBasesMirror + (size_t)(j + 1) * BS, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL((k_compact<false>), dim3(gridTotal), dim3(256), 0, st, q, cnt, 0u, (const unsigned long long*)contMask, (const uint32_t*)waveLocal, (const uint32_t*)blockSums,
+                       (const uint32_t*)keysTmp, ctx->queue[1 - side].as<uint32_t>(), ctx->keys[1 - side].as<uint32_t>());
+    HIPC(hipGetLastError());
+    ctx->lastQueueSide = 1 - side;
+    ctx->countersDirty = true;                                       // (counts[j + 1] was written after the batch's reset: the next batch clears its counters itself)
+    return IDKPT_OK;
 }
 
 static int flush_batch(dev_ctx* ctx)
@@ -1509,6 +1568,7 @@ static int flush_batch(dev_ctx* ctx)
     if (ctx->opt.graphProbe > 0 && !ctx->timing) capturing = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
 #endif
     if (ctx->timing) HIPC(hipEventRecord(ctx->evFrame[0], st));
+    ctx->defer.valid = false;                                      // (a deferred last bounce of the previous batch that nobody asked for: its buffers are reused now)
     if (ctx->countersDirty) { HIPC(hipMemsetAsync(work, 0, WORK_WORDS * 4, st)); HIPC(hipMemsetAsync(counts, 0, MAX_DEPTH_SLOTS * 4, st)); }   // (otherwise the previous batch's k_final_draw has reset them)
     ctx->countersDirty = true;
     uint32_t* hostCounts = ctx->dCountsMirror; uint32_t* hostBases = ctx->dBasesMirror;
@@ -1589,6 +1649,8 @@ static int flush_batch(dev_ctx* ctx)
                            (const uint32_t*)keysTmp, ctx->queue[1].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
     }
     int side = 1; // queue[side] holds the rays entering bounce j, its length is counts[j], sample k starts at bases[j][k]
+    // may the last bounce's continuation wait until somebody asks for it?  (k_shade_last: only where a hit of that bounce cannot change the radiance and nothing else of it reaches the frame)
+    const bool deferLast = fast && depth >= 2 && ctx->opt.deferLast != 0 && ctx->sceneNoEmission && !f.outputAovs && !(f.g.DoTraceLights && s.lightCount > 0) && !debug;
     for (int j = 1; j < depth; j++) {
         uint32_t* q = ctx->queue[side].as<uint32_t>(); uint32_t* k = ctx->keys[side].as<uint32_t>();
         const uint32_t* cnt = counts + j;
@@ -1658,6 +1720,13 @@ static int flush_batch(dev_ctx* ctx)
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
         }
         TRACE_T1();
+        if (deferLast && j == depth - 1 && gbase == nullptr) {
+            // the last bounce: only its radiance is visible in the frame (kernels_shade.hpp k_shade_last); state, queue and counts follow on demand (finish_deferred)
+            HIPC(ctx->radSave.ensure((size_t)ctx->maxBatch * ctx->Npad * 16)); HIPC(ctx->deferCount.ensure(64));
+            hipLaunchKernelGGL(k_shade_last, dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, (const uint32_t*)(bases + j * BS), ctx->radSave.as<float4>(), ctx->deferCount.as<uint32_t>());
+            ctx->defer.valid = true; ctx->defer.j = j; ctx->defer.side = side; ctx->defer.B = B; ctx->defer.total = total; ctx->defer.Npad = Npad;
+            break;
+        }
         hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, fast ? tr : trNone, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), gbase,
                            contMask, waveCounts, keysTmp);
         hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
@@ -1720,17 +1789,17 @@ static int32_t dev_Render(dev_ctx* ctx)
     return IDKPT_OK;
 }
 
-static int32_t dev_Synchronize(dev_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); SYNC_CHECKED(); return IDKPT_OK; }
+static int32_t dev_Synchronize(dev_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH_KEEP(); SYNC_CHECKED(); return IDKPT_OK; }
 
 // Launches whatever is pending without waiting for it (lets a host overlap its own work with the GPU).
-static int32_t dev_Flush(dev_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH(); return IDKPT_OK; }
+static int32_t dev_Flush(dev_ctx* ctx) { if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT; HIPC(hipSetDevice(ctx->device)); FLUSH_KEEP(); return IDKPT_OK; }
 
 static int32_t dev_SetMaxBatch(dev_ctx* ctx, int32_t maxBatch)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..256");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     HIPC(hipStreamSynchronize(ctx->stream));
     if (maxBatch == ctx->maxBatch) return IDKPT_OK;
     const int previous = ctx->maxBatch;
@@ -1754,7 +1823,7 @@ static int32_t dev_SetFrameRing(dev_ctx* ctx, int32_t frames)
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(frames >= 1 && frames <= 128, "idkptSetFrameRing: 1..128 frames");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     HIPC(hipStreamSynchronize(ctx->stream));
     if (frames == ctx->ringSize) return IDKPT_OK;
     ctx->ringSize = frames;
@@ -1781,7 +1850,7 @@ static int32_t dev_DownloadFrame(dev_ctx* ctx, int32_t slot, int32_t image, floa
     size_t need = (size_t)ctx->W * ctx->rows * 16;
     REQUIRE(bytes == need && need > 0, "idkptDownloadFrame: bytes must equal localRows*width*16");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image, slot), need, hipMemcpyDeviceToHost, ctx->stream));
     SYNC_CHECKED();
     return IDKPT_OK;
@@ -1793,7 +1862,7 @@ static int32_t dev_GetFrameDevicePtr(dev_ctx* ctx, int32_t slot, int32_t image, 
     REQUIRE(image >= 0 && image < 3, "idkptGetFrameDevicePtr: bad image id");
     REQUIRE(slot >= 0 && slot < ctx->ringSize, "idkptGetFrameDevicePtr: slot outside the frame ring");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();                                        // launches what is still deferred (stream-ordered: a consumer on the context's stream sees the finished image)
+    FLUSH_KEEP();                                        // launches what is still deferred (stream-ordered: a consumer on the context's stream sees the finished image)
     { int rc = check_overflow(ctx); if (rc) return rc; }   // (no wait: reports an overflow of batches that have already finished; a zero-copy consumer sees the rest at its next idkptSynchronize)
     *outPtr = image_ptr(ctx, image, slot);
     if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
@@ -1807,7 +1876,7 @@ static int32_t dev_Download(dev_ctx* ctx, int32_t image, float* rgba, size_t byt
     size_t need = (size_t)ctx->W * ctx->rows * 16;
     REQUIRE(bytes == need && need > 0, "idkptDownload: bytes must equal localRows*width*16");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     HIPC(hipMemcpyAsync(rgba, image_ptr(ctx, image, ctx->curSlot), need, hipMemcpyDeviceToHost, ctx->stream));
     SYNC_CHECKED();
     return IDKPT_OK;
@@ -1863,7 +1932,7 @@ static int32_t dev_DownloadPrimaryHits(dev_ctx* ctx, float* t, uint32_t* triangl
     size_t N = (size_t)ctx->W * ctx->rows;
     REQUIRE(pixelCount == N, "idkptDownloadPrimaryHits: pixelCount mismatch");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     if (!ctx->capturePrimary || ctx->primHit.bytes < N * 16) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptDownloadPrimaryHits: call idkptEnablePrimaryHitCapture(ctx,1) before idkptRender");
     std::vector<float4> h(N);
     HIPC(hipMemcpyAsync(h.data(), ctx->primHit.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1876,7 +1945,7 @@ static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
 {
     if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     SYNC_CHECKED();
     idkpt_stats s = ctx->stats;
     for (int j = 0; j < 16; j++) { const uint32_t* hb = ctx->hBases + (size_t)j * (MAX_BATCH + 1); s.LastAliveCounts[j] = (j >= 1 && j < ctx->st.RayDepth) ? hb[ctx->lastBatch] - hb[ctx->lastBatch - 1] : 0; }
@@ -1900,7 +1969,7 @@ static int32_t dev_ResetStats(dev_ctx* ctx)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    FLUSH_KEEP();
     HIPC(hipStreamSynchronize(ctx->stream));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;
@@ -1917,7 +1986,7 @@ static int32_t dev_GetImageDevicePtr(dev_ctx* ctx, int32_t image, void** outPtr,
     if (!ctx || !outPtr) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(image >= 0 && image < 3 && ctx->W > 0, "idkptGetImageDevicePtr: bad image / no size");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();                                        // launches what is still deferred
+    FLUSH_KEEP();                                        // launches what is still deferred
     { int rc = check_overflow(ctx); if (rc) return rc; }   // (no wait: see idkptGetFrameDevicePtr)
     *outPtr = image_ptr(ctx, image, ctx->curSlot);
     if (outBytes) *outBytes = (size_t)ctx->W * ctx->rows * 16;
