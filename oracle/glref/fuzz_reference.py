@@ -25,7 +25,9 @@ def run_case(seed, builder, G, O, T, configs, glref_check, draw_case):
         o.render(); r, q, k = o.rays().copy(), o.alive_queue().copy(), o.alive_keys().copy(); o.close()
         return r, q, k
     st1 = configs.apply_settings(T.Settings.default(), ov); st1.RayDepth = 1; st1.SamplesPerPixel = 1
-    pt = G.ReferencePathTracer(sc, w, h, st1); pt.set_camera(cam); pt.render()
+    sky = sc.sky_faces
+    distinct_1x1 = sky is not None and sky.shape[1] == 1 and not (np.asarray(sky) == np.asarray(sky)[0]).all()      # the C-ABI's "constant colour per face": unfiltered by definition
+    pt = G.ReferencePathTracer(sc, w, h, st1, sky_nearest=distinct_1x1); pt.set_camera(cam); pt.render()
     ref_rays, ref_q = pt.rays(T.GpuWavefrontRay), np.asarray(pt.final_alive, np.uint32); pt.accumulated = 0
     cur = oracle_state(1)
     rep = {"seed": seed, "size": [w, h], "triangles": int(len(sc.blas_triangles)), "settings": ov, "stages": 0, "rays": 0, "flips": 0, "beyond_tol": 0, "key_diffs": 0, "max_rel": 0.0, "beyond_by_field": {}}

@@ -327,9 +327,10 @@ class _ReferenceHost:
         # textures: unit 0 sky cube, unit 1 the 1x1 white default (handle 0), units 2.. the scene's texture table
         sky = scene.sky_faces if scene.sky_faces is not None else np.zeros((6, 1, 1, 4), np.float32)
         sky = np.ascontiguousarray(sky, np.float32)
-        # GL_LINEAR, seamless (SkyBoxManager.cs:44,74).  A 1x1 face is the C-ABI's "constant colour per face" (include/idkpt.h): not a cube map the reference
-        # would ever sample (its sky is an HDR or a computed atmosphere), so the sampler is GL_NEAREST there and the comparison covers everything else of such a case.
-        t = L.glref_cubemap(sky.shape[1], sky.ctypes.data, 0 if sky.shape[1] == 1 else 1); self._texs.append(t); L.glref_bind_texture(0, t)
+        # GL_LINEAR, seamless (SkyBoxManager.cs:44,74).  SIX DIFFERENT 1x1 faces are the C-ABI's "constant colour per face" (include/idkpt.h): not a cube map the
+        # reference would ever sample (its sky is an HDR or a computed atmosphere); a caller that compares such a case (oracle/glref/fuzz_reference.py) asks for GL_NEAREST
+        # (`sky_nearest`), so that the comparison covers everything else of the case.
+        t = L.glref_cubemap(sky.shape[1], sky.ctypes.data, 0 if getattr(self, "sky_nearest", False) else 1); self._texs.append(t); L.glref_bind_texture(0, t)
         white = np.ones((1, 1, 4), np.float32)
         for i, tex in enumerate([white] + [np.ascontiguousarray(x, np.float32) for x in scene.textures]):
             t = L.glref_texture2d(tex.shape[1], tex.shape[0], tex.ctypes.data, 1, 1); self._texs.append(t); L.glref_bind_texture(1 + i, t)
@@ -353,7 +354,8 @@ class ReferencePathTracer(_ReferenceHost):
     """Source/Render/PathTracer.cs driven over llvmpipe.  `scene` is idkengine_amd.gputypes.Scene (whose arrays are
     byte-exact mirrors of the reference's GPU structs, include/idkpt_types.h), `settings` is gputypes.Settings."""
 
-    def __init__(self, scene, width, height, settings, canonical_order=True, sort_count_fix=True):
+    def __init__(self, scene, width, height, settings, canonical_order=True, sort_count_fix=True, sky_nearest=False):
+        self.sky_nearest = sky_nearest
         self._init_host(scene, settings.UseTlas, settings.BlasStackSize,
                         {"PATH_TRACER_DO_RAY_SORTING": "1" if settings.DoRaySorting else "0",                 # PathTracer.cs:111
                          "PATH_TRACER_OUTPUT_AOVS": "1" if settings.OutputAOVs else "0"})                      # PathTracer.cs:123
