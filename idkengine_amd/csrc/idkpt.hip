@@ -197,6 +197,7 @@ static int alloc_frame_impl(dev_ctx* ctx)
     HIPC(ctx->sortHist.ensure((SORT_RADIX * nTiles + SORT_RADIX) * 4));
     for (int i = 0; i < 3; i++) { HIPC(ctx->img[i].ensure(N * 16 * ctx->ringSize)); HIPC(hipMemsetAsync(ctx->img[i].p, 0, N * 16 * ctx->ringSize, ctx->stream)); }   // slot s at offset s*N
     HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream));
+    ctx->defer.valid = false;      // (callers complete a deferred last bounce before they get here; whatever is left refers to buffers that are gone)
     ctx->countersDirty = true;   // (the first batch resets its counters itself)
     HIPC(hipMemsetAsync(ctx->aovA.p, 0, cap * 16, ctx->stream)); HIPC(hipMemsetAsync(ctx->aovN.p, 0, cap * 16, ctx->stream));
     HIPC(hipMemsetAsync(ctx->contFlag.p, 0, cap, ctx->stream));   // per-batch values are written by k_gen_primary; the pad ids [N, Npad) must read 0
@@ -1799,7 +1800,7 @@ static int32_t dev_SetMaxBatch(dev_ctx* ctx, int32_t maxBatch)
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(maxBatch >= 1 && maxBatch <= MAX_BATCH, "idkptSetMaxBatch: 1..256");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH_KEEP();
+    FLUSH();   // (the wavefront buffers are about to be reallocated: a deferred last bounce is completed first)
     HIPC(hipStreamSynchronize(ctx->stream));
     if (maxBatch == ctx->maxBatch) return IDKPT_OK;
     const int previous = ctx->maxBatch;
@@ -1823,7 +1824,7 @@ static int32_t dev_SetFrameRing(dev_ctx* ctx, int32_t frames)
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(frames >= 1 && frames <= 128, "idkptSetFrameRing: 1..128 frames");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH_KEEP();
+    FLUSH();   // (the wavefront buffers are about to be reallocated: a deferred last bounce is completed first)
     HIPC(hipStreamSynchronize(ctx->stream));
     if (frames == ctx->ringSize) return IDKPT_OK;
     ctx->ringSize = frames;
