@@ -253,6 +253,20 @@ def main():
         if args.pmc_child:
             out = {"pmc_child": True, "trace_launches": int(st["trace_launches"]), "ms_per_step": out["ms_per_step"]}
         if world * group == 1 and not args.no_extras:
+            # the same timed region with the last bounce shaded eagerly (option defer_last 0: new direction, throughput, Russian roulette and next queue of the bounce after
+            # which nothing is traced, every frame, as the reference does): what `value` would be without producing those unread outputs on demand (config.last_bounce)
+            pt.set_option("defer_last", 0)
+            eager = []
+            for _rep in range(3):
+                step_no[0] = 0; torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                if step_no[0] % B:
+                    finish_frame()
+                pt.synchronize(); torch.cuda.synchronize(); eager.append(time.perf_counter() - t0)
+            pt.set_option("defer_last", 1)
+            out["eager_last_bounce"] = {"mray_s": round(rays_rep / statistics.median(eager) / 1e6, 2), "ms_per_step": round(statistics.median(eager) / args.steps * 1e3, 4), "repeats": 3,
+                                        "what": "the timed region re-run with idkptSetDeveloperOption(defer_last, 0): bit-identical frames and ray state, the last bounce's continuation computed every frame"}
             out["single_frame"] = single_frame(pt, depth)
             if args.scene == "soup":
                 out["interior"] = interior_extras(S, pt, W, H, B)
