@@ -90,6 +90,7 @@ GLREF_CASES.update({
 FULL_SCENES = {
     "soup1m": lambda b: S.soup_scene(1000000, b, seed=1),
     "atrium262k": lambda b: S.atrium_scene(262000, b),
+    "atrium1m": lambda b: S.atrium_scene(1000000, b),
     "soup4m": lambda b: S.soup_scene(4000000, b, seed=3),
     "soup2m3": lambda b: S.soup_scene(2300000, b, seed=2),
     "lucy": configs.lucy_scene,
@@ -100,6 +101,7 @@ FULL_CASES = {
     "full_headline_sort_d5": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=5, DoRaySorting=1)),                       # configs[3] (sort on), 4 bounces
     "full_interior_d3": ("soup1m", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0)), 1920, 1080, dict(RayDepth=3)),                 # every pixel traverses
     "full_atrium262k_d5": ("atrium262k", S.atrium_camera, 1920, 1080, dict(RayDepth=5)),                                                   # configs[1] stand-in
+    "full_atrium1m_d2": ("atrium1m", S.atrium_camera, 1920, 1080, dict(RayDepth=2)),                                                       # the 1M-triangle atrium bench.py times beside the headline
     # the reference's own traversal-cost counter (BVHIntersect.glsl:45,60: +1 per node pair, +1.1 per triangle test) on the headline frame's primary rays:
     # pins the P and T that the roofline's algorithmic bytes are computed from against the reference's count, pixel by pixel and in total
     "full_headline_debugcost_d1": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=1, DoDebugBVHTraversal=1)),
