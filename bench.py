@@ -245,7 +245,7 @@ def main():
                                      f"atrium-{args.tris} (procedural two-storey colonnaded hall, connected surfaces, {len(scene.blas_triangles)} BLAS triangles, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, camera inside looking down the hall"),
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
                        "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation",
-                       "last_bounce": "every ray of the last bounce is traced and its radiance (sky on a miss; this scene has no emission) reaches the frame; the rest of that bounce's shading - new direction, throughput, Russian roulette, next queue: outputs the reference computes and nothing reads - is produced on demand (idkptDownloadRays / idkptDownloadAliveQueue / scene updates), bit-identical (DESIGN.md 4; option defer_last)", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
+                       "last_bounce": "every ray of the last bounce is traced and its radiance (sky on a miss; this scene has no emission, so hits add none) reaches the frame; the rest of that bounce's shading - new direction, throughput, Russian roulette, next queue: outputs the reference computes and nothing reads - is produced on demand (idkptDownloadRays / idkptDownloadAliveQueue / scene updates), bit-identical (DESIGN.md 4; option defer_last)", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
                        "bvh_build_s": round(build_s, 2), "blas_build_ms": blas_build_ms, "bvh_builder": builder_kind,
                        "n_gpu": n_gpu_report(torch, dist, world, group)},
             "roofline": roofline(st, pairs * reps / group, tri_tests * reps / group, traversed * reps / group, args, world * group, B if rem == 0 else (rem if q == 0 else None), torch, device),

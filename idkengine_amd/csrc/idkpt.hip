@@ -100,7 +100,7 @@ struct dev_ctx {
     idkpt_stats stats;
     uint32_t* hCounts = nullptr; uint32_t* dCountsMirror = nullptr;   // host-mapped mirror of the queue lengths (written by k_scan_blocks, read by the host after a sync)
     bool sceneNoEmission = false;   // no material / mesh of the uploaded scene emits and every texel is finite: a hit of the last bounce cannot change the radiance (k_shade_last)
-    struct { bool valid = false; int j = 0, side = 0, B = 0; uint32_t total = 0, Npad = 0; } defer;   // the last bounce of the last batch still owes its continuation (finish_deferred)
+    struct { bool valid = false, allHits = false; int j = 0, side = 0, B = 0; uint32_t total = 0, Npad = 0; } defer;   // the last bounce of the last batch still owes its continuation (finish_deferred)
     DevBuf radSave, deferCount;
     bool countersDirty = true;   // the batch counters were not reset by the last k_final_draw (first batch, or a batch that failed half way)
     uint32_t* hOverflow = nullptr; uint32_t* dOverflow = nullptr;   // host-mapped word the kernels set when a traversal-stack push is dropped (checked after every sync)
@@ -1505,7 +1505,8 @@ static int finish_deferred(dev_ctx* ctx)
     const uint32_t scanBlocks = ((total + 63) / 64 + SCAN_WAVES_PER_BLOCK - 1) / SCAN_WAVES_PER_BLOCK;
     const uint32_t* q = ctx->queue[side].as<uint32_t>();
     const uint32_t* cnt = ctx->deferCount.as<uint32_t>();            // (counts[j] itself was reset by the batch's last kernel)
-    hipLaunchKernelGGL(k_restore_last, dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>());
+    if (ctx->defer.allHits) hipLaunchKernelGGL((k_restore_last<true>), dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>());
+    else hipLaunchKernelGGL((k_restore_last<false>), dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>());
     hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, q, cnt, 0u, (const uint32_t*)(bases + j * BS), (const uint32_t*)nullptr, contMask, waveLocal, keysTmp);
     hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, cnt, 0u, blockSums, (const uint32_t*)waveLocal, counts + j + 1, (unsigned long long*)nullptr,
@@ -1651,7 +1652,8 @@ static int flush_batch(dev_ctx* ctx)
     }
     int side = 1; // queue[side] holds the rays entering bounce j, its length is counts[j], sample k starts at bases[j][k]
     // may the last bounce's continuation wait until somebody asks for it?  (k_shade_last: only where a hit of that bounce cannot change the radiance and nothing else of it reaches the frame)
-    const bool deferLast = fast && depth >= 2 && ctx->opt.deferLast != 0 && ctx->sceneNoEmission && !f.outputAovs && !(f.g.DoTraceLights && s.lightCount > 0) && !debug;
+    const bool deferLast = fast && depth >= 2 && ctx->opt.deferLast != 0 && !f.outputAovs && !debug;
+    const bool deferAllHits = !(ctx->sceneNoEmission && !(f.g.DoTraceLights && s.lightCount > 0));   // a hit of the last bounce may add radiance: emission somewhere in the scene, or light hits
     for (int j = 1; j < depth; j++) {
         uint32_t* q = ctx->queue[side].as<uint32_t>(); uint32_t* k = ctx->keys[side].as<uint32_t>();
         const uint32_t* cnt = counts + j;
@@ -1724,8 +1726,9 @@ static int flush_batch(dev_ctx* ctx)
         if (deferLast && j == depth - 1 && gbase == nullptr) {
             // the last bounce: only its radiance is visible in the frame (kernels_shade.hpp k_shade_last); state, queue and counts follow on demand (finish_deferred)
             HIPC(ctx->radSave.ensure((size_t)ctx->maxBatch * ctx->Npad * 16)); HIPC(ctx->deferCount.ensure(64));
-            hipLaunchKernelGGL(k_shade_last, dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, (const uint32_t*)(bases + j * BS), ctx->radSave.as<float4>(), ctx->deferCount.as<uint32_t>());
-            ctx->defer.valid = true; ctx->defer.j = j; ctx->defer.side = side; ctx->defer.B = B; ctx->defer.total = total; ctx->defer.Npad = Npad;
+            if (deferAllHits) hipLaunchKernelGGL((k_shade_last<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, (const uint32_t*)(bases + j * BS), ctx->radSave.as<float4>(), ctx->deferCount.as<uint32_t>());
+            else hipLaunchKernelGGL((k_shade_last<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, (const uint32_t*)(bases + j * BS), ctx->radSave.as<float4>(), ctx->deferCount.as<uint32_t>());
+            ctx->defer.allHits = deferAllHits; ctx->defer.valid = true; ctx->defer.j = j; ctx->defer.side = side; ctx->defer.B = B; ctx->defer.total = total; ctx->defer.Npad = Npad;
             break;
         }
         hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, fast ? tr : trNone, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), gbase,

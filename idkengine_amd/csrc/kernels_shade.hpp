@@ -117,12 +117,14 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
 
 // ---- the LAST bounce of a sample, when nothing of it is visible but radiance ---------------------------------------------------------------------------
 // NHit of the last bounce computes a continuation nobody traces: a new direction, throughput, a Russian-roulette decision, the next queue.  The image needs one
-// thing of it: the radiance a ray picks up at this hit — the sky on a miss, the surface's emission on a hit.  In a scene without emission (checked at upload:
-// every EmissiveFactor and EmissiveBias zero, every texel finite; no light hits enabled, no AOVs) a hit adds sEmissive * throughput = 0 to the radiance, so the
-// frame only needs the misses: k_shade_last adds the sky to them (the arithmetic of ShadeHit's miss branch) and remembers the radiance it replaced.  Everything
+// thing of it: the radiance a ray picks up at this hit — the sky on a miss, the surface's (or light's) emission on a hit.  Without AOVs that is all k_shade_last
+// computes.  In a scene without emission (checked at upload: every EmissiveFactor and EmissiveBias zero, every texel finite; no light hits enabled) a hit adds
+// sEmissive * throughput = 0, so only the misses are touched: the sky is added (the arithmetic of ShadeHit's miss branch) and the replaced radiance remembered.
+// Otherwise (ALL_HITS) every hit runs ShadeHit on a copy of its state up to the point where its radiance is final (alpha test, absorption, emission).  Everything
 // else of the bounce — ray state, alive queue, counts: what idkptDownloadRays / idkptDownloadAliveQueue / the next scene update may look at — is produced on demand
 // by the ordinary kernels (finish_deferred in idkpt.hip: k_restore_last, then k_shade<false>, the scan and the scatter), bit for bit what the eager path
 // leaves.  A hit whose throughput is not finite (0 * inf is not 0) takes ShadeHit on a copy of its state right here.
+template <bool ALL_HITS /* the scene emits, or lights are hit: every hit may add radiance */>
 __global__ __launch_bounds__(256) void k_shade_last(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, const uint32_t* qbase,
                                                     float4* radSave, uint32_t* deferCount)
 {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void k_shade_last(DScene s, Frame f, RayBufs r
     const HitRec hit = load_hit(hits, slot);
     const float4 b = rays.thr_px[idx];
     const bool miss = hit.T == PT_FLOAT_MAX;
-    const bool odd = !(__builtin_isfinite(b.x) && __builtin_isfinite(b.y) && __builtin_isfinite(b.z));
+    const bool odd = ALL_HITS || !(__builtin_isfinite(b.x) && __builtin_isfinite(b.y) && __builtin_isfinite(b.z));
     if (!miss && !odd) return;
     const float4 c = rays.rad_py[idx];
     radSave[slot] = c;
@@ -150,11 +152,12 @@ __global__ __launch_bounds__(256) void k_shade_last(DScene s, Frame f, RayBufs r
         AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
         const uint32_t gslot = slot - qbase[smp];
         uint32_t rng = gslot * 4096u + acc, key = 0;
-        (void)ShadeHit<false>(s, f, acc, hit, true, DecodeUnitVec(b.w, c.w), r, aov, rng, gslot, key);
+        (void)ShadeHit<false, true>(s, f, acc, hit, true, DecodeUnitVec(b.w, c.w), r, aov, rng, gslot, key);   // the radiance of this hit, on a copy of the state
         rays.rad_py[idx] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, c.w);
     }
 }
 // on demand, before the ordinary kernels run for the deferred bounce: the radiance k_shade_last replaced
+template <bool ALL_HITS>
 __global__ __launch_bounds__(256) void k_restore_last(RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, const float4* radSave)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -162,6 +165,6 @@ __global__ __launch_bounds__(256) void k_restore_last(RayBufs rays, HitBufs hits
     const uint32_t idx = queue[slot];
     const HitRec hit = load_hit(hits, slot);
     const float4 b = rays.thr_px[idx];
-    if (hit.T == PT_FLOAT_MAX || !(__builtin_isfinite(b.x) && __builtin_isfinite(b.y) && __builtin_isfinite(b.z))) rays.rad_py[idx] = radSave[slot];
+    if (ALL_HITS || hit.T == PT_FLOAT_MAX || !(__builtin_isfinite(b.x) && __builtin_isfinite(b.y) && __builtin_isfinite(b.z))) rays.rad_py[idx] = radSave[slot];
 }
 

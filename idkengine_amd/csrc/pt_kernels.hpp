@@ -446,7 +446,9 @@ DEV f3 SampleSky(const DScene& s, f3 d)
 struct RayState { f3 origin; float prevIor; f3 throughput; float pdx; f3 radiance; float pdy; };
 struct AovState { f3 albedo; float newWeight; f3 normal; };
 
-template <bool FIRST>
+// RAD_ONLY (k_shade_last): stop once the radiance of this hit is final — the continuation (SampleMaterial, the new ray, Russian roulette) is not wanted; everything the
+// radiance depends on (alpha test incl. its random number, absorption, emission) is the code below, unchanged.
+template <bool FIRST, bool RAD_ONLY = false>
 DEV bool ShadeHit(const DScene& s, const Frame& f, uint32_t acc, const HitRec& hit, bool hitScene, f3 rayDir, RayState& r, AovState& aov, uint32_t& rng, uint32_t gidSeed, uint32_t& sortingKey)
 {
     if (hitScene) {
@@ -526,6 +528,7 @@ DEV bool ShadeHit(const DScene& s, const Frame& f, uint32_t acc, const HitRec& h
         float cosTheta = dot(-rayDir, sNormal);
         if (cosTheta < 0.0f) { sNormal = sNormal * -1.0f; }
         r.radiance = r.radiance + sEmissive * r.throughput;
+        if (RAD_ONLY) return false;
 
         // SampleMaterial (Shading.glsl:59-150)
         float roughness2 = sRoughness * sRoughness;

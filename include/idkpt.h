@@ -313,7 +313,7 @@ IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
  * leaves every output bit-identical (tests/test_gpu_worklist.py, tests/test_gpu_layout.py).  The library itself reads no environment variables; the
  * Python host mirror forwards IDKPT_<NAME> for the tests and tools.  Names (value): "force_generic" (0/1: thread-per-ray kernels instead of the
  * persistent traversal kernel), "no_tile_cull", "no_lean_primary" (0/1), "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves",
- * "grid_hint", "grid_rays_x4", "grid_mid_waves" (scheduling of the traversal kernel; grid_rays_x4: quarter-rays per lane a small launch's grid is sized for, default 6, 0 = off; grid_mid_waves: waves per CU of launches below 14 M rays, default 20, 0 = off), "defer_last" (0/1, default 1: where the last bounce of a sample can only add sky radiance to the frame — no emission anywhere in the scene, no AOVs, no light hits — its ray state, alive queue and counts are produced when idkptDownloadRays / idkptDownloadAliveQueue or a scene update ask for them, not every frame), "node_layout" (0 reference order [default], 1 line couples depth-first, 2 line couples in
+ * "grid_hint", "grid_rays_x4", "grid_mid_waves" (scheduling of the traversal kernel; grid_rays_x4: quarter-rays per lane a small launch's grid is sized for, default 6, 0 = off; grid_mid_waves: waves per CU of launches below 14 M rays, default 20, 0 = off), "defer_last" (0/1, default 1: without AOVs only the radiance of a sample's last bounce reaches the frame — that is computed every frame; the bounce's continuation, i.e. ray state, alive queue and counts, is produced when idkptDownloadRays / idkptDownloadAliveQueue or a scene update ask for it), "node_layout" (0 reference order [default], 1 line couples depth-first, 2 line couples in
  * treelets of "treelet_depth" levels), "trace_order" (0 queue order [default], 1 spatial order for batches of >= 4 samples, 2 always),
  * "bvh_timing", "bvh_small" (idkptBuildBlasCore), "bvh_stackopt_host" (idkptBuildBlas: force the host fallback of the stack-size optimisation), "force_no_peer" (0/1, multi-device contexts: stage every device-to-device copy through pinned
  * host memory, as on a node whose GPUs refuse peer access), "trace_variant" (developer build of the library only).  Unknown names fail. */

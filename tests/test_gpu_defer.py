@@ -1,5 +1,5 @@
-"""The deferred last bounce (kernels_shade.hpp k_shade_last, idkpt.hip finish_deferred): where a hit of the last bounce cannot change the radiance — no emission
-anywhere in the scene, no AOVs, no light hits — the frame only needs the sky added to the rays that miss; ray state, alive queue and counts of that bounce are
+"""The deferred last bounce (kernels_shade.hpp k_shade_last, idkpt.hip finish_deferred): without AOVs the frame needs only the radiance of a sample's last bounce —
+the sky on the rays that miss and, in scenes that emit or with light hits, the radiance part of the hit shading; ray state, alive queue and counts of that bounce are
 produced when somebody asks for them.  Results must not depend on it: images without ever asking, state when asked (before and after more frames, and across a
 scene update), scenes where it must not apply, and the path for throughputs that are not finite."""
 import os
@@ -69,7 +69,8 @@ def test_state_of_a_deferred_frame_survives_a_scene_update(oracle_mod, native_bu
 
 
 @pytest.mark.parametrize("case", ["emissive", "aovs", "lights"])
-def test_scenes_and_settings_where_the_last_bounce_is_visible(case, oracle_mod, native_builder):
+def test_emissive_scenes_light_hits_and_aovs(case, oracle_mod, native_builder):
+    """Emission and light hits: every hit of the last bounce runs the radiance part of the shading (k_shade_last<true>); AOVs: nothing is deferred."""
     w, h = 64, 64; cam = S.cornell_camera(w, h)
     ov = dict(RayDepth=3)
     if case == "emissive":
