@@ -184,8 +184,9 @@ FULL_EXCEPTION_REASON = "closest-hit decision within rounding of a triangle edge
 # name -> most rays any stage of the case may list (= what the committed fixtures list: of 2 073 600 primary rays 4 on the soup seen from outside, 2 from inside,
 # 55 in the atrium, whose walls, floors and columns meet in exact shared edges; at most 1 per bounce stage after that).  By the binary64 brute force the oracle's hit
 # is the true closest hit on 3 of 4 / 2 of 2 / 24 of 55 of them, the reference's on 0 / 1 / 25; the rest are grazing hits neither arithmetic resolves.
+# full_cornell_lights_textures_d4: 319 of 2 073 600 primary rays graze a sphere light (the hit distance is a sqrt of a small discriminant: hit point and bounce direction 1e-4 ... 1.5e-3 apart, radiance and throughput identical).
 # full_headline_debugcost_d1 compares the traversal COST per pixel: 17 pixels where one box test of the walk falls on the other side (same hit, a few visits more or less).
-FULL_ALLOW = {"full_headline_d2": 4, "full_headline_debugcost_d1": 17, "full_headline_sort_d5": 4, "full_interior_d3": 2, "full_atrium262k_d5": 55, "full_atrium1m_d2": 82, "full_soup2m3_sort_d4": 2, "full_lucy_d5": 6, "full_helmet_sort_d4": 3, "full_soup4m_4k_d9": 7}    # (the last: of 8 294 400 rays)
+FULL_ALLOW = {"full_headline_d2": 4, "full_headline_debugcost_d1": 17, "full_headline_sort_d5": 4, "full_interior_d3": 2, "full_atrium262k_d5": 55, "full_atrium1m_d2": 82, "full_multi_instances_d3": 4, "full_multi_tlas_sort_d3": 3, "full_cornell_lights_textures_d4": 319, "full_soup2m3_sort_d4": 2, "full_lucy_d5": 6, "full_helmet_sort_d4": 3, "full_soup4m_4k_d9": 7}    # (the last: of 8 294 400 rays)
 
 
 def decode_unit_vec(px, py):

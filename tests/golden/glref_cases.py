@@ -40,6 +40,16 @@ def _textured_scene(b):
     return sc
 
 
+def _lights_textured_scene(b):
+    sc = _textured_scene(b)
+    from idkengine_amd import gputypes as T
+    lights = np.zeros(2, T.GpuLight)
+    lights[0]["Position"] = (0.3, 0.2, 0.4); lights[0]["Radius"] = 0.18; lights[0]["Color"] = (6.0, 5.0, 3.0); lights[0]["PointShadowIndex"] = -1
+    lights[1]["Position"] = (-0.5, -0.4, 0.1); lights[1]["Radius"] = 0.1; lights[1]["Color"] = (1.0, 2.0, 8.0); lights[1]["PointShadowIndex"] = -1
+    sc.lights = lights
+    return sc
+
+
 def _bias_normalmap_scene(b):
     """The Surface.glsl / Shading.glsl branches the other cases leave out: thin-walled (non-volumetric) transmission without tint,
     every GpuMesh bias (SurfaceApplyModificatons), a tangent-space normal map blended by NormalMapStrength, a transmission texture."""
@@ -95,6 +105,8 @@ FULL_SCENES = {
     "soup2m3": lambda b: S.soup_scene(2300000, b, seed=2),
     "lucy": configs.lucy_scene,
     "helmet": configs.helmet_scene,
+    "multi900k": lambda b: S.soup_scene_multi(900000, b, parts=3, seed=4),
+    "cornell_lights_tex": lambda b: _lights_textured_scene(b),
 }
 FULL_CASES = {
     "full_headline_d2": ("soup1m", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=2)),                                            # BASELINE configs[2], the bench line
@@ -108,6 +120,11 @@ FULL_CASES = {
     # the two meshes the reference ships (shared vertices, slivers), at full HD
     "full_lucy_d5": ("lucy", configs.lucy_camera, 1080, 1920, dict(RayDepth=5)),
     "full_helmet_sort_d4": ("helmet", configs.helmet_camera, 1920, 1080, dict(RayDepth=4, DoRaySorting=1)),
+    # several BLAS instances at scale: the instance loop (BVHIntersect.glsl:275-287) and the TLAS walk (:205-272) inside the persistent kernel
+    "full_multi_instances_d3": ("multi900k", lambda w, h: S.Camera(w, h), 1920, 1080, dict(RayDepth=3)),
+    "full_multi_tlas_sort_d3": ("multi900k", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0)), 1920, 1080, dict(RayDepth=3, UseTlas=1, DoRaySorting=1)),
+    # lights as surfaces, an emissive ceiling, bilinear / repeat textures, at full HD
+    "full_cornell_lights_textures_d4": ("cornell_lights_tex", S.cornell_camera, 1920, 1080, dict(RayDepth=4, DoTraceLights=1)),
     # more than 2^21 triangles with DoRaySorting: triangle ids alias in the reference's 21-bit sort key (NHit/compute.glsl:81) — the reference's own CountingSort on the aliased keys
     "full_soup2m3_sort_d4": ("soup2m3", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0)), 1920, 1080, dict(RayDepth=4, DoRaySorting=1)),
     "full_soup4m_4k_d9": ("soup4m", lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(0.3, 0.1, -1.0)), 3840, 2160, dict(RayDepth=9)),   # configs[4] stand-in (sample 0 of its 4 spp)
