@@ -72,7 +72,7 @@ struct dev_ctx {
     // config
     idkpt_settings st;          // effective settings
     idkpt_settings stCaller;    // the struct the host passed last (idkptSetSettings compares against this one)
-    int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0;
+    int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0, rowBandLog2 = 0;   // rows dealt in bands of 2^rowBandLog2 rows (idkptSetRowBands)
     float invProj[16], invView[16], viewPos[3];
     // frame ring (idkptSetFrameRing): ringSize result-image sets; every queued sample remembers its slot, its camera and its
     // AccumulatedSamples index, so several frames (different cameras) can be in flight in one batch
@@ -139,7 +139,14 @@ static int fail(dev_ctx* c, int code, const std::string& msg) { if (c) c->lastEr
 #define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
 #define REQUIRE(cond, msg) do { if (!(cond)) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
 
-static int local_rows(int H, int mod, int rem) { int n = 0; for (int y = rem; y < H; y += mod) n++; return n; }
+// rows y of the image with (y >> bandLog2) % mod == rem (bandLog2 = 0: y % mod == rem; mod = 1: the rows from rem on)
+static int local_rows(int H, int mod, int rem, int bandLog2 = 0)
+{
+    if (bandLog2 == 0) { int n = 0; for (int y = rem; y < H; y += mod) n++; return n; }
+    int n = 0; const int band = 1 << bandLog2;
+    for (int b = rem; (b << bandLog2) < H; b += mod) n += std::min(band, H - (b << bandLog2));
+    return n;
+}
 
 template <bool PRIMARY>
 static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
@@ -414,34 +421,40 @@ static int32_t dev_SetSize(dev_ctx* ctx, int32_t width, int32_t height)
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     REQUIRE(ctx->rowLimit == 0x7fffffff || ctx->rowRem + ctx->rowLimit <= height, "idkptSetSize: the strip set by idkptSetRowRange exceeds the new image height (set a new range first)");
-    REQUIRE(ctx->rowRem < height, "idkptSetSize: this context's row remainder (idkptSetRowSharding) is outside the new image height");
-    ctx->W = width; ctx->H = height; ctx->rows = std::min(ctx->rowLimit, local_rows(height, ctx->rowMod, ctx->rowRem));
+    REQUIRE((ctx->rowRem << ctx->rowBandLog2) < height, "idkptSetSize: this context's row remainder (idkptSetRowSharding / idkptSetRowBands) is outside the new image height");
+    ctx->W = width; ctx->H = height; ctx->rows = std::min(ctx->rowLimit, local_rows(height, ctx->rowMod, ctx->rowRem, ctx->rowBandLog2));
     return alloc_frame(ctx);
 }
 
-// size and row layout in one step (group layer): rows y with y % rowMod == rowRem (rowLimit = 0x7fffffff) or the strip [rowRem, rowRem + rowLimit) (rowMod = 1)
-static int32_t dev_SetLayout(dev_ctx* ctx, int32_t width, int32_t height, int32_t rowMod, int32_t rowRem, int32_t rowLimit)
+// size and row layout in one step (group layer): bands (y >> bandLog2) % rowMod == rowRem (rowLimit = 0x7fffffff) or the strip [rowRem, rowRem + rowLimit) (rowMod = 1, bandLog2 = 0)
+static int32_t dev_SetLayout(dev_ctx* ctx, int32_t width, int32_t height, int32_t rowMod, int32_t rowRem, int32_t rowLimit, int32_t bandLog2 = 0)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(width > 0 && height > 0 && width <= 4096 && height <= 65536, "idkptSetSize: bad size (FirstHit seeds pack x into 12 bits: width <= 4096)");
-    REQUIRE(rowMod >= 1 && rowRem >= 0 && rowRem < height && rowLimit >= 1 && (rowMod == 1 || rowRem < rowMod), "internal: bad row layout");
+    REQUIRE(rowMod >= 1 && rowRem >= 0 && bandLog2 >= 0 && bandLog2 <= 6 && (rowRem << bandLog2) < height && rowLimit >= 1 && (rowMod == 1 ? bandLog2 == 0 : rowRem < rowMod), "internal: bad row layout");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
-    ctx->W = width; ctx->H = height; ctx->rowMod = rowMod; ctx->rowRem = rowRem; ctx->rowLimit = rowLimit;
-    ctx->rows = std::min(rowLimit, local_rows(height, rowMod, rowRem));
+    ctx->W = width; ctx->H = height; ctx->rowMod = rowMod; ctx->rowRem = rowRem; ctx->rowLimit = rowLimit; ctx->rowBandLog2 = bandLog2;
+    ctx->rows = std::min(rowLimit, local_rows(height, rowMod, rowRem, bandLog2));
     return alloc_frame(ctx);
 }
 
-static int32_t dev_SetRowSharding(dev_ctx* ctx, int32_t rowModulo, int32_t rowRemainder)
+// rows dealt in bands of bandRows rows: band k of the image (rows [k * bandRows, (k + 1) * bandRows)) belongs to the context with k % rowModulo == rowRemainder
+// (bandRows = 1: idkptSetRowSharding)
+static int32_t dev_SetRowBands(dev_ctx* ctx, int32_t bandRows, int32_t rowModulo, int32_t rowRemainder)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
-    REQUIRE(rowModulo >= 1 && rowRemainder >= 0 && rowRemainder < rowModulo, "idkptSetRowSharding: need 0 <= remainder < modulo");
-    REQUIRE(ctx->W <= 0 || rowRemainder < ctx->H, "idkptSetRowSharding: no row of the image has this remainder");
+    REQUIRE(bandRows >= 1 && bandRows <= 64 && (bandRows & (bandRows - 1)) == 0, "idkptSetRowBands: bandRows must be a power of two in 1..64");
+    REQUIRE(rowModulo >= 1 && rowRemainder >= 0 && rowRemainder < rowModulo, "idkptSetRowSharding / idkptSetRowBands: need 0 <= remainder < modulo");
+    int bandLog2 = 0; while ((1 << bandLog2) < bandRows) bandLog2++;
+    if (rowModulo == 1) bandLog2 = 0;                                   // the whole frame: bands mean nothing
+    REQUIRE(ctx->W <= 0 || (rowRemainder << bandLog2) < ctx->H, "idkptSetRowSharding / idkptSetRowBands: no row of the image has this remainder");
     FLUSH();
-    ctx->rowMod = rowModulo; ctx->rowRem = rowRemainder; ctx->rowLimit = 0x7fffffff;
-    if (ctx->W > 0) { HIPC(hipSetDevice(ctx->device)); ctx->rows = local_rows(ctx->H, rowModulo, rowRemainder); return alloc_frame(ctx); }
+    ctx->rowMod = rowModulo; ctx->rowRem = rowRemainder; ctx->rowLimit = 0x7fffffff; ctx->rowBandLog2 = bandLog2;
+    if (ctx->W > 0) { HIPC(hipSetDevice(ctx->device)); ctx->rows = local_rows(ctx->H, rowModulo, rowRemainder, bandLog2); return alloc_frame(ctx); }
     return IDKPT_OK;
 }
+static int32_t dev_SetRowSharding(dev_ctx* ctx, int32_t rowModulo, int32_t rowRemainder) { return dev_SetRowBands(ctx, 1, rowModulo, rowRemainder); }
 
 static int32_t dev_SetRowRange(dev_ctx* ctx, int32_t firstRow, int32_t rowCount)
 {
@@ -449,7 +462,7 @@ static int32_t dev_SetRowRange(dev_ctx* ctx, int32_t firstRow, int32_t rowCount)
     REQUIRE(firstRow >= 0 && rowCount >= 1, "idkptSetRowRange: need firstRow >= 0 and rowCount >= 1");
     REQUIRE(ctx->W <= 0 || firstRow + rowCount <= ctx->H, "idkptSetRowRange: strip exceeds the image height");
     FLUSH();
-    ctx->rowMod = 1; ctx->rowRem = firstRow; ctx->rowLimit = rowCount;
+    ctx->rowMod = 1; ctx->rowRem = firstRow; ctx->rowLimit = rowCount; ctx->rowBandLog2 = 0;
     if (ctx->W > 0) { HIPC(hipSetDevice(ctx->device)); ctx->rows = std::min(ctx->rowLimit, local_rows(ctx->H, 1, firstRow)); return alloc_frame(ctx); }
     return IDKPT_OK;
 }
@@ -1531,7 +1544,7 @@ static int flush_batch(dev_ctx* ctx)
     DScene s = make_dscene(ctx);
     Frame f;
     memcpy(f.invProj, ctx->pending[0].cam, 64); memcpy(f.invView, ctx->pending[0].cam + 16, 64); memcpy(f.viewPos, ctx->pending[0].cam + 32, 12);   // the camera the samples were queued with
-    f.W = ctx->W; f.H = ctx->H; f.rowMod = ctx->rowMod; f.rowRem = ctx->rowRem; f.rows = ctx->rows;
+    f.W = ctx->W; f.H = ctx->H; f.rowMod = ctx->rowMod; f.rowRem = ctx->rowRem; f.rows = ctx->rows; f.rowBandLog2 = ctx->rowBandLog2;
     f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;
     f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
     f.outputAovs = ctx->st.OutputAOVs;

@@ -24,6 +24,7 @@ struct idkpt_ctx {
     bool frameOk = true;                                    // false after a failed re-layout: idkptRender refuses until the next successful idkptSetSize
     int W = 0, H = 0;
     int shardMode = IDKPT_SHARD_AUTO; bool strips = false;
+    int bandLog2 = 0;                                       // interleaved layouts: rows are dealt in bands of 2^bandLog2 rows (IDKPT_SHARD_BANDS: 8; IDKPT_SHARD_ROWS: 1)
     idkpt_settings st;
     int maxBatch = 1, pending = 0;
     std::vector<int> firstRow, rowCount;                    // strips: member d renders rows [firstRow[d], firstRow[d] + rowCount[d])
@@ -43,12 +44,13 @@ __global__ void k_group_bases(const uint32_t* stage, int lower, int stride, int 
     for (int d = 0; d < lower; d++) sum += stage[(size_t)d * stride + k + 1] - stage[(size_t)d * stride + k];
     gbase[k] = sum;
 }
-// full[y][x] = rows of member y % n, landed contiguously per member in `stage` (member d at rowOffset[d] rows)
-__global__ void k_interleave_rows(const float4* stage, float4* full, int W, int H, int n, const int* rowOffset)
+// full[y][x] = rows of member (y >> bandLog2) % n, landed contiguously per member in `stage` (member d at rowOffset[d] rows; its local row of image row y:
+// band (y >> bandLog2) / n of the member, row y & (band - 1) inside it — every band but the image's last is complete)
+__global__ void k_interleave_rows(const float4* stage, float4* full, int W, int H, int n, const int* rowOffset, int bandLog2)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)W * H) return;
-    const int y = (int)(i / W), x = (int)(i % W), d = y % n, ly = y / n;
+    const int y = (int)(i / W), x = (int)(i % W), band = y >> bandLog2, d = band % n, ly = ((band / n) << bandLog2) | (y & ((1 << bandLog2) - 1));
     full[i] = stage[((size_t)rowOffset[d] + ly) * W + x];
 }
 
@@ -111,14 +113,20 @@ static int group_sync(idkpt_ctx* c)
     return IDKPT_OK;
 }
 
-// (re)applies size + row layout to every member.  Strips for deep paths (exact slot numbering), interleaved rows otherwise.
+static bool mode_wants_strips(int mode, int rayDepth) { return mode == IDKPT_SHARD_STRIPS || (mode == IDKPT_SHARD_AUTO && rayDepth > 2); }
+// interleaved layouts: AUTO and BANDS deal bands of 8 rows (a wave's 8x8 pixel tile stays one 8x8 block of the image on every device: single rows cost
+// 1.5-4.5 % of traversal coherence at N = 2..8, profiles/r02_shard_coherence.txt), ROWS deals single rows.  Images too small for one band per device fall back to rows.
+static int mode_band_log2(int mode, int H, int n) { return (mode == IDKPT_SHARD_ROWS || (H + 7) / 8 < n) ? 0 : 3; }
+
+// (re)applies size + row layout to every member.  Strips for deep paths (exact slot numbering), interleaved bands / rows otherwise.
 static int group_layout(idkpt_ctx* c, int W, int H)
 {
     const int n = (int)c->n();
-    const bool strips = c->shardMode == IDKPT_SHARD_STRIPS || (c->shardMode == IDKPT_SHARD_AUTO && c->st.RayDepth > 2);
+    const bool strips = mode_wants_strips(c->shardMode, c->st.RayDepth);
     c->strips = strips;
     if (W <= 0) return IDKPT_OK;
     GREQ(H >= n, "idkptSetSize: a multi-device context needs at least one image row per device");     // (checked before any member is touched)
+    const int bandLog2 = strips ? 0 : mode_band_log2(c->shardMode, H, n);
     // A member's allocation can fail half way through the loop; the group then has no usable frame (idkptRender refuses) until a later
     // idkptSetSize / idkptSetSettings / idkptSetGroupSharding re-layout succeeds — never a mix of members on the old and the new size.
     c->frameOk = false;
@@ -126,7 +134,7 @@ static int group_layout(idkpt_ctx* c, int W, int H)
     for (int d = 0; d < n; d++) {
         int rc;
         if (strips) { strip_of(H, n, d, &first[d], &count[d]); rc = dev_SetLayout(c->dev[d], W, H, 1, first[d], count[d]); }
-        else { first[d] = d; count[d] = local_rows(H, n, d); rc = dev_SetLayout(c->dev[d], W, H, n, d, 0x7fffffff); }
+        else { first[d] = d << bandLog2; count[d] = local_rows(H, n, d, bandLog2); rc = dev_SetLayout(c->dev[d], W, H, n, d, 0x7fffffff, bandLog2); }
         if (rc) { for (dev_ctx* o : c->dev) o->frameOk = false; return mfail(c, c->dev[d], rc); }
         c->flushDoneValid[d] = 0;
     }
@@ -138,7 +146,7 @@ static int group_layout(idkpt_ctx* c, int W, int H)
     GHIP(c->rowOffDev.ensure((size_t)n * 4));
     GHIP(hipMemcpyAsync(c->rowOffDev.p, rowOff.data(), (size_t)n * 4, hipMemcpyHostToDevice, m0->stream));
     GHIP(hipStreamSynchronize(m0->stream));
-    c->W = W; c->H = H; c->firstRow = first; c->rowCount = count; c->frameOk = true;      // commit
+    c->W = W; c->H = H; c->firstRow = first; c->rowCount = count; c->bandLog2 = bandLog2; c->frameOk = true;      // commit
     return IDKPT_OK;
 }
 
@@ -156,7 +164,12 @@ static int group_download_image(idkpt_ctx* c, int image, int slot, float* rgba, 
         GHIP(hipSetDevice(m->device));
         const float4* src = image_ptr(m, image, slot);
         if (c->strips) GHIP(hipMemcpyAsync((char*)rgba + (size_t)c->firstRow[d] * rowBytes, src, (size_t)m->rows * rowBytes, hipMemcpyDeviceToHost, m->stream));
-        else GHIP(hipMemcpy2DAsync((char*)rgba + (size_t)d * rowBytes, (size_t)n * rowBytes, src, rowBytes, rowBytes, (size_t)m->rows, hipMemcpyDeviceToHost, m->stream));
+        else {
+            // band k of this member = band k * n + d of the image: one 2D copy whose "rows" are whole bands, plus the member's last band when the image cuts it short
+            const size_t band = (size_t)1 << c->bandLog2, bandBytes = band * rowBytes, fullBands = (size_t)m->rows >> c->bandLog2, tail = (size_t)m->rows - (fullBands << c->bandLog2);
+            if (fullBands) GHIP(hipMemcpy2DAsync((char*)rgba + (size_t)d * bandBytes, (size_t)n * bandBytes, src, bandBytes, bandBytes, fullBands, hipMemcpyDeviceToHost, m->stream));
+            if (tail) GHIP(hipMemcpyAsync((char*)rgba + ((size_t)d + fullBands * n) * bandBytes, (const char*)src + fullBands * bandBytes, tail * rowBytes, hipMemcpyDeviceToHost, m->stream));
+        }
     }
     return group_sync(c);
 }
@@ -191,7 +204,7 @@ static int group_gather_device(idkpt_ctx* c, int image, int slot, void** outPtr,
     for (int d = 1; d < n; d++) GHIP(hipStreamWaitEvent(m0->stream, c->evGather[d], 0));
     if (!c->strips) {
         const size_t px = (size_t)c->W * c->H;
-        hipLaunchKernelGGL(k_interleave_rows, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, m0->stream, (const float4*)c->gatherStage.p, (float4*)c->full[image].p, c->W, c->H, n, (const int*)c->rowOffDev.p);
+        hipLaunchKernelGGL(k_interleave_rows, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, m0->stream, (const float4*)c->gatherStage.p, (float4*)c->full[image].p, c->W, c->H, n, (const int*)c->rowOffDev.p, c->bandLog2);
         GHIP(hipGetLastError());
     }
     *outPtr = c->full[image].p;
@@ -203,7 +216,8 @@ static int group_gather_device(idkpt_ctx* c, int image, int slot, void** outPtr,
 static inline uint32_t global_pixel(const idkpt_ctx* c, int d, uint32_t local)
 {
     const uint32_t W = (uint32_t)c->W, ly = local / W, x = local % W;
-    const uint32_t y = c->strips ? (uint32_t)c->firstRow[d] + ly : ly * (uint32_t)c->n() + (uint32_t)d;
+    const uint32_t b = (uint32_t)c->bandLog2;
+    const uint32_t y = c->strips ? (uint32_t)c->firstRow[d] + ly : ((((ly >> b) * (uint32_t)c->n() + (uint32_t)d) << b) | (ly & ((1u << b) - 1u)));
     return y * W + x;
 }
 
@@ -284,13 +298,14 @@ int32_t idkptGetContextDeviceCount(idkpt_ctx* c, int32_t* outCount) { if (!c || 
 int32_t idkptSetGroupSharding(idkpt_ctx* c, int32_t mode)
 {
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
-    GREQ(mode == IDKPT_SHARD_AUTO || mode == IDKPT_SHARD_ROWS || mode == IDKPT_SHARD_STRIPS, "idkptSetGroupSharding: unknown mode");
+    GREQ(mode == IDKPT_SHARD_AUTO || mode == IDKPT_SHARD_ROWS || mode == IDKPT_SHARD_STRIPS || mode == IDKPT_SHARD_BANDS, "idkptSetGroupSharding: unknown mode");
     if (c->n() == 1) { c->shardMode = mode; return IDKPT_OK; }
     GFLUSH();
-    const bool was = c->strips;
+    const bool was = c->strips; const int wasBand = c->bandLog2;
     c->shardMode = mode;
-    const bool now = mode == IDKPT_SHARD_STRIPS || (mode == IDKPT_SHARD_AUTO && c->st.RayDepth > 2);
-    return now != was ? group_layout(c, c->W, c->H) : IDKPT_OK;
+    const bool now = mode_wants_strips(mode, c->st.RayDepth);
+    const int nowBand = now ? 0 : mode_band_log2(mode, c->H, (int)c->n());
+    return (now != was || (c->W > 0 && nowBand != wasBand)) ? group_layout(c, c->W, c->H) : IDKPT_OK;
 }
 
 int32_t idkptSetSize(idkpt_ctx* c, int32_t width, int32_t height)
@@ -306,6 +321,12 @@ int32_t idkptSetRowSharding(idkpt_ctx* c, int32_t rowModulo, int32_t rowRemainde
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
     ONE(dev_SetRowSharding(m, rowModulo, rowRemainder));
     return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetRowSharding: a multi-device context deals its rows itself (idkptSetGroupSharding)");
+}
+int32_t idkptSetRowBands(idkpt_ctx* c, int32_t bandRows, int32_t rowModulo, int32_t rowRemainder)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetRowBands(m, bandRows, rowModulo, rowRemainder));
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetRowBands: a multi-device context deals its rows itself (idkptSetGroupSharding)");
 }
 int32_t idkptSetRowRange(idkpt_ctx* c, int32_t firstRow, int32_t rowCount)
 {
@@ -326,7 +347,7 @@ int32_t idkptSetSettings(idkpt_ctx* c, const idkpt_settings* s)
     ONE(dev_SetSettings(m, s));
     if (memcmp(&c->st, s, sizeof(*s)) == 0) return IDKPT_OK;
     GFLUSH();
-    const bool wantStrips = c->shardMode == IDKPT_SHARD_STRIPS || (c->shardMode == IDKPT_SHARD_AUTO && s->RayDepth > 2);
+    const bool wantStrips = mode_wants_strips(c->shardMode, s->RayDepth);
     ALL(dev_SetSettings(m, s));                       // (validates; nothing is changed when it fails on the first member)
     c->st = *s;
     if (wantStrips != c->strips) { int rc = group_layout(c, c->W, c->H); if (rc) return rc; }   // the RayDepth setter resets the accumulation anyway (PathTracer.cs:16-25)

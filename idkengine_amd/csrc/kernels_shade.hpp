@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs 
     }
     AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
     int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
-    uint32_t gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
+    uint32_t gidSeed = first_hit_gid_seed(f.W, f.H, lx, global_row(f, ly));
     f3 rd = DecodeUnitVec(r.pdx, r.pdy);
     bool cont = ShadeHit<true>(s, f, acc, hit, hit.T != PT_FLOAT_MAX, rd, r, aov, rng, gidSeed, key);
     rays.o_ior[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, r.prevIor);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
             if (FIRST) {
                 f3 o2; f2 pd2; gen_primary(f, smp, pix, acc, o2, pd2, rng); // re-derives the RNG state after ray generation (cheaper than 4 B/pixel of HBM)
                 int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
-                gidSeed = first_hit_gid_seed(f.W, f.H, lx, ly * f.rowMod + f.rowRem);
+                gidSeed = first_hit_gid_seed(f.W, f.H, lx, global_row(f, ly));
             } else {
                 uint32_t gslot = (gbase ? gbase[smp] : 0u) + (slot - qbase[smp]);  // slot inside this sample's own queue (+ the alive rays of the strips above, idkptSetBounceExchange)
                 rng = gslot * 4096u + acc;            // NHit:54

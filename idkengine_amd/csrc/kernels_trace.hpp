@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
     const float r = f.g.LenseRadius, F = f.g.FocalLength;
     if (s.instanceCount >= 1 && s.instanceCount <= 256 && s.skySize <= 1 && !f.outputAovs && r >= 0.0f && F > 1e-3f && r / F <= 0.05f) {
         const float W = (float)f.W, H = (float)f.H;
-        const int gy0 = (int)(ty * 8) * f.rowMod + f.rowRem, gy1 = (int)(ty * 8 + 7) * f.rowMod + f.rowRem;   // global rows of the tile's first / last local row
+        const int gy0 = global_row(f, (int)(ty * 8)), gy1 = global_row(f, (int)(ty * 8 + 7));   // global rows of the tile's first / last local row (monotone in the local row)
         const float nx0 = ((float)(tx * 8) - 1.0f) / W * 2.0f - 1.0f, nx1 = ((float)(tx * 8) + 9.0f) / W * 2.0f - 1.0f;   // one pixel of slack on every side
         const float ny0 = ((float)gy0 - 1.0f) / H * 2.0f - 1.0f, ny1 = ((float)gy1 + 2.0f) / H * 2.0f - 1.0f;
         const f3 u[4] = {GetWorldSpaceDirection(invProj, invView, nx0, ny0), GetWorldSpaceDirection(invProj, invView, nx1, ny0),

@@ -35,6 +35,7 @@ struct DScene {
 struct Frame {
     float invProj[16]; float invView[16]; float viewPos[3];
     int W, H, rowMod, rowRem, rows;
+    int rowBandLog2;            // rows are dealt in bands of 2^rowBandLog2 rows (idkptSetRowBands; 0: single rows / a strip): see global_row
     GpuSettings g;
     uint32_t accumulated;       // AccumulatedSamples of sample 0 of the batch (== accum[0])
     int useTlas, stackCap, outputAovs;
@@ -312,6 +313,10 @@ DEV bool TraceRayAny(const DScene& s, const Frame& f, f3 ro, f3 rd, HitRec& hit,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Image row of a context's local row: band (ly >> b) of the context is band (ly >> b) * rowMod + rowRem of the image (b = 0: rows y % rowMod == rowRem,
+// or the strip that starts at rowRem when rowMod == 1).  Bands of 8 rows keep a wave's 8x8 pixel tile one 8x8 block of the image on every rank.
+DEV int global_row(const Frame& f, int ly) { return ((((ly >> f.rowBandLog2) * f.rowMod + f.rowRem) << f.rowBandLog2) | (ly & ((1 << f.rowBandLog2) - 1))); }
+
 // Primary ray generation (FirstHit/compute.glsl:44-77).  `pix` = local pixel index.
 // the value the reference's shaders would read as wavefrontPTSSBO.AccumulatedSamples for sample `smp` of the batch (FinalDraw's weight keeps the plain count)
 DEV uint32_t sample_index(const Frame& f, uint32_t smp) { return f.seqFirst + f.accum[smp] * f.seqStride; }
@@ -320,7 +325,7 @@ DEV void gen_primary(const Frame& f, uint32_t smp, uint32_t pix, uint32_t acc, f
     const float* cam = f.cams ? f.cams + 36u * smp : f.invProj;      // invProj[16] invView[16] viewPos[3], contiguous in both places
     const float* invProj = cam; const float* invView = cam + 16; const float* vp = cam + 32;
     int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
-    int y = ly * f.rowMod + f.rowRem, x = lx;
+    int y = global_row(f, ly), x = lx;
     uint32_t seed = (uint32_t)(y * 4096 + x) * (acc + 1u);
     float ox = rnd01(seed), oy = rnd01(seed);
     float nx = ((float)x + ox) / (float)f.W * 2.0f - 1.0f, ny = ((float)y + oy) / (float)f.H * 2.0f - 1.0f;

@@ -2,8 +2,9 @@
 CPU tests).  The reference is single-GPU; this is the MI355X-native extension north_star asks for:
 
   * scene/BVH replicated: rank 0 builds, every array is broadcast once per scene (RCCL broadcast, ~100 MB for 1M tris);
-  * pixels are independent given the scene (FirstHit/compute.glsl:81-97), so image rows are dealt round-robin:
-    rank r renders rows y with y % world == r (interleaving balances sky rows against geometry rows);
+  * pixels are independent given the scene (FirstHit/compute.glsl:81-97), so image rows are dealt round-robin in bands of 8 rows:
+    rank r renders rows y with (y // 8) % world == r (interleaving balances sky rows against geometry rows; bands of 8 keep every
+    8x8 pixel tile — the unit a wave of the ray generation and of the primary traversal works on — whole on every rank);
   * per frame the only exchange is the all-gather of the finished row shards (4.1 MB per GPU at 1080p on 8 GPUs);
   * no data-path collective inside a frame.  At RayDepth 2 (the headline metric) radiance is independent of the queue
     slot, so N-GPU output == 1-GPU output bit-for-bit.  For deeper paths the NHit RNG seeds depend on the
@@ -19,8 +20,19 @@ _SCENE_FIELDS = ["blas_nodes", "blas_triangles", "blas_descs", "blas_instances",
                  "vertex_positions", "vertices", "meshes", "materials", "mesh_transforms", "lights"]
 
 
-def rows_of_rank(height, world, rank):
-    return list(range(rank, height, world))
+ROW_BAND = 8      # rows per band of the default (interleaved) deal: idkptSetRowBands(8, world, rank)
+
+
+def rows_of_rank(height, world, rank, band=1):
+    """Image rows of rank `rank` when bands of `band` rows are dealt round-robin (band = 1: single rows), in increasing y."""
+    if band <= 1:
+        return list(range(rank, height, world))
+    return [y for y in range(height) if (y // band) % world == rank]
+
+
+def band_of_deal(height, world, band=ROW_BAND):
+    """The band height the default deal uses: `band` rows, or single rows when the image has fewer bands than ranks."""
+    return band if (height + band - 1) // band >= world else 1
 
 
 def strip_of_rank(height, world, rank):
@@ -111,20 +123,22 @@ class GpuShardRenderer:
     """Adapter: idkengine_amd.PathTracer rendering this rank's rows; exposes the local RGBA rows as a torch tensor that
     aliases the library's device image (no host copy before the RCCL all-gather)."""
 
-    def __init__(self, width, height, world, rank, device_index, exact_deep_paths=False, control_group=None):
+    def __init__(self, width, height, world, rank, device_index, exact_deep_paths=False, control_group=None, row_band=None):
         """exact_deep_paths: contiguous strips + per-bounce count exchange over `control_group` (a CPU/gloo group), so that N-GPU
-        output equals 1-GPU output bit for bit at any RayDepth (sorting off); default: interleaved rows, exact at RayDepth 2."""
+        output equals 1-GPU output bit for bit at any RayDepth (sorting off); default: interleaved bands of `row_band` rows (None: 8, or
+        single rows on images with fewer bands than ranks), exact at RayDepth 2."""
         from .pathtracer import PathTracer
         torch.cuda.set_device(device_index)
         self.device = torch.device("cuda", device_index)
         self.exact = exact_deep_paths
+        self.row_band = 1 if exact_deep_paths or world == 1 else (band_of_deal(height, world) if row_band is None else int(row_band))
         if exact_deep_paths:
             self.pt = PathTracer(width, height, device=device_index)
             first, count = strip_of_rank(height, world, rank)
             self.pt.SetRowRange(first, count)
             self.pt.SetBounceExchange(make_count_exchange(control_group))
         else:
-            self.pt = PathTracer(width, height, device=device_index, row_modulo=world, row_remainder=rank)
+            self.pt = PathTracer(width, height, device=device_index, row_modulo=world, row_remainder=rank, row_band=self.row_band)
         # render on a dedicated torch stream and issue the collectives under it: RCCL work is then ordered after the
         # kernels that produce the image, and later renders are ordered after the collective that reads it
         self.stream = torch.cuda.Stream(device=self.device)
@@ -160,16 +174,22 @@ class GpuShardRenderer:
 
 
 class ShardedFrame:
-    """Row-interleaved sharding of one frame over the ranks of a process group + all-gather of the shards."""
+    """Sharding of one frame over the ranks of a process group (interleaved bands / rows, or strips) + all-gather of the shards."""
 
     def __init__(self, renderer, width, height, group=None):
         self.r = renderer
         self.group = group
         self.world = dist.get_world_size(group); self.rank = dist.get_rank(group)
         self.width, self.height = width, height
-        self.max_rows = (height + self.world - 1) // self.world
-        self.strips = bool(getattr(renderer, "exact", False))           # contiguous strips (exact deep paths) or interleaved rows
-        assert renderer.rows == (strip_of_rank(height, self.world, self.rank)[1] if self.strips else len(rows_of_rank(height, self.world, self.rank)))
+        self.strips = bool(getattr(renderer, "exact", False))           # contiguous strips (exact deep paths) or interleaved bands / rows
+        self.band = int(getattr(renderer, "row_band", 1))
+        if self.strips:
+            self.rank_rows = [list(range(f, f + n)) for f, n in (strip_of_rank(height, self.world, r) for r in range(self.world))]
+        else:
+            self.rank_rows = [rows_of_rank(height, self.world, r, self.band) for r in range(self.world)]
+        self.max_rows = max(len(v) for v in self.rank_rows)
+        assert renderer.rows == len(self.rank_rows[self.rank])
+        self._row_index = None
 
     def render(self):
         self.r.render()
@@ -195,13 +215,26 @@ class ShardedFrame:
             dist.all_gather(parts, local.contiguous().clone(), group=self.group)   # clone: the collective works on torch-owned memory, the ring slots are free again
             full = torch.empty((count, self.height, self.width, 4), dtype=local.dtype, device=local.device)
             for r in range(self.world):
-                if self.strips:
-                    first, n = strip_of_rank(self.height, self.world, r)
-                    full[:, first:first + n] = parts[r][:, :n]
-                else:
-                    n = len(rows_of_rank(self.height, self.world, r))
-                    full[:, r::self.world] = parts[r][:, :n]
+                self._place(full, parts[r], r, 1)
             return full
+
+    def _place(self, full, part, r, dim):
+        """rows of rank r (the first len(rank_rows[r]) of `part` along `dim`) -> their image rows in `full`"""
+        rows = self.rank_rows[r]; n = len(rows)
+        sel = (slice(None),) * dim
+        if n == 0:
+            return
+        if self.strips:
+            full[sel + (slice(rows[0], rows[0] + n),)] = part[sel + (slice(0, n),)]
+        elif self.band <= 1:
+            full[sel + (slice(r, None, self.world),)] = part[sel + (slice(0, n),)]
+        else:
+            if self._row_index is None:
+                self._row_index = {}
+            idx = self._row_index.get((r, str(full.device)))
+            if idx is None:
+                idx = torch.tensor(rows, dtype=torch.long, device=full.device); self._row_index[(r, str(full.device))] = idx
+            full.index_copy_(dim, idx, part[sel + (slice(0, n),)])
 
     def _gather(self):
         local = self.r.local_image()
@@ -212,12 +245,7 @@ class ShardedFrame:
         dist.all_gather(parts, local.contiguous().clone(), group=self.group)       # clone (4 MB): torch-owned send buffer, decoupled from the library's image
         full = torch.empty((self.height, self.width, 4), dtype=local.dtype, device=local.device)
         for r in range(self.world):
-            if self.strips:
-                first, n = strip_of_rank(self.height, self.world, r)
-                full[first:first + n] = parts[r][:n]
-            else:
-                n = len(rows_of_rank(self.height, self.world, r))
-                full[r::self.world] = parts[r][:n]
+            self._place(full, parts[r], r, 0)
         return full
 
 

@@ -20,9 +20,10 @@ _OPTION_NAMES = ("force_generic", "no_tile_cull", "no_lean_primary", "leaf_min",
 
 
 class PathTracer:
-    def __init__(self, width, height, settings=None, device=0, row_modulo=1, row_remainder=0, devices=None):
+    def __init__(self, width, height, settings=None, device=0, row_modulo=1, row_remainder=0, devices=None, row_band=1):
         """devices: list of HIP device ids for ONE context that renders on several GPUs (idkptCreate(deviceCount = N)); an id may repeat
-        (two members on one GPU).  Otherwise one device (`device`), optionally one row shard of a process-per-GPU run (row_modulo/remainder)."""
+        (two members on one GPU).  Otherwise one device (`device`), optionally one row shard of a process-per-GPU run (row_modulo/remainder;
+        row_band: rows are dealt in bands of that many rows, idkptSetRowBands)."""
         self._L = _lib.load()
         n = C.c_int32(0)
         self._L.idkptGetDeviceCount(C.byref(n))
@@ -47,10 +48,13 @@ class PathTracer:
         self._cached_ray_depth = self._settings.RayDepth
         self._scene = None
         self.width, self.height = width, height
-        self.row_modulo, self.row_remainder = row_modulo, row_remainder
+        self.row_modulo, self.row_remainder, self.row_band = row_modulo, row_remainder, (int(row_band) if row_modulo > 1 else 1)
         self._row_limit = None
         if self.device_count == 1:
-            self._check(self._L.idkptSetRowSharding(ctx, row_modulo, row_remainder))
+            if self.row_band > 1:
+                self._check(self._L.idkptSetRowBands(ctx, self.row_band, row_modulo, row_remainder))
+            else:
+                self._check(self._L.idkptSetRowSharding(ctx, row_modulo, row_remainder))
         self._check(self._L.idkptSetSize(ctx, width, height))
         self._push_settings()
 
@@ -64,10 +68,15 @@ class PathTracer:
     def _push_settings(self):
         self._check(self._L.idkptSetSettings(self._ctx, C.addressof(self._settings)))
 
+    def global_rows(self):
+        """image rows of this context's local rows, in local order"""
+        b = self.row_band
+        ys = [y for y in range(self.height) if (y // b) % self.row_modulo == self.row_remainder] if self.row_modulo > 1 else list(range(self.row_remainder, self.height))
+        return ys if self._row_limit is None else ys[:self._row_limit]
+
     @property
     def rows(self):
-        n = len(range(self.row_remainder, self.height, self.row_modulo))
-        return n if self._row_limit is None else min(n, self._row_limit)
+        return len(self.global_rows())
 
     # ------------------------------------------------------------------ PathTracer.cs public surface
     def _prop(name, gpu=False):  # noqa: N805
@@ -207,13 +216,13 @@ class PathTracer:
         self._check(self._L.idkptSkin(self._ctx, input_offset, output_offset, joint_offset, count))
 
     def SetGroupSharding(self, mode):
-        """idkptSetGroupSharding: 0 auto (rows for RayDepth <= 2, strips + device-side count exchange beyond), 1 rows, 2 strips."""
+        """idkptSetGroupSharding: 0 auto (bands of 8 rows for RayDepth <= 2, strips + device-side count exchange beyond), 1 rows, 2 strips, 3 bands of 8 rows."""
         self._check(self._L.idkptSetGroupSharding(self._ctx, int(mode)))
 
     def SetRowRange(self, first_row, row_count):
         """idkptSetRowRange: this context renders the contiguous strip [first_row, first_row + row_count)."""
         self._check(self._L.idkptSetRowRange(self._ctx, int(first_row), int(row_count)))
-        self.row_modulo, self.row_remainder, self._row_limit = 1, int(first_row), int(row_count)
+        self.row_modulo, self.row_remainder, self._row_limit, self.row_band = 1, int(first_row), int(row_count), 1
 
     def SetBounceExchange(self, fn):
         """idkptSetBounceExchange: fn(bounce, local_counts ndarray[samples]) -> bases ndarray[samples] (alive rays of the same sample

@@ -149,11 +149,15 @@ IDKPT_API int32_t idkptGetContextDeviceCount(idkpt_ctx* ctx, int32_t* outCount);
 /* How a multi-device context deals the image rows to its devices (ignored by a one-device context):
  *   IDKPT_SHARD_ROWS    row y -> device y % N.  Balances sky rows against geometry rows; exact for RayDepth <= 2 (radiance does not depend on
  *                       the queue slot there), statistically equivalent beyond.
+ *   IDKPT_SHARD_BANDS   band of 8 rows k -> device k % N (row y -> device (y / 8) % N): the same balance, and every device keeps whole 8x8 pixel
+ *                       tiles — the unit a wave of the ray generation and of the primary traversal works on — so no traversal coherence is lost to
+ *                       the split (single rows: 1.5-4.5 % at N = 2..8).  Exact where ROWS is.
  *   IDKPT_SHARD_STRIPS  contiguous strips + a device-side exchange of the per-sample alive counts at every bounce (peer copies ordered by
  *                       events, no host synchronisation): every strip numbers its NHit queue slots after the alive rays of the strips above
  *                       it (NHit seeds its RNG from the slot, NHit/compute.glsl:54), so N devices == 1 device at any RayDepth with DoRaySorting off.
- *   IDKPT_SHARD_AUTO    (default) rows for RayDepth <= 2, strips beyond.  A change of layout restarts the accumulation (like idkptSetSize). */
-enum idkpt_group_sharding { IDKPT_SHARD_AUTO = 0, IDKPT_SHARD_ROWS = 1, IDKPT_SHARD_STRIPS = 2 };
+ *   IDKPT_SHARD_AUTO    (default) bands for RayDepth <= 2 (rows when the image has fewer bands than devices), strips beyond.  A change of layout
+ *                       restarts the accumulation (like idkptSetSize). */
+enum idkpt_group_sharding { IDKPT_SHARD_AUTO = 0, IDKPT_SHARD_ROWS = 1, IDKPT_SHARD_STRIPS = 2, IDKPT_SHARD_BANDS = 3 };
 IDKPT_API int32_t idkptSetGroupSharding(idkpt_ctx* ctx, int32_t mode);
 /* PathTracer.Dispose (PathTracer.cs:344-365) */
 IDKPT_API int32_t idkptDestroy(idkpt_ctx* ctx);
@@ -170,6 +174,10 @@ IDKPT_API int32_t idkptSetSize(idkpt_ctx* ctx, int32_t width, int32_t height);
  * (rowModulo = world size, rowRemainder = rank).  Images/ray buffers then hold only the local rows, in
  * increasing y.  (1,0) = whole frame.  No reference equivalent (single GPU); DESIGN.md "Multi-GPU". */
 IDKPT_API int32_t idkptSetRowSharding(idkpt_ctx* ctx, int32_t rowModulo, int32_t rowRemainder);
+/* The same deal in bands of bandRows rows (a power of two, 1..64; 1 = idkptSetRowSharding): this context renders the rows y with
+ * (y / bandRows) % rowModulo == rowRemainder, kept in increasing y.  bandRows = 8 keeps every 8x8 pixel tile — the unit a wave of the ray
+ * generation and of the primary traversal works on — whole on every rank (DESIGN.md "Multi-GPU"). */
+IDKPT_API int32_t idkptSetRowBands(idkpt_ctx* ctx, int32_t bandRows, int32_t rowModulo, int32_t rowRemainder);
 /* Contiguous strip instead of interleaved rows: this context renders image rows [firstRow, firstRow + rowCount).  Strips keep every
  * context's pixels contiguous in the canonical (pixel-index) order, which the exact multi-GPU mode below needs; interleaved rows
  * balance better and are the default for RayDepth 2. */

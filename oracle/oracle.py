@@ -157,7 +157,7 @@ def trace_shadows(scene, params, depth, normal_oct, visibility=None, use_tlas=Fa
 class OraclePathTracer:
     """Sequential CPU execution of the reference's FirstHit/NHit/FinalDraw schedule (PathTracer.cs:214-271)."""
 
-    def __init__(self, scene, width, height, row_modulo=1, row_remainder=0):
+    def __init__(self, scene, width, height, row_modulo=1, row_remainder=0, row_band=1):
         T = _dtypes(); L = lib()
         self.T = T
         d, keep = scene.desc()
@@ -167,6 +167,10 @@ class OraclePathTracer:
         self.rows = len(range(row_remainder, height, row_modulo))
         self._pt = L.ref_pt_create(self._scene, width, height, row_modulo, row_remainder)
         self.settings = T.Settings.default()
+        if row_band > 1 and row_modulo > 1:
+            # idkptSetRowBands: rows y with (y // row_band) % row_modulo == row_remainder
+            L.ref_pt_set_row_bands(C.c_void_p(self._pt), int(row_band), int(row_modulo), int(row_remainder))
+            self.rows = len([y for y in range(height) if (y // row_band) % row_modulo == row_remainder])
 
     def set_row_range(self, first_row, row_count):
         """idkptSetRowRange: contiguous strip [first_row, first_row + row_count)."""

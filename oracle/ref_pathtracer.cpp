@@ -426,7 +426,7 @@ static bool RussianRouletteTerminateRay(v3& throughput, Rng* rng)
 
 struct PT {
     const Scene* scene;
-    int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0;
+    int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0, rowBand = 1;   // rowBand: rows are dealt in bands of that many rows (idkptSetRowBands)
     idkpt_settings st;
     float invProj[16], invView[16], viewPos[3];
     uint32_t accumulated = 0;
@@ -586,7 +586,7 @@ static void RenderSample(PT& pt)
     // ---- FirstHit main (FirstHit/compute.glsl:44-98), one invocation per pixel ----
     #pragma omp parallel for schedule(dynamic, 1)
     for (int ly = 0; ly < rows; ly++) {
-        int y = ly * pt.rowMod + pt.rowRem;
+        int y = ((ly / pt.rowBand) * pt.rowMod + pt.rowRem) * pt.rowBand + ly % pt.rowBand;   // idkptSetRowBands (rowBand 1: y % rowMod == rowRem, or a strip)
         for (int x = 0; x < W; x++) {
             size_t rayIndex = (size_t)ly * W + x;
             Rng rng; rng.seed = (uint32_t)(y * 4096 + x) * (pt.sampleIndex() + 1u);
@@ -837,7 +837,18 @@ void ref_pt_destroy(void* p) { delete (PT*)p; }
 // idkptSetRowRange / idkptSetBounceExchange counterparts
 void ref_pt_set_row_range(void* p, int firstRow, int rowCount)
 {
-    PT* pt = (PT*)p; pt->rowMod = 1; pt->rowRem = firstRow; pt->rows = std::min(rowCount, pt->H - firstRow);
+    PT* pt = (PT*)p; pt->rowMod = 1; pt->rowRem = firstRow; pt->rowBand = 1; pt->rows = std::min(rowCount, pt->H - firstRow);
+    size_t N = (size_t)pt->W * pt->rows;
+    pt->rays.assign(N, GpuWavefrontRay{}); pt->aov.assign(N, GpuAovRay{});
+    for (int i = 0; i < 3; i++) pt->img[i].assign(4 * N, 0.0f);
+    pt->primT.assign(N, 0.0f); pt->primTri.assign(N, 0u); pt->primBary.assign(2 * N, 0.0f);
+    pt->accumulated = 0;
+}
+// idkptSetRowBands counterpart: rows y with (y / bandRows) % rowMod == rowRem
+void ref_pt_set_row_bands(void* p, int bandRows, int rowMod, int rowRem)
+{
+    PT* pt = (PT*)p; pt->rowBand = rowMod > 1 ? bandRows : 1; pt->rowMod = rowMod; pt->rowRem = rowRem;
+    pt->rows = 0; for (int y = 0; y < pt->H; y++) if ((y / pt->rowBand) % rowMod == rowRem) pt->rows++;
     size_t N = (size_t)pt->W * pt->rows;
     pt->rays.assign(N, GpuWavefrontRay{}); pt->aov.assign(N, GpuAovRay{});
     for (int i = 0; i < 3; i++) pt->img[i].assign(4 * N, 0.0f);

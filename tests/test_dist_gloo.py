@@ -18,9 +18,10 @@ def _free_port():
 
 
 class OracleShardRenderer:
-    def __init__(self, scene, cam, world, rank):
+    def __init__(self, scene, cam, world, rank, row_band=1):
         from oracle import oracle as O
-        self.pt = O.OraclePathTracer(scene, W, H, row_modulo=world, row_remainder=rank)
+        self.row_band = row_band
+        self.pt = O.OraclePathTracer(scene, W, H, row_modulo=world, row_remainder=rank, row_band=row_band)
         self.pt.set_camera(cam); self.pt.settings.RayDepth = 2
         self.rows, self.width = self.pt.rows, W
 
@@ -31,7 +32,7 @@ class OracleShardRenderer:
         return torch.from_numpy(self.pt.image())
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, row_band=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,7 +41,7 @@ def _worker(rank, world, port, q):
     scene = S.cornell_scene(NativeBuilder(), "mixed", instanced=True) if rank == 0 else None
     scene = D.broadcast_scene(scene, src=0)
     cam = S.cornell_camera(W, H)
-    frame = D.ShardedFrame(OracleShardRenderer(scene, cam, world, rank), W, H)
+    frame = D.ShardedFrame(OracleShardRenderer(scene, cam, world, rank, row_band), W, H)
     frame.render()
     full = frame.gather().numpy()
     import hashlib
@@ -50,12 +51,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_row_sharded_frame_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("row_band", [1, 8])
+def test_row_sharded_frame_world2_gloo(row_band):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, row_band)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
@@ -68,7 +73,7 @@ def test_row_sharded_frame_world2_gloo():
     sc = S.cornell_scene(NativeBuilder(), "mixed", instanced=True)
     ref = O.OraclePathTracer(sc, W, H); ref.set_camera(S.cornell_camera(W, H)); ref.settings.RayDepth = 2; ref.render()
     want = ref.image()
-    assert res[0][3] == 24 and res[1][3] == 23
+    assert (res[0][3], res[1][3]) == ((24, 23) if row_band == 1 else (24, 23))   # H = 47: rows 0,2,..,46 / bands 0-7, 16-23, 32-39 against 8-15, 24-31, 40-46
     assert res[0][2] == res[1][2]                                          # broadcast scene identical on both ranks
     for _, full, _, _ in res:                                              # every rank holds the full frame, == 1-process frame bit-for-bit
         assert full.shape == (H, W, 4)
@@ -147,13 +152,18 @@ def test_exact_deep_paths_world3_gloo():
 
 
 def test_rows_of_rank_partition():
-    from idkengine_amd.dist import rows_of_rank
+    from idkengine_amd.dist import rows_of_rank, band_of_deal
     for h, world in ((1080, 8), (47, 2), (5, 8)):
         rows = sorted(y for r in range(world) for y in rows_of_rank(h, world, r))
         assert rows == list(range(h))
+        for band in (2, 8, 16):
+            per_rank = [rows_of_rank(h, world, r, band) for r in range(world)]
+            assert sorted(y for v in per_rank for y in v) == list(range(h))
+            assert all(v == sorted(v) and all((y // band) % world == r for y in v) for r, v in enumerate(per_rank))
         from idkengine_amd.dist import strip_of_rank
         strips = [strip_of_rank(h, world, r) for r in range(world)]
         assert [y for f, n in strips for y in range(f, f + n)] == list(range(h))
+    assert band_of_deal(1080, 8) == 8 and band_of_deal(5, 8) == 1 and band_of_deal(47, 2) == 8
 
 
 def _worker_samples(rank, world, port, q):

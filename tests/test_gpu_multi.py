@@ -116,6 +116,44 @@ def test_sharded_frame_over_rccl_world1(native_builder):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("band,world", [(8, 3), (4, 2), (16, 2)])
+def test_row_bands_equal_the_oracle_and_tile_the_frame(native_builder, oracle_mod, band, world):
+    """idkptSetRowBands: rank r of `world` renders the rows y with (y // band) % world == r.  Every rank's context equals the oracle rendering the same
+    rows bit for bit (image, ray state, primary hits, alive queue, visit counters; the frame's last band is partial, one tile row straddles two bands when
+    band < 8), and at RayDepth 2 the ranks' images tile the one-context frame exactly."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd._lib import IdkPtError
+    from idkengine_amd import gputypes as T, dist as D
+    sc = S.soup_scene(20000, native_builder, seed=12, extent=3.0); w, h = 150, 93; cam = S.Camera(w, h, position=(0.0, 0.0, 7.5))
+    whole = gpu_render(sc, cam, w, h, frames=2, RayDepth=2)
+    full = np.zeros((h, w, 4), np.float32)
+    for r in range(world):
+        for depth, batch in ((2, 2), (4, 1)):
+            st = configs.apply_settings(T.Settings.default(), dict(RayDepth=depth))
+            p = PathTracer(w, h, settings=st, row_modulo=world, row_remainder=r, row_band=band)
+            p.UploadScene(sc); p.SetCamera(cam); p.enable_counters(True); p.enable_primary_hit_capture(True); p.set_max_batch(batch)
+            p.Compute(); p.Compute()
+            o = oracle_mod.OraclePathTracer(sc, w, h, row_modulo=world, row_remainder=r, row_band=band); o.set_camera(cam)
+            configs.apply_settings(o.settings, dict(RayDepth=depth)); o.enable_counters(True); o.render(); o.render()
+            rows = D.rows_of_rank(h, world, r, band)
+            assert p.rows == o.rows == len(rows) and p.global_rows() == rows
+            assert_equal(p, o)
+            if depth == 2:
+                full[rows] = p.Result
+            p.Dispose(); o.close()
+    assert (bits(full) == bits(whole.Result)).all()
+    whole.Dispose()
+    # argument checks: the band height is a power of two; a remainder without rows is refused
+    q = PathTracer(16, 16)
+    with pytest.raises(IdkPtError, match="power of two"):
+        q._check(q._L.idkptSetRowBands(q._ctx, 6, 2, 0))
+    with pytest.raises(IdkPtError, match="no row"):
+        q._check(q._L.idkptSetRowBands(q._ctx, 8, 4, 3))          # 16 rows = bands 0 and 1: band index 3 does not exist
+    q._check(q._L.idkptSetRowBands(q._ctx, 8, 2, 1)); q.row_modulo, q.row_remainder, q.row_band = 2, 1, 8
+    assert q.rows == 8
+    q.Dispose()
+
+
 def _device_ids(members):
     import ctypes as C
     from idkengine_amd import _lib
@@ -186,7 +224,7 @@ def test_multi_device_context_api_surface(native_builder, oracle_mod):
         p.UploadScene(sc); p.SetCamera(cam(96, 64)); p.RayDepth = 3; p.Compute()
     assert (bits(a.Result) == bits(b.Result)).all()
     # resize + explicit strips at depth 2 / explicit rows
-    for mode, depth in ((2, 2), (1, 2), (0, 4)):
+    for mode, depth in ((2, 2), (1, 2), (3, 2), (0, 2), (0, 4)):      # strips, rows, bands of 8, auto (= bands), auto (= strips)
         a.SetGroupSharding(mode)
         for p in (a, b):
             p.SetSize(123, 45); p.SetCamera(cam(123, 45)); p.RayDepth = depth; p.set_max_batch(2); p.Compute(); p.Compute()

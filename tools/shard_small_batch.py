@@ -1,5 +1,6 @@
-"""Developer tool (GPU box): what ONE rank of an N-GPU strong-scaling run does — the driver's 20 steps on 1/N of the frame's rows (y % N == r) —
-timed on one GPU, with the scheduling options that matter for small launches.  usage: python tools/shard_small_batch.py [N=8] [steps=20]"""
+"""Developer tool (GPU box): what ONE rank of an N-GPU strong-scaling run does — the driver's 20 steps on 1/N of the frame's rows (bands of SHARD_BANDS rows,
+(y // band) % N == r) — timed on one GPU, with the scheduling options that matter for small launches.
+usage: [SHARD_BANDS=1,8] [SHARD_OPTS=grid|none|"k=v,k=v;k=v"] [SHARD_MODS=1,2,4,8] python tools/shard_small_batch.py [N=8] [steps=20]"""
 import os
 import sys
 import time
@@ -16,12 +17,19 @@ if __name__ == "__main__" and os.environ.get("SHARD_TWO") != "1":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     sc = S.soup_scene(1000000, NativeBuilder(), seed=1); cam = S.Camera(W, H)
-    for mod in (1, N):
+    mods = [int(v) for v in os.environ["SHARD_MODS"].split(",")] if os.environ.get("SHARD_MODS") else [1, N]
+    bands = [int(v) for v in os.environ.get("SHARD_BANDS", "8").split(",")]
+    for mod, band in [(m, b) for m in mods for b in (bands if m > 1 else bands[:1])]:
         sets = ({}, {"leaf_min": 12}, {"leaf_min": 16}, {"leaf_min": 20}, {"grid_hint": 0}, {"trace_waves": 16}, {"trace_waves": 32})
-        if os.environ.get("SHARD_OPTS") == "grid":
+        so = os.environ.get("SHARD_OPTS", "none")
+        if so == "grid":
             sets = ({}, {"grid_rays_x4": 0}, {"grid_rays_x4": 8}, {"grid_rays_x4": 12}, {"grid_rays_x4": 16}, {"grid_rays_x4": 24}, {"trace_waves": 20}, {"trace_waves": 16}, {"trace_waves": 12})
+        elif so == "none":
+            sets = ({},)
+        elif so != "sched":
+            sets = tuple({kv.split("=")[0]: int(kv.split("=")[1]) for kv in grp.split(",") if kv} for grp in so.split(";"))
         for opts in sets:
-            pt = PathTracer(W, H, row_modulo=mod, row_remainder=0)
+            pt = PathTracer(W, H, row_modulo=mod, row_remainder=0, row_band=band)
             for k, v in opts.items():
                 pt.set_option(k, v)
             pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = 2; pt.set_max_batch(min(256, 32 * mod))
@@ -40,7 +48,7 @@ if __name__ == "__main__" and os.environ.get("SHARD_TWO") != "1":
                 ts.append(time.perf_counter() - t0)
             rays = pt.stats()["rays_traced"] / 9
             med = sorted(ts)[4]
-            print(f"rows y % {mod} == 0, {steps} steps, options {opts}: {med * 1e3:7.3f} ms per region, {rays / med / 1e6:8.1f} Mray/s on this GPU -> x{mod} = {rays * mod / med / 1e6:9.1f} Mray/s if every rank took as long", flush=True)
+            print(f"rows (y // {band}) % {mod} == 0, {steps} steps, options {opts}: {med * 1e3:7.3f} ms per region, {rays / med / 1e6:8.1f} Mray/s on this GPU -> x{mod} = {rays * mod / med / 1e6:9.1f} Mray/s if every rank took as long", flush=True)
             pt.Dispose()
 
 
