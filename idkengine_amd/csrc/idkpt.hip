@@ -62,7 +62,11 @@ struct DevOptions {
     int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
 };
 
-struct PendingSample { uint32_t accum; int slot; float cam[36]; };   // cam = invProj[16] invView[16] viewPos[3] pad
+// Scene versions (idkptSetSceneVersions): the buffers the render kernels read of the geometry an animated frame rewrites.  Each may hold several states
+// ("slots" of one arena); a queued sample remembers the slots that were current when it was queued (PendingSample::vs), so frames with different geometry can
+// be traced by one batch while later updates already write other slots (ver_writable).
+enum { VB_NODES = 0, VB_TNODES, VB_TRIVERTS, VB_VERTICES, VB_TLAS, VB_XFORMS, VB_COUNT };
+struct PendingSample { uint32_t accum; int slot; float cam[36]; uint8_t vs[VB_COUNT]; };   // cam = invProj[16] invView[16] viewPos[3] pad; vs = scene-version slots
 
 struct dev_ctx {
     int device = 0;
@@ -87,9 +91,17 @@ struct dev_ctx {
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
     std::vector<uint32_t> levelBase;                 // per BLAS base into levelNodes
+    std::vector<char> refitCoversAll;                // per BLAS: leaves + internal nodes of the refit schedule are every node but node 0 (a refit into a fresh slot needs no copy of the old nodes)
     int nodeCount = 0, triCount = 0, instanceCount = 0, tlasCount = 0, vertexCount = 0, meshCount = 0, materialCount = 0, xformCount = 0, lightCount = 0, skySize = 0, textureCount = 0, unskinnedCount = 0;
     int sceneStack = 1;
     bool layoutActive = false;                       // tnodes holds the derived order (else the traversal reads `nodes`)
+    // scene versions: slot count a versioned buffer may grow to, per buffer the bytes of one state / the slot pitch / the slots its arena holds / the current slot
+    int verSlots = 1; size_t vbytes[VB_COUNT] = {0}, vstride[VB_COUNT] = {0}; int valloc[VB_COUNT] = {1, 1, 1, 1, 1, 1}, vcur[VB_COUNT] = {0};
+    uint64_t lastMask[VB_COUNT] = {0};               // slots the last launched batch reads (a deferred last bounce still does: finish_deferred)
+    uint8_t lastSlots[VB_COUNT] = {0}; bool lastMulti = false;   // ... the one set of slots of a single-version batch, or "per sample: verTab"
+    DevBuf verTab; uint32_t* hVerTab = nullptr; hipEvent_t evVer[2] = {nullptr, nullptr}; int verHalf = 0;   // per-sample version table of the batch being launched (pinned, double-buffered staging)
+    char* hStage = nullptr; hipEvent_t evStage[4] = {nullptr, nullptr, nullptr, nullptr}; int stageNext = 0;   // pinned ring for small host -> device updates (joint matrices, transforms): no stream synchronisation per call
+    int (*groupFlushAll)(void* user) = nullptr;      // member of a multi-device context: launches what ALL members have queued (a member never flushes on its own)
     // wavefront state
     DevBuf trRec, contFlag, blockSums, rayO, rayT, rayR, aovA, aovN, hit, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, ordKeys[2], ordVals[2], ordIdx, contMask, waveCounts, counts, work, sortHist, counters64;
     DevBuf img[3];
@@ -152,6 +164,14 @@ template <bool PRIMARY>
 static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
                           const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters)
 {
+    if (s.ver) {                    // scene versions: the samples of this batch see different states of the geometry (VER instantiations, kernels_trace.hpp)
+#define T2VER(C, M) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 32, 1, false, 24, M, 0, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+        if (f.useTlas) { if (ctx->counters) T2VER(true, 2); else T2VER(false, 2); }
+        else if (ctx->instanceCount > 1) { if (ctx->counters) T2VER(true, 1); else T2VER(false, 1); }
+        else { if (ctx->counters) T2VER(true, 0); else T2VER(false, 0); }
+#undef T2VER
+        return;
+    }
     if (f.useTlas) {                // TLAS walk inside the kernel
         if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 2>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
         else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 2>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
@@ -247,8 +267,97 @@ static int check_overflow(dev_ctx* ctx)
 static int finish_deferred(dev_ctx* ctx);
 // FLUSH: issue the samples still queued, and complete a deferred last bounce (readers of ray state / queues, and everything that changes what its kernels would read).
 // FLUSH_KEEP: issue only (images, synchronisation, camera, statistics, batching knobs: nothing that looks at or invalidates the deferred part).
-#define FLUSH() do { int _rc = flush_batch(ctx); if (_rc) return _rc; _rc = finish_deferred(ctx); if (_rc) return _rc; } while (0)
-#define FLUSH_KEEP() do { int _rc = flush_batch(ctx); if (_rc) return _rc; } while (0)
+// (a member of a multi-device context never launches on its own: the group launches what ALL members have queued, idkpt_api.hpp group_flush_all)
+static int flush_any(dev_ctx* ctx);
+#define FLUSH() do { int _rc = flush_any(ctx); if (_rc) return _rc; _rc = finish_deferred(ctx); if (_rc) return _rc; } while (0)
+#define FLUSH_KEEP() do { int _rc = flush_any(ctx); if (_rc) return _rc; } while (0)
+
+// ---- scene versions -------------------------------------------------------------------------------------------------------------------------------
+// A scene update (skinning, refit, TLAS rebuild, a patched transform) used to launch every queued sample first: the kernels of a batch read "the" scene, so
+// an animated host rendered one frame at a time (a quarter of the batched rate).  With idkptSetSceneVersions(n > 1) the buffers those updates write — and the
+// render kernels read — are arenas of up to n slots.  An update that would overwrite a slot which queued samples (or the deferred last bounce of the launched
+// batch) still read moves the CURRENT state of that buffer to a free slot first (copying it unless the update rewrites all of it) and writes there; updates run
+// eagerly in stream order, rendering stays deferred, and a batch whose samples saw different slots gets a per-sample table (DScene::ver, VER kernels).
+// Everything is on the context's one stream, so kernels already launched are ordered before any later write: only unlaunched samples pin a slot.
+// With one slot (the default) the first branch below never finds room and falls through to "launch what is queued": exactly the old behaviour.
+static int flush_any(dev_ctx* ctx)
+{
+    if (ctx->pending.empty()) return IDKPT_OK;
+    return (ctx->grouped && !ctx->inGroupFlush && ctx->groupFlushAll) ? ctx->groupFlushAll(ctx->groupUser) : flush_batch(ctx);
+}
+static DevBuf& vb_buf(dev_ctx* ctx, int b)
+{
+    switch (b) { case VB_NODES: return ctx->nodes; case VB_TNODES: return ctx->tnodes; case VB_TRIVERTS: return ctx->triVerts; case VB_VERTICES: return ctx->vertices; case VB_TLAS: return ctx->tlas; default: return ctx->xforms; }
+}
+static char* vb_ptr(dev_ctx* ctx, int b, int slot) { return (char*)vb_buf(ctx, b).p + (size_t)slot * ctx->vstride[b]; }
+template <class T> static T* vb_cur(dev_ctx* ctx, int b) { return (T*)vb_ptr(ctx, b, ctx->vcur[b]); }
+// after idkptUploadScene / a clone / a re-derived node order: one state per buffer, in slot 0 of whatever allocation the buffer has
+static void ver_reset(dev_ctx* ctx)
+{
+    const size_t one[VB_COUNT] = {(size_t)ctx->nodeCount * 32, ctx->layoutActive ? (size_t)ctx->nodeCount * 32 : 0, (size_t)ctx->triCount * 48, (size_t)ctx->vertexCount * 16,
+                                  (size_t)std::max(ctx->tlasCount, 2 * ctx->instanceCount - 1) * 32, (size_t)ctx->xformCount * sizeof(GpuMeshTransform)};
+    for (int b = 0; b < VB_COUNT; b++) { ctx->vbytes[b] = one[b]; ctx->vstride[b] = (one[b] + 255) / 256 * 256; ctx->valloc[b] = 1; ctx->vcur[b] = 0; ctx->lastMask[b] = 0; ctx->lastSlots[b] = 0; }
+    ctx->lastMulti = false;
+}
+// the arena of buffer b gets room for every slot (first use of a second slot): only slot 0 is in use at that moment
+static int ver_grow(dev_ctx* ctx, int b)
+{
+    if (ctx->valloc[b] >= ctx->verSlots) return IDKPT_OK;
+    DevBuf& buf = vb_buf(ctx, b);
+    const size_t need = ctx->vstride[b] * (size_t)ctx->verSlots;
+    if (buf.bytes < need) {
+        DevBuf nb; HIPC(nb.ensure(need));
+        if (buf.p && ctx->vbytes[b]) HIPC(hipMemcpyAsync(nb.p, vb_ptr(ctx, b, ctx->vcur[b]), ctx->vbytes[b], hipMemcpyDeviceToDevice, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));            // (the old allocation is released right below; one-time cost per scene)
+        buf.release(); buf = nb; ctx->vcur[b] = 0;
+    }
+    ctx->valloc[b] = ctx->verSlots;
+    return IDKPT_OK;
+}
+// Where an update may write buffer b: *dst = the slot to write, *src = the slot that holds the current state (== *dst when the update can go in place).
+// `full`: the update rewrites every byte of the buffer's state (nothing to carry over).  May launch queued samples / complete a deferred bounce when no slot is free.
+static int ver_writable(dev_ctx* ctx, int b, bool full, char** src, char** dst)
+{
+    const int p = ctx->vcur[b];
+    auto free_slot = [&](uint64_t busy) { if (ctx->verSlots > 1 && ctx->vbytes[b] > 0) for (int k = 0; k < ctx->verSlots; k++) if (!((busy >> k) & 1ull)) return k; return -1; };
+    uint64_t pend = 0; for (const PendingSample& ps : ctx->pending) pend |= 1ull << ps.vs[b];
+    const uint64_t held = ctx->defer.valid ? ctx->lastMask[b] : 0ull;                 // slots the deferred last bounce of the launched batch still reads
+    if (!(((pend | held) >> p) & 1ull)) { *src = *dst = vb_ptr(ctx, b, p); return IDKPT_OK; }
+    int q = free_slot(pend | held);
+    if (q < 0 && held && (!((pend >> p) & 1ull) || free_slot(pend) >= 0)) {
+        // no room, and completing the deferred bounce makes some (the current slot itself, or another one): cheaper than launching a short batch
+        int rc = finish_deferred(ctx); if (rc) return rc;
+        if (!((pend >> p) & 1ull)) { *src = *dst = vb_ptr(ctx, b, p); return IDKPT_OK; }
+        q = free_slot(pend);
+    }
+    if (q < 0) {
+        // every slot is pinned by queued samples: they are launched now (and the continuation they defer completed); the write is ordered behind them on the stream
+        int rc = flush_any(ctx); if (rc) return rc;
+        rc = finish_deferred(ctx); if (rc) return rc;
+        *src = *dst = vb_ptr(ctx, b, p);
+        return IDKPT_OK;
+    }
+    { int rc = ver_grow(ctx, b); if (rc) return rc; }
+    *src = vb_ptr(ctx, b, ctx->vcur[b]); *dst = vb_ptr(ctx, b, q);
+    if (!full) { HIPC(hipMemcpyAsync(*dst, *src, ctx->vbytes[b], hipMemcpyDeviceToDevice, ctx->stream)); *src = *dst; }
+    ctx->vcur[b] = q;
+    return IDKPT_OK;
+}
+// An update of something the render kernels read that is NOT versioned (materials, meshes, lights, settings ...): queued samples are launched first.
+// Small host -> device update without a stream synchronisation: the bytes are staged in a pinned ring (4 x 256 KB) the copy engine reads later.
+#define STAGE_BYTES (256u * 1024u)
+static int staged_upload(dev_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return IDKPT_OK;
+    if (bytes > STAGE_BYTES) { HIPC(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); return IDKPT_OK; }   // (host arrays are only borrowed for the duration of the call)
+    if (!ctx->hStage) { HIPC(hipHostMalloc((void**)&ctx->hStage, (size_t)4 * STAGE_BYTES, hipHostMallocDefault)); for (int i = 0; i < 4; i++) HIPC(hipEventCreateWithFlags(&ctx->evStage[i], hipEventDisableTiming)); ctx->stageNext = 0; for (int i = 0; i < 4; i++) HIPC(hipEventRecord(ctx->evStage[i], ctx->stream)); }
+    const int k = ctx->stageNext; ctx->stageNext = (k + 1) & 3;
+    HIPC(hipEventSynchronize(ctx->evStage[k]));                // the copy that last read this quarter has finished
+    memcpy(ctx->hStage + (size_t)k * STAGE_BYTES, src, bytes);
+    HIPC(hipMemcpyAsync(dst, ctx->hStage + (size_t)k * STAGE_BYTES, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipEventRecord(ctx->evStage[k], ctx->stream));
+    return IDKPT_OK;
+}
 
 // Rows a traversal stack needs for one BLAS: BLAS.ComputeRequiredStackSize (Bvh/BLAS.cs:672-702) evaluated bottom-up.  Requires what the
 // validation established first: every child pair lies behind its parent (acyclic), so one reverse sweep over the node array suffices.
@@ -308,7 +417,8 @@ static int derive_nodes(dev_ctx* ctx, int blasId)
     if (!ctx->layoutActive) return IDKPT_OK;
     const GpuBlasDesc& d = ctx->hDescs[blasId];
     const uint32_t pairs = (uint32_t)d.NodeCount / 2;
-    hipLaunchKernelGGL(k_derive_nodes, dim3((pairs + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->nodes.as<float4>(), (const uint32_t*)ctx->nodeSlot.as<uint32_t>(), ctx->tnodes.as<float4>(), (uint32_t)d.NodeOffset, pairs);
+    char *src, *dst; int rc = ver_writable(ctx, VB_TNODES, ctx->hDescs.size() == 1 && d.NodeOffset == 0 && d.NodeCount == ctx->nodeCount, &src, &dst); if (rc) return rc;
+    hipLaunchKernelGGL(k_derive_nodes, dim3((pairs + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)vb_cur<float4>(ctx, VB_NODES), (const uint32_t*)ctx->nodeSlot.as<uint32_t>(), (float4*)dst, (uint32_t)d.NodeOffset, pairs);
     HIPC(hipGetLastError());
     return IDKPT_OK;
 }
@@ -319,6 +429,7 @@ static int derive_nodes(dev_ctx* ctx, int blasId)
 static int rebuild_node_layout(dev_ctx* ctx, const GpuBlasNode* hostNodes)
 {
     ctx->layoutActive = false;
+    ctx->vbytes[VB_TNODES] = 0; ctx->vstride[VB_TNODES] = 0; ctx->valloc[VB_TNODES] = 1; ctx->vcur[VB_TNODES] = 0;   // (callers have launched / completed everything that read the old order)
     if (ctx->opt.nodeLayout == 0) { ctx->tnodes.release(); ctx->nodeSlot.release(); return IDKPT_OK; }
     const size_t pairsTotal = (size_t)ctx->nodeCount / 2;
     std::vector<std::pair<int, int>> ranges;
@@ -333,6 +444,7 @@ static int rebuild_node_layout(dev_ctx* ctx, const GpuBlasNode* hostNodes)
     HIPC(ctx->nodeSlot.ensure(slots.size() * 4)); HIPC(ctx->tnodes.ensure(std::max<size_t>((size_t)ctx->nodeCount * 32, 64)));
     HIPC(hipMemcpyAsync(ctx->nodeSlot.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ctx->layoutActive = true;
+    ctx->vbytes[VB_TNODES] = (size_t)ctx->nodeCount * 32; ctx->vstride[VB_TNODES] = (ctx->vbytes[VB_TNODES] + 255) / 256 * 256;
     for (int b = 0; b < (int)ctx->hDescs.size(); b++) { int rc = derive_nodes(ctx, b); if (rc) { ctx->layoutActive = false; return rc; } }
     HIPC(hipStreamSynchronize(ctx->stream));            // `slots` is a stack vector
     return IDKPT_OK;
@@ -388,7 +500,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -399,6 +511,10 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     if (ctx->hBases) (void)hipHostFree(ctx->hBases);
     if (ctx->hCams) (void)hipHostFree(ctx->hCams);
     for (int i = 0; i < 2; i++) if (ctx->evCams[i]) (void)hipEventDestroy(ctx->evCams[i]);
+    if (ctx->hVerTab) (void)hipHostFree(ctx->hVerTab);
+    for (int i = 0; i < 2; i++) if (ctx->evVer[i]) (void)hipEventDestroy(ctx->evVer[i]);
+    if (ctx->hStage) (void)hipHostFree(ctx->hStage);
+    for (int i = 0; i < 4; i++) if (ctx->evStage[i]) (void)hipEventDestroy(ctx->evStage[i]);
     if (ctx->evFrame[0]) (void)hipEventDestroy(ctx->evFrame[0]);
     if (ctx->evFrame[1]) (void)hipEventDestroy(ctx->evFrame[1]);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
@@ -507,10 +623,12 @@ static int32_t dev_SetPerFrame(dev_ctx* ctx, const float invProjection[16], cons
 }
 static int32_t dev_SetPerFrameData(dev_ctx* ctx, const GpuPerFrameData* p) { if (!ctx || !p) return IDKPT_ERR_INVALID_ARGUMENT; return dev_SetPerFrame(ctx, p->InvProjection, p->InvView, p->ViewPos); }
 
+// triVerts[first, first + count) from the current positions, into a slot queued samples do not read (ver_writable)
 static int regather_triverts(dev_ctx* ctx, uint32_t first, uint32_t count)
 {
     if (count == 0) return IDKPT_OK;
-    hipLaunchKernelGGL(k_gather_triverts, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, ctx->tris.as<uint4>(), ctx->positions.as<float>(), ctx->triVerts.as<float4>(), first, count);
+    char *src, *dst; int rc = ver_writable(ctx, VB_TRIVERTS, first == 0 && count == (uint32_t)ctx->triCount, &src, &dst); if (rc) return rc;
+    hipLaunchKernelGGL(k_gather_triverts, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, ctx->tris.as<uint4>(), ctx->positions.as<float>(), (float4*)dst, first, count);
     HIPC(hipGetLastError());
     return IDKPT_OK;
 }
@@ -525,13 +643,13 @@ static int upload(dev_ctx* ctx, DevBuf& b, const void* src, size_t bytes)
 // The fast path stores nothing but a flag for pre-culled pixels of the most recent sample; this completes their ray state (origin,
 // direction, miss radiance) from the frame constants of that batch.  Must run while the scene the batch was rendered with is still
 // resident (the sky decides the miss radiance): called by idkptDownloadRays and before a new scene replaces the old one.
-static DScene make_dscene(dev_ctx* ctx);
+static DScene make_dscene_last(dev_ctx* ctx);
 static int materialize_culled_rays(dev_ctx* ctx)
 {
     if (!ctx->lastNeedsRegen) return IDKPT_OK;
     const size_t N = (size_t)ctx->W * ctx->rows;
     RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
-    hipLaunchKernelGGL(k_regen_culled, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, make_dscene(ctx), ctx->lastFrame, rays, (const uint8_t*)ctx->contFlag.as<uint8_t>(), (uint32_t)(ctx->lastBatch - 1), (uint32_t)N);
+    hipLaunchKernelGGL(k_regen_culled, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, make_dscene_last(ctx), ctx->lastFrame, rays, (const uint8_t*)ctx->contFlag.as<uint8_t>(), (uint32_t)(ctx->lastBatch - 1), (uint32_t)N);
     HIPC(hipGetLastError());
     ctx->lastNeedsRegen = false;
     return IDKPT_OK;
@@ -611,8 +729,9 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     ctx->lightCount = sc->Lights ? sc->LightCount : 0; ctx->textureCount = sc->TextureCount;
     ctx->hDescs.assign(sc->BlasDescs, sc->BlasDescs + sc->BlasDescCount);
     ctx->sceneStack = maxStack; ctx->tlasNeed = std::max(1, tlasNeed);
+    ver_reset(ctx);                                   // one state per versioned buffer, in slot 0 (everything that read the old scene was launched by FLUSH above)
     // refit schedule: internal nodes of every refittable BLAS grouped by depth (children have larger ids than parents)
-    ctx->levelOffsets.assign(sc->BlasDescCount, {}); ctx->levelBase.assign(sc->BlasDescCount, 0);
+    ctx->levelOffsets.assign(sc->BlasDescCount, {}); ctx->levelBase.assign(sc->BlasDescCount, 0); ctx->refitCoversAll.assign(sc->BlasDescCount, 0);
     std::vector<int32_t> allLevels;
     for (int bi = 0; bi < sc->BlasDescCount; bi++) {
         const GpuBlasDesc& d = sc->BlasDescs[bi];
@@ -625,6 +744,7 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
         uint32_t off = 0;
         for (auto& l : lv) { ctx->levelOffsets[bi].push_back(off); off += (uint32_t)l.size(); allLevels.insert(allLevels.end(), l.begin(), l.end()); }
         ctx->levelOffsets[bi].push_back(off);
+        ctx->refitCoversAll[bi] = (int64_t)off + (int64_t)d.LeafIndicesCount == (int64_t)d.NodeCount - 1;
     }
     if ((rc = upload(ctx, ctx->levelNodes, allLevels.data(), allLevels.size() * 4))) return rc;
     if ((rc = regather_triverts(ctx, 0, (uint32_t)sc->BlasTriangleCount))) return rc;
@@ -679,8 +799,12 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
                    &src->materials, &src->xforms, &src->lights, &src->sky, &src->levelNodes};
     for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++) {
         if (!f[i]->p || f[i]->bytes == 0) continue;
-        HIPC(d[i]->ensure(f[i]->bytes));
-        HIPC(member_copy(ctx->peer, d[i]->p, ctx->device, f[i]->p, src->device, f[i]->bytes, ctx->stream));
+        // a versioned buffer of the source may be an arena of several states: its current one goes to slot 0 here
+        int vb = -1; for (int b = 0; b < VB_COUNT; b++) if (f[i] == &vb_buf(src, b)) vb = b;
+        const size_t bytes = (vb >= 0 && src->vbytes[vb] > 0) ? src->vbytes[vb] : f[i]->bytes;
+        const char* from = (vb >= 0 && src->vbytes[vb] > 0) ? vb_ptr(src, vb, src->vcur[vb]) : (const char*)f[i]->p;
+        HIPC(d[i]->ensure(bytes));
+        HIPC(member_copy(ctx->peer, d[i]->p, ctx->device, from, src->device, bytes, ctx->stream));
     }
     for (auto& t : ctx->texData) t.release();
     ctx->texData.clear(); ctx->texDims = src->texDims;
@@ -695,7 +819,8 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
     ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
     ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
-    ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase;
+    ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase; ctx->refitCoversAll = src->refitCoversAll;
+    ver_reset(ctx);
     HIPC(hipStreamSynchronize(ctx->stream));           // td is a stack vector
     ctx->haveScene = true;
     std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
@@ -710,17 +835,19 @@ static int32_t dev_SetLightCount(dev_ctx* ctx, int32_t count)
     ctx->lightCount = count; return IDKPT_OK;
 }
 
-static DevBuf* which_buffer(dev_ctx* ctx, int which, size_t* cap)
+// buffer id -> allocation, size of its state, and (versioned buffers) which arena it is (-1: a plain buffer)
+static DevBuf* which_buffer(dev_ctx* ctx, int which, size_t* cap, int* vb)
 {
+    *vb = -1;
     switch (which) {
-        case IDKPT_BUF_MESH_TRANSFORMS: *cap = (size_t)ctx->xformCount * sizeof(GpuMeshTransform); return &ctx->xforms;
+        case IDKPT_BUF_MESH_TRANSFORMS: *cap = (size_t)ctx->xformCount * sizeof(GpuMeshTransform); *vb = VB_XFORMS; return &ctx->xforms;
         case IDKPT_BUF_VERTEX_POSITIONS: *cap = (size_t)ctx->vertexCount * 12; return &ctx->positions;
-        case IDKPT_BUF_VERTICES: *cap = (size_t)ctx->vertexCount * 16; return &ctx->vertices;
+        case IDKPT_BUF_VERTICES: *cap = (size_t)ctx->vertexCount * 16; *vb = VB_VERTICES; return &ctx->vertices;
         case IDKPT_BUF_MESHES: *cap = (size_t)ctx->meshCount * sizeof(GpuMesh); return &ctx->meshes;
         case IDKPT_BUF_MATERIALS: *cap = (size_t)ctx->materialCount * sizeof(GpuMaterial); return &ctx->materials;
         case IDKPT_BUF_LIGHTS: *cap = (size_t)IDKPT_MAX_LIGHTS * sizeof(GpuLight); return &ctx->lights;
-        case IDKPT_BUF_BLAS_NODES: *cap = (size_t)ctx->nodeCount * 32; return &ctx->nodes;
-        case IDKPT_BUF_TLAS_NODES: *cap = (size_t)ctx->tlasCount * 32; return &ctx->tlas;
+        case IDKPT_BUF_BLAS_NODES: *cap = (size_t)ctx->nodeCount * 32; *vb = VB_NODES; return &ctx->nodes;
+        case IDKPT_BUF_TLAS_NODES: *cap = (size_t)ctx->tlasCount * 32; *vb = VB_TLAS; return &ctx->tlas;
         case IDKPT_BUF_JOINT_MATRICES: *cap = ctx->joints.bytes; return &ctx->joints;
         default: return nullptr;
     }
@@ -731,23 +858,28 @@ static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes,
     if (!ctx || !data) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptUpdateBuffer: no scene uploaded");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
-    if (which == IDKPT_BUF_JOINT_MATRICES) { size_t need = offsetBytes + bytes; if (need > ctx->joints.bytes) { DevBuf nb; HIPC(nb.ensure(need)); if (ctx->joints.p) { HIPC(hipMemcpyAsync(nb.p, ctx->joints.p, ctx->joints.bytes, hipMemcpyDeviceToDevice, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); } ctx->joints.release(); ctx->joints = nb; } }
-    size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
+    // What queued samples still have to read decides whether they are launched first: joint matrices and vertex positions are read by the update kernels only
+    // (k_skin, k_gather_triverts: they run in stream order, right now); transforms, vertices and tree nodes are versioned (ver_writable finds or makes room);
+    // meshes, materials and lights are read by the shading kernels of every queued sample.
+    if (which == IDKPT_BUF_MESHES || which == IDKPT_BUF_MATERIALS || which == IDKPT_BUF_LIGHTS || which == IDKPT_BUF_BLAS_NODES || which == IDKPT_BUF_TLAS_NODES) FLUSH();
+    if (which == IDKPT_BUF_JOINT_MATRICES) { size_t need = offsetBytes + bytes; if (need > ctx->joints.bytes) { DevBuf nb; HIPC(nb.ensure(need)); if (ctx->joints.p) { HIPC(hipMemcpyAsync(nb.p, ctx->joints.p, ctx->joints.bytes, hipMemcpyDeviceToDevice, ctx->stream)); } HIPC(hipStreamSynchronize(ctx->stream)); ctx->joints.release(); ctx->joints = nb; } }
+    size_t cap = 0; int vb = -1; DevBuf* b = which_buffer(ctx, which, &cap, &vb);
     REQUIRE(b != nullptr, "idkptUpdateBuffer: unknown buffer");
     REQUIRE(offsetBytes + bytes <= cap, "idkptUpdateBuffer: range exceeds buffer");
     if (which == IDKPT_BUF_BLAS_NODES || which == IDKPT_BUF_TLAS_NODES) {
         // Patched tree nodes are validated like uploaded ones BEFORE they reach the device (a bad child index must not fault the GPU, a deeper tree must
         // not overflow the traversal stack), on a host copy of the array with the patch applied; BLAS nodes: the derived order is rebuilt from that copy.
+        // The patch must leave a valid tree after EVERY call (idkpt.h): a host that streams a rebuilt tree in pieces uses idkptUploadScene / idkptBuildTlas.
+        char* cur = vb_ptr(ctx, vb, ctx->vcur[vb]);           // (nothing is queued or deferred any more: the patch goes in place)
         std::vector<char> h(cap);
-        HIPC(hipMemcpyAsync(h.data(), b->p, cap, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
+        HIPC(hipMemcpyAsync(h.data(), cur, cap, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
         memcpy(h.data() + offsetBytes, data, bytes);
         if (which == IDKPT_BUF_BLAS_NODES) {
             int maxStack = 1;
             const char* why = validate_blas_nodes((const GpuBlasNode*)h.data(), ctx->nodeCount, ctx->hDescs.data(), (int)ctx->hDescs.size(), ctx->triCount, false, &maxStack);
             REQUIRE(why == nullptr, std::string("idkptUpdateBuffer: ") + (why ? why : ""));
             REQUIRE(ctx->st.BlasStackSize == 0 || ctx->st.BlasStackSize >= maxStack, "idkptUpdateBuffer: the patched BLAS needs a deeper traversal stack than the BlasStackSize set with idkptSetSettings");
-            HIPC(hipMemcpyAsync((char*)b->p + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+            HIPC(hipMemcpyAsync(cur + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
             ctx->sceneStack = maxStack;
             int rc = rebuild_node_layout(ctx, (const GpuBlasNode*)h.data()); if (rc) return rc;
         } else {
@@ -755,16 +887,17 @@ static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes,
             const int need = tlas_validate((const GpuTlasNode*)h.data(), ctx->tlasCount, ctx->instanceCount, &why);
             REQUIRE(need >= 0, std::string("idkptUpdateBuffer: ") + (why ? why : "bad TLAS"));
             REQUIRE(need <= TLAS_STACK_SIZE, "idkptUpdateBuffer: TLAS deeper than TLAS_STACK_SIZE (32)");
-            HIPC(hipMemcpyAsync((char*)b->p + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+            HIPC(hipMemcpyAsync(cur + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
             ctx->tlasNeed = std::max(1, need);
         }
         HIPC(hipStreamSynchronize(ctx->stream));
         return IDKPT_OK;
     }
     if (which == IDKPT_BUF_MESHES || which == IDKPT_BUF_MATERIALS) ctx->sceneNoEmission = false;   // (a patched material may emit: decided again at the next idkptUploadScene)
-    HIPC(hipMemcpyAsync((char*)b->p + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    char* dst = (char*)b->p;
+    if (vb >= 0) { char* src; int rc = ver_writable(ctx, vb, offsetBytes == 0 && bytes == cap, &src, &dst); if (rc) return rc; }
+    { int rc = staged_upload(ctx, dst + offsetBytes, data, bytes); if (rc) return rc; }   // (small updates — joints, transforms — do not wait for the stream)
     if (which == IDKPT_BUF_VERTEX_POSITIONS) { int rc = regather_triverts(ctx, 0, (uint32_t)ctx->triCount); if (rc) return rc; }
-    HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
 }
 
@@ -815,7 +948,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
         else { REQUIRE(value >= 1 && value <= 16, "idkptSetDeveloperOption: treelet_depth is 1..16"); o.treeletDepth = value; }
         if (ctx->haveScene) {                               // re-derive the resident scene
             std::vector<GpuBlasNode> h((size_t)ctx->nodeCount);
-            HIPC(hipMemcpyAsync(h.data(), ctx->nodes.p, h.size() * 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
+            HIPC(hipMemcpyAsync(h.data(), vb_cur<char>(ctx, VB_NODES), h.size() * 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
             int rc = rebuild_node_layout(ctx, h.data()); if (rc) return rc;
         }
     }
@@ -826,11 +959,11 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
 static int32_t dev_DownloadBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst)
 {
     if (!ctx || !dst) return IDKPT_ERR_INVALID_ARGUMENT;
-    size_t cap = 0; DevBuf* b = which_buffer(ctx, which, &cap);
+    size_t cap = 0; int vb = -1; DevBuf* b = which_buffer(ctx, which, &cap, &vb);
     REQUIRE(b != nullptr && offsetBytes + bytes <= cap, "idkptDownloadBuffer: bad buffer/range");
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
-    HIPC(hipMemcpyAsync(dst, (char*)b->p + offsetBytes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(dst, (vb >= 0 ? vb_ptr(ctx, vb, ctx->vcur[vb]) : (char*)b->p) + offsetBytes, bytes, hipMemcpyDeviceToHost, ctx->stream));   // the current state
     HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
 }
@@ -844,8 +977,18 @@ static int32_t dev_BuildTlas(dev_ctx* ctx, const GpuTlasNode* nodes, int32_t nod
     REQUIRE(need >= 0, std::string("idkptBuildTlas: ") + (why ? why : "bad TLAS"));
     REQUIRE(need <= TLAS_STACK_SIZE, "idkptBuildTlas: TLAS deeper than TLAS_STACK_SIZE (32)");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
-    int rc = upload(ctx, ctx->tlas, nodes, (size_t)nodeCount * 32); if (rc) return rc;
+    if ((size_t)nodeCount * 32 > ctx->vbytes[VB_TLAS] || nodeCount != ctx->tlasCount) {
+        // another node count (or more nodes than a slot holds): every queued sample is launched first, then the TLAS buffer is laid out anew
+        FLUSH();
+        if ((size_t)nodeCount * 32 > ctx->vbytes[VB_TLAS]) {
+            HIPC(hipStreamSynchronize(ctx->stream));
+            ctx->tlas.release();
+            ctx->vbytes[VB_TLAS] = (size_t)nodeCount * 32; ctx->vstride[VB_TLAS] = (ctx->vbytes[VB_TLAS] + 255) / 256 * 256; ctx->valloc[VB_TLAS] = 1; ctx->vcur[VB_TLAS] = 0;
+            HIPC(ctx->tlas.ensure(ctx->vstride[VB_TLAS]));
+        }
+    }
+    char *src, *dst; int rc = ver_writable(ctx, VB_TLAS, true, &src, &dst); if (rc) return rc;
+    HIPC(hipMemcpyAsync(dst, nodes, (size_t)nodeCount * 32, hipMemcpyHostToDevice, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
     ctx->tlasCount = nodeCount; ctx->tlasNeed = std::max(1, need);
     return IDKPT_OK;
@@ -857,15 +1000,15 @@ static int32_t dev_BuildTlasOnDevice(dev_ctx* ctx, int32_t searchRadius)
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptBuildTlasOnDevice: no scene uploaded");
     REQUIRE(searchRadius >= 1, "idkptBuildTlasOnDevice: searchRadius must be >= 1 (reference: 15)");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
     const int n = ctx->instanceCount, nodeCount = 2 * n - 1;
-    HIPC(ctx->tlas.ensure((size_t)nodeCount * 32));
+    if (nodeCount != ctx->tlasCount) FLUSH();            // (queued samples were queued with another node count; a slot always has room for 2n - 1 nodes: ver_reset)
+    char *tsrc, *tdst; { int rc = ver_writable(ctx, VB_TLAS, true, &tsrc, &tdst); if (rc) return rc; }
     // scratch: temp nodes (2n-1) + leaves (n) as float4 pairs, keys (n), pref (n)
     const size_t tempOff = 0, leafOff = (size_t)nodeCount * 32, keyOff = leafOff + (size_t)n * 32, prefOff = keyOff + (size_t)n * 4;
     HIPC(ctx->tlasScratch.ensure(prefOff + (size_t)n * 4));
     char* sc = ctx->tlasScratch.as<char>();
-    hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(),
-                       ctx->xforms.as<float4>(), n, (int)searchRadius, ctx->tlas.as<float4>(), (float4*)(sc + tempOff), (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff));
+    hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, ctx->stream, (const float4*)vb_cur<float4>(ctx, VB_NODES), ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(),
+                       (const float4*)vb_cur<float4>(ctx, VB_XFORMS), n, (int)searchRadius, (float4*)tdst, (float4*)(sc + tempOff), (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff));
     HIPC(hipGetLastError());
     ctx->tlasCount = nodeCount; ctx->tlasNeed = std::min(TLAS_STACK_SIZE, std::max(1, n));   // depth unknown on the host: all rows a tree over n leaves can need, up to the limit (beyond it: overflow flag)
     return IDKPT_OK;
@@ -1400,15 +1543,20 @@ static int32_t dev_RefitBlas(dev_ctx* ctx, int32_t blasId)
     const GpuBlasDesc& d = ctx->hDescs[blasId];
     if (!d.IsRefittable || d.LeafIndicesCount == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptRefitBlas: BLAS is not refittable (no leaf/parent indices)");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
+    // (no launch of the queued samples: the triangle records and the nodes are rewritten in slots they do not read, ver_writable)
     int rc = regather_triverts(ctx, (uint32_t)d.TriangleOffset, (uint32_t)d.TriangleCount); if (rc) return rc;
-    hipLaunchKernelGGL(k_refit_leaves, dim3((d.LeafIndicesCount + 63) / 64), dim3(64), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->tris.as<uint4>(), ctx->triVerts.as<float4>(),
+    // The refit writes every node of this BLAS but its unused node 0 (leaves, then the internal nodes level by level); topology words (.w) are read from the
+    // state being replaced, child boxes from the state being written.  A scene that is this one BLAS needs no copy of the old state (node 0 aside).
+    const bool whole = ctx->hDescs.size() == 1 && d.NodeOffset == 0 && d.NodeCount == ctx->nodeCount && ctx->refitCoversAll[blasId];
+    char *nsrc, *ndst; rc = ver_writable(ctx, VB_NODES, whole, &nsrc, &ndst); if (rc) return rc;
+    if (whole && nsrc != ndst) HIPC(hipMemcpyAsync(ndst, nsrc, 32, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_refit_leaves, dim3((d.LeafIndicesCount + 63) / 64), dim3(64), 0, ctx->stream, (const float4*)nsrc, (float4*)ndst, ctx->tris.as<uint4>(), (const float4*)vb_cur<float4>(ctx, VB_TRIVERTS),
                        ctx->leaves.as<int32_t>() + d.LeafIndicesOffset, (uint32_t)d.LeafIndicesCount, (uint32_t)d.NodeOffset, (uint32_t)d.TriangleOffset);
     const std::vector<uint32_t>& off = ctx->levelOffsets[blasId];
     for (int l = (int)off.size() - 2; l >= 0; l--) {
         uint32_t cnt = off[l + 1] - off[l];
         if (!cnt) continue;
-        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, ctx->nodes.as<float4>(), ctx->levelNodes.as<int32_t>() + ctx->levelBase[blasId] + off[l], cnt, (uint32_t)d.NodeOffset);
+        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, (const float4*)nsrc, (float4*)ndst, ctx->levelNodes.as<int32_t>() + ctx->levelBase[blasId] + off[l], cnt, (uint32_t)d.NodeOffset);
     }
     HIPC(hipGetLastError());
     return derive_nodes(ctx, blasId);          // the refitted boxes, in the order the traversal fetches them
@@ -1430,10 +1578,11 @@ static int32_t dev_Skin(dev_ctx* ctx, uint32_t inOff, uint32_t outOff, uint32_t 
     if (!ctx->haveScene || ctx->unskinnedCount == 0 || ctx->joints.bytes == 0) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptSkin: needs scene, unskinned vertices and joint matrices");
     REQUIRE((uint64_t)inOff + count <= (uint64_t)ctx->unskinnedCount && (uint64_t)outOff + count <= (uint64_t)ctx->vertexCount, "idkptSkin: range out of bounds");
     HIPC(hipSetDevice(ctx->device));
-    FLUSH();
     HIPC(ctx->prevPositions.ensure((size_t)ctx->vertexCount * 12));
+    // positions are read by update kernels only (stream order); the re-compressed normals / tangents go to a vertex slot no queued sample reads (ver_writable)
+    char *vsrc, *vdst; { int rc = ver_writable(ctx, VB_VERTICES, outOff == 0 && count == (uint32_t)ctx->vertexCount, &vsrc, &vdst); if (rc) return rc; }
     if (count) hipLaunchKernelGGL(k_skin, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, ctx->unskinned.as<GpuUnskinnedVertex>(), ctx->joints.as<float4>(), ctx->positions.as<float>(),
-                                  ctx->prevPositions.as<float>(), ctx->vertices.as<uint4>(), inOff, outOff, jointOff, count);
+                                  ctx->prevPositions.as<float>(), (const uint4*)vsrc, (uint4*)vdst, inOff, outOff, jointOff, count);
     HIPC(hipGetLastError());
     return IDKPT_OK;
 }
@@ -1454,18 +1603,24 @@ static int32_t dev_SetSampleSequence(dev_ctx* ctx, uint32_t first, uint32_t stri
 }
 static int32_t dev_GetAccumulatedSamples(dev_ctx* ctx, uint32_t* out) { if (!ctx || !out) return IDKPT_ERR_INVALID_ARGUMENT; *out = ctx->accum[ctx->curSlot]; return IDKPT_OK; }
 
-static DScene make_dscene(dev_ctx* ctx)
+// slots: which state of every versioned buffer the kernels read (null: the current one); multi: the batch's samples saw different states -> the pointers are the
+// arena bases and DScene::ver holds every sample's offsets (VER kernels)
+static DScene make_dscene(dev_ctx* ctx, const uint8_t* slots, bool multi)
 {
     DScene s;
-    s.nodes = ctx->nodes.as<float4>(); s.tnodes = ctx->layoutActive ? ctx->tnodes.as<float4>() : ctx->nodes.as<float4>(); s.tris = ctx->tris.as<uint4>(); s.triVerts = ctx->triVerts.as<float4>();
+    auto at = [&](int b) -> char* { return multi ? (char*)vb_buf(ctx, b).p : vb_ptr(ctx, b, slots ? slots[b] : ctx->vcur[b]); };
+    s.nodes = (const float4*)at(VB_NODES); s.tnodes = ctx->layoutActive ? (const float4*)at(VB_TNODES) : s.nodes; s.tris = ctx->tris.as<uint4>(); s.triVerts = (const float4*)at(VB_TRIVERTS);
     s.descs = ctx->descs.as<GpuBlasDesc>(); s.instances = ctx->instances.as<GpuBlasInstance>(); s.instanceCount = ctx->instanceCount;
-    s.tlas = ctx->tlas.as<float4>(); s.tlasCount = ctx->tlasCount; s.vertices = ctx->vertices.as<uint4>();
-    s.meshes = ctx->meshes.as<GpuMesh>(); s.materials = ctx->materials.as<GpuMaterial>(); s.xforms = ctx->xforms.as<float4>();
+    s.tlas = (const float4*)at(VB_TLAS); s.tlasCount = ctx->tlasCount; s.vertices = (const uint4*)at(VB_VERTICES);
+    s.meshes = ctx->meshes.as<GpuMesh>(); s.materials = ctx->materials.as<GpuMaterial>(); s.xforms = (const float4*)at(VB_XFORMS);
     s.lights = ctx->lights.as<GpuLight>(); s.lightCount = ctx->lightCount; s.sky = ctx->sky.as<float4>(); s.skySize = ctx->skySize;
     s.textures = ctx->texDescs.as<TexDesc>(); s.textureCount = ctx->textureCount;
     s.overflow = ctx->dOverflow;
+    s.ver = multi ? ctx->verTab.as<uint32_t>() : nullptr;
     return s;
 }
+static DScene make_dscene(dev_ctx* ctx) { return make_dscene(ctx, nullptr, false); }
+static DScene make_dscene_last(dev_ctx* ctx) { return make_dscene(ctx, ctx->lastSlots, ctx->lastMulti); }   // what the last launched batch read (finish_deferred, regeneration of culled rays)
 
 static float4* image_ptr(dev_ctx* ctx, int i, int slot) { return ctx->img[i].as<float4>() + (size_t)slot * ((size_t)ctx->W * ctx->rows); }
 
@@ -1508,7 +1663,8 @@ static int finish_deferred(dev_ctx* ctx)
     const int j = ctx->defer.j, side = ctx->defer.side, B = ctx->defer.B, BS = MAX_BATCH + 1;
     const uint32_t total = ctx->defer.total, Npad = ctx->defer.Npad, gridTotal = (total + 255) / 256;
     const Frame f = ctx->lastFrame;
-    DScene s = make_dscene(ctx);
+    DScene s = make_dscene_last(ctx);                                // the scene states the deferred batch was traced with (its slots are pinned until now: ver_writable)
+    const bool multiVer = ctx->lastMulti;
     RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
     HitBufs hits = {ctx->hit.as<float4>(), ctx->hitCost.as<float>()};
     TraceBufs tr = {ctx->trRec.as<float4>(), nullptr, nullptr};
@@ -1520,7 +1676,8 @@ static int finish_deferred(dev_ctx* ctx)
     const uint32_t* cnt = ctx->deferCount.as<uint32_t>();            // (counts[j] itself was reset by the batch's last kernel)
     if (ctx->defer.allHits) hipLaunchKernelGGL((k_restore_last<true>), dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>());
     else hipLaunchKernelGGL((k_restore_last<false>), dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>());
-    hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, q, cnt, 0u, (const uint32_t*)(bases + j * BS), (const uint32_t*)nullptr, contMask, waveLocal, keysTmp);
+    if (multiVer) hipLaunchKernelGGL((k_shade<false, true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, q, cnt, 0u, (const uint32_t*)(bases + j * BS), (const uint32_t*)nullptr, contMask, waveLocal, keysTmp);
+    else hipLaunchKernelGGL((k_shade<false, false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, q, cnt, 0u, (const uint32_t*)(bases + j * BS), (const uint32_t*)nullptr, contMask, waveLocal, keysTmp);
     hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, cnt, 0u, blockSums, (const uint32_t*)waveLocal, counts + j + 1, (unsigned long long*)nullptr,
                        (const unsigned long long*)contMask, (const uint32_t*)(bases + j * BS), Npad, B, bases + (j + 1) * BS,
@@ -1541,7 +1698,31 @@ static int flush_batch(dev_ctx* ctx)
     const uint32_t N = (uint32_t)((size_t)ctx->W * ctx->rows);
     const uint32_t Npad = ctx->Npad;
     const uint32_t total = (uint32_t)B * Npad;
-    DScene s = make_dscene(ctx);
+    // which state of the geometry every sample sees (scene versions): one for all -> plain pointers; else a per-sample table of offsets into the arenas (VER kernels)
+    bool multiVer = false;
+    for (int k = 1; k < B && !multiVer; k++) multiVer = memcmp(ctx->pending[k].vs, ctx->pending[0].vs, VB_COUNT) != 0;
+    for (int b = 0; b < VB_COUNT; b++) { uint64_t m = 0; for (int k = 0; k < B; k++) m |= 1ull << ctx->pending[k].vs[b]; ctx->lastMask[b] = m; ctx->lastSlots[b] = ctx->pending[0].vs[b]; }
+    ctx->lastMulti = multiVer;
+    if (multiVer) {
+        if (!ctx->hVerTab) {
+            HIPC(hipHostMalloc((void**)&ctx->hVerTab, (size_t)2 * MAX_BATCH * SCENE_VER_WORDS * 4, hipHostMallocDefault));
+            for (int i = 0; i < 2; i++) HIPC(hipEventCreateWithFlags(&ctx->evVer[i], hipEventDisableTiming));
+            ctx->verHalf = 0;
+        } else HIPC(hipEventSynchronize(ctx->evVer[ctx->verHalf]));          // the copy that last read this half has finished
+        uint32_t* stage = ctx->hVerTab + (size_t)ctx->verHalf * MAX_BATCH * SCENE_VER_WORDS;
+        for (int k = 0; k < B; k++) {
+            const uint8_t* vs = ctx->pending[k].vs;
+            uint32_t* row = stage + (size_t)k * SCENE_VER_WORDS;
+            for (int b = 0; b < VB_COUNT; b++) row[b] = (uint32_t)(((size_t)vs[b] * ctx->vstride[b]) / 16);   // 16-byte units
+            if (!ctx->layoutActive) row[VB_TNODES] = row[VB_NODES];
+            row[6] = row[7] = 0u;
+        }
+        HIPC(ctx->verTab.ensure((size_t)MAX_BATCH * SCENE_VER_WORDS * 4));
+        HIPC(hipMemcpyAsync(ctx->verTab.p, stage, (size_t)B * SCENE_VER_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipEventRecord(ctx->evVer[ctx->verHalf], ctx->stream));
+        ctx->verHalf ^= 1;
+    }
+    DScene s = make_dscene_last(ctx);
     Frame f;
     memcpy(f.invProj, ctx->pending[0].cam, 64); memcpy(f.invView, ctx->pending[0].cam + 16, 64); memcpy(f.viewPos, ctx->pending[0].cam + 32, 12);   // the camera the samples were queued with
     f.W = ctx->W; f.H = ctx->H; f.rowMod = ctx->rowMod; f.rowRem = ctx->rowRem; f.rows = ctx->rows; f.rowBandLog2 = ctx->rowBandLog2;
@@ -1568,6 +1749,7 @@ static int flush_batch(dev_ctx* ctx)
         ctx->camHalf ^= 1;
         f.cams = ctx->camTab.as<float>();
     }
+    f.tilePerSample = (f.cams != nullptr || multiVer) ? 1 : 0;
     RayBufs rays = {ctx->rayO.as<float4>(), ctx->rayT.as<float4>(), ctx->rayR.as<float4>(), ctx->aovA.as<float4>(), ctx->aovN.as<float4>()};
     HitBufs hits = {ctx->hit.as<float4>(), ctx->hitCost.as<float>()};
     uint32_t* counts = ctx->counts.as<uint32_t>();
@@ -1605,7 +1787,7 @@ static int flush_batch(dev_ctx* ctx)
     const bool debug = f.g.DoDebugBVHTraversal != 0;
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);
-    if (!fast && B != 1) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
+    if (!fast && (B != 1 || multiVer)) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
     unsigned long long* contMask = ctx->contMask.as<unsigned long long>();
     uint32_t* waveCounts = ctx->waveCounts.as<uint32_t>();
     const int BS = MAX_BATCH + 1;
@@ -1631,19 +1813,22 @@ static int flush_batch(dev_ctx* ctx)
             if (ctx->capturePrimary) hipLaunchKernelGGL(k_fill_miss, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N);
             tileClass = nullptr;
             if (cull && !ctx->opt.noTileCull) {   // sample-independent pre-classification of the 8x8 tiles (conservative whole-tile miss test)
-                const uint32_t classSets = f.cams ? (uint32_t)B : 1u;       // one classification per camera
+                const uint32_t classSets = f.tilePerSample ? (uint32_t)B : 1u;       // one classification per camera / scene version
                 HIPC(ctx->tileClass.ensure((size_t)genWaves * classSets));
-                hipLaunchKernelGGL(k_classify_tiles, dim3((genWaves + 255) / 256, classSets), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
+                if (multiVer) hipLaunchKernelGGL((k_classify_tiles<true>), dim3((genWaves + 255) / 256, classSets), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
+                else hipLaunchKernelGGL((k_classify_tiles<false>), dim3((genWaves + 255) / 256, classSets), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
                 tileClass = ctx->tileClass.as<uint8_t>();
             }
-            hipLaunchKernelGGL(k_gen_primary, dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
+            if (multiVer) hipLaunchKernelGGL((k_gen_primary<true>), dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
+            else hipLaunchKernelGGL((k_gen_primary<false>), dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
             TRACE_T0();
             uint32_t grid0 = traceGrid;
             if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4, midGrid);
             launch_trace2<true>(ctx, grid0, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
-            hipLaunchKernelGGL(k_shade_first, dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
+            if (multiVer) hipLaunchKernelGGL((k_shade_first<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
+            else hipLaunchKernelGGL((k_shade_first<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
             hipLaunchKernelGGL((k_scan_local<true>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)ctx->contFlag.as<uint8_t>(), contMask, waveLocal, blockSums);
         } else {
             TRACE_T0();
@@ -1652,7 +1837,7 @@ static int flush_batch(dev_ctx* ctx)
             else { if (debug) hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); else hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(g), dim3(WAVE), ldsBytes, st, s, f, rays, hits, N, work + 0, counters); }
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)0, N, ctx->primHit.as<float4>()); }
-            hipLaunchKernelGGL((k_shade<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, trNone, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+            hipLaunchKernelGGL((k_shade<true, false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, trNone, hits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, total, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                                contMask, waveCounts, keysTmp);
             hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
         }
@@ -1739,13 +1924,15 @@ static int flush_batch(dev_ctx* ctx)
         if (deferLast && j == depth - 1 && gbase == nullptr) {
             // the last bounce: only its radiance is visible in the frame (kernels_shade.hpp k_shade_last); state, queue and counts follow on demand (finish_deferred)
             HIPC(ctx->radSave.ensure((size_t)ctx->maxBatch * ctx->Npad * 16)); HIPC(ctx->deferCount.ensure(64));
-            if (deferAllHits) hipLaunchKernelGGL((k_shade_last<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, (const uint32_t*)(bases + j * BS), ctx->radSave.as<float4>(), ctx->deferCount.as<uint32_t>());
-            else hipLaunchKernelGGL((k_shade_last<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, (const uint32_t*)(bases + j * BS), ctx->radSave.as<float4>(), ctx->deferCount.as<uint32_t>());
+#define SHADE_LAST(A, V) hipLaunchKernelGGL((k_shade_last<A, V>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, hits, (const uint32_t*)q, cnt, (const uint32_t*)(bases + j * BS), ctx->radSave.as<float4>(), ctx->deferCount.as<uint32_t>())
+            if (deferAllHits) { if (multiVer) SHADE_LAST(true, true); else SHADE_LAST(true, false); }
+            else SHADE_LAST(false, false);                              // (misses only: the sky is not versioned)
+#undef SHADE_LAST
             ctx->defer.allHits = deferAllHits; ctx->defer.valid = true; ctx->defer.j = j; ctx->defer.side = side; ctx->defer.B = B; ctx->defer.total = total; ctx->defer.Npad = Npad;
             break;
         }
-        hipLaunchKernelGGL((k_shade<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, fast ? tr : trNone, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), gbase,
-                           contMask, waveCounts, keysTmp);
+        if (multiVer) hipLaunchKernelGGL((k_shade<false, true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, fast ? tr : trNone, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), gbase, contMask, waveCounts, keysTmp);
+        else hipLaunchKernelGGL((k_shade<false, false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, fast ? tr : trNone, hits, (const uint32_t*)q, cnt, 0u, (const uint32_t*)(bases + j * BS), gbase, contMask, waveCounts, keysTmp);
         hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, cnt, 0u, blockSums, (const uint32_t*)waveLocal, counts + j + 1, (unsigned long long*)(j + 1 < depth ? counters + 2 : nullptr),
                            (const unsigned long long*)contMask, (const uint32_t*)(bases + j * BS), Npad, B, bases + (j + 1) * BS,
@@ -1800,6 +1987,7 @@ static int32_t dev_Render(dev_ctx* ctx)
     for (int i = 0; i < ctx->st.SamplesPerPixel; i++) {
         PendingSample ps; ps.accum = ctx->accum[ctx->curSlot]++; ps.slot = ctx->curSlot;
         memcpy(ps.cam, ctx->invProj, 64); memcpy(ps.cam + 16, ctx->invView, 64); memcpy(ps.cam + 32, ctx->viewPos, 12); ps.cam[35] = 0.0f;
+        for (int b = 0; b < VB_COUNT; b++) ps.vs[b] = (uint8_t)ctx->vcur[b];           // the state of the geometry this sample sees
         ctx->pending.push_back(ps);
         if (!ctx->grouped && (int)ctx->pending.size() >= limit) { int rc = flush_batch(ctx); if (rc) return rc; }   // (members of a multi-device context: the group launches)
     }
@@ -1832,6 +2020,25 @@ static int32_t dev_SetMaxBatch(dev_ctx* ctx, int32_t maxBatch)
         }
         ctx->accum = acc; ctx->curSlot = slot; ctx->ringStarted = started;
     }
+    return IDKPT_OK;
+}
+
+// idkptSetSceneVersions: how many states of the geometry may be in flight (1: a scene update launches every queued sample first, as the reference's frame loop does)
+static int32_t dev_SetSceneVersions(dev_ctx* ctx, int32_t versions)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    REQUIRE(versions >= 1 && versions <= 64, "idkptSetSceneVersions: 1..64 versions");
+    HIPC(hipSetDevice(ctx->device));
+    if (versions == ctx->verSlots) return IDKPT_OK;
+    FLUSH();                                                           // nothing queued or deferred: every buffer has exactly one live state, its current one
+    if (versions < ctx->verSlots) {
+        for (int b = 0; b < VB_COUNT; b++) {
+            if (ctx->vcur[b] >= versions && ctx->vbytes[b] > 0) { HIPC(hipMemcpyAsync(vb_ptr(ctx, b, 0), vb_ptr(ctx, b, ctx->vcur[b]), ctx->vbytes[b], hipMemcpyDeviceToDevice, ctx->stream)); ctx->vcur[b] = 0; }
+            ctx->valloc[b] = std::min(ctx->valloc[b], versions);
+        }
+        HIPC(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->verSlots = versions;
     return IDKPT_OK;
 }
 

@@ -84,6 +84,10 @@ static int group_exchange(void* user, dev_ctx* m, int bounce, int samples, const
     return IDKPT_OK;
 }
 
+static int group_flush(idkpt_ctx* c);
+// what a member calls when a scene update finds no free scene-version slot (ver_writable, idkpt.hip): the whole group launches what it has queued
+static int group_flush_all(void* user) { return group_flush((idkpt_ctx*)user); }
+
 // launches what the members have queued.  Members are enqueued in row order, so a member only ever waits for members enqueued before it.
 static int group_flush(idkpt_ctx* c)
 {
@@ -251,7 +255,7 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
             ok = hipSetDevice(m->device) == hipSuccess;
             for (int j = 0; j < MAX_DEPTH_SLOTS && ok; j++) ok = hipEventCreateWithFlags(&c->evBounce[d][j], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&c->evFlushDone[d], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->evGather[d], hipEventDisableTiming) == hipSuccess;
-            m->grouped = true; m->groupIndex = d; m->evBounce = c->evBounce[d].data(); m->groupExchange = group_exchange; m->groupUser = c; m->peer = &c->peer;
+            m->grouped = true; m->groupIndex = d; m->evBounce = c->evBounce[d].data(); m->groupExchange = group_exchange; m->groupUser = c; m->peer = &c->peer; m->groupFlushAll = group_flush_all;
             // direct xGMI access between the members' devices (copies work without it through staging; a refusal is not an error)
             for (int d2 = 0; d2 < n; d2++) if (c->dev[d2]->device != m->device) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->device, c->dev[d2]->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(c->dev[d2]->device, 0); (void)hipGetLastError(); }
         }
@@ -376,7 +380,12 @@ int32_t idkptUploadScene(idkpt_ctx* c, const idkpt_scene_desc* scene)
     return IDKPT_OK;
 }
 #define REPLICATE(name, ...) do { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; ONE(dev_##name(m, ##__VA_ARGS__)); GFLUSH(); ALL(dev_##name(m, ##__VA_ARGS__)); return IDKPT_OK; } while (0)
-int32_t idkptUpdateBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, const void* data) { REPLICATE(UpdateBuffer, which, offsetBytes, bytes, data); }
+// Scene updates that the members apply through their scene-version slots (idkptSetSceneVersions): the group does NOT launch what is queued first — every member
+// finds or makes room itself (ver_writable) and, when it cannot, launches the whole group through group_flush_all.  All members hold the same queue and the same
+// version state (every call is replicated), so they take the same decisions.
+#define REPLICATE_VERSIONED(name, ...) do { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; ONE(dev_##name(m, ##__VA_ARGS__)); ALL(dev_##name(m, ##__VA_ARGS__)); return IDKPT_OK; } while (0)
+int32_t idkptUpdateBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, const void* data) { REPLICATE_VERSIONED(UpdateBuffer, which, offsetBytes, bytes, data); }
+int32_t idkptSetSceneVersions(idkpt_ctx* c, int32_t versions) { REPLICATE(SetSceneVersions, versions); }
 int32_t idkptSetLightCount(idkpt_ctx* c, int32_t count) { REPLICATE(SetLightCount, count); }
 int32_t idkptSetDeveloperOption(idkpt_ctx* c, const char* name, int32_t value)
 {
@@ -384,9 +393,9 @@ int32_t idkptSetDeveloperOption(idkpt_ctx* c, const char* name, int32_t value)
     if (c->n() > 1 && std::string(name) == "force_no_peer") { GFLUSH(); c->peer.forceStaged = value != 0; return IDKPT_OK; }   // device-to-device copies through pinned host memory
     REPLICATE(SetOption, name, value);
 }
-int32_t idkptBuildTlas(idkpt_ctx* c, const GpuTlasNode* nodes, int32_t nodeCount) { REPLICATE(BuildTlas, nodes, nodeCount); }
-int32_t idkptBuildTlasOnDevice(idkpt_ctx* c, int32_t searchRadius) { REPLICATE(BuildTlasOnDevice, searchRadius); }      // every member rebuilds its own copy (0.1 ms; cheaper than shipping it)
-int32_t idkptRefitBlas(idkpt_ctx* c, int32_t blasId) { REPLICATE(RefitBlas, blasId); }
+int32_t idkptBuildTlas(idkpt_ctx* c, const GpuTlasNode* nodes, int32_t nodeCount) { REPLICATE_VERSIONED(BuildTlas, nodes, nodeCount); }
+int32_t idkptBuildTlasOnDevice(idkpt_ctx* c, int32_t searchRadius) { REPLICATE_VERSIONED(BuildTlasOnDevice, searchRadius); }      // every member rebuilds its own copy (0.1 ms; cheaper than shipping it)
+int32_t idkptRefitBlas(idkpt_ctx* c, int32_t blasId) { REPLICATE_VERSIONED(RefitBlas, blasId); }
 int32_t idkptBuildBlasCore(idkpt_ctx* c, const float* fragmentBoxes, int32_t fragmentCount, GpuBlasNode* outNodes, int32_t* outSortedIdsX, int32_t* outLevels)
 {
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
@@ -410,7 +419,7 @@ int32_t idkptBuildBlasFetch(idkpt_ctx* c, GpuBlasNode* outNodes, GpuBlasTriangle
 }
 int32_t idkptCbrtProbe(idkpt_ctx* c, const float* in, float* out, int32_t n) { if (!c) return IDKPT_ERR_INVALID_ARGUMENT; dev_ctx* m = c->dev[0]; const int rc = dev_CbrtProbe(m, in, out, n); return rc ? mfail(c, m, rc) : IDKPT_OK; }
 int32_t idkptUploadUnskinnedVertices(idkpt_ctx* c, const GpuUnskinnedVertex* verts, int32_t count) { REPLICATE(UploadUnskinnedVertices, verts, count); }
-int32_t idkptSkin(idkpt_ctx* c, uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count) { REPLICATE(Skin, inOff, outOff, jointOff, count); }
+int32_t idkptSkin(idkpt_ctx* c, uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count) { REPLICATE_VERSIONED(Skin, inOff, outOff, jointOff, count); }
 int32_t idkptDownloadBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, void* dst)
 {
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_final_draw(DScene s, Frame f, RayBufs r
     if (f.outputAovs) { float4 oa = imgAlbedo[(size_t)slot * N + i], on = imgNormal[(size_t)slot * N + i]; ra = mk3(oa.x, oa.y, oa.z); rn = mk3(on.x, on.y, on.z); }
     const uint32_t px = i % (uint32_t)f.W, py = i / (uint32_t)f.W, tilesX = ((uint32_t)f.W + 7) / 8;
     const uint32_t tile = (py >> 3) * tilesX + (px >> 3), nTilesAll = tilesX * (((uint32_t)f.rows + 7) / 8);
-    const uint32_t sharedCls = (tileClass && !f.cams) ? tileClass[tile] : 0u;   // one camera for the whole batch: one lookup
+    const uint32_t sharedCls = (tileClass && !f.tilePerSample) ? tileClass[tile] : 0u;   // one camera and one scene version for the whole batch: one lookup
     for (int k = 0; k < f.batch; k++) {
         if (f.slotOf[k] != slot) {                       // next frame of the ring: store, switch, load
             imgResult[(size_t)slot * N + i] = make_float4(r.x, r.y, r.z, 1.0f);
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_final_draw(DScene s, Frame f, RayBufs r
         const size_t rid = (size_t)k * f.Npad + i;
         float w = 1.0f / ((float)f.accum[k] + 1.0f);
         // pixels of a pre-classified tile (k_classify_tiles): the radiance is the known sky colour of the class; nothing was stored per sample
-        const uint32_t cls = !tileClass ? 0u : (f.cams ? tileClass[(size_t)k * nTilesAll + tile] : sharedCls);   // one class per camera
+        const uint32_t cls = !tileClass ? 0u : (f.tilePerSample ? tileClass[(size_t)k * nTilesAll + tile] : sharedCls);   // one class per camera / scene version
         f3 nr = splat3(0.0f);
         if (cls == 0u) { float4 c = rays.rad_py[rid]; nr = mk3(c.x, c.y, c.z); }
         else if (cls <= 6u) { const float4 p = s.sky[cls - 1u]; nr = splat3(0.0f) + mk3(p.x, p.y, p.z) * splat3(1.0f); }

@@ -143,12 +143,13 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4*
 // BLAS refit (Shaders/BLASRefit/compute.glsl).  The reference walks leaf->root inside one dispatch behind an
 // atomicExchange "second arrival" lock; here the same unions are evaluated level by level (deepest first), one launch
 // per level, so no workgroup ever consumes another workgroup's stores inside a launch (per-XCD L2s are not coherent).
-__global__ void k_refit_leaves(float4* nodes, const uint4* tris, const float4* triVerts, const int32_t* leafIds, uint32_t leafCount, uint32_t nodeOffset, uint32_t triOffset)
+// (src: the node array being replaced — topology words; nodes: the array being written — the same array unless the refit goes to another scene-version slot)
+__global__ void k_refit_leaves(const float4* src, float4* nodes, const uint4* tris, const float4* triVerts, const int32_t* leafIds, uint32_t leafCount, uint32_t nodeOffset, uint32_t triOffset)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= leafCount) return;
     uint32_t id = nodeOffset + (uint32_t)leafIds[i];
-    float4 mn = nodes[2 * (size_t)id], mx = nodes[2 * (size_t)id + 1];
+    float4 mn = src[2 * (size_t)id], mx = src[2 * (size_t)id + 1];
     uint32_t start = triOffset + __float_as_uint(mn.w), count = __float_as_uint(mx.w);
     f3 bmin = splat3(PT_FLOAT_MAX), bmax = splat3(-PT_FLOAT_MAX);
     for (uint32_t k = start; k < start + count; k++) {
@@ -156,12 +157,12 @@ __global__ void k_refit_leaves(float4* nodes, const uint4* tris, const float4* t
     }
     nodes[2 * (size_t)id] = make_float4(bmin.x, bmin.y, bmin.z, mn.w); nodes[2 * (size_t)id + 1] = make_float4(bmax.x, bmax.y, bmax.z, mx.w);
 }
-__global__ void k_refit_level(float4* nodes, const int32_t* levelNodes, uint32_t count, uint32_t nodeOffset)
+__global__ void k_refit_level(const float4* src, float4* nodes, const int32_t* levelNodes, uint32_t count, uint32_t nodeOffset)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     uint32_t id = nodeOffset + (uint32_t)levelNodes[i];
-    float4 mn = nodes[2 * (size_t)id], mx = nodes[2 * (size_t)id + 1];
+    float4 mn = src[2 * (size_t)id], mx = src[2 * (size_t)id + 1];
     uint32_t child = nodeOffset + __float_as_uint(mn.w);
     float4 lmn = nodes[2 * (size_t)child], lmx = nodes[2 * (size_t)child + 1], rmn = nodes[2 * (size_t)child + 2], rmx = nodes[2 * (size_t)child + 3];
     nodes[2 * (size_t)id] = make_float4(gmin(lmn.x, rmn.x), gmin(lmn.y, rmn.y), gmin(lmn.z, rmn.z), mn.w);
@@ -169,7 +170,8 @@ __global__ void k_refit_level(float4* nodes, const int32_t* levelNodes, uint32_t
 }
 
 // Skinning (Shaders/Skinning/compute.glsl:14-47): 4-weight linear blend; joint matrices are row_major mat4x3 (3 x float4)
-__global__ void k_skin(const GpuUnskinnedVertex* unskinned, const float4* joints, float* positions, float* prevPositions, uint4* vertices,
+// (verticesIn: the vertex array being replaced — the uv words; vertices: the one being written; the same array unless the skinning goes to another scene-version slot)
+__global__ void k_skin(const GpuUnskinnedVertex* unskinned, const float4* joints, float* positions, float* prevPositions, const uint4* verticesIn, uint4* vertices,
                        uint32_t inOff, uint32_t outOff, uint32_t jointOff, uint32_t count)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,5 +195,5 @@ __global__ void k_skin(const GpuUnskinnedVertex* unskinned, const float4* joints
     size_t o = (size_t)(outOff + i);
     if (prevPositions) { prevPositions[3 * o] = positions[3 * o]; prevPositions[3 * o + 1] = positions[3 * o + 1]; prevPositions[3 * o + 2] = positions[3 * o + 2]; }
     positions[3 * o] = np.x; positions[3 * o + 1] = np.y; positions[3 * o + 2] = np.z;
-    uint4 v = vertices[o]; v.w = CompressSR11G11B10(nn); v.z = CompressSR11G11B10(nt); vertices[o] = v;
+    uint4 v = verticesIn[o]; v.w = CompressSR11G11B10(nn); v.z = CompressSR11G11B10(nt); vertices[o] = v;
 }

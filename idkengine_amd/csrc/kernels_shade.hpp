@@ -29,13 +29,15 @@ DEV void write_trace_ready(const DScene& s, const Frame& f, const TraceBufs& tr,
 
 // Fast-path FirstHit shading: only the rays that entered the traversal (active list, any order).  The continue decision
 // goes to a per-ray byte (pre-zeroed), which the ordered compaction turns back into pixel order.
-__global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* activeList, const uint32_t* activeCount,
+template <bool VER /* scene versions: every sample shades with the geometry it was queued with (pt_kernels.hpp DScene::ver) */>
+__global__ __launch_bounds__(256) void k_shade_first(DScene s0, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* activeList, const uint32_t* activeCount,
                                                      uint8_t* contFlag, uint32_t* seedsAndKeys, int lean /* k_gen_primary stored nothing but the trace-ready record of this ray */)
 {
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= *activeCount) return;
     const uint32_t rid = activeList[item];
     const uint32_t smp = rid / f.Npad, pix = rid - smp * f.Npad;
+    const DScene s = VER ? scene_of_sample(s0, smp) : s0;
     const uint32_t acc = sample_index(f, smp);
     const HitRec hit = load_hit(hits, rid);
     RayState r; uint32_t rng, key = 0;
@@ -60,8 +62,8 @@ __global__ __launch_bounds__(256) void k_shade_first(DScene s, Frame f, RayBufs 
     if (cont) { contFlag[rid] = 1; write_trace_ready(s, f, tr, rid, r); }
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm,
+template <bool FIRST, bool VER = false>
+__global__ __launch_bounds__(256) void k_shade(DScene s0, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, uint32_t countImm,
                                                const uint32_t* qbase, const uint32_t* gbase /* null: single context */, unsigned long long* contMask, uint32_t* waveCounts, uint32_t* keysTmp)
 {
     // FIRST: slots are ray ids (sample-major, Npad per sample, Npad % 64 == 0).  Otherwise slots are positions of the
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
         if (FIRST && pix >= (uint32_t)f.W * (uint32_t)f.rows) inRange = false; // padding of the sample segment
     }
     if (inRange) {
+        const DScene s = VER ? scene_of_sample(s0, smp) : s0;
         const uint32_t acc = sample_index(f, smp);
         float4 a = rays.o_ior[idx], b = rays.thr_px[idx], c = rays.rad_py[idx];
         const HitRec hit = load_hit(hits, slot);
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(256) void k_shade(DScene s, Frame f, RayBufs rays, 
 // else of the bounce — ray state, alive queue, counts: what idkptDownloadRays / idkptDownloadAliveQueue / the next scene update may look at — is produced on demand
 // by the ordinary kernels (finish_deferred in idkpt.hip: k_restore_last, then k_shade<false>, the scan and the scatter), bit for bit what the eager path
 // leaves.  A hit whose throughput is not finite (0 * inf is not 0) takes ShadeHit on a copy of its state right here.
-template <bool ALL_HITS /* the scene emits, or lights are hit: every hit may add radiance */>
-__global__ __launch_bounds__(256) void k_shade_last(DScene s, Frame f, RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, const uint32_t* qbase,
+template <bool ALL_HITS /* the scene emits, or lights are hit: every hit may add radiance */, bool VER = false>
+__global__ __launch_bounds__(256) void k_shade_last(DScene s0, Frame f, RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, const uint32_t* qbase,
                                                     float4* radSave, uint32_t* deferCount)
 {
     const uint32_t N = *countPtr;
@@ -141,11 +144,12 @@ __global__ __launch_bounds__(256) void k_shade_last(DScene s, Frame f, RayBufs r
     const float4 c = rays.rad_py[idx];
     radSave[slot] = c;
     if (miss) {
-        const f3 albedo = SampleSky(s, DecodeUnitVec(b.w, c.w));
+        const f3 albedo = SampleSky(s0, DecodeUnitVec(b.w, c.w));   // (the sky is not versioned)
         const f3 rad = mk3(c.x, c.y, c.z) + albedo * mk3(b.x, b.y, b.z);
         rays.rad_py[idx] = make_float4(rad.x, rad.y, rad.z, c.w);
     } else {
         const uint32_t smp = idx / f.Npad;
+        const DScene s = VER ? scene_of_sample(s0, smp) : s0;
         const uint32_t acc = sample_index(f, smp);
         const float4 a = rays.o_ior[idx];
         RayState r; r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;

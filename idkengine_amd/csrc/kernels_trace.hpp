@@ -64,11 +64,13 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 // The test is CONSERVATIVE (box strictly outside one side plane of the tile's pyramid, by a margin that covers the lens radius, the
 // direction tilt LenseRadius/FocalLength, one extra pixel of jitter and rounding); tiles that fail it take the exact per-pixel path,
 // so results are bit-identical either way.  class 0 = per-pixel path, 1..6 = miss + sky face (class-1), 7 = miss + no sky (black).
-__global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8_t* tileClass, uint32_t tilesX, uint32_t tilesY)
+template <bool VER>
+__global__ __launch_bounds__(256) void k_classify_tiles(DScene s0, Frame f, uint8_t* tileClass, uint32_t tilesX, uint32_t tilesY)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tilesX * tilesY) return;
-    const uint32_t smp = blockIdx.y;                                 // > 0 only with per-sample cameras (frame ring): one classification per sample
+    const uint32_t smp = blockIdx.y;                                 // > 0 only with per-sample cameras (frame ring) or scene versions: one classification per sample
+    const DScene s = VER ? scene_of_sample(s0, smp) : s0;
     const float* cam = f.cams ? f.cams + 36u * smp : f.invProj;
     const float* invProj = cam; const float* invView = cam + 16; const float* vp = cam + 32;
     const uint32_t tx = t % tilesX, ty = t / tilesX;
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s, Frame f, uint8
 // and pre-culls rays whose root-box test (BVHIntersect.glsl:32-39 with T = FLOAT_MAX) fails: those get their miss
 // record written here and never reach the traversal kernel.  Survivors are appended (wave ballot + one atomic per
 // wave) to an unordered active list; results are stored per pixel, so the list order is free.
-__global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut, uint8_t* contFlag,
+template <bool VER>
+__global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBufs rays, TraceBufs tr, int cull, uint32_t* activeList, uint32_t* activeCount, uint32_t* seedOut, uint8_t* contFlag,
                                                      const uint8_t* tileClass /* null: no tile pre-classification */,
                                                      int lean /* the traversal reads only the trace-ready record: k_shade_first regenerates the state of a surviving ray instead of reading it back */)
 {
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
     // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
     // rays of the same screen region (all samples) together -> coherent waves in the traversal kernel
     const uint32_t smp = blockIdx.x;                                   // sample of the batch
+    const DScene s = VER ? scene_of_sample(s0, smp) : s0;              // (workgroup-uniform)
     const uint32_t wave = (blockIdx.y * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
     const uint32_t tx = wave % tilesX, ty = wave / tilesX;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
     const uint32_t rid = smp * f.Npad + pix;                           // ray id inside the batch
     bool keep = false;
     const uint32_t nTilesAll = tilesX * (((uint32_t)f.rows + 7) / 8);
-    const uint32_t cls = (tileClass && wave < nTilesAll) ? tileClass[(f.cams ? (size_t)smp * nTilesAll : 0) + wave] : 0u;   // wave-uniform
+    const uint32_t cls = (tileClass && wave < nTilesAll) ? tileClass[(f.tilePerSample ? (size_t)smp * nTilesAll : 0) + wave] : 0u;   // wave-uniform
     if (valid && cls != 0u) {
         // the whole tile is a proven miss with a known sky colour (k_classify_tiles): FirstHit's miss branch without generating the ray
         // k_final_draw takes the colour from the tile class, idkptDownloadRays regenerates the ray state: one flag byte is all that is stored
@@ -265,7 +269,9 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s, Frame f, RayBufs
 // if/else form; +2.5 to +6 % on every view).  The stack pointer is the LDS address itself (pop = [sp], push = [sp + one row]: no index arithmetic).
 #define GRAB_SLICES 8u          // work-list counters of k_trace2 (power of two)
 #define GRAB_STRIDE 128u        // words between them (512 B: separate cache lines and memory channels)
-template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0>
+// VER: scene versions (DScene::ver): every ray traverses the geometry its sample was queued with; a lane keeps where that version's node pairs / triangle
+// records (MULTI: also its TLAS and transforms) start, in 16-byte units, and adds it to every fetch.  Hit records stay version-independent.
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0, bool VER = false>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
     constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     if (N == 0u) workLeft = false;
     uint32_t top = 0, slot = 0, leafFirst = 0, leafEnd = 0;
     uint32_t instIdx = 0, rayId = 0, nodeOff = 0, triOff = 0, xformId = 0;   // MULTI only: per-lane instance cursor (TLAS: next TLAS node) and BLAS offsets
+    uint32_t vNode = 0, vTri = 0, vNodeRef = 0, vTlas = 0, vXform = 0;         // VER only: where this ray's scene version starts in tnodes / triVerts (MULTI: nodes / tlas / xforms), in float4 units
     int tsp = 0; bool moreInst = false;                                       // TLAS stack pointer; "there are instances / TLAS nodes left for this ray"
     lds_u32* sp = stkBase;
     f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
@@ -355,6 +362,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 const uint32_t idx = ordered ? tr.orderIdx[item] : list[item];
                 slot = PRIMARY ? idx : (ordered ? tr.order[item] : item);
                 hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f;
+                if (VER) { const uint32_t* vt = s.ver + SCENE_VER_WORDS * (size_t)(idx / f.Npad); vNode = vt[1]; vTri = vt[2]; if (MULTI) { vNodeRef = vt[0]; vTlas = vt[4]; vXform = vt[5]; } }
                 if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203 (world-space ray)
                     float4 o = rays.o_ior[idx];
                     f3 wd = DecodeUnitVec(rays.thr_px[idx].w, rays.rad_py[idx].w), wo = mk3(o.x, o.y, o.z);
@@ -382,11 +390,12 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             bool adv = active && !leafPending && top == 0u && moreInst;
             while (__any(adv)) {
                 if (adv) {
-                    const float4 pmin = s.tlas[2 * (size_t)instIdx];
+                    const float4* tl4 = VER ? s.tlas + vTlas : s.tlas;
+                    const float4 pmin = tl4[2 * (size_t)instIdx];
                     const uint32_t packed = __float_as_uint(pmin.w), id = packed & 0x7fffffffu;
                     if ((packed >> 31) == 1u) {                                             // leaf: BVHIntersect.glsl:223-240
                         const GpuBlasInstance in2 = s.instances[id];
-                        const M34 inv = load_inv_model(s, in2.MeshTransformId);
+                        const M34 inv = load_inv_model_at(VER ? s.xforms + vXform : s.xforms, in2.MeshTransformId);
                         float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];
                         ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                         invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         const uint32_t l = id, r = id + 1;
                         float4 a = tr.rec[4 * (size_t)rayId], c = tr.rec[4 * (size_t)rayId + 2];                         // world-space origin and 1/dir
                         const f3 wo = mk3(a.x, a.y, a.z), winv = mk3(c.x, c.y, c.z);
-                        float4 lmin = s.tlas[2 * (size_t)l], lmax = s.tlas[2 * (size_t)l + 1], rmin = s.tlas[2 * (size_t)r], rmax = s.tlas[2 * (size_t)r + 1];
+                        float4 lmin = tl4[2 * (size_t)l], lmax = tl4[2 * (size_t)l + 1], rmin = tl4[2 * (size_t)r], rmax = tl4[2 * (size_t)r + 1];
                         float tMinLeft, tMinRight;
                         const bool tl = RayBoxIntersect(wo, winv, lmin, lmax, &tMinLeft) && tMinLeft < hitT;
                         const bool tr2 = RayBoxIntersect(wo, winv, rmin, rmax, &tMinRight) && tMinRight < hitT;
@@ -415,12 +424,12 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             while (__any(adv)) {
                 if (adv) {
                     const GpuBlasInstance in2 = s.instances[instIdx];
-                    const M34 inv = load_inv_model(s, in2.MeshTransformId);
+                    const M34 inv = load_inv_model_at(VER ? s.xforms + vXform : s.xforms, in2.MeshTransformId);
                     float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];                         // world-space origin / direction
                     ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                     invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
-                    const float4* root = s.nodes + 2 * (size_t)nodeOff + 2;
+                    const float4* root = (VER ? s.nodes + vNodeRef : s.nodes) + 2 * (size_t)nodeOff + 2;
                     float t1;
                     const bool enter = RayBoxIntersect(ro, invDir, root[0], root[1], &t1) && t1 < hitT;
                     sp = stkBase; top = enter ? 2u : 0u;
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             if (PROF) { pn[2]++; pn[3] += (unsigned long long)__builtin_popcountll(stepMask); }
             if (canStep) {
                 if (COUNT) nPairs++;
-                const float4* p = MULTI ? s.tnodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top;
+                const float4* p = (MULTI ? s.tnodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top) + (VER ? vNode : 0u);
                 if (DBG == 1) { uint32_t x0 = lane, x1 = lane, x2 = lane, x3 = lane;       // (bottleneck probe: 16 extra VALU instructions per step, four independent chains)
                     for (int k = 0; k < 4; k++) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)); }
                 if (DBG == 2) { uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;                   // (16 extra SALU instructions per step)
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             // (one triangle per round trip.  Requesting the two 48-B records of a two-triangle leaf together was measured in round 3: 88 instead of 75 VGPRs,
             // 5 instead of 6 waves per SIMD, every view 2-11 % slower; with the occupancy forced back, spills cost more — profiles/r03_trace_experiments.md)
             for (uint32_t i = leafFirst + tOff, e = leafEnd + tOff; i < e; i++) {
-                const float4* tv = s.triVerts + 3 * (size_t)i;
+                const float4* tv = s.triVerts + 3 * (size_t)i + (VER ? vTri : 0u);
                 float4 a = tv[0], b = tv[1], c = tv[2];
                 float by, bz, t;
                 if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hitT) {

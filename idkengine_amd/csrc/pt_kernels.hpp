@@ -30,7 +30,20 @@ struct DScene {
     const float4* sky; int skySize;
     const TexDesc* textures; int textureCount;
     uint32_t* overflow;         // host-mapped word: set when a traversal-stack push had to be dropped (idkpt.hip turns it into an error at the next sync)
+    // scene versions (idkptSetSceneVersions): samples of one batch may see different states of the geometry (animated frames in flight).  Null: every sample
+    // reads the pointers above.  Else the pointers above are the bases of the version arenas and row smp of this table holds, in 16-byte units, where the
+    // version of sample smp starts in each: [0] nodes [1] tnodes [2] triVerts [3] vertices [4] tlas [5] xforms [6..7] unused (kernels instantiated with VER)
+    const uint32_t* ver;
 };
+#define SCENE_VER_WORDS 8
+// the scene as sample smp of the batch sees it (VER instantiations only; per-lane pointers where smp varies inside a wave)
+DEV DScene scene_of_sample(const DScene& s, uint32_t smp)
+{
+    DScene v = s;
+    const uint32_t* t = s.ver + SCENE_VER_WORDS * (size_t)smp;
+    v.nodes = s.nodes + t[0]; v.tnodes = s.tnodes + t[1]; v.triVerts = s.triVerts + t[2]; v.vertices = s.vertices + t[3]; v.tlas = s.tlas + t[4]; v.xforms = s.xforms + t[5];
+    return v;
+}
 
 struct Frame {
     float invProj[16]; float invView[16]; float viewPos[3];
@@ -48,6 +61,7 @@ struct Frame {
     uint32_t seqFirst, seqStride;   // idkptSetSampleSequence: sample i of an accumulation draws the RNG streams of AccumulatedSamples = seqFirst + i * seqStride (reference: 0, 1)
     // frame ring (idkptSetFrameRing): sample k renders with camera cams[36*k ..] (null: the one camera above) into result-image slot slotOf[k]
     const float* cams; uint32_t slotOf[256];   // (dwords: scalar loads from the kernel-argument segment; gfx9 has no scalar byte load)
+    int tilePerSample;          // k_classify_tiles ran once per sample of the batch (per-sample cameras or scene versions): tile classes are indexed [sample][tile]
 };
 #define MAX_BATCH 256
 
@@ -146,7 +160,8 @@ DEV bool IntersectBlas(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& dref, b
     return anyHit;
 }
 
-DEV M34 load_inv_model(const DScene& s, uint32_t xformId) { const float4* x = s.xforms + 9 * (size_t)xformId; M34 m; m.r0 = x[3]; m.r1 = x[4]; m.r2 = x[5]; return m; }
+DEV M34 load_inv_model_at(const float4* xforms, uint32_t xformId) { const float4* x = xforms + 9 * (size_t)xformId; M34 m; m.r0 = x[3]; m.r1 = x[4]; m.r2 = x[5]; return m; }
+DEV M34 load_inv_model(const DScene& s, uint32_t xformId) { return load_inv_model_at(s.xforms, xformId); }
 
 // traceLights / maxDist: the path tracer passes (settings.DoTraceLights, FLOAT_MAX) (FirstHit:106, NHit:96); ray queries and the
 // shadow kernel pass their own (BVHIntersect.glsl:183, ShadowsRayTraced/compute.glsl:73)

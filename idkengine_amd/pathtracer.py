@@ -215,6 +215,10 @@ class PathTracer:
     def Skin(self, input_offset, output_offset, joint_offset, count):
         self._check(self._L.idkptSkin(self._ctx, input_offset, output_offset, joint_offset, count))
 
+    def SetSceneVersions(self, versions):
+        """idkptSetSceneVersions: up to `versions` states of the animated geometry in flight (scene updates no longer launch the queued samples first)."""
+        self._check(self._L.idkptSetSceneVersions(self._ctx, int(versions)))
+
     def SetGroupSharding(self, mode):
         """idkptSetGroupSharding: 0 auto (bands of 8 rows for RayDepth <= 2, strips + device-side count exchange beyond), 1 rows, 2 strips, 3 bands of 8 rows."""
         self._check(self._L.idkptSetGroupSharding(self._ctx, int(mode)))

@@ -202,7 +202,11 @@ IDKPT_API int32_t idkptSetPerFrameData(idkpt_ctx* ctx, const GpuPerFrameData* pe
 /* Replaces BBG.Buffer.Recreate(...) of SSBO 20-27 (Bvh/BVH.cs:441-451), SSBO 2-8 (ModelManager.cs:594-621),
  * lights UBO and skybox handle.  Builds the library's derived HBM layouts. */
 IDKPT_API int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* scene);
-/* Partial update: BBG.Buffer.UploadElements on one of the scene buffers (e.g. ModelManager.cs:236-261) */
+/* Partial update: BBG.Buffer.UploadElements on one of the scene buffers (e.g. ModelManager.cs:236-261).  A patch of BLAS / TLAS nodes is validated
+ * before it reaches the device (child indices, stack need) on a host copy of the array WITH the patch applied, so the array must be a valid tree after
+ * every call: a host that streams a rebuilt tree in several pieces uses idkptUploadScene / idkptBuildTlas / idkptBuildTlasOnDevice instead (each such
+ * patch also costs a device-to-host copy of the node array and two synchronisations).  Updates of up to 256 KB (joint matrices, transforms) do not wait
+ * for the GPU. */
 IDKPT_API int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, const void* data);
 IDKPT_API int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count);
 /* BVH.TlasBuild upload (Bvh/BVH.cs:278-298): host-built TLAS nodes replace SSBO 27 */
@@ -258,6 +262,18 @@ IDKPT_API int32_t idkptTraceRays(idkpt_ctx* ctx, const idkpt_ray* rays, size_t c
 IDKPT_API int32_t idkptTraceShadows(idkpt_ctx* ctx, const idkpt_shadow_params* params, const float* depth, const float* normalOct, float* visibility);
 /* Read back a scene buffer (tests: refit/skinning results). */
 IDKPT_API int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst);
+
+/* ---- scene versions: animated frames in flight (no reference equivalent) ------------------- */
+/* The reference's frame loop updates the geometry (ModelManager.Update: skinning, BLAS refit, TLAS rebuild; Source/ModelManager.cs:263-361) and then renders
+ * ONE frame with it.  With one scene state on the device, queued samples would have to be launched before every such update — an animated host would render
+ * one frame at a time, a quarter of the batched rate.  idkptSetSceneVersions(ctx, n) lets the buffers those updates rewrite (BLAS nodes and their derived
+ * triangle records, vertices, TLAS nodes, mesh transforms) hold up to n states each: idkptUpdateBuffer (positions, vertices, transforms, joints) / idkptSkin /
+ * idkptRefitBlas / idkptBuildTlas / idkptBuildTlasOnDevice run at once, into a state no queued sample reads, and every queued sample is traced with the
+ * geometry that was current when idkptRender queued it — frames with different geometry share one batch (with idkptSetFrameRing / idkptSetMaxBatch).
+ * Every frame's image is bit-identical to updating and rendering that frame alone.  When all n states are pinned by queued samples the library launches
+ * what is queued (exactly what it does before every update when n = 1, the default).  Memory: about 155 B x n per triangle.  Updates of meshes, materials,
+ * lights and settings still launch the queued samples first. */
+IDKPT_API int32_t idkptSetSceneVersions(idkpt_ctx* ctx, int32_t versions);
 
 /* ---- frame ring: several frames in flight (no reference equivalent) ------------------------ */
 /* The reference renders one frame at a time: Compute(), look at Result, move the camera, ResetAccumulation(), Compute() ...  One
