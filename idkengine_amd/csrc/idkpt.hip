@@ -22,6 +22,7 @@ using namespace ptd;
 // =================================================================================================== kernels (one translation unit)
 #include "kernels_common.hpp"
 #include "kernels_trace.hpp"
+#include "kernels_trace_split.hpp"
 #include "kernels_query.hpp"
 #include "kernels_shade.hpp"
 #include "kernels_queue.hpp"
@@ -59,6 +60,9 @@ struct DevOptions {
     int traceOrder = 0;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order (default: L2 hit rate 0.62 -> 0.88, launch -7 %, the permutation costs more), 1 = batches of >= 4 samples, 2 = always
     int traceVariant = 0;        // IDKPT_DEVELOPER builds only: instrumented / probe instantiations of k_trace2
     int bvhTiming = 0, bvhSmall = 32;   // idkptBuildBlasCore: phase times on stderr; subtrees of at most this many fragments are finished by one thread
+    int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
+    int splitDonor = 1;          // k_trace2s: 1 = only rays that have not hit anything yet donate subtrees, 0 = every busy lane does
+    int split = 0;               // k_trace2s (long rays split across the idle lanes of their wave once the work list is empty): 0 = never, 1 = launches below SPLIT_MAX_RAYS rays (default), 2 = every launch, 3 = every launch + every split ray traced again (test hook for the re-trace path)
     int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
 };
 
@@ -111,6 +115,7 @@ struct dev_ctx {
     // stats
     idkpt_stats stats;
     uint32_t* hCounts = nullptr; uint32_t* dCountsMirror = nullptr;   // host-mapped mirror of the queue lengths (written by k_scan_blocks, read by the host after a sync)
+    bool sceneNested = false;       // every child box of every BLAS lies inside its parent's box (what k_trace2s's exactness argument needs; refits keep it)
     bool sceneNoEmission = false;   // no material / mesh of the uploaded scene emits and every texel is finite: a hit of the last bounce cannot change the radiance (k_shade_last)
     struct { bool valid = false, allHits = false; int j = 0, side = 0, B = 0; uint32_t total = 0, Npad = 0; } defer;   // the last bounce of the last batch still owes its continuation (finish_deferred)
     DevBuf radSave, deferCount;
@@ -162,8 +167,20 @@ static int local_rows(int H, int mod, int rem, int bandLog2 = 0)
 
 template <bool PRIMARY>
 static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
-                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters)
+                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, bool spec = false)
 {
+#ifdef IDKPT_DEVELOPER
+    if (spec && !split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {   // the candidates of the next step are requested before this step's box tests (kernels_trace.hpp, DBG 8)
+        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 0, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        return;
+    }
+#endif
+    (void)spec;
+    if (split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && !ctx->counters && ctx->sceneNested && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {   // small launch: long rays are split across idle lanes (kernels_trace_split.hpp)
+        hipLaunchKernelGGL((k_trace2s<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work);
+        return;
+    }
     if (s.ver) {                    // scene versions: the samples of this batch see different states of the geometry (VER instantiations, kernels_trace.hpp)
 #define T2VER(C, M) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 32, 1, false, 24, M, 0, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         if (f.useTlas) { if (ctx->counters) T2VER(true, 2); else T2VER(false, 2); }
@@ -410,6 +427,25 @@ static const char* validate_blas_nodes(const GpuBlasNode* nodes, int nodeCount, 
     }
     *outMaxStack = maxStack;
     return nullptr;
+}
+
+// Are all BLASes nested — every child box inside its parent's box?  (What the builder produces, and what a refit keeps: a parent is the union of its children.
+// k_trace2s's exactness argument needs it; a host-patched tree that is not nested simply never gets that kernel.)  NaN coordinates compare false: not nested.
+static bool blas_nested(const GpuBlasNode* nodes, const GpuBlasDesc* descs, int descCount)
+{
+    for (int i = 0; i < descCount; i++) {
+        const GpuBlasDesc& d = descs[i];
+        for (int n = 1; n < d.NodeCount; n++) {
+            const GpuBlasNode& p = nodes[d.NodeOffset + n];
+            if (p.TriCount > 0 || p.TriStartOrChild == 0) continue;
+            for (int k = 0; k < 2; k++) {
+                const GpuBlasNode& c = nodes[d.NodeOffset + p.TriStartOrChild + k];
+                if (c.TriCount == 0 && c.TriStartOrChild == 0 && n != 0) continue;          // (an empty node is never entered)
+                for (int a = 0; a < 3; a++) if (!(c.Min[a] >= p.Min[a] && c.Max[a] <= p.Max[a])) return false;
+            }
+        }
+    }
+    return true;
 }
 
 static int derive_nodes(dev_ctx* ctx, int blasId)
@@ -729,6 +765,7 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     ctx->lightCount = sc->Lights ? sc->LightCount : 0; ctx->textureCount = sc->TextureCount;
     ctx->hDescs.assign(sc->BlasDescs, sc->BlasDescs + sc->BlasDescCount);
     ctx->sceneStack = maxStack; ctx->tlasNeed = std::max(1, tlasNeed);
+    ctx->sceneNested = blas_nested(sc->BlasNodes, sc->BlasDescs, sc->BlasDescCount);
     ver_reset(ctx);                                   // one state per versioned buffer, in slot 0 (everything that read the old scene was launched by FLUSH above)
     // refit schedule: internal nodes of every refittable BLAS grouped by depth (children have larger ids than parents)
     ctx->levelOffsets.assign(sc->BlasDescCount, {}); ctx->levelBase.assign(sc->BlasDescCount, 0); ctx->refitCoversAll.assign(sc->BlasDescCount, 0);
@@ -818,7 +855,7 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
     ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
     ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
-    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
+    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneNested = src->sceneNested; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
     ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase; ctx->refitCoversAll = src->refitCoversAll;
     ver_reset(ctx);
     HIPC(hipStreamSynchronize(ctx->stream));           // td is a stack vector
@@ -881,6 +918,7 @@ static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes,
             REQUIRE(ctx->st.BlasStackSize == 0 || ctx->st.BlasStackSize >= maxStack, "idkptUpdateBuffer: the patched BLAS needs a deeper traversal stack than the BlasStackSize set with idkptSetSettings");
             HIPC(hipMemcpyAsync(cur + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
             ctx->sceneStack = maxStack;
+            ctx->sceneNested = blas_nested((const GpuBlasNode*)h.data(), ctx->hDescs.data(), (int)ctx->hDescs.size());
             int rc = rebuild_node_layout(ctx, (const GpuBlasNode*)h.data()); if (rc) return rc;
         } else {
             const char* why = nullptr;
@@ -921,6 +959,15 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "grid_rays_x4") o.gridRaysX4 = std::max(0, value);
     else if (n == "grid_mid_waves") o.gridMidWaves = std::max(0, value);
     else if (n == "defer_last") o.deferLast = value != 0;
+    else if (n == "split") { REQUIRE(value >= 0 && value <= 3, "idkptSetDeveloperOption: split is 0..3"); o.split = value; }
+    else if (n == "split_donor") o.splitDonor = value != 0;
+    else if (n == "spec") {
+#ifdef IDKPT_DEVELOPER
+        REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: spec is 0..2"); o.spec = value;
+#else
+        REQUIRE(value == 0, "idkptSetDeveloperOption: spec needs the developer build of the library (libidkpt_dev.so)");
+#endif
+    }
 #ifdef IDKPT_DEVELOPER
     else if (n == "graph_probe") o.graphProbe = std::max(0, value);
 #endif
@@ -1225,10 +1272,21 @@ static int32_t dev_BuildBlas(dev_ctx* ctx, const float* positions, int32_t verte
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     REQUIRE(positions && tris && info && vertexCount > 0 && triCount > 0, "idkptBuildBlas: null argument or empty geometry");
     REQUIRE(triCount <= (1 << 26), "idkptBuildBlas: too many triangles");
-    for (int i = 0; i < triCount; i++) REQUIRE(tris[i].X < (uint32_t)vertexCount && tris[i].Y < (uint32_t)vertexCount && tris[i].Z < (uint32_t)vertexCount, "idkptBuildBlas: triangle index out of range");
-    {   // non-finite positions: the reference's builder has no defined result for them (NaN boxes, integer conversions of NaN) — refused, like idkbvhBuildBlas does
+    // One walk over the triangles: index range, the vertex range they reference, and — like idkbvhBuildBlas (bvh_builder.cpp), which this call mirrors — finiteness
+    // of the REFERENCED positions only (the reference's builder has no defined result for NaN boxes / integer conversions of NaN; vertices no triangle of this BLAS
+    // uses belong to other meshes of the host's global vertex array and are none of this call's business).
+    uint32_t vmin = 0xffffffffu, vmax = 0u;
+    {
         const uint32_t* pb = reinterpret_cast<const uint32_t*>(positions); uint32_t bad = 0;
-        for (size_t i = 0, e = (size_t)vertexCount * 3; i < e; i++) bad |= (uint32_t)((pb[i] & 0x7f800000u) == 0x7f800000u);
+        for (int i = 0; i < triCount; i++) {
+            const uint32_t v[3] = {tris[i].X, tris[i].Y, tris[i].Z};
+            REQUIRE(v[0] < (uint32_t)vertexCount && v[1] < (uint32_t)vertexCount && v[2] < (uint32_t)vertexCount, "idkptBuildBlas: triangle index out of range");
+            for (int k = 0; k < 3; k++) {
+                vmin = std::min(vmin, v[k]); vmax = std::max(vmax, v[k]);
+                const uint32_t* q = pb + 3 * (size_t)v[k];
+                bad |= (uint32_t)((q[0] & 0x7f800000u) == 0x7f800000u) | (uint32_t)((q[1] & 0x7f800000u) == 0x7f800000u) | (uint32_t)((q[2] & 0x7f800000u) == 0x7f800000u);
+            }
+        }
         REQUIRE(!bad, "idkptBuildBlas: a vertex position is not finite");
     }
     HIPC(hipSetDevice(ctx->device));
@@ -1241,10 +1299,13 @@ static int32_t dev_BuildBlas(dev_ctx* ctx, const float* positions, int32_t verte
     auto lap = [&](const char* what) { if (!timing) return; (void)hipStreamSynchronize(st); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[idkpt blas] %-14s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tq).count()); tq = t; };
     const int nT = triCount;
     const unsigned gT = (unsigned)((nT + 255) / 256);
-    HIPC(B.pos.ensure((size_t)vertexCount * 12)); HIPC(B.tris.ensure((size_t)nT * 16));
-    HIPC(hipMemcpyAsync(B.pos.p, positions, (size_t)vertexCount * 12, hipMemcpyHostToDevice, st));
+    // only the vertex range this BLAS references crosses PCIe (a host that passes its GLOBAL vertex array for every BLAS pays for its own vertices, not for
+    // O(#BLAS x V)); the kernels keep indexing with the host's ids through a pointer moved back by the range's first vertex
+    const size_t vRange = (size_t)vmax - vmin + 1;
+    HIPC(B.pos.ensure(vRange * 12)); HIPC(B.tris.ensure((size_t)nT * 16));
+    HIPC(hipMemcpyAsync(B.pos.p, positions + 3 * (size_t)vmin, vRange * 12, hipMemcpyHostToDevice, st));
     HIPC(hipMemcpyAsync(B.tris.p, tris, (size_t)nT * 16, hipMemcpyHostToDevice, st));
-    const float* dPos = B.pos.as<float>(); const uint4* dTris = B.tris.as<uint4>();
+    const float* dPos = B.pos.as<float>() - 3 * (ptrdiff_t)vmin; const uint4* dTris = B.tris.as<uint4>();
     lap("upload");
     // ---- fragments
     int F = nT;
@@ -1641,6 +1702,23 @@ static bool fast_path(dev_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st
 //     waves per CU for the same reason, and views whose launches are that small only with a few samples in flight (every pixel traversing) lose nothing measurable;
 //     above it 24 is never worse (profiles/r03_trace_experiments.md 9).
 #define GRID_MID_RAYS 14000000u
+// Which traversal kernel a launch gets: k_trace2s (kernels_trace_split.hpp: long rays split across the idle lanes of their wave once the work list is empty) pays
+// where a launch ends with a few long rays on an otherwise idle chip — launches of up to SPLIT_MAX_RAYS rays (a frame traced alone, the bounce launches of small
+// batches, one rank's share of an N-GPU frame); its extra registers (one wave per SIMD less) cost large launches more than their tails are worth.
+#define SPLIT_MAX_RAYS 4000000u
+static bool want_split(const dev_ctx* ctx, uint32_t prev, bool known)
+{
+    if (ctx->opt.split == 0) return false;
+    if (ctx->opt.split >= 2) return true;
+    return known && prev > 0u && prev < SPLIT_MAX_RAYS;
+}
+#define SPEC_MAX_RAYS 1500000u
+static bool want_spec(const dev_ctx* ctx, uint32_t prev, bool known)
+{
+    if (ctx->opt.spec == 0) return false;
+    if (ctx->opt.spec >= 2) return true;
+    return known && prev > 0u && prev < SPEC_MAX_RAYS;
+}
 static uint32_t small_launch_grid(uint32_t fullGrid, uint32_t prev, int hintMul, int raysX4, uint32_t midGrid)
 {
     if (prev == 0u || hintMul <= 0) return fullGrid;
@@ -1783,7 +1861,7 @@ static int flush_batch(dev_ctx* ctx)
     // (a launch never needs more waves than it can have rays: small frames would otherwise spend their time dispatching idle workgroups)
     const uint32_t traceGrid = std::min<uint32_t>((uint32_t)(ctx->numCUs * wavesPerCU), std::max<uint32_t>(1u, (uint32_t)(((size_t)B * N + 63) / 64)));
     const uint32_t midGrid = (ctx->opt.gridMidWaves > 0 && ctx->opt.traceWaves == 0) ? (uint32_t)(ctx->numCUs * std::min(wavesPerCU, ctx->opt.gridMidWaves)) : 0u;   // (an explicit trace_waves wins)
-    f.gridRaysX4 = (uint32_t)std::max(0, ctx->opt.gridRaysX4); f.gridMid = midGrid; f.gridMidRays = GRID_MID_RAYS;   // the same rules inside k_trace2, on the launch's actual ray count
+    f.gridRaysX4 = (uint32_t)std::max(0, ctx->opt.gridRaysX4); f.gridMid = midGrid; f.gridMidRays = GRID_MID_RAYS; f.splitMode = (ctx->opt.split == 3 ? 2 : 1) | (ctx->opt.splitDonor ? 4 : 0);   // the same rules inside k_trace2, on the launch's actual ray count
     const bool debug = f.g.DoDebugBVHTraversal != 0;
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);
@@ -1824,7 +1902,8 @@ static int flush_batch(dev_ctx* ctx)
             TRACE_T0();
             uint32_t grid0 = traceGrid;
             if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4, midGrid);
-            launch_trace2<true>(ctx, grid0, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters);
+            launch_trace2<true>(ctx, grid0, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters,
+                                want_split(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B), want_spec(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B));
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
             if (multiVer) hipLaunchKernelGGL((k_shade_first<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
@@ -1915,7 +1994,9 @@ static int flush_batch(dev_ctx* ctx)
         uint32_t gridj = traceGrid;
         const int hintMul = ctx->opt.gridHint;
         if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) gridj = small_launch_grid(traceGrid, ctx->hBases[(size_t)j * BS + B], hintMul, ctx->opt.gridRaysX4, midGrid);
-        if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, trj, hits, (const uint32_t*)q, cnt, work + j, counters);
+        if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, trj, hits, (const uint32_t*)q, cnt, work + j, counters,
+                                       want_split(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr),
+                                       want_spec(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr));
         else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);

@@ -275,6 +275,14 @@ template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF 
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
     constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
+    // DBG 8 ("speculative touch", developer build only): as soon as a node pair has arrived, one word of each place the ray can go next is requested — both
+    // children (the child pair of an internal child, the first triangle record of a leaf child) and the pair on top of the stack — before the box tests run, so
+    // that the fetch of whichever becomes the next step overlaps with this step's ~100 dependent instructions instead of following them.  Nothing of the traversal
+    // changes (same visits, same counters, same hits; tests + fuzz bit-identical).  Measured in round 4 and NOT shipped: 14 % slower on the headline view one frame
+    // at a time, 35-50 % slower where every pixel traverses, at every launch size — even a frame traced alone is bound by the rate at which blocks that miss L1/L2
+    // are delivered, not by the latency of its longest ray (profiles/r04_small_launch_experiments.md).
+    constexpr bool SPEC = DBG == 8;
+    uint32_t pfA = 0, pfB = 0, pfC = 0, pfSink = 0;
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     // LDS rows of this wave, one word per lane: row 0 = dummy (what a pop of the empty stack reads), rows 1 .. cap = stack entries 0 .. cap-1,
@@ -460,6 +468,18 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 const uint32_t popped = sp[0];                          // what a pop would return (in flight with the node pair; row 0 for an empty stack)
                 float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
                 const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
+                if (SPEC) {
+                    pfSink ^= pfA ^ pfB ^ pfC;                          // the words touched one step ago (they were requested before this step's pair, so they have arrived)
+                    const float4* nb = (MULTI ? s.tnodes + 2 * (size_t)nodeOff : nodes) + (VER ? vNode : 0u);
+                    const float4* tb = s.triVerts + 3 * (size_t)(MULTI ? triOff : triOffset) + (VER ? vTri : 0u);
+                    const float4* ta = lCount == 0u ? nb + 2 * (size_t)lStart : tb + 3 * (size_t)lStart;
+                    const float4* tc = rCount == 0u ? nb + 2 * (size_t)rStart : tb + 3 * (size_t)rStart;
+                    const float4* tp = nb + 2 * (size_t)(sp != stkBase ? popped : top);
+                    // (inline asm: a C++ load that nothing consumes is deleted, a volatile one becomes a system-scope load with a wait behind it.  The compiler does not
+                    // know these loads are in flight — it never waits for them; the registers are read one step later, behind the wait for that step's own, younger loads)
+                    asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off" : "=&v"(pfA), "=&v"(pfB), "=&v"(pfC) : "v"(ta), "v"(tc), "v"(tp));
+                    __builtin_amdgcn_sched_barrier(0);                 // (the box tests below must not be scheduled in front of the requests: the overlap is the point)
+                }
                 float tMinLeft, tMinRight;
                 const bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= hitT;
                 const bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hitT;
@@ -503,6 +523,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         }
     }
     if (ovf) *s.overflow = 1u;
+    if (SPEC) asm volatile("" :: "v"(pfSink ^ pfA ^ pfB ^ pfC));          // (keeps the touched words alive: nothing reads them)
     if (COUNT) flush_counters(counters, nPairs, nTris);
     if (PROF && lane == 0) { for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)&counters[4 + i], pc[i]); for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&counters[8 + i], pn[i]); }
 #undef PROF_MARK

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace2s(DScene s, Frame f, RayBufs 
         // ---- split: idle lanes adopt the bottom stack entry of busy lanes (only once the work list is exhausted)
         idle = __ballot(!active);
         if (!workLeft && idle != 0ull) {
-            unsigned long long donors = __ballot(active && !ownDone && splittable && sp != lo);
+            // (splitMode bit 2: only rays that have not hit anything yet donate — the rays that cross the whole scene, whose far subtrees no later hit will cull)
+            unsigned long long donors = __ballot(active && !ownDone && splittable && sp != lo && (!(f.splitMode & 4) || hitT == PT_FLOAT_MAX));
             int pairs = 0;
             while (donors != 0ull && idle != 0ull && pairs < 16) {
                 const int d = (int)__builtin_ctzll(donors), i = (int)__builtin_ctzll(idle);
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace2s(DScene s, Frame f, RayBufs 
         // ---- root pieces: combine and retire, or trace the ray again sequentially when the pieces are inconclusive (header comment)
         if (active && ownDone && kids == 0 && parent < 0) {
             const bool kidsWin = kT < hitT;                       // the own hit (also a light hit: T < MAX, TriangleId ~0) is first in order: ties stay with it
-            const bool retrace = kidsWin && (tie || gmin(second, hitT) < kLeafTmin || f.splitMode == 2);
+            const bool retrace = kidsWin && (tie || gmin(second, hitT) < kLeafTmin || (f.splitMode & 3) == 2);
             if (retrace) { splittable = false; needLoad = true; ownDone = false; }
             else {
                 if (kidsWin) { hitT = kT; hbx = kbx; hby = kby; hitTri = kTri; hitXform = inst.MeshTransformId; }

@@ -61,6 +61,7 @@ struct Frame {
     uint32_t seqFirst, seqStride;   // idkptSetSampleSequence: sample i of an accumulation draws the RNG streams of AccumulatedSamples = seqFirst + i * seqStride (reference: 0, 1)
     // frame ring (idkptSetFrameRing): sample k renders with camera cams[36*k ..] (null: the one camera above) into result-image slot slotOf[k]
     const float* cams; uint32_t slotOf[256];   // (dwords: scalar loads from the kernel-argument segment; gfx9 has no scalar byte load)
+    int splitMode;              // k_trace2s (kernels_trace_split.hpp): bits 0-1: 2 = every ray whose pieces found a hit is traced again sequentially (test hook for the re-trace path); bit 2: only rays without a hit donate subtrees
     int tilePerSample;          // k_classify_tiles ran once per sample of the batch (per-sample cameras or scene versions): tile classes are indexed [sample][tile]
 };
 #define MAX_BATCH 256

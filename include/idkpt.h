@@ -233,8 +233,9 @@ IDKPT_API int32_t idkptBuildBlasCore(idkpt_ctx* ctx, const float* fragmentBoxes,
  * into host arrays sized from outInfo (one build per context at a time).  Output bytes are those of libidkbvh's idkbvhBuildBlas (and therefore of
  * the reference's builder as far as that is pinned); nodes carry BLAS-local indices like BLAS.Build's.  A host-side service like
  * idkptBuildBlasCore: first device of the context, no scene needed, none touched.
- * IDKPT_ERR_INVALID_ARGUMENT (nothing built) for: a vertex id out of range, a vertex position that is not finite (the reference's builder has no defined
- * result for NaN / infinite boxes), a PreSplit that asks for more than 2^27 fragments, a triangle whose split recursion needs more than the 64 stack
+ * IDKPT_ERR_INVALID_ARGUMENT (nothing built) for: a vertex id out of range, a position of a vertex some triangle references that is not finite (the
+ * reference's builder has no defined result for NaN / infinite boxes; vertices no triangle references are neither checked nor uploaded: a host may pass
+ * its global vertex array for every BLAS), a PreSplit that asks for more than 2^27 fragments, a triangle whose split recursion needs more than the 64 stack
  * entries the reference allocates (PreSplitting.cs:57: it throws there).  idkbvhBuildBlas refuses the same inputs. */
 typedef struct idkpt_blas_build_info {
     int32_t NodeCount, TriangleCount, RequiredStackSize, ParentIndexCount, LeafIndexCount, FragmentCount, Levels, _pad;

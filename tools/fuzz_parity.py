@@ -96,7 +96,8 @@ def draw_case(seed, builder):
     frames = int(rng.integers(1, 6)); batch = int(rng.choice([1, 2, 5, 8]))
     st = configs.apply_settings(T.Settings.default(), ov)
     opts = {"node_layout": int(rng.choice([0, 0, 1, 2])), "treelet_depth": int(rng.integers(1, 6)), "trace_order": int(rng.choice([0, 0, 1, 2])),
-            "grid_rays_x4": int(rng.choice([6, 6, 0, 1, 64])), "grid_mid_waves": int(rng.choice([20, 20, 0, 3])), "defer_last": int(rng.choice([1, 1, 0])), "grid_hint": int(rng.choice([2, 2, 0, 1])), "trace_waves": int(rng.choice([0, 0, 1, 7]))}   # free choices of the implementation: never visible in the output
+            "grid_rays_x4": int(rng.choice([6, 6, 0, 1, 64])), "grid_mid_waves": int(rng.choice([20, 20, 0, 3])), "defer_last": int(rng.choice([1, 1, 0])), "grid_hint": int(rng.choice([2, 2, 0, 1])), "trace_waves": int(rng.choice([0, 0, 1, 7])),
+            "split": int(rng.choice([1, 2, 2, 3, 0])), "split_donor": int(rng.choice([0, 1]))}   # free choices of the implementation: never visible in the output (split is drawn last: the cases of earlier rounds keep their scenes)
     return sc, cam, w, h, ov, st, opts, frames, batch, nb
 
 
