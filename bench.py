@@ -149,7 +149,7 @@ def main():
         # ONE context on `group` devices: the library replicates the scene over xGMI, deals the rows and gathers the frame itself
         from idkengine_amd.pathtracer import PathTracer
         ndev = torch.cuda.device_count()
-        pt = PathTracer(W, H, devices=[d % ndev for d in range(group)])
+        pt = PathTracer(W, H, devices=[d % ndev for d in range(group)])   # (more members than GPUs: members share GPUs — said so in the metric string and in config.n_gpu)
         pt.UploadScene(scene); pt.SetCamera(cam)
         r = type("Single", (), {"pt": pt})()
 
@@ -230,13 +230,36 @@ def main():
         dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
     rays_rep, traversed_rep = rays_total.tolist()
     dt = statistics.median(repeat_s)
+    ranks_counted = None
+    if world > 1:                                        # (a collective: every rank takes part, rank 0 reports)
+        seen = torch.ones(1, dtype=torch.float64, device=device); dist.all_reduce(seen); ranks_counted = int(seen.item())
+    selftest = None
+    if world * group > 1 and not sample_parallel and depth <= 2 and not args.pmc_child:
+        # the N-GPU frame against ONE device, bit for bit (what tools/scale_selftest.py checks, here on the bench's own frame): two accumulated samples, the sharded
+        # frame exchanged as in the timed region, rank 0 renders the same two samples on its own device alone and compares
+        try:
+            import hashlib
+            pt.set_max_batch(2); pt.ResetAccumulation(); pt.Compute(); pt.Compute()
+            if group > 1:
+                got = pt.Result.tobytes()
+            else:
+                full = frame.gather(); torch.cuda.synchronize(); got = full.cpu().numpy().tobytes() if rank == 0 else None
+            if rank == 0:
+                from idkengine_amd.pathtracer import PathTracer as _One
+                one = _One(W, H, device=local_rank); one.UploadScene(scene); one.SetCamera(cam); one.RayDepth = depth; one.DoRaySorting = args.sort; one.set_max_batch(2)
+                one.Compute(); one.Compute(); want = one.Result.tobytes(); one.Dispose()
+                selftest = {"frame": "2 accumulated samples of the bench frame, sharded + exchanged vs rank 0's device alone", "bits_equal": got == want, "sha16": hashlib.sha256(got).hexdigest()[:16]}
+            pt.set_max_batch(B)
+        except Exception as e:   # noqa: BLE001
+            selftest = {"error": str(e)}
 
     if rank == 0:
         value = rays_rep / dt / 1e6
-        headline = (not sample_parallel) and (args.tris, depth, args.sort, W, H, args.batch, args.view, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world * group), "headline", "soup")
+        shared = group > torch.cuda.device_count() or (world > 1 and one_device)      # members / ranks share GPUs: a control-flow check, not an N-GPU measurement
+        headline = (not sample_parallel) and not shared and (args.tris, depth, args.sort, W, H, args.batch, args.view, args.scene) == (N_TRIS, RAY_DEPTH, 0, 1920, 1080, min(256, 32 * world * group), "headline", "soup")
         view_txt = "camera at z = 25 outside the soup (SURVEY 8d config 3)" if args.view == "headline" else "camera INSIDE the soup at the origin"
         out = {
-            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri {args.scene} scene, {args.view if args.scene == 'soup' else 'interior'} view (secondary config{', sample-parallel: whole frames per GPU' if sample_parallel else ''})", "value": round(value, 2), "unit": "Mray/s",
+            "metric": "Mray/s (primary+1 bounce) at 1920x1080, 1M-tri scene" if headline else f"Mray/s (RayDepth {depth}) at {W}x{H}, {args.tris}-tri {args.scene} scene, {args.view if args.scene == 'soup' else 'interior'} view (secondary config{', sample-parallel: whole frames per GPU' if sample_parallel else ''}{', ' + str(world * group) + ' members SHARING ' + str(torch.cuda.device_count()) + ' visible GPU(s): control flow only, not an N-GPU number' if shared else ''})", "value": round(value, 2), "unit": "Mray/s",
             "n_gpus": world * group, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if sample_parallel else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": reps, "repeat_ms": [round(x * 1e3, 3) for x in repeat_s], "statistic": "median repetition of the timed region",
@@ -247,7 +270,8 @@ def main():
                        "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation",
                        "last_bounce": "every ray of the last bounce is traced and its radiance (sky on a miss; this scene has no emission, so hits add none) reaches the frame; the rest of that bounce's shading - new direction, throughput, Russian roulette, next queue: outputs the reference computes and nothing reads - is produced on demand (idkptDownloadRays / idkptDownloadAliveQueue / scene updates), bit-identical (DESIGN.md 4; option defer_last)", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("contiguous strips + per-bounce alive-count exchange + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
                        "bvh_build_s": round(build_s, 2), "blas_build_ms": blas_build_ms, "bvh_builder": builder_kind,
-                       "n_gpu": n_gpu_report(torch, dist, world, group)},
+                       "blas_build_note": "blas_build_ms is the wall time of DeviceBuilder.build_blas as this script sees it: the device build (16 ms) + the download of nodes and triangles (23 ms together, profiles/r03_blas_build.txt) + numpy marshalling of 1 M triangles and the first call's allocations; untimed set-up, outside the metric",
+                       "n_gpu": n_gpu_report(torch, dist, world, group, pt, st, B, depth, args, ranks_counted, selftest)},
             "roofline": roofline(st, pairs * reps / group, tri_tests * reps / group, traversed * reps / group, args, world * group, B if rem == 0 else (rem if q == 0 else None), torch, device),
         }
         if args.pmc_child:
@@ -271,7 +295,10 @@ def main():
             if args.scene == "soup":
                 out["interior"] = interior_extras(S, pt, W, H, B)
                 out["atrium"] = atrium_extras(S, NativeBuilder, pt, W, H, B)
+                out["multi_blas"] = multi_blas_extras(S, NativeBuilder, pt, B)
+                out["animated"] = animated_extras(S, NativeBuilder, pt)
                 pt.UploadScene(scene)
+                out["queries"] = query_extras(S, pt, scene, cam)
             pt.SetCamera(cam); pt.RayDepth = depth; pt.set_max_batch(B)
         if world * group == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, scene, depth, args.view)
@@ -281,16 +308,25 @@ def main():
         dist.destroy_process_group()
 
 
-def n_gpu_report(torch, dist, world, group):
-    """What the N > 1 run actually ran on (tools/scale_selftest.py checks the same things and the bits): devices, peer access, ranks RCCL saw."""
+def n_gpu_report(torch, dist, world, group, pt=None, st=None, B=None, depth=None, args=None, ranks_counted=None, selftest=None):
+    """What the N > 1 run actually ran on (tools/scale_selftest.py checks the same things and the bits): devices, peer access, ranks RCCL saw, whether members
+    share GPUs, and how large this rank's traversal launches were — a poor scaling point then reads as "launches at the latency floor of their longest rays"
+    (~1 M rays per launch) or as "exchange", not as a riddle."""
     if world * group == 1:
         return None
     try:
         ndev = torch.cuda.device_count()
         ids = sorted({d % ndev for d in range(group)}) if group > 1 else list(range(min(ndev, world)))
-        rep = {"visible_devices": ndev, "devices_used": ids, "peer_access": [[1 if i == j else int(torch.cuda.can_device_access_peer(i, j)) for j in ids] for i in ids]}
+        rep = {"visible_devices": ndev, "members_or_ranks": world * group, "devices_used": ids, "members_share_gpus": bool(group > ndev),
+               "peer_access": [[1 if i == j else int(torch.cuda.can_device_access_peer(i, j)) for j in ids] for i in ids]}
         if world > 1:
-            rep["ranks"] = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size()}
+            rep["ranks"] = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "ranks_counted_by_all_reduce": ranks_counted}   # (every rank added 1 in an all-reduce: the collective itself says how many ranks RCCL connected)
+        if st is not None and B:
+            ac = st["alive_counts"]; per_batch = min(B, args.steps) if args is not None else B
+            rep["rank0_launches"] = {"samples_per_launch": per_batch, "primary_rays_per_launch": int(ac[0] * per_batch), "bounce_rays_per_launch": [int(a * per_batch) for a in ac[1:depth]],
+                                     "avg_trace_launch_us": round(st["trace_ms_total"] * 1e3 / max(1, st["trace_launches"]), 1), "trace_launches": int(st["trace_launches"]),
+                                     "row_deal": "bands of 8 rows, (y // 8) % N" if world > 1 else "one multi-device context (idkptSetGroupSharding AUTO: bands of 8 rows at RayDepth <= 2, strips beyond)"}
+        rep["selftest"] = selftest
         return rep
     except Exception as e:   # noqa: BLE001
         return {"error": str(e)}
@@ -308,6 +344,14 @@ def counter_pass(pt, B, depth):
         cum.append((cs["node_pair_visits"], cs["triangle_tests"], cum[-1][2] + trav, cs["rays_traced"]))
     pt.enable_counters(False)
     return cum
+
+
+def file_sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
 
 
 def gather_ceiling(set_log2_blocks=16):
@@ -402,7 +446,7 @@ def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, t
            "node_pair_visits_per_step": int(pairs / max(1, args.steps * max(1, args.repeats))), "triangle_tests_per_step": int(tri_tests / max(1, args.steps * max(1, args.repeats))),
            "hbm": {"peak": HBM_PEAK_GBS, "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 4), "counter_gbs": None, "counter_frac": None, "copy_measured_gbs": hbm_copy_gbs(torch, device),
                    "note": "algorithmic_frac > 1 is possible and says only that the bytes are served from cache; counter_* = (FETCH_SIZE + WRITE_SIZE) of this run's launches"},
-           "gather_measured": {"gbs": peak_hit, "frac": round(achieved / peak_hit, 4) if peak_hit else None, "l2_miss_set_gbs": peak_miss,
+           "gather_measured": {"gbs": peak_hit, "frac": round(achieved / peak_hit, 4) if peak_hit else None, "l2_miss_set_gbs": peak_miss, "ubench_sha16": file_sha16(os.path.join(ROOT, "tools", "ubench_lines.bin")),
                                "what": "not a guide peak: tools/ubench_lines.bin run by this bench - independent random 64-B block fetches (4 x 16-B loads per lane, the node-pair fetch), 32 waves/CU, from a 4 MB set (L2 hits) and from a 128 MB set (L2 misses served by the Infinity Cache)"}}
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # KiB -> bytes; FETCH_SIZE calibrated at 1.03 on this 64-B gather pattern (profiles/r01_bench_pmc_summary.json), no doubling
@@ -484,6 +528,80 @@ def atrium_extras(S, NativeBuilder, pt, w, h, B):
              "samples_in_flight": B, "primary_hit_fraction": round(st["alive_counts"][1] / float(w * h), 4)}
         e["single_frame"] = single_frame(pt, depth, frames=20)
         out[f"atrium_{tris // 1000}k_depth{depth}"] = e
+    return out
+
+
+def multi_blas_extras(S, NativeBuilder, pt, B):
+    """Secondary workload: the reference's DEFAULT scene shape, several models with one BLAS each and no TLAS (Source/Application.cs:484, Bvh/BVH.cs:17-25:
+    the instance loop of BVHIntersect.glsl:275-287 = k_trace2 MODE 1) and the same through the TLAS (MODE 2), against the same triangles in one BLAS."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_multi
+    from idkengine_amd.pathtracer import PathTracer
+    out = bench_multi.run(S, PathTracer, NativeBuilder(), N_TRIS, 3, "headline", RAY_DEPTH, B, W, H, pt=pt)
+    inner = bench_multi.run(S, PathTracer, NativeBuilder(), N_TRIS, 3, "interior", RAY_DEPTH, B, W, H, pt=pt)
+    out["interior_view"] = {k: inner[k] for k in ("instance_loop", "tlas", "one_blas_same_triangle_count")}
+    pt.UseTlas = 0
+    return out
+
+
+def animated_extras(S, NativeBuilder, pt, frames=64):
+    """Secondary workload (BASELINE.json configs[4], stand-in): refittable soup-1M, every vertex skinned by two joints, BLAS refit and TLAS rebuild on the device
+    every frame (ModelManager.cs:263-361), one 1-spp RayDepth-2 frame per geometry; one frame at a time and with frames in flight through scene versions."""
+    import numpy as np
+    from idkengine_amd import gputypes as T
+    sc = S.soup_scene(N_TRIS, NativeBuilder(), seed=1, refittable=True)
+    nv = len(sc.vertex_positions)
+    un = np.zeros(nv, T.GpuUnskinnedVertex)
+    un["Position"] = sc.vertex_positions; un["Normal"] = sc.vertices["Normal"]; un["Tangent"] = sc.vertices["Tangent"]; un["JointIndices"][:, 1] = 1
+    wgt = (0.5 + 0.5 * np.sin(sc.vertex_positions[:, 0] * 0.7)).astype(np.float32); un["JointWeights"][:, 0] = wgt; un["JointWeights"][:, 1] = 1.0 - wgt
+    pt.UploadScene(sc); pt.SetCamera(S.Camera(W, H)); pt.RayDepth = 2; pt.UseTlas = 0
+    pt.UploadUnskinnedVertices(un)
+
+    def joints(t):
+        j = np.zeros((2, 3, 4), np.float32); j[0, :, :3] = np.eye(3)
+        c, s_ = np.cos(0.05 * np.sin(t)), np.sin(0.05 * np.sin(t))
+        j[1, :, :3] = [[c, 0, s_], [0, 1, 0], [-s_, 0, c]]; j[0, :, 3] = (0.0, 0.05 * np.sin(1.3 * t), 0.0)
+        return j
+
+    out = {"workload": "refittable soup-1M (3 M vertices), per frame: 2 joint matrices -> idkptSkin -> idkptRefitBlas -> idkptBuildTlasOnDevice -> one 1-spp RayDepth-2 frame, 1920x1080"}
+    for F in (1, 8, 32):
+        pt.SetSceneVersions(2 * F if F > 1 else 1); pt.SetFrameRing(F); pt.set_max_batch(F)
+        for rep_ in range(2):
+            pt.synchronize(); pt.reset_stats(); t0 = time.perf_counter()
+            for k in range(frames):
+                pt.UpdateBuffer(T.IDKPT_BUF_JOINT_MATRICES, joints(0.5 + 0.1 * k)); pt.Skin(0, 0, 0, nv); pt.RefitBlas(0); pt.BuildTlasOnDevice()
+                pt.BeginFrame(); pt.Compute()
+            pt.flush(); pt.synchronize(); dt = (time.perf_counter() - t0) / frames
+        out[f"frames_in_flight_{F}"] = {"mray_s": round(pt.stats()["rays_traced"] / frames / dt / 1e6, 1), "ms_per_animated_frame": round(dt * 1e3, 4), "scene_versions": 2 * F if F > 1 else 1}
+    pt.SetSceneVersions(1); pt.SetFrameRing(1)
+    return out
+
+
+def query_extras(S, pt, scene, cam):
+    """The adjacent consumers: idkptTraceRays (closest / any hit, BVHIntersect.glsl:183-411) on one primary ray per pixel, and idkptTraceShadows
+    (Shaders/ShadowsRayTraced/compute.glsl) on the G-buffer of those hits.  Thread-per-ray kernels on the general traversal code; the times are whole calls,
+    i.e. they include the PCIe copies of the ray / hit arrays (64 B per ray) and of the G-buffer."""
+    import numpy as np
+    from idkengine_amd import gputypes as T
+    rays = S.primary_ray_queries(cam, W, H)
+    pt.TraceRays(rays[:4096])
+    out = {"workload": f"soup-{N_TRIS}, {W}x{H}: one ray per pixel centre; times are whole calls incl. host <-> device copies (32 B per ray in, 32 B per hit out)"}
+    for name, any_hit in (("closest_hit", False), ("any_hit", True)):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); hits = pt.TraceRays(rays, any_hit=any_hit); ts.append(time.perf_counter() - t0)
+        out[name] = {"mray_s": round(len(rays) / statistics.median(ts) / 1e6, 1), "ms_per_call": round(statistics.median(ts) * 1e3, 3), "rays": int(len(rays))}
+    hits = pt.TraceRays(rays)
+    depth, normal = S.gbuffer_from_hits(scene, cam, W, H, rays, hits)
+    lights = S.make_lights([((0.0, 30.0, 10.0), 0.5, (50.0, 50.0, 50.0))])
+    pt.UpdateBuffer(T.IDKPT_BUF_LIGHTS, lights); pt._check(pt._L.idkptSetLightCount(pt._ctx, 1))
+    prm = T.ShadowParams.make(cam.inv_proj_view, W, H, light_index=0, samples=1, noise_index=0, jitter=(0.0, 0.0))
+    pt.TraceShadows(prm, depth, normal)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); pt.TraceShadows(prm, depth, normal); ts.append(time.perf_counter() - t0)
+    out["rt_shadows"] = {"mray_s": round(W * H / statistics.median(ts) / 1e6, 1), "ms_per_call": round(statistics.median(ts) * 1e3, 3), "shadow_rays": W * H, "samples": 1}
+    pt._check(pt._L.idkptSetLightCount(pt._ctx, 0))
     return out
 
 
@@ -625,6 +743,25 @@ def cpu_baseline(S, scene, depth, view):
            "primary_only_csharp_semantics": {"value": round(p_rays / p_dt / 1e6, 3), "unit": "Mray/s", "per_core": round(p_rays / p_dt / 1e6 / eff[0], 4),
                                              "sample": f"{p_rays // (W * H)} full {W}x{H} frames of centre-of-pixel primary rays, closest hit only (no shading), {p_dt:.1f} s"},
            "note": "a reported baseline, not the target: the GPU/CPU ratio says nothing about kernel quality (roofline.frac does)"}
+    # BASELINE.json configs[0]: Cornell box (32 triangles), 256x256, through the reference's CPU traversal path (C# semantics, Gui.cs:1484-1503) — primary rays —
+    # and, as "primary + 1 bounce", the oracle's port of the whole path at RayDepth 2 on the same frame
+    try:
+        from idkengine_amd.bvh import NativeBuilder
+        csc = S.cornell_scene(NativeBuilder(), variant="diffuse"); ccam = S.cornell_camera(256, 256)
+        O.cpu_trace_primary(csc, ccam, 256, 256, threads=cores, want_hits=False)
+        c_rays, c_dt = 0, 0.0
+        while c_dt < 1.0:
+            t0 = time.perf_counter(); rr = O.cpu_trace_primary(csc, ccam, 256, 256, threads=cores, want_hits=False); c_dt += time.perf_counter() - t0; c_rays += int(rr["rays"])
+        co = O.OraclePathTracer(csc, 256, 256); co.set_camera(ccam); co.settings.RayDepth = 2; co.render(); r0 = co.stats()["rays_traced"]
+        o_dt, reps = 0.0, 0
+        while o_dt < 1.0:
+            t0 = time.perf_counter(); co.render(); o_dt += time.perf_counter() - t0; reps += 1
+        o_rays = co.stats()["rays_traced"] - r0; co.close()
+        out["cornell_256"] = {"workload": "BASELINE.json configs[0]: Cornell box (32 triangles), 256x256, 1 spp", "cores": eff[0], "omp_threads": cores,
+                              "primary_only_csharp_semantics_mray_s": round(c_rays / c_dt / 1e6, 3), "primary_plus_1_bounce_oracle_port_mray_s": round(o_rays / o_dt / 1e6, 3),
+                              "sample": f"{c_rays // 65536} frames of primary rays in {c_dt:.1f} s; {reps} RayDepth-2 frames of the oracle port in {o_dt:.1f} s"}
+    except Exception as e:   # noqa: BLE001
+        out["cornell_256"] = {"error": str(e)}
     if view == "headline":
         inter = measure(view_camera(S, "interior", W, H), 6.0)
         out["interior_view"] = {"value": inter["value"], "parallel_section_mray_s": inter["parallel_section"], "mray_s_per_core": inter["per_core"], "sample": inter["sample"]}

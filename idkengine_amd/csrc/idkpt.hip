@@ -734,8 +734,11 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     if (sc->Lights && sc->LightCount) HIPC(hipMemcpyAsync(ctx->lights.p, sc->Lights, (size_t)sc->LightCount * sizeof(GpuLight), hipMemcpyHostToDevice, ctx->stream));
     {   // can a surface of this scene add radiance?  (k_shade_last: without emission the last bounce's hits leave the radiance alone)
         bool none = true;
-        for (int i = 0; i < sc->MaterialCount && none; i++) { const GpuMaterial& m = sc->Materials[i]; none = m.EmissiveFactor[0] == 0.0f && m.EmissiveFactor[1] == 0.0f && m.EmissiveFactor[2] == 0.0f; }
-        for (int i = 0; i < sc->MeshCount && none; i++) none = sc->Meshes[i].EmissiveBias == 0.0f;
+        // (... and can the throughput a hit is shaded with be relied on to be finite when it came in finite?  Volumetric absorption multiplies it by exp(-absorbance x T)
+        // BEFORE the emission is added (ShadeHit): an infinite Absorbance / AbsorbanceBias with T == 0 makes it NaN, and 0 x NaN is not 0 — such scenes shade every hit)
+        auto fin = [](float v) { return v - v == 0.0f; };
+        for (int i = 0; i < sc->MaterialCount && none; i++) { const GpuMaterial& m = sc->Materials[i]; none = m.EmissiveFactor[0] == 0.0f && m.EmissiveFactor[1] == 0.0f && m.EmissiveFactor[2] == 0.0f && fin(m.Absorbance[0]) && fin(m.Absorbance[1]) && fin(m.Absorbance[2]); }
+        for (int i = 0; i < sc->MeshCount && none; i++) none = sc->Meshes[i].EmissiveBias == 0.0f && fin(sc->Meshes[i].AbsorbanceBias[0]) && fin(sc->Meshes[i].AbsorbanceBias[1]) && fin(sc->Meshes[i].AbsorbanceBias[2]);
         for (int i = 0; i < sc->TextureCount && none; i++) {      // (0 x a texel is only 0 for a finite texel)
             const idkpt_texture& t = sc->Textures[i];
             if (!(t.width > 0 && t.height > 0 && t.rgba)) { none = false; break; }

@@ -28,8 +28,8 @@ static inline bool internal(const Node& n) { return n.count == 0 && n.startOrChi
 
 // newSlot[k] = slot of pair k (nodes 2k, 2k+1) in the derived array; slots 0 (unused node + root) and 1 (the root's children) stay.
 // basePair = global pair index of this BLAS's pair 0 (NodeOffset / 2): 128-B alignment is a property of the whole array.
-// mode 0: identity; 1: couples + depth-first; 2: couples + treelets.  Returns false (identity) when the tree is not made of aligned
-// pairs (an odd child index: never produced by the reference's builder, legal for the traversal).
+// mode 0: identity; 1: couples + depth-first; 2: couples + treelets.  Returns false (identity) when the nodes are not a tree of aligned
+// pairs (an odd child index, a child pair with two parents: never produced by the reference's builder, legal for the traversal).
 static bool compute(const Node* nodes, int nodeCount, uint32_t basePair, int mode, int treeletDepth, std::vector<uint32_t>& newSlot)
 {
     const int P = nodeCount / 2;
@@ -38,13 +38,18 @@ static bool compute(const Node* nodes, int nodeCount, uint32_t basePair, int mod
     if (mode == 0 || P <= 2) return true;
     // child pairs and their weights
     std::vector<int> ch((size_t)2 * P, 0); std::vector<double> w((size_t)2 * P, 0.0);
+    std::vector<char> referenced((size_t)P, 0);
     for (int k = 0; k < P; k++) for (int i = 0; i < 2; i++) {
         const int n = 2 * k + i;
         if (n == 0) continue;                                   // node 0 is unused (the root is node 1)
         const Node& nd = nodes[n];
         if (!internal(nd)) continue;
-        if ((nd.startOrChild & 1u) || (int)(nd.startOrChild / 2) <= k || (int)(nd.startOrChild / 2) >= P) { for (int q = 0; q < P; q++) newSlot[q] = (uint32_t)q; return false; }
-        ch[n] = (int)(nd.startOrChild / 2); w[n] = half_area(nd);
+        const int c = (int)(nd.startOrChild / 2);
+        // not a tree of aligned pairs -> identity: an odd child index, or a child pair that two nodes share (a DAG: legal for the traversal — the validation only asks
+        // for children behind their parent — but the layout below would emit such a pair once per path to it and run past the BLAS's pair range)
+        if ((nd.startOrChild & 1u) || c <= k || c >= P || referenced[c]) { for (int q = 0; q < P; q++) newSlot[q] = (uint32_t)q; return false; }
+        referenced[c] = 1;
+        ch[n] = c; w[n] = half_area(nd);
     }
     // maximum-weight matching of parent/child pairs (tree DP, children have larger indices than their parents)
     std::vector<double> f0((size_t)P, 0.0), f1((size_t)P, -1.0); std::vector<signed char> pick((size_t)P, -1);

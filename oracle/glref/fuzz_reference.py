@@ -30,7 +30,7 @@ def run_case(seed, builder, G, O, T, configs, glref_check, draw_case):
     pt = G.ReferencePathTracer(sc, w, h, st1, sky_nearest=distinct_1x1); pt.set_camera(cam); pt.render()
     ref_rays, ref_q = pt.rays(T.GpuWavefrontRay), np.asarray(pt.final_alive, np.uint32); pt.accumulated = 0
     cur = oracle_state(1)
-    rep = {"seed": seed, "size": [w, h], "triangles": int(len(sc.blas_triangles)), "settings": ov, "stages": 0, "rays": 0, "flips": 0, "beyond_tol": 0, "key_diffs": 0, "max_rel": 0.0, "beyond_by_field": {}}
+    rep = {"seed": seed, "size": [w, h], "triangles": int(len(sc.blas_triangles)), "settings": ov, "textured": bool(len(sc.textures)), "stages": 0, "rays": 0, "flips": 0, "beyond_tol": 0, "key_diffs": 0, "max_rel": 0.0, "beyond_by_field": {}}
 
     def add(ids, cand, ref, cand_q, rq):
         flips = np.setxor1d(cand_q, rq)
@@ -83,6 +83,8 @@ def main():
            "beyond_tol": sum(r["beyond_tol"] for r in reps), "key_diffs": sum(r["key_diffs"] for r in reps), "max_rel_within_tol": max(r["max_rel"] for r in reps),
            "worst_error_of_the_rays_beyond_tolerance_by_field": {f: max(r["beyond_by_field"].get(f, 0.0) for r in reps) for f in glref_check.FIELDS if any(f in r["beyond_by_field"] for r in reps)},
            "cases_with_a_flip_or_a_value_beyond_tolerance": [r["seed"] for r in reps if r["flips"] or r["beyond_tol"]], "seconds": round(time.time() - t0, 1),
+           "textured_cases": sum(1 for r in reps if r["textured"]), "beyond_tol_in_textured_cases": sum(r["beyond_tol"] for r in reps if r["textured"]), "beyond_tol_in_untextured_cases": sum(r["beyond_tol"] for r in reps if not r["textured"]),
+           "worst_throughput_or_radiance_error_beyond_tolerance": max([max(r["beyond_by_field"].get("Throughput", 0.0), r["beyond_by_field"].get("Radiance", 0.0)) for r in reps] + [0.0]),
            "gate": {"rel_tol": glref_check.REL_TOL, "abs_floor": glref_check.ABS_FLOOR}}
     print(json.dumps(tot))
     if out:

@@ -209,6 +209,12 @@ def check_traversal_cost(fx, pairs, tri_tests):
     return {"pairs_plus_1.1_tests": mine, "reference_debugCost_sum": ref, "relative_difference": abs(mine - ref) / ref}
 
 
+# Random cases through the reference's shaders (oracle/glref/fuzz_reference.py): what may lie beyond the 1e-4 gate, and why.  llvmpipe's bilinear `texture()` and the
+# restated filter differ by up to 1.5e-4 absolute on one or two texels of a frame (GL leaves the precision of the filter weights to the implementation; hardware
+# samplers use 8-bit sub-texel weights, 2e-3), and a small throughput / radiance component turns that into a larger RELATIVE error.  So: textured cases only, at most
+# one ray in 10 000 of a run, at most 3e-3 in throughput / radiance (1 400 seeds of round 3: 7e-5 of the rays, worst 2.6e-3; profiles/r03_reference_fuzz*.json).
+# Untextured cases get no allowance here (the two lobe flips of those 1 400 seeds are outside the 60 seeds this gate runs on).
+SAMPLER_SPREAD_ALLOW = {"max_fraction_of_rays": 1e-4, "max_throughput_or_radiance_error": 3e-3, "untextured_rays_beyond": 0, "alive_flips": 0, "key_diffs": 0}
 FULL_ALLOW_FREE = {"full_headline_d2": 8, "full_atrium1m_d2": 9}     # pixels of the free-running two-sample frame beyond tolerance: pixels of the listed closest-hit rays
 
 

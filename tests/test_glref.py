@@ -175,3 +175,20 @@ def test_live_reference_fuzz_first_seeds():
     tot = json.loads(r.stdout.strip().splitlines()[-1])
     assert tot["cases"] == 12 and tot["stages"] >= 30 and tot["rays"] > 40000
     assert tot["flips"] == 0 and tot["beyond_tol"] == 0 and tot["key_diffs"] == 0, tot
+
+
+@live
+def test_live_reference_fuzz_textured_cases_within_the_sampler_spread():
+    """60 random cases (24 of them textured, 204 stages, 250 000 rays) through the reference's shaders: everything untextured inside the 1e-4 gate, no alive decision
+    and no sort key differs, and what textured cases leave beyond the gate stays inside the named, bounded allowance for the spread of GL's bilinear filter weights
+    (glref_check.SAMPLER_SPREAD_ALLOW: at most 1e-4 of the rays, at most 3e-3, textured cases only) — the finding of profiles/r03_reference_fuzz.json as a gate."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "fuzz_reference.py"), "60", "0"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    tot = json.loads(r.stdout.strip().splitlines()[-1])
+    A = glref_check.SAMPLER_SPREAD_ALLOW
+    assert tot["cases"] == 60 and tot["textured_cases"] >= 15 and tot["rays"] > 200000
+    assert tot["flips"] <= A["alive_flips"] and tot["key_diffs"] <= A["key_diffs"], tot
+    assert tot["beyond_tol_in_untextured_cases"] <= A["untextured_rays_beyond"], tot
+    assert tot["beyond_tol_in_textured_cases"] <= A["max_fraction_of_rays"] * tot["rays"], tot
+    assert tot["worst_throughput_or_radiance_error_beyond_tolerance"] <= A["max_throughput_or_radiance_error"], tot
+    assert set(tot["worst_error_of_the_rays_beyond_tolerance_by_field"]) <= {"Throughput", "Radiance"}, tot       # (no origin, no direction: no other lobe, no other hit)

@@ -103,3 +103,18 @@ def test_unaligned_child_index_keeps_the_reference_order(layout_lib, native_buil
     nodes["TriStartOrChild"][k] += 1            # an odd child index: legal for the traversal (any two consecutive nodes), never built by the reference
     ok, slot = _slots(layout_lib, nodes, 0, 1)
     assert not ok and (slot == np.arange(len(slot))).all()
+
+
+def test_shared_child_pair_keeps_the_reference_order(layout_lib, native_builder):
+    """Two internal nodes that point at the same child pair (a DAG): legal for the traversal — the upload validation only asks for children behind their
+    parent — but not a tree; the layout would emit the shared pair once per path and run past the BLAS's pair range.  It must fall back to the identity."""
+    from idkengine_amd import scenes as S
+    sc = S.soup_scene(800, native_builder, seed=2)
+    nodes = sc.blas_nodes.copy()
+    inner = np.nonzero((nodes["TriCount"] == 0) & (nodes["TriStartOrChild"] != 0) & (np.arange(len(nodes)) >= 2))[0]
+    a, b = int(inner[0]), int(inner[1])                     # b lies behind a; both get the child pair of the LATER one (still behind both parents)
+    later = max(int(nodes["TriStartOrChild"][a]), int(nodes["TriStartOrChild"][b]))
+    nodes["TriStartOrChild"][a] = later; nodes["TriStartOrChild"][b] = later
+    for mode in (1, 2):
+        ok, slot = _slots(layout_lib, nodes, 0, mode)
+        assert not ok and (slot == np.arange(len(slot))).all()

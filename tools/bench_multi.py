@@ -20,9 +20,10 @@ def measure(pt, depth, B, steps):
     pt.RayDepth = depth
     # exact visit counts of one displayed frame (B samples, counting build)
     pt.set_max_batch(1); pt.enable_counters(True); pt.reset_stats(); pt.ResetAccumulation()
+    trav_total = 0
     for _ in range(B):
-        pt.Compute()
-    pt.synchronize(); cs = pt.stats()
+        pt.Compute(); pt.synchronize(); cs = pt.stats()
+        trav_total += cs["alive_counts"][0] + sum(cs["alive_counts"][1:depth])      # rays of this sample that entered the traversal kernel
     pairs, tris = cs["node_pair_visits"], cs["triangle_tests"]
     pt.enable_counters(False)
     # batched
@@ -38,7 +39,7 @@ def measure(pt, depth, B, steps):
         pt.synchronize(); ts.append(time.perf_counter() - t0)
     st = pt.stats(); pt.enable_timing(False)
     rays = st["rays_traced"] / 5.0
-    trav = (st["alive_counts"][0] + sum(st["alive_counts"][1:depth]))          # of the last sample
+    trav = trav_total / float(B)                                                # traversed rays per step (mean over the displayed frame's samples)
     dt = statistics.median(ts)
     frames_counted = 5.0 * steps
     alg_bytes = (64.0 * pairs + 48.0 * tris) / B * frames_counted + 72.0 * trav * frames_counted
