@@ -60,9 +60,10 @@ struct DevOptions {
     int traceOrder = 0;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order (default: L2 hit rate 0.62 -> 0.88, launch -7 %, the permutation costs more), 1 = batches of >= 4 samples, 2 = always
     int traceVariant = 0;        // IDKPT_DEVELOPER builds only: instrumented / probe instantiations of k_trace2
     int bvhTiming = 0, bvhSmall = 32;   // idkptBuildBlasCore: phase times on stderr; subtrees of at most this many fragments are finished by one thread
+    int instanceRecords = 0;     // (default 0: measured slower as a whole — the records cost the producers more than they save the traversal, profiles/r04_multi_blas.md) scenes of 2..MAX_REC_INSTANCES instances (and USE_TLAS scenes of up to that many): one trace-ready record per (ray, instance), written by the producers (MODE 3 / 4 of k_trace2); 0: the instance entry is computed inside the traversal kernel (MODE 1 / 2)
     int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
     int splitDonor = 1;          // k_trace2s: 1 = only rays that have not hit anything yet donate subtrees, 0 = every busy lane does
-    int split = 0;               // k_trace2s (long rays split across the idle lanes of their wave once the work list is empty): 0 = never, 1 = launches below SPLIT_MAX_RAYS rays (default), 2 = every launch, 3 = every launch + every split ray traced again (test hook for the re-trace path)
+    int split = 1;               // k_trace2s (long rays split across the idle lanes of their wave once the work list is empty): 0 = never, 1 = small launches of sparse views (default, want_split), 2 = every launch, 3 = every launch + every split ray traced again (test hook for the re-trace path)
     int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
 };
 
@@ -183,22 +184,23 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
     }
     if (s.ver) {                    // scene versions: the samples of this batch see different states of the geometry (VER instantiations, kernels_trace.hpp)
 #define T2VER(C, M) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 32, 1, false, 24, M, 0, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
-        if (f.useTlas) { if (ctx->counters) T2VER(true, 2); else T2VER(false, 2); }
-        else if (ctx->instanceCount > 1) { if (ctx->counters) T2VER(true, 1); else T2VER(false, 1); }
+        const bool rec = f.recPerRay > 1;      // per-instance trace-ready records (scenes of up to MAX_REC_INSTANCES instances): MODE 3 / 4 instead of 1 / 2
+        if (f.useTlas) { if (rec) { if (ctx->counters) T2VER(true, 4); else T2VER(false, 4); } else { if (ctx->counters) T2VER(true, 2); else T2VER(false, 2); } }
+        else if (ctx->instanceCount > 1) { if (rec) { if (ctx->counters) T2VER(true, 3); else T2VER(false, 3); } else { if (ctx->counters) T2VER(true, 1); else T2VER(false, 1); } }
         else { if (ctx->counters) T2VER(true, 0); else T2VER(false, 0); }
 #undef T2VER
         return;
     }
-    if (f.useTlas) {                // TLAS walk inside the kernel
-        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 2>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
-        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 2>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+#define T2M(C, M) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 32, 1, false, 24, M>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+    if (f.useTlas) {                // TLAS walk inside the kernel (MODE 4: the leaves' instance entries come from per-instance records, MODE 2: computed in the kernel)
+        if (f.recPerRay > 1) { if (ctx->counters) T2M(true, 4); else T2M(false, 4); } else { if (ctx->counters) T2M(true, 2); else T2M(false, 2); }
         return;
     }
-    if (ctx->instanceCount > 1) {   // instance loop inside the kernel
-        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
-        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 1>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+    if (ctx->instanceCount > 1) {   // instance loop inside the kernel (MODE 3: per-instance records, MODE 1: computed in the kernel)
+        if (f.recPerRay > 1) { if (ctx->counters) T2M(true, 3); else T2M(false, 3); } else { if (ctx->counters) T2M(true, 1); else T2M(false, 1); }
         return;
     }
+#undef T2M
     if (ctx->counters) { hipLaunchKernelGGL((k_trace2<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return; }
 #ifdef IDKPT_DEVELOPER
     switch (ctx->opt.traceVariant) {   // developer builds (libidkpt_dev.so, option "trace_variant"): s_memtime-instrumented and probe instantiations; results are bit-identical
@@ -964,6 +966,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "defer_last") o.deferLast = value != 0;
     else if (n == "split") { REQUIRE(value >= 0 && value <= 3, "idkptSetDeveloperOption: split is 0..3"); o.split = value; }
     else if (n == "split_donor") o.splitDonor = value != 0;
+    else if (n == "instance_records") o.instanceRecords = value != 0;
     else if (n == "spec") {
 #ifdef IDKPT_DEVELOPER
         REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: spec is 0..2"); o.spec = value;
@@ -1708,12 +1711,18 @@ static bool fast_path(dev_ctx* ctx) { return ctx->instanceCount >= 1 && !ctx->st
 // Which traversal kernel a launch gets: k_trace2s (kernels_trace_split.hpp: long rays split across the idle lanes of their wave once the work list is empty) pays
 // where a launch ends with a few long rays on an otherwise idle chip — launches of up to SPLIT_MAX_RAYS rays (a frame traced alone, the bounce launches of small
 // batches, one rank's share of an N-GPU frame); its extra registers (one wave per SIMD less) cost large launches more than their tails are worth.
-#define SPLIT_MAX_RAYS 4000000u
-static bool want_split(const dev_ctx* ctx, uint32_t prev, bool known)
+// Measured (profiles/r04_small_launch_experiments.md): headline view one frame at a time (0.36 M + 0.28 M rays per launch) +8 %, three samples in flight +4 %, one
+// rank's share of an 8 / 4-GPU frame +12 % / +5 %; the atrium and the interior view one frame at a time (1.9-2.1 M rays per launch, every pixel traverses) -10 % / -1.5 %.
+// So: launches of fewer than SPLIT_MAX_RAYS rays, and only on views where most pixels miss the scene's root box (fewer than half of the primary rays entered the
+// traversal in the previous batch) — there the launch time is the dependent chain of the rays that cross the whole scene without hitting anything.
+#define SPLIT_MAX_RAYS 1500000u
+static bool want_split(const dev_ctx* ctx, uint32_t prev, bool known, int samples)
 {
     if (ctx->opt.split == 0) return false;
     if (ctx->opt.split >= 2) return true;
-    return known && prev > 0u && prev < SPLIT_MAX_RAYS;
+    const uint64_t pixels = (uint64_t)ctx->W * ctx->rows * (uint64_t)std::max(1, samples);
+    const bool sparse = ctx->lastFast && ctx->lastBatch == samples && (uint64_t)ctx->hCounts[MAX_DEPTH_SLOTS - 1] * 2u < pixels;
+    return known && sparse && prev > 0u && prev < SPLIT_MAX_RAYS;
 }
 #define SPEC_MAX_RAYS 1500000u
 static bool want_spec(const dev_ctx* ctx, uint32_t prev, bool known)
@@ -1811,6 +1820,10 @@ static int flush_batch(dev_ctx* ctx)
     f.stackCap = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack);
     f.outputAovs = ctx->st.OutputAOVs;
     f.batch = B; f.Npad = Npad;
+    // trace-ready records per ray id (pt_kernels.hpp Frame::recPerRay): one, or one per instance (+ the world ray under USE_TLAS) on scenes of few instances
+    f.recPerRay = 1;
+    if (ctx->opt.instanceRecords && ctx->instanceCount <= MAX_REC_INSTANCES && (ctx->instanceCount > 1 || ctx->st.UseTlas)) f.recPerRay = ctx->instanceCount + (ctx->st.UseTlas ? 1 : 0);
+    HIPC(ctx->trRec.ensure((size_t)ctx->maxBatch * Npad * 64 * (size_t)f.recPerRay));   // (grows on the first batch of such a scene; nothing of an earlier batch is read from it: a deferred last bounce is dropped below)
     for (int k = 0; k < MAX_BATCH; k++) { f.accum[k] = k < B ? ctx->pending[k].accum : 0u; f.slotOf[k] = (uint32_t)(k < B ? ctx->pending[k].slot : 0); }
     f.seqFirst = ctx->seqFirst; f.seqStride = ctx->seqStride;
     f.accumulated = f.seqFirst + f.accum[0] * f.seqStride;
@@ -1906,7 +1919,7 @@ static int flush_batch(dev_ctx* ctx)
             uint32_t grid0 = traceGrid;
             if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4, midGrid);
             launch_trace2<true>(ctx, grid0, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters,
-                                want_split(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B), want_spec(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B));
+                                want_split(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B), want_spec(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B));
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
             if (multiVer) hipLaunchKernelGGL((k_shade_first<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
@@ -1998,7 +2011,7 @@ static int flush_batch(dev_ctx* ctx)
         const int hintMul = ctx->opt.gridHint;
         if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) gridj = small_launch_grid(traceGrid, ctx->hBases[(size_t)j * BS + B], hintMul, ctx->opt.gridRaysX4, midGrid);
         if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, trj, hits, (const uint32_t*)q, cnt, work + j, counters,
-                                       want_split(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr),
+                                       want_split(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr, B),
                                        want_spec(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr));
         else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
@@ -2267,7 +2280,7 @@ static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
     uint64_t c[4] = {0, 0, 0, 0};
     HIPC(hipMemcpyAsync(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
-    if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13]); }
+    if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu | leafTests %llu leafTrips %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13], (unsigned long long)d[14], (unsigned long long)d[15]); }
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
     *out = s;
     return IDKPT_OK;

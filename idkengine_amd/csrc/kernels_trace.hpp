@@ -226,7 +226,8 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
         }
         f3 radiance = splat3(0.0f);
         if (keep) {
-            tr.rec[4 * (size_t)rid] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)rid + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.rec[4 * (size_t)rid + 2] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f);
+            if (f.recPerRay > 1) write_instance_records(s, f, tr, rid, origin, rd);           // one record per instance (+ the world ray under USE_TLAS): the traversal kernel only loads them
+            else { tr.rec[4 * (size_t)rid] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)rid + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.rec[4 * (size_t)rid + 2] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f); }
             if (!lean) seedOut[rid] = seed;                             // RNG state after ray generation, consumed by k_shade_first
         } else {
             // miss branch of FirstHit TraceRay (FirstHit/compute.glsl:225-233), evaluated right here
@@ -274,7 +275,10 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
 template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0, bool VER = false>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
-    constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
+    // MODE 3 / 4: MODE 1 / 2 on scenes of up to MAX_REC_INSTANCES instances, whose producers (k_gen_primary, the shading kernels) leave one trace-ready record per
+    // (ray, instance) — the ray in the instance's space, the root-box tMin, the BLAS's node / triangle offsets (write_instance_records, pt_kernels.hpp): entering an
+    // instance is three loads and a compare here instead of a matrix fetch, 27 multiply-adds, three IEEE divisions and a slab test run by a handful of lanes.
+    constexpr bool MULTI = MODE != 0, TLAS = MODE == 2 || MODE == 4, REC = MODE >= 3;
     // DBG 8 ("speculative touch", developer build only): as soon as a node pair has arrived, one word of each place the ray can go next is requested — both
     // children (the child pair of an internal child, the first triangle record of a leaf child) and the pair on top of the stack — before the box tests run, so
     // that the fetch of whichever becomes the next step overlaps with this step's ~100 dependent instructions instead of following them.  Nothing of the traversal
@@ -402,17 +406,25 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                     const float4 pmin = tl4[2 * (size_t)instIdx];
                     const uint32_t packed = __float_as_uint(pmin.w), id = packed & 0x7fffffffu;
                     if ((packed >> 31) == 1u) {                                             // leaf: BVHIntersect.glsl:223-240
+                        if (REC) {                                                          // the ray in this instance's space: prepared by the kernel that produced the ray
+                            const float4* r4 = rec_at(tr, f, rayId, id);
+                            const float4 a = r4[0], b = r4[1], c = r4[2];
+                            ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z);
+                            nodeOff = __float_as_uint(b.w); triOff = __float_as_uint(c.w); xformId = id;      // (xformId holds the INSTANCE here; its MeshTransformId is looked up when the hit is stored)
+                        } else {
                         const GpuBlasInstance in2 = s.instances[id];
                         const M34 inv = load_inv_model_at(VER ? s.xforms + vXform : s.xforms, in2.MeshTransformId);
                         float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];
                         ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                         invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
+                        }
                         sp = stkBase; top = 2u;                                             // no root test under USE_TLAS (:32)
                         if (tsp == 0 || tsp > f.tlasCap) moreInst = false; else instIdx = tstk[--tsp * WAVE];  // the pop the reference does after the BLAS; order-independent
                     } else {
                         const uint32_t l = id, r = id + 1;
-                        float4 a = tr.rec[4 * (size_t)rayId], c = tr.rec[4 * (size_t)rayId + 2];                         // world-space origin and 1/dir
+                        const float4* w4 = REC ? rec_at(tr, f, rayId, (uint32_t)s.instanceCount) : tr.rec + 4 * (size_t)rayId;
+                        float4 a = w4[0], c = w4[2];                                                                          // world-space origin and 1/dir
                         const f3 wo = mk3(a.x, a.y, a.z), winv = mk3(c.x, c.y, c.z);
                         float4 lmin = tl4[2 * (size_t)l], lmax = tl4[2 * (size_t)l + 1], rmin = tl4[2 * (size_t)r], rmax = tl4[2 * (size_t)r + 1];
                         float tMinLeft, tMinRight;
@@ -430,7 +442,15 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             // lanes whose current BLAS is exhausted move on to the next instance (loop: the root test may fail right away)
             bool adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
             while (__any(adv)) {
-                if (adv) {
+                if (adv && REC) {
+                    const float4* r4 = rec_at(tr, f, rayId, instIdx);
+                    const float4 a = r4[0], b = r4[1], c = r4[2];
+                    ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z);
+                    nodeOff = __float_as_uint(b.w); triOff = __float_as_uint(c.w); xformId = instIdx;              // (the instance; its MeshTransformId is looked up when the hit is stored)
+                    const bool enter = a.w < hitT;                                                                // root test (:32-39): tMin from the record, +inf = the ray misses the root box
+                    sp = stkBase; top = enter ? 2u : 0u;
+                    instIdx++;
+                } else if (adv) {
                     const GpuBlasInstance in2 = s.instances[instIdx];
                     const M34 inv = load_inv_model_at(VER ? s.xforms + vXform : s.xforms, in2.MeshTransformId);
                     float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];                         // world-space origin / direction
@@ -499,7 +519,15 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             }
         }
         PROF_MARK(1);
-        if (PROF) { unsigned long long lm = __ballot(leafPending); if (lm) { pn[4]++; pn[5] += (unsigned long long)__popcll(lm); } }
+        if (PROF) {   // leaf phases, lanes in them, and — for the "pooled (ray, triangle) pairs" question — the triangle tests of the wave and the loop trips (= the longest lane's count)
+            unsigned long long lm = __ballot(leafPending);
+            if (lm) {
+                pn[4]++; pn[5] += (unsigned long long)__popcll(lm);
+                uint32_t cntL = leafPending ? leafEnd - leafFirst : 0u, sum = cntL, mx = cntL;
+                for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); }
+                pn[6] += sum; pn[7] += mx;
+            }
+        }
         // ---- leaf phase
         if (leafPending) {
             const uint32_t tOff = MULTI ? triOff : triOffset;
@@ -518,7 +546,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         PROF_MARK(2);
         // ---- retire finished rays (MULTI: only after the last instance)
         if (active && top == 0u && (!MULTI || (TLAS ? !moreInst : instIdx >= (uint32_t)s.instanceCount))) {
-            store_hit(hits, slot, hitT, hbx, hby, hitTri, hitXform);
+            store_hit(hits, slot, hitT, hbx, hby, hitTri, (REC && hitTri != ~0u) ? s.instances[hitXform].MeshTransformId : hitXform);   // (REC: a triangle hit remembered its instance)
             active = false;
         }
     }

@@ -103,3 +103,26 @@ def test_device_tlas_build_matches_host_build(native_builder, oracle_builder, pa
         assert (bits(a.Result) == bits(b.Result)).all()
         a.Dispose(); b.Dispose()
     pt.Dispose()
+
+
+@pytest.mark.parametrize("records", [1, 0])
+@pytest.mark.parametrize("parts,use_tlas", [(2, 0), (3, 1), (8, 0), (8, 1), (9, 1)])
+def test_instance_entries_from_records_or_computed_in_the_kernel(native_builder, oracle_mod, monkeypatch, records, parts, use_tlas):
+    """Scenes of up to 8 instances leave one trace-ready record per (ray, instance) for the traversal kernel (k_trace2 MODE 3 / 4: the instance entry is three
+    loads); option instance_records 0 — and every scene with more instances (9 here) — computes the entry inside the kernel (MODE 1 / 2).  Either way: the oracle's
+    frame bit for bit (image, ray records, alive queue, primary hits, visit counters), with lights in front of the geometry, batched, sorted."""
+    monkeypatch.setenv("IDKPT_INSTANCE_RECORDS", str(records))
+    sc = S.soup_scene_multi(5000, native_builder, parts=parts, seed=11 + parts); w, h = 150, 90
+    sc.lights = S.make_lights([((0.0, 3.0, 14.0), 0.8, (9.0, 8.0, 7.0))])
+    cam = S.Camera(w, h, position=(1.0, 0.5, 24.0))
+    ov = dict(RayDepth=4, UseTlas=use_tlas, DoTraceLights=1, DoRaySorting=1)
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=3, **ov)
+    a = gpu_render(sc, cam, w, h, frames=3, **ov)
+    assert_equal(a, o)
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    b = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); b.UploadScene(sc); b.SetCamera(cam); b.set_max_batch(3)
+    for _ in range(3):
+        b.Compute()
+    assert (bits(b.Result) == bits(o.image(0))).all() and b.rays().tobytes() == o.rays().tobytes() and (b.alive_queue() == o.alive_queue()).all()
+    a.Dispose(); b.Dispose(); o.close()

@@ -34,7 +34,8 @@ if __name__ == "__main__":
                 print(view, batch, "no profile line", p.stderr[-400:]); continue
             v = [int(x) for x in re.findall(r"\d+", prof[-1])]
             refill, node, leaf, other, refills, refLanes, steps, stepLanes, leafPhases, leafLanes = v[:10]
+            leafTests, leafTrips = (v[10], v[11]) if len(v) >= 12 else (0, 0)
             tot = float(refill + node + leaf + other)
             print(f"{view:9s} batch {batch:2d}: wave cycles refill {100 * refill / tot:5.1f} %  node phase {100 * node / tot:5.1f} %  leaf phase {100 * leaf / tot:5.1f} %  other {100 * other / tot:5.1f} % | "
                   f"{node / max(1, steps):7.0f} cycles per node step ({stepLanes / max(1, steps):4.1f} lanes), {leaf / max(1, leafPhases):7.0f} per leaf phase ({leafLanes / max(1, leafPhases):4.1f} lanes), "
-                  f"{refill / max(1, refills):7.0f} per refill ({refLanes / max(1, refills):4.1f} lanes) | {res[-1] if res else ''}", flush=True)
+                  f"{refill / max(1, refills):7.0f} per refill ({refLanes / max(1, refills):4.1f} lanes) | per leaf phase {leafTests / max(1, leafPhases):5.1f} (ray, triangle) tests in {leafTrips / max(1, leafPhases):4.2f} loop trips | {res[-1] if res else ''}", flush=True)
