@@ -383,7 +383,8 @@ def pmc_passes(args, launches):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
-    sets = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "l2": ["TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]}
+    sets = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "l2": ["TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"],
+            "sq": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES"]}   # issue side: what a cache-resident, coherent launch is limited by
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--no-pmc", "--no-extras", "--no-cpu-baseline", "--repeats", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
              "--tris", str(args.tris), "--view", args.view, "--scene", args.scene, "--depth", str(args.depth), "--sort", str(args.sort), "--width", str(args.width), "--height", str(args.height),
              "--batch", str(args.batch)] + (["--cpu-build"] if args.cpu_build else [])
@@ -396,6 +397,8 @@ def pmc_passes(args, launches):
             r = subprocess.run([exe, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "b", "--"] + child, capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
+                if name == "sq":
+                    continue                                   # (the issue-side pass is an extra: the traffic figures stand without it)
                 return None
             n_child = None
             for line in r.stdout.splitlines():
@@ -458,6 +461,14 @@ def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, t
                       "l1_miss_bytes_per_launch": int(rq * 64.0) if rq is not None else None, "l2_miss_bytes_per_launch": int(m * 128.0) if m is not None else None,
                       "l1_hit_rate": round(1.0 - rq / ac, 4) if rq is not None and ac else None, "l2_hit_rate": round(h / (h + m), 4) if h is not None and m is not None and h + m > 0 else None,
                       "units": "L1 misses = TCP_TCC_READ_REQ x 64 B; L2 misses = TCC_MISS x 128-B lines; FETCH/WRITE_SIZE KiB x 1024"}
+        if pmc.get("SQ_INSTS_VALU"):
+            # issue side (a fourth pass): wave64 VALU instructions of a launch against the slots its duration offers (256 CUs x 4 SIMDs, 2.4 clk per wave64
+            # instruction on this chip: profiles/r02_ubench_halfwave.txt, 2.4 GHz) — the figure that says something about launches whose working set is cache-resident
+            slots = avg_launch_s * 2.4e9 * 1024.0 / 2.4
+            out["pmc"]["issue"] = {"valu_insts_per_launch": int(pmc["SQ_INSTS_VALU"]), "valu_issue_frac_at_2p4clk": round(pmc["SQ_INSTS_VALU"] / slots, 4) if slots > 0 else None,
+                                   "valu_lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4) if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU") else None,
+                                   "vmem_read_insts_per_launch": int(pmc.get("SQ_INSTS_VMEM_RD", 0)), "lds_insts_per_launch": int(pmc.get("SQ_INSTS_LDS", 0)), "salu_insts_per_launch": int(pmc.get("SQ_INSTS_SALU", 0)),
+                                   "waves_per_launch": int(pmc.get("SQ_WAVES", 0))}
     else:
         out["pmc"] = None
     return out

@@ -60,8 +60,14 @@ struct DevOptions {
     int traceOrder = 0;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order (default: L2 hit rate 0.62 -> 0.88, launch -7 %, the permutation costs more), 1 = batches of >= 4 samples, 2 = always
     int traceVariant = 0;        // IDKPT_DEVELOPER builds only: instrumented / probe instantiations of k_trace2
     int bvhTiming = 0, bvhSmall = 32;   // idkptBuildBlasCore: phase times on stderr; subtrees of at most this many fragments are finished by one thread
+    int poolMin = 12;            // pooled leaf phase: pairs a wave must have parked (below: every lane walks its own triangles as before; 0-20 measure the same, 32+ lose the gain)
+    int leafPool = -1;           // k_trace2<.., DBG = 16> (MODE 0): the leaf phase tests the wave's pooled (ray, triangle) pairs with all lanes in one round trip (kernels_trace.hpp).
+                                 // Mask of launch kinds: 1 = primary launches, 2 = the first bounce, 4 = later bounces.  -1 (default) = by measurement (profiles/r04_leaf_pool.md): later
+                                 // bounces always lose (few pairs per phase: -4 %), the first bounce gains 3-5 % where most pixels traverse the scene and loses 1 % on sparse views,
+                                 // the primary launch gains 4 % on sparse views and nothing elsewhere -> 1 on sparse views (fewer than half of the pixels enter the traversal), 3 otherwise
     int instanceRecords = 0;     // (default 0: measured slower as a whole — the records cost the producers more than they save the traversal, profiles/r04_multi_blas.md) scenes of 2..MAX_REC_INSTANCES instances (and USE_TLAS scenes of up to that many): one trace-ready record per (ray, instance), written by the producers (MODE 3 / 4 of k_trace2); 0: the instance entry is computed inside the traversal kernel (MODE 1 / 2)
     int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
+    int splitPeek = 64;          // k_trace2s: iterations between two looks at the work-list heads (a wave with < 32 idle lanes never refills, so it has to ask whether the list is empty).  Measured: 64 -> 16 -> 8 -> 2 = 2 147 -> 1 750 -> 1 743 -> 1 697 Mray/s on the headline view one frame at a time: splitting EARLY multiplies pieces (and their bookkeeping) while most lanes still have rays of their own; it pays in the real tail only
     int splitDonor = 1;          // k_trace2s: 1 = only rays that have not hit anything yet donate subtrees, 0 = every busy lane does
     int split = 1;               // k_trace2s (long rays split across the idle lanes of their wave once the work list is empty): 0 = never, 1 = small launches of sparse views (default, want_split), 2 = every launch, 3 = every launch + every split ray traced again (test hook for the re-trace path)
     int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
@@ -168,7 +174,7 @@ static int local_rows(int H, int mod, int rem, int bandLog2 = 0)
 
 template <bool PRIMARY>
 static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
-                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, bool spec = false)
+                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, bool spec = false, int bounce = 0)
 {
 #ifdef IDKPT_DEVELOPER
     if (spec && !split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {   // the candidates of the next step are requested before this step's box tests (kernels_trace.hpp, DBG 8)
@@ -201,6 +207,17 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         return;
     }
 #undef T2M
+    int poolMask = ctx->opt.leafPool;
+    if (poolMask < 0) {   // automatic: by view class, known from the previous batch of the same shape (unknown: the dense-view choice)
+        const uint64_t pixels = (uint64_t)ctx->W * ctx->rows * (uint64_t)std::max(1, f.batch);
+        const bool sparse = ctx->lastFast && ctx->lastBatch == f.batch && (uint64_t)ctx->hCounts[MAX_DEPTH_SLOTS - 1] * 2u < pixels;
+        poolMask = sparse ? 1 : 3;
+    }
+    if (((poolMask >> std::min(bounce, 2)) & 1) && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {      // pooled leaf phase (one BLAS instance, one scene version); option bits: primary launch, first bounce, later bounces
+        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        return;
+    }
     if (ctx->counters) { hipLaunchKernelGGL((k_trace2<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return; }
 #ifdef IDKPT_DEVELOPER
     switch (ctx->opt.traceVariant) {   // developer builds (libidkpt_dev.so, option "trace_variant"): s_memtime-instrumented and probe instantiations; results are bit-identical
@@ -966,7 +983,10 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "defer_last") o.deferLast = value != 0;
     else if (n == "split") { REQUIRE(value >= 0 && value <= 3, "idkptSetDeveloperOption: split is 0..3"); o.split = value; }
     else if (n == "split_donor") o.splitDonor = value != 0;
+    else if (n == "split_peek") o.splitPeek = std::max(1, value);
     else if (n == "instance_records") o.instanceRecords = value != 0;
+    else if (n == "leaf_pool") { REQUIRE(value >= -1 && value <= 7, "idkptSetDeveloperOption: leaf_pool is -1 (automatic) or a mask 0..7 (1: primary launches, 2: the first bounce, 4: later bounces)"); o.leafPool = value; }
+    else if (n == "pool_min") o.poolMin = std::max(0, value);
     else if (n == "spec") {
 #ifdef IDKPT_DEVELOPER
         REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: spec is 0..2"); o.spec = value;
@@ -1877,7 +1897,7 @@ static int flush_batch(dev_ctx* ctx)
     // (a launch never needs more waves than it can have rays: small frames would otherwise spend their time dispatching idle workgroups)
     const uint32_t traceGrid = std::min<uint32_t>((uint32_t)(ctx->numCUs * wavesPerCU), std::max<uint32_t>(1u, (uint32_t)(((size_t)B * N + 63) / 64)));
     const uint32_t midGrid = (ctx->opt.gridMidWaves > 0 && ctx->opt.traceWaves == 0) ? (uint32_t)(ctx->numCUs * std::min(wavesPerCU, ctx->opt.gridMidWaves)) : 0u;   // (an explicit trace_waves wins)
-    f.gridRaysX4 = (uint32_t)std::max(0, ctx->opt.gridRaysX4); f.gridMid = midGrid; f.gridMidRays = GRID_MID_RAYS; f.splitMode = (ctx->opt.split == 3 ? 2 : 1) | (ctx->opt.splitDonor ? 4 : 0);   // the same rules inside k_trace2, on the launch's actual ray count
+    f.gridRaysX4 = (uint32_t)std::max(0, ctx->opt.gridRaysX4); f.gridMid = midGrid; f.gridMidRays = GRID_MID_RAYS; f.splitMode = (ctx->opt.split == 3 ? 2 : 1) | (ctx->opt.splitDonor ? 4 : 0); f.poolMin = ctx->opt.poolMin; f.splitPeek = ctx->opt.splitPeek;   // the same rules inside k_trace2, on the launch's actual ray count
     const bool debug = f.g.DoDebugBVHTraversal != 0;
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);
@@ -2012,7 +2032,7 @@ static int flush_batch(dev_ctx* ctx)
         if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) gridj = small_launch_grid(traceGrid, ctx->hBases[(size_t)j * BS + B], hintMul, ctx->opt.gridRaysX4, midGrid);
         if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, trj, hits, (const uint32_t*)q, cnt, work + j, counters,
                                        want_split(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr, B),
-                                       want_spec(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr));
+                                       want_spec(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr), j);
         else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);

@@ -286,6 +286,12 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     // at a time, 35-50 % slower where every pixel traverses, at every launch size — even a frame traced alone is bound by the rate at which blocks that miss L1/L2
     // are delivered, not by the latency of its longest ray (profiles/r04_small_launch_experiments.md).
     constexpr bool SPEC = DBG == 8;
+    // DBG 16 ("pooled leaves", MODE 0): the leaf phase tests the wave's (ray, triangle) PAIRS with all 64 lanes in one round trip instead of every parked lane
+    // walking its own 1-8 triangles one dependent fetch after the other with 18-22 lanes active (instrumented: 23-48 pairs per leaf phase in 2.0-3.1 loop trips).
+    // Pairs are numbered by a ballot prefix sum over the parked lanes' triangle counts; the owners write (lane, k) for their pairs into the 64 words of the stack's
+    // dummy row, lane j picks up pair j, fetches its owner's ray through ds_bpermute and tests the triangle; the owners then collect their pairs' results IN ORDER with
+    // the reference's `t < T` (BVHIntersect.glsl:57-79) — the same tests on the same operands, the same sequence of T updates: bit-identical hits.
+    constexpr bool POOL = DBG == 16 && MODE == 0 && !VER;
     uint32_t pfA = 0, pfB = 0, pfC = 0, pfSink = 0;
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -529,6 +535,54 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             }
         }
         // ---- leaf phase
+        if (POOL) {
+            const unsigned long long pend = __builtin_amdgcn_ballot_w64(leafPending);
+            const uint32_t cnt = leafPending ? leafEnd - leafFirst : 0u;
+            if (pend != 0ull && __builtin_amdgcn_ballot_w64(cnt > 31u) == 0ull) {
+                // exclusive prefix sum of the counts over the lanes (counts < 32: five ballots), and the wave's total
+                uint32_t off = 0, total = 0;
+#pragma unroll
+                for (int b = 0; b < 5; b++) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(((cnt >> b) & 1u) != 0u);
+                    off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
+                    total += (uint32_t)__builtin_popcountll(m) << b;
+                }
+                uint32_t maxCnt = cnt;
+                for (int o = 32; o > 0; o >>= 1) maxCnt = max(maxCnt, (uint32_t)__shfl_xor((int)maxCnt, o));
+                lds_u32* const tbl = (lds_u32*)lds;                                   // the dummy row (row 0) of the stack: 64 words nobody's result depends on
+                // pooling saves the round trips after the first (maxCnt - 1 of them) and costs its bookkeeping: only where a lane has several triangles and the wave enough pairs
+                if (maxCnt >= 2u && total >= (uint32_t)f.poolMin)
+                for (uint32_t base = 0; base < total; base += 64u) {
+                    for (uint32_t k = 0; k < maxCnt; k++) { const uint32_t j = off + k - base; if (k < cnt && j < 64u) tbl[j] = lane | (k << 8); }
+                    __builtin_amdgcn_wave_barrier();
+                    const bool have = base + lane < total;
+                    const uint32_t e = have ? tbl[lane] : lane;                        // (idle slots test nothing: their result is +inf)
+                    const int src = (int)((e & 63u) << 2);
+                    const uint32_t kk = e >> 8;
+                    const f3 oro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ro.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ro.y))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ro.z))));
+                    const f3 ord = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rd.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rd.y))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rd.z))));
+                    const float oT = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(hitT)));
+                    const uint32_t oFirst = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)leafFirst);
+                    float pt = __builtin_inff(), pby = 0.0f, pbz = 0.0f;
+                    if (have) {
+                        const float4* tv = s.triVerts + 3 * (size_t)(oFirst + kk + triOffset);
+                        const float4 a = tv[0], b = tv[1], c = tv[2];
+                        float by, bz, t;
+                        if (RayTriangleIntersect(oro, ord, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < oT) { pt = t; pby = by; pbz = bz; }
+                    }
+                    // the owners collect their pairs of this pass in triangle order: exactly the reference's loop, the tests already done
+                    for (uint32_t k = 0; k < maxCnt; k++) {
+                        const uint32_t j = off + k - base;
+                        const int from = (int)((j & 63u) << 2);
+                        const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(pt)));
+                        const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(pby))), bz = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(pbz)));
+                        if (k < cnt && j < 64u && t < hitT) { hitTri = leafFirst + k + triOffset; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = inst.MeshTransformId; }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (base + 64u >= total) leafPending = false;
+                }
+            }
+        }
         if (leafPending) {
             const uint32_t tOff = MULTI ? triOff : triOffset;
             // (one triangle per round trip.  Requesting the two 48-B records of a two-triangle leaf together was measured in round 3: 88 instead of 75 VGPRs,

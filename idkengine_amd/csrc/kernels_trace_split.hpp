@@ -50,7 +50,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace2s(DScene s, Frame f, RayBufs 
     const float INF = __builtin_inff();
 
     bool active = false, leafPending = false, workLeft = true, needLoad = false;
-    uint32_t slice = blockIdx.x & (GRAB_SLICES - 1u), slicesDone = 0, chunkNext = 0, chunkEnd = 0, chunkSlice = 0, peekTick = 0;
+    uint32_t slice = blockIdx.x & (GRAB_SLICES - 1u), slicesDone = 0, chunkNext = 0, chunkEnd = 0, chunkSlice = 0, peekTick = 0, peekHead = 0;
+    bool peekPending = false;
     const uint32_t unitLog2 = (uint32_t)f.grabUnitLog2;
     const uint32_t nBlocks = (N + (1u << unitLog2) - 1u) >> unitLog2;
     const uint32_t grabChunk = f.grabFixed > 0 ? (uint32_t)f.grabFixed : 0u;
@@ -103,15 +104,20 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace2s(DScene s, Frame f, RayBufs 
                 parent = -1; splittable = true; needLoad = true; active = true;
             }
         }
-        // a wave that is too busy to refill still has to learn that the list is exhausted before it may split: peek at the slices' head words
-        // (every 64th iteration only: the load is a round trip to L2 that the whole wave waits for)
-        else if (workLeft && chunkNext >= chunkEnd && (uint32_t)__popcll(idle) >= 4u && (++peekTick & 63u) == 0u) {
-            bool done = true;
-            if (lane < GRAB_SLICES) {
-                const uint32_t len = ((nBlocks + GRAB_SLICES - 1u - lane) / GRAB_SLICES) << unitLog2;
-                done = __atomic_load_n(workCounter + GRAB_STRIDE * lane, __ATOMIC_RELAXED) >= len;
+        // a wave that is too busy to refill still has to learn that the list is exhausted before it may split: its first eight lanes peek at the slices' head words.
+        // The words are requested in one iteration and looked at in the next (the wave does not wait for the round trip), every f.splitPeek-th iteration (64) while at
+        // least four lanes are idle.  Looking more often was measured and is much worse (every 8th iteration: -19 % on the headline view one frame at a time, -29 % with
+        // three samples in flight): waves that start splitting while most of their lanes still carry rays of their own spend their time on pieces and bookkeeping.
+        else if (workLeft && chunkNext >= chunkEnd && (uint32_t)__popcll(idle) >= 4u) {
+            if (peekPending) {
+                const uint32_t len = ((nBlocks + GRAB_SLICES - 1u - (lane & (GRAB_SLICES - 1u))) / GRAB_SLICES) << unitLog2;
+                if (__ballot(lane >= GRAB_SLICES || peekHead >= len) == ~0ull) workLeft = false;
+                peekPending = false;
+            } else if (++peekTick >= (uint32_t)f.splitPeek) {
+                peekTick = 0;
+                if (lane < GRAB_SLICES) peekHead = __atomic_load_n(workCounter + GRAB_STRIDE * lane, __ATOMIC_RELAXED);
+                peekPending = true;
             }
-            if (__ballot(done) == ~0ull) workLeft = false;
         }
         // ---- (re)start of a root piece: the ray's record -> registers (new rays, and the sequential re-trace of an inconclusive ray)
         if (active && needLoad) {
