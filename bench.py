@@ -317,13 +317,13 @@ def n_gpu_report(torch, dist, world, group, pt=None, st=None, B=None, depth=None
     try:
         ndev = torch.cuda.device_count()
         ids = sorted({d % ndev for d in range(group)}) if group > 1 else list(range(min(ndev, world)))
-        rep = {"visible_devices": ndev, "members_or_ranks": world * group, "devices_used": ids, "members_share_gpus": bool(group > ndev),
+        rep = {"visible_devices": ndev, "members_or_ranks": world * group, "devices_used": ids, "members_share_gpus": bool(group > ndev or (world > 1 and os.environ.get("IDKPT_BENCH_ONE_DEVICE") == "1")),
                "peer_access": [[1 if i == j else int(torch.cuda.can_device_access_peer(i, j)) for j in ids] for i in ids]}
         if world > 1:
             rep["ranks"] = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "ranks_counted_by_all_reduce": ranks_counted}   # (every rank added 1 in an all-reduce: the collective itself says how many ranks RCCL connected)
         if st is not None and B:
             ac = st["alive_counts"]; per_batch = min(B, args.steps) if args is not None else B
-            rep["rank0_launches"] = {"samples_per_launch": per_batch, "primary_rays_per_launch": int(ac[0] * per_batch), "bounce_rays_per_launch": [int(a * per_batch) for a in ac[1:depth]],
+            rep["rank0_launches"] = {"samples_per_launch": per_batch, "primary_rays_per_launch": int(ac[0]), "bounce_rays_per_launch": [int(a * per_batch) for a in ac[1:depth]],   # ([0]: the whole batch's active list; [j]: the last sample's alive count x samples)
                                      "avg_trace_launch_us": round(st["trace_ms_total"] * 1e3 / max(1, st["trace_launches"]), 1), "trace_launches": int(st["trace_launches"]),
                                      "row_deal": "bands of 8 rows, (y // 8) % N" if world > 1 else "one multi-device context (idkptSetGroupSharding AUTO: bands of 8 rows at RayDepth <= 2, strips beyond)"}
         rep["selftest"] = selftest

@@ -25,6 +25,7 @@ using namespace ptd;
 #include "kernels_trace_split.hpp"
 #include "kernels_query.hpp"
 #include "kernels_shade.hpp"
+#include "kernels_trace_fused.hpp"
 #include "kernels_queue.hpp"
 #include "kernels_frame.hpp"
 #include "kernels_scene.hpp"
@@ -60,6 +61,7 @@ struct DevOptions {
     int traceOrder = 0;          // bounce launches handed out in spatial order (kernels_queue.hpp k_order_*): 0 = queue order (default: L2 hit rate 0.62 -> 0.88, launch -7 %, the permutation costs more), 1 = batches of >= 4 samples, 2 = always
     int traceVariant = 0;        // IDKPT_DEVELOPER builds only: instrumented / probe instantiations of k_trace2
     int bvhTiming = 0, bvhSmall = 32;   // idkptBuildBlasCore: phase times on stderr; subtrees of at most this many fragments are finished by one thread
+    int advMin = 0;              // k_trace2 MODE 1-4: instance entries / TLAS steps are taken by at least this many lanes together (or when no other lane has work); 0 = 8 for batches of >= 4 samples, 1 below (measured, 3-BLAS soup-1M: 1 / 8 / 16 / 24 / 32 = 3 365 / 3 408 / 3 226 / 2 925 / 2 568 Mray/s through the instance loop, 2 671 / 2 771 / 2 671 / 2 466 / 2 180 through the TLAS; one frame at a time 8 costs 1-6 %)
     int poolMin = 12;            // pooled leaf phase: pairs a wave must have parked (below: every lane walks its own triangles as before; 0-20 measure the same, 32+ lose the gain)
     int leafPool = -1;           // k_trace2<.., DBG = 16> (MODE 0): the leaf phase tests the wave's pooled (ray, triangle) pairs with all lanes in one round trip (kernels_trace.hpp).
                                  // Mask of launch kinds: 1 = primary launches, 2 = the first bounce, 4 = later bounces.  -1 (default) = by measurement (profiles/r04_leaf_pool.md): later
@@ -67,6 +69,8 @@ struct DevOptions {
                                  // the primary launch gains 4 % on sparse views and nothing elsewhere -> 1 on sparse views (fewer than half of the pixels enter the traversal), 3 otherwise
     int instanceRecords = 0;     // (default 0: measured slower as a whole — the records cost the producers more than they save the traversal, profiles/r04_multi_blas.md) scenes of 2..MAX_REC_INSTANCES instances (and USE_TLAS scenes of up to that many): one trace-ready record per (ray, instance), written by the producers (MODE 3 / 4 of k_trace2); 0: the instance entry is computed inside the traversal kernel (MODE 1 / 2)
     int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
+    int fused = 1;               // k_trace_fused (kernels_trace_fused.hpp): FirstHit + shading + the last NHit's traversal in one persistent launch at RayDepth 2.  0 off, 1 small launches on sparse views (want_fused), 2 wherever it is exact
+    int fusedShadeMin = 16;      // ... lanes that wait for the shading phase before it runs (or as many as are still tracing)
     int splitPeek = 64;          // k_trace2s: iterations between two looks at the work-list heads (a wave with < 32 idle lanes never refills, so it has to ask whether the list is empty).  Measured: 64 -> 16 -> 8 -> 2 = 2 147 -> 1 750 -> 1 743 -> 1 697 Mray/s on the headline view one frame at a time: splitting EARLY multiplies pieces (and their bookkeeping) while most lanes still have rays of their own; it pays in the real tail only
     int splitDonor = 1;          // k_trace2s: 1 = only rays that have not hit anything yet donate subtrees, 0 = every busy lane does
     int split = 1;               // k_trace2s (long rays split across the idle lanes of their wave once the work list is empty): 0 = never, 1 = small launches of sparse views (default, want_split), 2 = every launch, 3 = every launch + every split ray traced again (test hook for the re-trace path)
@@ -188,41 +192,44 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         hipLaunchKernelGGL((k_trace2s<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work);
         return;
     }
-    if (s.ver) {                    // scene versions: the samples of this batch see different states of the geometry (VER instantiations, kernels_trace.hpp)
-#define T2VER(C, M) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 32, 1, false, 24, M, 0, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
-        const bool rec = f.recPerRay > 1;      // per-instance trace-ready records (scenes of up to MAX_REC_INSTANCES instances): MODE 3 / 4 instead of 1 / 2
-        if (f.useTlas) { if (rec) { if (ctx->counters) T2VER(true, 4); else T2VER(false, 4); } else { if (ctx->counters) T2VER(true, 2); else T2VER(false, 2); } }
-        else if (ctx->instanceCount > 1) { if (rec) { if (ctx->counters) T2VER(true, 3); else T2VER(false, 3); } else { if (ctx->counters) T2VER(true, 1); else T2VER(false, 1); } }
-        else { if (ctx->counters) T2VER(true, 0); else T2VER(false, 0); }
-#undef T2VER
-        return;
-    }
-#define T2M(C, M) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 32, 1, false, 24, M>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
-    if (f.useTlas) {                // TLAS walk inside the kernel (MODE 4: the leaves' instance entries come from per-instance records, MODE 2: computed in the kernel)
-        if (f.recPerRay > 1) { if (ctx->counters) T2M(true, 4); else T2M(false, 4); } else { if (ctx->counters) T2M(true, 2); else T2M(false, 2); }
-        return;
-    }
-    if (ctx->instanceCount > 1) {   // instance loop inside the kernel (MODE 3: per-instance records, MODE 1: computed in the kernel)
-        if (f.recPerRay > 1) { if (ctx->counters) T2M(true, 3); else T2M(false, 3); } else { if (ctx->counters) T2M(true, 1); else T2M(false, 1); }
-        return;
-    }
-#undef T2M
+    // pooled leaf phase (kernels_trace.hpp, DBG 16): per launch kind — option leaf_pool, a mask: 1 = primary launches, 2 = the first bounce, 4 = later bounces; -1 = automatic
     int poolMask = ctx->opt.leafPool;
     if (poolMask < 0) {   // automatic: by view class, known from the previous batch of the same shape (unknown: the dense-view choice)
         const uint64_t pixels = (uint64_t)ctx->W * ctx->rows * (uint64_t)std::max(1, f.batch);
         const bool sparse = ctx->lastFast && ctx->lastBatch == f.batch && (uint64_t)ctx->hCounts[MAX_DEPTH_SLOTS - 1] * 2u < pixels;
         poolMask = sparse ? 1 : 3;
     }
-    if (((poolMask >> std::min(bounce, 2)) & 1) && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {      // pooled leaf phase (one BLAS instance, one scene version); option bits: primary launch, first bounce, later bounces
-        if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
-        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
+    const bool pool = ((poolMask >> std::min(bounce, 2)) & 1) && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);
+#define T2X(C, M, D, V) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 32, 1, false, 24, M, D, V>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+#define T2P(C, M, V) do { if (pool) T2X(C, M, 16, V); else T2X(C, M, 0, V); } while (0)
+#define T2C(M, V) do { if (ctx->counters) T2P(true, M, V); else T2P(false, M, V); } while (0)
+    const bool rec = f.recPerRay > 1;      // per-instance trace-ready records (scenes of up to MAX_REC_INSTANCES instances, option instance_records): MODE 3 / 4 instead of 1 / 2 (never pooled)
+    if (s.ver) {                    // scene versions: the samples of this batch see different states of the geometry (VER instantiations, kernels_trace.hpp)
+#define T2N(M, V) do { if (ctx->counters) T2X(true, M, 0, V); else T2X(false, M, 0, V); } while (0)      // (never pooled: the instance-loop / TLAS kernels gain nothing from it)
+        if (f.useTlas) { if (rec) T2N(4, true); else T2N(2, true); }
+        else if (ctx->instanceCount > 1) { if (rec) T2N(3, true); else T2N(1, true); }
+        else T2C(0, true);
         return;
     }
+    if (f.useTlas) {                // TLAS walk inside the kernel (MODE 4: the leaves' instance entries come from per-instance records, MODE 2: computed in the kernel)
+        if (rec) T2N(4, false); else T2N(2, false);
+        return;
+    }
+    if (ctx->instanceCount > 1) {   // instance loop inside the kernel (MODE 3: per-instance records, MODE 1: computed in the kernel)
+        if (rec) T2N(3, false); else T2N(1, false);
+        return;
+    }
+    if (pool) { if (ctx->counters) T2X(true, 0, 16, false); else T2X(false, 0, 16, false); return; }
+#undef T2N
+#undef T2C
+#undef T2P
+#undef T2X
     if (ctx->counters) { hipLaunchKernelGGL((k_trace2<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return; }
 #ifdef IDKPT_DEVELOPER
     switch (ctx->opt.traceVariant) {   // developer builds (libidkpt_dev.so, option "trace_variant"): s_memtime-instrumented and probe instantiations; results are bit-identical
         case 107: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 65>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // instrumented, old policy
         case 113: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // instrumented, default policy
+        case 116: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // instrumented, pooled leaf phase
 #define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         case 901: T2V(32, 20); return; case 902: T2V(40, 16); return;
         case 961: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // occupancy probes: 7 / 8 waves per SIMD forced (launch bounds)
@@ -984,9 +991,12 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "split") { REQUIRE(value >= 0 && value <= 3, "idkptSetDeveloperOption: split is 0..3"); o.split = value; }
     else if (n == "split_donor") o.splitDonor = value != 0;
     else if (n == "split_peek") o.splitPeek = std::max(1, value);
+    else if (n == "fused") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: fused is 0..2"); o.fused = value; }
+    else if (n == "fused_shade_min") o.fusedShadeMin = std::min(64, std::max(1, value));
     else if (n == "instance_records") o.instanceRecords = value != 0;
     else if (n == "leaf_pool") { REQUIRE(value >= -1 && value <= 7, "idkptSetDeveloperOption: leaf_pool is -1 (automatic) or a mask 0..7 (1: primary launches, 2: the first bounce, 4: later bounces)"); o.leafPool = value; }
     else if (n == "pool_min") o.poolMin = std::max(0, value);
+    else if (n == "adv_min") o.advMin = std::min(64, std::max(0, value));
     else if (n == "spec") {
 #ifdef IDKPT_DEVELOPER
         REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: spec is 0..2"); o.spec = value;
@@ -1744,6 +1754,16 @@ static bool want_split(const dev_ctx* ctx, uint32_t prev, bool known, int sample
     const bool sparse = ctx->lastFast && ctx->lastBatch == samples && (uint64_t)ctx->hCounts[MAX_DEPTH_SLOTS - 1] * 2u < pixels;
     return known && sparse && prev > 0u && prev < SPLIT_MAX_RAYS;
 }
+// k_trace_fused: where a batch's two traversal launches are bound by their longest rays, not by their ray count (the same regime as the split)
+// (measured: it saves launches, not chain length — +5 % where one sparse frame is traced alone, a loss everywhere else: kernels_trace_fused.hpp)
+#define FUSED_MAX_RAYS 600000u
+static bool want_fused(const dev_ctx* ctx, uint32_t prev, bool known, int samples)
+{
+    if (ctx->opt.fused == 0) return false;
+    if (ctx->opt.fused >= 2) return true;
+    const uint64_t pixels = (uint64_t)ctx->W * ctx->rows * (uint64_t)std::max(1, samples);
+    return known && prev > 0u && prev < FUSED_MAX_RAYS && (uint64_t)prev * 2u < pixels;
+}
 #define SPEC_MAX_RAYS 1500000u
 static bool want_spec(const dev_ctx* ctx, uint32_t prev, bool known)
 {
@@ -1784,8 +1804,8 @@ static int finish_deferred(dev_ctx* ctx)
     const uint32_t scanBlocks = ((total + 63) / 64 + SCAN_WAVES_PER_BLOCK - 1) / SCAN_WAVES_PER_BLOCK;
     const uint32_t* q = ctx->queue[side].as<uint32_t>();
     const uint32_t* cnt = ctx->deferCount.as<uint32_t>();            // (counts[j] itself was reset by the batch's last kernel)
-    if (ctx->defer.allHits) hipLaunchKernelGGL((k_restore_last<true>), dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>());
-    else hipLaunchKernelGGL((k_restore_last<false>), dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>());
+    if (ctx->defer.allHits) hipLaunchKernelGGL((k_restore_last<true>), dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>(), f.hitsByRid);
+    else hipLaunchKernelGGL((k_restore_last<false>), dim3(gridTotal), dim3(256), 0, st, rays, hits, q, cnt, (const float4*)ctx->radSave.as<float4>(), f.hitsByRid);
     if (multiVer) hipLaunchKernelGGL((k_shade<false, true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, q, cnt, 0u, (const uint32_t*)(bases + j * BS), (const uint32_t*)nullptr, contMask, waveLocal, keysTmp);
     else hipLaunchKernelGGL((k_shade<false, false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, q, cnt, 0u, (const uint32_t*)(bases + j * BS), (const uint32_t*)nullptr, contMask, waveLocal, keysTmp);
     hipLaunchKernelGGL((k_scan_local<false>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, cnt, 0u, (const uint8_t*)nullptr, contMask, waveLocal, blockSums);
@@ -1897,10 +1917,16 @@ static int flush_batch(dev_ctx* ctx)
     // (a launch never needs more waves than it can have rays: small frames would otherwise spend their time dispatching idle workgroups)
     const uint32_t traceGrid = std::min<uint32_t>((uint32_t)(ctx->numCUs * wavesPerCU), std::max<uint32_t>(1u, (uint32_t)(((size_t)B * N + 63) / 64)));
     const uint32_t midGrid = (ctx->opt.gridMidWaves > 0 && ctx->opt.traceWaves == 0) ? (uint32_t)(ctx->numCUs * std::min(wavesPerCU, ctx->opt.gridMidWaves)) : 0u;   // (an explicit trace_waves wins)
-    f.gridRaysX4 = (uint32_t)std::max(0, ctx->opt.gridRaysX4); f.gridMid = midGrid; f.gridMidRays = GRID_MID_RAYS; f.splitMode = (ctx->opt.split == 3 ? 2 : 1) | (ctx->opt.splitDonor ? 4 : 0); f.poolMin = ctx->opt.poolMin; f.splitPeek = ctx->opt.splitPeek;   // the same rules inside k_trace2, on the launch's actual ray count
+    f.gridRaysX4 = (uint32_t)std::max(0, ctx->opt.gridRaysX4); f.gridMid = midGrid; f.gridMidRays = GRID_MID_RAYS; f.splitMode = (ctx->opt.split == 3 ? 2 : 1) | (ctx->opt.splitDonor ? 4 : 0); f.poolMin = ctx->opt.poolMin; f.advMin = ctx->opt.advMin > 0 ? ctx->opt.advMin : (B >= 4 ? 8 : 1); f.splitPeek = ctx->opt.splitPeek;   // the same rules inside k_trace2, on the launch's actual ray count
     const bool debug = f.g.DoDebugBVHTraversal != 0;
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);
+    // one launch for FirstHit + the last NHit (kernels_trace_fused.hpp): RayDepth 2, one BLAS instance, the last bounce deferred (no AOVs, no debug view), nothing that looks at
+    // the primary hits or the visit counters, no per-bounce exchange with other contexts — and a launch small enough to be bound by its longest rays
+    const bool fused = fast && ctx->st.RayDepth == 2 && ctx->opt.deferLast != 0 && !f.outputAovs && !f.g.DoDebugBVHTraversal && !f.useTlas && ctx->instanceCount == 1 && !multiVer && !ctx->counters
+                       && !ctx->capturePrimary && !ctx->groupExchange && !ctx->exchangeFn && f.recPerRay == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)
+                       && want_fused(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B);
+    f.hitsByRid = fused ? 1 : 0; f.shadeMin = ctx->opt.fusedShadeMin;
     if (!fast && (B != 1 || multiVer)) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
     unsigned long long* contMask = ctx->contMask.as<unsigned long long>();
     uint32_t* waveCounts = ctx->waveCounts.as<uint32_t>();
@@ -1938,11 +1964,16 @@ static int flush_batch(dev_ctx* ctx)
             TRACE_T0();
             uint32_t grid0 = traceGrid;
             if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4, midGrid);
+            if (fused) {
+                // FirstHit's traversal, its shading and the bounce's traversal in one persistent launch (kernels_trace_fused.hpp); the bounce's hits are stored per ray id
+                hipLaunchKernelGGL((k_trace_fused<32>), dim3(grid0), dim3(WAVE), ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
+            } else
             launch_trace2<true>(ctx, grid0, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters,
                                 want_split(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B), want_spec(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B));
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
-            if (multiVer) hipLaunchKernelGGL((k_shade_first<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
+            if (fused) {}
+            else if (multiVer) hipLaunchKernelGGL((k_shade_first<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
             else hipLaunchKernelGGL((k_shade_first<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
             hipLaunchKernelGGL((k_scan_local<true>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)ctx->contFlag.as<uint8_t>(), contMask, waveLocal, blockSums);
         } else {
@@ -2024,6 +2055,7 @@ static int flush_batch(dev_ctx* ctx)
             hipLaunchKernelGGL(k_order_gather, dim3(gridTotal), dim3(256), 0, st, vin, (const uint32_t*)q, cnt, ctx->ordIdx.as<uint32_t>());
             trj.order = vin; trj.orderIdx = ctx->ordIdx.as<uint32_t>();
         }
+        if (!fused) {
         TRACE_T0();
         // grid of the bounce launch: its queue length is only known on the device; the length the same bounce had in the previous batch (pinned copy,
         // possibly one batch stale) is a good predictor, and a grid that is too small or too large only costs time (the waves are persistent)
@@ -2038,6 +2070,7 @@ static int flush_batch(dev_ctx* ctx)
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
         }
         TRACE_T1();
+        }
         if (deferLast && j == depth - 1 && gbase == nullptr) {
             // the last bounce: only its radiance is visible in the frame (kernels_shade.hpp k_shade_last); state, queue and counts follow on demand (finish_deferred)
             HIPC(ctx->radSave.ensure((size_t)ctx->maxBatch * ctx->Npad * 16)); HIPC(ctx->deferCount.ensure(64));
@@ -2300,7 +2333,7 @@ static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
     uint64_t c[4] = {0, 0, 0, 0};
     HIPC(hipMemcpyAsync(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
-    if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu | leafTests %llu leafTrips %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13], (unsigned long long)d[14], (unsigned long long)d[15]); }
+    if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113 || ctx->opt.traceVariant == 116) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu | leafTests %llu leafTrips %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13], (unsigned long long)d[14], (unsigned long long)d[15]); }
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
     *out = s;
     return IDKPT_OK;

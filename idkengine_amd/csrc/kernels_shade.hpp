@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s0, Frame f, RayBufs rays,
         const DScene s = VER ? scene_of_sample(s0, smp) : s0;
         const uint32_t acc = sample_index(f, smp);
         float4 a = rays.o_ior[idx], b = rays.thr_px[idx], c = rays.rad_py[idx];
-        const HitRec hit = load_hit(hits, slot);
+        const HitRec hit = load_hit(hits, (!FIRST && f.hitsByRid) ? idx : slot);   // (hitsByRid: the bounce was traced by k_trace_fused, which stores hits per ray id)
         if (FIRST && f.g.DoDebugBVHTraversal) {
             rays.o_ior[idx] = make_float4(a.x, a.y, a.z, hits.cost[slot]); // FirstHit:108-112
         } else {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_shade_last(DScene s0, Frame f, RayBufs 
     if (slot == 0u) *deferCount = N;                                // (the batch's last kernel resets the queue lengths: the on-demand pass reads this copy)
     if (slot >= N) return;
     const uint32_t idx = queue[slot];
-    const HitRec hit = load_hit(hits, slot);
+    const HitRec hit = load_hit(hits, f.hitsByRid ? idx : slot);
     const float4 b = rays.thr_px[idx];
     const bool miss = hit.T == PT_FLOAT_MAX;
     const bool odd = ALL_HITS || !(__builtin_isfinite(b.x) && __builtin_isfinite(b.y) && __builtin_isfinite(b.z));
@@ -163,12 +163,12 @@ __global__ __launch_bounds__(256) void k_shade_last(DScene s0, Frame f, RayBufs 
 }
 // on demand, before the ordinary kernels run for the deferred bounce: the radiance k_shade_last replaced
 template <bool ALL_HITS>
-__global__ __launch_bounds__(256) void k_restore_last(RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, const float4* radSave)
+__global__ __launch_bounds__(256) void k_restore_last(RayBufs rays, HitBufs hits, const uint32_t* queue, const uint32_t* countPtr, const float4* radSave, int hitsByRid)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= *countPtr) return;
     const uint32_t idx = queue[slot];
-    const HitRec hit = load_hit(hits, slot);
+    const HitRec hit = load_hit(hits, hitsByRid ? idx : slot);
     const float4 b = rays.thr_px[idx];
     if (ALL_HITS || hit.T == PT_FLOAT_MAX || !(__builtin_isfinite(b.x) && __builtin_isfinite(b.y) && __builtin_isfinite(b.z))) rays.rad_py[idx] = radSave[slot];
 }

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     // Pairs are numbered by a ballot prefix sum over the parked lanes' triangle counts; the owners write (lane, k) for their pairs into the 64 words of the stack's
     // dummy row, lane j picks up pair j, fetches its owner's ray through ds_bpermute and tests the triangle; the owners then collect their pairs' results IN ORDER with
     // the reference's `t < T` (BVHIntersect.glsl:57-79) — the same tests on the same operands, the same sequence of T updates: bit-identical hits.
-    constexpr bool POOL = DBG == 16 && MODE == 0 && !VER;
+    constexpr bool POOL = DBG == 16;     // (the host selects it for MODE 0 only: in the instance-loop / TLAS kernels it measured neutral to slightly negative, profiles/r04_leaf_pool.md)
     uint32_t pfA = 0, pfB = 0, pfC = 0, pfSink = 0;
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -406,6 +406,8 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         if (TLAS) {
             // lanes whose current BLAS is exhausted continue their TLAS walk until it reaches the next leaf (= instance) or ends
             bool adv = active && !leafPending && top == 0u && moreInst;
+            // (like parked leaves: the few lanes whose BLAS is exhausted wait until f.advMin of them can take their TLAS steps together — or nobody else has anything to do)
+            if (MULTI && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(adv)) < (uint32_t)f.advMin && __builtin_amdgcn_ballot_w64(active && (leafPending || top != 0u)) != 0ull) adv = false;
             while (__any(adv)) {
                 if (adv) {
                     const float4* tl4 = VER ? s.tlas + vTlas : s.tlas;
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         } else if (MULTI) {
             // lanes whose current BLAS is exhausted move on to the next instance (loop: the root test may fail right away)
             bool adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
+            if (MULTI && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(adv)) < (uint32_t)f.advMin && __builtin_amdgcn_ballot_w64(active && (leafPending || top != 0u)) != 0ull) adv = false;
             while (__any(adv)) {
                 if (adv && REC) {
                     const float4* r4 = rec_at(tr, f, rayId, instIdx);
@@ -562,10 +565,11 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                     const f3 oro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ro.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ro.y))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ro.z))));
                     const f3 ord = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rd.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rd.y))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rd.z))));
                     const float oT = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(hitT)));
-                    const uint32_t oFirst = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)leafFirst);
+                    const uint32_t oFirst = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(leafFirst + (MULTI ? triOff : triOffset)));   // the owner's first triangle, scene-wide index
+                    const uint32_t oVer = VER ? (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)vTri) : 0u;                               // ... and where its scene version's records start
                     float pt = __builtin_inff(), pby = 0.0f, pbz = 0.0f;
                     if (have) {
-                        const float4* tv = s.triVerts + 3 * (size_t)(oFirst + kk + triOffset);
+                        const float4* tv = s.triVerts + 3 * (size_t)(oFirst + kk) + oVer;
                         const float4 a = tv[0], b = tv[1], c = tv[2];
                         float by, bz, t;
                         if (RayTriangleIntersect(oro, ord, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < oT) { pt = t; pby = by; pbz = bz; }
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                         const int from = (int)((j & 63u) << 2);
                         const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(pt)));
                         const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(pby))), bz = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(pbz)));
-                        if (k < cnt && j < 64u && t < hitT) { hitTri = leafFirst + k + triOffset; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = inst.MeshTransformId; }
+                        if (k < cnt && j < 64u && t < hitT) { hitTri = leafFirst + k + (MULTI ? triOff : triOffset); hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = MULTI ? xformId : inst.MeshTransformId; }
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (base + 64u >= total) leafPending = false;

@@ -63,9 +63,12 @@ struct Frame {
     const float* cams; uint32_t slotOf[256];   // (dwords: scalar loads from the kernel-argument segment; gfx9 has no scalar byte load)
     int recPerRay;              // trace-ready records per ray id: 1 (one BLAS: the local ray; on-the-fly instance / TLAS walks: the world ray), or — scenes of up to MAX_REC_INSTANCES
                                 // instances — one record per instance (the ray in that instance's space, its root-box tMin, the BLAS's node / triangle offsets), plus the world ray behind them under USE_TLAS
+    int advMin;                 // k_trace2 MODE 1-4: lanes whose BLAS is exhausted wait for this many of their kind before they enter the next instance / walk the TLAS (1: at once)
     int poolMin;                // pooled leaf phase (k_trace2 DBG 16): (ray, triangle) pairs a wave must have parked before they are tested by all lanes together
     int splitPeek;              // k_trace2s: iterations between two looks at the work-list heads of a wave that is too busy to refill
     int splitMode;              // k_trace2s (kernels_trace_split.hpp): bits 0-1: 2 = every ray whose pieces found a hit is traced again sequentially (test hook for the re-trace path); bit 2: only rays without a hit donate subtrees
+    int shadeMin;               // k_trace_fused: lanes that wait for the shading phase before it runs
+    int hitsByRid;              // the last bounce's hit records are indexed by ray id instead of queue slot (k_trace_fused, kernels_trace_fused.hpp)
     int tilePerSample;          // k_classify_tiles ran once per sample of the batch (per-sample cameras or scene versions): tile classes are indexed [sample][tile]
 };
 #define MAX_BATCH 256

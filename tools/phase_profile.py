@@ -18,7 +18,7 @@ from sweep_trace import run, W, H
 view = sys.argv[1]
 sc = S.atrium_scene(1000000, NativeBuilder()) if view == "atrium" else S.soup_scene(1000000, NativeBuilder(), seed=1)
 cam = S.atrium_camera(W, H) if view == "atrium" else (S.Camera(W, H) if view == "headline" else S.Camera(W, H, position=(0.0, 0.0, 0.0)))
-r, img, rays = run(sc, cam, 113, int(sys.argv[2]), 64)
+r, img, rays = run(sc, cam, int(os.environ.get("PHASE_VARIANT", "113")), int(sys.argv[2]), 64)
 print("RESULT", view, sys.argv[2], r["mray_s"], r["trace_ms_per_frame"])
 ''' % (HERE, HERE)
 
