@@ -69,6 +69,7 @@ struct DevOptions {
                                  // the primary launch gains 4 % on sparse views and nothing elsewhere -> 1 on sparse views (fewer than half of the pixels enter the traversal), 3 otherwise
     int instanceRecords = 0;     // (default 0: measured slower as a whole — the records cost the producers more than they save the traversal, profiles/r04_multi_blas.md) scenes of 2..MAX_REC_INSTANCES instances (and USE_TLAS scenes of up to that many): one trace-ready record per (ray, instance), written by the producers (MODE 3 / 4 of k_trace2); 0: the instance entry is computed inside the traversal kernel (MODE 1 / 2)
     int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
+    int splitScatter = 6;        // k_trace2s: log2 of the entries that stay together when the work list is handed out scattered (6 = list order)
     int fused = 1;               // k_trace_fused (kernels_trace_fused.hpp): FirstHit + shading + the last NHit's traversal in one persistent launch at RayDepth 2.  0 off, 1 small launches on sparse views (want_fused), 2 wherever it is exact
     int fusedShadeMin = 16;      // ... lanes that wait for the shading phase before it runs (or as many as are still tracing)
     int splitPeek = 64;          // k_trace2s: iterations between two looks at the work-list heads (a wave with < 32 idle lanes never refills, so it has to ask whether the list is empty).  Measured: 64 -> 16 -> 8 -> 2 = 2 147 -> 1 750 -> 1 743 -> 1 697 Mray/s on the headline view one frame at a time: splitting EARLY multiplies pieces (and their bookkeeping) while most lanes still have rays of their own; it pays in the real tail only
@@ -229,6 +230,8 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
     switch (ctx->opt.traceVariant) {   // developer builds (libidkpt_dev.so, option "trace_variant"): s_memtime-instrumented and probe instantiations; results are bit-identical
         case 107: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 65>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // instrumented, old policy
         case 113: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // instrumented, default policy
+        case 121: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // the leaf's first triangle requested in the node step
+        case 122: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24, 0, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // ... instrumented
         case 116: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // instrumented, pooled leaf phase
 #define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         case 901: T2V(32, 20); return; case 902: T2V(40, 16); return;
@@ -991,6 +994,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "split") { REQUIRE(value >= 0 && value <= 3, "idkptSetDeveloperOption: split is 0..3"); o.split = value; }
     else if (n == "split_donor") o.splitDonor = value != 0;
     else if (n == "split_peek") o.splitPeek = std::max(1, value);
+    else if (n == "split_scatter") o.splitScatter = std::min(6, std::max(0, value));
     else if (n == "fused") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: fused is 0..2"); o.fused = value; }
     else if (n == "fused_shade_min") o.fusedShadeMin = std::min(64, std::max(1, value));
     else if (n == "instance_records") o.instanceRecords = value != 0;
@@ -1926,7 +1930,7 @@ static int flush_batch(dev_ctx* ctx)
     const bool fused = fast && ctx->st.RayDepth == 2 && ctx->opt.deferLast != 0 && !f.outputAovs && !f.g.DoDebugBVHTraversal && !f.useTlas && ctx->instanceCount == 1 && !multiVer && !ctx->counters
                        && !ctx->capturePrimary && !ctx->groupExchange && !ctx->exchangeFn && f.recPerRay == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)
                        && want_fused(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B);
-    f.hitsByRid = fused ? 1 : 0; f.shadeMin = ctx->opt.fusedShadeMin;
+    f.hitsByRid = fused ? 1 : 0; f.shadeMin = ctx->opt.fusedShadeMin; f.scatterLog2 = ctx->opt.splitScatter;
     if (!fast && (B != 1 || multiVer)) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
     unsigned long long* contMask = ctx->contMask.as<unsigned long long>();
     uint32_t* waveCounts = ctx->waveCounts.as<uint32_t>();

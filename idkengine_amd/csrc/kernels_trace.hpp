@@ -292,6 +292,10 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     // dummy row, lane j picks up pair j, fetches its owner's ray through ds_bpermute and tests the triangle; the owners then collect their pairs' results IN ORDER with
     // the reference's `t < T` (BVHIntersect.glsl:57-79) — the same tests on the same operands, the same sequence of T updates: bit-identical hits.
     constexpr bool POOL = DBG == 16;     // (the host selects it for MODE 0 only: in the instance-loop / TLAS kernels it measured neutral to slightly negative, profiles/r04_leaf_pool.md)
+    // DBG 32 ("first triangle on the way", MODE 0): a lane that finds a leaf requests the leaf's first triangle record right there, in the node step; the record
+    // travels while the other lanes keep stepping, and the leaf phase starts with its first test instead of a round trip (it has 2.0-3.1 of them, r04_phase_profile.txt).
+    constexpr bool PREF = DBG == 32;
+    float4 pfa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pfb = pfa, pfc = pfa;
     uint32_t pfA = 0, pfB = 0, pfC = 0, pfSink = 0;
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -516,6 +520,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 // (a lane that steps has no parked leaf, so its leaf registers are free: written unconditionally, BLAS-local; the leaf phase adds the offset)
                 leafFirst = intersectLeft ? lStart : rStart; leafEnd = !intersectRight ? lStart + lCount : rStart + rCount; leafPending = intersectLeft || intersectRight;
                 if (COUNT) nTris += leafPending ? leafEnd - leafFirst : 0u;
+                if (PREF && leafPending) { const float4* tv = s.triVerts + 3 * (size_t)(leafFirst + (MULTI ? triOff : triOffset)) + (VER ? vTri : 0u); pfa = tv[0]; pfb = tv[1]; pfc = tv[2]; }
                 const bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
                 const bool both = traverseLeft && traverseRight, none = !(traverseLeft || traverseRight);
                 const bool leftCloser = tMinLeft < tMinRight;
@@ -586,6 +591,21 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                     if (base + 64u >= total) leafPending = false;
                 }
             }
+        }
+        if (PREF && leafPending) {
+            const uint32_t tOff = MULTI ? triOff : triOffset;
+            uint32_t i = leafFirst + tOff; const uint32_t e = leafEnd + tOff;
+            float4 a = pfa, b = pfb, c = pfc;
+            while (true) {
+                float by, bz, t;
+                if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hitT) {
+                    hitTri = i; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = MULTI ? xformId : inst.MeshTransformId;
+                }
+                if (++i >= e) break;
+                const float4* tv = s.triVerts + 3 * (size_t)i + (VER ? vTri : 0u);
+                a = tv[0]; b = tv[1]; c = tv[2];
+            }
+            leafPending = false;
         }
         if (leafPending) {
             const uint32_t tOff = MULTI ? triOff : triOffset;

@@ -53,7 +53,14 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace2s(DScene s, Frame f, RayBufs 
     uint32_t slice = blockIdx.x & (GRAB_SLICES - 1u), slicesDone = 0, chunkNext = 0, chunkEnd = 0, chunkSlice = 0, peekTick = 0, peekHead = 0;
     bool peekPending = false;
     const uint32_t unitLog2 = (uint32_t)f.grabUnitLog2;
-    const uint32_t nBlocks = (N + (1u << unitLog2) - 1u) >> unitLog2;
+    // Scattered hand-out (Frame::scatterLog2 < 6): the list is in tile order (k_gen_primary: 8x8 pixels are 64 consecutive entries), so the rays that graze the scene for
+    // hundreds of steps come in runs — a wave that gets 64 of them has no idle lane to split onto while the waves next to it sit idle.  Viewed as a matrix of
+    // (64 >> scatterLog2) rows of groups of 2^scatterLog2 entries, the list is handed out column by column: a wave's 64 positions are 64 >> scatterLog2 groups from
+    // places far apart.  Positions run over the padded matrix (Nh >= N); which lane traces which entry is free, so nothing of the result changes.
+    const uint32_t scat = (uint32_t)f.scatterLog2 < 6u ? (uint32_t)f.scatterLog2 : 6u;
+    const uint32_t scatCols = (((N + (1u << scat) - 1u) >> scat) + (64u >> scat) - 1u) / (64u >> scat);      // groups per row
+    const uint32_t Nh = scat < 6u ? (scatCols * (64u >> scat)) << scat : N;
+    const uint32_t nBlocks = (Nh + (1u << unitLog2) - 1u) >> unitLog2;
     const uint32_t grabChunk = f.grabFixed > 0 ? (uint32_t)f.grabFixed : 0u;
     if (N == 0u) workLeft = false;
     uint32_t top = 0, slot = 0, rayIdx = 0, leafFirst = 0, leafEnd = 0, leafSplit = 0;
@@ -95,7 +102,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace2s(DScene s, Frame f, RayBufs 
                 chunkNext = got ? (fresh + need < end ? fresh + need : end) : 0u; chunkEnd = end; chunkSlice = slice;
                 if (got && fresh + want >= len) { slice = (slice + 1u) & (GRAB_SLICES - 1u); slicesDone++; }
             }
-            const uint32_t item = valid ? ((((q >> unitLog2) * GRAB_SLICES + sl) << unitLog2) | (q & ((1u << unitLog2) - 1u))) : N;
+            uint32_t item = valid ? ((((q >> unitLog2) * GRAB_SLICES + sl) << unitLog2) | (q & ((1u << unitLog2) - 1u))) : N;
+            if (scat < 6u && item < Nh) { const uint32_t gi = item >> scat, per = 64u >> scat; item = ((((gi & (per - 1u)) * scatCols) + gi / per) << scat) | (item & ((1u << scat) - 1u)); }
             if (slicesDone >= GRAB_SLICES && chunkNext >= chunkEnd) workLeft = false;
             if (!active && item < N) {
                 const bool ordered = !PRIMARY && tr.order != nullptr;
