@@ -612,6 +612,26 @@ def query_extras(S, pt, scene, cam):
     for _ in range(3):
         t0 = time.perf_counter(); pt.TraceShadows(prm, depth, normal); ts.append(time.perf_counter() - t0)
     out["rt_shadows"] = {"mray_s": round(W * H / statistics.median(ts) / 1e6, 1), "ms_per_call": round(statistics.median(ts) * 1e3, 3), "shadow_rays": W * H, "samples": 1}
+    # the same queries with rays / G-buffer / results resident in HBM (idkptTraceRaysDevice / idkptTraceShadowsDevice): what the kernels themselves do
+    try:
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d_rays = torch.from_numpy(np.frombuffer(rays.tobytes(), np.uint8).copy()).to(dev); d_hits = torch.zeros(len(rays) * 32, dtype=torch.uint8, device=dev)
+        d_depth = torch.from_numpy(np.ascontiguousarray(depth, np.float32)).to(dev); d_normal = torch.from_numpy(np.ascontiguousarray(normal, np.float32)).to(dev); d_vis = torch.zeros(H * W, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        res = {}
+        for name, fn in (("closest_hit", lambda: pt.TraceRaysDevice(d_rays.data_ptr(), d_hits.data_ptr(), len(rays))), ("any_hit", lambda: pt.TraceRaysDevice(d_rays.data_ptr(), d_hits.data_ptr(), len(rays), any_hit=True)),
+                         ("rt_shadows", lambda: pt.TraceShadowsDevice(prm, d_depth.data_ptr(), d_normal.data_ptr(), d_vis.data_ptr()))):
+            fn(); pt.synchronize(); ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    fn()
+                pt.synchronize(); ts.append((time.perf_counter() - t0) / 4.0)
+            res[name] = {"mray_s": round(len(rays) / statistics.median(ts) / 1e6, 1), "ms_per_call": round(statistics.median(ts) * 1e3, 3)}
+        out["device_resident"] = res
+    except Exception as e:   # noqa: BLE001
+        out["device_resident"] = {"error": str(e)}
     pt._check(pt._L.idkptSetLightCount(pt._ctx, 0))
     return out
 

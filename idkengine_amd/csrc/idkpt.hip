@@ -70,6 +70,7 @@ struct DevOptions {
     int instanceRecords = 0;     // (default 0: measured slower as a whole — the records cost the producers more than they save the traversal, profiles/r04_multi_blas.md) scenes of 2..MAX_REC_INSTANCES instances (and USE_TLAS scenes of up to that many): one trace-ready record per (ray, instance), written by the producers (MODE 3 / 4 of k_trace2); 0: the instance entry is computed inside the traversal kernel (MODE 1 / 2)
     int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
     int splitScatter = 6;        // k_trace2s: log2 of the entries that stay together when the work list is handed out scattered (6 = list order)
+    int queryScheduler = 1;      // idkptTraceRays (closest hit) through k_trace2's scheduler instead of the thread-per-ray kernel (kernels_query.hpp)
     int fused = 1;               // k_trace_fused (kernels_trace_fused.hpp): FirstHit + shading + the last NHit's traversal in one persistent launch at RayDepth 2.  0 off, 1 small launches on sparse views (want_fused), 2 wherever it is exact
     int fusedShadeMin = 16;      // ... lanes that wait for the shading phase before it runs (or as many as are still tracing)
     int splitPeek = 64;          // k_trace2s: iterations between two looks at the work-list heads (a wave with < 32 idle lanes never refills, so it has to ask whether the list is empty).  Measured: 64 -> 16 -> 8 -> 2 = 2 147 -> 1 750 -> 1 743 -> 1 697 Mray/s on the headline view one frame at a time: splitting EARLY multiplies pieces (and their bookkeeping) while most lanes still have rays of their own; it pays in the real tail only
@@ -102,7 +103,7 @@ struct dev_ctx {
     uint32_t seqFirst = 0, seqStride = 1;                         // idkptSetSampleSequence
     // scene
     bool haveScene = false, frameOk = false;
-    DevBuf nodes, tnodes, nodeSlot, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, tileClass, gbases;   // (+ camTab below)
+    DevBuf nodes, tnodes, nodeSlot, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, queryRec, queryList, tileClass, gbases;   // (+ camTab below)
     std::vector<DevBuf> texData; std::vector<std::pair<int, int>> texDims;
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
@@ -565,7 +566,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -995,6 +996,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "split_donor") o.splitDonor = value != 0;
     else if (n == "split_peek") o.splitPeek = std::max(1, value);
     else if (n == "split_scatter") o.splitScatter = std::min(6, std::max(0, value));
+    else if (n == "query_scheduler") o.queryScheduler = value != 0;
     else if (n == "fused") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: fused is 0..2"); o.fused = value; }
     else if (n == "fused_shade_min") o.fusedShadeMin = std::min(64, std::max(1, value));
     else if (n == "instance_records") o.instanceRecords = value != 0;
@@ -1572,7 +1574,7 @@ static int query_frame(dev_ctx* ctx, Frame& f, size_t& ldsBytes, uint32_t& grid)
 }
 
 // issue only (H2D, kernel, D2H on the context's stream); the caller synchronises.  hits must stay valid until then.
-static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
+static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits, bool devicePtrs = false /* rays / hits live on this context's device: no copies, nothing to wait for */)
 {
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceRays: no scene uploaded");
@@ -1586,19 +1588,44 @@ static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t co
     Frame f; size_t ldsBytes; uint32_t grid;
     int rc = query_frame(ctx, f, ldsBytes, grid); if (rc) return rc;
     DScene s = make_dscene(ctx);
-    HIPC(ctx->queryIn.ensure(count * sizeof(idkpt_ray))); HIPC(ctx->queryOut.ensure(count * sizeof(idkpt_hit)));
     hipStream_t st = ctx->stream;
-    HIPC(hipMemcpyAsync(ctx->queryIn.p, rays, count * sizeof(idkpt_ray), hipMemcpyHostToDevice, st));
-    HIPC(ctx->qwork.ensure(64));                                           // its own work-list counter: the frame's counters are reset by the frame's last kernel, not per batch
+    const idkpt_ray* dIn = rays; idkpt_hit* dOut = hits;
+    if (!devicePtrs) {
+        HIPC(ctx->queryIn.ensure(count * sizeof(idkpt_ray))); HIPC(ctx->queryOut.ensure(count * sizeof(idkpt_hit)));
+        HIPC(hipMemcpyAsync(ctx->queryIn.p, rays, count * sizeof(idkpt_ray), hipMemcpyHostToDevice, st));
+        dIn = ctx->queryIn.as<idkpt_ray>(); dOut = ctx->queryOut.as<idkpt_hit>();
+    }
+    HIPC(ctx->qwork.ensure((WORK_WORDS + 128) * 4));                       // its own work-list counters: the frame's are reset by the frame's last kernel, not per batch
     uint32_t* work = ctx->qwork.as<uint32_t>();
-    HIPC(hipMemsetAsync(work, 0, 4, st));
     const int lights = (flags & IDKPT_TRACE_LIGHTS) ? 1 : 0;
-    if (flags & IDKPT_TRACE_ANY_HIT) hipLaunchKernelGGL((k_trace_query<true>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, ctx->queryIn.as<idkpt_ray>(), ctx->queryOut.as<idkpt_hit>(), (uint32_t)count, lights, work);
-    else hipLaunchKernelGGL((k_trace_query<false>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, ctx->queryIn.as<idkpt_ray>(), ctx->queryOut.as<idkpt_hit>(), (uint32_t)count, lights, work);
+    if (!(flags & IDKPT_TRACE_ANY_HIT) && ctx->opt.queryScheduler && !f.g.DoDebugBVHTraversal) {
+        // closest hit: k_trace2's persistent-wave scheduler (kernels_query.hpp): prepare (lights, root test, trace-ready records) -> k_trace2 -> Hit flags
+        HIPC(ctx->queryRec.ensure(count * 64)); HIPC(ctx->queryList.ensure(count * 4));
+        HIPC(hipMemsetAsync(work, 0, (WORK_WORDS + 128) * 4, st));
+        uint32_t* listCount = work + WORK_WORDS;
+        f.queryMode = 1; f.g.DoTraceLights = 0;                            // (the lights are folded into the records)
+        f.grabUnitLog2 = std::min(24, std::max(6, ctx->opt.grabUnitLog2)); f.grabFixed = std::max(0, ctx->opt.grabFixed); f.leafMin = ctx->opt.leafMin > 0 ? ctx->opt.leafMin : 16;
+        f.poolMin = ctx->opt.poolMin; f.advMin = ctx->opt.advMin > 0 ? ctx->opt.advMin : 8; f.recPerRay = 1; f.batch = 1; f.Npad = (uint32_t)count;
+        TraceBufs tr = {ctx->queryRec.as<float4>(), nullptr, nullptr};
+        const uint32_t blocks = (uint32_t)((count + 255) / 256);
+        hipLaunchKernelGGL(k_query_prepare, dim3(blocks), dim3(256), 0, st, s, f, dIn, dOut, (uint32_t)count, lights, tr, ctx->queryList.as<uint32_t>(), listCount);
+        RayBufs noRays = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        HitBufs qhits = {(float4*)dOut, ctx->hitCost.as<float>()};
+        const uint32_t g2 = std::min<uint32_t>(grid, std::max<uint32_t>(1u, (uint32_t)((count + 63) / 64)));
+        launch_trace2<true>(ctx, g2, ldsBytes, st, s, f, noRays, tr, qhits, (const uint32_t*)ctx->queryList.as<uint32_t>(), (const uint32_t*)listCount, work, (uint64_t*)(work + WORK_WORDS + 64) /* visit counters of queries do not count as the frame's */);
+        hipLaunchKernelGGL(k_query_finish, dim3(blocks), dim3(256), 0, st, dIn, dOut, (const uint32_t*)ctx->queryList.as<uint32_t>(), (const uint32_t*)listCount);
+        HIPC(hipGetLastError());
+        if (!devicePtrs) HIPC(hipMemcpyAsync(hits, ctx->queryOut.p, count * sizeof(idkpt_hit), hipMemcpyDeviceToHost, st));
+        return IDKPT_OK;
+    }
+    HIPC(hipMemsetAsync(work, 0, 4, st));
+    if (flags & IDKPT_TRACE_ANY_HIT) hipLaunchKernelGGL((k_trace_query<true>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, dIn, dOut, (uint32_t)count, lights, work);
+    else hipLaunchKernelGGL((k_trace_query<false>), dim3(grid), dim3(WAVE), ldsBytes, st, s, f, dIn, dOut, (uint32_t)count, lights, work);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(hits, ctx->queryOut.p, count * sizeof(idkpt_hit), hipMemcpyDeviceToHost, st));
+    if (!devicePtrs) HIPC(hipMemcpyAsync(hits, ctx->queryOut.p, count * sizeof(idkpt_hit), hipMemcpyDeviceToHost, st));
     return IDKPT_OK;
 }
+static int32_t dev_TraceRaysDevice(dev_ctx* ctx, const idkpt_ray* dRays, size_t count, uint32_t flags, idkpt_hit* dHits) { return dev_TraceRaysIssue(ctx, dRays, count, flags, dHits, true); }
 static int32_t dev_TraceRays(dev_ctx* ctx, const idkpt_ray* rays, size_t count, uint32_t flags, idkpt_hit* hits)
 {
     int rc = dev_TraceRaysIssue(ctx, rays, count, flags, hits); if (rc) return rc;
@@ -1607,7 +1634,7 @@ static int32_t dev_TraceRays(dev_ctx* ctx, const idkpt_ray* rays, size_t count, 
     return IDKPT_OK;
 }
 
-static int32_t dev_TraceShadows(dev_ctx* ctx, const idkpt_shadow_params* p, const float* depth, const float* normalOct, float* visibility)
+static int32_t dev_TraceShadows(dev_ctx* ctx, const idkpt_shadow_params* p, const float* depth, const float* normalOct, float* visibility, bool devicePtrs = false)
 {
     if (!ctx || !p) return IDKPT_ERR_INVALID_ARGUMENT;
     if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptTraceShadows: no scene uploaded");
@@ -1622,19 +1649,25 @@ static int32_t dev_TraceShadows(dev_ctx* ctx, const idkpt_shadow_params* p, cons
     int rc = query_frame(ctx, f, ldsBytes, grid); if (rc) return rc;
     DScene s = make_dscene(ctx);
     const size_t N = (size_t)p->Width * p->Height;
-    HIPC(ctx->queryIn.ensure(N * 12)); HIPC(ctx->queryOut.ensure(N * 4));
     hipStream_t st = ctx->stream;
-    float* dDepth = ctx->queryIn.as<float>(); float2* dNormal = (float2*)(dDepth + N); float* dVis = ctx->queryOut.as<float>();
-    HIPC(hipMemcpyAsync(dDepth, depth, N * 4, hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(dNormal, normalOct, N * 8, hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(dVis, visibility, N * 4, hipMemcpyHostToDevice, st));
+    const float* dDepth = depth; const float2* dNormal = (const float2*)normalOct; float* dVis = visibility;
+    if (!devicePtrs) {
+        HIPC(ctx->queryIn.ensure(N * 12)); HIPC(ctx->queryOut.ensure(N * 4));
+        float* in = ctx->queryIn.as<float>();
+        HIPC(hipMemcpyAsync(in, depth, N * 4, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(in + N, normalOct, N * 8, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(ctx->queryOut.p, visibility, N * 4, hipMemcpyHostToDevice, st));
+        dDepth = in; dNormal = (const float2*)(in + N); dVis = ctx->queryOut.as<float>();
+    }
     const uint32_t tiles = (uint32_t)(((p->Width + 7) / 8) * ((p->Height + 7) / 8));
     hipLaunchKernelGGL(k_shadows, dim3(tiles), dim3(WAVE), ldsBytes, st, s, f, *p, (const float*)dDepth, (const float2*)dNormal, dVis);
     HIPC(hipGetLastError());
+    if (devicePtrs) return IDKPT_OK;                                       // (asynchronous, in stream order: idkptSynchronize or the host's own stream wait completes it)
     HIPC(hipMemcpyAsync(visibility, dVis, N * 4, hipMemcpyDeviceToHost, st));
     SYNC_CHECKED();
     return IDKPT_OK;
 }
+static int32_t dev_TraceShadowsDevice(dev_ctx* ctx, const idkpt_shadow_params* p, const float* dDepth, const float* dNormalOct, float* dVisibility) { return dev_TraceShadows(ctx, p, dDepth, dNormalOct, dVisibility, true); }
 
 static int32_t dev_RefitBlas(dev_ctx* ctx, int32_t blasId)
 {
@@ -1857,7 +1890,7 @@ static int flush_batch(dev_ctx* ctx)
         ctx->verHalf ^= 1;
     }
     DScene s = make_dscene_last(ctx);
-    Frame f;
+    Frame f; memset(&f, 0, sizeof(f));                                 // (every field a kernel variant may look at has a defined value: queryMode, hitsByRid, ...)
     memcpy(f.invProj, ctx->pending[0].cam, 64); memcpy(f.invView, ctx->pending[0].cam + 16, 64); memcpy(f.viewPos, ctx->pending[0].cam + 32, 12);   // the camera the samples were queued with
     f.W = ctx->W; f.H = ctx->H; f.rowMod = ctx->rowMod; f.rowRem = ctx->rowRem; f.rows = ctx->rows; f.rowBandLog2 = ctx->rowBandLog2;
     f.g = ctx->st.Gpu; f.useTlas = ctx->st.UseTlas;

@@ -453,6 +453,20 @@ int32_t idkptTraceShadows(idkpt_ctx* c, const idkpt_shadow_params* p, const floa
     return rc ? mfail(c, c->dev[0], rc) : IDKPT_OK;
 }
 
+// the same queries on buffers that already live on the context's device (a host's own G-buffer / ray buffers): no copies, asynchronous in stream order
+int32_t idkptTraceRaysDevice(idkpt_ctx* c, const idkpt_ray* dRays, size_t count, uint32_t flags, idkpt_hit* dHits)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_TraceRaysDevice(m, dRays, count, flags, dHits));
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptTraceRaysDevice: device pointers belong to one device; use a single-device context (or idkptTraceRays)");
+}
+int32_t idkptTraceShadowsDevice(idkpt_ctx* c, const idkpt_shadow_params* p, const float* dDepth, const float* dNormalOct, float* dVisibility)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_TraceShadowsDevice(m, p, dDepth, dNormalOct, dVisibility));
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptTraceShadowsDevice: device pointers belong to one device; use a single-device context (or idkptTraceShadows)");
+}
+
 int32_t idkptSetFrameRing(idkpt_ctx* c, int32_t frames) { REPLICATE(SetFrameRing, frames); }
 int32_t idkptBeginFrame(idkpt_ctx* c, int32_t* outSlot)
 {

@@ -27,6 +27,71 @@ __global__ __launch_bounds__(WAVE) void k_trace_query(DScene s, Frame f, const i
     }
 }
 
+// Closest-hit queries on k_trace2's scheduler (round 4).  The thread-per-ray kernel above runs TraceRay's nested loops with whatever lanes are still busy (1 559 Mray/s on one
+// primary ray per pixel of the headline view, 575 where every ray traverses: 2.5x the time k_trace2 needs for the same rays).  k_query_prepare does what TraceRay does before
+// its traversal (BVHIntersect.glsl:185-203: T = maxDist, the sphere lights; with one BLAS instance also RayTransform, 1/dir and the root-box test of :32-39) with all lanes
+// busy and leaves a trace-ready record per ray — the initial T in record[1].w, the light it belongs to in record[2].w (Frame::queryMode: k_trace2 starts from them instead of
+// FLOAT_MAX / 0) — rays that cannot enter the one BLAS get their final record right here; k_trace2 (MODE 0 / 1 / 2 by scene, as for frames) stores its 32-B hit records
+// straight into the caller's idkpt_hit array (same layout), and k_query_finish sets `Hit` = T != maxDist (:290).  Same operands, same order per ray: bit-identical to the
+// thread-per-ray kernel and the oracle (tests/test_gpu_queries.py).  TraceRayAny keeps the kernel above: its left-first walk with early exit is a different traversal.
+__global__ __launch_bounds__(256) void k_query_prepare(DScene s, Frame f, const idkpt_ray* rays, idkpt_hit* out, uint32_t N, int traceLights, TraceBufs tr, uint32_t* list, uint32_t* listCount)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (i < N) {
+        const float4 a = ((const float4*)rays)[2 * (size_t)i], b = ((const float4*)rays)[2 * (size_t)i + 1];
+        const f3 ro = mk3(a.x, a.y, a.z), rd = mk3(b.x, b.y, b.z);
+        const float maxDist = a.w;
+        float T = maxDist; uint32_t xf = 0u;
+        if (traceLights) {
+            for (int k = 0; k < s.lightCount; k++) {
+                const GpuLight& l = s.lights[k];
+                float tMin, tMax;
+                if (RaySphereIntersect(ro, rd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < T) { T = tMin < 0.0f ? tMax : tMin; xf = (uint32_t)k; }
+            }
+        }
+        if (f.useTlas) {
+            keep = s.tlasCount > 0;
+            tr.rec[4 * (size_t)i] = make_float4(ro.x, ro.y, ro.z, 0.0f); tr.rec[4 * (size_t)i + 1] = make_float4(rd.x, rd.y, rd.z, T);
+            tr.rec[4 * (size_t)i + 2] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, __uint_as_float(xf));
+        } else if (s.instanceCount > 1) {
+            keep = true;
+            tr.rec[4 * (size_t)i] = make_float4(ro.x, ro.y, ro.z, 0.0f); tr.rec[4 * (size_t)i + 1] = make_float4(rd.x, rd.y, rd.z, T);
+            tr.rec[4 * (size_t)i + 2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(xf));
+        } else {
+            const GpuBlasInstance inst = s.instances[0];
+            const M34 inv = load_inv_model(s, inst.MeshTransformId);
+            const f3 lo = xform34(inv, ro, 1.0f), ld = xform34(inv, rd, 0.0f);
+            const f3 iv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+            const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
+            float t1;
+            const float rootT = RayBoxIntersect(lo, iv, root[0], root[1], &t1) ? t1 : __builtin_inff();
+            keep = rootT < T;                                                      // (:32-39: the test k_trace2 would do first)
+            tr.rec[4 * (size_t)i] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)i + 1] = make_float4(ld.x, ld.y, ld.z, T);
+            tr.rec[4 * (size_t)i + 2] = make_float4(iv.x, iv.y, iv.z, __uint_as_float(xf));
+        }
+        if (!keep) {
+            ((float4*)out)[2 * (size_t)i] = make_float4(T, 0.0f, 0.0f, __uint_as_float(~0u));
+            ((uint4*)out)[2 * (size_t)i + 1] = make_uint4(xf, T != maxDist ? 1u : 0u, 0u, 0u);
+        }
+    }
+    // survivors -> work list (any order: results are stored per ray); one atomic per wave
+    const unsigned long long m = __ballot(keep);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(listCount, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, 0);
+    if (keep) list[base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = i;
+}
+__global__ __launch_bounds__(256) void k_query_finish(const idkpt_ray* rays, idkpt_hit* out, const uint32_t* list, const uint32_t* listCount)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *listCount) return;
+    const uint32_t i = list[k];
+    const float T = ((const float*)out)[8 * (size_t)i], maxDist = ((const float*)rays)[8 * (size_t)i + 3];
+    ((uint32_t*)out)[8 * (size_t)i + 5] = T != maxDist ? 1u : 0u;
+    ((uint32_t*)out)[8 * (size_t)i + 6] = 0u; ((uint32_t*)out)[8 * (size_t)i + 7] = 0u;
+}
+
 // k_shadows: Shaders/ShadowsRayTraced/compute.glsl:19-127 for one point shadow; one thread per pixel, 8x8 tiles per wave.
 DEV float InterleavedGradientNoise(float cx, float cy, uint32_t index) // Random.glsl:35-41
 {

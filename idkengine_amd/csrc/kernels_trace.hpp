@@ -384,6 +384,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 const uint32_t idx = ordered ? tr.orderIdx[item] : list[item];
                 slot = PRIMARY ? idx : (ordered ? tr.order[item] : item);
                 hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f;
+                if (f.queryMode) { hitT = tr.rec[4 * (size_t)idx + 1].w; hitXform = __float_as_uint(tr.rec[4 * (size_t)idx + 2].w); }   // idkptTraceRays (kernels_query.hpp k_query_prepare): T = maxDist or the nearest light, and that light
                 if (VER) { const uint32_t* vt = s.ver + SCENE_VER_WORDS * (size_t)(idx / f.Npad); vNode = vt[1]; vTri = vt[2]; if (MULTI) { vNodeRef = vt[0]; vTlas = vt[4]; vXform = vt[5]; } }
                 if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203 (world-space ray)
                     float4 o = rays.o_ior[idx];

@@ -15,7 +15,7 @@ from ._lib import IdkPtError
 
 
 # idkptSetDeveloperOption names; IDKPT_<NAME> in the environment is forwarded when a PathTracer is created (test / tuning hooks only)
-_OPTION_NAMES = ("force_generic", "no_tile_cull", "no_lean_primary", "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves", "grid_hint", "grid_rays_x4", "grid_mid_waves", "defer_last", "split", "split_donor", "split_peek", "split_scatter", "fused", "fused_shade_min", "spec", "instance_records", "leaf_pool", "pool_min", "adv_min",
+_OPTION_NAMES = ("force_generic", "no_tile_cull", "no_lean_primary", "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves", "grid_hint", "grid_rays_x4", "grid_mid_waves", "defer_last", "split", "split_donor", "split_peek", "query_scheduler", "split_scatter", "fused", "fused_shade_min", "spec", "instance_records", "leaf_pool", "pool_min", "adv_min",
                  "node_layout", "treelet_depth", "trace_order", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
 
 
@@ -204,6 +204,18 @@ class PathTracer:
         v = np.zeros(d.shape, np.float32) if visibility is None else np.ascontiguousarray(visibility, np.float32).copy()
         self._check(self._L.idkptTraceShadows(self._ctx, C.addressof(params), d.ctypes.data, n.ctypes.data, v.ctypes.data))
         return v
+
+    def TraceRaysDevice(self, d_rays, d_hits, count, any_hit=False, trace_lights=False):
+        """idkptTraceRaysDevice: d_rays / d_hits are device pointers (ints, e.g. torch tensor.data_ptr()) on this context's device: count x 32 B each.
+        Asynchronous in the context's stream order; synchronize() completes it."""
+        from . import gputypes as T
+        flags = (T.IDKPT_TRACE_ANY_HIT if any_hit else 0) | (T.IDKPT_TRACE_LIGHTS if trace_lights else 0)
+        self._check(self._L.idkptTraceRaysDevice(self._ctx, int(d_rays), int(count), flags, int(d_hits)))
+
+    def TraceShadowsDevice(self, params, d_depth, d_normal_oct, d_visibility):
+        """idkptTraceShadowsDevice: the three images are device pointers (W*H floats, W*H*2 floats, W*H floats in/out).  Asynchronous in stream order."""
+        import ctypes as C
+        self._check(self._L.idkptTraceShadowsDevice(self._ctx, C.addressof(params), int(d_depth), int(d_normal_oct), int(d_visibility)))
 
     def RefitBlas(self, blas_id):
         self._check(self._L.idkptRefitBlas(self._ctx, blas_id))

@@ -261,6 +261,12 @@ IDKPT_API int32_t idkptTraceRays(idkpt_ctx* ctx, const idkpt_ray* rays, size_t c
  * on keep their value).  The shader's GetRandomFloat01() (stochastic alpha) runs on an un-seeded RNG in the reference
  * (InitializeRandomSeed is commented out, :24); here the seed is 0 per invocation. */
 IDKPT_API int32_t idkptTraceShadows(idkpt_ctx* ctx, const idkpt_shadow_params* params, const float* depth, const float* normalOct, float* visibility);
+/* The same two queries on buffers that already live on the context's device — the engine's G-buffer (ShadowsRayTraced/compute.glsl:9-13 binds gBufferData and the
+ * result image directly), ray buffers another pass wrote.  No copies; the kernels are enqueued on the context's stream behind everything issued before and the
+ * call returns at once: idkptSynchronize (or a wait on idkptGetStream's stream) completes them.  Same layouts, same results bit for bit as the host-pointer calls
+ * (whose time is mostly their PCIe copies: 64 B per ray, 16 B per pixel).  Single-device contexts only (IDKPT_ERR_INVALID_OPERATION otherwise). */
+IDKPT_API int32_t idkptTraceRaysDevice(idkpt_ctx* ctx, const idkpt_ray* dRays, size_t count, uint32_t flags, idkpt_hit* dHits);
+IDKPT_API int32_t idkptTraceShadowsDevice(idkpt_ctx* ctx, const idkpt_shadow_params* params, const float* dDepth, const float* dNormalOct, float* dVisibility);
 /* Read back a scene buffer (tests: refit/skinning results). */
 IDKPT_API int32_t idkptDownloadBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst);
 
