@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--repeats", type=int, default=7, help="the timed region of --steps steps is repeated this often; the median repetition is reported")
+    ap.add_argument("--repeats", type=int, default=0, help="the timed region of --steps steps is repeated this often; the median repetition is reported.  0 (default): 7, "
+                    "or as many as it takes to time >= 150 ms in total (at most 25): a region of a few milliseconds (--steps 20) is shorter than the GPU's clock ramp after the idle gap between regions")
     ap.add_argument("--tris", type=int, default=N_TRIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-frame and interior-view measurements")
@@ -202,7 +203,8 @@ def main():
         finish_frame()
     pt.synchronize(); pt.reset_stats(); pt.enable_timing(True)
     repeat_s, rays_rank = [], 0
-    for _rep in range(max(1, args.repeats)):
+    want_reps = args.repeats if args.repeats > 0 else 7
+    while len(repeat_s) < want_reps:
         step_no[0] = 0
         if world > 1:
             dist.barrier()
@@ -221,6 +223,9 @@ def main():
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         repeat_s.append(tmax.item())
+        if args.repeats <= 0 and len(repeat_s) == 1:                      # (the same count on every rank: derived from the all-reduced time)
+            want_reps = int(min(25, max(7, -(-0.15 // max(repeat_s[0], 1e-6)))))
+    args.repeats = len(repeat_s)
     st = pt.stats()
     pt.enable_timing(False)
     reps = len(repeat_s)
@@ -742,8 +747,8 @@ def cpu_baseline(S, scene, depth, view):
     except Exception:
         pass
     cand = {16, 32, 64, 128, cores}
-    if quota:
-        cand |= {max(1, int(quota)), max(1, int(2 * quota))}
+    if quota:                                               # (under a quota more than 2x its threads only oversubscribe: a noisy probe picked 128 threads on a 16-core quota once and halved the baseline)
+        cand = {max(1, int(quota)), max(1, int(2 * quota))}
     best = (0.0, cores)
     for nthr in sorted(t for t in cand if t <= cores):
         O.set_num_threads(nthr)
@@ -770,7 +775,7 @@ def cpu_baseline(S, scene, depth, view):
     except Exception:
         affinity = None
     out = {"value": head["value"], "unit": "Mray/s", "cores": eff[0], "omp_threads": cores, "hw_threads": hw_threads, "cgroup_cpu_quota": quota, "sched_affinity": affinity, "cpu": cpu_model(), "kind": "port", "parallel_section_mray_s": head["parallel_section"],
-           "mray_s_per_core": head["per_core"], "sample": head["sample"] + f"; {cores} OpenMP threads (the fastest on a probe of 16/32/64/128/{hw_threads} and 1x/2x the container's CPU quota of {quota}; `cores` = min(threads, quota): what the process can actually occupy); C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET); scene and threads warm",
+           "mray_s_per_core": head["per_core"], "sample": head["sample"] + f"; {cores} OpenMP threads (the fastest on a probe of {'1x/2x the container CPU quota of ' + str(quota) if quota else '16/32/64/128/' + str(hw_threads)}; `cores` = min(threads, quota): what the process can actually occupy); C++/OpenMP restatement of the reference path incl. shading (the C# binary cannot run here: no .NET); scene and threads warm",
            "primary_only_csharp_semantics": {"value": round(p_rays / p_dt / 1e6, 3), "unit": "Mray/s", "per_core": round(p_rays / p_dt / 1e6 / eff[0], 4),
                                              "sample": f"{p_rays // (W * H)} full {W}x{H} frames of centre-of-pixel primary rays, closest hit only (no shading), {p_dt:.1f} s"},
            "note": "a reported baseline, not the target: the GPU/CPU ratio says nothing about kernel quality (roofline.frac does)"}
