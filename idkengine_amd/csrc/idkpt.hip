@@ -180,8 +180,14 @@ static int local_rows(int H, int mod, int rem, int bandLog2 = 0)
 
 template <bool PRIMARY>
 static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
-                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, bool spec = false, int bounce = 0)
+                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, bool spec = false, int bounce = 0, bool anyHit = false)
 {
+    if (anyHit) {   // idkptTraceRays with IDKPT_TRACE_ANY_HIT (kernels_query.hpp): TraceRayAny's walk on the same scheduler
+#define T2A(M) hipLaunchKernelGGL((k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+        if (f.useTlas) T2A(2); else if (ctx->instanceCount > 1) T2A(1); else T2A(0);
+#undef T2A
+        return;
+    }
 #ifdef IDKPT_DEVELOPER
     if (spec && !split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {   // the candidates of the next step are requested before this step's box tests (kernels_trace.hpp, DBG 8)
         if (ctx->counters) hipLaunchKernelGGL((k_trace2<PRIMARY, true, 32, 1, false, 24, 0, 8>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters);
@@ -1598,8 +1604,9 @@ static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t co
     HIPC(ctx->qwork.ensure((WORK_WORDS + 128) * 4));                       // its own work-list counters: the frame's are reset by the frame's last kernel, not per batch
     uint32_t* work = ctx->qwork.as<uint32_t>();
     const int lights = (flags & IDKPT_TRACE_LIGHTS) ? 1 : 0;
-    if (!(flags & IDKPT_TRACE_ANY_HIT) && ctx->opt.queryScheduler && !f.g.DoDebugBVHTraversal) {
-        // closest hit: k_trace2's persistent-wave scheduler (kernels_query.hpp): prepare (lights, root test, trace-ready records) -> k_trace2 -> Hit flags
+    if (ctx->opt.queryScheduler && !f.g.DoDebugBVHTraversal) {
+        const bool anyHit = (flags & IDKPT_TRACE_ANY_HIT) != 0;
+        // closest hit / any hit: k_trace2's persistent-wave scheduler (kernels_query.hpp): prepare (lights, root test, trace-ready records) -> k_trace2 -> Hit flags
         HIPC(ctx->queryRec.ensure(count * 64)); HIPC(ctx->queryList.ensure(count * 4));
         HIPC(hipMemsetAsync(work, 0, (WORK_WORDS + 128) * 4, st));
         uint32_t* listCount = work + WORK_WORDS;
@@ -1608,11 +1615,11 @@ static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t co
         f.poolMin = ctx->opt.poolMin; f.advMin = ctx->opt.advMin > 0 ? ctx->opt.advMin : 8; f.recPerRay = 1; f.batch = 1; f.Npad = (uint32_t)count;
         TraceBufs tr = {ctx->queryRec.as<float4>(), nullptr, nullptr};
         const uint32_t blocks = (uint32_t)((count + 255) / 256);
-        hipLaunchKernelGGL(k_query_prepare, dim3(blocks), dim3(256), 0, st, s, f, dIn, dOut, (uint32_t)count, lights, tr, ctx->queryList.as<uint32_t>(), listCount);
+        hipLaunchKernelGGL(k_query_prepare, dim3(blocks), dim3(256), 0, st, s, f, dIn, dOut, (uint32_t)count, lights, anyHit ? 1 : 0, tr, ctx->queryList.as<uint32_t>(), listCount);
         RayBufs noRays = {nullptr, nullptr, nullptr, nullptr, nullptr};
         HitBufs qhits = {(float4*)dOut, ctx->hitCost.as<float>()};
         const uint32_t g2 = std::min<uint32_t>(grid, std::max<uint32_t>(1u, (uint32_t)((count + 63) / 64)));
-        launch_trace2<true>(ctx, g2, ldsBytes, st, s, f, noRays, tr, qhits, (const uint32_t*)ctx->queryList.as<uint32_t>(), (const uint32_t*)listCount, work, (uint64_t*)(work + WORK_WORDS + 64) /* visit counters of queries do not count as the frame's */);
+        launch_trace2<true>(ctx, g2, ldsBytes, st, s, f, noRays, tr, qhits, (const uint32_t*)ctx->queryList.as<uint32_t>(), (const uint32_t*)listCount, work, (uint64_t*)(work + WORK_WORDS + 64) /* visit counters of queries do not count as the frame's */, false, false, 0, anyHit);
         hipLaunchKernelGGL(k_query_finish, dim3(blocks), dim3(256), 0, st, dIn, dOut, (const uint32_t*)ctx->queryList.as<uint32_t>(), (const uint32_t*)listCount);
         HIPC(hipGetLastError());
         if (!devicePtrs) HIPC(hipMemcpyAsync(hits, ctx->queryOut.p, count * sizeof(idkpt_hit), hipMemcpyDeviceToHost, st));

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(WAVE) void k_trace_query(DScene s, Frame f, const i
 // busy and leaves a trace-ready record per ray — the initial T in record[1].w, the light it belongs to in record[2].w (Frame::queryMode: k_trace2 starts from them instead of
 // FLOAT_MAX / 0) — rays that cannot enter the one BLAS get their final record right here; k_trace2 (MODE 0 / 1 / 2 by scene, as for frames) stores its 32-B hit records
 // straight into the caller's idkpt_hit array (same layout), and k_query_finish sets `Hit` = T != maxDist (:290).  Same operands, same order per ray: bit-identical to the
-// thread-per-ray kernel and the oracle (tests/test_gpu_queries.py).  TraceRayAny keeps the kernel above: its left-first walk with early exit is a different traversal.
-__global__ __launch_bounds__(256) void k_query_prepare(DScene s, Frame f, const idkpt_ray* rays, idkpt_hit* out, uint32_t N, int traceLights, TraceBufs tr, uint32_t* list, uint32_t* listCount)
+// thread-per-ray kernel and the oracle (tests/test_gpu_queries.py).  TraceRayAny takes the same route through k_trace2's ANY instantiations (left child first inside a BLAS,
+// the first intersection found ends the ray; a light in front of maxDist ends it right here).
+__global__ __launch_bounds__(256) void k_query_prepare(DScene s, Frame f, const idkpt_ray* rays, idkpt_hit* out, uint32_t N, int traceLights, int anyHit, TraceBufs tr, uint32_t* list, uint32_t* listCount)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
@@ -43,13 +44,18 @@ __global__ __launch_bounds__(256) void k_query_prepare(DScene s, Frame f, const 
         const f3 ro = mk3(a.x, a.y, a.z), rd = mk3(b.x, b.y, b.z);
         const float maxDist = a.w;
         float T = maxDist; uint32_t xf = 0u;
+        bool lightEnds = false;                                                    // TraceRayAny (:303-314): the first light in front of maxDist is the answer
         if (traceLights) {
-            for (int k = 0; k < s.lightCount; k++) {
+            for (int k = 0; k < s.lightCount && !lightEnds; k++) {
                 const GpuLight& l = s.lights[k];
                 float tMin, tMax;
-                if (RaySphereIntersect(ro, rd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < T) { T = tMin < 0.0f ? tMax : tMin; xf = (uint32_t)k; }
+                if (RaySphereIntersect(ro, rd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < T) { T = tMin < 0.0f ? tMax : tMin; xf = (uint32_t)k; lightEnds = anyHit != 0; }
             }
         }
+        if (lightEnds) {
+            ((float4*)out)[2 * (size_t)i] = make_float4(T, 0.0f, 0.0f, __uint_as_float(~0u));
+            ((uint4*)out)[2 * (size_t)i + 1] = make_uint4(xf, 1u, 0u, 0u);
+        } else
         if (f.useTlas) {
             keep = s.tlasCount > 0;
             tr.rec[4 * (size_t)i] = make_float4(ro.x, ro.y, ro.z, 0.0f); tr.rec[4 * (size_t)i + 1] = make_float4(rd.x, rd.y, rd.z, T);
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void k_query_prepare(DScene s, Frame f, const 
             tr.rec[4 * (size_t)i] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)i + 1] = make_float4(ld.x, ld.y, ld.z, T);
             tr.rec[4 * (size_t)i + 2] = make_float4(iv.x, iv.y, iv.z, __uint_as_float(xf));
         }
-        if (!keep) {
+        if (!keep && !lightEnds) {
             ((float4*)out)[2 * (size_t)i] = make_float4(T, 0.0f, 0.0f, __uint_as_float(~0u));
             ((uint4*)out)[2 * (size_t)i + 1] = make_uint4(xf, T != maxDist ? 1u : 0u, 0u, 0u);
         }

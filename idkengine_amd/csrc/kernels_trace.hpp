@@ -272,7 +272,9 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
 #define GRAB_STRIDE 128u        // words between them (512 B: separate cache lines and memory channels)
 // VER: scene versions (DScene::ver): every ray traverses the geometry its sample was queued with; a lane keeps where that version's node pairs / triangle
 // records (MULTI: also its TLAS and transforms) start, in 16-byte units, and adds it to every fetch.  Hit records stay version-independent.
-template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0, bool VER = false>
+// ANY: TraceRayAny (BVHIntersect.glsl:107-181, 299-411) for idkptTraceRays' any-hit queries: inside a BLAS the left child is visited first whatever the distances, the first
+// triangle of a leaf with t < T ends the ray (its remaining triangles, its stack, its remaining instances / TLAS nodes are dropped); T is the query's maxDist until then.
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0, bool VER = false, bool ANY = false>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
     // MODE 3 / 4: MODE 1 / 2 on scenes of up to MAX_REC_INSTANCES instances, whose producers (k_gen_primary, the shading kernels) leave one trace-ready record per
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 if (PREF && leafPending) { const float4* tv = s.triVerts + 3 * (size_t)(leafFirst + (MULTI ? triOff : triOffset)) + (VER ? vTri : 0u); pfa = tv[0]; pfb = tv[1]; pfc = tv[2]; }
                 const bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
                 const bool both = traverseLeft && traverseRight, none = !(traverseLeft || traverseRight);
-                const bool leftCloser = tMinLeft < tMinRight;
+                const bool leftCloser = ANY ? true : tMinLeft < tMinRight;   // (ANY: left first, BVHIntersect.glsl:165-168)
                 const uint32_t nearChild = both ? (leftCloser ? lStart : rStart) : (traverseLeft ? lStart : rStart);
                 sp[WAVE] = leftCloser ? rStart : lStart;                // the far child, above the top: part of the stack only if sp moves
                 const bool full = sp == stkFull, nonEmpty = sp != stkBase;
@@ -618,6 +620,11 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 float by, bz, t;
                 if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hitT) {
                     hitTri = i; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = MULTI ? xformId : inst.MeshTransformId;
+                    if (ANY) {   // the first intersection found wins: nothing of this ray is left to do
+                        top = 0u; sp = stkBase;
+                        if (MULTI) { instIdx = (uint32_t)s.instanceCount; moreInst = false; }
+                        break;
+                    }
                 }
             }
             leafPending = false;

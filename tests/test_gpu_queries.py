@@ -113,9 +113,9 @@ def test_device_pointer_queries_equal_the_host_pointer_calls(native_builder, ora
 
 
 @pytest.mark.parametrize("scene", ["one_blas", "instances", "tlas"])
-def test_closest_hit_queries_on_the_frame_scheduler_equal_the_thread_per_ray_kernel(native_builder, oracle_mod, scene):
-    """idkptTraceRays (closest hit) runs on k_trace2's persistent-wave scheduler (k_query_prepare -> k_trace2 -> k_query_finish); option query_scheduler 0 keeps the
-    thread-per-ray kernel.  Both equal the oracle's TraceRay (BVHIntersect.glsl:183-291) in every field: ragged counts, rays limited to a range shorter than their first hit,
+def test_queries_on_the_frame_scheduler_equal_the_thread_per_ray_kernel(native_builder, oracle_mod, scene):
+    """idkptTraceRays (closest and any hit) runs on k_trace2's persistent-wave scheduler (k_query_prepare -> k_trace2 -> k_query_finish); option query_scheduler 0 keeps the
+    thread-per-ray kernel.  Both equal the oracle's TraceRay / TraceRayAny (BVHIntersect.glsl:107-411) in every field: ragged counts, rays limited to a range shorter than their first hit,
     rays that start inside / outside the root box, sphere lights in front of and behind the geometry, visit counters of the frame untouched."""
     from idkengine_amd.pathtracer import PathTracer
     if scene == "one_blas":
@@ -133,10 +133,11 @@ def test_closest_hit_queries_on_the_frame_scheduler_equal_the_thread_per_ray_ker
             pt = PathTracer(16, 16); pt.set_option("query_scheduler", sched); pt.UploadScene(sc); pt.UseTlas = int(scene == "tlas")
             pt.enable_counters(True)
             for lights in (False, True):
-                got = pt.TraceRays(rays[:n], trace_lights=lights)
-                ref = oracle_mod.trace_rays(sc, rays[:n], trace_lights=lights, use_tlas=scene == "tlas")
-                assert got.tobytes() == ref.tobytes()
-                if n > 1000:
-                    assert (got["Hit"] != 0).any() and (got["Hit"] == 0).any()
+                for any_hit in (False, True):                   # (TraceRayAny takes the same route: k_trace2's ANY instantiations, BVHIntersect.glsl:107-181, 299-411)
+                    got = pt.TraceRays(rays[:n], any_hit=any_hit, trace_lights=lights)
+                    ref = oracle_mod.trace_rays(sc, rays[:n], any_hit=any_hit, trace_lights=lights, use_tlas=scene == "tlas")
+                    assert got.tobytes() == ref.tobytes()
+                    if n > 1000:
+                        assert (got["Hit"] != 0).any() and (got["Hit"] == 0).any()
             st = pt.stats(); assert st["node_pair_visits"] == 0 and st["triangle_tests"] == 0       # (queries do not count as frame traversal)
             pt.Dispose()
