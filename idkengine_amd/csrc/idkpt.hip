@@ -23,6 +23,7 @@ using namespace ptd;
 #include "kernels_common.hpp"
 #include "kernels_trace.hpp"
 #include "kernels_trace_split.hpp"
+#include "kernels_trace_quad.hpp"
 #include "kernels_query.hpp"
 #include "kernels_shade.hpp"
 #include "kernels_trace_fused.hpp"
@@ -71,6 +72,7 @@ struct DevOptions {
     int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
     int splitScatter = 6;        // k_trace2s: log2 of the entries that stay together when the work list is handed out scattered (6 = list order)
     int queryScheduler = 1;      // idkptTraceRays (closest hit) through k_trace2's scheduler instead of the thread-per-ray kernel (kernels_query.hpp)
+    int quad = 0;                // k_trace2q (kernels_trace_quad.hpp): two binary levels per round trip on a derived 192-B record.  0 off, 1 small launches (want_quad), 2 wherever it applies
     int fused = 1;               // k_trace_fused (kernels_trace_fused.hpp): FirstHit + shading + the last NHit's traversal in one persistent launch at RayDepth 2.  0 off, 1 small launches on sparse views (want_fused), 2 wherever it is exact
     int fusedShadeMin = 16;      // ... lanes that wait for the shading phase before it runs (or as many as are still tracing)
     int splitPeek = 64;          // k_trace2s: iterations between two looks at the work-list heads (a wave with < 32 idle lanes never refills, so it has to ask whether the list is empty).  Measured: 64 -> 16 -> 8 -> 2 = 2 147 -> 1 750 -> 1 743 -> 1 697 Mray/s on the headline view one frame at a time: splitting EARLY multiplies pieces (and their bookkeeping) while most lanes still have rays of their own; it pays in the real tail only
@@ -103,7 +105,7 @@ struct dev_ctx {
     uint32_t seqFirst = 0, seqStride = 1;                         // idkptSetSampleSequence
     // scene
     bool haveScene = false, frameOk = false;
-    DevBuf nodes, tnodes, nodeSlot, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, queryRec, queryList, tileClass, gbases;   // (+ camTab below)
+    DevBuf nodes, tnodes, nodeSlot, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, queryRec, queryList, quads, tileClass, gbases;   // (+ camTab below)
     std::vector<DevBuf> texData; std::vector<std::pair<int, int>> texDims;
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
@@ -111,6 +113,8 @@ struct dev_ctx {
     std::vector<char> refitCoversAll;                // per BLAS: leaves + internal nodes of the refit schedule are every node but node 0 (a refit into a fresh slot needs no copy of the old nodes)
     int nodeCount = 0, triCount = 0, instanceCount = 0, tlasCount = 0, vertexCount = 0, meshCount = 0, materialCount = 0, xformCount = 0, lightCount = 0, skySize = 0, textureCount = 0, unskinnedCount = 0;
     int sceneStack = 1;
+    int hInst0Blas = 0;                              // BlasId of instance 0 (MODE 0 traverses that BLAS)
+    bool quadValid = false;                          // `quads` (kernels_trace_quad.hpp) matches the current nodes
     bool layoutActive = false;                       // tnodes holds the derived order (else the traversal reads `nodes`)
     // scene versions: slot count a versioned buffer may grow to, per buffer the bytes of one state / the slot pitch / the slots its arena holds / the current slot
     int verSlots = 1; size_t vbytes[VB_COUNT] = {0}, vstride[VB_COUNT] = {0}; int valloc[VB_COUNT] = {1, 1, 1, 1, 1, 1}, vcur[VB_COUNT] = {0};
@@ -180,7 +184,7 @@ static int local_rows(int H, int mod, int rem, int bandLog2 = 0)
 
 template <bool PRIMARY>
 static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
-                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, bool spec = false, int bounce = 0, bool anyHit = false)
+                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, bool spec = false, int bounce = 0, bool anyHit = false, bool quad = false)
 {
     if (anyHit) {   // idkptTraceRays with IDKPT_TRACE_ANY_HIT (kernels_query.hpp): TraceRayAny's walk on the same scheduler
 #define T2A(M) hipLaunchKernelGGL((k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
@@ -196,6 +200,24 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
     }
 #endif
     (void)spec;
+    if (quad && !s.ver && !f.useTlas && ctx->instanceCount == 1 && !ctx->counters && ctx->verSlots == 1 && !f.queryMode && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {
+        // two binary levels per round trip (kernels_trace_quad.hpp); the 192-B records are (re-)derived when the nodes have changed since
+        bool ok = true;
+        if (!ctx->quadValid) {
+            ok = ctx->quads.ensure((size_t)ctx->nodeCount * 96 + 256) == hipSuccess;
+            if (ok) {
+                const float4* tn = (const float4*)s.tnodes;
+                for (const GpuBlasDesc& d : ctx->hDescs)
+                    if (d.NodeCount >= 4) hipLaunchKernelGGL(k_derive_quads, dim3(((uint32_t)d.NodeCount / 2 + 256) / 256), dim3(256), 0, st, tn + 2 * (size_t)d.NodeOffset, ctx->quads.as<float4>() + 6 * (size_t)d.NodeOffset, (uint32_t)d.NodeCount);
+                ctx->quadValid = true;
+            }
+        }
+        if (ok) {
+            const GpuBlasDesc& d0 = ctx->hDescs[ctx->hInst0Blas];
+            hipLaunchKernelGGL((k_trace2q<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, (const float4*)(ctx->quads.as<float4>() + 6 * (size_t)d0.NodeOffset));
+            return;
+        }
+    }
     if (split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && !ctx->counters && ctx->sceneNested && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {   // small launch: long rays are split across idle lanes (kernels_trace_split.hpp)
         hipLaunchKernelGGL((k_trace2s<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work);
         return;
@@ -347,6 +369,7 @@ template <class T> static T* vb_cur(dev_ctx* ctx, int b) { return (T*)vb_ptr(ctx
 // after idkptUploadScene / a clone / a re-derived node order: one state per buffer, in slot 0 of whatever allocation the buffer has
 static void ver_reset(dev_ctx* ctx)
 {
+    ctx->quadValid = false;
     const size_t one[VB_COUNT] = {(size_t)ctx->nodeCount * 32, ctx->layoutActive ? (size_t)ctx->nodeCount * 32 : 0, (size_t)ctx->triCount * 48, (size_t)ctx->vertexCount * 16,
                                   (size_t)std::max(ctx->tlasCount, 2 * ctx->instanceCount - 1) * 32, (size_t)ctx->xformCount * sizeof(GpuMeshTransform)};
     for (int b = 0; b < VB_COUNT; b++) { ctx->vbytes[b] = one[b]; ctx->vstride[b] = (one[b] + 255) / 256 * 256; ctx->valloc[b] = 1; ctx->vcur[b] = 0; ctx->lastMask[b] = 0; ctx->lastSlots[b] = 0; }
@@ -371,6 +394,7 @@ static int ver_grow(dev_ctx* ctx, int b)
 // `full`: the update rewrites every byte of the buffer's state (nothing to carry over).  May launch queued samples / complete a deferred bounce when no slot is free.
 static int ver_writable(dev_ctx* ctx, int b, bool full, char** src, char** dst)
 {
+    if (b == VB_NODES || b == VB_TNODES) ctx->quadValid = false;   // (somebody is about to rewrite node boxes: the quad records are re-derived before their next use)
     const int p = ctx->vcur[b];
     auto free_slot = [&](uint64_t busy) { if (ctx->verSlots > 1 && ctx->vbytes[b] > 0) for (int k = 0; k < ctx->verSlots; k++) if (!((busy >> k) & 1ull)) return k; return -1; };
     uint64_t pend = 0; for (const PendingSample& ps : ctx->pending) pend |= 1ull << ps.vs[b];
@@ -572,7 +596,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->quads, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -802,7 +826,7 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     ctx->nodeCount = sc->BlasNodeCount; ctx->triCount = sc->BlasTriangleCount; ctx->instanceCount = sc->BlasInstanceCount; ctx->tlasCount = sc->TlasNodes ? sc->TlasNodeCount : 0;
     ctx->vertexCount = sc->VertexCount; ctx->meshCount = sc->MeshCount; ctx->materialCount = sc->MaterialCount; ctx->xformCount = sc->MeshTransformCount;
     ctx->lightCount = sc->Lights ? sc->LightCount : 0; ctx->textureCount = sc->TextureCount;
-    ctx->hDescs.assign(sc->BlasDescs, sc->BlasDescs + sc->BlasDescCount);
+    ctx->hDescs.assign(sc->BlasDescs, sc->BlasDescs + sc->BlasDescCount); ctx->hInst0Blas = (int)sc->BlasInstances[0].BlasId;
     ctx->sceneStack = maxStack; ctx->tlasNeed = std::max(1, tlasNeed);
     ctx->sceneNested = blas_nested(sc->BlasNodes, sc->BlasDescs, sc->BlasDescCount);
     ver_reset(ctx);                                   // one state per versioned buffer, in slot 0 (everything that read the old scene was launched by FLUSH above)
@@ -894,7 +918,7 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
     ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
     ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
-    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneNested = src->sceneNested; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
+    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->hInst0Blas = src->hInst0Blas; ctx->quadValid = false; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneNested = src->sceneNested; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
     ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase; ctx->refitCoversAll = src->refitCoversAll;
     ver_reset(ctx);
     HIPC(hipStreamSynchronize(ctx->stream));           // td is a stack vector
@@ -1003,6 +1027,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "split_peek") o.splitPeek = std::max(1, value);
     else if (n == "split_scatter") o.splitScatter = std::min(6, std::max(0, value));
     else if (n == "query_scheduler") o.queryScheduler = value != 0;
+    else if (n == "quad") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: quad is 0..2"); o.quad = value; }
     else if (n == "fused") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: fused is 0..2"); o.fused = value; }
     else if (n == "fused_shade_min") o.fusedShadeMin = std::min(64, std::max(1, value));
     else if (n == "instance_records") o.instanceRecords = value != 0;
@@ -1808,6 +1833,14 @@ static bool want_fused(const dev_ctx* ctx, uint32_t prev, bool known, int sample
     const uint64_t pixels = (uint64_t)ctx->W * ctx->rows * (uint64_t)std::max(1, samples);
     return known && prev > 0u && prev < FUSED_MAX_RAYS && (uint64_t)prev * 2u < pixels;
 }
+// k_trace2q (kernels_trace_quad.hpp): two binary levels per round trip; 3x the bytes, so only where the chain of the longest rays bounds the launch
+#define QUAD_MAX_RAYS 1500000u
+static bool want_quad(const dev_ctx* ctx, uint32_t prev, bool known)
+{
+    if (ctx->opt.quad == 0) return false;
+    if (ctx->opt.quad >= 2) return true;
+    return known && prev > 0u && prev < QUAD_MAX_RAYS;
+}
 #define SPEC_MAX_RAYS 1500000u
 static bool want_spec(const dev_ctx* ctx, uint32_t prev, bool known)
 {
@@ -2013,7 +2046,8 @@ static int flush_batch(dev_ctx* ctx)
                 hipLaunchKernelGGL((k_trace_fused<32>), dim3(grid0), dim3(WAVE), ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
             } else
             launch_trace2<true>(ctx, grid0, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, work + 0, counters,
-                                want_split(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B), want_spec(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B));
+                                want_split(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B), want_spec(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B), 0, false,
+                                want_quad(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B));
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
             if (fused) {}
@@ -2108,7 +2142,8 @@ static int flush_batch(dev_ctx* ctx)
         if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) gridj = small_launch_grid(traceGrid, ctx->hBases[(size_t)j * BS + B], hintMul, ctx->opt.gridRaysX4, midGrid);
         if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, trj, hits, (const uint32_t*)q, cnt, work + j, counters,
                                        want_split(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr, B),
-                                       want_spec(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr), j);
+                                       want_spec(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr), j, false,
+                                       want_quad(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr));
         else {
             if (ctx->counters) hipLaunchKernelGGL((k_trace_queue<true>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);
             else hipLaunchKernelGGL((k_trace_queue<false>), dim3(traceGrid), dim3(WAVE), ldsBytes, st, s, f, rays, hits, (const uint32_t*)q, cnt, work + j, counters);

@@ -1,0 +1,89 @@
+"""k_trace2q (csrc/kernels_trace_quad.hpp): the traversal on derived 192-B records (a node pair + the pairs of its internal children) takes up to two of the reference's node
+steps (BVHIntersect.glsl:43-101) per memory round trip.  Every ray must execute exactly the sequential traversal: image, every ray record, alive queue and primary hits
+equal the oracle's bit for bit with the kernel forced on every launch, on scenes full of shared edges and coincident box faces, inside a triangle soup, with sphere lights,
+several samples per launch — and after the nodes changed under it (a host patch, a refit): the records are re-derived before their next use."""
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden")); sys.path.insert(0, HERE)
+import configs  # noqa: E402
+from idkengine_amd import scenes as S  # noqa: E402
+from gpu_helpers import bits, oracle_render  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(sc, cam, w, h, opts, frames, batch, **ov):
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov))
+    for k, v in opts.items():
+        pt.set_option(k, v)
+    pt.UploadScene(sc); pt.SetCamera(cam); pt.enable_primary_hit_capture(True); pt.set_max_batch(batch)
+    for _ in range(frames):
+        pt.Compute()
+    return pt
+
+
+def _same(pt, o):
+    assert (bits(pt.Result) == bits(o.image(0))).all()
+    gt, gtri, gb = pt.primary_hits(); ot, otri, ob = o.primary_hits()
+    assert (gtri == otri).all() and (bits(gt) == bits(ot)).all() and (bits(gb) == bits(ob)).all()
+    assert pt.rays().tobytes() == o.rays().tobytes()
+    assert (pt.alive_queue() == o.alive_queue()).all()
+    assert pt.stats()["rays_traced"] == o.stats()["rays_traced"]
+
+
+@pytest.mark.parametrize("case", ["cornell_lights", "soup_inside", "soup_outside", "atrium", "lucy"])
+def test_quad_records_replay_the_sequential_traversal(case, oracle_mod, native_builder):
+    ov = dict(RayDepth=4)
+    if case == "cornell_lights":
+        sc, w, h = S.cornell_scene(native_builder, variant="mixed"), 128, 96; cam = S.cornell_camera(w, h)
+        from idkengine_amd import gputypes as T
+        lights = np.zeros(2, T.GpuLight); lights["Position"] = [(0.0, 0.6, 0.2), (0.3, -0.2, 1.5)]; lights["Radius"] = [0.15, 0.1]; lights["Color"] = [(6.0, 5.0, 4.0), (1.0, 2.0, 6.0)]
+        sc.lights = lights; ov["DoTraceLights"] = 1
+    elif case == "soup_inside":
+        sc, w, h = S.soup_scene(40000, native_builder, seed=8), 200, 120; cam = S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(0.2, 0.1, -1.0))
+    elif case == "soup_outside":
+        sc, w, h = S.soup_scene(40000, native_builder, seed=9), 200, 120; cam = S.Camera(w, h)
+    elif case == "atrium":
+        sc, w, h = S.atrium_scene(30000, native_builder), 192, 108; cam = S.atrium_camera(w, h)
+    else:
+        m = np.load(os.path.join(HERE, "golden", "models", "lucy.npz"))
+        p = m["positions"].astype(np.float32); i = m["indices"].astype(np.uint32).reshape(-1, 3)
+        tp = p[i]; pp, ii, nrm, tan = S.flat_shaded(tp)
+        sc = S.assemble([{"meshes": [S.MeshInput(pp, ii, S.make_material((0.8, 0.7, 0.6, 1.0)), nrm, tan)]}], native_builder); w, h = 120, 160
+        c = 0.5 * (p.min(0) + p.max(0)); ext = float((p.max(0) - p.min(0)).max())
+        cam = S.Camera(w, h, position=(float(c[0]), float(c[1]), float(c[2] + 1.6 * ext)), fovy_deg=45.0)
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=3, **ov)
+    for opts, batch in (({"quad": 2}, 1), ({"quad": 2, "trace_waves": 1, "leaf_min": 1}, 1), ({"quad": 2, "node_layout": 0}, 3), ({"quad": 2, "grab_unit_log2": 6, "defer_last": 0}, 3), ({"quad": 1}, 1)):
+        pt = _render(sc, cam, w, h, opts, 3, batch, **ov)
+        _same(pt, o)
+        pt.Dispose()
+    o.close()
+
+
+def test_quad_records_follow_node_updates(oracle_mod, native_builder):
+    """A host patch of node boxes (idkptUpdateBuffer) and a refit (idkptRefitBlas) between frames: the records are derived again before the next launch reads them."""
+    from idkengine_amd import gputypes as T
+    sc = S.soup_scene(6000, native_builder, seed=3, refittable=True); w, h = 120, 80; cam = S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(0.1, 0.2, -1.0))
+    pt = _render(sc, cam, w, h, {"quad": 2}, 2, 1, RayDepth=3)
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=2, RayDepth=3)
+    _same(pt, o)
+    nodes = sc.blas_nodes.copy()
+    inner = [n for n in range(2, len(nodes)) if nodes["TriCount"][n] == 0 and nodes["TriStartOrChild"][n] != 0][:40]
+    for n in inner:                                                  # conservative growth of some child boxes: more is visited, nothing is lost
+        c = int(nodes["TriStartOrChild"][n]); nodes["Min"][c] -= np.float32(0.05); nodes["Max"][c] += np.float32(0.05)
+    pt.UpdateBuffer(T.IDKPT_BUF_BLAS_NODES, nodes); o.set_blas_nodes(nodes)
+    pt.Compute(); o.render()
+    _same(pt, o)
+    pos = sc.vertex_positions.copy(); pos[: len(pos) // 2] *= np.float32(1.03)
+    pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, pos); pt.RefitBlas(0)
+    refit = pt.DownloadBuffer(T.IDKPT_BUF_BLAS_NODES, T.GpuBlasNode, len(sc.blas_nodes))      # (the refit itself is checked in test_gpu_scene_updates.py: here the traversal of its result)
+    o.set_positions(pos); o.set_blas_nodes(refit)
+    pt.Compute(); o.render()
+    _same(pt, o)
+    pt.Dispose(); o.close()
