@@ -24,6 +24,7 @@ using namespace ptd;
 #include "kernels_trace.hpp"
 #include "kernels_trace_split.hpp"
 #include "kernels_trace_quad.hpp"
+#include "kernels_trace_park.hpp"
 #include "kernels_query.hpp"
 #include "kernels_shade.hpp"
 #include "kernels_trace_fused.hpp"
@@ -72,6 +73,7 @@ struct DevOptions {
     int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
     int splitScatter = 6;        // k_trace2s: log2 of the entries that stay together when the work list is handed out scattered (6 = list order)
     int queryScheduler = 1;      // idkptTraceRays (closest hit) through k_trace2's scheduler instead of the thread-per-ray kernel (kernels_query.hpp)
+    int park = 0;                // k_trace2p (kernels_trace_park.hpp): a lane may carry two parked leaves (the second found with a stale T, re-validated before it is tested).  Bit mask like leaf_pool: 1 primary launches, 2 first bounce, 4 later bounces
     int quad = 0;                // k_trace2q (kernels_trace_quad.hpp): two binary levels per round trip on a derived 192-B record.  0 off, 1 small launches (want_quad), 2 wherever it applies
     int fused = 1;               // k_trace_fused (kernels_trace_fused.hpp): FirstHit + shading + the last NHit's traversal in one persistent launch at RayDepth 2.  0 off, 1 small launches on sparse views (want_fused), 2 wherever it is exact
     int fusedShadeMin = 16;      // ... lanes that wait for the shading phase before it runs (or as many as are still tracing)
@@ -220,6 +222,10 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
     }
     if (split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && !ctx->counters && ctx->sceneNested && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {   // small launch: long rays are split across idle lanes (kernels_trace_split.hpp)
         hipLaunchKernelGGL((k_trace2s<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work);
+        return;
+    }
+    if (((ctx->opt.park >> std::min(bounce, 2)) & 1) && !s.ver && !f.useTlas && ctx->instanceCount == 1 && !ctx->counters && ctx->sceneNested && !f.queryMode && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)) {
+        hipLaunchKernelGGL((k_trace2p<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work);   // two parked leaves per lane (kernels_trace_park.hpp)
         return;
     }
     // pooled leaf phase (kernels_trace.hpp, DBG 16): per launch kind — option leaf_pool, a mask: 1 = primary launches, 2 = the first bounce, 4 = later bounces; -1 = automatic
@@ -1027,6 +1033,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "split_peek") o.splitPeek = std::max(1, value);
     else if (n == "split_scatter") o.splitScatter = std::min(6, std::max(0, value));
     else if (n == "query_scheduler") o.queryScheduler = value != 0;
+    else if (n == "park") o.park = value & 7;
     else if (n == "quad") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: quad is 0..2"); o.quad = value; }
     else if (n == "fused") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: fused is 0..2"); o.fused = value; }
     else if (n == "fused_shade_min") o.fusedShadeMin = std::min(64, std::max(1, value));

@@ -59,7 +59,10 @@ def test_quad_records_replay_the_sequential_traversal(case, oracle_mod, native_b
         c = 0.5 * (p.min(0) + p.max(0)); ext = float((p.max(0) - p.min(0)).max())
         cam = S.Camera(w, h, position=(float(c[0]), float(c[1]), float(c[2] + 1.6 * ext)), fovy_deg=45.0)
     o = oracle_render(oracle_mod, sc, cam, w, h, frames=3, **ov)
-    for opts, batch in (({"quad": 2}, 1), ({"quad": 2, "trace_waves": 1, "leaf_min": 1}, 1), ({"quad": 2, "node_layout": 0}, 3), ({"quad": 2, "grab_unit_log2": 6, "defer_last": 0}, 3), ({"quad": 1}, 1)):
+    # (+ k_trace2p, csrc/kernels_trace_park.hpp, option "park": a lane may carry a second parked leaf, found with a T that may still shrink and re-validated before its
+    # triangles are tested — another measured-and-not-shipped variant that has to report exactly the sequential hits)
+    for opts, batch in (({"quad": 2}, 1), ({"quad": 2, "trace_waves": 1, "leaf_min": 1}, 1), ({"quad": 2, "node_layout": 0}, 3), ({"quad": 2, "grab_unit_log2": 6, "defer_last": 0}, 3), ({"quad": 1}, 1),
+                        ({"park": 7}, 1), ({"park": 7, "trace_waves": 1, "leaf_min": 1}, 3), ({"park": 5, "leaf_min": 40, "defer_last": 0}, 3)):
         pt = _render(sc, cam, w, h, opts, 3, batch, **ov)
         _same(pt, o)
         pt.Dispose()

@@ -99,6 +99,7 @@ def draw_case(seed, builder):
             "grid_rays_x4": int(rng.choice([6, 6, 0, 1, 64])), "grid_mid_waves": int(rng.choice([20, 20, 0, 3])), "defer_last": int(rng.choice([1, 1, 0])), "grid_hint": int(rng.choice([2, 2, 0, 1])), "trace_waves": int(rng.choice([0, 0, 1, 7])),
             "split": int(rng.choice([1, 2, 2, 3, 0])), "split_donor": int(rng.choice([0, 1]))}
     opts["fused"] = int(rng.choice([0, 2, 2, 1])); opts["fused_shade_min"] = int(rng.choice([16, 1, 8, 32, 64]))
+    opts["quad"] = int(rng.choice([0, 0, 2])); opts["park"] = int(rng.choice([0, 0, 7, 2])); opts["query_scheduler"] = 1
     # free choices of the implementation: never visible in the output (split is drawn last: the cases of earlier rounds keep their scenes)
     return sc, cam, w, h, ov, st, opts, frames, batch, nb
 
