@@ -131,6 +131,7 @@ struct dev_ctx {
     DevBuf camTab;                                       // per-sample cameras of the batch being launched (ring mode)
     int rowLimit = 0x7fffffff;                           // idkptSetRowRange: at most this many local rows
     idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // exact multi-GPU deep paths (idkptSetBounceExchange)
+    idkpt_band_exchange_fn bandExchangeFn = nullptr; void* bandExchangeUser = nullptr; DevBuf bandTab;   // ... for interleaved rows / bands (idkptSetBandExchange)
     // stats
     idkpt_stats stats;
     uint32_t* hCounts = nullptr; uint32_t* dCountsMirror = nullptr;   // host-mapped mirror of the queue lengths (written by k_scan_blocks, read by the host after a sync)
@@ -602,7 +603,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
-                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->quads, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
+                     &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->quads, &ctx->bandTab, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
     for (DevBuf* b : all) b->release();
@@ -690,6 +691,14 @@ static int32_t dev_SetBounceExchange(dev_ctx* ctx, idkpt_bounce_exchange_fn fn, 
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     FLUSH();
     ctx->exchangeFn = fn; ctx->exchangeUser = user;
+    return IDKPT_OK;
+}
+
+static int32_t dev_SetBandExchange(dev_ctx* ctx, idkpt_band_exchange_fn fn, void* user)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    FLUSH();
+    ctx->bandExchangeFn = fn; ctx->bandExchangeUser = user;
     return IDKPT_OK;
 }
 
@@ -2008,7 +2017,7 @@ static int flush_batch(dev_ctx* ctx)
     // one launch for FirstHit + the last NHit (kernels_trace_fused.hpp): RayDepth 2, one BLAS instance, the last bounce deferred (no AOVs, no debug view), nothing that looks at
     // the primary hits or the visit counters, no per-bounce exchange with other contexts — and a launch small enough to be bound by its longest rays
     const bool fused = fast && ctx->st.RayDepth == 2 && ctx->opt.deferLast != 0 && !f.outputAovs && !f.g.DoDebugBVHTraversal && !f.useTlas && ctx->instanceCount == 1 && !multiVer && !ctx->counters
-                       && !ctx->capturePrimary && !ctx->groupExchange && !ctx->exchangeFn && f.recPerRay == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)
+                       && !ctx->capturePrimary && !ctx->groupExchange && !ctx->exchangeFn && !ctx->bandExchangeFn && f.recPerRay == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)
                        && want_fused(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B);
     f.hitsByRid = fused ? 1 : 0; f.shadeMin = ctx->opt.fusedShadeMin; f.scatterLog2 = ctx->opt.splitScatter;
     if (!fast && (B != 1 || multiVer)) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
@@ -2101,7 +2110,24 @@ static int flush_batch(dev_ctx* ctx)
             HIPC(hipMemcpyAsync(ctx->gbases.p, outBases.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
             HIPC(hipStreamSynchronize(st));                      // outBases is a stack vector
             gbase = ctx->gbases.as<uint32_t>();
+        } else if (ctx->bandExchangeFn && ctx->rowMod > 1 && !(ctx->st.DoRaySorting && j > 1)) {
+            // interleaved rows / bands (idkpt.h idkptSetBandExchange): the rays of one local band are a contiguous run of a sample's queue segment (ordered compaction);
+            // the host returns, per (sample, band), the alive rays of all contexts in the image bands before it; k_shade adds the position inside the run
+            const int bandRows = 1 << ctx->rowBandLog2, LB = (ctx->rows + bandRows - 1) / bandRows;
+            HIPC(ctx->bandTab.ensure((size_t)2 * MAX_BATCH * ((size_t)LB + 1) * 4));
+            uint32_t* dStarts = ctx->bandTab.as<uint32_t>(); uint32_t* dTab = dStarts + (size_t)MAX_BATCH * (LB + 1);
+            hipLaunchKernelGGL(k_band_starts, dim3((uint32_t)(((size_t)B * (LB + 1) + 255) / 256)), dim3(256), 0, st, (const uint32_t*)q, (const uint32_t*)(bases + j * BS), B, LB, (uint32_t)ctx->W * (uint32_t)bandRows, Npad, dStarts);
+            std::vector<uint32_t> starts((size_t)B * (LB + 1)), local((size_t)B * LB), outBases((size_t)B * LB, 0u), tab((size_t)B * LB);
+            HIPC(hipMemcpyAsync(starts.data(), dStarts, starts.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            for (int k2 = 0; k2 < B; k2++) for (int b2 = 0; b2 < LB; b2++) local[(size_t)k2 * LB + b2] = starts[(size_t)k2 * (LB + 1) + b2 + 1] - starts[(size_t)k2 * (LB + 1) + b2];
+            ctx->bandExchangeFn(ctx->bandExchangeUser, j, B, LB, local.data(), outBases.data());
+            for (int k2 = 0; k2 < B; k2++) for (int b2 = 0; b2 < LB; b2++) tab[(size_t)k2 * LB + b2] = outBases[(size_t)k2 * LB + b2] - starts[(size_t)k2 * (LB + 1) + b2];   // (mod 2^32: + position inside the sample's segment = global slot)
+            HIPC(hipMemcpyAsync(dTab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+            HIPC(hipStreamSynchronize(st));                      // tab is a stack vector
+            gbase = dTab; f.gbStride = LB; f.gbBands = 1;
         }
+        if (!(ctx->bandExchangeFn && ctx->rowMod > 1) || (ctx->st.DoRaySorting && j > 1)) { f.gbStride = 1; f.gbBands = 0; }
         if (ctx->st.DoRaySorting && j > 1) {
             // RaySorting() (PathTracer.cs:232-237): stable sort of (key, rayIndex); key = 21-bit triangle id with the batch's
             // sample index above it, so one sort orders every sample's queue exactly like a stand-alone counting sort

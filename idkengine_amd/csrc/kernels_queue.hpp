@@ -2,6 +2,20 @@
 // Part of the single translation unit idkpt.hip (included there, in this order); see DESIGN.md §4 for the kernel table.
 #pragma once
 
+// idkptSetBandExchange: where, inside sample k's segment [bases[k], bases[k + 1]) of the alive queue (ray ids = k * Npad + local pixel, ascending: ordered compaction),
+// the rays of local band b start — starts[k * (LB + 1) + b], relative to bases[k]; b = LB: the segment's length.  One binary search per (sample, band).
+__global__ __launch_bounds__(256) void k_band_starts(const uint32_t* queue, const uint32_t* bases, int B, int LB, uint32_t bandPixels, uint32_t Npad, uint32_t* starts)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint32_t)B * (uint32_t)(LB + 1)) return;
+    const uint32_t k = t / (uint32_t)(LB + 1), b = t % (uint32_t)(LB + 1);
+    const uint32_t lo0 = bases[k], hi0 = bases[k + 1];
+    const unsigned long long key = (unsigned long long)k * Npad + (unsigned long long)b * bandPixels;   // first ray id of that band
+    uint32_t lo = lo0, hi = hi0;
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((unsigned long long)queue[mid] < key) lo = mid + 1; else hi = mid; }
+    starts[t] = lo - lo0;
+}
+
 // Ordered (= sequential enqueue order) compaction in three launches: (1) per 256-wave block: continue masks (from the
 // shade kernel's ballots, or rebuilt from per-ray bytes) -> exclusive offsets inside the block + block total,
 // (2) one workgroup scans the block totals and derives the next queue length and every sample's first slot,

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene s0, Frame f, RayBufs rays,
                 int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
                 gidSeed = first_hit_gid_seed(f.W, f.H, lx, global_row(f, ly));
             } else {
-                uint32_t gslot = (gbase ? gbase[smp] : 0u) + (slot - qbase[smp]);  // slot inside this sample's own queue (+ the alive rays of the strips above, idkptSetBounceExchange)
+                uint32_t gslot = (gbase ? gbase[f.gbBands ? smp * (uint32_t)f.gbStride + ((pix / (uint32_t)f.W) >> f.rowBandLog2) : smp] : 0u) + (slot - qbase[smp]);  // slot inside this sample's own queue (+ the alive rays of the strips above, idkptSetBounceExchange)
                 rng = gslot * 4096u + acc;            // NHit:54
                 gidSeed = gslot;                      // Shading.glsl:74 with gl_GlobalInvocationID = (slot, 0)
             }

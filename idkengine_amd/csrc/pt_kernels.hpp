@@ -68,6 +68,7 @@ struct Frame {
     int splitPeek;              // k_trace2s: iterations between two looks at the work-list heads of a wave that is too busy to refill
     int splitMode;              // k_trace2s (kernels_trace_split.hpp): bits 0-1: 2 = every ray whose pieces found a hit is traced again sequentially (test hook for the re-trace path); bit 2: only rays without a hit donate subtrees
     int scatterLog2;            // k_trace2s: the work list is handed out in groups of 2^scatterLog2 entries taken from places far apart (6 = in list order)
+    int gbStride, gbBands;      // per-bounce slot bases (k_shade's gbase): one per sample (strips: stride 1, gbBands 0) or one per (sample, local band) for interleaved rows (idkptSetBandExchange)
     int queryMode;              // k_trace2 serves idkptTraceRays: a ray starts from the T / light its trace-ready record carries (record[1].w, record[2].w) instead of FLOAT_MAX / 0
     int shadeMin;               // k_trace_fused: lanes that wait for the shading phase before it runs
     int hitsByRid;              // the last bounce's hit records are indexed by ray id instead of queue slot (k_trace_fused, kernels_trace_fused.hpp)

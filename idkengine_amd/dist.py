@@ -8,8 +8,9 @@ CPU tests).  The reference is single-GPU; this is the MI355X-n
   * per frame the only exchange is the all-gather of the finished row shards (4.1 MB per GPU at 1080p on 8 GPUs);
   * no data-path collective inside a frame.  At RayDepth 2 (the headline metric) radiance is independent of the queue
     slot, so N-GPU output == 1-GPU output bit-for-bit.  For deeper paths the NHit RNG seeds depend on the
-    queue slot: `exact_deep_paths` switches to contiguous strips + an all-gather of the per-sample alive counts per bounce
-    (idkptSetRowRange / idkptSetBounceExchange, make_count_exchange), which restores bit-exact parity at any depth (sorting off);
+    queue slot: `exact_deep_paths` adds an all-gather of the per-(sample, band) alive counts per bounce (idkptSetBandExchange, make_band_exchange: the interleaved
+    deal stays) — or, with "strips", switches to contiguous strips + per-sample counts (idkptSetRowRange / idkptSetBounceExchange, make_count_exchange) — which
+    restores bit-exact parity at any depth (sorting off);
     without it parity beyond depth 2 is statistical.
 """
 import numpy as np
@@ -56,6 +57,45 @@ def make_count_exchange(group=None):
         for r in range(rank):
             base += parts[r].numpy()
         return base.astype(np.uint32)
+    return exchange
+
+
+def local_band_count(height, world, rank, band):
+    """Bands (complete or the image's last, partial one) that the round-robin deal gives to `rank`."""
+    total = (height + band - 1) // band
+    return len(range(rank, total, world))
+
+
+def band_bases(counts_by_rank, world):
+    """counts_by_rank[r][k][b] = alive rays of sample k in rank r's b-th band (image band b * world + r).  -> bases[r][k][b] = alive rays of sample k in all image bands
+    before that band (the arithmetic of idkptSetBandExchange's host side; also used by the tests)."""
+    samples = len(counts_by_rank[0])
+    total = sum(len(c[0]) if len(c) else 0 for c in counts_by_rank)
+    bases = [np.zeros_like(np.asarray(c, np.uint32)) for c in counts_by_rank]
+    for k in range(samples):
+        cum = 0
+        for gb in range(total):
+            r, b = gb % world, gb // world
+            bases[r][k][b] = cum
+            cum += int(counts_by_rank[r][k][b])
+    return bases
+
+
+def make_band_exchange(height, band, group=None):
+    """Host side of idkptSetBandExchange for one process per rank with rows dealt in bands of `band` rows: all-gather of the per-(sample, band) alive counts (a few hundred
+    uint32 per bounce and batch, on the CPU: a gloo group next to the RCCL one), then the running sum over the image's bands."""
+    rank = dist.get_rank(group); world = dist.get_world_size(group)
+    lbs = [local_band_count(height, world, r, band) for r in range(world)]
+    lb_max = max(lbs)
+
+    def exchange(bounce, local_counts):
+        samples = local_counts.shape[0]
+        mine = torch.zeros((samples, lb_max), dtype=torch.int64)
+        mine[:, :lbs[rank]] = torch.from_numpy(np.ascontiguousarray(local_counts, np.int64))
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        by_rank = [parts[r].numpy()[:, :lbs[r]].astype(np.uint32) for r in range(world)]
+        return band_bases(by_rank, world)[rank]
     return exchange
 
 
@@ -124,21 +164,25 @@ class GpuShardRenderer:
     aliases the library's device image (no host copy before the RCCL all-gather)."""
 
     def __init__(self, width, height, world, rank, device_index, exact_deep_paths=False, control_group=None, row_band=None):
-        """exact_deep_paths: contiguous strips + per-bounce count exchange over `control_group` (a CPU/gloo group), so that N-GPU
-        output equals 1-GPU output bit for bit at any RayDepth (sorting off); default: interleaved bands of `row_band` rows (None: 8, or
-        single rows on images with fewer bands than ranks), exact at RayDepth 2."""
+        """Rows are dealt in interleaved bands of `row_band` rows (None: 8, or single rows on images with fewer bands than ranks): exact at RayDepth 2 as is.
+        exact_deep_paths: + a per-bounce exchange of the per-band alive counts over `control_group` (a CPU/gloo group, idkptSetBandExchange), so that N-GPU output equals
+        1-GPU output bit for bit at ANY RayDepth (sorting off) with the balanced deal; exact_deep_paths="strips": contiguous strips + per-sample counts (round 2's mode:
+        exact as well, but 8 strips of the headline camera scale 4.2x where 8 interleaved shards scale 7.6x)."""
         from .pathtracer import PathTracer
         torch.cuda.set_device(device_index)
         self.device = torch.device("cuda", device_index)
-        self.exact = exact_deep_paths
-        self.row_band = 1 if exact_deep_paths or world == 1 else (band_of_deal(height, world) if row_band is None else int(row_band))
-        if exact_deep_paths:
+        strips = exact_deep_paths == "strips"
+        self.exact = strips                                              # (ShardedFrame: the rows of this renderer are a contiguous strip)
+        self.row_band = 1 if strips or world == 1 else (band_of_deal(height, world) if row_band is None else int(row_band))
+        if strips:
             self.pt = PathTracer(width, height, device=device_index)
             first, count = strip_of_rank(height, world, rank)
             self.pt.SetRowRange(first, count)
             self.pt.SetBounceExchange(make_count_exchange(control_group))
         else:
             self.pt = PathTracer(width, height, device=device_index, row_modulo=world, row_remainder=rank, row_band=self.row_band)
+            if exact_deep_paths and world > 1:
+                self.pt.SetBandExchange(make_band_exchange(height, self.row_band, control_group))
         # render on a dedicated torch stream and issue the collectives under it: RCCL work is then ordered after the
         # kernels that produce the image, and later renders are ordered after the collective that reads it
         self.stream = torch.cuda.Stream(device=self.device)

@@ -257,6 +257,24 @@ class PathTracer:
         self._xfn = proto(tramp)       # keep the trampoline alive as long as the context uses it
         self._check(self._L.idkptSetBounceExchange(self._ctx, self._xfn, None))
 
+    def SetBandExchange(self, fn):
+        """idkptSetBandExchange (interleaved rows / bands): fn(bounce, local_counts ndarray[samples, bands]) -> bases ndarray[samples, bands] = alive rays of the same
+        sample, over ALL contexts, in the image bands before each of this context's bands; None disables.  Exact N-GPU == 1-GPU results at any RayDepth (sorting off)."""
+        import ctypes as C
+        if fn is None:
+            self._bxfn = None
+            self._check(self._L.idkptSetBandExchange(self._ctx, None, None))
+            return
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+
+        def tramp(user, bounce, samples, bands, counts, out):
+            n = samples * bands
+            b = np.asarray(fn(int(bounce), np.ctypeslib.as_array(counts, shape=(n,)).astype(np.uint32).reshape(samples, bands)), np.uint32).reshape(-1)
+            for i in range(n):
+                out[i] = int(b[i])
+        self._bxfn = proto(tramp)      # keep the trampoline alive as long as the context uses it
+        self._check(self._L.idkptSetBandExchange(self._ctx, self._bxfn, None))
+
     def synchronize(self):
         self._check(self._L.idkptSynchronize(self._ctx))
 

@@ -190,6 +190,15 @@ IDKPT_API int32_t idkptSetRowRange(idkpt_ctx* ctx, int32_t firstRow, int32_t row
  * Exact with DoRaySorting off; with sorting on the per-context sort is local and parity beyond depth 2 is statistical.  NULL disables. */
 typedef void (*idkpt_bounce_exchange_fn)(void* user, int32_t bounce, int32_t sampleCount, const uint32_t* localCounts, uint32_t* outBases);
 IDKPT_API int32_t idkptSetBounceExchange(idkpt_ctx* ctx, idkpt_bounce_exchange_fn fn, void* user);
+/* The same for INTERLEAVED rows / bands (idkptSetRowSharding, idkptSetRowBands), which balance a frame far better than strips (on the headline camera 8 strips scale
+ * 4.2x, 8 interleaved shards 7.6x: the middle strips hold the scene).  A context's alive queue is in local pixel order, so the rays of one local band (bandRows rows; single
+ * rows with idkptSetRowSharding) are a contiguous run of slots.  At the start of bounce j the library calls fn(user, j, sampleCount, bandCount, localCounts, outBases) on the
+ * caller's thread (stream synchronised): localCounts[k * bandCount + b] = alive rays of in-flight sample k in this context's b-th band (image band b * rowModulo +
+ * rowRemainder) entering bounce j; the host fills outBases[k * bandCount + b] = alive rays of sample k, summed over ALL contexts, in the image bands BEFORE that band.
+ * Exact (N contexts == 1 context, bit for bit) at any RayDepth with DoRaySorting off; with sorting on the exchange is skipped beyond the first bounce.  Single-device
+ * contexts; NULL disables. */
+typedef void (*idkpt_band_exchange_fn)(void* user, int32_t bounce, int32_t sampleCount, int32_t bandCount, const uint32_t* localCounts, uint32_t* outBases);
+IDKPT_API int32_t idkptSetBandExchange(idkpt_ctx* ctx, idkpt_band_exchange_fn fn, void* user);
 /* Property setters of PathTracer (PathTracer.cs:12-125); changing anything but DoRussianRoulette/sorting/AOV
  * resets accumulation exactly like the reference setters do. */
 IDKPT_API int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* settings);

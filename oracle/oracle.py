@@ -192,6 +192,23 @@ class OraclePathTracer:
         self._xfn = proto(tramp)       # keep the trampoline alive
         lib().ref_pt_set_bounce_exchange(C.c_void_p(self._pt), self._xfn, None)
 
+    def set_band_exchange(self, fn):
+        """idkptSetBandExchange: fn(bounce, local_counts ndarray [bands]) -> bases ndarray [bands] (one sample per call here); None disables."""
+        if fn is None:
+            self._bxfn = None
+            lib().ref_pt_set_band_exchange(C.c_void_p(self._pt), None, None)
+            return
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+
+        def tramp(user, bounce, samples, bands, counts, out):
+            n = samples * bands
+            b = fn(int(bounce), np.array([counts[i] for i in range(n)], np.uint32).reshape(samples, bands))
+            b = np.asarray(b, np.uint32).reshape(-1)
+            for i in range(n):
+                out[i] = int(b[i])
+        self._bxfn = proto(tramp)      # keep the trampoline alive
+        lib().ref_pt_set_band_exchange(C.c_void_p(self._pt), self._bxfn, None)
+
     def close(self):
         if self._pt:
             lib().ref_pt_destroy(self._pt); lib().ref_scene_destroy(self._scene)

@@ -439,6 +439,7 @@ struct PT {
     std::vector<float> primT, primBary; std::vector<uint32_t> primTri;
     uint32_t aliveCounts[16];
     idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // multi-context exact mode (idkptSetBounceExchange)
+    idkpt_band_exchange_fn bandExchangeFn = nullptr; void* bandExchangeUser = nullptr;   // ... for interleaved rows / bands (idkptSetBandExchange)
     Counters counters; bool countersOn = false;
     uint64_t raysTraced = 0;
     double parallelSec = 0.0, totalSec = 0.0;   // cpu_baseline leg of bench.py: time inside the per-invocation (OpenMP) sections / whole RenderSample
@@ -632,6 +633,17 @@ static void RenderSample(PT& pt)
         // exact multi-context mode: global slot = local slot + alive rays of the contexts that own earlier rows (include/idkpt.h)
         uint32_t slotBase = 0;
         if (pt.exchangeFn) { uint32_t localCount = (uint32_t)A; pt.exchangeFn(pt.exchangeUser, j, 1, &localCount, &slotBase); }
+        // interleaved rows / bands (idkptSetBandExchange): the queue is in local pixel order, so the rays of one local band are a contiguous run of slots; the host returns,
+        // per band, the alive rays of ALL contexts in the image bands before it: global slot = that + the position inside the run
+        std::vector<uint32_t> bandStart, bandBase;
+        const bool banded = pt.bandExchangeFn && pt.rowMod > 1 && !(pt.st.DoRaySorting && j > 1);
+        if (banded) {
+            const int LB = (pt.rows + pt.rowBand - 1) / pt.rowBand;
+            std::vector<uint32_t> cnt((size_t)LB, 0u); bandStart.assign((size_t)LB + 1, 0u); bandBase.assign((size_t)LB, 0u);
+            for (size_t i = 0; i < A; i++) cnt[(size_t)((pt.alive[i] / (uint32_t)pt.W) / (uint32_t)pt.rowBand)]++;
+            for (int b = 0; b < LB; b++) bandStart[(size_t)b + 1] = bandStart[(size_t)b] + cnt[(size_t)b];
+            pt.bandExchangeFn(pt.bandExchangeUser, j, 1, LB, cnt.data(), bandBase.data());
+        }
         std::vector<uint8_t> cont2(A); std::vector<uint32_t> keyOut(A, 0u);
         std::vector<Counters> chunkCnt((A + 255) / 256);
         // ---- NHit main (NHit/compute.glsl:40-89), one invocation per queue slot ----
@@ -641,6 +653,7 @@ static void RenderSample(PT& pt)
             for (size_t slot = (size_t)chunk * 256; slot < std::min(A, (size_t)(chunk + 1) * 256); slot++) {
                 uint32_t rayIndex = pt.alive[slot];
                 uint32_t gslot = slotBase + (uint32_t)slot;
+                if (banded) { const size_t lb = (size_t)((rayIndex / (uint32_t)pt.W) / (uint32_t)pt.rowBand); gslot = bandBase[lb] + ((uint32_t)slot - bandStart[lb]); }
                 Rng rng; rng.seed = gslot * 4096u + pt.sampleIndex();
                 GpuWavefrontRay wr = pt.rays[rayIndex]; GpuAovRay ar = pt.aov[rayIndex];
                 uint32_t key = 0;
@@ -856,6 +869,7 @@ void ref_pt_set_row_bands(void* p, int bandRows, int rowMod, int rowRem)
     pt->accumulated = 0;
 }
 void ref_pt_set_bounce_exchange(void* p, idkpt_bounce_exchange_fn fn, void* user) { PT* pt = (PT*)p; pt->exchangeFn = fn; pt->exchangeUser = user; }
+void ref_pt_set_band_exchange(void* p, idkpt_band_exchange_fn fn, void* user) { PT* pt = (PT*)p; pt->bandExchangeFn = fn; pt->bandExchangeUser = user; }
 void ref_pt_set_settings(void* p, const idkpt_settings* s) { ((PT*)p)->st = *s; }
 void ref_pt_set_perframe(void* p, const float* invProj, const float* invView, const float* viewPos) { PT* pt = (PT*)p; memcpy(pt->invProj, invProj, 64); memcpy(pt->invView, invView, 64); memcpy(pt->viewPos, viewPos, 12); }
 void ref_pt_reset_accumulation(void* p) { ((PT*)p)->accumulated = 0; }

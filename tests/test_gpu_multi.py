@@ -292,3 +292,76 @@ def test_multi_device_context_without_peer_access(native_builder, members, monke
         ptr, nbytes = a.image_device_ptr(0)
         assert (bits(read_device_image(a, ptr, nbytes, (h, w, 4))) == bits(b.Result)).all()
         a.Dispose(); b.Dispose()
+
+
+
+@pytest.mark.parametrize("batch,band", [(1, 8), (3, 8), (2, 1)])
+def test_exact_deep_paths_with_interleaved_bands(native_builder, oracle_mod, batch, band):
+    """idkptSetRowBands / idkptSetRowSharding + idkptSetBandExchange: three contexts with the BALANCED deal (interleaved bands of 8 rows, or single interleaved rows), driven by
+    three host threads in lockstep, the exchange function running dist.band_bases over everybody's per-(sample, band) counts: the single-context frame bit for bit at
+    RayDepth 6 — image, ray state, total ray count — also with several accumulated samples per batch.  And one banded context against the oracle under an arbitrary
+    exchange function: both number their slots the same way."""
+    import threading
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import dist as D, gputypes as T
+    sc = S.soup_scene(30000, native_builder, seed=6, extent=3.0); w, h = 200, 131; cam = S.Camera(w, h, position=(0.0, 0.0, 7.0))
+    ov = dict(RayDepth=6)
+    frames = 3
+    one = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); one.UploadScene(sc); one.SetCamera(cam)
+    for _ in range(frames):
+        one.Compute()
+    want = one.Result; want_rays = one.rays(); want_count = one.stats()["rays_traced"]
+    world = 3
+    barrier = threading.Barrier(world)
+    board = {}
+
+    def exchange_for(rank):
+        def fn(bounce, counts):
+            board[(bounce, rank)] = counts.copy()
+            barrier.wait(timeout=60)
+            mine = D.band_bases([board[(bounce, r)] for r in range(world)], world)[rank]
+            barrier.wait(timeout=60)                     # nobody overwrites the board before everybody has read it
+            return mine
+        return fn
+
+    pts, errs = [], []
+    for r in range(world):
+        p = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov), row_modulo=world, row_remainder=r, row_band=band); p.UploadScene(sc); p.SetCamera(cam)
+        p.SetBandExchange(exchange_for(r)); p.set_max_batch(batch)
+        pts.append(p)
+
+    def run(p):
+        try:
+            for _ in range(frames):
+                p.Compute()
+            p.flush(); p.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e); barrier.abort()
+    threads = [threading.Thread(target=run, args=(p,)) for p in pts]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errs, errs
+    want_rays2 = want_rays.reshape(h, w)
+    for r, p in enumerate(pts):
+        rows = D.rows_of_rank(h, world, r, band)
+        assert (bits(p.Result) == bits(want[rows])).all()
+        assert p.rays().reshape(len(rows), w).tobytes() == want_rays2[rows].tobytes()
+    assert sum(p.stats()["rays_traced"] for p in pts) == want_count
+    # control: a shard without the exchange differs at this depth
+    q = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov), row_modulo=world, row_remainder=1, row_band=band); q.UploadScene(sc); q.SetCamera(cam)
+    for _ in range(frames):
+        q.Compute()
+    assert (bits(q.Result) != bits(want[D.rows_of_rank(h, world, 1, band)])).any()
+    # one banded context == the oracle under the same (arbitrary) exchange function
+    fake = lambda bounce, counts: (np.arange(counts.size, dtype=np.uint32).reshape(counts.shape) * np.uint32(977) + np.uint32(31 * bounce))   # noqa: E731
+    q.SetBandExchange(fake); q.ResetAccumulation(); q.set_max_batch(1)
+    o = oracle_mod.OraclePathTracer(sc, w, h, row_modulo=world, row_remainder=1, row_band=band); o.set_camera(cam); configs.apply_settings(o.settings, ov)
+    o.set_band_exchange(fake)
+    for _ in range(2):
+        q.Compute(); o.render()
+    assert (bits(q.Result) == bits(o.image(0))).all() and q.rays().tobytes() == o.rays().tobytes() and (q.alive_queue() == o.alive_queue()).all()
+    o.close()
+    for p in pts + [one, q]:
+        p.Dispose()

@@ -29,6 +29,11 @@ def test_random_api_sequences_match_unbatched_replay(native_builder, seed):
         a.set_option("defer_last", 0)                    # (debugging aid: both sides eager)
     b.set_option("defer_last", 0)                        # the replay also shades every last bounce eagerly; `a` defers it where it may (the soup scene does not emit)
     a.set_max_batch(int(rng.integers(2, 9)))
+    # free choices of the implementation on the deferring side (their own generator: the call sequences of earlier rounds stay what they were): the kernels a launch
+    # may be given — fused FirstHit + NHit, split, quad records, two parked leaves, pooled leaves — must never show in what a host reads
+    orng = np.random.default_rng(9000 + seed)
+    for name, values in (("fused", [1, 2, 2, 0]), ("split", [1, 2, 3, 0]), ("quad", [0, 0, 2]), ("park", [0, 0, 7, 2]), ("leaf_pool", [-1, 7, 0, 1]), ("trace_waves", [0, 0, 1])):
+        a.set_option(name, int(orng.choice(values)))
     size = sizes[0]
     for p in (a, b):
         p.UploadScene(scenes[0]); p.SetCamera(cams(*size)[0]); p.RayDepth = 3
