@@ -90,6 +90,18 @@ def main():
             log(f"row-sharded frame over {world} ranks (all-gather) == 1 device: {same}")
             ok &= same
         r.pt.Dispose()
+        # the same deal at RayDepth 5 with the per-band count exchange (idkptSetBandExchange over a gloo control group): exact beyond RayDepth 2 as well
+        control = dist.new_group(backend="gloo")
+        r = D.GpuShardRenderer(w, h, world, rank, dev_index, exact_deep_paths=True, control_group=control); r.upload_scene(scene); r.set_camera(cam); r.pt.RayDepth = 5; r.pt.set_max_batch(2)
+        frame = D.ShardedFrame(r, w, h)
+        for _ in range(3):
+            r.pt.Compute()
+        full = frame.gather(); torch.cuda.synchronize()
+        if rank == 0:
+            same = bool((bits(full.cpu().numpy()) == bits(one_device(5, 3, dev_index))).all())
+            log(f"RayDepth 5, rows in bands + per-band count exchange over {world} ranks == 1 device: {same}")
+            ok &= same
+        r.pt.Dispose()
         flag = torch.tensor([1.0 if ok else 0.0], device=device if not one_dev else "cpu"); dist.all_reduce(flag, op=dist.ReduceOp.MIN); ok = flag.item() > 0.5
         dist.destroy_process_group()
     if rank == 0:
