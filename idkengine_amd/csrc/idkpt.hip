@@ -2098,7 +2098,9 @@ static int flush_batch(dev_ctx* ctx)
         const uint32_t* kq = k;                                           // keys of the queue entries, position by position
         // exact multi-GPU deep paths: the host tells every sample how many alive rays the contexts above this strip hold (idkpt.h)
         const uint32_t* gbase = nullptr;
-        if (ctx->groupExchange) {   // member of a multi-device context: the group sums the counts of the members that own earlier rows, on the device (idkpt_api.hpp)
+        const bool bandExchange = ctx->bandExchangeFn && ctx->rowMod > 1 && !(ctx->st.DoRaySorting && j > 1);
+        if (bandExchange) {}                                               // (below; a member of a multi-device context with interleaved rows takes this route as well)
+        else if (ctx->groupExchange) {   // member of a multi-device context: the group sums the counts of the members that own earlier rows, on the device (idkpt_api.hpp)
             int rc = ctx->groupExchange(ctx->groupUser, ctx, j, B, &gbase); if (rc) { ctx->pending.clear(); return rc; }
         } else if (ctx->exchangeFn) {
             std::vector<uint32_t> hb(B + 1), local(B), outBases(B, 0u);
@@ -2110,7 +2112,8 @@ static int flush_batch(dev_ctx* ctx)
             HIPC(hipMemcpyAsync(ctx->gbases.p, outBases.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
             HIPC(hipStreamSynchronize(st));                      // outBases is a stack vector
             gbase = ctx->gbases.as<uint32_t>();
-        } else if (ctx->bandExchangeFn && ctx->rowMod > 1 && !(ctx->st.DoRaySorting && j > 1)) {
+        }
+        if (bandExchange) {
             // interleaved rows / bands (idkpt.h idkptSetBandExchange): the rays of one local band are a contiguous run of a sample's queue segment (ordered compaction);
             // the host returns, per (sample, band), the alive rays of all contexts in the image bands before it; k_shade adds the position inside the run
             const int bandRows = 1 << ctx->rowBandLog2, LB = (ctx->rows + bandRows - 1) / bandRows;
@@ -2127,7 +2130,7 @@ static int flush_batch(dev_ctx* ctx)
             HIPC(hipStreamSynchronize(st));                      // tab is a stack vector
             gbase = dTab; f.gbStride = LB; f.gbBands = 1;
         }
-        if (!(ctx->bandExchangeFn && ctx->rowMod > 1) || (ctx->st.DoRaySorting && j > 1)) { f.gbStride = 1; f.gbBands = 0; }
+        if (!bandExchange) { f.gbStride = 1; f.gbBands = 0; }
         if (ctx->st.DoRaySorting && j > 1) {
             // RaySorting() (PathTracer.cs:232-237): stable sort of (key, rayIndex); key = 21-bit triangle id with the batch's
             // sample index above it, so one sort orders every sample's queue exactly like a stand-alone counting sort

@@ -9,12 +9,36 @@
 //   * rows: interleaved (y % N == d: balances sky rows against geometry rows; N-device output == 1-device output bit for bit at RayDepth <= 2,
 //     where radiance does not depend on the queue slot) or contiguous strips with a device-side exchange of the per-sample alive counts
 //     at every bounce (exact at any depth with sorting off: NHit seeds its RNG from the queue slot, NHit/compute.glsl:54) — "auto" picks
-//     by RayDepth; no host synchronisation in either mode: members wait on each other's per-bounce events, counts travel by peer copies;
+//     by RayDepth; no host synchronisation in either mode: members wait on each other's per-bounce events, counts travel by peer copies.
+//     Interleaved rows / bands chosen explicitly stay exact beyond RayDepth 2 too: one host thread per member, meeting at every bounce (GroupBarrier below);
 //   * results: idkptDownload writes every member's rows straight into the host image (N PCIe links in parallel); idkptGetImageDevicePtr
 //     gathers the rows into a full frame on device 0 (peer copies + one interleave kernel).
 // With deviceCount == 1 every entry point forwards to the single member: no behavioural change, no overhead.
 #pragma once
 #include <array>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+
+// Interleaved rows / bands beyond RayDepth 2 (round 4): a band's slot base counts the alive rays of ALL members in the image bands before it — also of members that are
+// enqueued later — so the members' batches cannot be enqueued one after the other as the strips' are.  They are enqueued by one host thread per member, and the
+// per-bounce exchange is the single-context one (idkptSetBandExchange: dev_ctx::bandExchangeFn) with the members meeting at this barrier.
+struct GroupBarrier {
+    std::mutex m; std::condition_variable cv; int n = 0, arrived = 0; unsigned gen = 0; bool aborted = false;
+    void reset(int members) { std::lock_guard<std::mutex> l(m); n = members; arrived = 0; aborted = false; }
+    bool wait()
+    {
+        std::unique_lock<std::mutex> l(m);
+        if (aborted) return false;
+        const unsigned g = gen;
+        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); return true; }
+        cv.wait(l, [&] { return gen != g || aborted; });
+        return !aborted;
+    }
+    void abort() { std::lock_guard<std::mutex> l(m); aborted = true; cv.notify_all(); }
+};
+struct idkpt_ctx;
+struct GroupBandUser { idkpt_ctx* c; int d; };
 
 struct idkpt_ctx {
     std::vector<dev_ctx*> dev;
@@ -31,6 +55,7 @@ struct idkpt_ctx {
     std::vector<std::array<hipEvent_t, MAX_DEPTH_SLOTS>> evBounce;
     std::vector<hipEvent_t> evFlushDone, evGather; std::vector<char> flushDoneValid;
     std::vector<DevBuf> peerStage, gbase;                   // on member d: the lower members' per-sample bases of the current bounce; the summed slot bases
+    GroupBarrier bar; std::vector<GroupBandUser> bandUser; std::vector<std::vector<uint32_t>> bandCounts; std::vector<int> bandLB;   // interleaved layouts beyond RayDepth 2 (group_band_exchange)
     DevBuf full[3], gatherStage, rowOffDev;                 // on device 0: gathered full-frame images; landing zone of the interleaved rows; first landing row of every member
     size_t n() const { return dev.size(); }
 };
@@ -84,6 +109,27 @@ static int group_exchange(void* user, dev_ctx* m, int bounce, int samples, const
     return IDKPT_OK;
 }
 
+// the host side of idkptSetBandExchange inside one multi-device context: every member posts its per-(sample, band) alive counts, all meet, every member sums the
+// counts of the image bands before each of its own bands (image band g belongs to member g % n as its (g / n)-th band)
+static void group_band_exchange(void* user, int32_t bounce, int32_t samples, int32_t bands, const uint32_t* localCounts, uint32_t* outBases)
+{
+    (void)bounce;
+    GroupBandUser* u = (GroupBandUser*)user; idkpt_ctx* c = u->c; const int d = u->d, n = (int)c->n();
+    c->bandCounts[d].assign(localCounts, localCounts + (size_t)samples * bands); c->bandLB[d] = bands;
+    if (!c->bar.wait()) return;                                            // everybody has posted
+    int total = 0; for (int r = 0; r < n; r++) total += c->bandLB[r];
+    for (int k = 0; k < samples; k++) {
+        uint32_t cum = 0;
+        for (int g = 0; g < total; g++) {
+            const int r = g % n, b = g / n;
+            if (b >= c->bandLB[r]) continue;                                   // (cannot happen with a round-robin deal: kept for safety)
+            if (r == d) outBases[(size_t)k * bands + b] = cum;
+            cum += c->bandCounts[r][(size_t)k * c->bandLB[r] + b];
+        }
+    }
+    (void)c->bar.wait();                                                    // nobody posts the next bounce before everybody has read this one
+}
+
 static int group_flush(idkpt_ctx* c);
 // what a member calls when a scene update finds no free scene-version slot (ver_writable, idkpt.hip): the whole group launches what it has queued
 static int group_flush_all(void* user) { return group_flush((idkpt_ctx*)user); }
@@ -92,6 +138,28 @@ static int group_flush_all(void* user) { return group_flush((idkpt_ctx*)user); }
 static int group_flush(idkpt_ctx* c)
 {
     if (c->pending == 0) return IDKPT_OK;
+    // interleaved rows / bands beyond RayDepth 2 with sorting off: exact slot numbers need every member's band counts at every bounce -> one host thread per member,
+    // meeting in group_band_exchange (strips keep the pipelined, device-side exchange below; RayDepth <= 2 needs none)
+    const bool threaded = !c->strips && c->n() > 1 && c->st.RayDepth > 2;
+    for (size_t d = 0; d < c->n(); d++) { dev_ctx* m = c->dev[d]; m->bandExchangeFn = threaded ? group_band_exchange : nullptr; m->bandExchangeUser = threaded ? (void*)&c->bandUser[d] : nullptr; }
+    if (threaded) {
+        c->bar.reset((int)c->n());
+        std::vector<int> rcs(c->n(), IDKPT_OK);
+        std::vector<std::thread> th;
+        for (size_t d = 0; d < c->n(); d++)
+            th.emplace_back([c, d, &rcs]() {
+                dev_ctx* m = c->dev[d];
+                int rc = hipSetDevice(m->device) == hipSuccess ? IDKPT_OK : IDKPT_ERR_HIP;
+                if (rc == IDKPT_OK) { m->inGroupFlush = true; rc = flush_batch(m); m->inGroupFlush = false; }
+                rcs[d] = rc;
+                if (rc) c->bar.abort();                                      // (the others leave their exchanges and finish; the group reports this member's error)
+            });
+        for (std::thread& t : th) t.join();
+        (void)hipSetDevice(c->dev[0]->device);
+        for (size_t d = 0; d < c->n(); d++) if (rcs[d]) { for (dev_ctx* o : c->dev) o->pending.clear(); c->pending = 0; return mfail(c, c->dev[d], rcs[d]); }
+        c->pending = 0;
+        return IDKPT_OK;
+    }
     for (size_t d = 0; d < c->n(); d++) {
         dev_ctx* m = c->dev[d];
         GHIP(hipSetDevice(m->device));
@@ -249,6 +317,7 @@ int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** o
     if (n > 1) {
         c->firstRow.assign(n, 0); c->rowCount.assign(n, 0); c->evBounce.resize(n); c->evFlushDone.assign(n, nullptr); c->evGather.assign(n, nullptr);
         c->flushDoneValid.assign(n, 0); c->peerStage.resize(n); c->gbase.resize(n);
+        c->bandUser.resize(n); c->bandCounts.resize(n); c->bandLB.assign(n, 0); for (int d = 0; d < n; d++) c->bandUser[d] = GroupBandUser{c, d};
         bool ok = true;
         for (int d = 0; d < n && ok; d++) {
             dev_ctx* m = c->dev[d];

@@ -147,15 +147,18 @@ typedef struct idkpt_stats {
 IDKPT_API int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** outCtx);
 IDKPT_API int32_t idkptGetContextDeviceCount(idkpt_ctx* ctx, int32_t* outCount);
 /* How a multi-device context deals the image rows to its devices (ignored by a one-device context):
- *   IDKPT_SHARD_ROWS    row y -> device y % N.  Balances sky rows against geometry rows; exact for RayDepth <= 2 (radiance does not depend on
- *                       the queue slot there), statistically equivalent beyond.
+ *   IDKPT_SHARD_ROWS    row y -> device y % N.  Balances sky rows against geometry rows.  Exact at any RayDepth with DoRaySorting off: up to RayDepth 2
+ *                       nothing has to be exchanged (radiance does not depend on the queue slot there); beyond, the members' batches are enqueued by one
+ *                       host thread each and meet at every bounce to exchange their per-(sample, row) alive counts (idkptSetBandExchange's contract inside
+ *                       the group: one stream synchronisation per member and bounce) so that every member numbers its NHit slots as one device does.
  *   IDKPT_SHARD_BANDS   band of 8 rows k -> device k % N (row y -> device (y / 8) % N): the same balance, and every device keeps whole 8x8 pixel
  *                       tiles — the unit a wave of the ray generation and of the primary traversal works on — so no traversal coherence is lost to
- *                       the split (single rows: 1.5-4.5 % at N = 2..8).  Exact where ROWS is.
+ *                       the split (single rows: 1.5-4.5 % at N = 2..8).  Exact where ROWS is (any RayDepth, the same per-bounce meeting beyond 2).
  *   IDKPT_SHARD_STRIPS  contiguous strips + a device-side exchange of the per-sample alive counts at every bounce (peer copies ordered by
  *                       events, no host synchronisation): every strip numbers its NHit queue slots after the alive rays of the strips above
  *                       it (NHit seeds its RNG from the slot, NHit/compute.glsl:54), so N devices == 1 device at any RayDepth with DoRaySorting off.
- *   IDKPT_SHARD_AUTO    (default) bands for RayDepth <= 2 (rows when the image has fewer bands than devices), strips beyond.  A change of layout
+ *   IDKPT_SHARD_AUTO    (default) bands for RayDepth <= 2 (rows when the image has fewer bands than devices), strips beyond (the exchange that needs no host
+ *                       synchronisation; on views with many empty rows BANDS balances better: 8 strips of the headline camera scale 4.2x, 8 interleaved shards 7.6x).  A change of layout
  *                       restarts the accumulation (like idkptSetSize). */
 enum idkpt_group_sharding { IDKPT_SHARD_AUTO = 0, IDKPT_SHARD_ROWS = 1, IDKPT_SHARD_STRIPS = 2, IDKPT_SHARD_BANDS = 3 };
 IDKPT_API int32_t idkptSetGroupSharding(idkpt_ctx* ctx, int32_t mode);

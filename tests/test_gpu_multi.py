@@ -365,3 +365,34 @@ def test_exact_deep_paths_with_interleaved_bands(native_builder, oracle_mod, bat
     o.close()
     for p in pts + [one, q]:
         p.Dispose()
+
+
+@pytest.mark.parametrize("members", [2, 3])
+def test_multi_device_context_interleaved_rows_are_exact_at_any_depth(native_builder, members):
+    """idkptSetGroupSharding(ROWS / BANDS) beyond RayDepth 2: the members' batches are enqueued by one host thread each and meet at every bounce to exchange their
+    per-(sample, band) alive counts (the single-context idkptSetBandExchange inside the group): image, ray state, alive queue and counters equal the one-device
+    context's bit for bit — batched, several samples per call, a height no member count divides; with ray sorting on the frame still renders (statistical beyond the first bounce)."""
+    from idkengine_amd.pathtracer import PathTracer
+    from idkengine_amd import gputypes as T
+    sc = S.soup_scene(30000, native_builder, seed=22, extent=3.0); w, h = 200, 117; cam = S.Camera(w, h, position=(0.0, 0.0, 8.0))
+    ids = _device_ids(members)
+    for mode, depth, batch, spp in ((3, 5, 1, 1), (3, 6, 3, 1), (1, 4, 2, 2), (3, 3, 8, 1)):
+        mk = lambda: configs.apply_settings(T.Settings.default(), dict(RayDepth=depth, SamplesPerPixel=spp))   # noqa: E731
+        a = PathTracer(w, h, settings=mk(), devices=ids); a.SetGroupSharding(mode); b = PathTracer(w, h, settings=mk())
+        for p in (a, b):
+            p.UploadScene(sc); p.SetCamera(cam); p.set_max_batch(batch)
+            for _ in range(3):
+                p.Compute()
+        assert (bits(a.Result) == bits(b.Result)).all(), (mode, depth, batch)
+        assert a.rays().tobytes() == b.rays().tobytes(), (mode, depth, batch)
+        assert (a.alive_queue() == b.alive_queue()).all()
+        assert a.stats()["rays_traced"] == b.stats()["rays_traced"]
+        a.RayDepth = 2; b.RayDepth = 2                      # back to the pipelined schedule on the same context
+        for p in (a, b):
+            p.Compute(); p.Compute()
+        assert (bits(a.Result) == bits(b.Result)).all()
+        a.Dispose(); b.Dispose()
+    st = configs.apply_settings(T.Settings.default(), dict(RayDepth=5, DoRaySorting=1))
+    a = PathTracer(w, h, settings=st, devices=ids); a.SetGroupSharding(3); a.UploadScene(sc); a.SetCamera(cam); a.Compute(); a.Compute()
+    assert np.isfinite(a.Result).all() and a.AccumulatedSamples == 2
+    a.Dispose()

@@ -64,9 +64,15 @@ def main():
                 for _ in range(3):
                     g.Compute()
                 same = bool((bits(g.Result) == bits(want)).all())
-                g.Dispose()
                 log(f"RayDepth {depth}, {'host-staged copies' if no_peer else 'peer copies'}: {n}-member context == 1 device: {same}")
                 ok &= same
+                if depth > 2 and not no_peer:        # the balanced deal beyond RayDepth 2: members enqueued by one host thread each, per-band count exchange at every bounce
+                    g.SetGroupSharding(3)            # (a change of layout restarts the accumulation)
+                    for _ in range(3):
+                        g.Compute()
+                    same = bool((bits(g.Result) == bits(want)).all()); ok &= same
+                    log(f"RayDepth {depth}, bands of 8 rows + per-band count exchange: {n}-member context == 1 device: {same}")
+                g.Dispose()
     else:
         import torch.distributed as dist
         from idkengine_amd import dist as D
