@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call AA: band exchange (exact deep paths with the balanced deal), random API with kernel options, the multi / instances suites
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04aa
 ( timeout 1200 python -m pytest tests/test_gpu_multi.py tests/test_gpu_zz_random_api.py tests/test_gpu_quad.py tests/test_gpu_boundary.py -q -m gpu --maxfail=6 2>&1 | tail -15 ) > gpurun_out/r04aa/tests.log
 ( timeout 600 python tools/fuzz_parity.py 200 19000 2>&1 | grep -v ": OK" | tail -8 ) > gpurun_out/r04aa/fuzz.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call B: the split kernel — parity (tests + fuzz), then A/B against the plain kernel on single frames, small batches and N-GPU shards
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04b
 ( timeout 900 python -m pytest tests/test_gpu_split.py -q -m gpu --maxfail=6 2>&1 | tail -40 ) > gpurun_out/r04b/split_tests.log
 ( timeout 600 python tools/fuzz_parity.py 120 9000 2>&1 | grep -v ": OK" | tail -20 ) > gpurun_out/r04b/fuzz.log

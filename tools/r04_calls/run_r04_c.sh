@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call C: speculative touch (spec) parity + A/B; split with hitless donors; device builder vs oracle
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04c
 ( timeout 600 python -m pytest tests/test_gpu_split.py tests/test_gpu_builder.py -q -m gpu --maxfail=6 2>&1 | tail -15 ) > gpurun_out/r04c/tests_a.log
 ( IDKPT_SPEC=2 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_worklist.py tests/test_gpu_nocounters.py tests/test_gpu_batching.py -q -m gpu --maxfail=6 2>&1 | tail -15 ) > gpurun_out/r04c/tests_spec.log

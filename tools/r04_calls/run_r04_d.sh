@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call D: baseline of the multi-BLAS modes; kernel timelines of a frame traced alone and of one rank's share of an 8-GPU run
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04d
 ( timeout 900 python tools/bench_multi.py 1000000 3 headline > gpurun_out/r04d/multi_headline.json 2> gpurun_out/r04d/multi_headline.txt )

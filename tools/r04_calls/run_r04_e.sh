@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call E: what bounds a frame traced alone?  instrumented per-step cycles at the current grid rule, the floor with few waves per CU, kernel timelines
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04e
 ( IDKPT_LIB_PATH=$PWD/idkengine_amd/libidkpt_dev.so timeout 600 python tools/phase_profile.py 2>&1 | tail -8 ) > gpurun_out/r04e/phase_profile.txt

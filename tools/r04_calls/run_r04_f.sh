@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call F: per-instance trace-ready records (k_trace2 MODE 3 / 4) parity + A/B; split with bound propagation
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04f
 ( timeout 900 python -m pytest tests/test_gpu_instances.py tests/test_gpu_split.py tests/test_gpu_versions.py tests/test_gpu_glref_full.py tests/test_gpu_glref.py tests/test_gpu_scene_updates.py -q -m gpu --maxfail=8 2>&1 | tail -25 ) > gpurun_out/r04f/tests.log
 ( timeout 600 python tools/fuzz_parity.py 150 9700 2>&1 | grep -v ": OK" | tail -20 ) > gpurun_out/r04f/fuzz.log

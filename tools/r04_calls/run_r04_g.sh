@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call G: restructured split kernel (cold state in LDS, no-pieces fast path), 4 vs 5 waves per SIMD; leaf pooling statistics
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04g
 ( timeout 600 python -m pytest tests/test_gpu_split.py tests/test_gpu_instances.py -q -m gpu --maxfail=6 2>&1 | tail -8 ) > gpurun_out/r04g/tests.log
 ( IDKPT_SPLIT=2 timeout 600 python tools/fuzz_parity.py 120 9900 2>&1 | grep -v ": OK" | tail -20 ) > gpurun_out/r04g/fuzz.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call K: split kernel — how soon a busy wave learns that the work list is empty (split_peek), and the grid of a small launch when idle lanes can help
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04k
 ( IDKPT_SPLIT=2 timeout 300 python -m pytest tests/test_gpu_split.py -q -m gpu --maxfail=3 2>&1 | tail -4 ) > gpurun_out/r04k/tests.log
 ( SWEEP_TAG=r04k1 SWEEP_OPT=SPLIT_PEEK:64,16,8,4,2,1 IDKPT_SPLIT=2 SWEEP_BATCHES=1,3 SWEEP_DEPTHS=2 timeout 900 python tools/sweep_r03.py headline 2>&1 | tail -13 ) > gpurun_out/r04k/peek.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call N: pooled leaves in the instance / TLAS / scene-version kernels (parity + numbers); the N > 1 bench paths on this one GPU; PMC of a lone frame; pooled phase profile
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04n
 ( timeout 900 python -m pytest tests/test_gpu_instances.py tests/test_gpu_versions.py tests/test_gpu_scene_updates.py tests/test_gpu_glref_full.py tests/test_gpu_glref.py tests/test_gpu_multi.py tests/test_gpu_configscale.py -q -m gpu --maxfail=8 2>&1 | tail -8 ) > gpurun_out/r04n/tests.log

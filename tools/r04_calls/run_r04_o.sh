@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call O: instance entries / TLAS steps taken by several lanes together (adv_min); instrumented A/B of the pooled leaf phase on one box
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04o
 ( IDKPT_ADV_MIN=16 timeout 600 python -m pytest tests/test_gpu_instances.py tests/test_gpu_scene_updates.py -q -m gpu --maxfail=4 2>&1 | tail -4 ) > gpurun_out/r04o/tests.log
 for a in 1 8 16 24 32; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call P: k_trace_fused — parity (tests + fuzz at RayDepth 2), then A/B on single frames, small batches and N-GPU shards
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04p
 ( timeout 900 python -m pytest tests/test_gpu_fused.py -q -m gpu --maxfail=6 2>&1 | tail -40 ) > gpurun_out/r04p/fused_tests.log
 ( FUZZ_DEPTH=2 timeout 600 python tools/fuzz_parity.py 150 12000 2>&1 | grep -v ": OK" | tail -20 ) > gpurun_out/r04p/fuzz_d2.log

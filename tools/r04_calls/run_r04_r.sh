@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call R: k_trace2s with the work list handed out scattered (split_scatter): parity, then single frames / small batches / one rank of 8
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04r
 ( IDKPT_SPLIT_SCATTER=3 timeout 900 python -m pytest tests/test_gpu_split.py -q -m gpu --maxfail=6 2>&1 | tail -5 ) > gpurun_out/r04r/split_tests_scatter3.log
 ( IDKPT_SPLIT_SCATTER=0 timeout 900 python -m pytest tests/test_gpu_split.py -q -m gpu --maxfail=6 2>&1 | tail -5 ) > gpurun_out/r04r/split_tests_scatter0.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call S: device-pointer queries (test + rates), the suites that the fused / scatter / adv_min changes touch
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04s
 ( timeout 900 python -m pytest tests/test_gpu_queries.py tests/test_gpu_fused.py tests/test_gpu_split.py tests/test_gpu_defer.py tests/test_gpu_boundary.py -q -m gpu --maxfail=6 2>&1 | tail -15 ) > gpurun_out/r04s/tests.log
 ( timeout 600 python - <<'PY'

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call T: device-resident query rates; the whole GPU suite on the current tree
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04t
 ( timeout 600 python - <<'PY'
 import json, sys

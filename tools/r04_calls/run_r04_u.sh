@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call U: closest-hit queries on k_trace2's scheduler: parity (every test that calls idkptTraceRays), then rates old / new, headline and interior rays
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04u
 ( timeout 900 python -m pytest tests/test_gpu_queries.py tests/test_gpu_glref.py tests/test_gpu_instances.py tests/test_gpu_multi.py tests/test_gpu_boundary.py tests/test_metamorphic.py -q -m gpu --maxfail=6 2>&1 | tail -15 ) > gpurun_out/r04u/tests.log
 for q in 1 0; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call X: any-hit queries on the scheduler: parity, rates
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04x
 ( timeout 900 python -m pytest tests/test_gpu_queries.py tests/test_gpu_glref.py tests/test_gpu_instances.py tests/test_gpu_multi.py tests/test_gpu_boundary.py tests/test_metamorphic.py -q -m gpu --maxfail=6 2>&1 | tail -15 ) > gpurun_out/r04x/tests.log
 ( timeout 600 python - <<'PY'

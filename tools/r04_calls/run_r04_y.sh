@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call Y: quad records (k_trace2q): parity, then A/B on single frames, small batches, batches of 32, one rank of 8
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04y
 ( timeout 900 python -m pytest tests/test_gpu_quad.py -q -m gpu --maxfail=6 2>&1 | tail -25 ) > gpurun_out/r04y/quad_tests.log
 ( IDKPT_QUAD=2 timeout 600 python tools/fuzz_parity.py 100 15000 2>&1 | grep -v ": OK" | tail -8 ) > gpurun_out/r04y/fuzz_quad.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, GPU call Z: two parked leaves per lane (k_trace2p): parity on the suites that render frames, then A/B against the plain and the pooled kernel
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04z
 ( IDKPT_PARK=7 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_split.py tests/test_gpu_fused.py tests/test_gpu_defer.py tests/test_gpu_glref.py -q -m gpu --maxfail=6 2>&1 | tail -8 ) > gpurun_out/r04z/tests_park.log
 ( IDKPT_PARK=7 timeout 600 python tools/fuzz_parity.py 150 18000 2>&1 | grep -v ": OK" | tail -8 ) > gpurun_out/r04z/fuzz_park.log
