@@ -45,6 +45,12 @@ __global__ __launch_bounds__(256) void k_final_draw(DScene s, Frame f, RayBufs r
         f3 nr = splat3(0.0f);
         if (cls == 0u) { float4 c = rays.rad_py[rid]; nr = mk3(c.x, c.y, c.z); }
         else if (cls <= 6u) { const float4 p = s.sky[cls - 1u]; nr = splat3(0.0f) + mk3(p.x, p.y, p.z) * splat3(1.0f); }
+        else if (cls == 8u) {                            // textured sky: the miss branch of FirstHit (FirstHit:225-233) for this sample's ray, generated here (k_regen_culled does the same on demand)
+            f3 origin; f2 pd; uint32_t seed;
+            gen_primary(f, (uint32_t)k, i, sample_index(f, (uint32_t)k), origin, pd, seed);
+            const f3 albedo = SampleSky(s, DecodeUnitVec(pd.x, pd.y));
+            nr = splat3(0.0f) + albedo * splat3(1.0f);
+        }
         if (f.g.DoDebugBVHTraversal) nr = TurboColormap(rays.o_ior[rid].w / 150.0f);
         r = gmix(r, nr, w);
         if (f.outputAovs) { float4 a = rays.aovA[rid], n = rays.aovN[rid]; ra = gmix(ra, mk3(a.x, a.y, a.z), w); rn = gmix(rn, mk3(n.x, n.y, n.z), w); }

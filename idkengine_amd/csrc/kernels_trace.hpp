@@ -63,7 +63,9 @@ __global__ __launch_bounds__(WAVE) void k_trace_queue(DScene s, Frame f, RayBufs
 // sky, needs no per-pixel ray generation at all: its pixels are the FirstHit miss branch with a known colour (FirstHit:225-233).
 // The test is CONSERVATIVE (box strictly outside one side plane of the tile's pyramid, by a margin that covers the lens radius, the
 // direction tilt LenseRadius/FocalLength, one extra pixel of jitter and rounding); tiles that fail it take the exact per-pixel path,
-// so results are bit-identical either way.  class 0 = per-pixel path, 1..6 = miss + sky face (class-1), 7 = miss + no sky (black).
+// so results are bit-identical either way.  class 0 = per-pixel path, 1..6 = miss + sky face (class-1), 7 = miss + no sky (black),
+// 8 = miss + a textured sky (an HDR cube map, the engine's default: SkyBoxManager.cs:44,74): k_final_draw generates the pixel's ray and samples the sky itself
+// (the arithmetic of k_gen_primary's miss branch), so nothing is stored per sample for those pixels either.
 template <bool VER>
 __global__ __launch_bounds__(256) void k_classify_tiles(DScene s0, Frame f, uint8_t* tileClass, uint32_t tilesX, uint32_t tilesY)
 {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s0, Frame f, uint
     const uint32_t tx = t % tilesX, ty = t / tilesX;
     uint8_t cls = 0;
     const float r = f.g.LenseRadius, F = f.g.FocalLength;
-    if (s.instanceCount >= 1 && s.instanceCount <= 256 && s.skySize <= 1 && !f.outputAovs && r >= 0.0f && F > 1e-3f && r / F <= 0.05f) {
+    if (s.instanceCount >= 1 && s.instanceCount <= 256 && !f.outputAovs && r >= 0.0f && F > 1e-3f && r / F <= 0.05f) {
         const float W = (float)f.W, H = (float)f.H;
         const int gy0 = global_row(f, (int)(ty * 8)), gy1 = global_row(f, (int)(ty * 8 + 7));   // global rows of the tile's first / last local row (monotone in the local row)
         const float nx0 = ((float)(tx * 8) - 1.0f) / W * 2.0f - 1.0f, nx1 = ((float)(tx * 8) + 9.0f) / W * 2.0f - 1.0f;   // one pixel of slack on every side
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s0, Frame f, uint
         }
         if (outside) {
             if (s.skySize <= 0) cls = 7;
+            else if (s.skySize > 1) cls = 8;
             else {
                 // one sky face for every direction of the beam: a strictly dominant axis, same sign, at all four corners, by more than
                 // twice the possible tilt (lens + oct-encoding round trip)

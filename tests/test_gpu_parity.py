@@ -158,6 +158,26 @@ def test_tile_preclassification_is_conservative(native_builder, oracle_mod, monk
         c.UploadScene(S.soup_scene(500, native_builder, seed=3, sky_color=(0.1, 0.2, 0.3)))
         assert c.rays().tobytes() == b.rays().tobytes()
         a.Dispose(); b.Dispose(); c.Dispose(); o.close()
+    # a textured sky (an HDR cube map, the engine's default: SkyBoxManager.cs:44,74): pre-classified tiles (class 8) store nothing per sample either — k_final_draw generates
+    # the pixel's ray and samples the cube map itself; with the classification, without it and the oracle agree on every bit, batched over a frame ring of cameras too
+    import copy
+    sky = np.zeros((6, 5, 5, 4), np.float32); sky[..., :3] = np.random.default_rng(7).uniform(0.0, 3.0, (6, 5, 5, 3)); sky[..., 3] = 1.0
+    sc2 = copy.copy(sc); sc2.sky_faces = sky
+    cam = S.Camera(w, h, position=(0.0, 0.0, 9.0))
+    ov = dict(RayDepth=3, LenseRadius=lens, FocalLength=6.0, SamplesPerPixel=2)
+    a = gpu_render(sc2, cam, w, h, frames=2, **ov); o = oracle_render(oracle_mod, sc2, cam, w, h, frames=2, **ov)
+    assert_equal(a, o)
+    monkeypatch.setenv("IDKPT_NO_TILE_CULL", "1")
+    b = gpu_render(sc2, cam, w, h, frames=2, **ov)
+    monkeypatch.delenv("IDKPT_NO_TILE_CULL")
+    assert (bits(a.Result) == bits(b.Result)).all() and a.rays().tobytes() == b.rays().tobytes()
+    a.set_max_batch(4); b.set_max_batch(1)
+    for p in (a, b):
+        p.ResetAccumulation()
+        for _ in range(4):
+            p.Compute()
+    assert (bits(a.Result) == bits(b.Result)).all() and a.rays().tobytes() == b.rays().tobytes()
+    a.Dispose(); b.Dispose(); o.close()
     # row-sharded context: the tile's rows are every 3rd image row
     from idkengine_amd.pathtracer import PathTracer
     cam = S.Camera(w, h, position=(0.0, 0.0, 9.0))
