@@ -273,7 +273,7 @@ def main():
                                      f"atrium-{args.tris} (procedural two-storey colonnaded hall, connected surfaces, {len(scene.blas_triangles)} BLAS triangles, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, camera inside looking down the hall"),
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
                        "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation",
-                       "last_bounce": "every ray of the last bounce is traced and its radiance (sky on a miss; this scene has no emission, so hits add none) reaches the frame; the rest of that bounce's shading - new direction, throughput, Russian roulette, next queue: outputs the reference computes and nothing reads - is produced on demand (idkptDownloadRays / idkptDownloadAliveQueue / scene updates), bit-identical (DESIGN.md 4; option defer_last)", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin (strips + device-side count exchange beyond RayDepth 2), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("rows in bands of 8 round-robin over ranks + per-bounce exchange of the per-band alive counts (idkptSetBandExchange: exact at any RayDepth) + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
+                       "last_bounce": "every ray of the last bounce is traced and its radiance (sky on a miss; this scene has no emission, so hits add none) reaches the frame; the rest of that bounce's shading - new direction, throughput, Russian roulette, next queue: outputs the reference computes and nothing reads - is produced on demand (idkptDownloadRays / idkptDownloadAliveQueue / scene updates), bit-identical (DESIGN.md 4; option defer_last)", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin in bands of 8 (beyond RayDepth 2 with the per-band alive-count exchange: exact at any depth), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("rows in bands of 8 round-robin over ranks + per-bounce exchange of the per-band alive counts (idkptSetBandExchange: exact at any RayDepth) + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
                        "bvh_build_s": round(build_s, 2), "blas_build_ms": blas_build_ms, "bvh_builder": builder_kind,
                        "blas_build_note": "blas_build_ms is the wall time of DeviceBuilder.build_blas as this script sees it: the device build (16 ms) + the download of nodes and triangles (23 ms together, profiles/r03_blas_build.txt) + numpy marshalling of 1 M triangles and the first call's allocations; untimed set-up, outside the metric",
                        "n_gpu": n_gpu_report(torch, dist, world, group, pt, st, B, depth, args, ranks_counted, selftest)},
@@ -330,7 +330,7 @@ def n_gpu_report(torch, dist, world, group, pt=None, st=None, B=None, depth=None
             ac = st["alive_counts"]; per_batch = min(B, args.steps) if args is not None else B
             rep["rank0_launches"] = {"samples_per_launch": per_batch, "primary_rays_per_launch": int(ac[0]), "bounce_rays_per_launch": [int(a * per_batch) for a in ac[1:depth]],   # ([0]: the whole batch's active list; [j]: the last sample's alive count x samples)
                                      "avg_trace_launch_us": round(st["trace_ms_total"] * 1e3 / max(1, st["trace_launches"]), 1), "trace_launches": int(st["trace_launches"]),
-                                     "row_deal": "bands of 8 rows, (y // 8) % N" if world > 1 else "one multi-device context (idkptSetGroupSharding AUTO: bands of 8 rows at RayDepth <= 2, strips beyond)"}
+                                     "row_deal": "bands of 8 rows, (y // 8) % N" if world > 1 else "one multi-device context (idkptSetGroupSharding AUTO: bands of 8 rows)"}
         rep["selftest"] = selftest
         return rep
     except Exception as e:   # noqa: BLE001

@@ -185,7 +185,9 @@ static int group_sync(idkpt_ctx* c)
     return IDKPT_OK;
 }
 
-static bool mode_wants_strips(int mode, int rayDepth) { return mode == IDKPT_SHARD_STRIPS || (mode == IDKPT_SHARD_AUTO && rayDepth > 2); }
+// (round 4: AUTO deals bands at every RayDepth — beyond 2 with the per-band count exchange — because strips balance badly on views with empty rows: BASELINE configs[3]
+// on 8 GPUs projects 6.0x with bands against 3.8x with strips, profiles/r04_raw/shard_config4_batch32.txt; strips only when asked for)
+static bool mode_wants_strips(int mode, int rayDepth) { (void)rayDepth; return mode == IDKPT_SHARD_STRIPS; }
 // interleaved layouts: AUTO and BANDS deal bands of 8 rows (a wave's 8x8 pixel tile stays one 8x8 block of the image on every device: single rows cost
 // 1.5-4.5 % of traversal coherence at N = 2..8, profiles/r02_shard_coherence.txt), ROWS deals single rows.  Images too small for one band per device fall back to rows.
 static int mode_band_log2(int mode, int H, int n) { return (mode == IDKPT_SHARD_ROWS || (H + 7) / 8 < n) ? 0 : 3; }

@@ -232,7 +232,7 @@ class PathTracer:
         self._check(self._L.idkptSetSceneVersions(self._ctx, int(versions)))
 
     def SetGroupSharding(self, mode):
-        """idkptSetGroupSharding: 0 auto (bands of 8 rows for RayDepth <= 2, strips + device-side count exchange beyond), 1 rows, 2 strips, 3 bands of 8 rows."""
+        """idkptSetGroupSharding: 0 auto (= bands of 8 rows at every RayDepth, with the per-band count exchange beyond 2), 1 rows, 2 strips + device-side count exchange, 3 bands of 8 rows."""
         self._check(self._L.idkptSetGroupSharding(self._ctx, int(mode)))
 
     def SetRowRange(self, first_row, row_count):

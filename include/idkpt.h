@@ -157,8 +157,9 @@ IDKPT_API int32_t idkptGetContextDeviceCount(idkpt_ctx* ctx, int32_t* outCount);
  *   IDKPT_SHARD_STRIPS  contiguous strips + a device-side exchange of the per-sample alive counts at every bounce (peer copies ordered by
  *                       events, no host synchronisation): every strip numbers its NHit queue slots after the alive rays of the strips above
  *                       it (NHit seeds its RNG from the slot, NHit/compute.glsl:54), so N devices == 1 device at any RayDepth with DoRaySorting off.
- *   IDKPT_SHARD_AUTO    (default) bands for RayDepth <= 2 (rows when the image has fewer bands than devices), strips beyond (the exchange that needs no host
- *                       synchronisation; on views with many empty rows BANDS balances better: 8 strips of the headline camera scale 4.2x, 8 interleaved shards 7.6x).  A change of layout
+ *   IDKPT_SHARD_AUTO    (default) = BANDS (ROWS when the image has fewer bands than devices) at every RayDepth.  (Rounds 2-3 switched to STRIPS beyond RayDepth 2, the
+ *                       exchange that needs no host synchronisation; but strips balance badly on views with empty rows — BASELINE configs[3] dealt over 8 GPUs projects
+ *                       6.0x with bands against 3.8x with strips — and since round 4 the interleaved deals are exact at any depth as well.)  A change of layout
  *                       restarts the accumulation (like idkptSetSize). */
 enum idkpt_group_sharding { IDKPT_SHARD_AUTO = 0, IDKPT_SHARD_ROWS = 1, IDKPT_SHARD_STRIPS = 2, IDKPT_SHARD_BANDS = 3 };
 IDKPT_API int32_t idkptSetGroupSharding(idkpt_ctx* ctx, int32_t mode);

@@ -163,16 +163,16 @@ def _device_ids(members):
 
 @pytest.mark.parametrize("members", [2, 3])
 def test_multi_device_context_equals_one_device(native_builder, oracle_mod, members):
-    """idkptCreate(deviceCount = N): ONE handle rendering every frame on N members (rows for RayDepth <= 2, strips + device-side alive-count
-    exchange beyond) must return what a one-device context returns, bit for bit: the three images, the per-pixel ray state, primary hits,
+    """idkptCreate(deviceCount = N): ONE handle rendering every frame on N members (bands of 8 rows, beyond RayDepth 2 with the per-band alive-count exchange; or strips + the device-side
+    exchange when asked for) must return what a one-device context returns, bit for bit: the three images, the per-pixel ray state, primary hits,
     the alive queue, the ray and visit counters — batched or not, several samples per call, a size no member count divides."""
     from idkengine_amd.pathtracer import PathTracer
     from idkengine_amd import gputypes as T
     sc = S.soup_scene(30000, native_builder, seed=21, extent=3.0); w, h = 200, 117; cam = S.Camera(w, h, position=(0.0, 0.0, 8.0))
     ids = _device_ids(members)
-    for depth, sort, batch, spp, aov in ((2, 0, 1, 1, 0), (2, 1, 4, 2, 1), (5, 0, 3, 1, 0), (4, 0, 1, 3, 1), (7, 0, 8, 1, 0)):
+    for depth, sort, batch, spp, aov, mode in ((2, 0, 1, 1, 0, 0), (2, 1, 4, 2, 1, 0), (5, 0, 3, 1, 0, 0), (4, 0, 1, 3, 1, 2), (7, 0, 8, 1, 0, 2), (6, 0, 2, 1, 1, 0)):   # mode 0: auto (bands at every depth), 2: strips + device-side exchange
         st = configs.apply_settings(T.Settings.default(), dict(RayDepth=depth, DoRaySorting=sort, SamplesPerPixel=spp, OutputAOVs=aov))
-        a = PathTracer(w, h, settings=st, devices=ids); b = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), dict(RayDepth=depth, DoRaySorting=sort, SamplesPerPixel=spp, OutputAOVs=aov)))
+        a = PathTracer(w, h, settings=st, devices=ids); a.SetGroupSharding(mode); b = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), dict(RayDepth=depth, DoRaySorting=sort, SamplesPerPixel=spp, OutputAOVs=aov)))
         for p in (a, b):
             p.UploadScene(sc); p.SetCamera(cam); p.enable_counters(True); p.enable_primary_hit_capture(True); p.set_max_batch(batch)
             for _ in range(3):
@@ -224,7 +224,7 @@ def test_multi_device_context_api_surface(native_builder, oracle_mod):
         p.UploadScene(sc); p.SetCamera(cam(96, 64)); p.RayDepth = 3; p.Compute()
     assert (bits(a.Result) == bits(b.Result)).all()
     # resize + explicit strips at depth 2 / explicit rows
-    for mode, depth in ((2, 2), (1, 2), (3, 2), (0, 2), (0, 4)):      # strips, rows, bands of 8, auto (= bands), auto (= strips)
+    for mode, depth in ((2, 2), (1, 2), (3, 2), (0, 2), (0, 4), (2, 4)):      # strips, rows, bands of 8, auto (= bands), auto beyond RayDepth 2 (= bands + exchange), strips beyond RayDepth 2
         a.SetGroupSharding(mode)
         for p in (a, b):
             p.SetSize(123, 45); p.SetCamera(cam(123, 45)); p.RayDepth = depth; p.set_max_batch(2); p.Compute(); p.Compute()
@@ -274,9 +274,9 @@ def test_multi_device_context_without_peer_access(native_builder, members, monke
     monkeypatch.setenv("IDKPT_FORCE_NO_PEER", "1")
     sc = S.soup_scene(20000, native_builder, seed=33, extent=3.0, refittable=True); w, h = 160, 101; cam = S.Camera(w, h, position=(0.0, 0.0, 8.0))
     ids = _device_ids(members)
-    for depth, batch in ((2, 2), (5, 3)):
+    for depth, batch, mode in ((2, 2, 0), (5, 3, 2), (5, 2, 0)):      # (mode 2: strips, whose per-bounce count exchange is a device-to-device copy; 0: bands, exchanged on the host beyond RayDepth 2)
         st = lambda: configs.apply_settings(T.Settings.default(), dict(RayDepth=depth))   # noqa: E731
-        a = PathTracer(w, h, settings=st(), devices=ids); b = PathTracer(w, h, settings=st())
+        a = PathTracer(w, h, settings=st(), devices=ids); a.SetGroupSharding(mode); b = PathTracer(w, h, settings=st())
         for p in (a, b):
             p.UploadScene(sc); p.SetCamera(cam); p.set_max_batch(batch)
             for _ in range(4):

@@ -3,7 +3,7 @@
   python tools/scale_selftest.py [--gpus N]
       one process, ONE multi-device context (idkptCreate(deviceCount = N)): prints the visible devices and the peer-access matrix, renders a
       small frame on 1 device and on N members (ids wrap around when fewer GPUs are visible), with xGMI peer copies and with every copy staged
-      through the host (option "force_no_peer"), at RayDepth 2 (rows) and 5 (strips + device-side count exchange), and compares the bits.
+      through the host (option "force_no_peer"), at RayDepth 2 and 5 (bands of 8 rows; beyond RayDepth 2 with the per-band count exchange), plus explicit strips + device-side count exchange at RayDepth 5, and compares the bits.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/scale_selftest.py
       one process per GPU: prints rank -> device, checks that RCCL ("nccl") sees N ranks (all-reduce of the ranks), renders the same frame
       row-sharded over the ranks (dist.GpuShardRenderer + ShardedFrame, all-gather over RCCL) and rank 0 compares it with its own 1-device frame.
@@ -66,12 +66,12 @@ def main():
                 same = bool((bits(g.Result) == bits(want)).all())
                 log(f"RayDepth {depth}, {'host-staged copies' if no_peer else 'peer copies'}: {n}-member context == 1 device: {same}")
                 ok &= same
-                if depth > 2 and not no_peer:        # the balanced deal beyond RayDepth 2: members enqueued by one host thread each, per-band count exchange at every bounce
-                    g.SetGroupSharding(3)            # (a change of layout restarts the accumulation)
+                if depth > 2 and not no_peer:        # round 2's deal: contiguous strips + device-side, event-ordered count exchange (no host synchronisation)
+                    g.SetGroupSharding(2)            # (a change of layout restarts the accumulation)
                     for _ in range(3):
                         g.Compute()
                     same = bool((bits(g.Result) == bits(want)).all()); ok &= same
-                    log(f"RayDepth {depth}, bands of 8 rows + per-band count exchange: {n}-member context == 1 device: {same}")
+                    log(f"RayDepth {depth}, explicit strips + device-side count exchange: {n}-member context == 1 device: {same}")
                 g.Dispose()
     else:
         import torch.distributed as dist
