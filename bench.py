@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--sort", type=int, default=0, help="DoRaySorting (headline = 0)")
     ap.add_argument("--width", type=int, default=W, help="secondary-table runs only (headline = 1920)")
     ap.add_argument("--height", type=int, default=H, help="secondary-table runs only (headline = 1080)")
-    ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: per-bounce exchange of the per-band alive counts (gloo control group, idkptSetBandExchange) so that RayDepth > 2 output equals the 1-GPU output bit for bit with the same interleaved deal; default = no exchange (exact at RayDepth 2)")
+    ap.add_argument("--exact-deep-paths", action="store_true", help="N > 1 only: per-bounce exchange of the per-band alive counts (RCCL all-gather on the render stream, idkptSetBandExchangeDevice) so that RayDepth > 2 output equals the 1-GPU output bit for bit with the same interleaved deal; default = no exchange (exact at RayDepth 2)")
     ap.add_argument("--interactive", type=int, default=0, metavar="F", help="secondary mode: every step is a NEW frame (own camera, own image, ResetAccumulation semantics) with F frames in flight through the frame ring; every finished frame is exchanged when N > 1")
     ap.add_argument("--spawn", action="store_true", help="--gpus N without a launcher: start N processes (torch.distributed.run, one rank per GPU, RCCL) instead of the default ONE process driving ONE multi-device context (idkptCreate(deviceCount = N))")
     ap.add_argument("--shard", choices=["rows", "samples"], default="rows", help="one process per GPU (torch.distributed launch) only.  rows (default): the frame's rows are dealt over the ranks (bit-identical to one GPU, strong scaling: BASELINE.json's metric).  samples: every rank renders WHOLE frames for its own sample indices (idkptSetSampleSequence(rank, N)), one all-reduce per displayed frame, weak scaling — a secondary mode, never reported under the headline metric string")
@@ -165,8 +165,7 @@ def main():
             pt = r.pt
             frame = D.SampleParallelFrame(r)
         else:
-            control = dist.new_group(backend="gloo") if (world > 1 and args.exact_deep_paths) else None   # CPU-side group for the tiny count exchange
-            r = D.GpuShardRenderer(W, H, world, rank, local_rank, exact_deep_paths=bool(control), control_group=control)
+            r = D.GpuShardRenderer(W, H, world, rank, local_rank, exact_deep_paths=bool(world > 1 and args.exact_deep_paths))   # (the per-band count exchange is enqueued on the render stream: RCCL all-gather + prefix sum)
             r.upload_scene(scene); r.set_camera(cam)
             pt = r.pt
             frame = D.ShardedFrame(r, W, H) if world > 1 else None
@@ -273,7 +272,7 @@ def main():
                                      f"atrium-{args.tris} (procedural two-storey colonnaded hall, connected surfaces, {len(scene.blas_triangles)} BLAS triangles, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, camera inside looking down the hall"),
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
                        "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation",
-                       "last_bounce": "every ray of the last bounce is traced and its radiance (sky on a miss; this scene has no emission, so hits add none) reaches the frame; the rest of that bounce's shading - new direction, throughput, Russian roulette, next queue: outputs the reference computes and nothing reads - is produced on demand (idkptDownloadRays / idkptDownloadAliveQueue / scene updates), bit-identical (DESIGN.md 4; option defer_last)", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin in bands of 8 (beyond RayDepth 2 with the per-band alive-count exchange: exact at any depth), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("rows in bands of 8 round-robin over ranks + per-bounce exchange of the per-band alive counts (idkptSetBandExchange: exact at any RayDepth) + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
+                       "last_bounce": "every ray of the last bounce is traced and its radiance (sky on a miss; this scene has no emission, so hits add none) reaches the frame; the rest of that bounce's shading - new direction, throughput, Russian roulette, next queue: outputs the reference computes and nothing reads - is produced on demand (idkptDownloadRays / idkptDownloadAliveQueue / scene updates), bit-identical (DESIGN.md 4; option defer_last)", "sharding": ("one process, one multi-device context (idkptCreate(deviceCount = N)): scene replicated by peer copies, rows dealt round-robin in bands of 8 (beyond RayDepth 2 with the per-band alive-count exchange: exact at any depth), frame gathered on device 0" if group > 1 else (("sample-parallel: every rank renders whole frames for the sample indices rank, rank + N, ... (idkptSetSampleSequence); the displayed frame of N x samples_in_flight samples is the all-reduced mean of the ranks' accumulations; nothing is exchanged inside a frame" if sample_parallel else ("rows in bands of 8 round-robin over ranks + per-bounce exchange of the per-band alive counts enqueued on the render stream (idkptSetBandExchangeDevice: exact at any RayDepth, no host synchronisation) + all-gather" if args.exact_deep_paths else "rows round-robin over ranks + all-gather")) if world > 1 else "none")),
                        "bvh_build_s": round(build_s, 2), "blas_build_ms": blas_build_ms, "bvh_builder": builder_kind,
                        "blas_build_note": "blas_build_ms is the wall time of DeviceBuilder.build_blas as this script sees it: the device build (16 ms) + the download of nodes and triangles (23 ms together, profiles/r03_blas_build.txt) + numpy marshalling of 1 M triangles and the first call's allocations; untimed set-up, outside the metric",
                        "n_gpu": n_gpu_report(torch, dist, world, group, pt, st, B, depth, args, ranks_counted, selftest)},

@@ -131,7 +131,8 @@ struct dev_ctx {
     DevBuf camTab;                                       // per-sample cameras of the batch being launched (ring mode)
     int rowLimit = 0x7fffffff;                           // idkptSetRowRange: at most this many local rows
     idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // exact multi-GPU deep paths (idkptSetBounceExchange)
-    idkpt_band_exchange_fn bandExchangeFn = nullptr; void* bandExchangeUser = nullptr; DevBuf bandTab;   // ... for interleaved rows / bands (idkptSetBandExchange)
+    idkpt_band_exchange_fn bandExchangeFn = nullptr; void* bandExchangeUser = nullptr; DevBuf bandTab;
+    idkpt_band_exchange_device_fn bandExchangeDevFn = nullptr; void* bandExchangeDevUser = nullptr;   // ... enqueued on the stream, no host synchronisation (idkptSetBandExchangeDevice)   // ... for interleaved rows / bands (idkptSetBandExchange)
     // stats
     idkpt_stats stats;
     uint32_t* hCounts = nullptr; uint32_t* dCountsMirror = nullptr;   // host-mapped mirror of the queue lengths (written by k_scan_blocks, read by the host after a sync)
@@ -699,6 +700,14 @@ static int32_t dev_SetBandExchange(dev_ctx* ctx, idkpt_band_exchange_fn fn, void
     if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
     FLUSH();
     ctx->bandExchangeFn = fn; ctx->bandExchangeUser = user;
+    return IDKPT_OK;
+}
+
+static int32_t dev_SetBandExchangeDevice(dev_ctx* ctx, idkpt_band_exchange_device_fn fn, void* user)
+{
+    if (!ctx) return IDKPT_ERR_INVALID_ARGUMENT;
+    FLUSH();
+    ctx->bandExchangeDevFn = fn; ctx->bandExchangeDevUser = user;
     return IDKPT_OK;
 }
 
@@ -2017,7 +2026,7 @@ static int flush_batch(dev_ctx* ctx)
     // one launch for FirstHit + the last NHit (kernels_trace_fused.hpp): RayDepth 2, one BLAS instance, the last bounce deferred (no AOVs, no debug view), nothing that looks at
     // the primary hits or the visit counters, no per-bounce exchange with other contexts — and a launch small enough to be bound by its longest rays
     const bool fused = fast && ctx->st.RayDepth == 2 && ctx->opt.deferLast != 0 && !f.outputAovs && !f.g.DoDebugBVHTraversal && !f.useTlas && ctx->instanceCount == 1 && !multiVer && !ctx->counters
-                       && !ctx->capturePrimary && !ctx->groupExchange && !ctx->exchangeFn && !ctx->bandExchangeFn && f.recPerRay == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)
+                       && !ctx->capturePrimary && !ctx->groupExchange && !ctx->exchangeFn && !ctx->bandExchangeFn && !ctx->bandExchangeDevFn && f.recPerRay == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)
                        && want_fused(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B);
     f.hitsByRid = fused ? 1 : 0; f.shadeMin = ctx->opt.fusedShadeMin; f.scatterLog2 = ctx->opt.splitScatter;
     if (!fast && (B != 1 || multiVer)) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
@@ -2098,7 +2107,7 @@ static int flush_batch(dev_ctx* ctx)
         const uint32_t* kq = k;                                           // keys of the queue entries, position by position
         // exact multi-GPU deep paths: the host tells every sample how many alive rays the contexts above this strip hold (idkpt.h)
         const uint32_t* gbase = nullptr;
-        const bool bandExchange = ctx->bandExchangeFn && ctx->rowMod > 1 && !(ctx->st.DoRaySorting && j > 1);
+        const bool bandExchange = (ctx->bandExchangeFn || ctx->bandExchangeDevFn) && ctx->rowMod > 1 && !(ctx->st.DoRaySorting && j > 1);
         if (bandExchange) {}                                               // (below; a member of a multi-device context with interleaved rows takes this route as well)
         else if (ctx->groupExchange) {   // member of a multi-device context: the group sums the counts of the members that own earlier rows, on the device (idkpt_api.hpp)
             int rc = ctx->groupExchange(ctx->groupUser, ctx, j, B, &gbase); if (rc) { ctx->pending.clear(); return rc; }
@@ -2117,9 +2126,19 @@ static int flush_batch(dev_ctx* ctx)
             // interleaved rows / bands (idkpt.h idkptSetBandExchange): the rays of one local band are a contiguous run of a sample's queue segment (ordered compaction);
             // the host returns, per (sample, band), the alive rays of all contexts in the image bands before it; k_shade adds the position inside the run
             const int bandRows = 1 << ctx->rowBandLog2, LB = (ctx->rows + bandRows - 1) / bandRows;
-            HIPC(ctx->bandTab.ensure((size_t)2 * MAX_BATCH * ((size_t)LB + 1) * 4));
+            HIPC(ctx->bandTab.ensure((size_t)4 * MAX_BATCH * ((size_t)LB + 1) * 4));
             uint32_t* dStarts = ctx->bandTab.as<uint32_t>(); uint32_t* dTab = dStarts + (size_t)MAX_BATCH * (LB + 1);
             hipLaunchKernelGGL(k_band_starts, dim3((uint32_t)(((size_t)B * (LB + 1) + 255) / 256)), dim3(256), 0, st, (const uint32_t*)q, (const uint32_t*)(bases + j * BS), B, LB, (uint32_t)ctx->W * (uint32_t)bandRows, Npad, dStarts);
+            if (ctx->bandExchangeDevFn) {
+                // device-side variant: counts -> (the host enqueues its exchange on this stream) -> bases -> table; nothing waits on the host
+                uint32_t* dCounts = dTab + (size_t)MAX_BATCH * (LB + 1); uint32_t* dBases = dCounts + (size_t)MAX_BATCH * (LB + 1);
+                const uint32_t nb = (uint32_t)(((size_t)B * LB + 255) / 256);
+                hipLaunchKernelGGL(k_band_counts, dim3(nb), dim3(256), 0, st, (const uint32_t*)dStarts, B, LB, dCounts);
+                HIPC(hipGetLastError());
+                ctx->bandExchangeDevFn(ctx->bandExchangeDevUser, j, B, LB, dCounts, dBases, (void*)st);
+                hipLaunchKernelGGL(k_band_tab, dim3(nb), dim3(256), 0, st, (const uint32_t*)dStarts, (const uint32_t*)dBases, B, LB, dTab);
+                gbase = dTab; f.gbStride = LB; f.gbBands = 1;
+            } else {
             std::vector<uint32_t> starts((size_t)B * (LB + 1)), local((size_t)B * LB), outBases((size_t)B * LB, 0u), tab((size_t)B * LB);
             HIPC(hipMemcpyAsync(starts.data(), dStarts, starts.size() * 4, hipMemcpyDeviceToHost, st));
             HIPC(hipStreamSynchronize(st));
@@ -2129,6 +2148,7 @@ static int flush_batch(dev_ctx* ctx)
             HIPC(hipMemcpyAsync(dTab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
             HIPC(hipStreamSynchronize(st));                      // tab is a stack vector
             gbase = dTab; f.gbStride = LB; f.gbBands = 1;
+            }
         }
         if (!bandExchange) { f.gbStride = 1; f.gbBands = 0; }
         if (ctx->st.DoRaySorting && j > 1) {

@@ -409,6 +409,12 @@ int32_t idkptSetRowRange(idkpt_ctx* c, int32_t firstRow, int32_t rowCount)
     ONE(dev_SetRowRange(m, firstRow, rowCount));
     return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetRowRange: a multi-device context deals its rows itself (idkptSetGroupSharding)");
 }
+int32_t idkptSetBandExchangeDevice(idkpt_ctx* c, idkpt_band_exchange_device_fn fn, void* user)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    ONE(dev_SetBandExchangeDevice(m, fn, user));
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetBandExchangeDevice: a multi-device context deals and numbers its rows itself");
+}
 int32_t idkptSetBandExchange(idkpt_ctx* c, idkpt_band_exchange_fn fn, void* user)
 {
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;

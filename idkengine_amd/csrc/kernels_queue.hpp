@@ -2,6 +2,23 @@
 // Part of the single translation unit idkpt.hip (included there, in this order); see DESIGN.md §4 for the kernel table.
 #pragma once
 
+// idkptSetBandExchangeDevice: counts[k][b] = starts[k][b + 1] - starts[k][b] before the host's enqueued exchange, tab[k][b] = bases[k][b] - starts[k][b] after it (k_shade adds
+// the position inside the sample's segment): the two ends of the device-side path, no host synchronisation in between
+__global__ __launch_bounds__(256) void k_band_counts(const uint32_t* starts, int B, int LB, uint32_t* counts)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint32_t)B * (uint32_t)LB) return;
+    const uint32_t k = t / (uint32_t)LB, b = t % (uint32_t)LB;
+    counts[t] = starts[k * (uint32_t)(LB + 1) + b + 1] - starts[k * (uint32_t)(LB + 1) + b];
+}
+__global__ __launch_bounds__(256) void k_band_tab(const uint32_t* starts, const uint32_t* bases, int B, int LB, uint32_t* tab)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint32_t)B * (uint32_t)LB) return;
+    const uint32_t k = t / (uint32_t)LB, b = t % (uint32_t)LB;
+    tab[t] = bases[t] - starts[k * (uint32_t)(LB + 1) + b];
+}
+
 // idkptSetBandExchange: where, inside sample k's segment [bases[k], bases[k + 1]) of the alive queue (ray ids = k * Npad + local pixel, ascending: ordered compaction),
 // the rays of local band b start — starts[k * (LB + 1) + b], relative to bases[k]; b = LB: the segment's length.  One binary search per (sample, band).
 __global__ __launch_bounds__(256) void k_band_starts(const uint32_t* queue, const uint32_t* bases, int B, int LB, uint32_t bandPixels, uint32_t Npad, uint32_t* starts)

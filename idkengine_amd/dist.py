@@ -155,8 +155,30 @@ def broadcast_scene(scene, src=0, device=None, group=None):
 class _DevArray:
     """Minimal __cuda_array_interface__ carrier so torch can alias the library's device image without a copy."""
 
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    def __init__(self, ptr, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def make_band_exchange_device(height, band, device, stream, group=None):
+    """Host side of idkptSetBandExchangeDevice for one process per rank: nothing but ENQUEUED work on `stream` (the stream the context renders on) — an all-gather of the
+    per-(sample, band) alive counts (RCCL under the nccl backend) and the running sum over the image's bands as a handful of torch ops — so the exact deep-path mode never
+    synchronises the host.  Image band g = b * world + r is rank r's b-th band: [samples, bands, world] flattened IS the image order."""
+    rank = dist.get_rank(group); world = dist.get_world_size(group)
+    lbs = [local_band_count(height, world, r, band) for r in range(world)]
+    lb_max = max(lbs)
+
+    def exchange(bounce, samples, bands, d_counts, d_bases, hip_stream):
+        assert bands == lbs[rank] and int(hip_stream) == int(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            counts = torch.as_tensor(_DevArray(d_counts, (samples, bands), "<i4"), device=device)       # (alive counts fit 31 bits)
+            mine = torch.zeros((samples, lb_max), dtype=torch.int32, device=device); mine[:, :bands] = counts
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            img = torch.stack(parts, dim=2).reshape(samples, lb_max * world).to(torch.int64)          # image-band order; bands a rank does not own count 0
+            excl = torch.cumsum(img, dim=1) - img
+            mine_bases = excl.reshape(samples, lb_max, world)[:, :bands, rank].to(torch.int32).contiguous()
+            torch.as_tensor(_DevArray(d_bases, (samples, bands), "<i4"), device=device).copy_(mine_bases)
+    return exchange
 
 
 class GpuShardRenderer:
@@ -165,8 +187,9 @@ class GpuShardRenderer:
 
     def __init__(self, width, height, world, rank, device_index, exact_deep_paths=False, control_group=None, row_band=None):
         """Rows are dealt in interleaved bands of `row_band` rows (None: 8, or single rows on images with fewer bands than ranks): exact at RayDepth 2 as is.
-        exact_deep_paths: + a per-bounce exchange of the per-band alive counts over `control_group` (a CPU/gloo group, idkptSetBandExchange), so that N-GPU output equals
-        1-GPU output bit for bit at ANY RayDepth (sorting off) with the balanced deal; exact_deep_paths="strips": contiguous strips + per-sample counts (round 2's mode:
+        exact_deep_paths: + a per-bounce exchange of the per-band alive counts, so that N-GPU output equals 1-GPU output bit for bit at ANY RayDepth (sorting off) with the
+        balanced deal — enqueued on the render stream over the default group (RCCL all-gather + prefix sum, idkptSetBandExchangeDevice: no host synchronisation), or, when a
+        `control_group` (CPU / gloo) is given, on the host (idkptSetBandExchange: one stream synchronisation per bounce); exact_deep_paths="strips": contiguous strips + per-sample counts (round 2's mode:
         exact as well, but 8 strips of the headline camera scale 4.2x where 8 interleaved shards scale 7.6x)."""
         from .pathtracer import PathTracer
         torch.cuda.set_device(device_index)
@@ -181,12 +204,15 @@ class GpuShardRenderer:
             self.pt.SetBounceExchange(make_count_exchange(control_group))
         else:
             self.pt = PathTracer(width, height, device=device_index, row_modulo=world, row_remainder=rank, row_band=self.row_band)
-            if exact_deep_paths and world > 1:
-                self.pt.SetBandExchange(make_band_exchange(height, self.row_band, control_group))
         # render on a dedicated torch stream and issue the collectives under it: RCCL work is then ordered after the
         # kernels that produce the image, and later renders are ordered after the collective that reads it
         self.stream = torch.cuda.Stream(device=self.device)
         self.pt.set_stream(self.stream.cuda_stream)
+        if exact_deep_paths and not strips and world > 1:
+            if control_group is not None:      # a CPU (gloo) control group: host-side exchange, one stream synchronisation per bounce
+                self.pt.SetBandExchange(make_band_exchange(height, self.row_band, control_group))
+            else:                              # the default group on the render stream: RCCL all-gather + prefix sum enqueued, no host synchronisation
+                self.pt.SetBandExchangeDevice(make_band_exchange_device(height, self.row_band, self.device, self.stream))
         self.width, self.height, self.rows = width, height, self.pt.rows
 
     def upload_scene(self, scene):

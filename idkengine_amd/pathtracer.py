@@ -275,6 +275,21 @@ class PathTracer:
         self._bxfn = proto(tramp)      # keep the trampoline alive as long as the context uses it
         self._check(self._L.idkptSetBandExchange(self._ctx, self._bxfn, None))
 
+    def SetBandExchangeDevice(self, fn):
+        """idkptSetBandExchangeDevice: fn(bounce, samples, bands, d_counts_ptr, d_bases_ptr, hip_stream_ptr) ENQUEUES on that stream whatever fills the bases (device
+        pointers to uint32[samples * bands]) and returns; no host synchronisation.  None disables."""
+        import ctypes as C
+        if fn is None:
+            self._bxdfn = None
+            self._check(self._L.idkptSetBandExchangeDevice(self._ctx, None, None))
+            return
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
+
+        def tramp(user, bounce, samples, bands, d_counts, d_bases, stream):
+            fn(int(bounce), int(samples), int(bands), int(d_counts or 0), int(d_bases or 0), int(stream or 0))
+        self._bxdfn = proto(tramp)     # keep the trampoline alive as long as the context uses it
+        self._check(self._L.idkptSetBandExchangeDevice(self._ctx, self._bxdfn, None))
+
     def synchronize(self):
         self._check(self._L.idkptSynchronize(self._ctx))
 

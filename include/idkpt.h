@@ -203,6 +203,12 @@ IDKPT_API int32_t idkptSetBounceExchange(idkpt_ctx* ctx, idkpt_bounce_exchange_f
  * contexts; NULL disables. */
 typedef void (*idkpt_band_exchange_fn)(void* user, int32_t bounce, int32_t sampleCount, int32_t bandCount, const uint32_t* localCounts, uint32_t* outBases);
 IDKPT_API int32_t idkptSetBandExchange(idkpt_ctx* ctx, idkpt_band_exchange_fn fn, void* user);
+/* The same exchange without leaving the device: localCounts / outBases are DEVICE pointers (uint32[sampleCount * bandCount], valid until the next call) and the callback only
+ * ENQUEUES, on `hipStream` (the context's stream, behind the kernel that writes the counts), whatever fills outBases — an RCCL all-gather of the counts and a small
+ * prefix-sum kernel (idkengine_amd/dist.py make_band_exchange_device does it with torch.distributed on the same stream) — and returns; the library never synchronises
+ * the stream for it.  Takes precedence over idkptSetBandExchange when both are set. */
+typedef void (*idkpt_band_exchange_device_fn)(void* user, int32_t bounce, int32_t sampleCount, int32_t bandCount, const uint32_t* dLocalCounts, uint32_t* dOutBases, void* hipStream);
+IDKPT_API int32_t idkptSetBandExchangeDevice(idkpt_ctx* ctx, idkpt_band_exchange_device_fn fn, void* user);
 /* Property setters of PathTracer (PathTracer.cs:12-125); changing anything but DoRussianRoulette/sorting/AOV
  * resets accumulation exactly like the reference setters do. */
 IDKPT_API int32_t idkptSetSettings(idkpt_ctx* ctx, const idkpt_settings* settings);

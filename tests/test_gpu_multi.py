@@ -295,8 +295,8 @@ def test_multi_device_context_without_peer_access(native_builder, members, monke
 
 
 
-@pytest.mark.parametrize("batch,band", [(1, 8), (3, 8), (2, 1)])
-def test_exact_deep_paths_with_interleaved_bands(native_builder, oracle_mod, batch, band):
+@pytest.mark.parametrize("batch,band,on_device", [(1, 8, False), (3, 8, False), (2, 1, False), (3, 8, True)])
+def test_exact_deep_paths_with_interleaved_bands(native_builder, oracle_mod, batch, band, on_device):
     """idkptSetRowBands / idkptSetRowSharding + idkptSetBandExchange: three contexts with the BALANCED deal (interleaved bands of 8 rows, or single interleaved rows), driven by
     three host threads in lockstep, the exchange function running dist.band_bases over everybody's per-(sample, band) counts: the single-context frame bit for bit at
     RayDepth 6 — image, ray state, total ray count — also with several accumulated samples per batch.  And one banded context against the oracle under an arbitrary
@@ -327,7 +327,22 @@ def test_exact_deep_paths_with_interleaved_bands(native_builder, oracle_mod, bat
     pts, errs = [], []
     for r in range(world):
         p = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov), row_modulo=world, row_remainder=r, row_band=band); p.UploadScene(sc); p.SetCamera(cam)
-        p.SetBandExchange(exchange_for(r)); p.set_max_batch(batch)
+        if on_device:
+            # idkptSetBandExchangeDevice: counts and bases are device buffers and the callback may merely enqueue on the context's stream (dist.make_band_exchange_device does,
+            # with an all-gather); this one drains the stream and goes through the same board, which a callback is free to do
+            import torch
+            from idkengine_amd.dist import _DevArray
+
+            def dev_fn(bounce, samples, bands, d_counts, d_bases, stream, _fn=exchange_for(r)):
+                torch.cuda.ExternalStream(stream).synchronize()
+                counts = torch.as_tensor(_DevArray(d_counts, (samples, bands), "<i4"), device="cuda:0").cpu().numpy().astype(np.uint32)
+                bases = np.asarray(_fn(bounce, counts), np.uint32).astype(np.int64).astype(np.int32)
+                torch.as_tensor(_DevArray(d_bases, (samples, bands), "<i4"), device="cuda:0").copy_(torch.from_numpy(bases.reshape(samples, bands)))
+                torch.cuda.synchronize()
+            p.SetBandExchangeDevice(dev_fn)
+        else:
+            p.SetBandExchange(exchange_for(r))
+        p.set_max_batch(batch)
         pts.append(p)
 
     def run(p):

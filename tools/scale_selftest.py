@@ -96,9 +96,8 @@ def main():
             log(f"row-sharded frame over {world} ranks (all-gather) == 1 device: {same}")
             ok &= same
         r.pt.Dispose()
-        # the same deal at RayDepth 5 with the per-band count exchange (idkptSetBandExchange over a gloo control group): exact beyond RayDepth 2 as well
-        control = dist.new_group(backend="gloo")
-        r = D.GpuShardRenderer(w, h, world, rank, dev_index, exact_deep_paths=True, control_group=control); r.upload_scene(scene); r.set_camera(cam); r.pt.RayDepth = 5; r.pt.set_max_batch(2)
+        # the same deal at RayDepth 5 with the per-band count exchange enqueued on the render stream (idkptSetBandExchangeDevice: all-gather + prefix sum): exact beyond RayDepth 2 as well
+        r = D.GpuShardRenderer(w, h, world, rank, dev_index, exact_deep_paths=True); r.upload_scene(scene); r.set_camera(cam); r.pt.RayDepth = 5; r.pt.set_max_batch(2)
         frame = D.ShardedFrame(r, w, h)
         for _ in range(3):
             r.pt.Compute()
