@@ -73,6 +73,7 @@ struct DevOptions {
     int spec = 0;                // developer build only: k_trace2<.., DBG = 8> (speculative touch of both children and the stack top before the box tests): 0 = never (default: measured slower at every launch size, profiles/r04_small_launch_experiments.md), 1 = launches below SPEC_MAX_RAYS rays, 2 = every launch
     int splitScatter = 6;        // k_trace2s: log2 of the entries that stay together when the work list is handed out scattered (6 = list order)
     int queryScheduler = 1;      // idkptTraceRays (closest hit) through k_trace2's scheduler instead of the thread-per-ray kernel (kernels_query.hpp)
+    int groupThreads = -1;       // multi-device contexts (idkpt_api.hpp group_flush): members' batches enqueued by one host thread each also where no exchange needs it (-1: from 4 members on)
     int park = 0;                // k_trace2p (kernels_trace_park.hpp): a lane may carry two parked leaves (the second found with a stale T, re-validated before it is tested).  Bit mask like leaf_pool: 1 primary launches, 2 first bounce, 4 later bounces
     int quad = 0;                // k_trace2q (kernels_trace_quad.hpp): two binary levels per round trip on a derived 192-B record.  0 off, 1 small launches (want_quad), 2 wherever it applies
     int fused = 1;               // k_trace_fused (kernels_trace_fused.hpp): FirstHit + shading + the last NHit's traversal in one persistent launch at RayDepth 2.  0 off, 1 small launches on sparse views (want_fused), 2 wherever it is exact
@@ -1052,6 +1053,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "split_scatter") o.splitScatter = std::min(6, std::max(0, value));
     else if (n == "query_scheduler") o.queryScheduler = value != 0;
     else if (n == "park") o.park = value & 7;
+    else if (n == "group_threads") o.groupThreads = value;
     else if (n == "quad") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: quad is 0..2"); o.quad = value; }
     else if (n == "fused") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: fused is 0..2"); o.fused = value; }
     else if (n == "fused_shade_min") o.fusedShadeMin = std::min(64, std::max(1, value));

@@ -140,8 +140,12 @@ static int group_flush(idkpt_ctx* c)
     if (c->pending == 0) return IDKPT_OK;
     // interleaved rows / bands beyond RayDepth 2 with sorting off: exact slot numbers need every member's band counts at every bounce -> one host thread per member,
     // meeting in group_band_exchange (strips keep the pipelined, device-side exchange below; RayDepth <= 2 needs none)
-    const bool threaded = !c->strips && c->n() > 1 && c->st.RayDepth > 2;
-    for (size_t d = 0; d < c->n(); d++) { dev_ctx* m = c->dev[d]; m->bandExchangeFn = threaded ? group_band_exchange : nullptr; m->bandExchangeUser = threaded ? (void*)&c->bandUser[d] : nullptr; }
+    // (option group_threads: the interleaved layouts at RayDepth <= 2 need no exchange and can be enqueued by one thread or by one per member — N x ~15 launches of host
+    // time in a row or side by side; -1 = one per member from 4 members on)
+    const bool exchange = !c->strips && c->n() > 1 && c->st.RayDepth > 2;
+    const int threadsOpt = c->dev[0]->opt.groupThreads;
+    const bool threaded = exchange || (!c->strips && c->n() > 1 && (threadsOpt < 0 ? c->n() >= 4 : threadsOpt != 0));
+    for (size_t d = 0; d < c->n(); d++) { dev_ctx* m = c->dev[d]; m->bandExchangeFn = exchange ? group_band_exchange : nullptr; m->bandExchangeUser = exchange ? (void*)&c->bandUser[d] : nullptr; }
     if (threaded) {
         c->bar.reset((int)c->n());
         std::vector<int> rcs(c->n(), IDKPT_OK);
