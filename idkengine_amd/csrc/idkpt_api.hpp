@@ -423,7 +423,7 @@ int32_t idkptSetBandExchange(idkpt_ctx* c, idkpt_band_exchange_fn fn, void* user
 {
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
     ONE(dev_SetBandExchange(m, fn, user));
-    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetBandExchange: a multi-device context deals and numbers its rows itself (strips + device-side exchange beyond RayDepth 2)");
+    return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptSetBandExchange: a multi-device context deals and numbers its rows itself");
 }
 int32_t idkptSetBounceExchange(idkpt_ctx* c, idkpt_bounce_exchange_fn fn, void* user)
 {
