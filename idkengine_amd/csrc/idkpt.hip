@@ -244,12 +244,30 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
 #define T2C(M, V) do { if (ctx->counters) T2P(true, M, V); else T2P(false, M, V); } while (0)
     const bool rec = f.recPerRay > 1;      // per-instance trace-ready records (scenes of up to MAX_REC_INSTANCES instances, option instance_records): MODE 3 / 4 instead of 1 / 2 (never pooled)
     if (s.ver) {                    // scene versions: the samples of this batch see different states of the geometry (VER instantiations, kernels_trace.hpp)
-#define T2N(M, V) do { if (ctx->counters) T2X(true, M, 0, V); else T2X(false, M, 0, V); } while (0)      // (never pooled: the instance-loop / TLAS kernels gain nothing from it)
+// the instance-loop / TLAS kernels: never pooled (they gain nothing from it), and idle lanes are refilled from 16 on instead of 32 — their rays live two to three BLAS walks,
+// so a refill is rarer per step than in MODE 0 and lanes are what these modes lack (profiles/r04_multi_blas.md: 8 / 12 / 16 / 24 / 32 / 48 = 3 524 / 3 572 / 3 592-3 654 / 3 616 /
+// 3 446-3 474 / 2 684 Mray/s through the instance loop, TLAS alike; MODE 0 keeps 32: 24 measured -4.5 % there in round 1)
+#define T2M(C, M, V) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 16, 1, false, 24, M, 0, V>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+#define T2N(M, V) do { if (ctx->counters) T2M(true, M, V); else T2M(false, M, V); } while (0)
         if (f.useTlas) { if (rec) T2N(4, true); else T2N(2, true); }
         else if (ctx->instanceCount > 1) { if (rec) T2N(3, true); else T2N(1, true); }
         else T2C(0, true);
         return;
     }
+#ifdef IDKPT_DEVELOPER
+    // developer probe (trace_variant 24 / 48 / 16): the refill threshold of the instance-loop / TLAS kernels (their rays live two to three BLAS walks: fewer refills per step than MODE 0's)
+    if (!rec && !ctx->counters && (f.useTlas || ctx->instanceCount > 1) && (ctx->opt.traceVariant == 24 || ctx->opt.traceVariant == 48 || ctx->opt.traceVariant == 16 || ctx->opt.traceVariant == 8 || ctx->opt.traceVariant == 12)) {
+#define T2R(R, M) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, 24, M, 0, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+        const int m = f.useTlas ? 2 : 1;
+        if (ctx->opt.traceVariant == 24) { if (m == 2) T2R(24, 2); else T2R(24, 1); }
+        else if (ctx->opt.traceVariant == 48) { if (m == 2) T2R(48, 2); else T2R(48, 1); }
+        else if (ctx->opt.traceVariant == 16) { if (m == 2) T2R(16, 2); else T2R(16, 1); }
+        else if (ctx->opt.traceVariant == 12) { if (m == 2) T2R(12, 2); else T2R(12, 1); }
+        else { if (m == 2) T2R(8, 2); else T2R(8, 1); }
+#undef T2R
+        return;
+    }
+#endif
     if (f.useTlas) {                // TLAS walk inside the kernel (MODE 4: the leaves' instance entries come from per-instance records, MODE 2: computed in the kernel)
         if (rec) T2N(4, false); else T2N(2, false);
         return;
@@ -260,6 +278,7 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
     }
     if (pool) { if (ctx->counters) T2X(true, 0, 16, false); else T2X(false, 0, 16, false); return; }
 #undef T2N
+#undef T2M
 #undef T2C
 #undef T2P
 #undef T2X
@@ -272,7 +291,7 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         case 122: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24, 0, 32>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // ... instrumented
         case 116: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;  // instrumented, pooled leaf phase
 #define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
-        case 901: T2V(32, 20); return; case 902: T2V(40, 16); return;
+        case 901: T2V(32, 20); return; case 902: T2V(40, 16); return; case 903: T2V(24, 24); return; case 904: T2V(16, 24); return;   // (903 / 904: MODE 0's refill threshold re-measured in round 4)
         case 961: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // occupancy probes: 7 / 8 waves per SIMD forced (launch bounds)
         case 962: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 8, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;
 #define T2D(D) hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, D>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
