@@ -22,6 +22,7 @@ using namespace ptd;
 // =================================================================================================== kernels (one translation unit)
 #include "kernels_common.hpp"
 #include "kernels_trace.hpp"
+#include "kernels_wide.hpp"
 #include "kernels_trace_split.hpp"
 #include "kernels_trace_quad.hpp"
 #include "kernels_trace_park.hpp"
@@ -81,6 +82,9 @@ struct DevOptions {
     int splitPeek = 64;          // k_trace2s: iterations between two looks at the work-list heads (a wave with < 32 idle lanes never refills, so it has to ask whether the list is empty).  Measured: 64 -> 16 -> 8 -> 2 = 2 147 -> 1 750 -> 1 743 -> 1 697 Mray/s on the headline view one frame at a time: splitting EARLY multiplies pieces (and their bookkeeping) while most lanes still have rays of their own; it pays in the real tail only
     int splitDonor = 1;          // k_trace2s: 1 = only rays that have not hit anything yet donate subtrees, 0 = every busy lane does
     int split = 1;               // k_trace2s (long rays split across the idle lanes of their wave once the work list is empty): 0 = never, 1 = small launches of sparse views (default, want_split), 2 = every launch, 3 = every launch + every split ray traced again (test hook for the re-trace path)
+    int wide = 1;                // k_trace_wide (kernels_wide.hpp): closest-hit launches of one-BLAS scenes walk the derived 4-wide nodes; rays it cannot vouch for are re-traced by k_trace2.  0 = k_trace2 only
+    int wideCap = 0;             // ... rows of its per-lane stack (0: 24; a ray that needs more is re-traced by k_trace2)
+    int wideCount = 0;           // ... count node visits / leaf records / triangle tests (idkpt_stats.Wide*)
     int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
 };
 
@@ -94,6 +98,7 @@ struct dev_ctx {
     int device = 0;
     hipStream_t stream = nullptr; bool ownStream = true;
     std::string lastError;
+    idkpt_error_fn errFn = nullptr; void* errUser = nullptr;   // idkptSetErrorCallback
     int numCUs = 256;
     // config
     idkpt_settings st;          // effective settings
@@ -118,6 +123,8 @@ struct dev_ctx {
     int sceneStack = 1;
     int hInst0Blas = 0;                              // BlasId of instance 0 (MODE 0 traverses that BLAS)
     bool quadValid = false;                          // `quads` (kernels_trace_quad.hpp) matches the current nodes
+    // wide nodes (kernels_wide.hpp): derived per BLAS from nodes + triVerts.  wideTopoValid: the children lists match the node topology; wideFillValid: boxes / leaf records match the current boxes and positions
+    DevBuf wnodes, wleaf, wids, wpair, wcounts, wtotals; std::vector<uint32_t> wNodeOff, wLeafOff; bool wideTopoValid = false, wideFillValid = false;
     bool layoutActive = false;                       // tnodes holds the derived order (else the traversal reads `nodes`)
     // scene versions: slot count a versioned buffer may grow to, per buffer the bytes of one state / the slot pitch / the slots its arena holds / the current slot
     int verSlots = 1; size_t vbytes[VB_COUNT] = {0}, vstride[VB_COUNT] = {0}; int valloc[VB_COUNT] = {1, 1, 1, 1, 1, 1}, vcur[VB_COUNT] = {0};
@@ -173,7 +180,9 @@ static void resolve_trace_events(dev_ctx* ctx)
 #define TRACE_T0() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
 #define TRACE_T1() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
 
-static int fail(dev_ctx* c, int code, const std::string& msg) { if (c) c->lastError = msg; return code; }
+// every failing entry point ends here: the message is kept for idkptGetLastError and handed to the host's error callback (idkptSetErrorCallback; oidnSetDeviceErrorFunction's
+// pattern, Source/OIDN/OIDN.cs:108-109) on the thread that detected the error
+static int fail(dev_ctx* c, int code, const std::string& msg) { if (c) { c->lastError = msg; if (c->errFn) c->errFn(c->errUser, (int32_t)code, c->lastError.c_str()); } return code; }
 // (a failed runtime call leaves its code in the thread's last-error slot: reset it, or the next hipGetLastError() check would report it again)
 #define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
 #define REQUIRE(cond, msg) do { if (!(cond)) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
@@ -187,6 +196,50 @@ static int local_rows(int H, int mod, int rem, int bandLog2 = 0)
     return n;
 }
 
+// ---- wide nodes (kernels_wide.hpp): which launches use them, and their derivation on the device ----------------------------------------------------------------
+// One-BLAS scenes, closest hit, the reference's counters not asked for, one scene version: everything else keeps k_trace2.
+static bool wide_wanted(const dev_ctx* ctx) { return ctx->opt.wide != 0 && ctx->instanceCount == 1 && !ctx->st.UseTlas && ctx->verSlots == 1 && !ctx->counters && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100 || ctx->opt.traceVariant == 213); }
+static int wide_stack_rows(const dev_ctx* ctx) { return std::min(96, std::max(4, ctx->opt.wideCap > 0 ? ctx->opt.wideCap : 24)); }
+// (re-)derives what is stale: the children lists after an upload / a node patch (k_wide_topo, one workgroup per BLAS), box bytes and leaf records after anything that
+// moved boxes or positions (k_wide_fill).  Stream-ordered in front of the batch that is about to be launched; with one scene version every update launches the queued samples first.
+static char* vb_ptr(dev_ctx* ctx, int b, int slot);
+static int wide_prepare(dev_ctx* ctx)
+{
+    if (ctx->wideTopoValid && ctx->wideFillValid) return IDKPT_OK;
+    if (!ctx->wtotals.p) { HIPC(ctx->wtotals.ensure(64)); HIPC(hipMemsetAsync(ctx->wtotals.p, 0, 64, ctx->stream)); }
+    const size_t nb = ctx->hDescs.size();
+    hipStream_t st = ctx->stream;
+    const float4* nodes = (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]);
+    const float4* triVerts = (const float4*)vb_ptr(ctx, VB_TRIVERTS, ctx->vcur[VB_TRIVERTS]);
+    if (!ctx->wideTopoValid) {
+        ctx->wNodeOff.assign(nb + 1, 0u); ctx->wLeafOff.assign(nb + 1, 0u);
+        for (size_t b = 0; b < nb; b++) {
+            const GpuBlasDesc& d = ctx->hDescs[b];
+            const uint32_t pairs = (uint32_t)std::max(0, d.NodeCount) / 2u + 1u, leavesMax = pairs + 1u;                       // a wide node stands for at least one pair; a tree of L leaves has L - 1 internal nodes
+            ctx->wNodeOff[b + 1] = ctx->wNodeOff[b] + pairs;
+            ctx->wLeafOff[b + 1] = ctx->wLeafOff[b] + 5u * leavesMax + 3u * (uint32_t)std::max(0, d.TriangleCount) + 4u;   // 2 + 3 per leaf-range triangle (a leaf pair may share one triangle)
+        }
+        HIPC(ctx->wnodes.ensure((size_t)ctx->wNodeOff[nb] * 64 + 64)); HIPC(ctx->wids.ensure((size_t)ctx->wNodeOff[nb] * 16 + 16)); HIPC(ctx->wpair.ensure((size_t)ctx->wNodeOff[nb] * 4 + 16));
+        HIPC(ctx->wleaf.ensure((size_t)ctx->wLeafOff[nb] * 16 + 80)); HIPC(ctx->wcounts.ensure(nb * 8 + 8));
+        for (size_t b = 0; b < nb; b++) {
+            const GpuBlasDesc& d = ctx->hDescs[b];
+            hipLaunchKernelGGL(k_wide_topo, dim3(1), dim3(WIDE_TOPO_THREADS), 0, st, nodes + 2 * (size_t)d.NodeOffset, (uint32_t)d.NodeCount, ctx->wpair.as<uint32_t>() + ctx->wNodeOff[b],
+                               ctx->wids.as<uint4>() + ctx->wNodeOff[b], ctx->wnodes.as<uint4>() + 4 * (size_t)ctx->wNodeOff[b], ctx->wcounts.as<uint32_t>() + 2 * b);
+        }
+        HIPC(hipGetLastError());
+        ctx->wideTopoValid = true; ctx->wideFillValid = false;
+    }
+    for (size_t b = 0; b < nb; b++) {
+        const GpuBlasDesc& d = ctx->hDescs[b];
+        const uint32_t pairs = ctx->wNodeOff[b + 1] - ctx->wNodeOff[b];
+        hipLaunchKernelGGL(k_wide_fill, dim3((pairs + 255) / 256), dim3(256), 0, st, nodes + 2 * (size_t)d.NodeOffset, triVerts + 3 * (size_t)d.TriangleOffset, (const uint4*)(ctx->wids.as<uint4>() + ctx->wNodeOff[b]),
+                           ctx->wnodes.as<uint4>() + 4 * (size_t)ctx->wNodeOff[b], ctx->wleaf.as<float4>() + ctx->wLeafOff[b], (const uint32_t*)(ctx->wcounts.as<uint32_t>() + 2 * b));
+    }
+    HIPC(hipGetLastError());
+    ctx->wideFillValid = true;
+    return IDKPT_OK;
+}
+
 template <bool PRIMARY>
 static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
                           const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, bool spec = false, int bounce = 0, bool anyHit = false, bool quad = false)
@@ -195,6 +248,25 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
 #define T2A(M) hipLaunchKernelGGL((k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         if (f.useTlas) T2A(2); else if (ctx->instanceCount > 1) T2A(1); else T2A(0);
 #undef T2A
+        return;
+    }
+    if (ctx->wideFillValid && ctx->wideTopoValid && wide_wanted(ctx) && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid) {
+        // wide-node walk (kernels_wide.hpp), then — on the launch's own list of the rays it does not vouch for, almost always empty — the exact kernel
+        const int b0 = ctx->hInst0Blas;
+        WideBufs wb;
+        wb.nodes = (const uint4*)(ctx->wnodes.as<uint4>() + 4 * (size_t)ctx->wNodeOff[b0]); wb.leaves = (const float4*)(ctx->wleaf.as<float4>() + ctx->wLeafOff[b0]);
+        wb.flagCount = work + 128; wb.flagA = ctx->sortKeys.as<uint32_t>(); wb.flagB = ctx->sortVals.as<uint32_t>(); wb.totals = ctx->wtotals.as<unsigned long long>(); wb.cap = wide_stack_rows(ctx);
+        const size_t ldsW = (size_t)(wb.cap + 2) * WAVE * 4 + (size_t)std::max(0, ctx->opt.ldsPad);     // + the dummy and the spare row
+#ifdef IDKPT_DEVELOPER
+        if (ctx->opt.traceVariant == 213) hipLaunchKernelGGL((k_trace_wide<PRIMARY, false, 32, true>), dim3(grid), dim3(WAVE), ldsW, st, s, f, rays, tr, hits, list, cnt, work, wb, counters);   // s_memtime-instrumented
+        else
+#endif
+        if (ctx->opt.wideCount) hipLaunchKernelGGL((k_trace_wide<PRIMARY, true>), dim3(grid), dim3(WAVE), ldsW, st, s, f, rays, tr, hits, list, cnt, work, wb, counters);
+        else hipLaunchKernelGGL((k_trace_wide<PRIMARY, false>), dim3(grid), dim3(WAVE), ldsW, st, s, f, rays, tr, hits, list, cnt, work, wb, counters);
+        TraceBufs trf = tr; trf.order = nullptr; trf.orderIdx = nullptr;
+        if (!PRIMARY) { trf.order = wb.flagA; trf.orderIdx = wb.flagB; }        // position -> queue slot and ray id (the hit is stored at the slot, as always)
+        Frame ff = f; ff.gridRaysX4 = 6u; ff.gridMid = 0u;                       // (the device sizes the launch from its actual count: k_trace2's own rule)
+        hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(std::min<uint32_t>(grid, 2048u)), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)wb.flagA, (const uint32_t*)wb.flagCount, work + 64, counters);
         return;
     }
 #ifdef IDKPT_DEVELOPER
@@ -386,7 +458,14 @@ static int flush_any(dev_ctx* ctx);
 static int flush_any(dev_ctx* ctx)
 {
     if (ctx->pending.empty()) return IDKPT_OK;
-    return (ctx->grouped && !ctx->inGroupFlush && ctx->groupFlushAll) ? ctx->groupFlushAll(ctx->groupUser) : flush_batch(ctx);
+    if (!(ctx->grouped && !ctx->inGroupFlush && ctx->groupFlushAll)) return flush_batch(ctx);
+    // the group launches every member's batch and leaves some other member's device current: the caller (an update of THIS member: hipMalloc,
+    // event creation, kernel launches follow) continues on its own device
+    const int rc = ctx->groupFlushAll(ctx->groupUser);
+    const hipError_t e = hipSetDevice(ctx->device);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, IDKPT_ERR_HIP, std::string("hipSetDevice after the group flush: ") + hipGetErrorString(e));
+    return IDKPT_OK;
 }
 static DevBuf& vb_buf(dev_ctx* ctx, int b)
 {
@@ -397,11 +476,25 @@ template <class T> static T* vb_cur(dev_ctx* ctx, int b) { return (T*)vb_ptr(ctx
 // after idkptUploadScene / a clone / a re-derived node order: one state per buffer, in slot 0 of whatever allocation the buffer has
 static void ver_reset(dev_ctx* ctx)
 {
-    ctx->quadValid = false;
+    ctx->quadValid = false; ctx->wideTopoValid = false; ctx->wideFillValid = false;
     const size_t one[VB_COUNT] = {(size_t)ctx->nodeCount * 32, ctx->layoutActive ? (size_t)ctx->nodeCount * 32 : 0, (size_t)ctx->triCount * 48, (size_t)ctx->vertexCount * 16,
                                   (size_t)std::max(ctx->tlasCount, 2 * ctx->instanceCount - 1) * 32, (size_t)ctx->xformCount * sizeof(GpuMeshTransform)};
     for (int b = 0; b < VB_COUNT; b++) { ctx->vbytes[b] = one[b]; ctx->vstride[b] = (one[b] + 255) / 256 * 256; ctx->valloc[b] = 1; ctx->vcur[b] = 0; ctx->lastMask[b] = 0; ctx->lastSlots[b] = 0; }
     ctx->lastMulti = false;
+}
+// ... and every buffer really holds one whole slot: a scene uploaded without TLAS nodes (legal when !UseTlas) leaves `tlas` a 16-byte allocation while its slot
+// is sized for the 2n - 1 nodes idkptBuildTlas / idkptBuildTlasOnDevice write in place later (ver_writable hands out slot 0 without looking at the allocation)
+static int ver_reserve(dev_ctx* ctx)
+{
+    for (int b = 0; b < VB_COUNT; b++) {
+        DevBuf& buf = vb_buf(ctx, b);
+        if (ctx->vbytes[b] == 0 || buf.bytes >= ctx->vbytes[b]) continue;
+        DevBuf nb; HIPC(nb.ensure(ctx->vstride[b]));
+        if (buf.p && buf.bytes) HIPC(hipMemcpyAsync(nb.p, buf.p, std::min(buf.bytes, ctx->vbytes[b]), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));            // (the old allocation is released right below; once per upload, only for a buffer that was short)
+        buf.release(); buf = nb;
+    }
+    return IDKPT_OK;
 }
 // the arena of buffer b gets room for every slot (first use of a second slot): only slot 0 is in use at that moment
 static int ver_grow(dev_ctx* ctx, int b)
@@ -422,6 +515,7 @@ static int ver_grow(dev_ctx* ctx, int b)
 // `full`: the update rewrites every byte of the buffer's state (nothing to carry over).  May launch queued samples / complete a deferred bounce when no slot is free.
 static int ver_writable(dev_ctx* ctx, int b, bool full, char** src, char** dst)
 {
+    if (b == VB_NODES || b == VB_TRIVERTS) ctx->wideFillValid = false;   // (node boxes or triangle positions are about to change: boxes and leaf records of the wide nodes are re-derived before their next use)
     if (b == VB_NODES || b == VB_TNODES) ctx->quadValid = false;   // (somebody is about to rewrite node boxes: the quad records are re-derived before their next use)
     const int p = ctx->vcur[b];
     auto free_slot = [&](uint64_t busy) { if (ctx->verSlots > 1 && ctx->vbytes[b] > 0) for (int k = 0; k < ctx->verSlots; k++) if (!((busy >> k) & 1ull)) return k; return -1; };
@@ -623,7 +717,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* all[] = {&ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
+    DevBuf* all[] = {&ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tnodes, &ctx->nodeSlot, &ctx->ordKeys[0], &ctx->ordKeys[1], &ctx->ordVals[0], &ctx->ordVals[1], &ctx->ordIdx, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
                      &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->quads, &ctx->bandTab, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
@@ -874,6 +968,7 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     ctx->sceneStack = maxStack; ctx->tlasNeed = std::max(1, tlasNeed);
     ctx->sceneNested = blas_nested(sc->BlasNodes, sc->BlasDescs, sc->BlasDescCount);
     ver_reset(ctx);                                   // one state per versioned buffer, in slot 0 (everything that read the old scene was launched by FLUSH above)
+    if ((rc = ver_reserve(ctx))) return rc;
     // refit schedule: internal nodes of every refittable BLAS grouped by depth (children have larger ids than parents)
     ctx->levelOffsets.assign(sc->BlasDescCount, {}); ctx->levelBase.assign(sc->BlasDescCount, 0); ctx->refitCoversAll.assign(sc->BlasDescCount, 0);
     std::vector<int32_t> allLevels;
@@ -965,6 +1060,7 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->hInst0Blas = src->hInst0Blas; ctx->quadValid = false; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneNested = src->sceneNested; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed; ctx->layoutActive = src->layoutActive;
     ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase; ctx->refitCoversAll = src->refitCoversAll;
     ver_reset(ctx);
+    { int rc = ver_reserve(ctx); if (rc) return rc; }
     HIPC(hipStreamSynchronize(ctx->stream));           // td is a stack vector
     ctx->haveScene = true;
     std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
@@ -1024,7 +1120,7 @@ static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes,
             REQUIRE(why == nullptr, std::string("idkptUpdateBuffer: ") + (why ? why : ""));
             REQUIRE(ctx->st.BlasStackSize == 0 || ctx->st.BlasStackSize >= maxStack, "idkptUpdateBuffer: the patched BLAS needs a deeper traversal stack than the BlasStackSize set with idkptSetSettings");
             HIPC(hipMemcpyAsync(cur + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
-            ctx->sceneStack = maxStack;
+            ctx->sceneStack = maxStack; ctx->wideTopoValid = false; ctx->wideFillValid = false;   // (the tree itself may have changed: the wide nodes are derived anew)
             ctx->sceneNested = blas_nested((const GpuBlasNode*)h.data(), ctx->hDescs.data(), (int)ctx->hDescs.size());
             int rc = rebuild_node_layout(ctx, (const GpuBlasNode*)h.data()); if (rc) return rc;
         } else {
@@ -1090,6 +1186,9 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
 #ifdef IDKPT_DEVELOPER
     else if (n == "graph_probe") o.graphProbe = std::max(0, value);
 #endif
+    else if (n == "wide") { REQUIRE(value >= 0 && value <= 1, "idkptSetDeveloperOption: wide is 0 or 1"); FLUSH(); o.wide = value; }
+    else if (n == "wide_cap") { REQUIRE(value >= 0 && value <= 96, "idkptSetDeveloperOption: wide_cap is 0 (default) or 4..96 rows"); o.wideCap = value; }
+    else if (n == "wide_count") o.wideCount = value != 0;
     else if (n == "bvh_timing") o.bvhTiming = value != 0;
     else if (n == "bvh_small") o.bvhSmall = value;
     else if (n == "bvh_stackopt_host") o.bvhStackOptHost = value != 0;
@@ -1125,6 +1224,17 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
 static int32_t dev_DownloadBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, void* dst)
 {
     if (!ctx || !dst) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (which == IDKPT_BUF_WIDE_NODES || which == IDKPT_BUF_WIDE_LEAVES || which == IDKPT_BUF_WIDE_COUNTS) {   // read-only views of the derived traversal structure (tests, tools)
+        if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptDownloadBuffer: no scene uploaded");
+        HIPC(hipSetDevice(ctx->device));
+        FLUSH();
+        { int rc = wide_prepare(ctx); if (rc) return rc; }
+        DevBuf& wbuf = which == IDKPT_BUF_WIDE_NODES ? ctx->wnodes : (which == IDKPT_BUF_WIDE_LEAVES ? ctx->wleaf : ctx->wcounts);
+        REQUIRE(offsetBytes + bytes <= (which == IDKPT_BUF_WIDE_COUNTS ? ctx->hDescs.size() * 8 : wbuf.bytes), "idkptDownloadBuffer: bad buffer/range");
+        HIPC(hipMemcpyAsync(dst, (char*)wbuf.p + offsetBytes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+        return IDKPT_OK;
+    }
     size_t cap = 0; int vb = -1; DevBuf* b = which_buffer(ctx, which, &cap, &vb);
     REQUIRE(b != nullptr && offsetBytes + bytes <= cap, "idkptDownloadBuffer: bad buffer/range");
     HIPC(hipSetDevice(ctx->device));
@@ -2044,10 +2154,12 @@ static int flush_batch(dev_ctx* ctx)
     const bool debug = f.g.DoDebugBVHTraversal != 0;
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);
+    if (fast && wide_wanted(ctx)) { int rc = wide_prepare(ctx); if (rc) { ctx->pending.clear(); return rc; } }
     // one launch for FirstHit + the last NHit (kernels_trace_fused.hpp): RayDepth 2, one BLAS instance, the last bounce deferred (no AOVs, no debug view), nothing that looks at
     // the primary hits or the visit counters, no per-bounce exchange with other contexts — and a launch small enough to be bound by its longest rays
     const bool fused = fast && ctx->st.RayDepth == 2 && ctx->opt.deferLast != 0 && !f.outputAovs && !f.g.DoDebugBVHTraversal && !f.useTlas && ctx->instanceCount == 1 && !multiVer && !ctx->counters
                        && !ctx->capturePrimary && !ctx->groupExchange && !ctx->exchangeFn && !ctx->bandExchangeFn && !ctx->bandExchangeDevFn && f.recPerRay == 1 && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)
+                       && !(wide_wanted(ctx) && ctx->opt.fused < 2)    // (the wide-node walk shortens the dependent chains the fused launch only stops paying launches for)
                        && want_fused(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B);
     f.hitsByRid = fused ? 1 : 0; f.shadeMin = ctx->opt.fusedShadeMin; f.scatterLog2 = ctx->opt.splitScatter;
     if (!fast && (B != 1 || multiVer)) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
@@ -2489,8 +2601,9 @@ static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
     uint64_t c[4] = {0, 0, 0, 0};
     HIPC(hipMemcpyAsync(c, ctx->counters64.p, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
-    if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113 || ctx->opt.traceVariant == 116) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu | leafTests %llu leafTrips %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13], (unsigned long long)d[14], (unsigned long long)d[15]); }
+    if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113 || ctx->opt.traceVariant == 116 || ctx->opt.traceVariant == 213) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu | leafTests %llu leafTrips %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13], (unsigned long long)d[14], (unsigned long long)d[15]); }
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
+    if (ctx->wtotals.p) { uint64_t w[4] = {0, 0, 0, 0}; HIPC(hipMemcpyAsync(w, ctx->wtotals.p, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); s.WideFlaggedRays = w[0]; s.WideNodeVisits = w[1]; s.WideLeafRecords = w[2]; s.WideTriangleTests = w[3]; }
     *out = s;
     return IDKPT_OK;
 }
@@ -2504,7 +2617,7 @@ static int32_t dev_ResetStats(dev_ctx* ctx)
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;
     memset(ctx->hCounts, 0, (MAX_DEPTH_SLOTS - 1) * 4);     // (the last word, the length of the primary active list, is also the grid hint of the next batch: idkptGetStats reports it only once frames were rendered)
-    HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
+    HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream)); if (ctx->wtotals.p) HIPC(hipMemsetAsync(ctx->wtotals.p, 0, 64, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
 }
 

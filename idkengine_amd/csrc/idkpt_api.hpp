@@ -43,6 +43,7 @@ struct GroupBandUser { idkpt_ctx* c; int d; };
 struct idkpt_ctx {
     std::vector<dev_ctx*> dev;
     std::string lastError;
+    idkpt_error_fn errFn = nullptr; void* errUser = nullptr;
     PeerPolicy peer;                                        // how the members copy to each other (xGMI peer copies, or staged through the host)
     hipEvent_t evGatherStart = nullptr;                     // device 0: what was queued on its stream before a gather (the consumer of the previous frame)
     bool frameOk = true;                                    // false after a failed re-layout: idkptRender refuses until the next successful idkptSetSize
@@ -80,7 +81,8 @@ __global__ void k_interleave_rows(const float4* stage, float4* full, int W, int 
 }
 
 // one place for the last error: the context's string; a one-device context mirrors it into its member (idkptGetLastError reads the member there)
-static int gfail(idkpt_ctx* c, int code, const std::string& msg) { c->lastError = msg; if (c->n() == 1) c->dev[0]->lastError = msg; return code; }
+// (group-level errors reach the host's error callback here; a member's own error already did in fail(), so mfail only copies the message)
+static int gfail(idkpt_ctx* c, int code, const std::string& msg) { c->lastError = msg; if (c->n() == 1) c->dev[0]->lastError = msg; if (c->errFn) c->errFn(c->errUser, (int32_t)code, c->lastError.c_str()); return code; }
 static int mfail(idkpt_ctx* c, dev_ctx* m, int rc) { c->lastError = m->lastError; return rc; }
 #define GREQ(cond, msg) do { if (!(cond)) return gfail(c, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
 #define GHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return gfail(c, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
@@ -116,7 +118,8 @@ static void group_band_exchange(void* user, int32_t bounce, int32_t samples, int
     (void)bounce;
     GroupBandUser* u = (GroupBandUser*)user; idkpt_ctx* c = u->c; const int d = u->d, n = (int)c->n();
     c->bandCounts[d].assign(localCounts, localCounts + (size_t)samples * bands); c->bandLB[d] = bands;
-    if (!c->bar.wait()) return;                                            // everybody has posted
+    // (a member failed and aborted the barrier: this batch is reported as failed by group_flush; the bases are zeroed so that nothing reads what the buffer held)
+    if (!c->bar.wait()) { memset(outBases, 0, (size_t)samples * bands * sizeof(uint32_t)); return; }   // everybody has posted
     int total = 0; for (int r = 0; r < n; r++) total += c->bandLB[r];
     for (int k = 0; k < samples; k++) {
         uint32_t cum = 0;
@@ -369,6 +372,14 @@ int32_t idkptGetLastError(idkpt_ctx* c, const char** outMessage)
     if (!c || !outMessage) return IDKPT_ERR_INVALID_ARGUMENT;
     if (c->n() == 1) return dev_GetLastError(c->dev[0], outMessage);      // (gfail mirrors group-level messages into the member)
     *outMessage = c->lastError.c_str();
+    return IDKPT_OK;
+}
+
+int32_t idkptSetErrorCallback(idkpt_ctx* c, idkpt_error_fn fn, void* user)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    c->errFn = fn; c->errUser = user;
+    for (dev_ctx* m : c->dev) { m->errFn = fn; m->errUser = user; }
     return IDKPT_OK;
 }
 

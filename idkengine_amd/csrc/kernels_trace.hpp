@@ -272,7 +272,8 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
 // BVHIntersect.glsl:81-101 is a select — no nested exec-mask regions (15 branches and 20 instructions fewer per step than the
 // if/else form; +2.5 to +6 % on every view).  The stack pointer is the LDS address itself (pop = [sp], push = [sp + one row]: no index arithmetic).
 #define GRAB_SLICES 8u          // work-list counters of k_trace2 (power of two)
-#define GRAB_STRIDE 128u        // words between them (512 B: separate cache lines and memory channels)
+#define GRAB_STRIDE 256u        // words between them (1 KB: separate cache lines and memory channels).  Word j of a line: the launch of bounce j; word 64 + j: the exact re-trace
+                                // launch behind a wide-node launch (kernels_wide.hpp); words 128 + j of line 0: that launch's count of flagged rays
 // VER: scene versions (DScene::ver): every ray traverses the geometry its sample was queued with; a lane keeps where that version's node pairs / triangle
 // records (MULTI: also its TLAS and transforms) start, in 16-byte units, and adds it to every fetch.  Hit records stay version-independent.
 // ANY: TraceRayAny (BVHIntersect.glsl:107-181, 299-411) for idkptTraceRays' any-hit queries: inside a BLAS the left child is visited first whatever the distances, the first

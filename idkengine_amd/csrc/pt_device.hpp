@@ -220,7 +220,7 @@ DEV bool RayTriangleIntersect(f3 ro, f3 rd, f3 p0, f3 p1, f3 p2, float* by, floa
 // The x/y slabs go through 2-wide vectors so that the compiler emits v_pk_add_f32 / v_pk_mul_f32 (gfx950 packed FP32: two IEEE
 // operations per instruction, same roundings); the traversal kernel is VALU-issue bound, this takes 8 of ~65 instructions off a node step.
 typedef float v2f __attribute__((ext_vector_type(2)));
-DEV bool RayBoxIntersect(f3 o, f3 invDir, float4 bmin, float4 bmax, float* t1)
+DEV bool RayBoxIntersect(f3 o, f3 invDir, float4 bmin, float4 bmax, float* t1, float* t2Out = nullptr)
 {
     const v2f oxy = {o.x, o.y}, ixy = {invDir.x, invDir.y};
     const v2f lo2 = (v2f{bmin.x, bmin.y} - oxy) * ixy, hi2 = (v2f{bmax.x, bmax.y} - oxy) * ixy;
@@ -230,6 +230,7 @@ DEV bool RayBoxIntersect(f3 o, f3 invDir, float4 bmin, float4 bmax, float* t1)
     f3 tbg = mk3(gmax(t0s.x, t1s.x), gmax(t0s.y, t1s.y), gmax(t0s.z, t1s.z));
     *t1 = gmax(tsm.x, gmax(tsm.y, gmax(tsm.z, 0.0f)));
     float t2 = gmin(tbg.x, gmin(tbg.y, tbg.z));
+    if (t2Out) *t2Out = t2;
     return *t1 <= t2;
 }
 // :48-69

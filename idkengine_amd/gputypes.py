@@ -95,7 +95,8 @@ class Stats(C.Structure):
     _fields_ = [("RaysTraced", C.c_uint64), ("PrimaryRays", C.c_uint64), ("Frames", C.c_uint64),
                 ("LastAliveCounts", C.c_uint32 * 16), ("LastTraceMs", C.c_float), ("LastFrameMs", C.c_float),
                 ("NodePairVisits", C.c_uint64), ("TriangleTests", C.c_uint64),
-                ("TraceMsTotal", C.c_double), ("TraceLaunches", C.c_uint64)]
+                ("TraceMsTotal", C.c_double), ("TraceLaunches", C.c_uint64),
+                ("WideFlaggedRays", C.c_uint64), ("WideNodeVisits", C.c_uint64), ("WideLeafRecords", C.c_uint64), ("WideTriangleTests", C.c_uint64)]
 
 
 def _ptr(a):
@@ -163,7 +164,7 @@ class Scene:
 
 # enum idkpt_buffer (include/idkpt.h)
 (IDKPT_BUF_MESH_TRANSFORMS, IDKPT_BUF_VERTEX_POSITIONS, IDKPT_BUF_VERTICES, IDKPT_BUF_MESHES, IDKPT_BUF_MATERIALS, IDKPT_BUF_LIGHTS,
- IDKPT_BUF_BLAS_NODES, IDKPT_BUF_TLAS_NODES, IDKPT_BUF_JOINT_MATRICES) = range(9)
+ IDKPT_BUF_BLAS_NODES, IDKPT_BUF_TLAS_NODES, IDKPT_BUF_JOINT_MATRICES, IDKPT_BUF_WIDE_NODES, IDKPT_BUF_WIDE_LEAVES, IDKPT_BUF_WIDE_COUNTS) = range(12)
 
 
 # ray queries / RT shadows (include/idkpt.h: idkpt_ray, idkpt_hit, idkpt_shadow_params, enum idkpt_trace_flags)

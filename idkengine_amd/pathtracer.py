@@ -16,7 +16,7 @@ from ._lib import IdkPtError
 
 # idkptSetDeveloperOption names; IDKPT_<NAME> in the environment is forwarded when a PathTracer is created (test / tuning hooks only)
 _OPTION_NAMES = ("force_generic", "no_tile_cull", "no_lean_primary", "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves", "grid_hint", "grid_rays_x4", "grid_mid_waves", "defer_last", "split", "split_donor", "split_peek", "group_threads", "park", "quad", "query_scheduler", "split_scatter", "fused", "fused_shade_min", "spec", "instance_records", "leaf_pool", "pool_min", "adv_min",
-                 "node_layout", "treelet_depth", "trace_order", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
+                 "node_layout", "treelet_depth", "trace_order", "wide", "wide_cap", "wide_count", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
 
 
 class PathTracer:
@@ -60,6 +60,10 @@ class PathTracer:
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
+        err = getattr(self, "_callback_error", None)
+        if err is not None:            # an exchange callback raised while the library was inside a launch (ctypes cannot propagate it): re-raise here
+            self._callback_error = None
+            raise err
         if rc != 0:
             msg = C.c_char_p()
             self._L.idkptGetLastError(self._ctx, C.byref(msg))
@@ -244,51 +248,70 @@ class PathTracer:
         """idkptSetBounceExchange: fn(bounce, local_counts ndarray[samples]) -> bases ndarray[samples] (alive rays of the same sample
         held by the contexts that own earlier rows); None disables.  Needed for exact N-GPU == 1-GPU results beyond RayDepth 2."""
         import ctypes as C
+        old = getattr(self, "_xfn", None)   # the library launches what is queued before it swaps the pointer: the old trampoline must outlive the call
         if fn is None:
-            self._xfn = None
             self._check(self._L.idkptSetBounceExchange(self._ctx, None, None))
+            self._xfn = None; del old
             return
         proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 
         def tramp(user, bounce, n, counts, out):
-            b = fn(int(bounce), np.array([counts[i] for i in range(n)], np.uint32))
-            for i in range(n):
-                out[i] = int(b[i])
-        self._xfn = proto(tramp)       # keep the trampoline alive as long as the context uses it
-        self._check(self._L.idkptSetBounceExchange(self._ctx, self._xfn, None))
+            try:
+                b = fn(int(bounce), np.array([counts[i] for i in range(n)], np.uint32))
+                for i in range(n):
+                    out[i] = int(b[i])
+            except BaseException as e:     # ctypes would swallow it and leave `out` unfilled: zero the bases and re-raise from the next _check
+                for i in range(n):
+                    out[i] = 0
+                self._callback_error = e
+        new = proto(tramp)
+        self._check(self._L.idkptSetBounceExchange(self._ctx, new, None))
+        self._xfn = new; del old       # keep the trampoline alive as long as the context uses it
 
     def SetBandExchange(self, fn):
         """idkptSetBandExchange (interleaved rows / bands): fn(bounce, local_counts ndarray[samples, bands]) -> bases ndarray[samples, bands] = alive rays of the same
         sample, over ALL contexts, in the image bands before each of this context's bands; None disables.  Exact N-GPU == 1-GPU results at any RayDepth (sorting off)."""
         import ctypes as C
+        old = getattr(self, "_bxfn", None)   # (see SetBounceExchange: released only after the library has swapped the pointer)
         if fn is None:
-            self._bxfn = None
             self._check(self._L.idkptSetBandExchange(self._ctx, None, None))
+            self._bxfn = None; del old
             return
         proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 
         def tramp(user, bounce, samples, bands, counts, out):
             n = samples * bands
-            b = np.asarray(fn(int(bounce), np.ctypeslib.as_array(counts, shape=(n,)).astype(np.uint32).reshape(samples, bands)), np.uint32).reshape(-1)
-            for i in range(n):
-                out[i] = int(b[i])
-        self._bxfn = proto(tramp)      # keep the trampoline alive as long as the context uses it
-        self._check(self._L.idkptSetBandExchange(self._ctx, self._bxfn, None))
+            try:
+                b = np.asarray(fn(int(bounce), np.ctypeslib.as_array(counts, shape=(n,)).astype(np.uint32).reshape(samples, bands)), np.uint32).reshape(-1)
+                for i in range(n):
+                    out[i] = int(b[i])
+            except BaseException as e:
+                for i in range(n):
+                    out[i] = 0
+                self._callback_error = e
+        new = proto(tramp)
+        self._check(self._L.idkptSetBandExchange(self._ctx, new, None))
+        self._bxfn = new; del old      # keep the trampoline alive as long as the context uses it
 
     def SetBandExchangeDevice(self, fn):
         """idkptSetBandExchangeDevice: fn(bounce, samples, bands, d_counts_ptr, d_bases_ptr, hip_stream_ptr) ENQUEUES on that stream whatever fills the bases (device
         pointers to uint32[samples * bands]) and returns; no host synchronisation.  None disables."""
         import ctypes as C
+        old = getattr(self, "_bxdfn", None)
         if fn is None:
-            self._bxdfn = None
             self._check(self._L.idkptSetBandExchangeDevice(self._ctx, None, None))
+            self._bxdfn = None; del old
             return
         proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 
         def tramp(user, bounce, samples, bands, d_counts, d_bases, stream):
-            fn(int(bounce), int(samples), int(bands), int(d_counts or 0), int(d_bases or 0), int(stream or 0))
-        self._bxdfn = proto(tramp)     # keep the trampoline alive as long as the context uses it
-        self._check(self._L.idkptSetBandExchangeDevice(self._ctx, self._bxdfn, None))
+            try:
+                fn(int(bounce), int(samples), int(bands), int(d_counts or 0), int(d_bases or 0), int(stream or 0))
+            except BaseException as e:     # (nothing was enqueued: the bases of this bounce are whatever the buffer held; the error surfaces at the next _check)
+                self._callback_error = e
+        new = proto(tramp)
+        self._check(self._L.idkptSetBandExchangeDevice(self._ctx, new, None))
+        self._bxdfn = new; del old     # keep the trampoline alive as long as the context uses it
 
     def synchronize(self):
         self._check(self._L.idkptSynchronize(self._ctx))
@@ -331,7 +354,8 @@ class PathTracer:
         self._check(self._L.idkptGetStats(self._ctx, C.addressof(s)))
         return {"rays_traced": s.RaysTraced, "primary_rays": s.PrimaryRays, "frames": s.Frames, "alive_counts": list(s.LastAliveCounts),
                 "last_frame_ms": s.LastFrameMs, "node_pair_visits": s.NodePairVisits, "triangle_tests": s.TriangleTests,
-                "trace_ms_total": s.TraceMsTotal, "trace_launches": s.TraceLaunches}
+                "trace_ms_total": s.TraceMsTotal, "trace_launches": s.TraceLaunches,
+                "wide_flagged_rays": s.WideFlaggedRays, "wide_node_visits": s.WideNodeVisits, "wide_leaf_records": s.WideLeafRecords, "wide_triangle_tests": s.WideTriangleTests}
 
     def reset_stats(self):
         self._check(self._L.idkptResetStats(self._ctx))

@@ -48,6 +48,10 @@ enum idkpt_buffer {
     IDKPT_BUF_BLAS_NODES = 6,      /* SSBO 22 */
     IDKPT_BUF_TLAS_NODES = 7,      /* SSBO 27 */
     IDKPT_BUF_JOINT_MATRICES = 8,  /* SSBO 16 (3x4 row-major per joint, Skinning) */
+    /* idkptDownloadBuffer only — the traversal structure the library derives from the BLAS nodes (no reference counterpart; csrc/wide_nodes.hpp): */
+    IDKPT_BUF_WIDE_NODES = 9,      /* 64-byte wide nodes, BLAS b at 64 * (sum over earlier BLASes of NodeCount / 2 + 1) */
+    IDKPT_BUF_WIDE_LEAVES = 10,    /* leaf records, 16-byte units */
+    IDKPT_BUF_WIDE_COUNTS = 11,    /* per BLAS: uint32 wide nodes in use, uint32 16-byte units of leaf records in use */
 };
 
 /* One RGBA32F image of the texture table (stand-in for GL bindless textures; sampled at LOD 0 with
@@ -132,6 +136,10 @@ typedef struct idkpt_stats {
     uint64_t TriangleTests;
     double   TraceMsTotal;      /* sum of HIP-event durations of all traversal-kernel launches since idkptResetStats (timing enabled) */
     uint64_t TraceLaunches;     /* number of traversal-kernel launches in TraceMsTotal */
+    uint64_t WideFlaggedRays;   /* rays the wide-node walk did not vouch for and the exact BVH2 kernel traced again, since idkptResetStats (kernels_wide.hpp) */
+    uint64_t WideNodeVisits;    /* only with the developer option "wide_count": 64-byte wide nodes fetched ... */
+    uint64_t WideLeafRecords;   /* ... leaf records fetched (80 bytes: the BVH2 leaf node + its first triangle) ... */
+    uint64_t WideTriangleTests; /* ... triangle tests of the wide-node walk (every one beyond a record's first is another 48-byte fetch) */
 } idkpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -160,13 +168,21 @@ IDKPT_API int32_t idkptGetContextDeviceCount(idkpt_ctx* ctx, int32_t* outCount);
  *   IDKPT_SHARD_AUTO    (default) = BANDS (ROWS when the image has fewer bands than devices) at every RayDepth.  (Rounds 2-3 switched to STRIPS beyond RayDepth 2, the
  *                       exchange that needs no host synchronisation; but strips balance badly on views with empty rows — BASELINE configs[3] dealt over 8 GPUs projects
  *                       6.0x with bands against 3.8x with strips — and since round 4 the interleaved deals are exact at any depth as well.)  A change of layout
- *                       restarts the accumulation (like idkptSetSize). */
+ *                       restarts the accumulation (like idkptSetSize).
+ *   With DoRaySorting ON beyond RayDepth 2 no layout is bit-identical to one device (the sorted slot of a ray depends on every other ray of the frame; the exchange
+ *   is skipped from the second bounce on): the N-device image is then another legal execution of the reference's own nondeterministic schedule, equal in distribution only. */
 enum idkpt_group_sharding { IDKPT_SHARD_AUTO = 0, IDKPT_SHARD_ROWS = 1, IDKPT_SHARD_STRIPS = 2, IDKPT_SHARD_BANDS = 3 };
 IDKPT_API int32_t idkptSetGroupSharding(idkpt_ctx* ctx, int32_t mode);
 /* PathTracer.Dispose (PathTracer.cs:344-365) */
 IDKPT_API int32_t idkptDestroy(idkpt_ctx* ctx);
 /* OIDN.GetDeviceError style (OIDN/OIDN.cs:108-112): pointer stays valid until the next call on ctx */
 IDKPT_API int32_t idkptGetLastError(idkpt_ctx* ctx, const char** outMessage);
+/* OIDN.SetDeviceErrorFunction style (OIDN/OIDN.cs:108-109; the engine's own debug-callback habit, Render/.../PathTracerPipeline.cs:237-243): optional.  `fn` is called
+ * with the status code and the message idkptGetLastError would return, at the moment an entry point fails and before it returns that status — on the calling thread,
+ * or, for an error inside one member of a multi-device context whose batches are enqueued by one host thread per device, on that thread.  `message` is only valid
+ * during the call.  NULL removes the callback.  The callback must not call back into the library with the same context. */
+typedef void (*idkpt_error_fn)(void* user, int32_t status, const char* message);
+IDKPT_API int32_t idkptSetErrorCallback(idkpt_ctx* ctx, idkpt_error_fn fn, void* user);
 /* Library/device probe usable before Create (NativeLibrary.TryLoad pattern, OIDN/OIDN.cs:11-20) */
 IDKPT_API int32_t idkptGetDeviceCount(int32_t* outCount);
 IDKPT_API const char* idkptGetVersionString(void);

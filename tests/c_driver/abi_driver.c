@@ -28,6 +28,14 @@ static void* load(const char* dir, const char* name, size_t* bytes)
     return p;
 }
 
+struct cb_state { int calls; int32_t status; char message[512]; };
+static void on_error(void* user, int32_t status, const char* message)
+{
+    struct cb_state* s = (struct cb_state*)user;
+    s->calls++; s->status = status;
+    strncpy(s->message, message ? message : "", sizeof s->message - 1);
+}
+
 #define CHECK(call) do { int32_t rc_ = (call); if (rc_ != IDKPT_OK) { const char* m_ = ""; idkptGetLastError(ctx, &m_); \
     fprintf(stderr, "%s failed: %d (%s)\n", #call, (int)rc_, m_ ? m_ : ""); return 3; } } while (0)
 
@@ -84,6 +92,15 @@ int main(int argc, char** argv)
     if (idkptSetSize(ctx, -1, 5) == IDKPT_OK) { fprintf(stderr, "expected an error for a negative size\n"); return 5; }
     const char* msg = NULL; idkptGetLastError(ctx, &msg);
     if (!msg || !msg[0]) { fprintf(stderr, "expected a last-error message\n"); return 5; }
+    /* the optional error callback (oidnSetDeviceErrorFunction's pattern): same status, same message, before the failing call returns */
+    struct cb_state cb = {0, 0, {0}};
+    CHECK(idkptSetErrorCallback(ctx, on_error, &cb));
+    const int32_t rcBad = idkptSetSize(ctx, 7, -3);
+    if (rcBad == IDKPT_OK || cb.calls != 1 || cb.status != rcBad) { fprintf(stderr, "error callback: calls %d status %d (call returned %d)\n", cb.calls, cb.status, rcBad); return 6; }
+    idkptGetLastError(ctx, &msg);
+    if (!msg || strcmp(msg, cb.message) != 0) { fprintf(stderr, "error callback message differs from idkptGetLastError\n"); return 6; }
+    CHECK(idkptSetErrorCallback(ctx, NULL, NULL));
+    if (idkptSetSize(ctx, 7, -3) == IDKPT_OK || cb.calls != 1) { fprintf(stderr, "removed error callback was still called\n"); return 6; }
 
     char path[1024];
     snprintf(path, sizeof path, "%s/result.bin", dir);

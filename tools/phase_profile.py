@@ -27,7 +27,7 @@ if __name__ == "__main__":
         sys.exit("set IDKPT_LIB_PATH to idkengine_amd/libidkpt_dev.so (python -c 'from idkengine_amd import build as B; B.build_hip(developer=True)')")
     for view in ("headline", "interior", "atrium"):
         for batch in (32, 1):
-            p = subprocess.run([sys.executable, "-c", CHILD, view, str(batch)], capture_output=True, text=True, timeout=600)
+            p = subprocess.run([sys.executable, "-c", CHILD, view, str(batch)], capture_output=True, text=True, timeout=600)   # (PHASE_VARIANT=213 in the environment: the wide-node walk's instrumented instantiation)
             prof = [l for l in p.stderr.splitlines() if l.startswith("[idkpt prof]")]
             res = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
             if not prof:
