@@ -82,7 +82,10 @@ struct DevOptions {
     int splitPeek = 64;          // k_trace2s: iterations between two looks at the work-list heads (a wave with < 32 idle lanes never refills, so it has to ask whether the list is empty).  Measured: 64 -> 16 -> 8 -> 2 = 2 147 -> 1 750 -> 1 743 -> 1 697 Mray/s on the headline view one frame at a time: splitting EARLY multiplies pieces (and their bookkeeping) while most lanes still have rays of their own; it pays in the real tail only
     int splitDonor = 1;          // k_trace2s: 1 = only rays that have not hit anything yet donate subtrees, 0 = every busy lane does
     int split = 1;               // k_trace2s (long rays split across the idle lanes of their wave once the work list is empty): 0 = never, 1 = small launches of sparse views (default, want_split), 2 = every launch, 3 = every launch + every split ray traced again (test hook for the re-trace path)
-    int wide = 1;                // k_trace_wide (kernels_wide.hpp): closest-hit launches of one-BLAS scenes walk the derived 4-wide nodes; rays it cannot vouch for are re-traced by k_trace2.  0 = k_trace2 only
+    int wide = 0;                // k_trace_wide (kernels_wide.hpp): closest-hit launches of one-BLAS scenes walk the derived 4-wide nodes; rays it cannot vouch for are re-traced by k_trace2.
+                                 // 0 (default) = k_trace2 only.  Measured in round 5 (profiles/r05_wide_nodes.md): 0.57x the dependent round trips, 0.61x the vector-memory requests, half the
+                                 // memory-wait cycles — and 1.34x the VALU instructions, with the SIMDs' VALU issue already 80 % busy under k_trace2: 0.93-1.00x with 32 samples in flight,
+                                 // 0.5-0.8x one frame at a time (the re-trace launch has its own latency floor).  Bit-identical results either way (tests/test_gpu_wide.py).
     int wideCap = 0;             // ... rows of its per-lane stack (0: 24; a ray that needs more is re-traced by k_trace2)
     int wideCount = 0;           // ... count node visits / leaf records / triangle tests (idkpt_stats.Wide*)
     int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)

@@ -112,8 +112,8 @@ def test_wide_walk_equals_oracle(name, mk_scene, mk_cam, w, h, ov, oracle_mod, n
     o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
     aov = bool(ov.get("OutputAOVs"))
     stats = {}
-    for label, env in (("default", {}), ("off", {"IDKPT_WIDE": "0"}), ("short_stack", {"IDKPT_WIDE_CAP": "4"}), ("one_wave_per_cu", {"IDKPT_TRACE_WAVES": "1", "IDKPT_LEAF_MIN": "1"}),
-                       ("odd_hand_out", {"IDKPT_GRAB_UNIT_LOG2": "6", "IDKPT_GRAB_FIXED": "100", "IDKPT_LEAF_MIN": "64"})):
+    for label, env in (("default", {"IDKPT_WIDE": "1"}), ("off", {"IDKPT_WIDE": "0"}), ("short_stack", {"IDKPT_WIDE": "1", "IDKPT_WIDE_CAP": "4"}), ("one_wave_per_cu", {"IDKPT_WIDE": "1", "IDKPT_TRACE_WAVES": "1", "IDKPT_LEAF_MIN": "1"}),
+                       ("odd_hand_out", {"IDKPT_WIDE": "1", "IDKPT_GRAB_UNIT_LOG2": "6", "IDKPT_GRAB_FIXED": "100", "IDKPT_LEAF_MIN": "64"})):
         pt = _env(env, lambda: gpu_render(sc, cam, w, h, counters=False, **ov))
         _env(env, lambda: assert_equal(pt, o, aov=aov, counters=False))
         stats[label] = pt.stats()
@@ -138,13 +138,14 @@ def test_wide_walk_batched_samples_lights_and_counts(oracle_mod, native_builder)
     w = h = 128; cam = S.cornell_camera(w, h)
     for extra in (dict(), dict(DoRaySorting=1)):
         ov = dict(RayDepth=5, DoTraceLights=1, **extra)
-        pt = gpu_render(sc, cam, w, h, counters=False, **ov); o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+        pt = _env({"IDKPT_WIDE": "1"}, lambda: gpu_render(sc, cam, w, h, counters=False, **ov)); o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
         assert_equal(pt, o, counters=False)
+        assert pt.stats()["wide_flagged_rays"] >= 0
         pt.Dispose(); o.close()
     sc = S.soup_scene(20000, native_builder, seed=9); w, h = 250, 130
     cam = S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(-0.3, 0.2, -1.0))
     o = oracle_render(oracle_mod, sc, cam, w, h, frames=5, RayDepth=3)
-    pt = PathTracer(w, h); pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = 3; pt.set_max_batch(5); pt.set_option("wide_count", 1)
+    pt = PathTracer(w, h); pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = 3; pt.set_max_batch(5); pt.set_option("wide", 1); pt.set_option("wide_count", 1)
     for _ in range(5):
         pt.Compute()
     assert (bits(pt.Result) == bits(o.image(0))).all() and pt.rays().tobytes() == o.rays().tobytes() and (pt.alive_queue() == o.alive_queue()).all()
@@ -158,7 +159,7 @@ def test_wide_walk_batched_samples_lights_and_counts(oracle_mod, native_builder)
 def test_wide_nodes_follow_refit_and_node_patches(oracle_mod, oracle_builder, native_builder, host_build):
     """k_wide_fill after a refit (boxes and positions moved, topology kept), k_wide_topo after a node patch (idkptUpdateBuffer on the BLAS nodes)."""
     sc = S.soup_scene(20000, native_builder, seed=12, refittable=True); w, h = 320, 180; cam = S.Camera(w, h, position=(0.0, 0.0, 4.0))
-    pt = gpu_render(sc, cam, w, h, counters=False, RayDepth=3)
+    pt = _env({"IDKPT_WIDE": "1"}, lambda: gpu_render(sc, cam, w, h, counters=False, RayDepth=3))
     o = oracle_render(oracle_mod, sc, cam, w, h, RayDepth=3)
     assert (bits(pt.Result) == bits(o.image())).all(); o.close()
     rng = np.random.default_rng(3)

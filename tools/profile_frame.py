@@ -6,9 +6,11 @@ from idkengine_amd import scenes as S
 from idkengine_amd.pathtracer import PathTracer
 
 def get_scene(n):
-    from oracle import oracle as O   # dev tool only
+    from idkengine_amd.bvh import NativeBuilder
     parts = int(os.environ.get("PARTS", "1"))
-    return S.soup_scene(n, O.OracleBuilder()) if parts == 1 else S.soup_scene_multi(n, O.OracleBuilder(), parts)
+    if os.environ.get("VIEW") == "atrium":
+        return S.atrium_scene(n, NativeBuilder())
+    return S.soup_scene(n, NativeBuilder()) if parts == 1 else S.soup_scene_multi(n, NativeBuilder(), parts)
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
@@ -17,14 +19,19 @@ if __name__ == "__main__":
     batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     sc = get_scene(n)
     pt = PathTracer(1920, 1080)
-    pt.UploadScene(sc); pt.SetCamera(S.Camera(1920, 1080)); pt.RayDepth = depth; pt.DoRaySorting = int(os.environ.get('SORT', '0')); pt.set_max_batch(batch)
-    for _ in range(3):
-        pt.ResetAccumulation(); pt.Compute()
+    view = os.environ.get("VIEW", "headline")   # headline | interior | atrium
+    cam = S.atrium_camera(1920, 1080) if view == "atrium" else (S.Camera(1920, 1080, position=(0.0, 0.0, 0.0)) if view == "interior" else S.Camera(1920, 1080))
+    pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = depth; pt.DoRaySorting = int(os.environ.get('SORT', '0')); pt.set_max_batch(batch)
+    reset = batch == 1                          # one frame at a time: Reset -> Compute (-> flush); batches: consecutive samples of one accumulation
+    for _ in range(max(3, batch)):
+        if reset: pt.ResetAccumulation()
+        pt.Compute()
     pt.synchronize(); pt.reset_stats()
     t0 = time.time()
     for _ in range(frames):
-        pt.ResetAccumulation(); pt.Compute()
+        if reset: pt.ResetAccumulation()
+        pt.Compute()
     pt.synchronize()
     dt = (time.time() - t0) / frames
     st = pt.stats()
-    print("ms/frame", dt * 1e3, "Mray/s", st["rays_traced"] / frames / dt / 1e6, st["alive_counts"][:depth + 1])
+    print("ms/frame", dt * 1e3, "Mray/s", st["rays_traced"] / frames / dt / 1e6, st["alive_counts"][:depth + 1], "flagged/frame", st["wide_flagged_rays"] / frames)
