@@ -1,0 +1,157 @@
+// host_context.hpp — buffers, options and state of one device's context (dev_ctx); error plumbing.
+// Part of the single translation unit idkpt.hip (included there, in this order).
+#pragma once
+
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n) { if (n <= bytes && p) return hipSuccess; if (p) (void)hipFree(p); p = nullptr; bytes = 0; if (n == 0) return hipSuccess; hipError_t e = hipMalloc(&p, n); if (e == hipSuccess) bytes = n; return e; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// Tuning / test options (idkptSetDeveloperOption; none is part of the reference's interface and results are bit-identical under all of them:
+// tests/test_gpu_worklist.py, test_gpu_layout.py).  The library itself never reads the environment; the Python host mirror forwards IDKPT_<NAME>.
+struct DevOptions {
+    int forceGeneric = 0;        // thread-per-ray kernels instead of k_trace2 (the cross-check of the tests)
+    int noTileCull = 0;          // per-pixel root-box cull only
+    int noLeanPrimary = 0;       // k_gen_primary stores the full ray state of surviving rays
+    int leafMin = 0;             // k_trace2: lanes parked on a leaf before the node phase is left (0: 16 for batches of >= 4 samples, 12 below)
+    int grabUnitLog2 = 10, grabFixed = 0;   // work-list hand-out: run length of a slice, entries reserved per atomic (0: what the refill needs)
+    int ldsPad = 0;              // bytes of LDS added per workgroup of k_trace2 (caps the resident waves)
+    int traceWaves = 0;          // one-wave workgroups per CU in the persistent grid (0: what LDS allows, at most 32)
+    int gridHint = 2;            // bounce launches: grid = gridHint x the queue length the same bounce had in the previous batch (0: full grid)
+    int deferLast = 1;           // the last bounce's continuation (state, queue) on demand instead of every frame, where only radiance of it is visible (kernels_shade.hpp k_shade_last)
+    int graphProbe = 0;          // developer build only: capture the next batch into a hipGraph and time this many replays (tools/graph_probe.py)
+    int gridMidWaves = 20;       // launches below GRID_MID_RAYS rays: one-wave workgroups per CU (0: off) — see small_launch_grid
+    int gridRaysX4 = 6;          // small launches: quarter-rays per lane the persistent grid is sized for (from the previous batch's counts; 0: gridHint's rule alone)
+    int traceVariant = 0;        // IDKPT_DEVELOPER builds only: instrumented / probe instantiations of k_trace2
+    int bvhTiming = 0, bvhSmall = 32;   // idkptBuildBlasCore: phase times on stderr; subtrees of at most this many fragments are finished by one thread
+    int advMin = 0;              // k_trace2 MODE 1-4: instance entries / TLAS steps are taken by at least this many lanes together (or when no other lane has work); 0 = 8 for batches of >= 4 samples, 1 below (measured, 3-BLAS soup-1M: 1 / 8 / 16 / 24 / 32 = 3 365 / 3 408 / 3 226 / 2 925 / 2 568 Mray/s through the instance loop, 2 671 / 2 771 / 2 671 / 2 466 / 2 180 through the TLAS; one frame at a time 8 costs 1-6 %)
+    int poolMin = 12;            // pooled leaf phase: pairs a wave must have parked (below: every lane walks its own triangles as before; 0-20 measure the same, 32+ lose the gain)
+    int leafPool = -1;           // k_trace2<.., DBG = 16> (MODE 0): the leaf phase tests the wave's pooled (ray, triangle) pairs with all lanes in one round trip (kernels_trace.hpp).
+                                 // Mask of launch kinds: 1 = primary launches, 2 = the first bounce, 4 = later bounces.  -1 (default) = by measurement (profiles/r04_leaf_pool.md): later
+                                 // bounces always lose (few pairs per phase: -4 %), the first bounce gains 3-5 % where most pixels traverse the scene and loses 1 % on sparse views,
+                                 // the primary launch gains 4 % on sparse views and nothing elsewhere -> 1 on sparse views (fewer than half of the pixels enter the traversal), 3 otherwise
+    int splitScatter = 6;        // k_trace2s: log2 of the entries that stay together when the work list is handed out scattered (6 = list order)
+    int queryScheduler = 1;      // idkptTraceRays (closest hit) through k_trace2's scheduler instead of the thread-per-ray kernel (kernels_query.hpp)
+    int groupThreads = -1;       // multi-device contexts (idkpt_api.hpp group_flush): members' batches enqueued by one host thread each also where no exchange needs it (-1: from 4 members on)
+    int fused = 1;               // k_trace_fused (kernels_trace_fused.hpp): FirstHit + shading + the last NHit's traversal in one persistent launch at RayDepth 2.  0 off, 1 small launches on sparse views (want_fused), 2 wherever it is exact
+    int fusedShadeMin = 16;      // ... lanes that wait for the shading phase before it runs (or as many as are still tracing)
+    int splitPeek = 64;          // k_trace2s: iterations between two looks at the work-list heads (a wave with < 32 idle lanes never refills, so it has to ask whether the list is empty).  Measured: 64 -> 16 -> 8 -> 2 = 2 147 -> 1 750 -> 1 743 -> 1 697 Mray/s on the headline view one frame at a time: splitting EARLY multiplies pieces (and their bookkeeping) while most lanes still have rays of their own; it pays in the real tail only
+    int splitDonor = 1;          // k_trace2s: 1 = only rays that have not hit anything yet donate subtrees, 0 = every busy lane does
+    int split = 1;               // k_trace2s (long rays split across the idle lanes of their wave once the work list is empty): 0 = never, 1 = small launches of sparse views (default, want_split), 2 = every launch, 3 = every launch + every split ray traced again (test hook for the re-trace path)
+    int wide = 0;                // k_trace_wide (kernels_wide.hpp): closest-hit launches of one-BLAS scenes walk the derived 4-wide nodes; rays it cannot vouch for are re-traced by k_trace2.
+                                 // 0 (default) = k_trace2 only.  Measured in round 5 (profiles/r05_wide_nodes.md): 0.57x the dependent round trips, 0.61x the vector-memory requests, half the
+                                 // memory-wait cycles — and 1.34x the VALU instructions, with the SIMDs' VALU issue already 80 % busy under k_trace2: 0.93-1.00x with 32 samples in flight,
+                                 // 0.5-0.8x one frame at a time (the re-trace launch has its own latency floor).  Bit-identical results either way (tests/test_gpu_wide.py).
+    int wideCap = 0;             // ... rows of its per-lane stack (0: 24; a ray that needs more is re-traced by k_trace2)
+    int wideCount = 0;           // ... count node visits / leaf records / triangle tests (idkpt_stats.Wide*)
+    int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
+};
+
+// Scene versions (idkptSetSceneVersions): the buffers the render kernels read of the geometry an animated frame rewrites.  Each may hold several states
+// ("slots" of one arena); a queued sample remembers the slots that were current when it was queued (PendingSample::vs), so frames with different geometry can
+// be traced by one batch while later updates already write other slots (ver_writable).
+enum { VB_NODES = 0, VB_TRIVERTS, VB_VERTICES, VB_TLAS, VB_XFORMS, VB_COUNT };
+struct PendingSample { uint32_t accum; int slot; float cam[36]; uint8_t vs[VB_COUNT]; };   // cam = invProj[16] invView[16] viewPos[3] pad; vs = scene-version slots
+
+struct dev_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr; bool ownStream = true;
+    std::string lastError;
+    idkpt_error_fn errFn = nullptr; void* errUser = nullptr;   // idkptSetErrorCallback
+    int numCUs = 256;
+    // config
+    idkpt_settings st;          // effective settings
+    idkpt_settings stCaller;    // the struct the host passed last (idkptSetSettings compares against this one)
+    int W = 0, H = 0, rowMod = 1, rowRem = 0, rows = 0, rowBandLog2 = 0;   // rows dealt in bands of 2^rowBandLog2 rows (idkptSetRowBands)
+    float invProj[16], invView[16], viewPos[3];
+    // frame ring (idkptSetFrameRing): ringSize result-image sets; every queued sample remembers its slot, its camera and its
+    // AccumulatedSamples index, so several frames (different cameras) can be in flight in one batch
+    int ringSize = 1, curSlot = 0; bool ringStarted = false; std::vector<uint32_t> accum = std::vector<uint32_t>(1, 0u);
+    bool counters = false, timing = false, capturePrimary = false;
+    DevOptions opt;
+    uint32_t seqFirst = 0, seqStride = 1;                         // idkptSetSampleSequence
+    // scene
+    bool haveScene = false, frameOk = false;
+    DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, queryRec, queryList, tileClass, gbases;   // (+ camTab below)
+    std::vector<DevBuf> texData; std::vector<std::pair<int, int>> texDims;
+    std::vector<GpuBlasDesc> hDescs;
+    std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
+    std::vector<uint32_t> levelBase;                 // per BLAS base into levelNodes
+    std::vector<char> refitCoversAll;                // per BLAS: leaves + internal nodes of the refit schedule are every node but node 0 (a refit into a fresh slot needs no copy of the old nodes)
+    int nodeCount = 0, triCount = 0, instanceCount = 0, tlasCount = 0, vertexCount = 0, meshCount = 0, materialCount = 0, xformCount = 0, lightCount = 0, skySize = 0, textureCount = 0, unskinnedCount = 0;
+    int sceneStack = 1;
+    int hInst0Blas = 0;                              // BlasId of instance 0 (MODE 0 traverses that BLAS)
+    // wide nodes (kernels_wide.hpp): derived per BLAS from nodes + triVerts.  wideTopoValid: the children lists match the node topology; wideFillValid: boxes / leaf records match the current boxes and positions
+    DevBuf wnodes, wleaf, wids, wpair, wcounts, wtotals; std::vector<uint32_t> wNodeOff, wLeafOff; bool wideTopoValid = false, wideFillValid = false;
+    // scene versions: slot count a versioned buffer may grow to, per buffer the bytes of one state / the slot pitch / the slots its arena holds / the current slot
+    int verSlots = 1; size_t vbytes[VB_COUNT] = {0}, vstride[VB_COUNT] = {0}; int valloc[VB_COUNT] = {1, 1, 1, 1, 1}, vcur[VB_COUNT] = {0};
+    uint64_t lastMask[VB_COUNT] = {0};               // slots the last launched batch reads (a deferred last bounce still does: finish_deferred)
+    uint8_t lastSlots[VB_COUNT] = {0}; bool lastMulti = false;   // ... the one set of slots of a single-version batch, or "per sample: verTab"
+    DevBuf verTab; uint32_t* hVerTab = nullptr; hipEvent_t evVer[2] = {nullptr, nullptr}; int verHalf = 0;   // per-sample version table of the batch being launched (pinned, double-buffered staging)
+    char* hStage = nullptr; hipEvent_t evStage[4] = {nullptr, nullptr, nullptr, nullptr}; int stageNext = 0;   // pinned ring for small host -> device updates (joint matrices, transforms): no stream synchronisation per call
+    int (*groupFlushAll)(void* user) = nullptr;      // member of a multi-device context: launches what ALL members have queued (a member never flushes on its own)
+    // wavefront state
+    DevBuf trRec, contFlag, blockSums, rayO, rayT, rayR, aovA, aovN, hit, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, contMask, waveCounts, counts, work, sortHist, counters64;
+    DevBuf img[3];
+    DevBuf camTab;                                       // per-sample cameras of the batch being launched (ring mode)
+    int rowLimit = 0x7fffffff;                           // idkptSetRowRange: at most this many local rows
+    idkpt_bounce_exchange_fn exchangeFn = nullptr; void* exchangeUser = nullptr;   // exact multi-GPU deep paths (idkptSetBounceExchange)
+    idkpt_band_exchange_fn bandExchangeFn = nullptr; void* bandExchangeUser = nullptr; DevBuf bandTab;
+    idkpt_band_exchange_device_fn bandExchangeDevFn = nullptr; void* bandExchangeDevUser = nullptr;   // ... enqueued on the stream, no host synchronisation (idkptSetBandExchangeDevice)   // ... for interleaved rows / bands (idkptSetBandExchange)
+    // stats
+    idkpt_stats stats;
+    uint32_t* hCounts = nullptr; uint32_t* dCountsMirror = nullptr;   // host-mapped mirror of the queue lengths (written by k_scan_blocks, read by the host after a sync)
+    bool sceneNested = false;       // every child box of every BLAS lies inside its parent's box (what k_trace2s's exactness argument needs; refits keep it)
+    bool sceneNoEmission = false;   // no material / mesh of the uploaded scene emits and every texel is finite: a hit of the last bounce cannot change the radiance (k_shade_last)
+    struct { bool valid = false, allHits = false; int j = 0, side = 0, B = 0; uint32_t total = 0, Npad = 0; } defer;   // the last bounce of the last batch still owes its continuation (finish_deferred)
+    DevBuf radSave, deferCount;
+    bool countersDirty = true;   // the batch counters were not reset by the last k_final_draw (first batch, or a batch that failed half way)
+    uint32_t* hOverflow = nullptr; uint32_t* dOverflow = nullptr;   // host-mapped word the kernels set when a traversal-stack push is dropped (checked after every sync)
+    int tlasNeed = 1;            // rows the TLAS walk needs (validated for host-built TLAS nodes; min(instances, TLAS_STACK_SIZE) for a device build)
+    hipEvent_t evFrame[2] = {nullptr, nullptr};
+    // trace-kernel timing (idkptEnableTiming): one event pair per trace launch, resolved lazily in idkptGetStats
+    std::vector<hipEvent_t> evPool; size_t evUsed = 0;
+    double traceMsAcc = 0.0; uint64_t traceLaunchesAcc = 0;
+    int lastQueueSide = 0; int lastQueueCountSlot = 0; bool lastFast = false, lastNeedsRegen = false; int lastBatch = 1; Frame lastFrame;
+    int maxBatch = 1; uint32_t Npad = 0; std::vector<PendingSample> pending; DevBuf bases, qwork; uint32_t* hBases = nullptr; uint32_t* dBasesMirror = nullptr;
+    float* hCams = nullptr; hipEvent_t evCams[2] = {nullptr, nullptr}; int camHalf = 0;   // pinned, double-buffered staging of the per-sample cameras (frame ring)    // member of a multi-device context (idkpt_api.hpp): samples are only queued (the group launches all members together), per-bounce events tell
+    // the members that own later rows when this member's alive counts of a bounce are final, and the group supplies the slot bases
+    bool grouped = false, inGroupFlush = false; int groupIndex = 0;
+    hipEvent_t* evBounce = nullptr;                              // [MAX_DEPTH_SLOTS]; evBounce[j] = bases[j] (alive counts entering bounce j) written
+    int (*groupExchange)(void* user, dev_ctx* member, int bounce, int samples, const uint32_t** outBases) = nullptr; void* groupUser = nullptr;
+    struct BuilderScratch* bscratch = nullptr;                    // device buffers of idkptBuildBlas / idkptBuildBlasCore, kept between calls (grow only)
+    struct PeerPolicy* peer = nullptr;                           // multi-device contexts: how device-to-device copies are made (member_copy)
+};
+
+static hipEvent_t next_event(dev_ctx* ctx)
+{
+    if (ctx->evUsed == ctx->evPool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ctx->evPool.push_back(e); }
+    return ctx->evPool[ctx->evUsed++];
+}
+// folds all recorded (start, stop) pairs into the accumulators; requires the stream to be idle
+static void resolve_trace_events(dev_ctx* ctx)
+{
+    for (size_t i = 0; i + 1 < ctx->evUsed; i += 2) { float ms = 0.0f; if (hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]) == hipSuccess) { ctx->traceMsAcc += ms; ctx->traceLaunchesAcc++; } }
+    ctx->evUsed = 0;
+}
+#define TRACE_T0() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
+#define TRACE_T1() do { if (ctx->timing) { hipEvent_t _e = next_event(ctx); if (_e) (void)hipEventRecord(_e, st); } } while (0)
+
+// every failing entry point ends here: the message is kept for idkptGetLastError and handed to the host's error callback (idkptSetErrorCallback; oidnSetDeviceErrorFunction's
+// pattern, Source/OIDN/OIDN.cs:108-109) on the thread that detected the error
+static int fail(dev_ctx* c, int code, const std::string& msg) { if (c) { c->lastError = msg; if (c->errFn) c->errFn(c->errUser, (int32_t)code, c->lastError.c_str()); } return code; }
+// (a failed runtime call leaves its code in the thread's last-error slot: reset it, or the next hipGetLastError() check would report it again)
+#define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+#define REQUIRE(cond, msg) do { if (!(cond)) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
+
+// rows y of the image with (y >> bandLog2) % mod == rem (bandLog2 = 0: y % mod == rem; mod = 1: the rows from rem on)
+static int local_rows(int H, int mod, int rem, int bandLog2 = 0)
+{
+    if (bandLog2 == 0) { int n = 0; for (int y = rem; y < H; y += mod) n++; return n; }
+    int n = 0; const int band = 1 << bandLog2;
+    for (int b = rem; (b << bandLog2) < H; b += mod) n += std::min(band, H - (b << bandLog2));
+    return n;
+}

@@ -1,0 +1,140 @@
+// host_launch.hpp — derivation of the wide nodes and the one place that picks a traversal kernel for a launch (launch_trace2).
+// Part of the single translation unit idkpt.hip (included there, in this order).
+#pragma once
+
+// ---- wide nodes (kernels_wide.hpp): which launches use them, and their derivation on the device ----------------------------------------------------------------
+// One-BLAS scenes, closest hit, the reference's counters not asked for, one scene version: everything else keeps k_trace2.
+static bool wide_wanted(const dev_ctx* ctx) { return ctx->opt.wide != 0 && ctx->instanceCount == 1 && !ctx->st.UseTlas && ctx->verSlots == 1 && !ctx->counters && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100 || ctx->opt.traceVariant == 213); }
+static int wide_stack_rows(const dev_ctx* ctx) { return std::min(96, std::max(4, ctx->opt.wideCap > 0 ? ctx->opt.wideCap : 24)); }
+// (re-)derives what is stale: the children lists after an upload / a node patch (k_wide_topo, one workgroup per BLAS), box bytes and leaf records after anything that
+// moved boxes or positions (k_wide_fill).  Stream-ordered in front of the batch that is about to be launched; with one scene version every update launches the queued samples first.
+static char* vb_ptr(dev_ctx* ctx, int b, int slot);
+static int wide_prepare(dev_ctx* ctx)
+{
+    if (ctx->wideTopoValid && ctx->wideFillValid) return IDKPT_OK;
+    if (!ctx->wtotals.p) { HIPC(ctx->wtotals.ensure(64)); HIPC(hipMemsetAsync(ctx->wtotals.p, 0, 64, ctx->stream)); }
+    const size_t nb = ctx->hDescs.size();
+    hipStream_t st = ctx->stream;
+    const float4* nodes = (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]);
+    const float4* triVerts = (const float4*)vb_ptr(ctx, VB_TRIVERTS, ctx->vcur[VB_TRIVERTS]);
+    if (!ctx->wideTopoValid) {
+        ctx->wNodeOff.assign(nb + 1, 0u); ctx->wLeafOff.assign(nb + 1, 0u);
+        for (size_t b = 0; b < nb; b++) {
+            const GpuBlasDesc& d = ctx->hDescs[b];
+            const uint32_t pairs = (uint32_t)std::max(0, d.NodeCount) / 2u + 1u, leavesMax = pairs + 1u;                       // a wide node stands for at least one pair; a tree of L leaves has L - 1 internal nodes
+            ctx->wNodeOff[b + 1] = ctx->wNodeOff[b] + pairs;
+            ctx->wLeafOff[b + 1] = ctx->wLeafOff[b] + 5u * leavesMax + 3u * (uint32_t)std::max(0, d.TriangleCount) + 4u;   // 2 + 3 per leaf-range triangle (a leaf pair may share one triangle)
+        }
+        HIPC(ctx->wnodes.ensure((size_t)ctx->wNodeOff[nb] * 64 + 64)); HIPC(ctx->wids.ensure((size_t)ctx->wNodeOff[nb] * 16 + 16)); HIPC(ctx->wpair.ensure((size_t)ctx->wNodeOff[nb] * 4 + 16));
+        HIPC(ctx->wleaf.ensure((size_t)ctx->wLeafOff[nb] * 16 + 80)); HIPC(ctx->wcounts.ensure(nb * 8 + 8));
+        for (size_t b = 0; b < nb; b++) {
+            const GpuBlasDesc& d = ctx->hDescs[b];
+            hipLaunchKernelGGL(k_wide_topo, dim3(1), dim3(WIDE_TOPO_THREADS), 0, st, nodes + 2 * (size_t)d.NodeOffset, (uint32_t)d.NodeCount, ctx->wpair.as<uint32_t>() + ctx->wNodeOff[b],
+                               ctx->wids.as<uint4>() + ctx->wNodeOff[b], ctx->wnodes.as<uint4>() + 4 * (size_t)ctx->wNodeOff[b], ctx->wcounts.as<uint32_t>() + 2 * b);
+        }
+        HIPC(hipGetLastError());
+        ctx->wideTopoValid = true; ctx->wideFillValid = false;
+    }
+    for (size_t b = 0; b < nb; b++) {
+        const GpuBlasDesc& d = ctx->hDescs[b];
+        const uint32_t pairs = ctx->wNodeOff[b + 1] - ctx->wNodeOff[b];
+        hipLaunchKernelGGL(k_wide_fill, dim3((pairs + 255) / 256), dim3(256), 0, st, nodes + 2 * (size_t)d.NodeOffset, triVerts + 3 * (size_t)d.TriangleOffset, (const uint4*)(ctx->wids.as<uint4>() + ctx->wNodeOff[b]),
+                           ctx->wnodes.as<uint4>() + 4 * (size_t)ctx->wNodeOff[b], ctx->wleaf.as<float4>() + ctx->wLeafOff[b], (const uint32_t*)(ctx->wcounts.as<uint32_t>() + 2 * b));
+    }
+    HIPC(hipGetLastError());
+    ctx->wideFillValid = true;
+    return IDKPT_OK;
+}
+
+// One traversal launch over `list` (cnt entries, on the device): the instantiation of k_trace2 — or k_trace2s / k_trace_wide — that serves this scene, these settings and this launch.
+// The shipped instantiations (everything else the template can express is unreachable from here):
+//   k_trace2<P, C, 32, 1, false, 24, 0, 0 | 16, V>   one BLAS instance (MODE 0), plain or pooled leaf phase       P: primary / bounce launch, C: counting build, V: scene versions
+//   k_trace2<P, C, 16, 1, false, 24, 1 | 2, 0, V>    instance loop / TLAS walk inside the kernel (MODE 1 / 2)
+//   k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>   any-hit queries (idkptTraceRays with IDKPT_TRACE_ANY_HIT), M = 0 / 1 / 2
+//   k_trace2s<P>                                      small launches of sparse views: long rays split across idle lanes (kernels_trace_split.hpp)
+//   k_trace_wide<P, C'> + k_trace2<P, false>          option "wide": the wide-node walk and the exact re-trace of the rays it does not vouch for (kernels_wide.hpp)
+// Developer builds (-DIDKPT_DEVELOPER, option "trace_variant") add the s_memtime-instrumented and the scheduling-probe instantiations.
+template <bool PRIMARY>
+static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
+                          const uint32_t* list, const uint32_t* cnt, uint32_t* work, uint64_t* counters, bool split = false, int bounce = 0, bool anyHit = false)
+{
+    const bool stock = ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100;
+    if (anyHit) {   // idkptTraceRays with IDKPT_TRACE_ANY_HIT (kernels_query.hpp): TraceRayAny's walk on the same scheduler
+#define T2A(M) hipLaunchKernelGGL((k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+        if (f.useTlas) T2A(2); else if (ctx->instanceCount > 1) T2A(1); else T2A(0);
+#undef T2A
+        return;
+    }
+    if (ctx->wideFillValid && ctx->wideTopoValid && wide_wanted(ctx) && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid) {
+        // wide-node walk (kernels_wide.hpp), then — on the launch's own list of the rays it does not vouch for, almost always empty — the exact kernel
+        const int b0 = ctx->hInst0Blas;
+        WideBufs wb;
+        wb.nodes = (const uint4*)(ctx->wnodes.as<uint4>() + 4 * (size_t)ctx->wNodeOff[b0]); wb.leaves = (const float4*)(ctx->wleaf.as<float4>() + ctx->wLeafOff[b0]);
+        wb.flagCount = work + 128; wb.flagA = ctx->sortKeys.as<uint32_t>(); wb.flagB = ctx->sortVals.as<uint32_t>(); wb.totals = ctx->wtotals.as<unsigned long long>(); wb.cap = wide_stack_rows(ctx);
+        const size_t ldsW = (size_t)(wb.cap + 2) * WAVE * 4 + (size_t)std::max(0, ctx->opt.ldsPad);     // + the dummy and the spare row
+#ifdef IDKPT_DEVELOPER
+        if (ctx->opt.traceVariant == 213) hipLaunchKernelGGL((k_trace_wide<PRIMARY, false, 32, true>), dim3(grid), dim3(WAVE), ldsW, st, s, f, rays, tr, hits, list, cnt, work, wb, counters);   // s_memtime-instrumented
+        else
+#endif
+        if (ctx->opt.wideCount) hipLaunchKernelGGL((k_trace_wide<PRIMARY, true>), dim3(grid), dim3(WAVE), ldsW, st, s, f, rays, tr, hits, list, cnt, work, wb, counters);
+        else hipLaunchKernelGGL((k_trace_wide<PRIMARY, false>), dim3(grid), dim3(WAVE), ldsW, st, s, f, rays, tr, hits, list, cnt, work, wb, counters);
+        TraceBufs trf = tr; trf.order = nullptr; trf.orderIdx = nullptr;
+        if (!PRIMARY) { trf.order = wb.flagA; trf.orderIdx = wb.flagB; }        // position -> queue slot and ray id (the hit is stored at the slot, as always)
+        Frame ff = f; ff.gridRaysX4 = 6u; ff.gridMid = 0u;                       // (the device sizes the launch from its actual count: k_trace2's own rule)
+        hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(std::min<uint32_t>(grid, 2048u)), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)wb.flagA, (const uint32_t*)wb.flagCount, work + 64, counters);
+        return;
+    }
+    if (split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && !ctx->counters && ctx->sceneNested && stock) {   // small launch: long rays are split across idle lanes (kernels_trace_split.hpp)
+        hipLaunchKernelGGL((k_trace2s<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work);
+        return;
+    }
+    // pooled leaf phase (kernels_trace.hpp, DBG 16): per launch kind — option leaf_pool, a mask: 1 = primary launches, 2 = the first bounce, 4 = later bounces; -1 = automatic
+    int poolMask = ctx->opt.leafPool;
+    if (poolMask < 0) {   // automatic: by view class, known from the previous batch of the same shape (unknown: the dense-view choice)
+        const uint64_t pixels = (uint64_t)ctx->W * ctx->rows * (uint64_t)std::max(1, f.batch);
+        const bool sparse = ctx->lastFast && ctx->lastBatch == f.batch && (uint64_t)ctx->hCounts[MAX_DEPTH_SLOTS - 1] * 2u < pixels;
+        poolMask = sparse ? 1 : 3;
+    }
+    const bool pool = ((poolMask >> std::min(bounce, 2)) & 1) && stock;
+#define T2X(C, M, D, V) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 32, 1, false, 24, M, D, V>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+#define T2P(C, V) do { if (pool) T2X(C, 0, 16, V); else T2X(C, 0, 0, V); } while (0)
+// the instance-loop / TLAS kernels: never pooled (they gain nothing from it), and idle lanes are refilled from 16 on instead of 32 — their rays live two to three BLAS walks,
+// so a refill is rarer per step than in MODE 0 and lanes are what these modes lack (profiles/r04_multi_blas.md; MODE 0 keeps 32: 24 measured -4.5 % there in round 1)
+#define T2M(C, M, V) hipLaunchKernelGGL((k_trace2<PRIMARY, C, 16, 1, false, 24, M, 0, V>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+#define T2N(M, V) do { if (ctx->counters) T2M(true, M, V); else T2M(false, M, V); } while (0)
+#ifdef IDKPT_DEVELOPER
+    if (!s.ver && !ctx->counters && !stock) {
+        const int v = ctx->opt.traceVariant;
+        if ((f.useTlas || ctx->instanceCount > 1) && (v == 24 || v == 48 || v == 16 || v == 8 || v == 12)) {   // the refill threshold of the instance-loop / TLAS kernels
+#define T2R(R, M) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, 24, M, 0, false>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+            const int m = f.useTlas ? 2 : 1;
+            if (v == 24) { if (m == 2) T2R(24, 2); else T2R(24, 1); } else if (v == 48) { if (m == 2) T2R(48, 2); else T2R(48, 1); } else if (v == 16) { if (m == 2) T2R(16, 2); else T2R(16, 1); }
+            else if (v == 12) { if (m == 2) T2R(12, 2); else T2R(12, 1); } else { if (m == 2) T2R(8, 2); else T2R(8, 1); }
+#undef T2R
+            return;
+        }
+        if (!f.useTlas && ctx->instanceCount == 1) switch (v) {   // s_memtime-instrumented and scheduling-probe instantiations of MODE 0; results are bit-identical
+            case 107: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, true, 65>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // instrumented, round 1's policy
+            case 113: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // instrumented, default policy
+            case 116: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, true, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // instrumented, pooled leaf phase
+#define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
+            case 901: T2V(32, 20); return; case 902: T2V(40, 16); return; case 903: T2V(24, 24); return; case 904: T2V(16, 24); return;   // refill threshold / parked-leaf threshold probes
+#undef T2V
+            case 961: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // occupancy probes: 7 / 8 waves per SIMD forced (launch bounds)
+            case 962: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 8, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;
+            default: break;
+        }
+    }
+#endif
+    if (s.ver) {                    // scene versions: the samples of this batch see different states of the geometry (VER instantiations, kernels_trace.hpp)
+        if (f.useTlas) T2N(2, true); else if (ctx->instanceCount > 1) T2N(1, true); else if (ctx->counters) T2P(true, true); else T2P(false, true);
+        return;
+    }
+    if (f.useTlas) { T2N(2, false); return; }                   // TLAS walk inside the kernel
+    if (ctx->instanceCount > 1) { T2N(1, false); return; }      // instance loop inside the kernel
+    if (ctx->counters) T2P(true, false); else T2P(false, false);
+#undef T2N
+#undef T2M
+#undef T2P
+#undef T2X
+}

@@ -1,0 +1,55 @@
+// host_options.hpp — idkptSetDeveloperOption.
+// Part of the single translation unit idkpt.hip (included there, in this order).
+#pragma once
+
+// idkptSetDeveloperOption: tuning / test hooks (DevOptions above).  Unknown names are an error, so that a typo cannot silently test nothing.
+static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
+{
+    if (!ctx || !name) return IDKPT_ERR_INVALID_ARGUMENT;
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    DevOptions& o = ctx->opt;
+    const std::string n(name);
+    if (n == "force_generic") o.forceGeneric = value != 0;
+    else if (n == "no_tile_cull") o.noTileCull = value != 0;
+    else if (n == "no_lean_primary") o.noLeanPrimary = value != 0;
+    else if (n == "leaf_min") o.leafMin = std::max(0, value);
+    else if (n == "grab_unit_log2") o.grabUnitLog2 = value;
+    else if (n == "grab_fixed") o.grabFixed = value;
+    else if (n == "lds_pad") o.ldsPad = value;
+    else if (n == "trace_waves") o.traceWaves = std::max(0, value);
+    else if (n == "grid_hint") o.gridHint = std::max(0, value);
+    else if (n == "grid_rays_x4") o.gridRaysX4 = std::max(0, value);
+    else if (n == "grid_mid_waves") o.gridMidWaves = std::max(0, value);
+    else if (n == "defer_last") o.deferLast = value != 0;
+    else if (n == "split") { REQUIRE(value >= 0 && value <= 3, "idkptSetDeveloperOption: split is 0..3"); o.split = value; }
+    else if (n == "split_donor") o.splitDonor = value != 0;
+    else if (n == "split_peek") o.splitPeek = std::max(1, value);
+    else if (n == "split_scatter") o.splitScatter = std::min(6, std::max(0, value));
+    else if (n == "query_scheduler") o.queryScheduler = value != 0;
+    else if (n == "group_threads") o.groupThreads = value;
+    else if (n == "fused") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: fused is 0..2"); o.fused = value; }
+    else if (n == "fused_shade_min") o.fusedShadeMin = std::min(64, std::max(1, value));
+    else if (n == "leaf_pool") { REQUIRE(value >= -1 && value <= 7, "idkptSetDeveloperOption: leaf_pool is -1 (automatic) or a mask 0..7 (1: primary launches, 2: the first bounce, 4: later bounces)"); o.leafPool = value; }
+    else if (n == "pool_min") o.poolMin = std::max(0, value);
+    else if (n == "adv_min") o.advMin = std::min(64, std::max(0, value));
+#ifdef IDKPT_DEVELOPER
+    else if (n == "graph_probe") o.graphProbe = std::max(0, value);
+#endif
+    else if (n == "wide") { REQUIRE(value >= 0 && value <= 1, "idkptSetDeveloperOption: wide is 0 or 1"); FLUSH(); o.wide = value; }
+    else if (n == "wide_cap") { REQUIRE(value >= 0 && value <= 96, "idkptSetDeveloperOption: wide_cap is 0 (default) or 4..96 rows"); o.wideCap = value; }
+    else if (n == "wide_count") o.wideCount = value != 0;
+    else if (n == "bvh_timing") o.bvhTiming = value != 0;
+    else if (n == "bvh_small") o.bvhSmall = value;
+    else if (n == "bvh_stackopt_host") o.bvhStackOptHost = value != 0;
+    else if (n == "force_no_peer") { }                 // (multi-device contexts: idkpt_api.hpp; nothing to stage on one device)
+    else if (n == "trace_variant") {
+#ifdef IDKPT_DEVELOPER
+        o.traceVariant = value;
+#else
+        REQUIRE(value == 0 || value == 100, "idkptSetDeveloperOption: trace_variant needs the developer build of the library (libidkpt_dev.so)");
+#endif
+    }
+    else return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "idkptSetDeveloperOption: unknown option '" + n + "'");
+    return IDKPT_OK;
+}

@@ -102,20 +102,3 @@ __global__ void k_capture_primary(HitBufs hits, size_t first, uint32_t n, float4
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = hits.hit[2 * (first + i)];
 }
-
-// derived layout: the node pairs of one BLAS in the order k_trace2 fetches them (node_layout.hpp).  Pair k of the reference array (nodes 2k, 2k+1,
-// BLAS-local) goes to slot[k]; an internal node's child index c becomes 2 * slot[c / 2]; boxes, leaf ranges and empty nodes are copied as they are.
-// Re-run whenever the reference array changes (upload, idkptRefitBlas, idkptUpdateBuffer): the permutation depends on the topology only.
-__global__ void k_derive_nodes(const float4* nodes, const uint32_t* slot, float4* tnodes, uint32_t nodeOffset, uint32_t pairCount)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= pairCount) return;
-    const float4* src = nodes + 2 * ((size_t)nodeOffset + 2 * (size_t)k);
-    const uint32_t* sl = slot + nodeOffset / 2;
-    float4 a0 = src[0], a1 = src[1], b0 = src[2], b1 = src[3];
-    const uint32_t ac = __float_as_uint(a0.w), an = __float_as_uint(a1.w), bc = __float_as_uint(b0.w), bn = __float_as_uint(b1.w);
-    if (an == 0u && ac != 0u && !(k == 0u)) a0.w = __uint_as_float(2u * sl[ac >> 1]);          // (node 0 of a BLAS is unused)
-    if (bn == 0u && bc != 0u) b0.w = __uint_as_float(2u * sl[bc >> 1]);
-    float4* dst = tnodes + 2 * ((size_t)nodeOffset + 2 * (size_t)sl[k]);
-    dst[0] = a0; dst[1] = a1; dst[2] = b0; dst[3] = b1;
-}

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_scatter(const uint32_t* key
     for (int k = 0; k < SORT_ITEMS; k++) {
         uint32_t i = tile * SORT_TILE + k * SORT_BLOCK + threadIdx.x;
         bool valid = i < N;
-        uint32_t key = valid ? keys[i] : 0, val = valid ? (vals ? vals[i] : i) : 0;   // (no value array: the item's own index — first pass of k_order_*)
+        uint32_t key = valid ? keys[i] : 0, val = valid ? (vals ? vals[i] : i) : 0;   // (no value array: the item's own index)
         uint32_t d = (key >> shift) & (SORT_RADIX - 1);
         // rank among lanes of this wave with the same digit (match via 7 ballots)
         unsigned long long same = __ballot(valid);
@@ -192,16 +192,4 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_scatter(const uint32_t* key
         if (threadIdx.x < SORT_RADIX) { uint32_t tot = 0; for (uint32_t w2 = 0; w2 < SORT_BLOCK / 64; w2++) tot += waveDigit[w2][threadIdx.x]; digitBase[threadIdx.x] += tot; }
         __syncthreads();
     }
-}
-
-// ---- trace order of a bounce launch (DESIGN.md §4 "trace order").  The alive queue is grouped by sample and, inside a sample, in pixel order;
-// diffuse bounce rays that start at the same place of the scene are therefore traced at unrelated times, and the node pairs around their origin
-// are fetched from the Infinity Cache again for every one of them.  The queue's ORDER is semantics (a ray's slot seeds its RNG, NHit/compute.glsl:54),
-// but when a slot is traced is not: two passes of the radix sort above over the top 14 bits of the key (the id of the triangle the ray starts on:
-// BLAS leaf order = spatial order), values = slots, give a permutation that brings the rays of ALL samples of a batch that leave the same
-// neighbourhood together; k_trace2 hands out positions of the permutation and stores every hit at its slot.  Results are bit-identical.
-__global__ __launch_bounds__(256) void k_order_gather(const uint32_t* order, const uint32_t* queue, const uint32_t* countPtr, uint32_t* orderIdx)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < *countPtr) orderIdx[i] = queue[order[i]];
 }

@@ -229,8 +229,7 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
         }
         f3 radiance = splat3(0.0f);
         if (keep) {
-            if (f.recPerRay > 1) write_instance_records(s, f, tr, rid, origin, rd);           // one record per instance (+ the world ray under USE_TLAS): the traversal kernel only loads them
-            else { tr.rec[4 * (size_t)rid] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)rid + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.rec[4 * (size_t)rid + 2] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f); }
+            tr.rec[4 * (size_t)rid] = make_float4(lo.x, lo.y, lo.z, rootT); tr.rec[4 * (size_t)rid + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f); tr.rec[4 * (size_t)rid + 2] = make_float4(invDir.x, invDir.y, invDir.z, 0.0f);
             if (!lean) seedOut[rid] = seed;                             // RNG state after ray generation, consumed by k_shade_first
         } else {
             // miss branch of FirstHit TraceRay (FirstHit/compute.glsl:225-233), evaluated right here
@@ -281,28 +280,14 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
 template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0, bool VER = false, bool ANY = false>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
-    // MODE 3 / 4: MODE 1 / 2 on scenes of up to MAX_REC_INSTANCES instances, whose producers (k_gen_primary, the shading kernels) leave one trace-ready record per
-    // (ray, instance) — the ray in the instance's space, the root-box tMin, the BLAS's node / triangle offsets (write_instance_records, pt_kernels.hpp): entering an
-    // instance is three loads and a compare here instead of a matrix fetch, 27 multiply-adds, three IEEE divisions and a slab test run by a handful of lanes.
-    constexpr bool MULTI = MODE != 0, TLAS = MODE == 2 || MODE == 4, REC = MODE >= 3;
-    // DBG 8 ("speculative touch", developer build only): as soon as a node pair has arrived, one word of each place the ray can go next is requested — both
-    // children (the child pair of an internal child, the first triangle record of a leaf child) and the pair on top of the stack — before the box tests run, so
-    // that the fetch of whichever becomes the next step overlaps with this step's ~100 dependent instructions instead of following them.  Nothing of the traversal
-    // changes (same visits, same counters, same hits; tests + fuzz bit-identical).  Measured in round 4 and NOT shipped: 14 % slower on the headline view one frame
-    // at a time, 35-50 % slower where every pixel traverses, at every launch size — even a frame traced alone is bound by the rate at which blocks that miss L1/L2
-    // are delivered, not by the latency of its longest ray (profiles/r04_small_launch_experiments.md).
-    constexpr bool SPEC = DBG == 8;
+    static_assert(MODE >= 0 && MODE <= 2 && (DBG == 0 || DBG == 16), "k_trace2: MODE 0-2, DBG 0 or 16 (pooled leaf phase)");
+    constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
     // DBG 16 ("pooled leaves", MODE 0): the leaf phase tests the wave's (ray, triangle) PAIRS with all 64 lanes in one round trip instead of every parked lane
     // walking its own 1-8 triangles one dependent fetch after the other with 18-22 lanes active (instrumented: 23-48 pairs per leaf phase in 2.0-3.1 loop trips).
     // Pairs are numbered by a ballot prefix sum over the parked lanes' triangle counts; the owners write (lane, k) for their pairs into the 64 words of the stack's
     // dummy row, lane j picks up pair j, fetches its owner's ray through ds_bpermute and tests the triangle; the owners then collect their pairs' results IN ORDER with
     // the reference's `t < T` (BVHIntersect.glsl:57-79) — the same tests on the same operands, the same sequence of T updates: bit-identical hits.
     constexpr bool POOL = DBG == 16;     // (the host selects it for MODE 0 only: in the instance-loop / TLAS kernels it measured neutral to slightly negative, profiles/r04_leaf_pool.md)
-    // DBG 32 ("first triangle on the way", MODE 0): a lane that finds a leaf requests the leaf's first triangle record right there, in the node step; the record
-    // travels while the other lanes keep stepping, and the leaf phase starts with its first test instead of a round trip (it has 2.0-3.1 of them, r04_phase_profile.txt).
-    constexpr bool PREF = DBG == 32;
-    float4 pfa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pfb = pfa, pfc = pfa;
-    uint32_t pfA = 0, pfB = 0, pfC = 0, pfSink = 0;
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     // LDS rows of this wave, one word per lane: row 0 = dummy (what a pop of the empty stack reads), rows 1 .. cap = stack entries 0 .. cap-1,
@@ -324,7 +309,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     const GpuBlasInstance inst = s.instances[0];
     const int nodeOffset = s.descs[inst.BlasId].NodeOffset;
     const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
-    const float4* nodes = s.tnodes + 2 * (size_t)nodeOffset;      // the derived order (node_layout.hpp): same pairs, same child relations, other positions
+    const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
 
     bool active = false, leafPending = false, workLeft = true;
     // work-list state of this wave (wave-uniform): the slice it grabs from, how many slices it has seen handed out, and the positions
@@ -336,7 +321,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     if (N == 0u) workLeft = false;
     uint32_t top = 0, slot = 0, leafFirst = 0, leafEnd = 0;
     uint32_t instIdx = 0, rayId = 0, nodeOff = 0, triOff = 0, xformId = 0;   // MULTI only: per-lane instance cursor (TLAS: next TLAS node) and BLAS offsets
-    uint32_t vNode = 0, vTri = 0, vNodeRef = 0, vTlas = 0, vXform = 0;         // VER only: where this ray's scene version starts in tnodes / triVerts (MULTI: nodes / tlas / xforms), in float4 units
+    uint32_t vNode = 0, vTri = 0, vTlas = 0, vXform = 0;         // VER only: where this ray's scene version starts in nodes / triVerts (MULTI: also tlas / xforms), in float4 units
     int tsp = 0; bool moreInst = false;                                       // TLAS stack pointer; "there are instances / TLAS nodes left for this ray"
     lds_u32* sp = stkBase;
     f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
@@ -391,7 +376,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 slot = PRIMARY ? idx : (ordered ? tr.order[item] : item);
                 hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f;
                 if (f.queryMode) { hitT = tr.rec[4 * (size_t)idx + 1].w; hitXform = __float_as_uint(tr.rec[4 * (size_t)idx + 2].w); }   // idkptTraceRays (kernels_query.hpp k_query_prepare): T = maxDist or the nearest light, and that light
-                if (VER) { const uint32_t* vt = s.ver + SCENE_VER_WORDS * (size_t)(idx / f.Npad); vNode = vt[1]; vTri = vt[2]; if (MULTI) { vNodeRef = vt[0]; vTlas = vt[4]; vXform = vt[5]; } }
+                if (VER) { const uint32_t* vt = s.ver + SCENE_VER_WORDS * (size_t)(idx / f.Npad); vNode = vt[0]; vTri = vt[1]; if (MULTI) { vTlas = vt[3]; vXform = vt[4]; } }
                 if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203 (world-space ray)
                     float4 o = rays.o_ior[idx];
                     f3 wd = DecodeUnitVec(rays.thr_px[idx].w, rays.rad_py[idx].w), wo = mk3(o.x, o.y, o.z);
@@ -425,24 +410,17 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                     const float4 pmin = tl4[2 * (size_t)instIdx];
                     const uint32_t packed = __float_as_uint(pmin.w), id = packed & 0x7fffffffu;
                     if ((packed >> 31) == 1u) {                                             // leaf: BVHIntersect.glsl:223-240
-                        if (REC) {                                                          // the ray in this instance's space: prepared by the kernel that produced the ray
-                            const float4* r4 = rec_at(tr, f, rayId, id);
-                            const float4 a = r4[0], b = r4[1], c = r4[2];
-                            ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z);
-                            nodeOff = __float_as_uint(b.w); triOff = __float_as_uint(c.w); xformId = id;      // (xformId holds the INSTANCE here; its MeshTransformId is looked up when the hit is stored)
-                        } else {
                         const GpuBlasInstance in2 = s.instances[id];
                         const M34 inv = load_inv_model_at(VER ? s.xforms + vXform : s.xforms, in2.MeshTransformId);
                         float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];
                         ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                         invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
-                        }
                         sp = stkBase; top = 2u;                                             // no root test under USE_TLAS (:32)
                         if (tsp == 0 || tsp > f.tlasCap) moreInst = false; else instIdx = tstk[--tsp * WAVE];  // the pop the reference does after the BLAS; order-independent
                     } else {
                         const uint32_t l = id, r = id + 1;
-                        const float4* w4 = REC ? rec_at(tr, f, rayId, (uint32_t)s.instanceCount) : tr.rec + 4 * (size_t)rayId;
+                        const float4* w4 = tr.rec + 4 * (size_t)rayId;
                         float4 a = w4[0], c = w4[2];                                                                          // world-space origin and 1/dir
                         const f3 wo = mk3(a.x, a.y, a.z), winv = mk3(c.x, c.y, c.z);
                         float4 lmin = tl4[2 * (size_t)l], lmax = tl4[2 * (size_t)l + 1], rmin = tl4[2 * (size_t)r], rmax = tl4[2 * (size_t)r + 1];
@@ -462,22 +440,14 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             bool adv = active && !leafPending && top == 0u && instIdx < (uint32_t)s.instanceCount;
             if (MULTI && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(adv)) < (uint32_t)f.advMin && __builtin_amdgcn_ballot_w64(active && (leafPending || top != 0u)) != 0ull) adv = false;
             while (__any(adv)) {
-                if (adv && REC) {
-                    const float4* r4 = rec_at(tr, f, rayId, instIdx);
-                    const float4 a = r4[0], b = r4[1], c = r4[2];
-                    ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z);
-                    nodeOff = __float_as_uint(b.w); triOff = __float_as_uint(c.w); xformId = instIdx;              // (the instance; its MeshTransformId is looked up when the hit is stored)
-                    const bool enter = a.w < hitT;                                                                // root test (:32-39): tMin from the record, +inf = the ray misses the root box
-                    sp = stkBase; top = enter ? 2u : 0u;
-                    instIdx++;
-                } else if (adv) {
+                if (adv) {
                     const GpuBlasInstance in2 = s.instances[instIdx];
                     const M34 inv = load_inv_model_at(VER ? s.xforms + vXform : s.xforms, in2.MeshTransformId);
                     float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];                         // world-space origin / direction
                     ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                     invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
-                    const float4* root = (VER ? s.nodes + vNodeRef : s.nodes) + 2 * (size_t)nodeOff + 2;
+                    const float4* root = (VER ? s.nodes + vNode : s.nodes) + 2 * (size_t)nodeOff + 2;
                     float t1;
                     const bool enter = RayBoxIntersect(ro, invDir, root[0], root[1], &t1) && t1 < hitT;
                     sp = stkBase; top = enter ? 2u : 0u;
@@ -496,30 +466,10 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             if (PROF) { pn[2]++; pn[3] += (unsigned long long)__builtin_popcountll(stepMask); }
             if (canStep) {
                 if (COUNT) nPairs++;
-                const float4* p = (MULTI ? s.tnodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top) + (VER ? vNode : 0u);
-                if (DBG == 1) { uint32_t x0 = lane, x1 = lane, x2 = lane, x3 = lane;       // (bottleneck probe: 16 extra VALU instructions per step, four independent chains)
-                    for (int k = 0; k < 4; k++) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)); }
-                if (DBG == 2) { uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;                   // (16 extra SALU instructions per step)
-                    for (int k = 0; k < 4; k++) asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1" : "+s"(y0), "+s"(y1), "+s"(y2), "+s"(y3)); }
-                if (DBG == 3) { uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;                   // (48 extra SALU instructions per step)
-                    for (int k = 0; k < 12; k++) asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1" : "+s"(y0), "+s"(y1), "+s"(y2), "+s"(y3)); }
-                if (DBG == 4) { uint32_t x0 = lane, x1 = lane, x2 = lane, x3 = lane;       // (48 extra VALU instructions per step)
-                    for (int k = 0; k < 12; k++) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)); }
+                const float4* p = (MULTI ? s.nodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top) + (VER ? vNode : 0u);
                 const uint32_t popped = sp[0];                          // what a pop would return (in flight with the node pair; row 0 for an empty stack)
                 float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
                 const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
-                if (SPEC) {
-                    pfSink ^= pfA ^ pfB ^ pfC;                          // the words touched one step ago (they were requested before this step's pair, so they have arrived)
-                    const float4* nb = (MULTI ? s.tnodes + 2 * (size_t)nodeOff : nodes) + (VER ? vNode : 0u);
-                    const float4* tb = s.triVerts + 3 * (size_t)(MULTI ? triOff : triOffset) + (VER ? vTri : 0u);
-                    const float4* ta = lCount == 0u ? nb + 2 * (size_t)lStart : tb + 3 * (size_t)lStart;
-                    const float4* tc = rCount == 0u ? nb + 2 * (size_t)rStart : tb + 3 * (size_t)rStart;
-                    const float4* tp = nb + 2 * (size_t)(sp != stkBase ? popped : top);
-                    // (inline asm: a C++ load that nothing consumes is deleted, a volatile one becomes a system-scope load with a wait behind it.  The compiler does not
-                    // know these loads are in flight — it never waits for them; the registers are read one step later, behind the wait for that step's own, younger loads)
-                    asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off" : "=&v"(pfA), "=&v"(pfB), "=&v"(pfC) : "v"(ta), "v"(tc), "v"(tp));
-                    __builtin_amdgcn_sched_barrier(0);                 // (the box tests below must not be scheduled in front of the requests: the overlap is the point)
-                }
                 float tMinLeft, tMinRight;
                 const bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= hitT;
                 const bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= hitT;
@@ -527,7 +477,6 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 // (a lane that steps has no parked leaf, so its leaf registers are free: written unconditionally, BLAS-local; the leaf phase adds the offset)
                 leafFirst = intersectLeft ? lStart : rStart; leafEnd = !intersectRight ? lStart + lCount : rStart + rCount; leafPending = intersectLeft || intersectRight;
                 if (COUNT) nTris += leafPending ? leafEnd - leafFirst : 0u;
-                if (PREF && leafPending) { const float4* tv = s.triVerts + 3 * (size_t)(leafFirst + (MULTI ? triOff : triOffset)) + (VER ? vTri : 0u); pfa = tv[0]; pfb = tv[1]; pfc = tv[2]; }
                 const bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
                 const bool both = traverseLeft && traverseRight, none = !(traverseLeft || traverseRight);
                 const bool leftCloser = ANY ? true : tMinLeft < tMinRight;   // (ANY: left first, BVHIntersect.glsl:165-168)
@@ -599,21 +548,6 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
                 }
             }
         }
-        if (PREF && leafPending) {
-            const uint32_t tOff = MULTI ? triOff : triOffset;
-            uint32_t i = leafFirst + tOff; const uint32_t e = leafEnd + tOff;
-            float4 a = pfa, b = pfb, c = pfc;
-            while (true) {
-                float by, bz, t;
-                if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t) && t < hitT) {
-                    hitTri = i; hbx = 1.0f - by - bz; hby = by; hitT = t; hitXform = MULTI ? xformId : inst.MeshTransformId;
-                }
-                if (++i >= e) break;
-                const float4* tv = s.triVerts + 3 * (size_t)i + (VER ? vTri : 0u);
-                a = tv[0]; b = tv[1]; c = tv[2];
-            }
-            leafPending = false;
-        }
         if (leafPending) {
             const uint32_t tOff = MULTI ? triOff : triOffset;
             // (one triangle per round trip.  Requesting the two 48-B records of a two-triangle leaf together was measured in round 3: 88 instead of 75 VGPRs,
@@ -636,12 +570,11 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
         PROF_MARK(2);
         // ---- retire finished rays (MULTI: only after the last instance)
         if (active && top == 0u && (!MULTI || (TLAS ? !moreInst : instIdx >= (uint32_t)s.instanceCount))) {
-            store_hit(hits, slot, hitT, hbx, hby, hitTri, (REC && hitTri != ~0u) ? s.instances[hitXform].MeshTransformId : hitXform);   // (REC: a triangle hit remembered its instance)
+            store_hit(hits, slot, hitT, hbx, hby, hitTri, hitXform);
             active = false;
         }
     }
     if (ovf) *s.overflow = 1u;
-    if (SPEC) asm volatile("" :: "v"(pfSink ^ pfA ^ pfB ^ pfC));          // (keeps the touched words alive: nothing reads them)
     if (COUNT) flush_counters(counters, nPairs, nTris);
     if (PROF && lane == 0) { for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)&counters[4 + i], pc[i]); for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&counters[8 + i], pn[i]); }
 #undef PROF_MARK

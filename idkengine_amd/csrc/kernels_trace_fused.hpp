@@ -38,7 +38,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_fused(DScene s, Frame f, RayB
     const GpuBlasInstance inst = s.instances[0];
     const int nodeOffset = s.descs[inst.BlasId].NodeOffset;
     const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
-    const float4* nodes = s.tnodes + 2 * (size_t)nodeOffset;
+    const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
 
     bool active = false, leafPending = false, workLeft = true;
     bool bounce = false, shadePend = false;                          // this lane's ray is the bounce ray of its pixel; its primary ray is finished and waits for the shading phase

@@ -16,7 +16,6 @@ struct TexDesc { const float4* data; int w, h; };
 
 struct DScene {
     const float4* nodes;        // 2 x float4 per GpuBlasNode: {Min.xyz, TriStartOrChild}, {Max.xyz, TriCount}
-    const float4* tnodes;       // derived: the same node pairs in the order k_trace2 fetches them (node_layout.hpp; child indices rewritten, pairs 0 and 1 of every BLAS in place); == nodes when no derived order is in use
     const uint4* tris;          // GpuBlasTriangle
     const float4* triVerts;     // derived: 3 x float4 per BLAS triangle (leaf order): positions of X,Y,Z (w unused)
     const GpuBlasDesc* descs;
@@ -32,7 +31,7 @@ struct DScene {
     uint32_t* overflow;         // host-mapped word: set when a traversal-stack push had to be dropped (idkpt.hip turns it into an error at the next sync)
     // scene versions (idkptSetSceneVersions): samples of one batch may see different states of the geometry (animated frames in flight).  Null: every sample
     // reads the pointers above.  Else the pointers above are the bases of the version arenas and row smp of this table holds, in 16-byte units, where the
-    // version of sample smp starts in each: [0] nodes [1] tnodes [2] triVerts [3] vertices [4] tlas [5] xforms [6..7] unused (kernels instantiated with VER)
+    // version of sample smp starts in each: [0] nodes [1] triVerts [2] vertices [3] tlas [4] xforms [5..7] unused (kernels instantiated with VER)
     const uint32_t* ver;
 };
 #define SCENE_VER_WORDS 8
@@ -41,7 +40,7 @@ DEV DScene scene_of_sample(const DScene& s, uint32_t smp)
 {
     DScene v = s;
     const uint32_t* t = s.ver + SCENE_VER_WORDS * (size_t)smp;
-    v.nodes = s.nodes + t[0]; v.tnodes = s.tnodes + t[1]; v.triVerts = s.triVerts + t[2]; v.vertices = s.vertices + t[3]; v.tlas = s.tlas + t[4]; v.xforms = s.xforms + t[5];
+    v.nodes = s.nodes + t[0]; v.triVerts = s.triVerts + t[1]; v.vertices = s.vertices + t[2]; v.tlas = s.tlas + t[3]; v.xforms = s.xforms + t[4];
     return v;
 }
 
@@ -61,8 +60,6 @@ struct Frame {
     uint32_t seqFirst, seqStride;   // idkptSetSampleSequence: sample i of an accumulation draws the RNG streams of AccumulatedSamples = seqFirst + i * seqStride (reference: 0, 1)
     // frame ring (idkptSetFrameRing): sample k renders with camera cams[36*k ..] (null: the one camera above) into result-image slot slotOf[k]
     const float* cams; uint32_t slotOf[256];   // (dwords: scalar loads from the kernel-argument segment; gfx9 has no scalar byte load)
-    int recPerRay;              // trace-ready records per ray id: 1 (one BLAS: the local ray; on-the-fly instance / TLAS walks: the world ray), or — scenes of up to MAX_REC_INSTANCES
-                                // instances — one record per instance (the ray in that instance's space, its root-box tMin, the BLAS's node / triangle offsets), plus the world ray behind them under USE_TLAS
     int advMin;                 // k_trace2 MODE 1-4: lanes whose BLAS is exhausted wait for this many of their kind before they enter the next instance / walk the TLAS (1: at once)
     int poolMin;                // pooled leaf phase (k_trace2 DBG 16): (ray, triangle) pairs a wave must have parked before they are tested by all lanes together
     int splitPeek;              // k_trace2s: iterations between two looks at the work-list heads of a wave that is too busy to refill
@@ -87,12 +84,10 @@ struct TraceBufs {              // derived, per ray id: the ray ready for the tr
     float4* rec;                // that a refill touches one cache line per ray instead of three): [0] RayTransform(origin) (Ray.glsl:7-12), .w = tMin of
                                 // the root-box test (+inf = miss), so that the traversal kernel's root test is one compare; [1] RayTransform(direction), not renormalised; [2] 1 / [1] (IntersectionRoutines.glsl:29); [3] unused.
                                 // Several instances / TLAS: [0],[1] hold the WORLD-space ray, [2] the world 1/dir (TLAS only).
-    // trace order of a bounce launch (null: queue order): the launch hands out positions of `order`; order[i] = queue slot, orderIdx[i] = the ray id in that
-    // slot.  The slots — which seed NHit's RNG (NHit/compute.glsl:54) — stay what they are; only WHEN a slot is traced changes (kernels_queue.hpp, k_order_*).
+    // a bounce launch over a SUBSET of the queue (null: the whole queue in order): the launch hands out positions of `order`; order[i] = queue slot, orderIdx[i] = the ray id
+    // in that slot — the exact re-trace behind a wide-node launch (kernels_wide.hpp).  The slot a hit is stored at — which seeds NHit's RNG (NHit/compute.glsl:54) — stays what it is.
     const uint32_t* order; const uint32_t* orderIdx;
 };
-#define MAX_REC_INSTANCES 8
-DEV float4* rec_at(const TraceBufs& tr, const Frame& f, uint32_t rid, uint32_t k) { return tr.rec + 4 * ((size_t)rid * (uint32_t)f.recPerRay + k); }
 struct HitBufs {                // indexed by queue slot: one 32-B record per slot (one aligned store sector instead of a 16-B and a 4-B partial write)
     float4* hit;                // [2*slot] = T, BaryXY.x, BaryXY.y, TriangleId (bits); [2*slot+1].x = MeshTransformId or light index (bits)
     float* cost;                // debugCost (only written in DoDebugBVHTraversal mode)
@@ -175,28 +170,6 @@ DEV bool IntersectBlas(const DScene& s, f3 ro, f3 rd, const GpuBlasDesc& dref, b
 
 DEV M34 load_inv_model_at(const float4* xforms, uint32_t xformId) { const float4* x = xforms + 9 * (size_t)xformId; M34 m; m.r0 = x[3]; m.r1 = x[4]; m.r2 = x[5]; return m; }
 DEV M34 load_inv_model(const DScene& s, uint32_t xformId) { return load_inv_model_at(s.xforms, xformId); }
-
-// One record per instance (scenes of up to MAX_REC_INSTANCES instances, Frame::recPerRay > 1): what the instance loop / a TLAS leaf does per ray and instance
-// (BVHIntersect.glsl:231-232, 281-282: RayTransform; IntersectionRoutines.glsl:29: 1/dir; :32-39: the root-box test of the instance loop) computed HERE, with all
-// lanes busy and the matrices in scalar registers, instead of by a few lanes inside the persistent traversal kernel.  Same expressions, same bits.
-DEV void write_instance_records(const DScene& s, const Frame& f, const TraceBufs& tr, uint32_t rid, f3 origin, f3 rd)
-{
-    for (int k = 0; k < s.instanceCount; k++) {
-        const GpuBlasInstance inst = s.instances[k];
-        const M34 inv = load_inv_model(s, inst.MeshTransformId);
-        const f3 lo = xform34(inv, origin, 1.0f), ld = xform34(inv, rd, 0.0f);
-        const f3 iv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
-        const int nodeOff = s.descs[inst.BlasId].NodeOffset, triOff = s.descs[inst.BlasId].TriangleOffset;
-        float rootT = __builtin_inff();                                  // USE_TLAS enters a leaf's BLAS without a root test (:32)
-        if (!f.useTlas) { const float4* root = s.nodes + 2 * (size_t)nodeOff + 2; float t1; if (RayBoxIntersect(lo, iv, root[0], root[1], &t1)) rootT = t1; }
-        float4* o = rec_at(tr, f, rid, (uint32_t)k);
-        o[0] = make_float4(lo.x, lo.y, lo.z, rootT); o[1] = make_float4(ld.x, ld.y, ld.z, __uint_as_float((uint32_t)nodeOff)); o[2] = make_float4(iv.x, iv.y, iv.z, __uint_as_float((uint32_t)triOff));
-    }
-    if (f.useTlas) {   // the world ray for the TLAS slab tests (:209), behind the instance records
-        float4* o = rec_at(tr, f, rid, (uint32_t)s.instanceCount);
-        o[0] = make_float4(origin.x, origin.y, origin.z, 0.0f); o[1] = make_float4(rd.x, rd.y, rd.z, 0.0f); o[2] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, 0.0f);
-    }
-}
 
 // traceLights / maxDist: the path tracer passes (settings.DoTraceLights, FLOAT_MAX) (FirstHit:106, NHit:96); ray queries and the
 // shadow kernel pass their own (BVHIntersect.glsl:183, ShadowsRayTraced/compute.glsl:73)

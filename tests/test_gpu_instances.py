@@ -105,13 +105,10 @@ def test_device_tlas_build_matches_host_build(native_builder, oracle_builder, pa
     pt.Dispose()
 
 
-@pytest.mark.parametrize("records", [1, 0])
 @pytest.mark.parametrize("parts,use_tlas", [(2, 0), (3, 1), (8, 0), (8, 1), (9, 1)])
-def test_instance_entries_from_records_or_computed_in_the_kernel(native_builder, oracle_mod, monkeypatch, records, parts, use_tlas):
-    """Scenes of up to 8 instances leave one trace-ready record per (ray, instance) for the traversal kernel (k_trace2 MODE 3 / 4: the instance entry is three
-    loads); option instance_records 0 — and every scene with more instances (9 here) — computes the entry inside the kernel (MODE 1 / 2).  Either way: the oracle's
+def test_instance_entries_computed_in_the_kernel(native_builder, oracle_mod, parts, use_tlas):
+    """The instance loop / the TLAS walk of k_trace2 (MODE 1 / 2: RayTransform, 1/dir and the root-box test per (ray, instance) inside the persistent kernel): the oracle's
     frame bit for bit (image, ray records, alive queue, primary hits, visit counters), with lights in front of the geometry, batched, sorted."""
-    monkeypatch.setenv("IDKPT_INSTANCE_RECORDS", str(records))
     sc = S.soup_scene_multi(5000, native_builder, parts=parts, seed=11 + parts); w, h = 150, 90
     sc.lights = S.make_lights([((0.0, 3.0, 14.0), 0.8, (9.0, 8.0, 7.0))])
     cam = S.Camera(w, h, position=(1.0, 0.5, 24.0))

@@ -32,7 +32,7 @@ def test_random_api_sequences_match_unbatched_replay(native_builder, seed):
     # free choices of the implementation on the deferring side (their own generator: the call sequences of earlier rounds stay what they were): the kernels a launch
     # may be given — fused FirstHit + NHit, split, quad records, two parked leaves, pooled leaves — must never show in what a host reads
     orng = np.random.default_rng(9000 + seed)
-    for name, values in (("fused", [1, 2, 2, 0]), ("split", [1, 2, 3, 0]), ("quad", [0, 0, 2]), ("park", [0, 0, 7, 2]), ("leaf_pool", [-1, 7, 0, 1]), ("trace_waves", [0, 0, 1])):
+    for name, values in (("fused", [1, 2, 2, 0]), ("split", [1, 2, 3, 0]), ("wide", [0, 0, 1]), ("wide_cap", [0, 0, 5]), ("leaf_pool", [-1, 7, 0, 1]), ("trace_waves", [0, 0, 1])):
         a.set_option(name, int(orng.choice(values)))
     size = sizes[0]
     for p in (a, b):

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace2p(DScene s, Frame f, RayBufs 
     const GpuBlasInstance inst = s.instances[0];
     const int nodeOffset = s.descs[inst.BlasId].NodeOffset;
     const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
-    const float4* nodes = s.tnodes + 2 * (size_t)nodeOffset;
+    const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
     const float INF = __builtin_inff();
 
     bool active = false, leafPending = false, workLeft = true;

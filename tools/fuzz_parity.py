@@ -95,11 +95,12 @@ def draw_case(seed, builder):
     if rng.random() < 0.3: ov.update(FocalLength=float(rng.uniform(0.5, 2.0) * extent), LenseRadius=float(rng.uniform(0.005, 0.05) * extent))
     frames = int(rng.integers(1, 6)); batch = int(rng.choice([1, 2, 5, 8]))
     st = configs.apply_settings(T.Settings.default(), ov)
-    opts = {"node_layout": int(rng.choice([0, 0, 1, 2])), "treelet_depth": int(rng.integers(1, 6)), "trace_order": int(rng.choice([0, 0, 1, 2])),
-            "grid_rays_x4": int(rng.choice([6, 6, 0, 1, 64])), "grid_mid_waves": int(rng.choice([20, 20, 0, 3])), "defer_last": int(rng.choice([1, 1, 0])), "grid_hint": int(rng.choice([2, 2, 0, 1])), "trace_waves": int(rng.choice([0, 0, 1, 7])),
+    _legacy = (int(rng.choice([0, 0, 1, 2])), int(rng.integers(1, 6)), int(rng.choice([0, 0, 1, 2])))   # (draws of options that left the product in round 5: the cases of earlier rounds keep their scenes)
+    opts = {"grid_rays_x4": int(rng.choice([6, 6, 0, 1, 64])), "grid_mid_waves": int(rng.choice([20, 20, 0, 3])), "defer_last": int(rng.choice([1, 1, 0])), "grid_hint": int(rng.choice([2, 2, 0, 1])), "trace_waves": int(rng.choice([0, 0, 1, 7])),
             "split": int(rng.choice([1, 2, 2, 3, 0])), "split_donor": int(rng.choice([0, 1]))}
     opts["fused"] = int(rng.choice([0, 2, 2, 1])); opts["fused_shade_min"] = int(rng.choice([16, 1, 8, 32, 64]))
-    opts["quad"] = int(rng.choice([0, 0, 2])); opts["park"] = int(rng.choice([0, 0, 7, 2])); opts["query_scheduler"] = 1
+    _legacy2 = (int(rng.choice([0, 0, 2])), int(rng.choice([0, 0, 7, 2]))); opts["query_scheduler"] = 1
+    opts["wide"] = int(rng.choice([0, 1, 1])); opts["wide_cap"] = int(rng.choice([0, 0, 6]))     # the wide-node walk (kernels_wide.hpp) on the one-BLAS cases
     # free choices of the implementation: never visible in the output (split is drawn last: the cases of earlier rounds keep their scenes)
     return sc, cam, w, h, ov, st, opts, frames, batch, nb
 
