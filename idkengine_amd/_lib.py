@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("IDKPT_LIB_PATH") or os.path.join(_HERE, "libidkpt.so"
 
 # every symbol include/idkpt.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
-    "idkptCreate", "idkptDestroy", "idkptGetLastError", "idkptSetErrorCallback", "idkptGetDeviceCount", "idkptGetVersionString", "idkptGetContextDeviceCount", "idkptSetGroupSharding",
+    "idkptCreate", "idkptDestroy", "idkptGetLastError", "idkptSetErrorCallback", "idkptGetDeviceCount", "idkptGetVersionString", "idkptGetContextDeviceCount", "idkptGetTransportInfo", "idkptTransportSelfTest", "idkptSetGroupSharding",
     "idkptSetSize", "idkptSetSceneVersions", "idkptSetRowSharding", "idkptSetRowBands", "idkptSetRowRange", "idkptSetBounceExchange", "idkptSetBandExchange", "idkptSetBandExchangeDevice", "idkptSetSettings", "idkptGetSettings",
     "idkptSetPerFrame", "idkptSetPerFrameData", "idkptUploadScene", "idkptUpdateBuffer", "idkptSetLightCount",
     "idkptBuildTlas", "idkptBuildTlasOnDevice", "idkptBuildBlasCore", "idkptBuildBlas", "idkptBuildBlasFetch", "idkptCbrtProbe", "idkptRefitBlas", "idkptUploadUnskinnedVertices", "idkptSkin", "idkptDownloadBuffer",
@@ -37,7 +37,7 @@ def load():
     vp, i32, u32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t
     sig = {
         "idkptCreate": [i32, C.POINTER(i32), C.POINTER(vp)], "idkptDestroy": [vp], "idkptGetLastError": [vp, C.POINTER(C.c_char_p)], "idkptSetErrorCallback": [vp, vp, vp],
-        "idkptGetDeviceCount": [C.POINTER(i32)], "idkptGetContextDeviceCount": [vp, C.POINTER(i32)], "idkptSetGroupSharding": [vp, i32], "idkptSetSize": [vp, i32, i32], "idkptSetRowSharding": [vp, i32, i32], "idkptSetSceneVersions": [vp, i32], "idkptSetRowBands": [vp, i32, i32, i32],
+        "idkptGetDeviceCount": [C.POINTER(i32)], "idkptGetContextDeviceCount": [vp, C.POINTER(i32)], "idkptGetTransportInfo": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_char_p)], "idkptTransportSelfTest": [i32, C.POINTER(i32), C.c_char_p, sz], "idkptSetGroupSharding": [vp, i32], "idkptSetSize": [vp, i32, i32], "idkptSetRowSharding": [vp, i32, i32], "idkptSetSceneVersions": [vp, i32], "idkptSetRowBands": [vp, i32, i32, i32],
         "idkptSetRowRange": [vp, i32, i32], "idkptSetBounceExchange": [vp, vp, vp], "idkptSetBandExchange": [vp, vp, vp], "idkptSetBandExchangeDevice": [vp, vp, vp], "idkptSetSettings": [vp, vp], "idkptGetSettings": [vp, vp],
         "idkptSetPerFrame": [vp, vp, vp, vp], "idkptSetPerFrameData": [vp, vp], "idkptUploadScene": [vp, vp],
         "idkptUpdateBuffer": [vp, i32, sz, sz, vp], "idkptSetLightCount": [vp, i32], "idkptBuildTlas": [vp, vp, i32], "idkptBuildTlasOnDevice": [vp, i32], "idkptBuildBlasCore": [vp, vp, i32, vp, vp, vp], "idkptBuildBlas": [vp, vp, i32, vp, i32, i32, C.c_float, vp], "idkptBuildBlasFetch": [vp, vp, vp, vp, vp], "idkptCbrtProbe": [vp, vp, vp, i32], "idkptTraceRays": [vp, vp, sz, u32, vp], "idkptTraceShadows": [vp, vp, vp, vp, vp], "idkptTraceRaysDevice": [vp, vp, sz, u32, vp], "idkptTraceShadowsDevice": [vp, vp, vp, vp, vp], "idkptSetFrameRing": [vp, i32], "idkptBeginFrame": [vp, C.POINTER(i32)],

@@ -431,9 +431,13 @@ static hipError_t member_copy(PeerPolicy* pol, void* dst, int dstDev, const void
 
 // Multi-device contexts: the scene one member uploaded (validated, derived layouts built) is replicated to another member device-to-device
 // (hipMemcpyPeerAsync: xGMI between MI355X GPUs) instead of crossing PCIe once per GPU — the "broadcast of the BVH" of the group layer.
-static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
+// Three steps so that the copies themselves can be the member-to-member peer copies below or one RCCL broadcast per buffer over all members (idkpt_api.hpp):
+// clone_prepare sizes this member's buffers and lists (destination, source on `src`, bytes); the caller moves the bytes; clone_finish adopts the scene.
+struct CloneItem { void* dst; const void* src; size_t bytes; };
+static int clone_prepare(dev_ctx* ctx, dev_ctx* src, std::vector<CloneItem>& items)
 {
     if (!ctx || !src || !src->haveScene) return IDKPT_ERR_INVALID_ARGUMENT;
+    items.clear();
     HIPC(hipSetDevice(ctx->device));
     FLUSH();
     { int rc = materialize_culled_rays(ctx); if (rc) return rc; }   // while the old sky is still resident
@@ -448,17 +452,22 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
         const size_t bytes = (vb >= 0 && src->vbytes[vb] > 0) ? src->vbytes[vb] : f[i]->bytes;
         const char* from = (vb >= 0 && src->vbytes[vb] > 0) ? vb_ptr(src, vb, src->vcur[vb]) : (const char*)f[i]->p;
         HIPC(d[i]->ensure(bytes));
-        HIPC(member_copy(ctx->peer, d[i]->p, ctx->device, from, src->device, bytes, ctx->stream));
+        items.push_back({d[i]->p, from, bytes});
     }
     for (auto& t : ctx->texData) t.release();
     ctx->texData.clear(); ctx->texDims = src->texDims;
-    std::vector<TexDesc> td;
     for (size_t i = 0; i < src->texData.size(); i++) {
         ctx->texData.emplace_back();
         HIPC(ctx->texData.back().ensure(src->texData[i].bytes));
-        HIPC(member_copy(ctx->peer, ctx->texData.back().p, ctx->device, src->texData[i].p, src->device, src->texData[i].bytes, ctx->stream));
-        td.push_back({ctx->texData.back().as<float4>(), src->texDims[i].first, src->texDims[i].second});
+        items.push_back({ctx->texData.back().p, src->texData[i].p, src->texData[i].bytes});
     }
+    return IDKPT_OK;
+}
+static int clone_finish(dev_ctx* ctx, dev_ctx* src)
+{
+    HIPC(hipSetDevice(ctx->device));
+    std::vector<TexDesc> td;
+    for (size_t i = 0; i < src->texData.size(); i++) td.push_back({ctx->texData[i].as<float4>(), src->texDims[i].first, src->texDims[i].second});
     { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
     ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
     ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
@@ -470,6 +479,15 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     ctx->haveScene = true;
     std::fill(ctx->accum.begin(), ctx->accum.end(), 0u);
     return IDKPT_OK;
+}
+
+// one member from another by peer copies (xGMI: hipMemcpyPeerAsync; staged through the host where peer access is refused)
+static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
+{
+    std::vector<CloneItem> items;
+    int rc = clone_prepare(ctx, src, items); if (rc) return rc;
+    for (const CloneItem& it : items) HIPC(member_copy(ctx->peer, it.dst, ctx->device, it.src, src->device, it.bytes, ctx->stream));
+    return clone_finish(ctx, src);
 }
 
 static int32_t dev_SetLightCount(dev_ctx* ctx, int32_t count)

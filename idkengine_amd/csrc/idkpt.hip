@@ -42,5 +42,6 @@ using namespace ptd;
 #include "host_schedule.hpp"
 #include "host_readback.hpp"
 #include "host_options.hpp"
+#include "transport_rccl.hpp"
 
 #include "idkpt_api.hpp"

@@ -45,6 +45,7 @@ struct idkpt_ctx {
     std::string lastError;
     idkpt_error_fn errFn = nullptr; void* errUser = nullptr;
     PeerPolicy peer;                                        // how the members copy to each other (xGMI peer copies, or staged through the host)
+    RcclTransport rccl; int transportOpt = 0;               // option "transport": 0 = RCCL where it can be formed, else peer copies; 1 = peer copies; 2 = RCCL or fail (transport_rccl.hpp)
     hipEvent_t evGatherStart = nullptr;                     // device 0: what was queued on its stream before a gather (the consumer of the previous frame)
     bool frameOk = true;                                    // false after a failed re-layout: idkptRender refuses until the next successful idkptSetSize
     int W = 0, H = 0;
@@ -84,6 +85,15 @@ __global__ void k_interleave_rows(const float4* stage, float4* full, int W, int 
 // (group-level errors reach the host's error callback here; a member's own error already did in fail(), so mfail only copies the message)
 static int gfail(idkpt_ctx* c, int code, const std::string& msg) { c->lastError = msg; if (c->n() == 1) c->dev[0]->lastError = msg; if (c->errFn) c->errFn(c->errUser, (int32_t)code, c->lastError.c_str()); return code; }
 static int mfail(idkpt_ctx* c, dev_ctx* m, int rc) { c->lastError = m->lastError; return rc; }
+// RCCL for the bulk device-to-device traffic of this context (scene replication, frame gather), or not: decided at the first use, reported by idkptGetTransportInfo
+static bool group_rccl(idkpt_ctx* c)
+{
+    if (c->n() < 2 || c->transportOpt == 1) return false;
+    if (!c->rccl.tried) { std::vector<int> devs; for (dev_ctx* m : c->dev) devs.push_back(m->device); (void)c->rccl.init(devs); }
+    return c->rccl.ready;
+}
+// a failing RCCL call: say so once, stop using RCCL on this context (the caller repeats the operation with peer copies)
+static void group_rccl_failed(idkpt_ctx* c) { fprintf(stderr, "[idkpt] warning: %s; this context uses peer copies from now on\n", c->rccl.lastError.c_str()); c->rccl.why = c->rccl.lastError; c->rccl.shutdown(); }
 #define GREQ(cond, msg) do { if (!(cond)) return gfail(c, IDKPT_ERR_INVALID_ARGUMENT, msg); } while (0)
 #define GHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); return gfail(c, IDKPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
 #define ONE(call) do { if (c->n() == 1) { dev_ctx* m = c->dev[0]; return call; } } while (0)
@@ -255,7 +265,7 @@ static int group_download_image(idkpt_ctx* c, int image, int slot, float* rgba, 
     return group_sync(c);
 }
 
-// member rows -> full frame on device 0 (peer copies; interleaved rows land in a staging area and are woven together by one kernel)
+// member rows -> full frame on device 0 (RCCL send / recv, or peer copies; interleaved rows land in a staging area and are woven together by one kernel)
 static int group_gather_device(idkpt_ctx* c, int image, int slot, void** outPtr, size_t* outBytes)
 {
     GREQ(image >= 0 && image < 3 && c->W > 0, "idkptGetImageDevicePtr: bad image / no size");
@@ -273,6 +283,22 @@ static int group_gather_device(idkpt_ctx* c, int image, int slot, void** outPtr,
     // the host ordered behind idkptGetStream): no member may write them before that work is done.
     GHIP(hipEventRecord(c->evGatherStart, m0->stream));
     if (c->peer.forceStaged) GHIP(hipEventSynchronize(c->evGatherStart));          // (staged copies land from the host, outside any stream order)
+    bool viaRccl = group_rccl(c) && !c->peer.forceStaged;
+    if (viaRccl) {
+        // grouped ncclSend (member d, behind its FinalDraw) / ncclRecv (device 0, behind evGatherStart by stream order); member 0's own rows are a local copy
+        std::vector<const void*> src(n); std::vector<void*> dst(n); std::vector<size_t> bytes(n); std::vector<int> devs(n); std::vector<hipStream_t> streams(n);
+        for (int d = 0; d < n; d++) {
+            dev_ctx* m = c->dev[d];
+            src[d] = image_ptr(m, image, slot); bytes[d] = (size_t)m->rows * rowBytes; devs[d] = m->device; streams[d] = m->stream;
+            dst[d] = c->strips ? (char*)c->full[image].p + (size_t)c->firstRow[d] * rowBytes : (char*)c->gatherStage.p + (size_t)rowOff[d] * rowBytes;
+            if (d > 0) { GHIP(hipSetDevice(m->device)); GHIP(hipStreamWaitEvent(m->stream, c->evGatherStart, 0)); }
+        }
+        GHIP(hipSetDevice(m0->device));
+        if (bytes[0]) GHIP(hipMemcpyAsync(dst[0], src[0], bytes[0], hipMemcpyDeviceToDevice, m0->stream));
+        if (!c->rccl.gather(src, dst, bytes, devs, streams)) { group_rccl_failed(c); viaRccl = false; }
+        else for (int d = 0; d < n; d++) { GHIP(hipSetDevice(c->dev[d]->device)); GHIP(hipEventRecord(c->evGather[d], c->dev[d]->stream)); }
+    }
+    if (!viaRccl)
     for (int d = 0; d < n; d++) {
         dev_ctx* m = c->dev[d];
         GHIP(hipSetDevice(m->device));
@@ -348,6 +374,7 @@ int32_t idkptDestroy(idkpt_ctx* c)
 {
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
     for (dev_ctx* m : c->dev) { (void)hipSetDevice(m->device); (void)hipStreamSynchronize(m->stream); }
+    c->rccl.shutdown();
     if (c->n() > 1) {
         for (size_t d = 0; d < c->n(); d++) {
             (void)hipSetDevice(c->dev[d]->device);
@@ -384,6 +411,24 @@ int32_t idkptSetErrorCallback(idkpt_ctx* c, idkpt_error_fn fn, void* user)
 }
 
 int32_t idkptGetContextDeviceCount(idkpt_ctx* c, int32_t* outCount) { if (!c || !outCount) return IDKPT_ERR_INVALID_ARGUMENT; *outCount = (int32_t)c->n(); return IDKPT_OK; }
+
+int32_t idkptGetTransportInfo(idkpt_ctx* c, int32_t* outKind, int32_t* outRanks, int32_t* outRcclVersion, const char** outDetail)
+{
+    if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
+    const bool rccl = group_rccl(c);               // (forms the communicators if that has not been tried yet: the answer is what the next upload / gather will use)
+    if (outKind) *outKind = c->n() < 2 ? IDKPT_TRANSPORT_NONE : (rccl ? IDKPT_TRANSPORT_RCCL : IDKPT_TRANSPORT_PEER_COPY);
+    if (outRanks) *outRanks = rccl ? (int32_t)c->rccl.comms.size() : 0;
+    if (outRcclVersion) *outRcclVersion = c->rccl.version;
+    if (outDetail) *outDetail = c->n() < 2 ? "one device: nothing travels" : (rccl ? c->rccl.api->path.c_str() : (c->transportOpt == 1 ? "peer copies by option" : c->rccl.why.c_str()));
+    return IDKPT_OK;
+}
+int32_t idkptTransportSelfTest(int32_t device, int32_t* outRcclVersion, char* outDetail, size_t detailBytes)
+{
+    std::string why;
+    const int32_t rc = rccl_self_test((int)device, outRcclVersion, &why);
+    if (outDetail && detailBytes) { snprintf(outDetail, detailBytes, "%s", rc == IDKPT_OK ? "ok" : why.c_str()); }
+    return rc;
+}
 
 int32_t idkptSetGroupSharding(idkpt_ctx* c, int32_t mode)
 {
@@ -474,6 +519,28 @@ int32_t idkptUploadScene(idkpt_ctx* c, const idkpt_scene_desc* scene)
     ONE(dev_UploadScene(m, scene));
     GFLUSH();
     { int rc = dev_UploadScene(c->dev[0], scene); if (rc) return mfail(c, c->dev[0], rc); }          // host -> device 0 (validated there)
+    // device 0 -> every other device: one ncclBroadcast per buffer over all members (RCCL), or member-by-member peer copies
+    if (c->transportOpt == 2 && !group_rccl(c)) return gfail(c, IDKPT_ERR_INVALID_OPERATION, "idkptUploadScene: option transport = 2 asks for RCCL, which is not usable here: " + c->rccl.why);
+    if (group_rccl(c)) {
+        const size_t n = c->n();
+        std::vector<std::vector<CloneItem>> items(n);
+        for (size_t d = 1; d < n; d++) { int rc = clone_prepare(c->dev[d], c->dev[0], items[d]); if (rc) return mfail(c, c->dev[d], rc); }
+        std::vector<int> devs; std::vector<hipStream_t> streams;
+        for (dev_ctx* m : c->dev) { devs.push_back(m->device); streams.push_back(m->stream); }
+        bool good = true;
+        for (size_t i = 0; i < items[1].size() && good; i++) {
+            std::vector<void*> dst(n); dst[0] = (void*)items[1][i].src;
+            for (size_t d = 1; d < n; d++) dst[d] = items[d][i].dst;
+            good = c->rccl.broadcast(dst, items[1][i].bytes, devs, streams);
+        }
+        if (!good) {   // (nothing of the scene is in use yet: the same buffers are filled again by peer copies)
+            group_rccl_failed(c);
+            for (size_t d = 1; d < n; d++) { dev_ctx* ctx = c->dev[d]; for (const CloneItem& it : items[d]) { if (member_copy(ctx->peer, it.dst, ctx->device, it.src, c->dev[0]->device, it.bytes, ctx->stream) != hipSuccess) return gfail(c, IDKPT_ERR_HIP, "idkptUploadScene: device-to-device copy failed"); } }
+        }
+        for (size_t d = 1; d < n; d++) { int rc = clone_finish(c->dev[d], c->dev[0]); if (rc) return mfail(c, c->dev[d], rc); }
+        (void)hipSetDevice(c->dev[0]->device);
+        return IDKPT_OK;
+    }
     for (size_t d = 1; d < c->n(); d++) { int rc = dev_CloneSceneFrom(c->dev[d], c->dev[0]); if (rc) return mfail(c, c->dev[d], rc); }   // device 0 -> device d
     return IDKPT_OK;
 }
@@ -489,6 +556,12 @@ int32_t idkptSetDeveloperOption(idkpt_ctx* c, const char* name, int32_t value)
 {
     if (!c || !name) return IDKPT_ERR_INVALID_ARGUMENT;
     if (c->n() > 1 && std::string(name) == "force_no_peer") { GFLUSH(); c->peer.forceStaged = value != 0; return IDKPT_OK; }   // device-to-device copies through pinned host memory
+    if (std::string(name) == "transport") {                                                                                   // how the members' bulk traffic travels (transport_rccl.hpp)
+        GREQ(value >= 0 && value <= 2, "idkptSetDeveloperOption: transport is 0 (RCCL where usable), 1 (peer copies) or 2 (RCCL required)");
+        if (c->n() > 1) GFLUSH();
+        c->transportOpt = value;
+        return IDKPT_OK;
+    }
     REPLICATE(SetOption, name, value);
 }
 int32_t idkptBuildTlas(idkpt_ctx* c, const GpuTlasNode* nodes, int32_t nodeCount) { REPLICATE_VERSIONED(BuildTlas, nodes, nodeCount); }

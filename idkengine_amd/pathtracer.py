@@ -16,7 +16,7 @@ from ._lib import IdkPtError
 
 # idkptSetDeveloperOption names; IDKPT_<NAME> in the environment is forwarded when a PathTracer is created (test / tuning hooks only)
 _OPTION_NAMES = ("force_generic", "no_tile_cull", "no_lean_primary", "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves", "grid_hint", "grid_rays_x4", "grid_mid_waves", "defer_last", "split", "split_donor", "split_peek", "group_threads", "query_scheduler", "split_scatter", "fused", "fused_shade_min", "leaf_pool", "pool_min", "adv_min",
-                 "wide", "wide_cap", "wide_count", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
+                 "wide", "wide_cap", "wide_count", "transport", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
 
 
 class PathTracer:
@@ -312,6 +312,19 @@ class PathTracer:
         new = proto(tramp)
         self._check(self._L.idkptSetBandExchangeDevice(self._ctx, new, None))
         self._bxdfn = new; del old     # keep the trampoline alive as long as the context uses it
+
+    def transport_info(self):
+        """idkptGetTransportInfo: how a multi-device context moves its bulk device-to-device traffic ('none' | 'peer-copy' | 'rccl'), the RCCL ranks, version, and the library path / the reason RCCL is not in use."""
+        kind = C.c_int32(); ranks = C.c_int32(); ver = C.c_int32(); detail = C.c_char_p()
+        self._check(self._L.idkptGetTransportInfo(self._ctx, C.byref(kind), C.byref(ranks), C.byref(ver), C.byref(detail)))
+        return {"transport": ("none", "peer-copy", "rccl")[kind.value], "rccl_ranks": ranks.value, "rccl_version": ver.value, "detail": (detail.value or b"").decode()}
+
+    @staticmethod
+    def transport_self_test(device=0):
+        """idkptTransportSelfTest: (status, rccl version, detail) of a one-rank RCCL round trip on `device`."""
+        L = _lib.load(); ver = C.c_int32(); buf = C.create_string_buffer(512)
+        rc = L.idkptTransportSelfTest(device, C.byref(ver), buf, 512)
+        return rc, ver.value, buf.value.decode()
 
     def synchronize(self):
         self._check(self._L.idkptSynchronize(self._ctx))

@@ -154,6 +154,19 @@ typedef struct idkpt_stats {
  * idkptSetRowRange + idkptSetBounceExchange (idkengine_amd/dist.py). */
 IDKPT_API int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** outCtx);
 IDKPT_API int32_t idkptGetContextDeviceCount(idkpt_ctx* ctx, int32_t* outCount);
+/* How the bulk device-to-device traffic of a multi-device context travels — the replication of the scene member 0 uploaded and the gather of the members' rows on
+ * device 0 (north_star: "RCCL broadcast of the BVH + gather of tiles over xGMI").  RCCL is probed at run time (dlopen of librccl.so, the NativeLibrary.TryLoad pattern of
+ * OIDN/OIDN.cs:11-20; the library does not link against it): one communicator per member (ncclCommInitAll), ncclBroadcast per scene buffer, grouped ncclSend / ncclRecv
+ * for the gather.  Where RCCL is absent, cannot form the communicators (two members on one GPU) or a call fails, the context uses xGMI peer copies (hipMemcpyPeerAsync)
+ * and reports why.  Developer option "transport": 0 (default) RCCL where usable, 1 peer copies, 2 RCCL or idkptUploadScene fails.  The tiny per-bounce count exchange of
+ * IDKPT_SHARD_STRIPS always uses peer copies ordered by events (4 bytes per sample: a collective launch would cost more than it moves).
+ * outKind: IDKPT_TRANSPORT_*; outRanks: ranks of the RCCL communicator (0 without RCCL); outRcclVersion: ncclGetVersion (0 if never loaded); outDetail: the library path, or
+ * the reason RCCL is not in use (valid until the next call on ctx).  Any out pointer may be NULL. */
+enum idkpt_transport { IDKPT_TRANSPORT_NONE = 0, IDKPT_TRANSPORT_PEER_COPY = 1, IDKPT_TRANSPORT_RCCL = 2 };
+IDKPT_API int32_t idkptGetTransportInfo(idkpt_ctx* ctx, int32_t* outKind, int32_t* outRanks, int32_t* outRcclVersion, const char** outDetail);
+/* Loads RCCL and runs a one-rank communicator on `device` through every call the transport uses (broadcast, send + recv, all-gather), checking the bytes: what a host
+ * — or a test on a one-GPU box — runs to know that the RCCL path is usable before it creates an N-device context.  outDetail (optional, detailBytes bytes): "ok" or the reason. */
+IDKPT_API int32_t idkptTransportSelfTest(int32_t device, int32_t* outRcclVersion, char* outDetail, size_t detailBytes);
 /* How a multi-device context deals the image rows to its devices (ignored by a one-device context):
  *   IDKPT_SHARD_ROWS    row y -> device y % N.  Balances sky rows against geometry rows.  Exact at any RayDepth with DoRaySorting off: up to RayDepth 2
  *                       nothing has to be exchanged (radiance does not depend on the queue slot there); beyond, the members' batches are enqueued by one
