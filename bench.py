@@ -268,7 +268,12 @@ def main():
             "higher_is_better": True, "scaling": "weak" if sample_parallel else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": reps, "repeat_ms": [round(x * 1e3, 3) for x in repeat_s], "statistic": "median repetition of the timed region",
             "traversed_mray_s": round(traversed_rep / dt / 1e6, 2),
-            "config": {"workload": (f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, {view_txt}" if args.scene == "soup" else
+            **transport_report(dist, world, group, pt, ranks_counted, one_device),
+            "config": {"headline_notes": ([f"{100.0 * (1.0 - traversed_rep / max(1.0, rays_rep)):.0f} % of the counted rays never enter the BVH: primary rays whose 8x8 tile or whose own root-box test misses the scene "
+                                          "(pre-classified sky; the same frame bit for bit) - the rate of the rays that do traverse is traversed_mray_s",
+                                          "defer_last=1: the continuation of the last bounce (next direction, throughput, queue) is produced on demand, not every frame - eager_last_bounce is the rate without it",
+                                          f"{B} samples in flight per launch - single_frame is the rate of a host that synchronises after every frame (SURVEY 8(d)'s protocol)"] if args.scene == "soup" and args.view == "headline" else None),
+                       "workload": (f"soup-{args.tris} (seeded random triangles, SweepSAH+PreSplit BVH, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, {view_txt}" if args.scene == "soup" else
                                      f"atrium-{args.tris} (procedural two-storey colonnaded hall, connected surfaces, {len(scene.blas_triangles)} BLAS triangles, 1 BLAS), {W}x{H}, 1 spp, RayDepth {depth}, sort {'on' if args.sort else 'off'}, white sky, camera inside looking down the hall"),
                        "rays_per_step": int(rays_rep / args.steps), "traversed_rays_per_step": int(traversed_rep / args.steps),
                        "samples_in_flight": B, "displayed_frame": f"{B} accumulated samples, then exchange + ResetAccumulation",
@@ -295,21 +300,52 @@ def main():
             pt.set_option("defer_last", 1)
             out["eager_last_bounce"] = {"mray_s": round(rays_rep / statistics.median(eager) / 1e6, 2), "ms_per_step": round(statistics.median(eager) / args.steps * 1e3, 4), "repeats": 3,
                                         "what": "the timed region re-run with idkptSetDeveloperOption(defer_last, 0): bit-identical frames and ray state, the last bounce's continuation computed every frame"}
-            out["single_frame"] = single_frame(pt, depth)
+            out["single_frame"] = safe(single_frame, pt, depth)
             if args.scene == "soup":
-                out["interior"] = interior_extras(S, pt, W, H, B)
-                out["atrium"] = atrium_extras(S, NativeBuilder, pt, W, H, B)
-                out["multi_blas"] = multi_blas_extras(S, NativeBuilder, pt, B)
-                out["animated"] = animated_extras(S, NativeBuilder, pt)
-                pt.UploadScene(scene)
-                out["queries"] = query_extras(S, pt, scene, cam)
-            pt.SetCamera(cam); pt.RayDepth = depth; pt.set_max_batch(B)
+                # secondary blocks: each one on its own — a failure inside one is reported in its place and costs neither the metric line nor the other blocks
+                out["interior"] = safe(interior_extras, S, pt, W, H, B)
+                out["atrium"] = safe(atrium_extras, S, NativeBuilder, pt, W, H, B)
+                out["multi_blas"] = safe(multi_blas_extras, S, NativeBuilder, pt, B)
+                if isinstance(out["multi_blas"], dict):
+                    out["multi_blas"]["atrium_per_mesh"] = safe(atrium_per_mesh_extras, S, NativeBuilder, pt, W, H, B)
+                out["animated"] = safe(animated_extras, S, NativeBuilder, pt)
+                safe(pt.UploadScene, scene)
+                out["wide_nodes"] = safe(wide_extras, S, NativeBuilder, pt, scene, cam, W, H, B)
+                safe(pt.UploadScene, scene)
+                out["queries"] = safe(query_extras, S, pt, scene, cam)
+            pt.UseTlas = 0; pt.SetCamera(cam); pt.RayDepth = depth; pt.set_max_batch(B)
         if world * group == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, scene, depth, args.view)
+            out["cpu_baseline"] = safe(cpu_baseline, S, scene, depth, args.view)
         print(json.dumps(out), flush=True)
     r.pt.Dispose()
     if world > 1:
         dist.destroy_process_group()
+
+
+def safe(fn, *a, **k):
+    """A secondary measurement must not cost the metric line: its failure is reported in its place."""
+    try:
+        return fn(*a, **k)
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        return {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
+
+
+def transport_report(dist, world, group, pt, ranks_counted, one_device):
+    """Top-level answer to "did RCCL carry the N > 1 run, and how many ranks did it see": torch.distributed ranks -> the backend and the count an all-reduce of ones
+    returned; one multi-device context -> idkptGetTransportInfo (RCCL communicator formed inside the library, or its peer copies and why)."""
+    if world > 1:
+        backend = dist.get_backend()
+        return {"transport": "rccl (torch.distributed, backend nccl)" if backend == "nccl" else f"{backend} (control-flow check: ranks share one GPU)" if one_device else backend,
+                "rccl_ranks_seen": ranks_counted if backend == "nccl" else None, "ranks": world}
+    if group > 1:
+        try:
+            info = pt.transport_info()
+            return {"transport": info["transport"] + (" (inside idkptCreate(N): ncclCommInitAll, ncclBroadcast of the scene, grouped ncclSend/ncclRecv gather)" if info["transport"] == "rccl" else f" ({info['detail']})"),
+                    "rccl_ranks_seen": info["rccl_ranks"] if info["transport"] == "rccl" else None, "ranks": group}
+        except Exception as e:   # noqa: BLE001
+            return {"transport": f"unknown ({e})", "rccl_ranks_seen": None, "ranks": group}
+    return {"transport": "none (one GPU)", "rccl_ranks_seen": None, "ranks": 1}
 
 
 def n_gpu_report(torch, dist, world, group, pt=None, st=None, B=None, depth=None, args=None, ranks_counted=None, selftest=None):
@@ -384,8 +420,8 @@ def pmc_passes(args, launches):
     import glob
     import shutil
     import tempfile
-    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if exe is None:
+    exe = os.environ.get("IDKPT_BENCH_ROCPROFV3") or shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)   # (the override: the test that takes the tool away)
+    if exe is None or not os.path.exists(exe):
         return None
     sets = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "l2": ["TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"],
             "sq": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES"]}   # issue side: what a cache-resident, coherent launch is limited by
@@ -475,6 +511,7 @@ def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, t
                                    "waves_per_launch": int(pmc.get("SQ_WAVES", 0))}
     else:
         out["pmc"] = None
+        out["pmc_reason"] = ("--no-pmc" if args.no_pmc else "not an N = 1 run" if world != 1 else "the rocprofv3 --pmc child passes did not produce counters for this launch schedule (rocprofv3 missing or failed): achieved / frac above are from HIP events alone")
     return out
 
 
@@ -543,6 +580,46 @@ def atrium_extras(S, NativeBuilder, pt, w, h, B):
              "samples_in_flight": B, "primary_hit_fraction": round(st["alive_counts"][1] / float(w * h), 4)}
         e["single_frame"] = single_frame(pt, depth, frames=20)
         out[f"atrium_{tris // 1000}k_depth{depth}"] = e
+    return out
+
+
+def wide_extras(S, NativeBuilder, pt, scene, cam, w, h, B):
+    """Secondary block: the wide-node walk (developer option "wide", csrc/kernels_wide.hpp: 4-wide quantised nodes derived from the reference's BVH2, rays it does not
+    vouch for re-traced by k_trace2; bit-identical frames, tests/test_gpu_wide.py) against the default on the three views — it is NOT the default: profiles/r05_wide_nodes.md."""
+    out = {"what": "option wide = 1 vs the default (k_trace2 alone): Mray/s with the bench's samples in flight and one frame at a time, rays re-traced by the exact kernel, and the walk's own fetch counts"}
+    atrium = S.atrium_scene(N_TRIS, NativeBuilder())
+    for name, sc, cm in (("headline", scene, cam), ("interior", scene, view_camera(S, "interior", w, h)), ("atrium", atrium, S.atrium_camera(w, h))):
+        pt.UploadScene(sc); pt.SetCamera(cm); pt.RayDepth = RAY_DEPTH
+        row = {}
+        for wide in (0, 1):
+            pt.set_option("wide", wide)
+            rays, dt = timed_batch(pt, B, 2 * B)
+            row["wide" if wide else "default"] = {"mray_s": round(rays / dt / 1e6, 1), "single_frame_mray_s": single_frame(pt, RAY_DEPTH, frames=12)["mray_s"]}
+        pt.set_option("wide", 1); pt.set_option("wide_count", 1); pt.set_max_batch(4); pt.reset_stats(); pt.ResetAccumulation()
+        for _ in range(4):
+            pt.Compute()
+        pt.synchronize(); st = pt.stats()
+        pt.set_option("wide_count", 0); pt.set_option("wide", 0)
+        row["per_step"] = {"wide_node_visits": int(st["wide_node_visits"] / 4), "leaf_records": int(st["wide_leaf_records"] / 4), "triangle_tests": int(st["wide_triangle_tests"] / 4),
+                           "rays_retraced_exactly": round(st["wide_flagged_rays"] / 4.0, 1), "rays": int(st["rays_traced"] / 4)}
+        row["speedup_batched"] = round(row["wide"]["mray_s"] / row["default"]["mray_s"], 3)
+        out[name] = row
+    return out
+
+
+def atrium_per_mesh_extras(S, NativeBuilder, pt, w, h, B):
+    """The atrium as the reference would hold it: one BLAS per mesh (87 BLASes, Bvh/BVH.cs:156), through the instance loop (the default) and through a TLAS built on
+    the device (idkptBuildTlasOnDevice), against the same triangles hoisted into one BLAS (atrium block)."""
+    sc = S.atrium_scene(N_TRIS, NativeBuilder(), per_mesh_blas=True)
+    out = {"workload": f"procedural atrium, {len(sc.blas_descs)} BLASes (one per mesh), {len(sc.blas_triangles)} BLAS triangles, {w}x{h}, RayDepth {RAY_DEPTH}, camera inside"}
+    pt.UploadScene(sc); pt.SetCamera(S.atrium_camera(w, h)); pt.RayDepth = RAY_DEPTH
+    for name, tlas in (("instance_loop", 0), ("tlas_built_on_device", 1)):
+        if tlas:
+            pt.BuildTlasOnDevice()
+        pt.UseTlas = tlas
+        rays, dt = timed_batch(pt, B, B, reps=3)
+        out[name] = {"mray_s": round(rays / dt / 1e6, 1), "ms_per_step": round(dt / B * 1e3, 4), "single_frame_mray_s": single_frame(pt, RAY_DEPTH, frames=8)["mray_s"]}
+    pt.UseTlas = 0
     return out
 
 

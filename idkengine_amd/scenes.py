@@ -427,12 +427,13 @@ def _grid_mesh(fn, nu, nv, material, flip=False):
     return MeshInput(P.reshape(-1, 3).astype(np.float32), tri.astype(np.uint32), material, n.reshape(-1, 3).astype(np.float32), t.reshape(-1, 3).astype(np.float32), uv)
 
 
-def atrium_scene(target_tris, builder, seed=7, sky_color=(1.0, 1.0, 1.0)):
+def atrium_scene(target_tris, builder, seed=7, sky_color=(1.0, 1.0, 1.0), per_mesh_blas=False):
     """A procedural two-storey colonnaded atrium (floor, outer walls with relief, two rows of columns on two levels, arches, gallery slabs,
     hanging drapes, vases) tessellated to about `target_tris` triangles in ONE BLAS: the layout of the Sponza atrium BASELINE.json's configs[1]
     and north_star's "Sponza-class scene" refer to (the reference checkout ships Sponza.gltf without its geometry buffer, so the real mesh is not
     available).  Unlike the random soup, surfaces are connected 2-manifolds with shared vertices, large empty spaces and occlusion.
-    Hall: x in [-18, 18] (long axis), z in [-7, 7], y in [0, 12]; open to the sky."""
+    Hall: x in [-18, 18] (long axis), z in [-7, 7], y in [0, 12]; open to the sky.
+    per_mesh_blas: one BLAS per mesh (87 of them) instead — the reference's default layout of a multi-mesh model without hoisting (Bvh/BVH.cs:156)."""
     rng = np.random.default_rng(seed)
     k = max(1.0, (target_tris / 42000.0) ** 0.5)                      # linear tessellation factor (the base model below has ~42 k triangles at k = 1)
 
@@ -471,6 +472,8 @@ def atrium_scene(target_tris, builder, seed=7, sky_color=(1.0, 1.0, 1.0)):
     for cx in np.linspace(-13.5, 13.5, 7):
         meshes.append(_grid_mesh(lambda u, v, cx=cx: (cx + (0.35 + 0.2 * np.sin(3.14159 * v) ** 2) * np.sin(3.14159 * v) ** 0.5 * np.cos(6.28318 * u), 0.05 + 1.3 * v,
                                                      (0.35 + 0.2 * np.sin(3.14159 * v) ** 2) * np.sin(3.14159 * v) ** 0.5 * np.sin(6.28318 * u)), q(16), q(10), bronze))
+    if per_mesh_blas:
+        return assemble([{"meshes": [m]} for m in meshes], builder, sky_color=sky_color)
     return assemble([{"meshes": meshes}], builder, sky_color=sky_color)
 
 
