@@ -388,14 +388,33 @@ IDKPT_API int32_t idkptEnableCounters(idkpt_ctx* ctx, int32_t enable);
 /* enable=1: record HIP events (on the context's stream) around each idkptRender and around every traversal-kernel launch */
 IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
 
-/* Tuning / test hooks — not part of the reference's interface (PathTracer.cs has no counterpart) and never needed for correct results: every option
- * leaves every output bit-identical (tests/test_gpu_worklist.py, tests/test_gpu_layout.py).  The library itself reads no environment variables; the
- * Python host mirror forwards IDKPT_<NAME> for the tests and tools.  Names (value): "force_generic" (0/1: thread-per-ray kernels instead of the
- * persistent traversal kernel), "no_tile_cull", "no_lean_primary" (0/1), "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves",
- * "grid_hint", "grid_rays_x4", "grid_mid_waves" (scheduling of the traversal kernel; grid_rays_x4: quarter-rays per lane a small launch's grid is sized for, default 6, 0 = off; grid_mid_waves: waves per CU of launches below 14 M rays, default 20, 0 = off), "defer_last" (0/1, default 1: without AOVs only the radiance of a sample's last bounce reaches the frame — that is computed every frame; the bounce's continuation, i.e. ray state, alive queue and counts, is produced when idkptDownloadRays / idkptDownloadAliveQueue or a scene update ask for it), "node_layout" (0 reference order [default], 1 line couples depth-first, 2 line couples in
- * treelets of "treelet_depth" levels), "trace_order" (0 queue order [default], 1 spatial order for batches of >= 4 samples, 2 always),
- * "bvh_timing", "bvh_small" (idkptBuildBlasCore), "bvh_stackopt_host" (idkptBuildBlas: force the host fallback of the stack-size optimisation), "force_no_peer" (0/1, multi-device contexts: stage every device-to-device copy through pinned
- * host memory, as on a node whose GPUs refuse peer access), "trace_variant" (developer build of the library only).  Unknown names fail. */
+/* Tuning / test hooks — not part of the reference's interface (PathTracer.cs has no counterpart) and never needed for correct results: every option leaves
+ * every output bit-identical (tests/test_gpu_worklist.py, test_gpu_wide.py, test_gpu_zz_random_api.py, tools/fuzz_parity.py draw them).  The library reads no
+ * environment variable; the Python host mirror forwards IDKPT_<NAME> for tests and tools.  Unknown names fail.  Every name, its values and its default:
+ *   which kernels a launch may be given
+ *     "force_generic"    0* / 1      thread-per-ray traversal kernels instead of the persistent k_trace2 (the tests' cross-check)
+ *     "split"            0-3 (1*)    k_trace2s, long rays split across idle lanes: 0 never, 1 small launches of sparse views, 2 always, 3 always + every split ray re-traced
+ *     "split_donor" 0 / 1*, "split_peek" >= 1 (64*), "split_scatter" 0-6 (6*)      its donor rule, how often a busy wave looks at the work list, hand-out granularity
+ *     "fused"            0-2 (1*)    k_trace_fused (FirstHit + shading + last NHit in one launch at RayDepth 2): 0 never, 1 small sparse launches, 2 wherever exact
+ *     "fused_shade_min"  1-64 (16*)  lanes that wait for its shading phase
+ *     "leaf_pool"        -1* / 0-7   pooled leaf phase of k_trace2 MODE 0: mask 1 primary launches, 2 first bounce, 4 later bounces; -1 by view class
+ *     "pool_min"         >= 0 (12*)  (ray, triangle) pairs a wave must have parked before they are pooled
+ *     "wide"             0* / 1      k_trace_wide: closest hits over the derived 4-wide nodes, unvouched rays re-traced by k_trace2 (csrc/wide_nodes.hpp; profiles/r05_wide_nodes.md)
+ *     "wide_cap"         0* / 4-96   rows of its per-lane stack (0 = 24)        "wide_count" 0* / 1   count its node / leaf-record / triangle fetches (idkpt_stats.Wide*)
+ *     "query_scheduler"  0 / 1*      idkptTraceRays through k_trace2's scheduler (0: thread-per-ray kernel, the cross-check)
+ *     "defer_last"       0 / 1*      without AOVs only the radiance of a sample's last bounce is computed per frame; its continuation when a host asks (idkptDownloadRays ...)
+ *     "no_tile_cull"     0* / 1      no per-tile pre-classification of sky tiles      "no_lean_primary" 0* / 1   k_gen_primary stores the full state of surviving rays
+ *   scheduling of the traversal kernels
+ *     "leaf_min"         0* / 1-64   lanes parked on a leaf before the node phase is left (0: 16 for batches of >= 4 samples, 12 below)
+ *     "adv_min"          0* / 1-64   MODE 1 / 2: lanes that enter the next instance / walk the TLAS together (0: 8 for batches of >= 4 samples, 1 below)
+ *     "grab_unit_log2"   6-24 (10*)  run length of a work-list slice        "grab_fixed" >= 0 (0*)   entries reserved per atomic (0: what the refill needs)
+ *     "trace_waves"      0* / n      one-wave workgroups per CU of the persistent grid (0: what LDS allows, at most 32)      "lds_pad" >= 0 (0*)   extra LDS bytes per workgroup
+ *     "grid_hint" (2*), "grid_rays_x4" (6*), "grid_mid_waves" (20*)   grid of a launch from the previous batch's counts: x the queue length; quarter-rays per lane; waves per CU below 14 M rays; 0 = off
+ *   multi-device contexts
+ *     "transport"        0* / 1 / 2  RCCL where usable / peer copies / RCCL or fail (idkptGetTransportInfo)      "force_no_peer" 0* / 1   stage device-to-device copies through pinned host memory
+ *     "group_threads"    -1* / 0 / 1 members' batches enqueued by one host thread each (-1: from 4 members on)
+ *   builder                "bvh_timing" 0* / 1 (phase times on stderr), "bvh_small" (32*), "bvh_stackopt_host" 0* / 1 (force the host fallback of OptimizeStackSize)
+ *   developer builds only  "trace_variant" (s_memtime-instrumented / probe instantiations: 107, 113, 116, 213, 901-904, 961, 962), "graph_probe"   (libidkpt_dev.so, -DIDKPT_DEVELOPER) */
 IDKPT_API int32_t idkptSetDeveloperOption(idkpt_ctx* ctx, const char* name, int32_t value);
 
 /* ---- interop (device pointers as void*, for RCCL gather of row shards by the host process) -- */

@@ -73,6 +73,8 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     out = sys.argv[3] if len(sys.argv) > 3 else None
     seeds = [int(x) for x in os.environ["FUZZ_SEEDS"].split(",")] if os.environ.get("FUZZ_SEEDS") else list(range(first, first + cases))
+    if os.environ.get("FUZZ_SAMPLER") == "llvmpipe":        # the checker's sampler in llvmpipe's arithmetic (ref_pathtracer.cpp ref_set_sampler_mode): what part of the textured cases' residue is the sampler's freedom
+        O.lib().ref_set_sampler_mode(1)
     builder = NativeBuilder()
     t0 = time.time(); reps = []
     for seed in seeds:
@@ -85,7 +87,7 @@ def main():
            "cases_with_a_flip_or_a_value_beyond_tolerance": [r["seed"] for r in reps if r["flips"] or r["beyond_tol"]], "seconds": round(time.time() - t0, 1),
            "textured_cases": sum(1 for r in reps if r["textured"]), "beyond_tol_in_textured_cases": sum(r["beyond_tol"] for r in reps if r["textured"]), "beyond_tol_in_untextured_cases": sum(r["beyond_tol"] for r in reps if not r["textured"]),
            "worst_throughput_or_radiance_error_beyond_tolerance": max([max(r["beyond_by_field"].get("Throughput", 0.0), r["beyond_by_field"].get("Radiance", 0.0)) for r in reps] + [0.0]),
-           "gate": {"rel_tol": glref_check.REL_TOL, "abs_floor": glref_check.ABS_FLOOR}}
+           "gate": {"rel_tol": glref_check.REL_TOL, "abs_floor": glref_check.ABS_FLOOR}, "checker_sampler": os.environ.get("FUZZ_SAMPLER") or "gl-spec"}
     print(json.dumps(tot))
     if out:
         json.dump({"total": tot, "cases": reps}, open(out, "w"), indent=1)

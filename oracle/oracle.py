@@ -60,6 +60,7 @@ def lib():
         L.ref_set_num_threads.argtypes = [C.c_int]; L.ref_get_max_threads.restype = C.c_int
         L.ref_cpu_trace_primary.restype = C.c_uint64
         L.ref_cpu_trace_primary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_set_sampler_mode.argtypes = [C.c_int]
         L.ref_pcg_hash.restype = C.c_uint32; L.ref_pcg_hash.argtypes = [C.POINTER(C.c_uint32)]
         L.ref_float_to_key.restype = C.c_uint32; L.ref_float_to_key.argtypes = [C.c_float]
         L.ref_morton30.restype = C.c_uint32; L.ref_morton30.argtypes = [C.c_float] * 3

@@ -238,11 +238,44 @@ static bool TraceRayAny(const Scene& s, const Ray& ray, HitInfo& hit, bool trace
 // ---- texture / sky sampling (stand-in for GL bindless samplers; DESIGN.md "Textures") ----
 // handle 0 = 1x1 white (Utils/ModelLoader.cs:1857-1877).  Bilinear, repeat wrap, LOD 0, texel centres at (i+0.5)/w.
 struct RGBA { float r, g, b, a; };
+// Sampler arithmetic of the checker (process-wide, ref_set_sampler_mode).  0 (default, what the HIP path implements): the filter as the GL specification writes it —
+// u * size - 0.5 on the unreduced coordinate, weights = its fraction, GLSL mix for the two lerps.  1: the same filter in the arithmetic Mesa llvmpipe uses for a
+// non-power-of-two REPEAT dimension of a float texture (lp_bld_sample_soa.c: the coordinate is reduced to [0, 1) FIRST — `coord = fract(coord)` — then unnormalised, and the
+// lerps are v0 + w * (v1 - v0)).  GL leaves both choices to the implementation; mode 1 exists to show that the few rays of textured cases beyond the 1e-4 gate against
+// llvmpipe are this freedom and nothing else (tests/test_glref.py, oracle/glref/fuzz_reference.py --sampler llvmpipe).
+static int g_sampler_mode = 0;
+extern "C" void ref_set_sampler_mode(int mode) { g_sampler_mode = mode; }
+static bool is_pot(int n) { return n > 0 && (n & (n - 1)) == 0; }
+static RGBA SampleTexLlvmpipe(const Scene::Tex& t, v2 uv)
+{
+    float w[2]; int i0[2], i1[2];
+    const float u[2] = {uv.x, uv.y}; const int n[2] = {t.w, t.h};
+    for (int a = 0; a < 2; a++) {
+        float c;
+        if (is_pot(n[a])) c = u[a] * (float)n[a] - 0.5f;                        // power of two: unnormalise, then wrap the integer coordinate with a mask
+        else { float f = u[a] - gfloor(u[a]); c = f * (float)n[a] - 0.5f; }     // otherwise: fract first
+        const float fl = gfloor(c);
+        w[a] = c - fl;
+        int k0 = (int)fl, k1 = k0 + 1;
+        k0 %= n[a]; if (k0 < 0) k0 += n[a];
+        k1 %= n[a]; if (k1 < 0) k1 += n[a];
+        i0[a] = k0; i1[a] = k1;
+    }
+    float c[4];
+    for (int k = 0; k < 4; k++) {
+        const float v00 = t.rgba[4 * ((size_t)i0[1] * t.w + i0[0]) + k], v01 = t.rgba[4 * ((size_t)i0[1] * t.w + i1[0]) + k];
+        const float v10 = t.rgba[4 * ((size_t)i1[1] * t.w + i0[0]) + k], v11 = t.rgba[4 * ((size_t)i1[1] * t.w + i1[0]) + k];
+        const float r0 = v00 + w[0] * (v01 - v00), r1 = v10 + w[0] * (v11 - v10);
+        c[k] = r0 + w[1] * (r1 - r0);
+    }
+    RGBA o = {c[0], c[1], c[2], c[3]}; return o;
+}
 static RGBA SampleTex(const Scene& s, uint64_t handle, v2 uv)
 {
     if (handle == 0 || handle > s.textures.size()) { RGBA w = {1, 1, 1, 1}; return w; }
     const Scene::Tex& t = s.textures[handle - 1];
     if (t.w == 1 && t.h == 1) { RGBA c = {t.rgba[0], t.rgba[1], t.rgba[2], t.rgba[3]}; return c; }
+    if (g_sampler_mode == 1) return SampleTexLlvmpipe(t, uv);
     float fx = uv.x * (float)t.w - 0.5f, fy = uv.y * (float)t.h - 0.5f;
     float x0f = gfloor(fx), y0f = gfloor(fy);
     float ax = fx - x0f, ay = fy - y0f;

@@ -55,18 +55,25 @@ def main():
         ids = [d % ndev for d in range(n)]
         log(f"one process, {ndev} visible device(s): " + ", ".join(f"{i}={torch.cuda.get_device_name(i)}" for i in range(ndev)))
         log(f"members -> devices {ids}; peer-access matrix over devices {sorted(set(ids))}: {peer_matrix(torch, sorted(set(ids)))}")
+        rc, ver, detail = PathTracer.transport_self_test(0)
+        log(f"RCCL self test on device 0 (one-rank communicator: broadcast, send / recv, all-gather): status {rc}, version {ver}, {detail}")
+        ok &= rc == 0
         for depth in (2, 5):
             want = one_device(depth, 3)
-            for no_peer in (0, 1):
+            for no_peer, transport in ((0, 0), (0, 1), (1, 1)):       # RCCL where the communicators can be formed (distinct devices); peer copies; host-staged copies
                 g = PathTracer(w, h, devices=ids)
-                g.set_option("force_no_peer", no_peer)
+                g.set_option("force_no_peer", no_peer); g.set_option("transport", transport)
                 g.UploadScene(sc); g.SetCamera(cam); g.RayDepth = depth; g.set_max_batch(2)
                 for _ in range(3):
                     g.Compute()
                 same = bool((bits(g.Result) == bits(want)).all())
-                log(f"RayDepth {depth}, {'host-staged copies' if no_peer else 'peer copies'}: {n}-member context == 1 device: {same}")
-                ok &= same
-                if depth > 2 and not no_peer:        # round 2's deal: contiguous strips + device-side, event-ordered count exchange (no host synchronisation)
+                ptr, nbytes = g.image_device_ptr(0); g.synchronize()      # the gather of the members' rows on device 0 runs too
+                info = g.transport_info()
+                log(f"RayDepth {depth}, transport {info['transport']} ({info['rccl_ranks']} RCCL ranks; {info['detail']}){', host-staged copies' if no_peer else ''}: {n}-member context == 1 device: {same}")
+                ok &= same and nbytes == w * h * 16
+                if transport == 0 and len(set(ids)) == len(ids) and len(ids) > 1:
+                    ok &= info["transport"] == "rccl" and info["rccl_ranks"] == len(ids)          # on a real N-GPU node RCCL must have carried this run
+                if depth > 2 and not no_peer and transport == 1:        # round 2's deal: contiguous strips + device-side, event-ordered count exchange (no host synchronisation)
                     g.SetGroupSharding(2)            # (a change of layout restarts the accumulation)
                     for _ in range(3):
                         g.Compute()
