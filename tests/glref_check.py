@@ -209,11 +209,17 @@ def check_traversal_cost(fx, pairs, tri_tests):
     return {"pairs_plus_1.1_tests": mine, "reference_debugCost_sum": ref, "relative_difference": abs(mine - ref) / ref}
 
 
-# Random cases through the reference's shaders (oracle/glref/fuzz_reference.py): what may lie beyond the 1e-4 gate, and why.  llvmpipe's bilinear `texture()` and the
-# restated filter differ by up to 1.5e-4 absolute on one or two texels of a frame (GL leaves the precision of the filter weights to the implementation; hardware
-# samplers use 8-bit sub-texel weights, 2e-3), and a small throughput / radiance component turns that into a larger RELATIVE error.  So: textured cases only, at most
-# one ray in 10 000 of a run, at most 3e-3 in throughput / radiance (1 400 seeds of round 3: 7e-5 of the rays, worst 2.6e-3; profiles/r03_reference_fuzz*.json).
-# Untextured cases get no allowance here (the two lobe flips of those 1 400 seeds are outside the 60 seeds this gate runs on).
+# Random cases through the reference's shaders (oracle/glref/fuzz_reference.py): what may lie beyond the 1e-4 gate on TEXTURED cases, and why.  Round 5 measured it
+# (profiles/r05_raw/reference_fuzz_1400_*.json, 1 400 seeds, 7.2 M rays, 430 textured cases):
+#   * it is NOT the sampler: llvmpipe's bilinear filter agrees with the GL-specification arithmetic of the oracle / the HIP path to 1.2e-7 on power-of-two textures and to
+#     2e-5 (|uv| <= 64) on the others (it reduces the coordinate to [0, 1) first); with the oracle's sampler switched to llvmpipe's arithmetic (ref_set_sampler_mode(1),
+#     which reproduces llvmpipe's texels to 2 ulp) the rays beyond the gate are the same: 480 -> 483;
+#   * it IS the textures' contrast: the fuzz draws 1..8 x 1..8 texels of uniform noise in [0, 1] — up to 8 units of value per unit of uv — and every quantity that enters a
+#     lookup (hit point, interpolated uv) carries the few-ulp freedom GLSL leaves the driver.  The same 1 400 cases with the textures' contrast scaled to 0.02 about 0.5:
+#     480 -> 11 textured rays beyond the gate, i.e. the rate of untextured cases (22, the two lobe flips and their followers).
+# So the allowance below is a bound on (texture gradient) x (input difference inside the gate), for the noise textures of the fuzz: textured cases only, at most one ray in
+# 10 000 of a run, at most 3e-3 in throughput / radiance (1 400 seeds: 6.7e-5 of the rays).  The same cases at contrast 0.02 get NO allowance (tests/test_glref.py), nor do
+# untextured cases (the lobe flips of those 1 400 seeds are outside the 60 seeds the gate runs on).
 SAMPLER_SPREAD_ALLOW = {"max_fraction_of_rays": 1e-4, "max_throughput_or_radiance_error": 3e-3, "untextured_rays_beyond": 0, "alive_flips": 0, "key_diffs": 0}
 FULL_ALLOW_FREE = {"full_headline_d2": 8, "full_atrium1m_d2": 9}     # pixels of the free-running two-sample frame beyond tolerance: pixels of the listed closest-hit rays
 

@@ -192,3 +192,18 @@ def test_live_reference_fuzz_textured_cases_within_the_sampler_spread():
     assert tot["beyond_tol_in_textured_cases"] <= A["max_fraction_of_rays"] * tot["rays"], tot
     assert tot["worst_throughput_or_radiance_error_beyond_tolerance"] <= A["max_throughput_or_radiance_error"], tot
     assert set(tot["worst_error_of_the_rays_beyond_tolerance_by_field"]) <= {"Throughput", "Radiance"}, tot       # (no origin, no direction: no other lobe, no other hit)
+
+
+@live
+def test_live_reference_fuzz_textured_residue_is_texture_contrast_not_the_sampler():
+    """The same 60 cases twice more: (a) with the textures' contrast scaled to 0.02 about 0.5 — the textured cases then sit inside the plain 1e-4 gate like the untextured
+    ones, no allowance; (b) at full contrast with the oracle's sampler switched to llvmpipe's own arithmetic (coordinate reduced to [0, 1) first, lerp as v0 + w (v1 - v0)) —
+    the rays beyond the gate do not go away.  Together: what SAMPLER_SPREAD_ALLOW covers is (texture gradient) x (input differences inside the gate), not filter weights."""
+    def run(env):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "fuzz_reference.py"), "60", "0"], capture_output=True, text=True, timeout=1500, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    flat = run({"FUZZ_TEX_CONTRAST": "0.02"})
+    assert flat["textured_cases"] >= 15 and flat["beyond_tol"] == 0 and flat["flips"] == 0 and flat["key_diffs"] == 0, flat
+    llvm = run({"FUZZ_SAMPLER": "llvmpipe"})
+    assert llvm["checker_sampler"] == "llvmpipe" and llvm["beyond_tol_in_textured_cases"] >= 6 and llvm["beyond_tol_in_untextured_cases"] == 0, llvm

@@ -79,6 +79,8 @@ def random_scene(rng, builder):
         sc.sky_faces = faces
     if use_tex:
         sc.textures = [rng.uniform(0.0, 1.0, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), 4)).astype(np.float32) for _ in range(3)]
+        if os.environ.get("FUZZ_TEX_CONTRAST"):      # (oracle/glref/fuzz_reference.py: the same cases with the textures' contrast scaled about 0.5 — how much of a residue is texture gradient x input difference)
+            sc.textures = [(np.float32(0.5) + (t - np.float32(0.5)) * np.float32(float(os.environ["FUZZ_TEX_CONTRAST"]))).astype(np.float32) for t in sc.textures]
     return sc, extent, lights is not None, nb
 
 
