@@ -19,6 +19,7 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
+#include <functional>
 
 // Interleaved rows / bands beyond RayDepth 2 (round 4): a band's slot base counts the alive rays of ALL members in the image bands before it — also of members that are
 // enqueued later — so the members' batches cannot be enqueued one after the other as the strips' are.  They are enqueued by one host thread per member, and the
@@ -36,6 +37,42 @@ struct GroupBarrier {
         return !aborted;
     }
     void abort() { std::lock_guard<std::mutex> l(m); aborted = true; cv.notify_all(); }
+};
+// One host thread per member, kept for the lifetime of the context (created at the first threaded flush): a flush hands every worker its member's batch and waits
+// for all of them — no thread creation per flush (a deep-path frame flushes once per batch of samples; round 4 spawned and joined N threads each time).
+struct GroupWorkers {
+    std::vector<std::thread> th;
+    std::mutex m; std::condition_variable cvGo, cvDone;
+    unsigned epoch = 0; int remaining = 0; bool quit = false;
+    std::function<void(size_t)> job;
+    void start(size_t n)
+    {
+        if (!th.empty()) return;
+        for (size_t d = 0; d < n; d++)
+            th.emplace_back([this, d]() {
+                unsigned seen = 0;
+                for (;;) {
+                    std::function<void(size_t)> j;
+                    { std::unique_lock<std::mutex> l(m); cvGo.wait(l, [&] { return quit || epoch != seen; }); if (quit) return; seen = epoch; j = job; }
+                    j(d);
+                    { std::lock_guard<std::mutex> l(m); if (--remaining == 0) cvDone.notify_all(); }
+                }
+            });
+    }
+    void run(const std::function<void(size_t)>& j)       // every worker runs j(its index); returns when all are done
+    {
+        std::unique_lock<std::mutex> l(m);
+        job = j; remaining = (int)th.size(); epoch++;
+        cvGo.notify_all();
+        cvDone.wait(l, [&] { return remaining == 0; });
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> l(m); quit = true; }
+        cvGo.notify_all();
+        for (std::thread& t : th) if (t.joinable()) t.join();
+        th.clear();
+    }
 };
 struct idkpt_ctx;
 struct GroupBandUser { idkpt_ctx* c; int d; };
@@ -57,6 +94,7 @@ struct idkpt_ctx {
     std::vector<std::array<hipEvent_t, MAX_DEPTH_SLOTS>> evBounce;
     std::vector<hipEvent_t> evFlushDone, evGather; std::vector<char> flushDoneValid;
     std::vector<DevBuf> peerStage, gbase;                   // on member d: the lower members' per-sample bases of the current bounce; the summed slot bases
+    GroupWorkers workers;                                   // one enqueuing thread per member (threaded flushes)
     GroupBarrier bar; std::vector<GroupBandUser> bandUser; std::vector<std::vector<uint32_t>> bandCounts; std::vector<int> bandLB;   // interleaved layouts beyond RayDepth 2 (group_band_exchange)
     DevBuf full[3], gatherStage, rowOffDev;                 // on device 0: gathered full-frame images; landing zone of the interleaved rows; first landing row of every member
     size_t n() const { return dev.size(); }
@@ -162,16 +200,14 @@ static int group_flush(idkpt_ctx* c)
     if (threaded) {
         c->bar.reset((int)c->n());
         std::vector<int> rcs(c->n(), IDKPT_OK);
-        std::vector<std::thread> th;
-        for (size_t d = 0; d < c->n(); d++)
-            th.emplace_back([c, d, &rcs]() {
-                dev_ctx* m = c->dev[d];
-                int rc = hipSetDevice(m->device) == hipSuccess ? IDKPT_OK : IDKPT_ERR_HIP;
-                if (rc == IDKPT_OK) { m->inGroupFlush = true; rc = flush_batch(m); m->inGroupFlush = false; }
-                rcs[d] = rc;
-                if (rc) c->bar.abort();                                      // (the others leave their exchanges and finish; the group reports this member's error)
-            });
-        for (std::thread& t : th) t.join();
+        c->workers.start(c->n());
+        c->workers.run([c, &rcs](size_t d) {
+            dev_ctx* m = c->dev[d];
+            int rc = hipSetDevice(m->device) == hipSuccess ? IDKPT_OK : IDKPT_ERR_HIP;      // (the current device is per host thread: set on every job, the member list may be any ids)
+            if (rc == IDKPT_OK) { m->inGroupFlush = true; rc = flush_batch(m); m->inGroupFlush = false; }
+            rcs[d] = rc;
+            if (rc) c->bar.abort();                                          // (the others leave their exchanges and finish; the group reports this member's error)
+        });
         (void)hipSetDevice(c->dev[0]->device);
         for (size_t d = 0; d < c->n(); d++) if (rcs[d]) { for (dev_ctx* o : c->dev) o->pending.clear(); c->pending = 0; return mfail(c, c->dev[d], rcs[d]); }
         c->pending = 0;
@@ -374,6 +410,7 @@ int32_t idkptDestroy(idkpt_ctx* c)
 {
     if (!c) return IDKPT_ERR_INVALID_ARGUMENT;
     for (dev_ctx* m : c->dev) { (void)hipSetDevice(m->device); (void)hipStreamSynchronize(m->stream); }
+    c->workers.stop();
     c->rccl.shutdown();
     if (c->n() > 1) {
         for (size_t d = 0; d < c->n(); d++) {

@@ -48,7 +48,7 @@ struct Node {
     uint32_t qlo[3];           // per axis: byte k = lower bound of child k in cells from the origin, rounded down
     uint32_t qhi[3];           // per axis: byte k = upper bound of child k, rounded up
     uint32_t child[4];         // internal child: index of its wide node (BLAS-local); leaf child: LEAF_BIT | offset of its leaf record in 16-byte units (BLAS-local)
-    uint32_t ref01, ref23;     // BVH2 node ids (BLAS-local) of the children, 16 bits each where they fit (diagnostics only; 0xffff = does not fit)
+    uint32_t pad[2];           // zero
 };
 static_assert(sizeof(Node) == 64, "wide node is one 64-byte block");
 
@@ -181,10 +181,8 @@ inline HostBuild build_host(const Bvh2Node* nodes, uint32_t nodeCount, const flo
         uint32_t ids[4]; const int n = expand_pair(nodes, B.pairOf[i], ids);
         Node w; memset(&w, 0, sizeof w);
         quantize_node(nodes, ids, n, &w);
-        uint16_t r16[4] = {0xffff, 0xffff, 0xffff, 0xffff};
         for (int k = 0; k < n; k++) {
             const Bvh2Node& c = nodes[ids[k]];
-            r16[k] = ids[k] < 0xffffu ? (uint16_t)ids[k] : 0xffffu;
             if (c.triCount == 0u) { w.child[k] = (uint32_t)B.pairOf.size(); B.pairOf.push_back(c.startOrChild); }
             else {
                 w.child[k] = LEAF_BIT | (uint32_t)(B.leafRecs.size() / 4);
@@ -196,7 +194,6 @@ inline HostBuild build_host(const Bvh2Node* nodes, uint32_t nodeCount, const flo
                 for (uint32_t t = 0; t < c.triCount; t++) { const uint32_t m = outside_leaf_box(c, tv + 12 * (size_t)t) ? 1u : 0u; memcpy(&B.leafRecs[at + 12 * (size_t)t + 3], &m, 4); }
             }
         }
-        w.ref01 = r16[0] | ((uint32_t)r16[1] << 16); w.ref23 = r16[2] | ((uint32_t)r16[3] << 16);
         B.nodes.push_back(w);
     }
     return B;
