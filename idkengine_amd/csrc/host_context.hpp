@@ -47,6 +47,13 @@ struct DevOptions {
                                  // 0.5-0.8x one frame at a time (the re-trace launch has its own latency floor).  Bit-identical results either way (tests/test_gpu_wide.py).
     int wideCap = 0;             // ... rows of its per-lane stack (0: 24; a ray that needs more is re-traced by k_trace2)
     int wideCount = 0;           // ... count node visits / leaf records / triangle tests (idkpt_stats.Wide*)
+    int instTlas = 8;            // k_trace_inst (kernels_trace_inst.hpp): scenes of at least this many BLAS instances rendered WITHOUT UseTlas (the reference's instance loop, its default) are walked
+                                 // through a TLAS the library builds for itself; rays whose result could depend on the loop's order are traced again by the exact loop.  0 = the loop only.
+                                 // Measured (round 5, profiles/r05_instance_tlas.md): the atrium as 87 BLASes 453 -> 1 641 Mray/s (3.6x; one frame at a time 363 -> 1 029), 0.3 % of the
+                                 // rays traced again.  Bit-identical hits either way (tests/test_gpu_inst_tlas.py, tools/fuzz_parity.py).
+    int instTlasOverlap = 10;    // ... only where the instances' boxes overlap little: a random line through the scene meets at most this many PERCENT of them (k_tlas_build measures it).
+                                 // 64 clusters at 5 / 10 / 20 / 30 %: the tree is 2.2x / 1.7x / 1.1x / 0.8x the loop seen from outside and 1.6x / 0.77x / 0.7x / 0.7x seen from inside;
+                                 // soup-1M in 12 / 60 interleaved parts (72 / 37 %): 0.73-0.89x / 0.87-1.03x; the atrium's 87 meshes: 2.7 %.  100 = whatever the overlap
     int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
 };
 
@@ -86,6 +93,10 @@ struct dev_ctx {
     int hInst0Blas = 0;                              // BlasId of instance 0 (MODE 0 traverses that BLAS)
     // wide nodes (kernels_wide.hpp): derived per BLAS from nodes + triVerts.  wideTopoValid: the children lists match the node topology; wideFillValid: boxes / leaf records match the current boxes and positions
     DevBuf wnodes, wleaf, wids, wpair, wcounts, wtotals; std::vector<uint32_t> wNodeOff, wLeafOff; bool wideTopoValid = false, wideFillValid = false;
+    // the library's own TLAS for the instance loop (kernels_trace_inst.hpp): padded PLOC tree over the instances, and the per-triangle "not contained in its leaf box" marks;
+    // both derived on the device before the first batch that wants them and after everything that moves boxes, positions or transforms
+    DevBuf itlas, imarks, ichunks; int itlasNeed = 1; uint32_t ichunkCount = 0; bool itlasValid = false, imarksValid = false;
+    float* hInstOverlap = nullptr; float* dInstOverlap = nullptr; bool instOverlapKnown = false, itlasBuilt = false;   // host-mapped: instance boxes a random line meets (k_tlas_build); known = read at least once since the upload
     // scene versions: slot count a versioned buffer may grow to, per buffer the bytes of one state / the slot pitch / the slots its arena holds / the current slot
     int verSlots = 1; size_t vbytes[VB_COUNT] = {0}, vstride[VB_COUNT] = {0}; int valloc[VB_COUNT] = {1, 1, 1, 1, 1}, vcur[VB_COUNT] = {0};
     uint64_t lastMask[VB_COUNT] = {0};               // slots the last launched batch reads (a deferred last bounce still does: finish_deferred)

@@ -9,10 +9,12 @@ static int wide_stack_rows(const dev_ctx* ctx) { return std::min(96, std::max(4,
 // (re-)derives what is stale: the children lists after an upload / a node patch (k_wide_topo, one workgroup per BLAS), box bytes and leaf records after anything that
 // moved boxes or positions (k_wide_fill).  Stream-ordered in front of the batch that is about to be launched; with one scene version every update launches the queued samples first.
 static char* vb_ptr(dev_ctx* ctx, int b, int slot);
+// totals of the optional walks since idkptResetStats (idkpt_stats.Wide*, InstTlasFlaggedRays): eight 64-bit words, zeroed when first needed
+static int totals_ensure(dev_ctx* ctx) { if (!ctx->wtotals.p) { HIPC(ctx->wtotals.ensure(64)); HIPC(hipMemsetAsync(ctx->wtotals.p, 0, 64, ctx->stream)); } return IDKPT_OK; }
 static int wide_prepare(dev_ctx* ctx)
 {
     if (ctx->wideTopoValid && ctx->wideFillValid) return IDKPT_OK;
-    if (!ctx->wtotals.p) { HIPC(ctx->wtotals.ensure(64)); HIPC(hipMemsetAsync(ctx->wtotals.p, 0, 64, ctx->stream)); }
+    { int rc = totals_ensure(ctx); if (rc) return rc; }
     const size_t nb = ctx->hDescs.size();
     hipStream_t st = ctx->stream;
     const float4* nodes = (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]);
@@ -46,6 +48,60 @@ static int wide_prepare(dev_ctx* ctx)
     return IDKPT_OK;
 }
 
+// ---- the library's own TLAS for the instance loop (kernels_trace_inst.hpp) ---------------------------------------------------------------------------------------
+// Several instances, no UseTlas, closest hit, one scene version, the reference's counters not asked for: everything else keeps the exact loop (k_trace2 MODE 1).
+static bool inst_tlas_wanted(const dev_ctx* ctx)
+{
+    return ctx->opt.instTlas > 0 && ctx->instanceCount >= std::max(2, ctx->opt.instTlas) && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters
+           && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);
+}
+// derives what is stale and decides whether the next batch walks the tree (*use): the instances' overlap is measured on the device into host-mapped memory; the first
+// measurement after an upload is waited for, later ones (animated transforms) are read whenever they have arrived — the decision only moves time, never a result
+static int inst_tlas_prepare(dev_ctx* ctx, bool* use)
+{
+    *use = false;
+    { int rc = totals_ensure(ctx); if (rc) return rc; }
+    hipStream_t st = ctx->stream;
+    const float4* nodes = (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]);
+    const int n = ctx->instanceCount, nodeCount = 2 * n - 1;
+    if (!ctx->hInstOverlap) { HIPC(hipHostMalloc((void**)&ctx->hInstOverlap, 64, hipHostMallocMapped)); *ctx->hInstOverlap = 0.0f; HIPC(hipHostGetDevicePointer((void**)&ctx->dInstOverlap, ctx->hInstOverlap, 0)); }
+    if (!ctx->itlasValid) {
+        const size_t leafOff = (size_t)nodeCount * 32, keyOff = leafOff + (size_t)n * 32, prefOff = keyOff + (size_t)n * 4;
+        HIPC(ctx->tlasScratch.ensure(prefOff + (size_t)n * 4)); HIPC(ctx->itlas.ensure((size_t)nodeCount * 32));
+        char* sc = ctx->tlasScratch.as<char>();
+        const float4* xf = (const float4*)vb_ptr(ctx, VB_XFORMS, ctx->vcur[VB_XFORMS]);
+#define ITLAS_BUILD(leavesOnly) hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, 15 /* TLAS.cs: SearchRadius */, \
+                                                   ctx->itlas.as<float4>(), (float4*)sc, (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff), 1, ctx->dInstOverlap, leavesOnly)
+        ITLAS_BUILD(1);                                                       // the overlap of the boxes as they are now
+        HIPC(hipGetLastError());
+        if (!ctx->instOverlapKnown) { HIPC(hipStreamSynchronize(st)); ctx->instOverlapKnown = true; }
+        const bool worth = ctx->opt.instTlasOverlap >= 100 || *(volatile float*)ctx->hInstOverlap * 100.0f <= (float)ctx->opt.instTlasOverlap * (float)n;
+        if (worth) { ITLAS_BUILD(0); HIPC(hipGetLastError()); }
+#undef ITLAS_BUILD
+        ctx->itlasBuilt = worth;
+        ctx->itlasNeed = std::min(TLAS_STACK_SIZE, std::max(1, n));          // (a ray that needs more rows is traced by the exact loop)
+        ctx->itlasValid = true;
+    }
+    if (!ctx->itlasBuilt) return IDKPT_OK;
+    if (!ctx->imarksValid) {
+        if (ctx->ichunkCount == 0) {   // the flattened (BLAS, chunk of 256 nodes) table: once per upload
+            std::vector<uint32_t> tab;
+            for (size_t b = 0; b < ctx->hDescs.size(); b++) for (int first = 0; first < ctx->hDescs[b].NodeCount; first += 256) { tab.push_back((uint32_t)b); tab.push_back((uint32_t)first); }
+            ctx->ichunkCount = (uint32_t)(tab.size() / 2);
+            HIPC(ctx->ichunks.ensure(tab.size() * 4 + 8));
+            if (!tab.empty()) { HIPC(hipMemcpyAsync(ctx->ichunks.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }   // (tab is a stack vector)
+        }
+        HIPC(ctx->imarks.ensure((size_t)std::max(1, ctx->triCount)));
+        HIPC(hipMemsetAsync(ctx->imarks.p, 0, (size_t)std::max(1, ctx->triCount), st));
+        if (ctx->ichunkCount) hipLaunchKernelGGL(k_mark_triangles, dim3(ctx->ichunkCount), dim3(256), 0, st, nodes, (const float4*)vb_ptr(ctx, VB_TRIVERTS, ctx->vcur[VB_TRIVERTS]), ctx->descs.as<GpuBlasDesc>(),
+                                                 (const uint2*)ctx->ichunks.as<uint2>(), ctx->imarks.as<uint8_t>());
+        HIPC(hipGetLastError());
+        ctx->imarksValid = true;
+    }
+    *use = true;
+    return IDKPT_OK;
+}
+
 // One traversal launch over `list` (cnt entries, on the device): the instantiation of k_trace2 — or k_trace2s / k_trace_wide — that serves this scene, these settings and this launch.
 // The shipped instantiations (everything else the template can express is unreachable from here):
 //   k_trace2<P, C, 32, 1, false, 24, 0, 0 | 16, V>   one BLAS instance (MODE 0), plain or pooled leaf phase       P: primary / bounce launch, C: counting build, V: scene versions
@@ -53,6 +109,7 @@ static int wide_prepare(dev_ctx* ctx)
 //   k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>   any-hit queries (idkptTraceRays with IDKPT_TRACE_ANY_HIT), M = 0 / 1 / 2
 //   k_trace2s<P>                                      small launches of sparse views: long rays split across idle lanes (kernels_trace_split.hpp)
 //   k_trace_wide<P, C'> + k_trace2<P, false>          option "wide": the wide-node walk and the exact re-trace of the rays it does not vouch for (kernels_wide.hpp)
+//   k_trace_inst<P> + k_trace2<P, false, 16, .., 1>   option "inst_tlas" (default: from 8 instances on): the instance loop through the library's own TLAS + the exact loop for flagged rays
 // Developer builds (-DIDKPT_DEVELOPER, option "trace_variant") add the s_memtime-instrumented and the scheduling-probe instantiations.
 template <bool PRIMARY>
 static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t st, const DScene& s, const Frame& f, const RayBufs& rays, const TraceBufs& tr, const HitBufs& hits,
@@ -82,6 +139,18 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         if (!PRIMARY) { trf.order = wb.flagA; trf.orderIdx = wb.flagB; }        // position -> queue slot and ray id (the hit is stored at the slot, as always)
         Frame ff = f; ff.gridRaysX4 = 6u; ff.gridMid = 0u;                       // (the device sizes the launch from its actual count: k_trace2's own rule)
         hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(std::min<uint32_t>(grid, 2048u)), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)wb.flagA, (const uint32_t*)wb.flagCount, work + 64, counters);
+        return;
+    }
+    if (f.instTlas && ctx->itlasValid && ctx->itlasBuilt && ctx->imarksValid && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid && !ctx->counters) {
+        // the instance loop through the library's own TLAS (kernels_trace_inst.hpp), then — on the launch's own list of flagged rays — the exact loop
+        InstTlasBufs ib;
+        ib.tlas = (const float4*)ctx->itlas.as<float4>(); ib.marks = (const uint8_t*)ctx->imarks.as<uint8_t>(); ib.tlasCap = ctx->itlasNeed;
+        ib.flagCount = work + 128; ib.flagA = ctx->sortKeys.as<uint32_t>(); ib.flagB = ctx->sortVals.as<uint32_t>(); ib.totals = ctx->wtotals.as<unsigned long long>() + 4;
+        hipLaunchKernelGGL((k_trace_inst<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, ib);
+        TraceBufs trf = tr; trf.order = nullptr; trf.orderIdx = nullptr;
+        if (!PRIMARY) { trf.order = ib.flagA; trf.orderIdx = ib.flagB; }
+        Frame ff = f; ff.gridRaysX4 = 6u; ff.gridMid = 0u;
+        hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 24, 1, 0, false>), dim3(std::min<uint32_t>(grid, 2048u)), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)ib.flagA, (const uint32_t*)ib.flagCount, work + 64, counters);
         return;
     }
     if (split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && !ctx->counters && ctx->sceneNested && stock) {   // small launch: long rays are split across idle lanes (kernels_trace_split.hpp)

@@ -121,7 +121,7 @@ static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
     if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113 || ctx->opt.traceVariant == 116 || ctx->opt.traceVariant == 213) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu | leafTests %llu leafTrips %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13], (unsigned long long)d[14], (unsigned long long)d[15]); }
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
-    if (ctx->wtotals.p) { uint64_t w[4] = {0, 0, 0, 0}; HIPC(hipMemcpyAsync(w, ctx->wtotals.p, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); s.WideFlaggedRays = w[0]; s.WideNodeVisits = w[1]; s.WideLeafRecords = w[2]; s.WideTriangleTests = w[3]; }
+    if (ctx->wtotals.p) { uint64_t w[5] = {0, 0, 0, 0, 0}; HIPC(hipMemcpyAsync(w, ctx->wtotals.p, 40, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); s.WideFlaggedRays = w[0]; s.WideNodeVisits = w[1]; s.WideLeafRecords = w[2]; s.WideTriangleTests = w[3]; s.InstTlasFlaggedRays = w[4]; }
     *out = s;
     return IDKPT_OK;
 }

@@ -4,15 +4,15 @@
 // One handle, N GPUs (north_star: "tiles of the framebuffer optionally sharded across the 8 GPUs of one node ... broadcast of the BVH +
 // gather of tiles over xGMI"; the reference itself is single-GPU, Source/EntryPoint.cs:10-33):
 //   * every device gets a member context (dev_ctx: own stream, own wavefront buffers, its rows of the frame);
-//   * the scene crosses PCIe once (member 0) and is replicated device-to-device with hipMemcpyPeerAsync — point-to-point copies are what
-//     xGMI is; no collective library is needed inside one process;
+//   * the scene crosses PCIe once (member 0) and is replicated device-to-device: one ncclBroadcast per scene buffer where RCCL can form the
+//     communicators (transport_rccl.hpp, dlopen), otherwise hipMemcpyPeerAsync — point-to-point copies are what xGMI is;
 //   * rows: interleaved (y % N == d: balances sky rows against geometry rows; N-device output == 1-device output bit for bit at RayDepth <= 2,
 //     where radiance does not depend on the queue slot) or contiguous strips with a device-side exchange of the per-sample alive counts
 //     at every bounce (exact at any depth with sorting off: NHit seeds its RNG from the queue slot, NHit/compute.glsl:54) — "auto" picks
 //     by RayDepth; no host synchronisation in either mode: members wait on each other's per-bounce events, counts travel by peer copies.
 //     Interleaved rows / bands chosen explicitly stay exact beyond RayDepth 2 too: one host thread per member, meeting at every bounce (GroupBarrier below);
 //   * results: idkptDownload writes every member's rows straight into the host image (N PCIe links in parallel); idkptGetImageDevicePtr
-//     gathers the rows into a full frame on device 0 (peer copies + one interleave kernel).
+//     gathers the rows into a full frame on device 0 (grouped ncclSend / ncclRecv or peer copies + one interleave kernel).
 // With deviceCount == 1 every entry point forwards to the single member: no behavioural change, no overhead.
 #pragma once
 #include <array>
@@ -809,6 +809,7 @@ int32_t idkptGetStats(idkpt_ctx* c, idkpt_stats* out)
     for (size_t d = 0; d < c->n(); d++) {
         idkpt_stats s; int rc = dev_GetStats(c->dev[d], &s); if (rc) return mfail(c, c->dev[d], rc);
         sum.RaysTraced += s.RaysTraced; sum.PrimaryRays += s.PrimaryRays; sum.NodePairVisits += s.NodePairVisits; sum.TriangleTests += s.TriangleTests;
+        sum.WideFlaggedRays += s.WideFlaggedRays; sum.WideNodeVisits += s.WideNodeVisits; sum.WideLeafRecords += s.WideLeafRecords; sum.WideTriangleTests += s.WideTriangleTests; sum.InstTlasFlaggedRays += s.InstTlasFlaggedRays;
         for (int j = 0; j < 16; j++) sum.LastAliveCounts[j] += s.LastAliveCounts[j];
         sum.LastFrameMs = std::max(sum.LastFrameMs, s.LastFrameMs); sum.LastTraceMs = std::max(sum.LastTraceMs, s.LastTraceMs);       // the devices run side by side
         sum.TraceMsTotal = std::max(sum.TraceMsTotal, s.TraceMsTotal);

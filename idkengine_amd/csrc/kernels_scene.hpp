@@ -33,7 +33,8 @@ DEV void block_scan2(uint32_t a, uint32_t b, uint32_t* sa, uint32_t* sb, uint32_
 }
 
 __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4* blasNodes, const GpuBlasDesc* descs, const GpuBlasInstance* instances, const float4* xforms,
-                                                                    int n, int searchRadius, float4* nodes /* 2n-1 */, float4* temp /* 2n-1 */, float4* leaf /* n */, uint32_t* keys /* n */, int* pref /* n */)
+                                                                    int n, int searchRadius, float4* nodes /* 2n-1 */, float4* temp /* 2n-1 */, float4* leaf /* n */, uint32_t* keys /* n */, int* pref /* n */,
+                                                                    int padded = 0, float* overlapOut = nullptr, int leavesOnly = 0)
 {
     __shared__ float red[6][TLAS_BUILD_THREADS / 64];
     __shared__ float gbox[6];
@@ -49,6 +50,29 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4*
         const float4* x = xforms + 9 * (size_t)in.MeshTransformId;
         const float4 m0 = x[0], m1 = x[1], m2 = x[2];
         float bmn[3] = {PT_FLOAT_MAX, PT_FLOAT_MAX, PT_FLOAT_MAX}, bmx[3] = {-PT_FLOAT_MAX, -PT_FLOAT_MAX, -PT_FLOAT_MAX};
+        if (padded) {
+            // The library's own TLAS for the instance loop (kernels_trace_inst.hpp): the loop takes a ray into BLAS space with InvModel and nothing else (BVHIntersect.glsl:281-282), so the
+            // world-space region whose rays can pass its root test is the image of the root box under the inverse OF InvModel — inverted here, in double, whatever the host's Model
+            // says — padded by 2^-10 of its size and of its distance from the origin (thousands of fp32 roundings of either transform).  A singular or non-finite InvModel: all of space.
+            const float4 i0 = x[3], i1 = x[4], i2 = x[5];
+            const double A[3][3] = {{i0.x, i0.y, i0.z}, {i1.x, i1.y, i1.z}, {i2.x, i2.y, i2.z}}, tb[3] = {i0.w, i1.w, i2.w};
+            const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+            const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+            const double inv[3][3] = {{c00 / det, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det},
+                                      {c01 / det, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det},
+                                      {c02 / det, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det}};
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool ok = det == det && fabs(det) > 1e-300;
+            for (int c = 0; c < 8; c++) {
+                const double q[3] = {(double)((c & 1) ? rmax.x : rmin.x) - tb[0], (double)((c & 2) ? rmax.y : rmin.y) - tb[1], (double)((c & 4) ? rmax.z : rmin.z) - tb[2]};
+                for (int k = 0; k < 3; k++) { const double w = inv[k][0] * q[0] + inv[k][1] * q[1] + inv[k][2] * q[2]; ok = ok && w == w && fabs(w) < 1e30; lo[k] = w < lo[k] ? w : lo[k]; hi[k] = w > hi[k] ? w : hi[k]; }
+            }
+            for (int k = 0; k < 3; k++) {
+                const double ext = hi[k] - lo[k], mag = fabs(lo[k]) > fabs(hi[k]) ? fabs(lo[k]) : fabs(hi[k]);
+                const double pad = (ext > mag ? ext : mag) * (1.0 / 1024.0) + 1e-30;
+                bmn[k] = ok ? (float)(lo[k] - pad) : -PT_FLOAT_MAX; bmx[k] = ok ? (float)(hi[k] + pad) : PT_FLOAT_MAX;
+            }
+        } else
         for (int c = 0; c < 8; c++) {
             const float cx = (c & 1) ? rmax.x : rmin.x, cy = (c & 2) ? rmax.y : rmin.y, cz = (c & 4) ? rmax.z : rmin.z;
             const float w[3] = {(cx * m0.x) + (cy * m0.y) + (cz * m0.z) + (1.0f * m0.w), (cx * m1.x) + (cy * m1.y) + (cz * m1.z) + (1.0f * m1.w), (cx * m2.x) + (cy * m2.y) + (cz * m2.z) + (1.0f * m2.w)};
@@ -67,6 +91,24 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4*
     __syncthreads();
     if (t < 3) { float a = PT_FLOAT_MAX, b = -PT_FLOAT_MAX; for (int w = 0; w < T / 64; w++) { a = tlas_minN(a, red[t][w]); b = tlas_maxN(b, red[3 + t][w]); } gbox[t] = a; gbox[3 + t] = b; }
     __syncthreads();
+    if (overlapOut) {
+        // how many instance boxes a random line through the scene's box meets (sum of the boxes' half areas over the half area of their union): what the instance loop
+        // walks per ray against the n root tests it makes — the host's measure of whether a tree over the instances can pay (host_launch.hpp inst_tlas_prepare)
+        float sum = 0.0f;
+        for (int i = t; i < n; i += T) sum += tlas_half_area(leaf[2 * (size_t)i], leaf[2 * (size_t)i + 1]);
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        __syncthreads();
+        if ((t & 63) == 0) red[0][t >> 6] = sum;
+        __syncthreads();
+        if (t == 0) {
+            float tot = 0.0f; for (int w = 0; w < T / 64; w++) tot += red[0][w];
+            const float all = tlas_half_area(make_float4(gbox[0], gbox[1], gbox[2], 0.0f), make_float4(gbox[3], gbox[4], gbox[5], 0.0f));
+            const float e = tot / all;
+            *overlapOut = (e == e && e >= 0.0f && e < 3.0e38f) ? e : (float)n;      // (degenerate or unbounded boxes: "every instance")
+        }
+        __syncthreads();
+    }
+    if (leavesOnly) return;
     // ---- Morton-30 keys of the box centres (MyMath.cs:241-257, 283-299)
     for (int i = t; i < n; i += T) {
         const float4 a = leaf[2 * (size_t)i], b = leaf[2 * (size_t)i + 1];

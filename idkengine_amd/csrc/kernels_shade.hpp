@@ -11,7 +11,7 @@ DEV void write_trace_ready(const DScene& s, const Frame& f, const TraceBufs& tr,
     f3 rd = DecodeUnitVec(r.pdx, r.pdy);
     if (f.useTlas || s.instanceCount > 1) {   // the traversal kernel walks the TLAS / instance list and transforms the world ray itself
         tr.rec[4 * (size_t)rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, 0.0f); tr.rec[4 * (size_t)rid + 1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-        if (f.useTlas) tr.rec[4 * (size_t)rid + 2] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, 0.0f);   // world 1/dir for the TLAS slab tests (:209)
+        if (f.useTlas || f.instTlas) tr.rec[4 * (size_t)rid + 2] = make_float4(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z, 0.0f);   // world 1/dir for the TLAS slab tests (:209)
         return;
     }
     GpuBlasInstance inst = s.instances[0];

@@ -102,14 +102,15 @@ __global__ __launch_bounds__(256) void k_classify_tiles(DScene s0, Frame f, uint
         // Each must lie beyond one side plane by more than the margin.
         int nBoxes = s.instanceCount;
         uint32_t tlasChild = 0;
-        if (f.useTlas) {
+        const bool viaTlas = f.useTlas || f.instTlas;        // (instTlas: s.tlas is the library's own, padded tree over the instances — kernels_trace_inst.hpp: beyond its boxes no instance can be hit)
+        if (viaTlas) {
             nBoxes = 0;
             if (s.tlasCount > 0) { const uint32_t packed = __float_as_uint(s.tlas[0].w); if ((packed >> 31) == 0u) { nBoxes = 2; tlasChild = packed & 0x7fffffffu; } }
         }
         bool outside = nBoxes > 0;
         for (int ii = 0; ii < nBoxes && outside; ii++) {
             float4 bmin, bmax, m0 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), m1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f), m2 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-            if (f.useTlas) { bmin = s.tlas[2 * (size_t)(tlasChild + ii)]; bmax = s.tlas[2 * (size_t)(tlasChild + ii) + 1]; }
+            if (viaTlas) { bmin = s.tlas[2 * (size_t)(tlasChild + ii)]; bmax = s.tlas[2 * (size_t)(tlasChild + ii) + 1]; }
             else {
                 const GpuBlasInstance inst = s.instances[ii];
                 const float4* root = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset + 2;
@@ -195,8 +196,9 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
         f3 lo = origin, ld = rd, invDir = splat3(0.0f);   // several instances / TLAS: the traversal kernel transforms the world ray per instance
         float rootT = __builtin_inff();                   // single instance: tMin of the root-box test (+inf = miss), consumed by k_trace2
         keep = !cull;
-        if (f.useTlas) {
+        if (f.useTlas || f.instTlas) {
             // first TLAS step (BVHIntersect.glsl:242-249) with T = FLOAT_MAX: a ray that misses both children of the root is a miss
+            // (instTlas — the instance loop walked through the library's own tree, kernels_trace_inst.hpp: its padded boxes hold every instance, so the same two tests stand for the loop's n root tests)
             invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
             if (cull) {
                 if (s.tlasCount == 0) keep = false;

@@ -1,0 +1,247 @@
+// kernels_trace_inst.hpp — the reference's instance LOOP (several BLAS instances, no USE_TLAS: BVHIntersect.glsl:275-287, its default mode, Bvh/BVH.cs:156) walked through a
+// TLAS the library builds for itself, with the loop's results.
+// Part of the single translation unit idkpt.hip (included there, in this order).
+//
+// WHY.  The loop hands every ray to every instance in list order: a ray pays one root-box test per instance and walks each BLAS it touches with whatever T the instances
+// before it happened to leave.  With the atrium as 87 BLASes (one per mesh) that is 454 Mray/s against 1 641 through a TLAS (profiles/r05_bench_line.json) — but a host that
+// has not set UseTlas gets the loop's hits, and they are not the TLAS walk's: `t < T` keeps the FIRST of two equal hits, and first means list order in one, distance order
+// in the other.
+// WHAT.  k_tlas_build's PLOC tree (the reference's own builder, Bvh/TLAS.cs:28-141) over boxes that are the images of the BLAS root boxes under the inverse of InvModel —
+// the matrix the loop itself transforms rays with — padded (kernels_scene.hpp, padded = 1).  k_trace_inst walks it front to back and enters an instance with the loop's own
+// RayTransform and root test; inside a BLAS it is k_trace2's node / leaf phases.  Everything that produces a number is the loop's arithmetic on the loop's data; what the
+// tree changes is the ORDER in which a ray meets its candidates and the T they are culled with.
+// WHY THE RESULTS STAY THE LOOP'S (the argument of wide_nodes.hpp, whose constants these are):
+//   * every cull — TLAS box, instance root box, BLAS child box — keeps a slack: a box is entered while t1 <= T * CULL (1 + 2^-14); T only falls, so a box culled at some
+//     moment has t1 above the final T * CULL;
+//   * the walk remembers the second-best hit distance among other triangles (starting from the ray's initial T) and t1 of the leaf box its best hit was found in;
+//   * a ray is FLAGGED, and traced again by the exact loop (k_trace2 MODE 1 over the launch's list of flagged rays), if that second-best distance or that t1 lies inside
+//     T * WINDOW (1 + 2^-16), if its best hit is a MARKED triangle (a PreSplit fragment, not contained in its leaf box: which copy of the triangle the loop reports depends on
+//     its order), if a component of 1/dir is not finite for the world ray or for an instance it enters (NaN slabs), or if a stack overflowed.
+//   For an unflagged ray with winner f at T: no other candidate lies within T * WINDOW (one would have been met: its boxes start at most t * (1 + a) <= T * CULL in front of
+//   it — the ASSUMPTION of wide_nodes.hpp, `a` <= 3 * 2^-16), so whatever T the loop holds when it comes to an ancestor box of f is above T * WINDOW >= t1(leaf of f) >=
+//   t1(every ancestor, by the monotonicity of IEEE subtraction and multiplication: ancestors contain the leaf box) — also its strict root test (:33-39) passes — it reaches f,
+//   accepts it, and nothing it meets later has t < T: same TriangleId, T, barycentrics, MeshTransformId, bit for bit.  A ray without any hit met a superset of what the loop
+//   meets.  Not covered, as there: the visit counters (DoDebugBVHTraversal, the counting build), any-hit queries (first found = list order) — those keep the loop.
+#pragma once
+
+struct InstTlasBufs {
+    const float4* tlas;                  // the library's own TLAS (GpuTlasNode layout: root = 0, children adjacent, bit 31 of .w = leaf, the rest = child / instance)
+    const uint8_t* marks;                // per BLAS triangle (leaf order, scene-wide index): 1 = not contained in (one of) its leaf box(es)
+    int tlasCap;                         // rows of the per-lane TLAS stack
+    uint32_t* flagCount; uint32_t* flagA; uint32_t* flagB;    // this launch's list of flagged rays (kernels_wide.hpp has the same hand-over)
+    unsigned long long* totals;          // [0] flagged rays since idkptResetStats
+};
+
+// marks[t] = 1 for every triangle of a leaf that the leaf's box does not contain.  One thread per BLAS node; chunk k of 256 nodes belongs to BLAS chunks[k].x and starts at
+// its node chunks[k].y (BLAS sizes differ by orders of magnitude: the table is the flattened (BLAS, chunk) list, made once per upload).  marks is zeroed before.
+__global__ __launch_bounds__(256) void k_mark_triangles(const float4* nodes, const float4* triVerts, const GpuBlasDesc* descs, const uint2* chunks, uint8_t* marks)
+{
+    const uint2 ch = chunks[blockIdx.x];
+    const GpuBlasDesc d = descs[ch.x];
+    const uint32_t n = ch.y + threadIdx.x;
+    if (n < 2u || n >= (uint32_t)d.NodeCount) return;                        // (node 0 is padding, node 1 the root: never a leaf)
+    const float4 bmin = nodes[2 * ((size_t)d.NodeOffset + n)], bmax = nodes[2 * ((size_t)d.NodeOffset + n) + 1];
+    const uint32_t start = __float_as_uint(bmin.w), cnt = __float_as_uint(bmax.w);
+    for (uint32_t t = 0; t < cnt; t++) {
+        const size_t g = (size_t)d.TriangleOffset + start + t;
+        bool inside = true;
+        for (int v = 0; v < 3; v++) { const float4 p = triVerts[3 * g + v]; inside = inside && p.x >= bmin.x && p.x <= bmax.x && p.y >= bmin.y && p.y <= bmax.y && p.z >= bmin.z && p.z <= bmax.z; }
+        if (!inside) marks[g] = 1;                                           // (NaN positions: marked)
+    }
+}
+
+template <bool PRIMARY, int REFILL_MIN = 16>
+__global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, InstTlasBufs ib)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    // LDS rows as in k_trace2: row 0 = dummy, rows 1 .. cap = BLAS stack, row cap + 1 = spare, then the TLAS rows
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* const stkBase = (lds_u32*)lds + lane;
+    const int cap = f.stackCap;
+    lds_u32* const stkFull = stkBase + cap * WAVE;
+    uint32_t* const tstk = lds + lane + (cap + 2) * WAVE;
+    const uint32_t N = *countPtr;
+    {
+        uint32_t want = gridDim.x;
+        if (f.gridRaysX4 > 0u) want = max((uint32_t)(((unsigned long long)N * 4ull / f.gridRaysX4 + 63ull) / 64ull), min(want, 1024u));
+        if (f.gridMid > 0u && N < f.gridMidRays) want = min(want, f.gridMid);
+        if (blockIdx.x >= max(want, 1u)) return;
+    }
+    bool active = false, leafPending = false, workLeft = N != 0u;
+    uint32_t slice = blockIdx.x & (GRAB_SLICES - 1u), slicesDone = 0, chunkNext = 0, chunkEnd = 0, chunkSlice = 0;
+    const uint32_t unitLog2 = (uint32_t)f.grabUnitLog2;
+    const uint32_t nBlocks = (N + (1u << unitLog2) - 1u) >> unitLog2;
+    const uint32_t grabChunk = f.grabFixed > 0 ? (uint32_t)f.grabFixed : 0u;
+    uint32_t top = 0, slot = 0, rayIdx = 0, leafFirst = 0, leafEnd = 0, leftEnd = 0, rightStart = 0;
+    uint32_t tnode = 0, nodeOff = 0, triOff = 0, xformId = 0;
+    int tsp = 0; bool moreInst = false;
+    lds_u32* sp = stkBase;
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), invDir = splat3(0.0f);
+    float hitT = 0.0f, cullT = 0.0f, second = 0.0f, bestLeafT1 = 0.0f, tL = 0.0f, tR = 0.0f, hbx = 0.0f, hby = 0.0f;
+    uint32_t hitTri = ~0u, hitXform = 0, flags = 0;
+
+    while (true) {
+        // ---- retire finished rays: store the hit, or hand the ray to the exact loop
+        {
+            const bool done = active && top == 0u && !leafPending && !moreInst;
+            if (__builtin_amdgcn_ballot_w64(done) != 0ull) {
+                bool flagged = false;
+                if (done) {
+                    const float win = hitT * wide::WINDOW;
+                    flagged = flags != 0u || (hitTri != ~0u && (second <= win || bestLeafT1 > win || ib.marks[hitTri] != 0));
+                    if (!flagged) store_hit(hits, slot, hitT, hbx, hby, hitTri, hitXform);
+                    active = false;
+                }
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(flagged);
+                if (fm != 0ull) {
+                    const uint32_t cntF = (uint32_t)__builtin_popcountll(fm);
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__builtin_ctzll(fm)) { base = atomicAdd(ib.flagCount, cntF); atomicAdd(ib.totals, (unsigned long long)cntF); }
+                    base = (uint32_t)__shfl((int)base, __builtin_ctzll(fm));
+                    if (flagged) {
+                        const uint32_t at = base + (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1ull));
+                        if (PRIMARY) ib.flagA[at] = rayIdx; else { ib.flagA[at] = slot; ib.flagB[at] = rayIdx; }
+                    }
+                }
+            }
+        }
+        // ---- refill idle lanes (k_trace2's sliced work list, kernels_trace.hpp)
+        unsigned long long idle = __ballot(!active);
+        if (workLeft && ((uint32_t)__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
+            const uint32_t n = (uint32_t)__popcll(idle);
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t avail = chunkEnd - chunkNext;
+            uint32_t q, sl; bool valid = true;
+            if (avail >= n) { q = chunkNext + rank; sl = chunkSlice; chunkNext += n; }
+            else {
+                const uint32_t need = n - avail, want = grabChunk > need ? grabChunk : need;
+                uint32_t fresh = 0, len = 0; bool got = false;
+                while (slicesDone < GRAB_SLICES) {
+                    len = ((nBlocks + GRAB_SLICES - 1u - slice) / GRAB_SLICES) << unitLog2;
+                    fresh = wave_grab(workCounter + GRAB_STRIDE * slice, want);
+                    if (fresh < len) { got = true; break; }
+                    slice = (slice + 1u) & (GRAB_SLICES - 1u); slicesDone++;
+                }
+                q = rank < avail ? chunkNext + rank : fresh + (rank - avail); sl = rank < avail ? chunkSlice : slice;
+                valid = rank < avail || (got && q < len);
+                const uint32_t end = got ? (fresh + want < len ? fresh + want : len) : 0u;
+                chunkNext = got ? (fresh + need < end ? fresh + need : end) : 0u; chunkEnd = end; chunkSlice = slice;
+                if (got && fresh + want >= len) { slice = (slice + 1u) & (GRAB_SLICES - 1u); slicesDone++; }
+            }
+            const uint32_t item = valid ? ((((q >> unitLog2) * GRAB_SLICES + sl) << unitLog2) | (q & ((1u << unitLog2) - 1u))) : N;
+            if (slicesDone >= GRAB_SLICES && chunkNext >= chunkEnd) workLeft = false;
+            if (!active && item < N) {
+                const uint32_t idx = list[item];
+                rayIdx = idx; slot = PRIMARY ? idx : item;
+                hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f; flags = 0u; bestLeafT1 = 0.0f;
+                if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203 (world-space ray)
+                    float4 o = rays.o_ior[idx];
+                    f3 wd = DecodeUnitVec(rays.thr_px[idx].w, rays.rad_py[idx].w), wo = mk3(o.x, o.y, o.z);
+                    for (int i = 0; i < s.lightCount; i++) {
+                        const GpuLight& l = s.lights[i];
+                        float tMin, tMax;
+                        if (RaySphereIntersect(wo, wd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hitT) { hitT = tMin < 0.0f ? tMax : tMin; hitXform = (uint32_t)i; hitTri = ~0u; }
+                    }
+                }
+                second = hitT; cullT = hitT * wide::CULL;
+                const float4 c = tr.rec[4 * (size_t)idx + 2];                  // world 1/dir (written for this walk: Frame::instTlas)
+                const bool finite = gabs(c.x) < __builtin_inff() && gabs(c.y) < __builtin_inff() && gabs(c.z) < __builtin_inff();
+                if (!finite) flags = 1u;
+                active = true; leafPending = false; sp = stkBase; top = 0u; tsp = 0; tnode = 0u; moreInst = finite;
+            }
+        }
+        if (__ballot(active) == 0ull) { if (!workLeft) break; continue; }
+
+        // ---- TLAS walk: lanes whose current BLAS is exhausted go on until they reach the next instance they enter, or the end
+        {
+            bool adv = active && !leafPending && top == 0u && moreInst;
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(adv)) < (uint32_t)f.advMin && __builtin_amdgcn_ballot_w64(active && (leafPending || top != 0u)) != 0ull) adv = false;
+            while (__any(adv)) {
+                if (adv) {
+                    const float4 pmin = ib.tlas[2 * (size_t)tnode];
+                    const uint32_t packed = __float_as_uint(pmin.w), id = packed & 0x7fffffffu;
+                    if ((packed >> 31) == 1u) {                                             // an instance: the loop's body (BVHIntersect.glsl:277-286, :32-39)
+                        const GpuBlasInstance in2 = s.instances[id];
+                        const M34 inv = load_inv_model_at(s.xforms, in2.MeshTransformId);
+                        float4 a = tr.rec[4 * (size_t)rayIdx], b = tr.rec[4 * (size_t)rayIdx + 1];
+                        ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
+                        invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
+                        const float4* root = s.nodes + 2 * (size_t)nodeOff + 2;
+                        float t1;
+                        const bool enter = RayBoxIntersect(ro, invDir, root[0], root[1], &t1) && t1 <= cullT;
+                        const bool finite = gabs(invDir.x) < __builtin_inff() && gabs(invDir.y) < __builtin_inff() && gabs(invDir.z) < __builtin_inff();
+                        sp = stkBase; top = (enter && finite) ? 2u : 0u;
+                        if (tsp == 0) moreInst = false; else tnode = tstk[--tsp * WAVE];
+                        if (!finite) { flags |= 1u; moreInst = false; }                     // (the exact loop traces this ray: nothing more to do for it here)
+                    } else {
+                        const uint32_t l = id, r = id + 1;
+                        const float4* w4 = tr.rec + 4 * (size_t)rayIdx;
+                        float4 a = w4[0], c = w4[2];
+                        const f3 wo = mk3(a.x, a.y, a.z), winv = mk3(c.x, c.y, c.z);
+                        float4 lmin = ib.tlas[2 * (size_t)l], lmax = ib.tlas[2 * (size_t)l + 1], rmin = ib.tlas[2 * (size_t)r], rmax = ib.tlas[2 * (size_t)r + 1];
+                        float tMinLeft, tMinRight;
+                        const bool tl = RayBoxIntersect(wo, winv, lmin, lmax, &tMinLeft) && tMinLeft <= cullT;
+                        const bool tr2 = RayBoxIntersect(wo, winv, rmin, rmax, &tMinRight) && tMinRight <= cullT;
+                        if (tl || tr2) {
+                            if (tl && tr2) {
+                                const bool lc = tMinLeft < tMinRight; tnode = lc ? l : r;
+                                if (tsp < ib.tlasCap) { tstk[tsp * WAVE] = lc ? r : l; tsp++; } else { flags |= 2u; moreInst = false; }
+                            } else tnode = tl ? l : r;
+                        } else { if (tsp == 0) moreInst = false; else tnode = tstk[--tsp * WAVE]; }
+                    }
+                }
+                adv = active && !leafPending && top == 0u && moreInst;
+            }
+        }
+
+        // ---- node phase (k_trace2's branch-free step, culled with the slack)
+        while (true) {
+            const bool canStep = active && !leafPending && top != 0u;
+            const unsigned long long stepMask = __builtin_amdgcn_ballot_w64(canStep);
+            if (stepMask == 0ull) break;
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && leafPending)) >= f.leafMin) break;
+            if (canStep) {
+                const float4* p = s.nodes + 2 * ((size_t)nodeOff + top);
+                const uint32_t popped = sp[0];
+                float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+                const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);
+                float tMinLeft, tMinRight;
+                const bool hitLeft = RayBoxIntersect(ro, invDir, lmin, lmax, &tMinLeft) && tMinLeft <= cullT;
+                const bool hitRight = RayBoxIntersect(ro, invDir, rmin, rmax, &tMinRight) && tMinRight <= cullT;
+                const bool intersectLeft = hitLeft && lCount > 0, intersectRight = hitRight && rCount > 0;
+                leafFirst = intersectLeft ? lStart : rStart; leafEnd = !intersectRight ? lStart + lCount : rStart + rCount; leafPending = intersectLeft || intersectRight;
+                // which leaf box(es) a triangle of the range [leafFirst, leafEnd) was reached through: the left one below leftEnd, the right one from rightStart on (a pair may share one)
+                leftEnd = intersectLeft ? lStart + lCount : 0u; rightStart = intersectRight ? rStart : 0xffffffffu; tL = tMinLeft; tR = tMinRight;
+                const bool traverseLeft = hitLeft && lCount == 0, traverseRight = hitRight && rCount == 0;
+                const bool both = traverseLeft && traverseRight, none = !(traverseLeft || traverseRight);
+                const bool leftCloser = tMinLeft < tMinRight;
+                const uint32_t nearChild = both ? (leftCloser ? lStart : rStart) : (traverseLeft ? lStart : rStart);
+                sp[WAVE] = leftCloser ? rStart : lStart;
+                const bool full = sp == stkFull, nonEmpty = sp != stkBase;
+                flags |= (both && full) ? 2u : 0u;                       // (the push is dropped: the exact loop traces this ray)
+                top = none ? (nonEmpty ? popped : 0u) : nearChild;
+                sp += (both && !full) ? (int)WAVE : ((none && nonEmpty) ? -(int)WAVE : 0);
+            }
+        }
+        // ---- leaf phase
+        if (leafPending) {
+            for (uint32_t i = leafFirst; i < leafEnd; i++) {
+                const float4* tv = s.triVerts + 3 * (size_t)(i + triOff);
+                float4 a = tv[0], b = tv[1], c = tv[2];
+                float by, bz, t;
+                if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t)) {
+                    const uint32_t id = i + triOff;
+                    const bool other = id != hitTri || xformId != hitXform;     // (two instances may share a BLAS: the same triangle index under another transform is another candidate)
+                    if (t < hitT) {
+                        if (other) second = gmin(second, hitT);
+                        hitT = t; cullT = t * wide::CULL; hbx = 1.0f - by - bz; hby = by; hitTri = id; hitXform = xformId;
+                        bestLeafT1 = gmin(i < leftEnd ? tL : __builtin_inff(), i >= rightStart ? tR : __builtin_inff());
+                    } else if (other) second = gmin(second, t);
+                }
+            }
+            leafPending = false;
+        }
+    }
+}

@@ -69,6 +69,7 @@ struct Frame {
     int queryMode;              // k_trace2 serves idkptTraceRays: a ray starts from the T / light its trace-ready record carries (record[1].w, record[2].w) instead of FLOAT_MAX / 0
     int shadeMin;               // k_trace_fused: lanes that wait for the shading phase before it runs
     int hitsByRid;              // the last bounce's hit records are indexed by ray id instead of queue slot (k_trace_fused, kernels_trace_fused.hpp)
+    int instTlas;               // several instances without USE_TLAS walked through the library's own TLAS (kernels_trace_inst.hpp): the producers of a ray also write its world 1/dir
     int tilePerSample;          // k_classify_tiles ran once per sample of the batch (per-sample cameras or scene versions): tile classes are indexed [sample][tile]
 };
 #define MAX_BATCH 256
@@ -83,7 +84,7 @@ struct RayBufs {                // SoA planes of the reference's GpuWavefrontRay
 struct TraceBufs {              // derived, per ray id: the ray ready for the traversal kernel, one 64-B record (the size and alignment of a node pair, so
     float4* rec;                // that a refill touches one cache line per ray instead of three): [0] RayTransform(origin) (Ray.glsl:7-12), .w = tMin of
                                 // the root-box test (+inf = miss), so that the traversal kernel's root test is one compare; [1] RayTransform(direction), not renormalised; [2] 1 / [1] (IntersectionRoutines.glsl:29); [3] unused.
-                                // Several instances / TLAS: [0],[1] hold the WORLD-space ray, [2] the world 1/dir (TLAS only).
+                                // Several instances / TLAS: [0],[1] hold the WORLD-space ray, [2] the world 1/dir (TLAS walks only: USE_TLAS or Frame::instTlas).
     // a bounce launch over a SUBSET of the queue (null: the whole queue in order): the launch hands out positions of `order`; order[i] = queue slot, orderIdx[i] = the ray id
     // in that slot — the exact re-trace behind a wide-node launch (kernels_wide.hpp).  The slot a hit is stored at — which seeds NHit's RNG (NHit/compute.glsl:54) — stays what it is.
     const uint32_t* order; const uint32_t* orderIdx;

@@ -140,6 +140,8 @@ typedef struct idkpt_stats {
     uint64_t WideNodeVisits;    /* only with the developer option "wide_count": 64-byte wide nodes fetched ... */
     uint64_t WideLeafRecords;   /* ... leaf records fetched (80 bytes: the BVH2 leaf node + its first triangle) ... */
     uint64_t WideTriangleTests; /* ... triangle tests of the wide-node walk (every one beyond a record's first is another 48-byte fetch) */
+    uint64_t InstTlasFlaggedRays; /* rays of multi-instance scenes without UseTlas that the walk through the library's own TLAS did not vouch for and the exact instance loop traced
+                                   * again, since idkptResetStats (developer option "inst_tlas", kernels_trace_inst.hpp) */
 } idkpt_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -401,6 +403,10 @@ IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
  *     "pool_min"         >= 0 (12*)  (ray, triangle) pairs a wave must have parked before they are pooled
  *     "wide"             0* / 1      k_trace_wide: closest hits over the derived 4-wide nodes, unvouched rays re-traced by k_trace2 (csrc/wide_nodes.hpp; profiles/r05_wide_nodes.md)
  *     "wide_cap"         0* / 4-96   rows of its per-lane stack (0 = 24)        "wide_count" 0* / 1   count its node / leaf-record / triangle fetches (idkpt_stats.Wide*)
+ *     "inst_tlas"        >= 0 (8*)   k_trace_inst: scenes of at least this many BLAS instances rendered WITHOUT UseTlas (the reference's instance loop, BVHIntersect.glsl:275-287) walk a
+ *                                    TLAS the library builds for itself; rays whose hit could depend on the loop's order are traced again by the exact loop (idkpt_stats.InstTlasFlaggedRays;
+ *                                    csrc/kernels_trace_inst.hpp, profiles/r05_instance_tlas.md).  0 = the loop only.  Not used with the counting build, DoDebugBVHTraversal, scene versions.
+ *     "inst_tlas_overlap" 0-100 (10*) ... only while a random line through the scene meets at most this many percent of the instances' boxes (measured on the device at every rebuild)
  *     "query_scheduler"  0 / 1*      idkptTraceRays through k_trace2's scheduler (0: thread-per-ray kernel, the cross-check)
  *     "defer_last"       0 / 1*      without AOVs only the radiance of a sample's last bounce is computed per frame; its continuation when a host asks (idkptDownloadRays ...)
  *     "no_tile_cull"     0* / 1      no per-tile pre-classification of sky tiles      "no_lean_primary" 0* / 1   k_gen_primary stores the full state of surviving rays

@@ -88,11 +88,13 @@ def test_atrium_at_bench_size(tris, depth, mod, rem, oracle_mod, native_builder)
     pt.Dispose(); o.close(); o2.close()
 
 
-@pytest.mark.parametrize("use_tlas", [0, 1], ids=["instance_loop", "tlas_built_on_device"])
-def test_atrium_per_mesh_blas_at_bench_size(use_tlas, oracle_mod, native_builder):
+@pytest.mark.parametrize("use_tlas,own_tlas", [(0, 0), (1, 0), (0, 1)], ids=["instance_loop", "tlas_built_on_device", "instance_loop_through_own_tlas"])
+def test_atrium_per_mesh_blas_at_bench_size(use_tlas, own_tlas, oracle_mod, native_builder):
     """bench.py's `multi_blas.atrium_per_mesh` block: the 1-M-triangle atrium held as the reference would hold a multi-mesh model without hoisting — 87 BLASes,
     one per mesh (Bvh/BVH.cs:156) — through the instance loop (BVHIntersect.glsl:275-287) and through the TLAS that idkptBuildTlasOnDevice builds (:205-272), 1920x1080,
-    RayDepth 2, the bench's camera; two samples in one batch; rows y % 16 == 5 on both sides.  The wide-node option (one-BLAS scenes only) must be a no-op here."""
+    RayDepth 2, the bench's camera; two samples in one batch; rows y % 16 == 5 on both sides.  The wide-node option (one-BLAS scenes only) must be a no-op here.
+    own_tlas: the instance loop as the bench runs it — walked through the library's own TLAS (kernels_trace_inst.hpp; the counting build keeps the exact loop, so counters are off): the
+    oracle's loop frame bit for bit, with a small share of the rays handed back to the exact loop."""
     sc = S.atrium_scene(1_000_000, native_builder, per_mesh_blas=True)
     assert len(sc.blas_descs) == 87
     w, h = 1920, 1080; cam = S.atrium_camera(w, h)
@@ -100,7 +102,7 @@ def test_atrium_per_mesh_blas_at_bench_size(use_tlas, oracle_mod, native_builder
     ov = dict(RayDepth=2, UseTlas=use_tlas)
     pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov), row_modulo=16, row_remainder=5)
     pt.set_option("wide", 1)
-    pt.UploadScene(sc); pt.SetCamera(cam); pt.enable_counters(True); pt.enable_primary_hit_capture(True); pt.set_max_batch(2)
+    pt.UploadScene(sc); pt.SetCamera(cam); pt.enable_counters(not own_tlas); pt.enable_primary_hit_capture(True); pt.set_max_batch(2)
     if use_tlas:
         pt.BuildTlasOnDevice()
         sc.tlas_nodes = pt.DownloadBuffer(T.IDKPT_BUF_TLAS_NODES, T.GpuTlasNode, 2 * 87 - 1)      # the oracle walks the very tree the device built (its build is pinned in test_gpu_scene_updates.py)
@@ -108,6 +110,11 @@ def test_atrium_per_mesh_blas_at_bench_size(use_tlas, oracle_mod, native_builder
     configs.apply_settings(o.settings, ov); o.enable_counters(True)
     for _ in range(2):
         pt.Compute(); o.render()
-    _assert_shard_equal(pt, o)
+    _assert_shard_equal(pt, o, counters=not own_tlas)
     assert pt.stats()["wide_flagged_rays"] == 0
+    flagged = pt.stats()["inst_tlas_flagged_rays"]
+    if own_tlas:
+        assert 0 < flagged < 0.05 * pt.stats()["rays_traced"], flagged      # (connected surfaces: rays through shared edges tie; PreSplit fragments)
+    else:
+        assert flagged == 0
     pt.Dispose(); o.close()

@@ -1,0 +1,131 @@
+"""The reference's instance loop (several BLAS instances, no UseTlas: BVHIntersect.glsl:275-287) walked through the library's own TLAS (csrc/kernels_trace_inst.hpp,
+developer option "inst_tlas"): the loop's results bit for bit — image, ray records, alive queue, primary hits — against the CPU oracle's loop, on scenes chosen for what the
+argument has to flag: exact ties between instances, instanced BLASes, PreSplit fragments, transforms that are not rigid, stale leaf boxes."""
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import configs  # noqa: E402,F401
+from idkengine_amd import scenes as S  # noqa: E402
+from idkengine_amd import gputypes as T  # noqa: E402
+from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _from_two_instances_on(monkeypatch):
+    monkeypatch.setenv("IDKPT_INST_TLAS", "2")        # (the default starts at 8 instances ...)
+    monkeypatch.setenv("IDKPT_INST_TLAS_OVERLAP", "100")   # (... and asks for little overlap between them: these scenes interleave their BLASes on purpose)
+
+
+def _check(oracle_mod, sc, cam, w, h, frames=1, **ov):
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=frames, **ov)
+    a = gpu_render(sc, cam, w, h, counters=False, frames=frames, **ov)
+    assert_equal(a, o, counters=False)
+    st = a.stats(); a.Dispose(); o.close()
+    return st["inst_tlas_flagged_rays"], st["rays_traced"]
+
+
+@pytest.mark.parametrize("parts,tris,depth,sort,lights", [(2, 3000, 4, 1, 0), (3, 6000, 5, 0, 1), (12, 6000, 4, 1, 1), (60, 12000, 3, 0, 0), (600, 3600, 3, 1, 0)])
+def test_soup_parts_equal_the_loop(native_builder, oracle_mod, parts, tris, depth, sort, lights):
+    sc = S.soup_scene_multi(tris, native_builder, parts=parts, seed=3 + parts, **(dict(extent=4.0, edge=0.4) if parts == 600 else {})); w, h = 160, 96
+    if lights:
+        sc.lights = S.make_lights([((0.0, 3.0, 14.0), 0.8, (9.0, 8.0, 7.0))])
+    cam = S.Camera(w, h, position=(0.0, 0.0, 11.0), fovy_deg=60.0) if parts == 600 else S.Camera(w, h, position=(1.0, 0.5, 24.0))
+    flagged, rays = _check(oracle_mod, sc, cam, w, h, frames=2, RayDepth=depth, DoRaySorting=sort, DoTraceLights=lights)
+    assert flagged < 0.02 * rays, (flagged, rays)
+
+
+def test_batched_samples_and_the_option_switched_off(native_builder, oracle_mod, monkeypatch):
+    """Three samples in one batch through the own TLAS == the same frame with the option off (the exact loop) == the oracle; the flagged-ray total only moves with the option on."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.soup_scene_multi(8000, native_builder, parts=9, seed=21); w, h = 200, 120; cam = S.Camera(w, h, position=(1.0, 0.5, 24.0))
+    ov = dict(RayDepth=4, SamplesPerPixel=3)
+    o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+    res = []
+    for opt in (2, 0):
+        pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); pt.set_option("inst_tlas", opt)
+        pt.UploadScene(sc); pt.SetCamera(cam); pt.set_max_batch(3); pt.Compute(); pt.flush()
+        assert (bits(pt.Result) == bits(o.image(0))).all() and pt.rays().tobytes() == o.rays().tobytes() and (pt.alive_queue() == o.alive_queue()).all()
+        res.append(pt.stats()["inst_tlas_flagged_rays"]); pt.Dispose()
+    assert res[1] == 0
+    o.close()
+
+
+def _instanced(native_builder, transforms, blas_ids, n_blas=2, tris=1500, seed=5, presplit=False):
+    """n_blas soups (optionally with scene-spanning triangles that PreSplit cuts up) and an instance list that uses them several times."""
+    blases = []
+    for k in range(n_blas):
+        tp = S.soup_triangles(tris, seed + 31 * k, 3.0, 0.3)
+        if presplit:
+            tp = np.concatenate([tp, np.float32([[[-3, -3, -2.5], [3, -3, -2.4], [0, 3, 2.6]], [[-3, 0.1, -3], [3, 0.2, 3], [-3, 0.3, 3]]])])
+        p, i, nrm, tan = S.flat_shaded(tp)
+        blases.append({"meshes": [S.MeshInput(p, i, S.make_material((0.8, 0.7, 0.6, 1.0)), nrm, tan)]})
+    sc = S.assemble(blases, native_builder, build_tlas=False)
+    inst = np.zeros(len(blas_ids), T.GpuBlasInstance); inst["BlasId"] = blas_ids; inst["MeshTransformId"] = np.arange(len(blas_ids))
+    sc.blas_instances = inst
+    sc.mesh_transforms = np.concatenate([S.transform_from_matrix(m) for m in transforms])
+    return sc
+
+
+def test_instanced_blases_with_exact_ties(native_builder, oracle_mod):
+    """Seven instances of two BLASes; instances 1 and 4 are the same BLAS under the same matrix (every hit of one ties with the other: the loop reports the lower instance,
+    i.e. MeshTransformId 1), instance 6 repeats instance 2 shifted by a hair (near ties inside the window)."""
+    m = [np.eye(4), S.rotation_y(30.0) @ S.translation((2.0, 0.0, 0.0)), S.rotation_y(-50.0) @ S.translation((-2.5, 0.5, 1.0)), S.translation((0.0, 3.0, -2.0)),
+         S.rotation_y(30.0) @ S.translation((2.0, 0.0, 0.0)), S.rotation_y(75.0) @ S.translation((1.0, -3.0, 0.0)), S.rotation_y(-50.0) @ S.translation((-2.5, 0.5 + 1e-6, 1.0))]
+    sc = _instanced(native_builder, m, [0, 1, 0, 1, 1, 0, 0])
+    w, h = 192, 128; cam = S.Camera(w, h, position=(0.5, 0.5, 13.0), fovy_deg=60.0)
+    flagged, rays = _check(oracle_mod, sc, cam, w, h, frames=2, RayDepth=4)
+    assert flagged > 100, flagged                                        # the tied instances cover a good part of the frame
+
+
+def test_presplit_fragments_are_handed_back(native_builder, oracle_mod):
+    sc = _instanced(native_builder, [np.eye(4), S.rotation_y(40.0) @ S.translation((1.0, 0.2, 0.0)), S.rotation_y(-70.0) @ S.translation((-1.0, -0.3, 0.5))], [0, 1, 0], presplit=True)
+    assert len(sc.blas_triangles) > 2 * 1502                             # PreSplit made fragments
+    w, h = 192, 128; cam = S.Camera(w, h, position=(0.5, 0.8, 9.0), fovy_deg=60.0)
+    flagged, rays = _check(oracle_mod, sc, cam, w, h, frames=2, RayDepth=3)
+    assert flagged > 100, flagged                                        # the big triangles fill most of the view and every hit on one is a fragment's
+
+
+def test_non_rigid_transforms(native_builder, oracle_mod):
+    """Non-uniform scale and shear: the world box of an instance is the image of its root box under the inverse of InvModel (computed by the library in double and padded),
+    and T stays a world-space distance because the loop does not renormalise the BLAS-space direction (Ray.glsl:7-12)."""
+    sh = np.eye(4); sh[0, 1] = 0.4; sh[2, 0] = -0.3
+    m = [np.diag([2.0, 0.5, 1.5, 1.0]), sh @ S.translation((3.0, 0.0, 0.0)), S.rotation_y(20.0) @ np.diag([0.7, 1.8, 0.9, 1.0]) @ S.translation((-3.0, 1.0, 0.0)), S.translation((0.0, -2.0, 1.0)),
+         np.diag([40.0, 40.0, 0.02, 1.0]) @ S.translation((0.0, 0.0, -6.0))]
+    sc = _instanced(native_builder, m, [0, 1, 1, 0, 1])
+    w, h = 192, 128; cam = S.Camera(w, h, position=(0.5, 0.5, 14.0), fovy_deg=60.0)
+    flagged, rays = _check(oracle_mod, sc, cam, w, h, frames=2, RayDepth=3)
+    assert flagged < 0.05 * rays, (flagged, rays)
+
+
+def test_updates_rebuild_the_own_tlas_and_the_marks(native_builder, oracle_mod):
+    """Moving the instances (idkptUpdateBuffer of the transforms) and moving vertices (positions: triangles leave their leaf boxes -> marked) between frames: every frame equals
+    the oracle's frame of the scene in that state."""
+    from idkengine_amd.pathtracer import PathTracer
+    sc = S.soup_scene_multi(6000, native_builder, parts=10, seed=8); w, h = 160, 96; cam = S.Camera(w, h, position=(1.0, 0.5, 24.0))
+    ov = dict(RayDepth=3)
+    pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); pt.UploadScene(sc); pt.SetCamera(cam)
+    def same():
+        o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+        pt.ResetAccumulation(); pt.Compute()
+        assert (bits(pt.Result) == bits(o.image(0))).all() and pt.rays().tobytes() == o.rays().tobytes()
+        o.close()
+    same()
+    rng = np.random.default_rng(4)
+    xf = sc.mesh_transforms.copy()
+    for i in range(len(xf)):
+        xf[i] = S.transform_from_matrix(S.rotation_y(float(rng.uniform(0, 360))) @ S.translation(tuple(rng.uniform(-5, 5, 3))))[0]
+    sc.mesh_transforms = xf; pt.UpdateBuffer(T.IDKPT_BUF_MESH_TRANSFORMS, xf)
+    same()
+    f0 = pt.stats()["inst_tlas_flagged_rays"]
+    pos = sc.vertex_positions.copy(); pos[::7] += np.float32(0.05)       # every seventh vertex leaves its leaf box (no refit: the boxes are stale, as the loop sees them)
+    sc.vertex_positions = pos; pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, pos)
+    same()
+    assert pt.stats()["inst_tlas_flagged_rays"] > f0
+    pt.Dispose()
