@@ -47,6 +47,11 @@ struct DevOptions {
                                  // 0.5-0.8x one frame at a time (the re-trace launch has its own latency floor).  Bit-identical results either way (tests/test_gpu_wide.py).
     int wideCap = 0;             // ... rows of its per-lane stack (0: 24; a ray that needs more is re-traced by k_trace2)
     int wideCount = 0;           // ... count node visits / leaf records / triangle tests (idkpt_stats.Wide*)
+    int instSieve = 8;           // k_trace_inst<P, EXACT>: scenes of at least this many instances (up to 1024) that keep the instance loop run it with the instances a ray cannot meet sieved out up front
+                                 // (the kernel that serves the own-TLAS walk's flagged rays, as the main kernel): exact by construction, visit for visit.  0 = k_trace2 MODE 1.
+    int instSieveOverlap = 50;   // ... while a random line meets at most this many percent of the instances' boxes.  Measured against k_trace2 MODE 1 (profiles/r05_instance_tlas.md): the atrium's 87
+                                 // meshes 2.2x; 64 clusters at 10 / 20 / 30 % overlap 1.68x / 1.44x / 1.19x from outside, 1.30x / 0.88x / 0.85x from inside; soup-1M in 60 parts (37 %) 1.06x / 1.12x,
+                                 // in 12 parts (72 %) 1.03x / 0.98x
     int instTlas = 8;            // k_trace_inst (kernels_trace_inst.hpp): scenes of at least this many BLAS instances rendered WITHOUT UseTlas (the reference's instance loop, its default) are walked
                                  // through a TLAS the library builds for itself; rays whose result could depend on the loop's order are traced again by the exact loop.  0 = the loop only.
                                  // Measured (round 5, profiles/r05_instance_tlas.md): the atrium as 87 BLASes 453 -> 1 641 Mray/s (3.6x; one frame at a time 363 -> 1 029), 0.3 % of the
@@ -95,8 +100,9 @@ struct dev_ctx {
     DevBuf wnodes, wleaf, wids, wpair, wcounts, wtotals; std::vector<uint32_t> wNodeOff, wLeafOff; bool wideTopoValid = false, wideFillValid = false;
     // the library's own TLAS for the instance loop (kernels_trace_inst.hpp): padded PLOC tree over the instances, and the per-triangle "not contained in its leaf box" marks;
     // both derived on the device before the first batch that wants them and after everything that moves boxes, positions or transforms
+    DevBuf instRec; bool instRecValid = false;            // DScene::instRec (k_inst_records): one scene version only; re-derived with the own TLAS's triggers
     DevBuf itlas, imarks, ichunks; int itlasNeed = 1; uint32_t ichunkCount = 0; bool itlasValid = false, imarksValid = false;
-    float* hInstOverlap = nullptr; float* dInstOverlap = nullptr; bool instOverlapKnown = false, itlasBuilt = false;   // host-mapped: instance boxes a random line meets (k_tlas_build); known = read at least once since the upload
+    float* hInstOverlap = nullptr; float* dInstOverlap = nullptr; bool instOverlapKnown = false, itlasBuilt = false, isieveWorth = false;   // host-mapped: instance boxes a random line meets (k_tlas_build); known = read at least once since the upload
     // scene versions: slot count a versioned buffer may grow to, per buffer the bytes of one state / the slot pitch / the slots its arena holds / the current slot
     int verSlots = 1; size_t vbytes[VB_COUNT] = {0}, vstride[VB_COUNT] = {0}; int valloc[VB_COUNT] = {1, 1, 1, 1, 1}, vcur[VB_COUNT] = {0};
     uint64_t lastMask[VB_COUNT] = {0};               // slots the last launched batch reads (a deferred last bounce still does: finish_deferred)

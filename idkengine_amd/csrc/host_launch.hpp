@@ -10,6 +10,7 @@ static int wide_stack_rows(const dev_ctx* ctx) { return std::min(96, std::max(4,
 // moved boxes or positions (k_wide_fill).  Stream-ordered in front of the batch that is about to be launched; with one scene version every update launches the queued samples first.
 static char* vb_ptr(dev_ctx* ctx, int b, int slot);
 // totals of the optional walks since idkptResetStats (idkpt_stats.Wide*, InstTlasFlaggedRays): eight 64-bit words, zeroed when first needed
+static int inst_tlas_rows(const dev_ctx* ctx) { return std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount)); }   // LDS rows behind the BLAS stack: the own TLAS's stack, or an instance mask of 32 x that many bits
 static int totals_ensure(dev_ctx* ctx) { if (!ctx->wtotals.p) { HIPC(ctx->wtotals.ensure(64)); HIPC(hipMemsetAsync(ctx->wtotals.p, 0, 64, ctx->stream)); } return IDKPT_OK; }
 static int wide_prepare(dev_ctx* ctx)
 {
@@ -48,18 +49,35 @@ static int wide_prepare(dev_ctx* ctx)
     return IDKPT_OK;
 }
 
+// ---- instance records (DScene::instRec, k_inst_records) for the walk through the library's own TLAS: stream-ordered in front of the launch that reads them -----------
+static int inst_records_prepare(dev_ctx* ctx)
+{
+    if (ctx->instRecValid || ctx->instanceCount < 2 || ctx->verSlots != 1) return IDKPT_OK;
+    HIPC(ctx->instRec.ensure((size_t)ctx->instanceCount * 96));
+    hipLaunchKernelGGL(k_inst_records, dim3((ctx->instanceCount + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]), ctx->descs.as<GpuBlasDesc>(),
+                       ctx->instances.as<GpuBlasInstance>(), (const float4*)vb_ptr(ctx, VB_XFORMS, ctx->vcur[VB_XFORMS]), ctx->instanceCount, ctx->instRec.as<float4>());
+    HIPC(hipGetLastError());
+    ctx->instRecValid = true;
+    return IDKPT_OK;
+}
+
 // ---- the library's own TLAS for the instance loop (kernels_trace_inst.hpp) ---------------------------------------------------------------------------------------
 // Several instances, no UseTlas, closest hit, one scene version, the reference's counters not asked for: everything else keeps the exact loop (k_trace2 MODE 1).
-static bool inst_tlas_wanted(const dev_ctx* ctx)
+static bool inst_tlas_wanted(const dev_ctx* ctx, bool sieve = false /* the same question for the exact loop with the instance sieve (option inst_sieve) */)
 {
-    return ctx->opt.instTlas > 0 && ctx->instanceCount >= std::max(2, ctx->opt.instTlas) && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters
+    const int from = sieve ? ctx->opt.instSieve : ctx->opt.instTlas;
+    if (sieve && ctx->instanceCount > 1024) return false;
+    return from > 0 && ctx->instanceCount >= std::max(2, from) && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters
            && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);
 }
-// derives what is stale and decides whether the next batch walks the tree (*use): the instances' overlap is measured on the device into host-mapped memory; the first
-// measurement after an upload is waited for, later ones (animated transforms) are read whenever they have arrived — the decision only moves time, never a result
-static int inst_tlas_prepare(dev_ctx* ctx, bool* use)
+// derives what is stale and decides how the next batch of a several-instance scene without UseTlas is traced: through the library's own tree (*useTlas), by the exact loop with the
+// instance sieve (*useSieve), or by k_trace2 MODE 1 (neither).  The instances' overlap is measured on the device into host-mapped memory; the first measurement after an upload is
+// waited for, later ones (animated transforms) are read whenever they have arrived — the decision only moves time, never a result
+static int inst_tlas_prepare(dev_ctx* ctx, bool* useTlas, bool* useSieve)
 {
-    *use = false;
+    *useTlas = false; *useSieve = false;
+    const bool wantT = inst_tlas_wanted(ctx), wantS = inst_tlas_wanted(ctx, true);
+    if (!wantT && !wantS) return IDKPT_OK;
     { int rc = totals_ensure(ctx); if (rc) return rc; }
     hipStream_t st = ctx->stream;
     const float4* nodes = (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]);
@@ -75,14 +93,19 @@ static int inst_tlas_prepare(dev_ctx* ctx, bool* use)
         ITLAS_BUILD(1);                                                       // the overlap of the boxes as they are now
         HIPC(hipGetLastError());
         if (!ctx->instOverlapKnown) { HIPC(hipStreamSynchronize(st)); ctx->instOverlapKnown = true; }
-        const bool worth = ctx->opt.instTlasOverlap >= 100 || *(volatile float*)ctx->hInstOverlap * 100.0f <= (float)ctx->opt.instTlasOverlap * (float)n;
+        const float met = *(volatile float*)ctx->hInstOverlap * 100.0f;      // percent of the instances' boxes a random line meets, x n
+        const bool worth = wantT && (ctx->opt.instTlasOverlap >= 100 || met <= (float)ctx->opt.instTlasOverlap * (float)n);
         if (worth) { ITLAS_BUILD(0); HIPC(hipGetLastError()); }
 #undef ITLAS_BUILD
         ctx->itlasBuilt = worth;
-        ctx->itlasNeed = std::min(TLAS_STACK_SIZE, std::max(1, n));          // (a ray that needs more rows is traced by the exact loop)
+        ctx->isieveWorth = !worth && wantS && (ctx->opt.instSieveOverlap >= 100 || met <= (float)ctx->opt.instSieveOverlap * (float)n);
+        ctx->itlasNeed = inst_tlas_rows(ctx);                                // (a ray that needs more rows is traced by the exact loop)
         ctx->itlasValid = true;
     }
-    if (!ctx->itlasBuilt) return IDKPT_OK;
+    const bool tree = ctx->itlasBuilt && wantT, sieve = !tree && wantS && (ctx->isieveWorth || ctx->itlasBuilt);   // (the options that change what is wanted invalidate the decision: host_options.hpp)
+    if (!tree && !sieve) return IDKPT_OK;
+    { int rc = inst_records_prepare(ctx); if (rc) return rc; }
+    if (!tree) { *useSieve = true; return IDKPT_OK; }
     if (!ctx->imarksValid) {
         if (ctx->ichunkCount == 0) {   // the flattened (BLAS, chunk of 256 nodes) table: once per upload
             std::vector<uint32_t> tab;
@@ -98,7 +121,7 @@ static int inst_tlas_prepare(dev_ctx* ctx, bool* use)
         HIPC(hipGetLastError());
         ctx->imarksValid = true;
     }
-    *use = true;
+    *useTlas = true;
     return IDKPT_OK;
 }
 
@@ -141,16 +164,25 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         hipLaunchKernelGGL((k_trace2<PRIMARY, false>), dim3(std::min<uint32_t>(grid, 2048u)), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)wb.flagA, (const uint32_t*)wb.flagCount, work + 64, counters);
         return;
     }
-    if (f.instTlas && ctx->itlasValid && ctx->itlasBuilt && ctx->imarksValid && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid && !ctx->counters) {
+    if (f.instTlas && ctx->itlasValid && ctx->itlasBuilt && ctx->imarksValid && s.instRec && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid && !ctx->counters) {
         // the instance loop through the library's own TLAS (kernels_trace_inst.hpp), then — on the launch's own list of flagged rays — the exact loop
         InstTlasBufs ib;
         ib.tlas = (const float4*)ctx->itlas.as<float4>(); ib.marks = (const uint8_t*)ctx->imarks.as<uint8_t>(); ib.tlasCap = ctx->itlasNeed;
         ib.flagCount = work + 128; ib.flagA = ctx->sortKeys.as<uint32_t>(); ib.flagB = ctx->sortVals.as<uint32_t>(); ib.totals = ctx->wtotals.as<unsigned long long>() + 4;
+        ib.maskWords = (ctx->instanceCount + 31) / 32;
         hipLaunchKernelGGL((k_trace_inst<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, ib);
         TraceBufs trf = tr; trf.order = nullptr; trf.orderIdx = nullptr;
         if (!PRIMARY) { trf.order = ib.flagA; trf.orderIdx = ib.flagB; }
         Frame ff = f; ff.gridRaysX4 = 6u; ff.gridMid = 0u;
-        hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 24, 1, 0, false>), dim3(std::min<uint32_t>(grid, 2048u)), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)ib.flagA, (const uint32_t*)ib.flagCount, work + 64, counters);
+        const uint32_t g2 = std::min<uint32_t>(grid, 2048u);
+        // the flagged rays: the exact loop, with the instances a ray cannot meet sieved out up front (k_trace_inst<P, true>) while a lane's mask fits the rows LDS has for it
+        if (ib.maskWords <= inst_tlas_rows(ctx)) hipLaunchKernelGGL((k_trace_inst<PRIMARY, true>), dim3(g2), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)ib.flagA, (const uint32_t*)ib.flagCount, work + 64, ib);
+        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 16, 1, false, 24, 1, 0, false>), dim3(g2), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)ib.flagA, (const uint32_t*)ib.flagCount, work + 64, counters);
+        return;
+    }
+    if (f.instSieve && s.instRec && !s.ver && !f.useTlas && !f.hitsByRid && !ctx->counters) {   // the exact loop with the per-ray instance sieve (kernels_trace_inst.hpp, EXACT)
+        InstTlasBufs ib; memset(&ib, 0, sizeof(ib)); ib.maskWords = (ctx->instanceCount + 31) / 32;
+        hipLaunchKernelGGL((k_trace_inst<PRIMARY, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, ib);
         return;
     }
     if (split && !s.ver && !f.useTlas && ctx->instanceCount == 1 && !ctx->counters && ctx->sceneNested && stock) {   // small launch: long rays are split across idle lanes (kernels_trace_split.hpp)

@@ -44,6 +44,16 @@ static int32_t dev_TraceRaysIssue(dev_ctx* ctx, const idkpt_ray* rays, size_t co
     const int lights = (flags & IDKPT_TRACE_LIGHTS) ? 1 : 0;
     if (ctx->opt.queryScheduler && !f.g.DoDebugBVHTraversal) {
         const bool anyHit = (flags & IDKPT_TRACE_ANY_HIT) != 0;
+        if (!anyHit && ctx->instanceCount > 1 && !f.useTlas) {   // closest hits of a several-instance scene without UseTlas: the exact loop with its instance sieve where a frame would use it or the own TLAS (kernels_trace_inst.hpp)
+            bool useT = false, useS = false;
+            rc = inst_tlas_prepare(ctx, &useT, &useS); if (rc) return rc;
+            if ((useT || useS) && ctx->instRecValid) {
+                f.instSieve = 1; s.instRec = (const float4*)ctx->instRec.as<float4>();
+                ldsBytes = (size_t)(f.stackCap + 2 + inst_tlas_rows(ctx)) * WAVE * 4;
+                if (ldsBytes > 64 * 1024) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack");
+                grid = (uint32_t)(ctx->numCUs * std::max(1, (int)std::min<size_t>(32, (160 * 1024) / ldsBytes)));
+            }
+        }
         // closest hit / any hit: k_trace2's persistent-wave scheduler (kernels_query.hpp): prepare (lights, root test, trace-ready records) -> k_trace2 -> Hit flags
         HIPC(ctx->queryRec.ensure(count * 64)); HIPC(ctx->queryList.ensure(count * 4));
         HIPC(hipMemsetAsync(work, 0, (WORK_WORDS + 128) * 4, st));

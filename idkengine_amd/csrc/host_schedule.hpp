@@ -11,6 +11,7 @@ static DScene make_dscene(dev_ctx* ctx, const uint8_t* slots, bool multi)
     s.nodes = (const float4*)at(VB_NODES); s.tris = ctx->tris.as<uint4>(); s.triVerts = (const float4*)at(VB_TRIVERTS);
     s.descs = ctx->descs.as<GpuBlasDesc>(); s.instances = ctx->instances.as<GpuBlasInstance>(); s.instanceCount = ctx->instanceCount;
     s.tlas = (const float4*)at(VB_TLAS); s.tlasCount = ctx->tlasCount; s.vertices = (const uint4*)at(VB_VERTICES);
+    s.instRec = nullptr;        // (set for the batches that walk the library's own TLAS, flush_batch)
     s.meshes = ctx->meshes.as<GpuMesh>(); s.materials = ctx->materials.as<GpuMaterial>(); s.xforms = (const float4*)at(VB_XFORMS);
     s.lights = ctx->lights.as<GpuLight>(); s.lightCount = ctx->lightCount; s.sky = ctx->sky.as<float4>(); s.skySize = ctx->skySize;
     s.textures = ctx->texDescs.as<TexDesc>(); s.textureCount = ctx->textureCount;
@@ -199,9 +200,10 @@ static int flush_batch(dev_ctx* ctx)
     f.grabUnitLog2 = std::min(24, std::max(6, ctx->opt.grabUnitLog2)); f.grabFixed = std::max(0, ctx->opt.grabFixed);   // work-list hand-out (kernels_trace.hpp)
     f.leafMin = ctx->opt.leafMin > 0 ? ctx->opt.leafMin : (B >= 4 ? 16 : 12);        // (measured: 16-20 with many samples in flight, 12 for a frame traced alone; tools/sweep_sched.py)
     f.instTlas = 0;                                                           // the instance loop through the library's own TLAS (kernels_trace_inst.hpp): decided per batch, the rays' producers look at it too
-    if (fast_path(ctx) && inst_tlas_wanted(ctx)) { bool use = false; int rc = inst_tlas_prepare(ctx, &use); if (rc) { ctx->pending.clear(); return rc; } f.instTlas = use ? 1 : 0; }
-    if (f.instTlas) { s.tlas = (const float4*)ctx->itlas.as<float4>(); s.tlasCount = 2 * ctx->instanceCount - 1; }   // (what the kernels of this batch see as "the TLAS": only the primary rays' pre-cull and k_trace_inst look at it)
-    size_t ldsBytes = (size_t)(f.stackCap + 2 + (f.useTlas ? f.tlasCap : (f.instTlas ? std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount)) : 0))) * WAVE * 4;   // + the dummy and the spare row of k_trace2's stack (kernels_trace.hpp)
+    if (fast_path(ctx)) { bool useT = false, useS = false; int rc = inst_tlas_prepare(ctx, &useT, &useS); if (rc) { ctx->pending.clear(); return rc; } f.instTlas = useT ? 1 : 0; f.instSieve = useS ? 1 : 0; }
+    if (f.instSieve) s.instRec = (const float4*)ctx->instRec.as<float4>();
+    if (f.instTlas) { s.tlas = (const float4*)ctx->itlas.as<float4>(); s.tlasCount = 2 * ctx->instanceCount - 1; s.instRec = (const float4*)ctx->instRec.as<float4>(); }   // (what the kernels of this batch see as "the TLAS": only the primary rays' pre-cull and k_trace_inst look at it)
+    size_t ldsBytes = (size_t)(f.stackCap + 2 + (f.useTlas ? f.tlasCap : ((f.instTlas || f.instSieve) ? inst_tlas_rows(ctx) : 0))) * WAVE * 4;   // + the dummy and the spare row of k_trace2's stack (kernels_trace.hpp)
     ldsBytes += (size_t)std::max(0, ctx->opt.ldsPad);   // option "lds_pad": caps the waves per CU (occupancy experiments)
     if (ldsBytes > 64 * 1024) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, "BlasStackSize too large for the LDS traversal stack"); }
     // persistent trace grid: as many 1-wave workgroups as the chip holds (32 waves/CU, limited by LDS)

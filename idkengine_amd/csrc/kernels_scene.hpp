@@ -9,6 +9,23 @@
 // rank = the reference's stable LSD radix sort), then PLOC rounds: every node picks its best partner inside +-searchRadius
 // (FindBestMatch, TLAS.cs:271-301, strict '<' keeps the first best), mutual pairs merge, output positions come from an ordered
 // block scan so the node array is identical to the serial build, bit for bit.
+// Instance records (DScene::instRec): everything an instance entry of the traversal kernels reads, gathered per instance.  Re-derived after uploads, transform updates, refits, node patches.
+__global__ void k_inst_records(const float4* blasNodes, const GpuBlasDesc* descs, const GpuBlasInstance* instances, const float4* xforms, int n, float4* out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const GpuBlasInstance in = instances[i];
+    const GpuBlasDesc d = descs[in.BlasId];
+    const float4* root = blasNodes + 2 * ((size_t)d.NodeOffset + 1);
+    const float4* x = xforms + 9 * (size_t)in.MeshTransformId;
+    float4* o = out + 6 * (size_t)i;
+    o[0] = x[3]; o[1] = x[4]; o[2] = x[5];
+    const float4 rmin = root[0], rmax = root[1];
+    o[3] = make_float4(rmin.x, rmin.y, rmin.z, __uint_as_float((uint32_t)d.NodeOffset));
+    o[4] = make_float4(rmax.x, rmax.y, rmax.z, __uint_as_float((uint32_t)d.TriangleOffset));
+    o[5] = make_float4(__uint_as_float((uint32_t)in.MeshTransformId), __uint_as_float((uint32_t)in.BlasId), 0.0f, 0.0f);
+}
+
 #define TLAS_BUILD_THREADS 1024
 DEV uint32_t tlas_insert_two_zeros(uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; }
 DEV uint32_t tlas_to_uint_sat(float f) { if (f != f || f <= 0.0f) return 0u; if (f >= 4294967296.0f) return 0xffffffffu; return (uint32_t)f; }

@@ -443,6 +443,8 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             if (MULTI && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(adv)) < (uint32_t)f.advMin && __builtin_amdgcn_ballot_w64(active && (leafPending || top != 0u)) != 0ull) adv = false;
             while (__any(adv)) {
                 if (adv) {
+                    // (three dependent fetches — instance, transform + descriptor, root node — that are cheap: the tables are tiny and hot, and the root node shares its 128-byte line
+                    // with the pair the walk fetches next.  One gathered record per instance, DScene::instRec, measured 4-14 % SLOWER here in round 5: profiles/r05_instance_tlas.md)
                     const GpuBlasInstance in2 = s.instances[instIdx];
                     const M34 inv = load_inv_model_at(VER ? s.xforms + vXform : s.xforms, in2.MeshTransformId);
                     float4 a = tr.rec[4 * (size_t)rayId], b = tr.rec[4 * (size_t)rayId + 1];                         // world-space origin / direction

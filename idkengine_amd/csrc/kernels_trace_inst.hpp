@@ -22,12 +22,20 @@
 //   t1(every ancestor, by the monotonicity of IEEE subtraction and multiplication: ancestors contain the leaf box) — also its strict root test (:33-39) passes — it reaches f,
 //   accepts it, and nothing it meets later has t < T: same TriangleId, T, barycentrics, MeshTransformId, bit for bit.  A ray without any hit met a superset of what the loop
 //   meets.  Not covered, as there: the visit counters (DoDebugBVHTraversal, the counting build), any-hit queries (first found = list order) — those keep the loop.
+//
+// THE FLAGGED RAYS' LOOP (k_trace_inst<P, EXACT = true>).  The exact loop over 87 instances is 87 x three dependent fetches per ray before anything is walked, and a launch of a
+// few thousand flagged rays lasts as long as that chain — which a frame traced alone pays twice.  The EXACT instantiation is the loop itself with one thing hoisted: when a wave
+// takes new rays it runs over the instance records once, wave-uniformly (scalar loads, no dependent chain), and every lane notes in a bit mask (LDS rows) which root boxes its ray
+// meets at all (RayBoxIntersect's boolean, the loop's own expression on the loop's own operands: an instance whose box the ray does not meet is never entered by the loop, whatever T).
+// Then the lane walks the set bits in list order with the loop's own entry — RayTransform, 1/dir, root test with the strict `t1 < T` — and k_trace2's node / leaf phases with the
+// exact culls.  Nothing is approximated and nothing flagged: the same instances are entered in the same order with the same T.
 #pragma once
 
 struct InstTlasBufs {
     const float4* tlas;                  // the library's own TLAS (GpuTlasNode layout: root = 0, children adjacent, bit 31 of .w = leaf, the rest = child / instance)
     const uint8_t* marks;                // per BLAS triangle (leaf order, scene-wide index): 1 = not contained in (one of) its leaf box(es)
     int tlasCap;                         // rows of the per-lane TLAS stack
+    int maskWords;                       // EXACT: 32-bit words of a lane's instance mask (they use the TLAS rows: the host sizes LDS for the larger of the two)
     uint32_t* flagCount; uint32_t* flagA; uint32_t* flagB;    // this launch's list of flagged rays (kernels_wide.hpp has the same hand-over)
     unsigned long long* totals;          // [0] flagged rays since idkptResetStats
 };
@@ -50,7 +58,7 @@ __global__ __launch_bounds__(256) void k_mark_triangles(const float4* nodes, con
     }
 }
 
-template <bool PRIMARY, int REFILL_MIN = 16>
+template <bool PRIMARY, bool EXACT = false, int REFILL_MIN = 16>
 __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, InstTlasBufs ib)
 {
     extern __shared__ uint32_t lds[];
@@ -89,8 +97,9 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                 bool flagged = false;
                 if (done) {
                     const float win = hitT * wide::WINDOW;
-                    flagged = flags != 0u || (hitTri != ~0u && (second <= win || bestLeafT1 > win || ib.marks[hitTri] != 0));
+                    flagged = !EXACT && (flags != 0u || (hitTri != ~0u && (second <= win || bestLeafT1 > win || ib.marks[hitTri] != 0)));
                     if (!flagged) store_hit(hits, slot, hitT, hbx, hby, hitTri, hitXform);
+                    if (EXACT && flags != 0u) *s.overflow = 1u;          // (a dropped push: reported like k_trace2's, the upload-time validation makes it unreachable)
                     active = false;
                 }
                 const unsigned long long fm = __builtin_amdgcn_ballot_w64(flagged);
@@ -131,9 +140,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
             }
             const uint32_t item = valid ? ((((q >> unitLog2) * GRAB_SLICES + sl) << unitLog2) | (q & ((1u << unitLog2) - 1u))) : N;
             if (slicesDone >= GRAB_SLICES && chunkNext >= chunkEnd) workLeft = false;
-            if (!active && item < N) {
-                const uint32_t idx = list[item];
-                rayIdx = idx; slot = PRIMARY ? idx : item;
+            const bool fresh = !active && item < N;
+            if (fresh) {
+                const bool ordered = !PRIMARY && tr.order != nullptr;          // (the launch over a wide / own-TLAS launch's flagged rays: position -> queue slot and ray id, pt_kernels.hpp TraceBufs)
+                const uint32_t idx = ordered ? tr.orderIdx[item] : list[item];
+                rayIdx = idx; slot = PRIMARY ? idx : (ordered ? tr.order[item] : item);
                 hitT = PT_FLOAT_MAX; hitTri = ~0u; hitXform = 0; hbx = 0.0f; hby = 0.0f; flags = 0u; bestLeafT1 = 0.0f;
                 if (f.g.DoTraceLights) { // BVHIntersect.glsl:189-203 (world-space ray)
                     float4 o = rays.o_ior[idx];
@@ -144,15 +155,63 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                         if (RaySphereIntersect(wo, wd, mk3(l.Position[0], l.Position[1], l.Position[2]), l.Radius, &tMin, &tMax) && tMin < hitT) { hitT = tMin < 0.0f ? tMax : tMin; hitXform = (uint32_t)i; hitTri = ~0u; }
                     }
                 }
-                second = hitT; cullT = hitT * wide::CULL;
+                if (EXACT && f.queryMode) { hitT = tr.rec[4 * (size_t)idx + 1].w; hitXform = __float_as_uint(tr.rec[4 * (size_t)idx + 2].w); }   // idkptTraceRays (kernels_query.hpp k_query_prepare): T = maxDist or the nearest light, and that light
+                second = hitT; cullT = EXACT ? hitT : hitT * wide::CULL;
                 const float4 c = tr.rec[4 * (size_t)idx + 2];                  // world 1/dir (written for this walk: Frame::instTlas)
-                const bool finite = gabs(c.x) < __builtin_inff() && gabs(c.y) < __builtin_inff() && gabs(c.z) < __builtin_inff();
+                const bool finite = EXACT || (gabs(c.x) < __builtin_inff() && gabs(c.y) < __builtin_inff() && gabs(c.z) < __builtin_inff());
                 if (!finite) flags = 1u;
                 active = true; leafPending = false; sp = stkBase; top = 0u; tsp = 0; tnode = 0u; moreInst = finite;
+            }
+            if (EXACT && __builtin_amdgcn_ballot_w64(fresh) != 0ull) {
+                // which root boxes the new rays meet at all: one wave-uniform pass over the instance records (see the header)
+                f3 wo = splat3(0.0f), wd = splat3(0.0f);
+                if (fresh) { const float4 a = tr.rec[4 * (size_t)rayIdx], b = tr.rec[4 * (size_t)rayIdx + 1]; wo = mk3(a.x, a.y, a.z); wd = mk3(b.x, b.y, b.z); }
+                const int n = s.instanceCount;
+                for (int w = 0; w < ib.maskWords; w++) {
+                    uint32_t m = 0u;
+                    const int last = min(n, 32 * (w + 1));
+                    for (int i = 32 * w; i < last; i++) {
+                        const float4* ir = s.instRec + 6 * (size_t)i;
+                        M34 inv; inv.r0 = ir[0]; inv.r1 = ir[1]; inv.r2 = ir[2];
+                        const float4 rootMin = ir[3], rootMax = ir[4];
+                        const f3 lo = xform34(inv, wo, 1.0f), ld = xform34(inv, wd, 0.0f);
+                        float t1;
+                        if (RayBoxIntersect(lo, mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z), rootMin, rootMax, &t1)) m |= 1u << (i & 31);
+                    }
+                    if (fresh) tstk[w * WAVE] = m;
+                }
             }
         }
         if (__ballot(active) == 0ull) { if (!workLeft) break; continue; }
 
+        // ---- EXACT: lanes whose current BLAS is exhausted take the next instance of their mask, in list order, with the loop's own entry (BVHIntersect.glsl:277-286, :32-39)
+        if (EXACT) {
+            bool adv = active && !leafPending && top == 0u && moreInst;
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(adv)) < (uint32_t)f.advMin && __builtin_amdgcn_ballot_w64(active && (leafPending || top != 0u)) != 0ull) adv = false;
+            while (__any(adv)) {
+                if (adv) {
+                    uint32_t w = tnode >> 5;                                               // tnode: the first instance index not yet looked at
+                    uint32_t m = w < (uint32_t)ib.maskWords ? tstk[w * WAVE] & (0xffffffffu << (tnode & 31u)) : 0u;
+                    while (m == 0u && ++w < (uint32_t)ib.maskWords) m = tstk[w * WAVE];
+                    if (m == 0u) moreInst = false;
+                    else {
+                        const uint32_t id = (w << 5) + (uint32_t)__builtin_ctz(m);
+                        tnode = id + 1u;
+                        const float4* ir = s.instRec + 6 * (size_t)id;
+                        M34 inv; inv.r0 = ir[0]; inv.r1 = ir[1]; inv.r2 = ir[2];
+                        const float4 rootMin = ir[3], rootMax = ir[4];
+                        nodeOff = __float_as_uint(rootMin.w); triOff = __float_as_uint(rootMax.w); xformId = __float_as_uint(ir[5].x);
+                        float4 a = tr.rec[4 * (size_t)rayIdx], b = tr.rec[4 * (size_t)rayIdx + 1];
+                        ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
+                        invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        float t1;
+                        const bool enter = RayBoxIntersect(ro, invDir, rootMin, rootMax, &t1) && t1 < hitT;
+                        sp = stkBase; top = enter ? 2u : 0u;
+                    }
+                }
+                adv = active && !leafPending && top == 0u && moreInst;
+            }
+        } else
         // ---- TLAS walk: lanes whose current BLAS is exhausted go on until they reach the next instance they enter, or the end
         {
             bool adv = active && !leafPending && top == 0u && moreInst;
@@ -162,15 +221,15 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                     const float4 pmin = ib.tlas[2 * (size_t)tnode];
                     const uint32_t packed = __float_as_uint(pmin.w), id = packed & 0x7fffffffu;
                     if ((packed >> 31) == 1u) {                                             // an instance: the loop's body (BVHIntersect.glsl:277-286, :32-39)
-                        const GpuBlasInstance in2 = s.instances[id];
-                        const M34 inv = load_inv_model_at(s.xforms, in2.MeshTransformId);
+                        const float4* ir = s.instRec + 6 * (size_t)id;                      // the instance's record (pt_kernels.hpp DScene::instRec; this walk is only launched with it)
+                        M34 inv; inv.r0 = ir[0]; inv.r1 = ir[1]; inv.r2 = ir[2];
+                        const float4 rootMin = ir[3], rootMax = ir[4];
+                        nodeOff = __float_as_uint(rootMin.w); triOff = __float_as_uint(rootMax.w); xformId = __float_as_uint(ir[5].x);
                         float4 a = tr.rec[4 * (size_t)rayIdx], b = tr.rec[4 * (size_t)rayIdx + 1];
                         ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                         invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                        nodeOff = (uint32_t)s.descs[in2.BlasId].NodeOffset; triOff = (uint32_t)s.descs[in2.BlasId].TriangleOffset; xformId = in2.MeshTransformId;
-                        const float4* root = s.nodes + 2 * (size_t)nodeOff + 2;
                         float t1;
-                        const bool enter = RayBoxIntersect(ro, invDir, root[0], root[1], &t1) && t1 <= cullT;
+                        const bool enter = RayBoxIntersect(ro, invDir, rootMin, rootMax, &t1) && t1 <= cullT;
                         const bool finite = gabs(invDir.x) < __builtin_inff() && gabs(invDir.y) < __builtin_inff() && gabs(invDir.z) < __builtin_inff();
                         sp = stkBase; top = (enter && finite) ? 2u : 0u;
                         if (tsp == 0) moreInst = false; else tnode = tstk[--tsp * WAVE];
@@ -236,7 +295,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                     const bool other = id != hitTri || xformId != hitXform;     // (two instances may share a BLAS: the same triangle index under another transform is another candidate)
                     if (t < hitT) {
                         if (other) second = gmin(second, hitT);
-                        hitT = t; cullT = t * wide::CULL; hbx = 1.0f - by - bz; hby = by; hitTri = id; hitXform = xformId;
+                        hitT = t; cullT = EXACT ? t : t * wide::CULL; hbx = 1.0f - by - bz; hby = by; hitTri = id; hitXform = xformId;
                         bestLeafT1 = gmin(i < leftEnd ? tL : __builtin_inff(), i >= rightStart ? tR : __builtin_inff());
                     } else if (other) second = gmin(second, t);
                 }

@@ -21,6 +21,9 @@ struct DScene {
     const GpuBlasDesc* descs;
     const GpuBlasInstance* instances; int instanceCount;
     const float4* tlas; int tlasCount;
+    const float4* instRec;      // derived (k_inst_records), or null: 6 x float4 per BLAS instance — InvModel rows 0-2, {root Min.xyz, NodeOffset}, {root Max.xyz, TriangleOffset}, {MeshTransformId, BlasId, 0, 0}:
+                                // what a leaf of the library's own TLAS needs to enter an instance in ONE round trip instead of three dependent ones (instance -> desc + transform -> root node;
+                                // kernels_trace_inst.hpp: +5 %.  The instance loop itself is 4-14 % slower with it — kernels_trace.hpp — and keeps its three fetches)
     const uint4* vertices;      // GpuVertex {uv.x, uv.y, tangent, normal} as raw dwords
     const GpuMesh* meshes;
     const GpuMaterial* materials;
@@ -69,6 +72,7 @@ struct Frame {
     int queryMode;              // k_trace2 serves idkptTraceRays: a ray starts from the T / light its trace-ready record carries (record[1].w, record[2].w) instead of FLOAT_MAX / 0
     int shadeMin;               // k_trace_fused: lanes that wait for the shading phase before it runs
     int hitsByRid;              // the last bounce's hit records are indexed by ray id instead of queue slot (k_trace_fused, kernels_trace_fused.hpp)
+    int instSieve;              // several instances without USE_TLAS: the exact loop with the per-ray instance sieve (kernels_trace_inst.hpp, EXACT) instead of k_trace2 MODE 1
     int instTlas;               // several instances without USE_TLAS walked through the library's own TLAS (kernels_trace_inst.hpp): the producers of a ray also write its world 1/dir
     int tilePerSample;          // k_classify_tiles ran once per sample of the batch (per-sample cameras or scene versions): tile classes are indexed [sample][tile]
 };

@@ -407,6 +407,9 @@ IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
  *                                    TLAS the library builds for itself; rays whose hit could depend on the loop's order are traced again by the exact loop (idkpt_stats.InstTlasFlaggedRays;
  *                                    csrc/kernels_trace_inst.hpp, profiles/r05_instance_tlas.md).  0 = the loop only.  Not used with the counting build, DoDebugBVHTraversal, scene versions.
  *     "inst_tlas_overlap" 0-100 (10*) ... only while a random line through the scene meets at most this many percent of the instances' boxes (measured on the device at every rebuild)
+ *     "inst_sieve"       >= 0 (8*)   k_trace_inst<EXACT>: scenes of at least this many instances (at most 1024) that keep the loop run it with the instances a ray's line cannot meet sieved out when
+ *                                    the wave takes the ray — the loop itself, visit for visit (also: the kernel behind the own-TLAS walk's flagged rays, and idkptTraceRays' closest hits).  0 = k_trace2 MODE 1
+ *     "inst_sieve_overlap" 0-100 (50*) ... only up to this overlap (as above)
  *     "query_scheduler"  0 / 1*      idkptTraceRays through k_trace2's scheduler (0: thread-per-ray kernel, the cross-check)
  *     "defer_last"       0 / 1*      without AOVs only the radiance of a sample's last bounce is computed per frame; its continuation when a host asks (idkptDownloadRays ...)
  *     "no_tile_cull"     0* / 1      no per-tile pre-classification of sky tiles      "no_lean_primary" 0* / 1   k_gen_primary stores the full state of surviving rays

@@ -49,12 +49,41 @@ def test_batched_samples_and_the_option_switched_off(native_builder, oracle_mod,
     o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
     res = []
     for opt in (2, 0):
-        pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); pt.set_option("inst_tlas", opt)
+        pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); pt.set_option("inst_tlas", opt); pt.set_option("inst_sieve", 0)
         pt.UploadScene(sc); pt.SetCamera(cam); pt.set_max_batch(3); pt.Compute(); pt.flush()
         assert (bits(pt.Result) == bits(o.image(0))).all() and pt.rays().tobytes() == o.rays().tobytes() and (pt.alive_queue() == o.alive_queue()).all()
         res.append(pt.stats()["inst_tlas_flagged_rays"]); pt.Dispose()
     assert res[1] == 0
     o.close()
+
+
+@pytest.mark.parametrize("parts,tris,depth,lights", [(2, 3000, 4, 1), (12, 6000, 4, 0), (70, 14000, 3, 0), (600, 3600, 3, 0)])
+def test_the_sieved_exact_loop_as_the_main_kernel(native_builder, oracle_mod, monkeypatch, parts, tris, depth, lights):
+    """Option inst_sieve: the kernel that traces the own-TLAS walk's flagged rays (k_trace_inst<P, EXACT>: the loop itself, the instances a ray cannot meet sieved out when the
+    wave takes the ray; 70 and 600 instances: masks of 3 and 19 words) run over every ray.  Nothing is flagged on this path."""
+    monkeypatch.setenv("IDKPT_INST_TLAS", "0"); monkeypatch.setenv("IDKPT_INST_SIEVE", "2"); monkeypatch.setenv("IDKPT_INST_SIEVE_OVERLAP", "100")
+    sc = S.soup_scene_multi(tris, native_builder, parts=parts, seed=40 + parts, **(dict(extent=4.0, edge=0.4) if parts == 600 else {})); w, h = 160, 96
+    if lights:
+        sc.lights = S.make_lights([((0.0, 3.0, 14.0), 0.8, (9.0, 8.0, 7.0))])
+    cam = S.Camera(w, h, position=(0.0, 0.0, 11.0), fovy_deg=60.0) if parts == 600 else S.Camera(w, h, position=(1.0, 0.5, 24.0))
+    flagged, rays = _check(oracle_mod, sc, cam, w, h, frames=2, RayDepth=depth, DoRaySorting=1, DoTraceLights=lights)
+    assert flagged == 0
+
+
+@pytest.mark.parametrize("parts,tris", [(12, 6000), (600, 3600)])
+def test_closest_hit_queries_through_the_sieve(native_builder, oracle_mod, monkeypatch, parts, tris):
+    """idkptTraceRays (closest hit) on a several-instance scene without UseTlas runs the exact loop with its instance sieve wherever a frame would use it or the own TLAS; any-hit
+    queries (first found = list order) keep k_trace2's loop.  20 000 random rays, with and without a maximal distance: the oracle's hits, byte for byte."""
+    from idkengine_amd.pathtracer import PathTracer
+    from gpu_helpers import _queries
+    monkeypatch.setenv("IDKPT_INST_SIEVE", "2"); monkeypatch.setenv("IDKPT_INST_SIEVE_OVERLAP", "100")
+    sc = S.soup_scene_multi(tris, native_builder, parts=parts, seed=77, **(dict(extent=4.0, edge=0.4) if parts == 600 else {}))
+    pt = PathTracer(64, 64); pt.UploadScene(sc)
+    for max_dist in (3.4028235e+38, 5.0):
+        rays = _queries(20000, 23, 6.0, max_dist=max_dist)
+        for any_hit in (False, True):
+            assert pt.TraceRays(rays, any_hit=any_hit).tobytes() == oracle_mod.trace_rays(sc, rays, any_hit=any_hit, use_tlas=False).tobytes()
+    pt.Dispose()
 
 
 def _instanced(native_builder, transforms, blas_ids, n_blas=2, tris=1500, seed=5, presplit=False):

@@ -14,14 +14,14 @@ from idkengine_amd.pathtracer import PathTracer  # noqa: E402
 
 def modes(pt, B):
     out = {}
-    for name, tlas, own, ovl in (("own_tlas", 0, 2, 100), ("exact_loop", 0, 0, 100), ("default", 0, 8, 20), ("tlas_mode", 1, 2, 100)):
+    for name, tlas, own, ovl, sieve, sovl in (("own_tlas", 0, 2, 100, 0, 100), ("exact_loop", 0, 0, 100, 0, 100), ("sieved_loop", 0, 0, 100, 2, 100), ("default", 0, 8, 10, 8, 50), ("tlas_mode", 1, 2, 100, 0, 100)):
         if tlas:
             pt.BuildTlasOnDevice()
-        pt.UseTlas = tlas; pt.set_option("inst_tlas", own); pt.set_option("inst_tlas_overlap", ovl)
+        pt.UseTlas = tlas; pt.set_option("inst_tlas", own); pt.set_option("inst_tlas_overlap", ovl); pt.set_option("inst_sieve", sieve); pt.set_option("inst_sieve_overlap", sovl)
         rays, dt = bench.timed_batch(pt, B, B, reps=3)
         st = pt.stats()
         out[name] = {"mray_s": round(rays / dt / 1e6, 1), "single_frame_mray_s": bench.single_frame(pt, bench.RAY_DEPTH, frames=8)["mray_s"], "flagged_share": round(st["inst_tlas_flagged_rays"] / max(st["rays_traced"], 1), 5)}
-    pt.UseTlas = 0
+    pt.UseTlas = 0; pt.set_option("inst_sieve", 8); pt.set_option("inst_sieve_overlap", 50); pt.set_option("inst_tlas", 8); pt.set_option("inst_tlas_overlap", 10)
     out["own_over_exact"] = round(out["own_tlas"]["mray_s"] / out["exact_loop"]["mray_s"], 3)
     return out
 
