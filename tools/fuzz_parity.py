@@ -41,6 +41,8 @@ def random_scene(rng, builder):
     # the reference's sort key keeps (NHit/compute.glsl:81) and beyond what most index arithmetic of small scenes ever sees
     big = rng.random() < float(os.environ.get("FUZZ_P_BIG", "0.015"))
     nb = int(rng.integers(1, 5))
+    if os.environ.get("FUZZ_BLASES"):                     # e.g. FUZZ_BLASES=2,14: a soak of the several-instance paths (other scenes than the default draw's: the stream shifts)
+        lo_, hi_ = (int(v) for v in os.environ["FUZZ_BLASES"].split(",")); nb = int(rng.integers(lo_, hi_ + 1))
     extent = float(rng.choice([1.5, 4.0, 10.0]))
     use_tex = rng.random() < 0.3
     blases = []
@@ -95,6 +97,7 @@ def draw_case(seed, builder):
     ov = dict(RayDepth=int(rng.integers(1, 8)), DoRaySorting=int(rng.random() < 0.4), DoRussianRoulette=int(rng.random() < 0.8), OutputAOVs=int(rng.random() < 0.4),
               DoTraceLights=int(has_lights and rng.random() < 0.8), UseTlas=int(nb > 1 and rng.random() < 0.5), SamplesPerPixel=int(rng.choice([1, 1, 2, 3])))
     if rng.random() < 0.3: ov.update(FocalLength=float(rng.uniform(0.5, 2.0) * extent), LenseRadius=float(rng.uniform(0.005, 0.05) * extent))
+    if os.environ.get("FUZZ_BLASES") and rng.random() < 0.8: ov["UseTlas"] = 0
     frames = int(rng.integers(1, 6)); batch = int(rng.choice([1, 2, 5, 8]))
     st = configs.apply_settings(T.Settings.default(), ov)
     _legacy = (int(rng.choice([0, 0, 1, 2])), int(rng.integers(1, 6)), int(rng.choice([0, 0, 1, 2])))   # (draws of options that left the product in round 5: the cases of earlier rounds keep their scenes)
