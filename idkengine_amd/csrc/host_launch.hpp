@@ -66,7 +66,7 @@ static int inst_records_prepare(dev_ctx* ctx)
 static bool inst_tlas_wanted(const dev_ctx* ctx, bool sieve = false /* the same question for the exact loop with the instance sieve (option inst_sieve) */)
 {
     const int from = sieve ? ctx->opt.instSieve : ctx->opt.instTlas;
-    if (sieve && ctx->instanceCount > 1024) return false;
+    if (ctx->instanceCount > (sieve ? 1024 : 4096)) return false;       // (a lane's mask has 32 LDS rows; k_tlas_build is one workgroup: beyond a few thousand instances its cost per transform update is not the loop's business)
     return from > 0 && ctx->instanceCount >= std::max(2, from) && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters
            && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);
 }
