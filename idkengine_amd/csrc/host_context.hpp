@@ -47,6 +47,8 @@ struct DevOptions {
                                  // 0.5-0.8x one frame at a time (the re-trace launch has its own latency floor).  Bit-identical results either way (tests/test_gpu_wide.py).
     int wideCap = 0;             // ... rows of its per-lane stack (0: 24; a ray that needs more is re-traced by k_trace2)
     int wideCount = 0;           // ... count node visits / leaf records / triangle tests (idkpt_stats.Wide*)
+    int genPixelMajor = 8;       // k_gen_primary: batches of at least this many samples append their primary rays pixel by pixel (a traversal wave = 4 pixels x 16 samples — rays that differ by their sub-pixel
+                                 // jitter — instead of one 8x8 tile of one sample); 0 = never.  Measured (profiles/r05_pixel_major.md): interior view +5 %, RayDepth 5 +2 %, atrium +1 %, headline +-0
     int instSieve = 8;           // k_trace_inst<P, EXACT>: scenes of at least this many instances (up to 1024) that keep the instance loop run it with the instances a ray cannot meet sieved out up front
                                  // (the kernel that serves the own-TLAS walk's flagged rays, as the main kernel): exact by construction, visit for visit.  0 = k_trace2 MODE 1.
     int instSieveOverlap = 50;   // ... while a random line meets at most this many percent of the instances' boxes.  Measured against k_trace2 MODE 1 (profiles/r05_instance_tlas.md): the atrium's 87

@@ -257,8 +257,10 @@ static int flush_batch(dev_ctx* ctx)
                 else hipLaunchKernelGGL((k_classify_tiles<false>), dim3((genWaves + 255) / 256, classSets), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
                 tileClass = ctx->tileClass.as<uint8_t>();
             }
-            if (multiVer) hipLaunchKernelGGL((k_gen_primary<true>), dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
-            else hipLaunchKernelGGL((k_gen_primary<false>), dim3(B, (genWaves + 15) / 16), dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
+            f.genPixelMajor = (ctx->opt.genPixelMajor > 0 && B >= ctx->opt.genPixelMajor) ? 1 : 0;
+            const dim3 genGrid = f.genPixelMajor ? dim3((B + 15) / 16, genWaves) : dim3(B, (genWaves + 15) / 16);
+            if (multiVer) hipLaunchKernelGGL((k_gen_primary<true>), genGrid, dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
+            else hipLaunchKernelGGL((k_gen_primary<false>), genGrid, dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
             TRACE_T0();
             uint32_t grid0 = traceGrid;
             if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4, midGrid);

@@ -170,21 +170,26 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
                                                      const uint8_t* tileClass /* null: no tile pre-classification */,
                                                      int lean /* the traversal reads only the trace-ready record: k_shade_first regenerates the state of a surviving ray instead of reading it back */)
 {
-    __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase;
+    __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase; __shared__ unsigned long long keepMask[16];
     // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
-    // rays of the same screen region (all samples) together -> coherent waves in the traversal kernel
-    const uint32_t smp = blockIdx.x;                                   // sample of the batch
-    const DScene s = VER ? scene_of_sample(s0, smp) : s0;              // (workgroup-uniform)
-    const uint32_t wave = (blockIdx.y * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    // rays of the same screen region (all samples) together -> coherent waves in the traversal kernel.
+    // f.genPixelMajor (batches of >= 8 samples): grid = (groups of 16 samples, tiles) — a workgroup is ONE tile under 16 samples, and it appends its survivors pixel by pixel
+    // (all samples of a pixel side by side): a wave of the traversal kernel then holds 4 pixels x 16 samples, rays that differ by their sub-pixel jitter only
+    const bool pm = f.genPixelMajor != 0;
+    const uint32_t smp = pm ? blockIdx.x * 16u + (threadIdx.x >> 6) : blockIdx.x;   // sample of the batch
+    const DScene s = VER ? scene_of_sample(s0, min(smp, (uint32_t)f.batch - 1u)) : s0;   // (wave-uniform)
+    const uint32_t wave = pm ? blockIdx.y : (blockIdx.y * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
     const uint32_t tx = wave % tilesX, ty = wave / tilesX;
+    // (the 4 pixels a traversal wave gets are 4 neighbours of a tile row; walking the tile in Morton order instead — 2x2 blocks — measured the same in the traversal and cost the
+    // streaming kernels their coalescing: atrium -4 %, profiles/r05_pixel_major.md)
     const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
-    const bool valid = x < (uint32_t)f.W && y < (uint32_t)f.rows;
+    const bool valid = x < (uint32_t)f.W && y < (uint32_t)f.rows && smp < (uint32_t)f.batch;
     const uint32_t pix = y * (uint32_t)f.W + x;
     const uint32_t rid = smp * f.Npad + pix;                           // ray id inside the batch
     bool keep = false;
     const uint32_t nTilesAll = tilesX * (((uint32_t)f.rows + 7) / 8);
-    const uint32_t cls = (tileClass && wave < nTilesAll) ? tileClass[(f.tilePerSample ? (size_t)smp * nTilesAll : 0) + wave] : 0u;   // wave-uniform
+    const uint32_t cls = (tileClass && wave < nTilesAll) ? tileClass[(f.tilePerSample ? (size_t)min(smp, (uint32_t)f.batch - 1u) * nTilesAll : 0) + wave] : 0u;   // wave-uniform
     if (valid && cls != 0u) {
         // the whole tile is a proven miss with a known sky colour (k_classify_tiles): FirstHit's miss branch without generating the ray
         // k_final_draw takes the colour from the tile class, idkptDownloadRays regenerates the ray state: one flag byte is all that is stored
@@ -250,6 +255,20 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
     // measured in round 3 and changes nothing: this kernel is not bound by its counter, profiles/r03_trace_experiments.md)
     const unsigned long long m = __ballot(keep);
     const uint32_t wv = threadIdx.x >> 6;
+    if (pm) {
+        if (!f.tilePerSample && cls != 0u) return;          // (a tile classified as sky for every sample: workgroup-uniform, nothing to append)
+        if (lane == 0) keepMask[wv] = m;
+        __syncthreads();
+        uint32_t cnt = 0, before = 0;                       // samples of this workgroup that keep pixel `lane`; those of them in waves before this one
+        for (uint32_t w = 0; w < 16u; w++) { const uint32_t b = (uint32_t)(keepMask[w] >> lane) & 1u; cnt += b; before += w < wv ? b : 0u; }
+        uint32_t incl = cnt;                                // inclusive scan over the 64 pixels
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off); incl += lane >= (uint32_t)off ? v : 0u; }
+        const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+        if (threadIdx.x == 0) blockBase = tot ? atomicAdd(activeCount, tot) : 0u;
+        __syncthreads();
+        if (keep) activeList[blockBase + (incl - cnt) + before] = rid;
+        return;
+    }
     if (lane == 0) waveKeep[wv] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) { uint32_t tot = 0; for (int i = 0; i < 16; i++) { uint32_t c = waveKeep[i]; waveKeep[i] = tot; tot += c; } blockBase = tot ? atomicAdd(activeCount, tot) : 0u; }

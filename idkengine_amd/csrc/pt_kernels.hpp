@@ -72,6 +72,7 @@ struct Frame {
     int queryMode;              // k_trace2 serves idkptTraceRays: a ray starts from the T / light its trace-ready record carries (record[1].w, record[2].w) instead of FLOAT_MAX / 0
     int shadeMin;               // k_trace_fused: lanes that wait for the shading phase before it runs
     int hitsByRid;              // the last bounce's hit records are indexed by ray id instead of queue slot (k_trace_fused, kernels_trace_fused.hpp)
+    int genPixelMajor;          // k_gen_primary appends a tile's survivors pixel by pixel over 16 samples (batches of >= 8 samples): kernels_trace.hpp
     int instSieve;              // several instances without USE_TLAS: the exact loop with the per-ray instance sieve (kernels_trace_inst.hpp, EXACT) instead of k_trace2 MODE 1
     int instTlas;               // several instances without USE_TLAS walked through the library's own TLAS (kernels_trace_inst.hpp): the producers of a ray also write its world 1/dir
     int tilePerSample;          // k_classify_tiles ran once per sample of the batch (per-sample cameras or scene versions): tile classes are indexed [sample][tile]
