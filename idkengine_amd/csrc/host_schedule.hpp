@@ -258,9 +258,10 @@ static int flush_batch(dev_ctx* ctx)
                 tileClass = ctx->tileClass.as<uint8_t>();
             }
             f.genPixelMajor = (ctx->opt.genPixelMajor > 0 && B >= ctx->opt.genPixelMajor) ? 1 : 0;
-            const dim3 genGrid = f.genPixelMajor ? dim3((B + 15) / 16, genWaves) : dim3(B, (genWaves + 15) / 16);
-            if (multiVer) hipLaunchKernelGGL((k_gen_primary<true>), genGrid, dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
-            else hipLaunchKernelGGL((k_gen_primary<false>), genGrid, dim3(1024), 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
+            const int genGroups = (B + 15) / 16, genPer = (B + genGroups - 1) / genGroups;     // pixel-major: the batch in equal groups of at most 16 samples, one wave per sample
+            const dim3 genGrid = f.genPixelMajor ? dim3(genGroups, genWaves) : dim3(B, (genWaves + 15) / 16), genBlock = f.genPixelMajor ? dim3(64 * genPer) : dim3(1024);
+            if (multiVer) hipLaunchKernelGGL((k_gen_primary<true>), genGrid, genBlock, 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
+            else hipLaunchKernelGGL((k_gen_primary<false>), genGrid, genBlock, 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
             TRACE_T0();
             uint32_t grid0 = traceGrid;
             if (ctx->opt.gridRaysX4 > 0 && ctx->lastFast && ctx->lastBatch == B) grid0 = small_launch_grid(traceGrid, ctx->hCounts[MAX_DEPTH_SLOTS - 1], 2, ctx->opt.gridRaysX4, midGrid);

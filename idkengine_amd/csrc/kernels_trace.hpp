@@ -173,10 +173,12 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
     __shared__ uint32_t waveKeep[16]; __shared__ uint32_t blockBase; __shared__ unsigned long long keepMask[16];
     // grid = (samples, tile groups): the samples of one tile group are dispatched back to back, so the active list keeps
     // rays of the same screen region (all samples) together -> coherent waves in the traversal kernel.
-    // f.genPixelMajor (batches of >= 8 samples): grid = (groups of 16 samples, tiles) — a workgroup is ONE tile under 16 samples, and it appends its survivors pixel by pixel
-    // (all samples of a pixel side by side): a wave of the traversal kernel then holds 4 pixels x 16 samples, rays that differ by their sub-pixel jitter only
+    // f.genPixelMajor (batches of >= 8 samples): grid = (groups of G <= 16 samples, tiles), G waves per workgroup — a workgroup is ONE tile under G samples (the batch split into equal
+    // groups: 32 samples = 2 x 16, the driver's 20 = 2 x 10), and it appends its survivors pixel by pixel (all samples of a pixel side by side): a wave of the traversal kernel then
+    // holds 64 / G pixels x G samples, rays that differ by their sub-pixel jitter only
     const bool pm = f.genPixelMajor != 0;
-    const uint32_t smp = pm ? blockIdx.x * 16u + (threadIdx.x >> 6) : blockIdx.x;   // sample of the batch
+    const uint32_t G = blockDim.x >> 6;                                 // pixel-major: samples (= waves) of this workgroup
+    const uint32_t smp = pm ? blockIdx.x * G + (threadIdx.x >> 6) : blockIdx.x;   // sample of the batch
     const DScene s = VER ? scene_of_sample(s0, min(smp, (uint32_t)f.batch - 1u)) : s0;   // (wave-uniform)
     const uint32_t wave = pm ? blockIdx.y : (blockIdx.y * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const uint32_t tilesX = ((uint32_t)f.W + 7) / 8;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
         if (lane == 0) keepMask[wv] = m;
         __syncthreads();
         uint32_t cnt = 0, before = 0;                       // samples of this workgroup that keep pixel `lane`; those of them in waves before this one
-        for (uint32_t w = 0; w < 16u; w++) { const uint32_t b = (uint32_t)(keepMask[w] >> lane) & 1u; cnt += b; before += w < wv ? b : 0u; }
+        for (uint32_t w = 0; w < G; w++) { const uint32_t b = (uint32_t)(keepMask[w] >> lane) & 1u; cnt += b; before += w < wv ? b : 0u; }
         uint32_t incl = cnt;                                // inclusive scan over the 64 pixels
         for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off); incl += lane >= (uint32_t)off ? v : 0u; }
         const uint32_t tot = (uint32_t)__shfl((int)incl, 63);

@@ -14,7 +14,8 @@ pt = PathTracer(W, H); pt.enable_timing(True)
 res = {}
 soup = S.soup_scene(bench.N_TRIS, NativeBuilder(), seed=1)
 atrium = S.atrium_scene(bench.N_TRIS, NativeBuilder())
-for name, sc, cam, depth in (("headline", soup, bench.view_camera(S, "headline", W, H), 2), ("interior", soup, bench.view_camera(S, "interior", W, H), 2), ("atrium", atrium, S.atrium_camera(W, H), 2), ("interior_d5", soup, bench.view_camera(S, "interior", W, H), 5)):
+for name, sc, cam, depth, B in (("headline", soup, bench.view_camera(S, "headline", W, H), 2, 32), ("headline_20_samples", soup, bench.view_camera(S, "headline", W, H), 2, 20), ("interior", soup, bench.view_camera(S, "interior", W, H), 2, 32),
+                               ("interior_20_samples", soup, bench.view_camera(S, "interior", W, H), 2, 20), ("atrium", atrium, S.atrium_camera(W, H), 2, 32), ("interior_d5", soup, bench.view_camera(S, "interior", W, H), 5, 32)):
     pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = depth
     row = {}; ref = None
     for opt in (0, 8, 0, 8):
