@@ -258,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
     const unsigned long long m = __ballot(keep);
     const uint32_t wv = threadIdx.x >> 6;
     if (pm) {
-        if (!f.tilePerSample && cls != 0u) return;          // (a tile classified as sky for every sample: workgroup-uniform, nothing to append)
+        if (cls != 0u) return;                               // (a tile classified as sky — pixel-major batches share one classification: workgroup-uniform, nothing to append)
         if (lane == 0) keepMask[wv] = m;
         __syncthreads();
         uint32_t cnt = 0, before = 0;                       // samples of this workgroup that keep pixel `lane`; those of them in waves before this one
