@@ -49,6 +49,8 @@ struct DevOptions {
     int wideCount = 0;           // ... count node visits / leaf records / triangle tests (idkpt_stats.Wide*)
     int genPixelMajor = 8;       // k_gen_primary: batches of at least this many samples append their primary rays pixel by pixel (a traversal wave = 4 pixels x 16 samples — rays that differ by their sub-pixel
                                  // jitter — instead of one 8x8 tile of one sample); 0 = never.  Measured (profiles/r05_pixel_major.md): interior view +5 %, RayDepth 5 +2 %, atrium +1 %, headline +-0
+    int genGroupMax = 16;        // ... samples per group (= waves per workgroup of k_gen_primary), at most 16.  Mean trace launch, interior view: 2 / 4 / 8 / 16 samples 33.5 / 32.8 / 32.4 / 31.8 ms (tile-major 33.9);
+                                 // 32 (two passes per wave) 31.5 ms, but the two-pass kernel itself cost the headline view 1 %: not kept
     int instSieve = 8;           // k_trace_inst<P, EXACT>: scenes of at least this many instances (up to 1024) that keep the instance loop run it with the instances a ray cannot meet sieved out up front
                                  // (the kernel that serves the own-TLAS walk's flagged rays, as the main kernel): exact by construction, visit for visit.  0 = k_trace2 MODE 1.
     int instSieveOverlap = 50;   // ... while a random line meets at most this many percent of the instances' boxes.  Measured against k_trace2 MODE 1 (profiles/r05_instance_tlas.md): the atrium's 87

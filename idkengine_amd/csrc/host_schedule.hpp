@@ -260,7 +260,7 @@ static int flush_batch(dev_ctx* ctx)
             // (not where the samples of a batch are different frames — their own cameras or scene versions: the same pixel is then not the same ray, and under scene versions not even the
             // same node addresses; measured on the animated bench, 8 / 32 frames in flight: 3 291 / 3 716 -> 3 011 / 3 117 Mray/s)
             f.genPixelMajor = (ctx->opt.genPixelMajor > 0 && B >= ctx->opt.genPixelMajor && !f.tilePerSample) ? 1 : 0;
-            const int genGroups = (B + 15) / 16, genPer = (B + genGroups - 1) / genGroups;     // pixel-major: the batch in equal groups of at most 16 samples, one wave per sample
+            const int genMax = std::min(16, std::max(1, ctx->opt.genGroupMax)), genGroups = (B + genMax - 1) / genMax, genPer = (B + genGroups - 1) / genGroups;     // pixel-major: the batch in equal groups of at most 16 samples, one wave per sample
             const dim3 genGrid = f.genPixelMajor ? dim3(genGroups, genWaves) : dim3(B, (genWaves + 15) / 16), genBlock = f.genPixelMajor ? dim3(64 * genPer) : dim3(1024);
             if (multiVer) hipLaunchKernelGGL((k_gen_primary<true>), genGrid, genBlock, 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
             else hipLaunchKernelGGL((k_gen_primary<false>), genGrid, genBlock, 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);
