@@ -221,6 +221,9 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
 #define T2V(R, L) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, L>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
             case 901: T2V(32, 20); return; case 902: T2V(40, 16); return; case 903: T2V(24, 24); return; case 904: T2V(16, 24); return;   // refill threshold / parked-leaf threshold probes
 #undef T2V
+#define T2Q(R) do { if (PRIMARY) hipLaunchKernelGGL((k_trace2<PRIMARY, false, R, 1, false, 24, 0, 16>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); } while (0)
+            case 911: T2Q(16); return; case 912: T2Q(24); return; case 913: T2Q(48); return; case 914: T2Q(8); return;   // refill threshold of the PRIMARY launch (pooled leaf phase) under the pixel-major list; bounces as shipped
+#undef T2Q
             case 961: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 7, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;   // occupancy probes: 7 / 8 waves per SIMD forced (launch bounds)
             case 962: hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 8, false, 24>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters); return;
             default: break;
