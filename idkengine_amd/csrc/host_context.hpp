@@ -49,6 +49,8 @@ struct DevOptions {
     int wideCount = 0;           // ... count node visits / leaf records / triangle tests (idkpt_stats.Wide*)
     int genPixelMajor = 8;       // k_gen_primary: batches of at least this many samples append their primary rays pixel by pixel (a traversal wave = 4 pixels x 16 samples — rays that differ by their sub-pixel
                                  // jitter — instead of one 8x8 tile of one sample); 0 = never.  Measured (profiles/r05_pixel_major.md): interior view +5 %, RayDepth 5 +2 %, atrium +1 %, headline +-0
+    int bouncePixelMajor = 1;    // ... and the first bounce is traced in that order too (k_shade_first appends the continuing rays to a list of its own, their hits are stored per ray id):
+                                 // 0 never, 1 on sparse views (measured: +1.1-2.2 % there, -2 % where every pixel traverses), 2 always
     int genGroupMax = 16;        // ... samples per group (= waves per workgroup of k_gen_primary), at most 16.  Mean trace launch, interior view: 2 / 4 / 8 / 16 samples 33.5 / 32.8 / 32.4 / 31.8 ms (tile-major 33.9);
                                  // 32 (two passes per wave) 31.5 ms, but the two-pass kernel itself cost the headline view 1 %: not kept
     int instSieve = 8;           // k_trace_inst<P, EXACT>: scenes of at least this many instances (up to 1024) that keep the instance loop run it with the instances a ray cannot meet sieved out up front
@@ -115,6 +117,7 @@ struct dev_ctx {
     char* hStage = nullptr; hipEvent_t evStage[4] = {nullptr, nullptr, nullptr, nullptr}; int stageNext = 0;   // pinned ring for small host -> device updates (joint matrices, transforms): no stream synchronisation per call
     int (*groupFlushAll)(void* user) = nullptr;      // member of a multi-device context: launches what ALL members have queued (a member never flushes on its own)
     // wavefront state
+    DevBuf pmList;                                       // the first bounce's work list in pixel-major order (k_shade_first)
     DevBuf trRec, contFlag, blockSums, rayO, rayT, rayR, aovA, aovN, hit, hitCost, primHit, queue[2], keys[2], keysTmp, sortKeys, sortVals, contMask, waveCounts, counts, work, sortHist, counters64;
     DevBuf img[3];
     DevBuf camTab;                                       // per-sample cameras of the batch being launched (ring mode)

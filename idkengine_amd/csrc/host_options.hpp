@@ -37,6 +37,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "graph_probe") o.graphProbe = std::max(0, value);
 #endif
     else if (n == "inst_tlas_overlap") { REQUIRE(value >= 0 && value <= 100, "idkptSetDeveloperOption: inst_tlas_overlap is a percentage"); FLUSH(); o.instTlasOverlap = value; ctx->itlasValid = false; }
+    else if (n == "bounce_pixel_major") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: bounce_pixel_major is 0..2"); o.bouncePixelMajor = value; }
     else if (n == "gen_group_max") { REQUIRE(value >= 1 && value <= 16, "idkptSetDeveloperOption: gen_group_max is 1..16"); o.genGroupMax = value; }
     else if (n == "gen_pixel_major") { REQUIRE(value >= 0, "idkptSetDeveloperOption: gen_pixel_major is >= 0"); o.genPixelMajor = value; }
     else if (n == "inst_sieve_overlap") { REQUIRE(value >= 0 && value <= 100, "idkptSetDeveloperOption: inst_sieve_overlap is a percentage"); FLUSH(); o.instSieveOverlap = value; ctx->itlasValid = false; }

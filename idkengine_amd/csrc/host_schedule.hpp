@@ -234,6 +234,7 @@ static int flush_batch(dev_ctx* ctx)
     // ---- FirstHit
     uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (capacity uints), free until the first sort
     uint32_t* activeCount = counts + (MAX_DEPTH_SLOTS - 1);
+    uint32_t* pmList = nullptr; uint32_t* const pmCount = counts + (MAX_DEPTH_SLOTS - 2); bool pmBounce = false;   // (RayDepth < MAX_DEPTH_SLOTS - 1: the word is nobody's queue length; reset with the others)
     TraceBufs tr = {ctx->trRec.as<float4>(), nullptr, nullptr};
     TraceBufs trNone = {nullptr, nullptr, nullptr};
     uint32_t* waveLocal = waveCounts;                     // per-wave exclusive offset inside its 256-wave scan block
@@ -276,8 +277,17 @@ static int flush_batch(dev_ctx* ctx)
             TRACE_T1();
             if (ctx->capturePrimary) { HIPC(ctx->primHit.ensure((size_t)N * 16)); hipLaunchKernelGGL(k_capture_primary, dim3((N + 255) / 256), dim3(256), 0, st, hits, (size_t)(B - 1) * Npad, N, ctx->primHit.as<float4>()); }
             if (fused) {}
-            else if (multiVer) hipLaunchKernelGGL((k_shade_first<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
-            else hipLaunchKernelGGL((k_shade_first<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean);
+            else {
+                // the first bounce in the primary list's pixel-major order (kernels_shade.hpp k_shade_first): its own work list, hits per ray id
+                // (only on sparse views — fewer than half of the pixels entered the traversal in the previous batch of this shape, the pooled leaf phase's rule: measured +1.1 % / +2.2 % on
+                // the headline view with 32 / 20 samples in flight, and -1.9 % / -2.3 % where every pixel traverses: the alive queue's runs of 64 neighbouring pixels are coherent there already,
+                // and this list is in the order the workgroups happened to append; option bounce_pixel_major: 0 never, 1 sparse views, 2 always)
+                const bool sparseView = ctx->lastFast && ctx->lastBatch >= 1 && (uint64_t)ctx->hCounts[MAX_DEPTH_SLOTS - 1] * 2u < (uint64_t)ctx->W * ctx->rows * (uint64_t)ctx->lastBatch;   // (per sample: the previous batch may have had another size — a warm-up)
+                pmBounce = f.genPixelMajor && (ctx->opt.bouncePixelMajor >= 2 || (ctx->opt.bouncePixelMajor == 1 && sparseView)) && depth >= 2 && !multiVer;
+                if (pmBounce) { HIPC(ctx->pmList.ensure((size_t)total * 4)); pmList = ctx->pmList.as<uint32_t>(); }
+                if (multiVer) hipLaunchKernelGGL((k_shade_first<true>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                else hipLaunchKernelGGL((k_shade_first<false>), dim3(gridTotal), dim3(256), 0, st, s, f, rays, tr, hits, (const uint32_t*)activeList, (const uint32_t*)activeCount, ctx->contFlag.as<uint8_t>(), keysTmp, lean, pmList, pmCount);
+            }
             hipLaunchKernelGGL((k_scan_local<true>), dim3(scanBlocks), dim3(SCAN_WAVES_PER_BLOCK), 0, st, (const uint32_t*)nullptr, total, (const uint8_t*)ctx->contFlag.as<uint8_t>(), contMask, waveLocal, blockSums);
         } else {
             TRACE_T0();
@@ -304,6 +314,7 @@ static int flush_batch(dev_ctx* ctx)
     for (int j = 1; j < depth; j++) {
         uint32_t* q = ctx->queue[side].as<uint32_t>(); uint32_t* k = ctx->keys[side].as<uint32_t>();
         const uint32_t* cnt = counts + j;
+        f.hitsByRid = (fused || (pmBounce && j == 1)) ? 1 : 0;                  // how this bounce's hit records are indexed (what its shading kernels are told)
         // exact multi-GPU deep paths: the host tells every sample how many alive rays the contexts above this strip hold (idkpt.h)
         const uint32_t* gbase = nullptr;
         const bool bandExchange = (ctx->bandExchangeFn || ctx->bandExchangeDevFn) && ctx->rowMod > 1 && !(ctx->st.DoRaySorting && j > 1);
@@ -374,6 +385,11 @@ static int flush_batch(dev_ctx* ctx)
         uint32_t gridj = traceGrid;
         const int hintMul = ctx->opt.gridHint;
         if (hintMul > 0 && ctx->lastBatch == B && ctx->hBases) gridj = small_launch_grid(traceGrid, ctx->hBases[(size_t)j * BS + B], hintMul, ctx->opt.gridRaysX4, midGrid);
+        if (fast && pmBounce && j == 1) {   // the list k_shade_first wrote: ray ids, hits stored per ray id (the PRIMARY instantiations read exactly that)
+            Frame ft = f; ft.hitsByRid = 0;
+            launch_trace2<true>(ctx, gridj, ldsBytes, st, s, ft, rays, tr, hits, (const uint32_t*)pmList, (const uint32_t*)pmCount, work + j, counters,
+                                want_split(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr, B), j);
+        } else
         if (fast) launch_trace2<false>(ctx, gridj, ldsBytes, st, s, f, rays, tr, hits, (const uint32_t*)q, cnt, work + j, counters,
                                        want_split(ctx, ctx->hBases ? ctx->hBases[(size_t)j * BS + B] : 0u, ctx->lastFast && ctx->lastBatch == B && ctx->hBases != nullptr, B), j);
         else {

@@ -31,35 +31,53 @@ DEV void write_trace_ready(const DScene& s, const Frame& f, const TraceBufs& tr,
 // goes to a per-ray byte (pre-zeroed), which the ordered compaction turns back into pixel order.
 template <bool VER /* scene versions: every sample shades with the geometry it was queued with (pt_kernels.hpp DScene::ver) */>
 __global__ __launch_bounds__(256) void k_shade_first(DScene s0, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* activeList, const uint32_t* activeCount,
-                                                     uint8_t* contFlag, uint32_t* seedsAndKeys, int lean /* k_gen_primary stored nothing but the trace-ready record of this ray */)
+                                                     uint8_t* contFlag, uint32_t* seedsAndKeys, int lean /* k_gen_primary stored nothing but the trace-ready record of this ray */,
+                                                     uint32_t* pmList /* or null */, uint32_t* pmCount)
 {
+    __shared__ uint32_t waveCont[4]; __shared__ uint32_t blockBase;
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= *activeCount) return;
-    const uint32_t rid = activeList[item];
-    const uint32_t smp = rid / f.Npad, pix = rid - smp * f.Npad;
-    const DScene s = VER ? scene_of_sample(s0, smp) : s0;
-    const uint32_t acc = sample_index(f, smp);
-    const HitRec hit = load_hit(hits, rid);
-    RayState r; uint32_t rng, key = 0;
-    if (lean) {   // the state FirstHit:44-77 starts a primary ray with, recomputed (same arithmetic, same bits) instead of 52 B written and read back
-        f2 pd; gen_primary(f, smp, pix, acc, r.origin, pd, rng);
-        r.prevIor = 1.0f; r.throughput = splat3(1.0f); r.pdx = pd.x; r.radiance = splat3(0.0f); r.pdy = pd.y;
-    } else {
-        float4 a = rays.o_ior[rid], b = rays.thr_px[rid], c = rays.rad_py[rid];
-        r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;
-        rng = seedsAndKeys[rid];
+    const bool live = item < *activeCount;
+    if (!pmList && !live) return;
+    bool cont = false; uint32_t rid = 0;
+    if (live) {
+        rid = activeList[item];
+        const uint32_t smp = rid / f.Npad, pix = rid - smp * f.Npad;
+        const DScene s = VER ? scene_of_sample(s0, smp) : s0;
+        const uint32_t acc = sample_index(f, smp);
+        const HitRec hit = load_hit(hits, rid);
+        RayState r; uint32_t rng, key = 0;
+        if (lean) {   // the state FirstHit:44-77 starts a primary ray with, recomputed (same arithmetic, same bits) instead of 52 B written and read back
+            f2 pd; gen_primary(f, smp, pix, acc, r.origin, pd, rng);
+            r.prevIor = 1.0f; r.throughput = splat3(1.0f); r.pdx = pd.x; r.radiance = splat3(0.0f); r.pdy = pd.y;
+        } else {
+            float4 a = rays.o_ior[rid], b = rays.thr_px[rid], c = rays.rad_py[rid];
+            r.origin = mk3(a.x, a.y, a.z); r.prevIor = a.w; r.throughput = mk3(b.x, b.y, b.z); r.pdx = b.w; r.radiance = mk3(c.x, c.y, c.z); r.pdy = c.w;
+            rng = seedsAndKeys[rid];
+        }
+        AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
+        int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
+        uint32_t gidSeed = first_hit_gid_seed(f.W, f.H, lx, global_row(f, ly));
+        f3 rd = DecodeUnitVec(r.pdx, r.pdy);
+        cont = ShadeHit<true>(s, f, acc, hit, hit.T != PT_FLOAT_MAX, rd, r, aov, rng, gidSeed, key);
+        rays.o_ior[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, r.prevIor);
+        rays.thr_px[rid] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
+        rays.rad_py[rid] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
+        if (f.outputAovs) { rays.aovA[rid] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[rid] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
+        seedsAndKeys[rid] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
+        if (cont) { contFlag[rid] = 1; write_trace_ready(s, f, tr, rid, r); }
     }
-    AovState aov; aov.albedo = splat3(0.0f); aov.normal = splat3(0.0f); aov.newWeight = 1.0f;
-    int lx = (int)(pix % (uint32_t)f.W), ly = (int)(pix / (uint32_t)f.W);
-    uint32_t gidSeed = first_hit_gid_seed(f.W, f.H, lx, global_row(f, ly));
-    f3 rd = DecodeUnitVec(r.pdx, r.pdy);
-    bool cont = ShadeHit<true>(s, f, acc, hit, hit.T != PT_FLOAT_MAX, rd, r, aov, rng, gidSeed, key);
-    rays.o_ior[rid] = make_float4(r.origin.x, r.origin.y, r.origin.z, r.prevIor);
-    rays.thr_px[rid] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.pdx);
-    rays.rad_py[rid] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, r.pdy);
-    if (f.outputAovs) { rays.aovA[rid] = make_float4(aov.albedo.x, aov.albedo.y, aov.albedo.z, aov.newWeight); rays.aovN[rid] = make_float4(aov.normal.x, aov.normal.y, aov.normal.z, 0.0f); }
-    seedsAndKeys[rid] = (key & ((1u << IDKPT_SORT_KEY_BITS) - 1u)) | (smp << IDKPT_SORT_KEY_BITS);
-    if (cont) { contFlag[rid] = 1; write_trace_ready(s, f, tr, rid, r); }
+    if (pmList) {
+        // the first bounce's work list in THIS kernel's order — the pixel-major order of the primary list (k_gen_primary): the continuing rays of a pixel's samples side by side,
+        // rays that start within a pixel's footprint of each other.  The alive queue (ordered compaction, slot = RNG seed) is built as always; this list only says in which
+        // order the traversal kernel takes the rays, and their hits are stored per ray id (Frame::hitsByRid).  One atomic per workgroup.
+        const unsigned long long m = __ballot(cont);
+        const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) waveCont[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t tot = 0; for (int i = 0; i < 4; i++) { const uint32_t c = waveCont[i]; waveCont[i] = tot; tot += c; } blockBase = tot ? atomicAdd(pmCount, tot) : 0u; }
+        __syncthreads();
+        if (cont) pmList[blockBase + waveCont[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rid;
+    }
 }
 
 template <bool FIRST, bool VER = false>

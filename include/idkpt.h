@@ -414,6 +414,7 @@ IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
  *     "defer_last"       0 / 1*      without AOVs only the radiance of a sample's last bounce is computed per frame; its continuation when a host asks (idkptDownloadRays ...)
  *     "gen_pixel_major"  >= 0 (8*)   batches of at least this many samples hand their primary rays to the traversal pixel by pixel (a wave = 4 pixels x 16 samples instead of an 8x8 tile of one
  *                                    sample; profiles/r05_pixel_major.md); 0 = never.   "gen_group_max" 1-16 (16*): samples per group of that list
+ *     "bounce_pixel_major" 0-2 (1*) the first bounce traced in that order too (its own work list, hits per ray id): 0 never, 1 on sparse views, 2 always
  *     "no_tile_cull"     0* / 1      no per-tile pre-classification of sky tiles      "no_lean_primary" 0* / 1   k_gen_primary stores the full state of surviving rays
  *   scheduling of the traversal kernels
  *     "leaf_min"         0* / 1-64   lanes parked on a leaf before the node phase is left (0: 16 for batches of >= 4 samples, 12 below)

@@ -18,8 +18,9 @@ for name, sc, cam, depth, B in (("headline", soup, bench.view_camera(S, "headlin
                                ("interior_20_samples", soup, bench.view_camera(S, "interior", W, H), 2, 20), ("atrium", atrium, S.atrium_camera(W, H), 2, 32), ("interior_d5", soup, bench.view_camera(S, "interior", W, H), 5, 32)):
     pt.UploadScene(sc); pt.SetCamera(cam); pt.RayDepth = depth
     row = {}; ref = None
-    for opt in (0, 8, 0, 8):
-        pt.set_option("gen_pixel_major", opt)
+    which = os.environ.get("AB_OPTION", "gen_pixel_major")            # AB_OPTION=bounce_pixel_major: the first bounce's list (0 / 1) under the pixel-major primary list
+    for opt in ((0, 2, 0, 2) if which == "bounce_pixel_major" else (0, 8, 0, 8)):
+        pt.set_option(which, opt)
         rays, dt = bench.timed_batch(pt, B, B, reps=5)
         st = pt.stats()
         img = np.ascontiguousarray(pt.Result).view(np.uint32)
@@ -28,5 +29,4 @@ for name, sc, cam, depth, B in (("headline", soup, bench.view_camera(S, "headlin
         row.setdefault(str(opt), []).append({"mray_s": round(rays / dt / 1e6, 1), "trace_ms_per_launch": round(st["trace_ms_total"] / max(st["trace_launches"], 1), 4)})
     res[name] = row
     print(json.dumps({name: row}), flush=True)
-pt.set_option("gen_pixel_major", 0)
 pt.Dispose()

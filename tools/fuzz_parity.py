@@ -106,7 +106,7 @@ def draw_case(seed, builder):
     opts["fused"] = int(rng.choice([0, 2, 2, 1])); opts["fused_shade_min"] = int(rng.choice([16, 1, 8, 32, 64]))
     _legacy2 = (int(rng.choice([0, 0, 2])), int(rng.choice([0, 0, 7, 2]))); opts["query_scheduler"] = 1
     opts["wide"] = int(rng.choice([0, 1, 1])); opts["wide_cap"] = int(rng.choice([0, 0, 6]))     # the wide-node walk (kernels_wide.hpp) on the one-BLAS cases
-    opts["inst_tlas_overlap"] = 100; opts["inst_tlas"] = int(rng.choice([2, 2, 0, 8])); opts["inst_sieve"] = int(rng.choice([0, 2])); opts["inst_sieve_overlap"] = 100; opts["gen_pixel_major"] = int(rng.choice([8, 2, 0]))                                            # the instance loop through the library's own TLAS (kernels_trace_inst.hpp) on the several-BLAS cases without UseTlas
+    opts["inst_tlas_overlap"] = 100; opts["inst_tlas"] = int(rng.choice([2, 2, 0, 8])); opts["inst_sieve"] = int(rng.choice([0, 2])); opts["inst_sieve_overlap"] = 100; opts["gen_pixel_major"] = int(rng.choice([8, 2, 0])); opts["bounce_pixel_major"] = int(rng.choice([2, 1, 0]))                                            # the instance loop through the library's own TLAS (kernels_trace_inst.hpp) on the several-BLAS cases without UseTlas
     # free choices of the implementation: never visible in the output (split is drawn last: the cases of earlier rounds keep their scenes)
     return sc, cam, w, h, ov, st, opts, frames, batch, nb
 
