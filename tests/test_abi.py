@@ -99,3 +99,18 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert out.returncode != 0
     assert "needs a GPU" in (out.stderr + out.stdout)
     assert not any(line.startswith("{") for line in out.stdout.splitlines())      # no metric line
+
+
+def test_every_developer_option_is_documented_and_forwarded():
+    """idkptSetDeveloperOption: every name the library accepts (csrc/host_options.hpp, csrc/idkpt_api.hpp) is documented in include/idkpt.h with its values and default, and the
+    Python host mirror forwards IDKPT_<NAME> for exactly those names (graph_probe exists in developer builds only)."""
+    import re
+    csrc = os.path.join(ROOT, "idkengine_amd", "csrc")
+    text = open(os.path.join(csrc, "host_options.hpp")).read() + open(os.path.join(csrc, "idkpt_api.hpp")).read()
+    accepted = set(re.findall(r'n == "([a-z0-9_]+)"', text)) | set(re.findall(r'name\) == "([a-z0-9_]+)"', text))
+    header = open(os.path.join(ROOT, "include", "idkpt.h")).read()
+    from idkengine_amd.pathtracer import _OPTION_NAMES
+    assert len(accepted) >= 40
+    assert [n for n in sorted(accepted) if f'"{n}"' not in header] == []
+    assert sorted(accepted - set(_OPTION_NAMES)) == ["graph_probe"]
+    assert sorted(set(_OPTION_NAMES) - accepted) == []
