@@ -7,7 +7,7 @@ from . import gputypes as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libidkbvh.so")
-SYMBOLS = ["idkbvhBuildBlas", "idkbvhBlasBegin", "idkbvhBlasFragments", "idkbvhBlasCoreCpu", "idkbvhBlasCoreGet", "idkbvhBlasCoreSet", "idkbvhBlasCoreBuffers", "idkbvhBlasFinish", "idkbvhBlasGetInfo", "idkbvhBlasCopy", "idkbvhBlasFree", "idkbvhInstanceWorldBounds", "idkbvhBuildTlas", "idkbvhRefitBlas"]
+SYMBOLS = ["idkbvhBuildBlas", "idkbvhBlasBegin", "idkbvhBlasFragments", "idkbvhBlasCoreCpu", "idkbvhBlasCoreGet", "idkbvhBlasCoreSet", "idkbvhBlasCoreBuffers", "idkbvhBlasFinish", "idkbvhBlasGetInfo", "idkbvhBlasCopy", "idkbvhBlasFree", "idkbvhSetPhaseTiming", "idkbvhInstanceWorldBounds", "idkbvhBuildTlas", "idkbvhRefitBlas"]
 _lib = None
 
 
@@ -33,6 +33,7 @@ def load():
         L.idkbvhBlasGetInfo.argtypes = [C.c_void_p, C.c_void_p]
         L.idkbvhBlasCopy.argtypes = [C.c_void_p] * 5
         L.idkbvhBlasFree.argtypes = [C.c_void_p]; L.idkbvhBlasFree.restype = None
+        L.idkbvhSetPhaseTiming.argtypes = [C.c_int32]; L.idkbvhSetPhaseTiming.restype = None
         L.idkbvhInstanceWorldBounds.argtypes = [C.c_void_p] * 3
         L.idkbvhBuildTlas.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.idkbvhRefitBlas.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]

@@ -30,6 +30,7 @@
 #include "../../include/idkbvh.h"
 
 namespace {
+static std::atomic<int> g_phaseTiming{0};   // idkbvhSetPhaseTiming
 
 constexpr int kThreadedRecursionThreshold = 1 << 13; // BLAS.cs:28
 constexpr int kThreadedSortingThreshold = 1 << 16;   // BLAS.cs:29
@@ -644,7 +645,7 @@ struct Builder {
     void begin(bool refittable, float factor, int threads)
     {
         t0 = tp = std::chrono::steady_clock::now();
-        timing = getenv("IDKBVH_TIMING") != nullptr;   // developer knob: phase times on stderr
+        timing = g_phaseTiming.load(std::memory_order_relaxed) != 0;   // idkbvhSetPhaseTiming: phase times on stderr
         getrusage(RUSAGE_SELF, &ru0);
         maxThreads = threads <= 0 ? defaultThreadCount() : threads;
         refit = refittable;
@@ -791,6 +792,7 @@ int32_t idkbvhBlasCopy(const idkbvh_blas* h, GpuBlasNode* nodes, GpuBlasTriangle
     return 0;
 }
 void idkbvhBlasFree(idkbvh_blas* h) { delete h; }
+void idkbvhSetPhaseTiming(int32_t enabled) { g_phaseTiming.store(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 int32_t idkbvhInstanceWorldBounds(const GpuBlasNode* root, const GpuMeshTransform* xf, float out[6])
 {

@@ -63,6 +63,8 @@ IDKBVH_API int32_t idkbvhBlasGetInfo(const idkbvh_blas* blas, idkbvh_blas_info* 
 /* Copies the results into caller arrays sized from idkbvhBlasGetInfo (parents/leaves may be NULL). */
 IDKBVH_API int32_t idkbvhBlasCopy(const idkbvh_blas* blas, GpuBlasNode* nodes, GpuBlasTriangle* triangles, int32_t* parentIndices, int32_t* leafIndices);
 IDKBVH_API void    idkbvhBlasFree(idkbvh_blas* blas);
+/* Developer knob (process-wide, default off): builds print their phase times on stderr.  The library reads no environment variable. */
+IDKBVH_API void    idkbvhSetPhaseTiming(int32_t enabled);
 
 /* Box.Transformed(blas.Root bounds, ModelMatrix) (Shapes/Box.cs:177-187, Bvh/BVH.cs:285-296): out = min.xyz, max.xyz */
 IDKBVH_API int32_t idkbvhInstanceWorldBounds(const GpuBlasNode* blasRoot, const GpuMeshTransform* transform, float outMinMax[6]);

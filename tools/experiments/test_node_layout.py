@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 @pytest.fixture(scope="module")
 def layout_lib(tmp_path_factory):
     so = tmp_path_factory.mktemp("layout") / "liblayoutcheck.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Werror", os.path.join(HERE, "c_driver", "layout_check.cpp"), "-o", str(so)])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Werror", os.path.join(HERE, "layout_check.cpp"), "-o", str(so)])
     L = C.CDLL(str(so))
     L.layout_compute.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_void_p]
     L.layout_compute.restype = C.c_int
