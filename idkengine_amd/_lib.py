@@ -8,13 +8,13 @@ LIB_PATH = os.environ.get("IDKPT_LIB_PATH") or os.path.join(_HERE, "libidkpt.so"
 
 # every symbol include/idkpt.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
-    "idkptCreate", "idkptDestroy", "idkptGetLastError", "idkptSetErrorCallback", "idkptGetDeviceCount", "idkptGetVersionString", "idkptGetContextDeviceCount", "idkptGetTransportInfo", "idkptTransportSelfTest", "idkptSetGroupSharding",
+    "idkptCreate", "idkptDestroy", "idkptGetLastError", "idkptSetErrorCallback", "idkptGetDeviceCount", "idkptGetVersionString", "idkptGetAbiVersion", "idkptGetContextDeviceCount", "idkptGetTransportInfo", "idkptTransportSelfTest", "idkptSetGroupSharding",
     "idkptSetSize", "idkptSetSceneVersions", "idkptSetRowSharding", "idkptSetRowBands", "idkptSetRowRange", "idkptSetBounceExchange", "idkptSetBandExchange", "idkptSetBandExchangeDevice", "idkptSetSettings", "idkptGetSettings",
     "idkptSetPerFrame", "idkptSetPerFrameData", "idkptUploadScene", "idkptUpdateBuffer", "idkptSetLightCount",
     "idkptBuildTlas", "idkptBuildTlasOnDevice", "idkptBuildBlasCore", "idkptBuildBlas", "idkptBuildBlasFetch", "idkptCbrtProbe", "idkptRefitBlas", "idkptUploadUnskinnedVertices", "idkptSkin", "idkptDownloadBuffer",
     "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptSetSampleSequence", "idkptRender", "idkptSynchronize", "idkptDownload",
     "idkptDownloadRays", "idkptDownloadAliveQueue", "idkptEnablePrimaryHitCapture", "idkptDownloadPrimaryHits",
-    "idkptGetStats", "idkptResetStats", "idkptEnableCounters", "idkptEnableTiming", "idkptGetImageDevicePtr",
+    "idkptGetStats", "idkptGetStatsSized", "idkptResetStats", "idkptEnableCounters", "idkptEnableTiming", "idkptGetImageDevicePtr",
     "idkptSetStream", "idkptGetStream", "idkptSetDeveloperOption", "idkptSetMaxBatch", "idkptFlush", "idkptTraceRays", "idkptTraceShadows", "idkptTraceRaysDevice", "idkptTraceShadowsDevice", "idkptSetFrameRing", "idkptBeginFrame", "idkptDownloadFrame", "idkptGetFrameDevicePtr",
 ]
 
@@ -46,7 +46,7 @@ def load():
         "idkptDownloadBuffer": [vp, i32, sz, sz, vp], "idkptResetAccumulation": [vp], "idkptSetSampleSequence": [vp, u32, u32], "idkptGetAccumulatedSamples": [vp, C.POINTER(u32)],
         "idkptRender": [vp], "idkptSynchronize": [vp], "idkptDownload": [vp, i32, vp, sz], "idkptDownloadRays": [vp, vp, sz],
         "idkptDownloadAliveQueue": [vp, vp, sz, C.POINTER(u32)], "idkptEnablePrimaryHitCapture": [vp, i32],
-        "idkptDownloadPrimaryHits": [vp, vp, vp, vp, sz], "idkptGetStats": [vp, vp], "idkptResetStats": [vp],
+        "idkptDownloadPrimaryHits": [vp, vp, vp, vp, sz], "idkptGetStats": [vp, vp], "idkptGetStatsSized": [vp, vp, sz], "idkptResetStats": [vp],
         "idkptEnableCounters": [vp, i32], "idkptEnableTiming": [vp, i32], "idkptGetImageDevicePtr": [vp, i32, C.POINTER(vp), C.POINTER(sz)],
         "idkptSetStream": [vp, vp], "idkptGetStream": [vp, C.POINTER(vp)], "idkptSetDeveloperOption": [vp, C.c_char_p, i32], "idkptSetMaxBatch": [vp, i32], "idkptFlush": [vp],
     }
@@ -54,6 +54,8 @@ def load():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i32
+    L.idkptGetAbiVersion.argtypes = []
+    L.idkptGetAbiVersion.restype = i32
     L.idkptGetVersionString.argtypes = []
     L.idkptGetVersionString.restype = C.c_char_p
     _lib = L

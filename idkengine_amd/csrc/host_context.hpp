@@ -65,6 +65,13 @@ struct DevOptions {
     int instTlasOverlap = 10;    // ... only where the instances' boxes overlap little: a random line through the scene meets at most this many PERCENT of them (k_tlas_build measures it).
                                  // 64 clusters at 5 / 10 / 20 / 30 %: the tree is 2.2x / 1.7x / 1.1x / 0.8x the loop seen from outside and 1.6x / 0.77x / 0.7x / 0.7x seen from inside;
                                  // soup-1M in 12 / 60 interleaved parts (72 / 37 %): 0.73-0.89x / 0.87-1.03x; the atrium's 87 meshes: 2.7 %.  100 = whatever the overlap
+    int packet = 1;              // k_trace_packet (kernels_packet.hpp): primary launches of one-BLAS scenes whose work list is pixel-major (batches of >= gen_pixel_major samples) walk the BVH2 as
+                                 // packets — one shared walk per wave, node pairs through the scalar cache; rays it cannot vouch for are re-traced by k_trace2.  0 = never, 1 (default) = where the
+                                 // kernel's own counters say the wave's rays want the same nodes (packet_decide: live lanes per node step), 2 = every primary launch of a one-BLAS scene
+                                 // (whatever the list's order: the tests' setting).  Bit-identical results either way (tests/test_gpu_packet.py).
+    int packetMinLive = 60;      // ... percent of a wave's lanes that must be live in an average node step for the packet walk to stay on (tools/packet_sim.cpp: break-even against k_trace2's
+                                 // 39 live lanes of 64 is 61 %; measured: profiles/r06_packet.md)
+    int packetWaves = 0;         // ... one-wave workgroups per CU of its persistent grid (0: 28 — 7 waves per SIMD at its 68 VGPRs)
     int bvhStackOptHost = 0;            // idkptBuildBlas: take OptimizeStackSize's decisions from the reference's own walk on a host copy (the fallback path, forced: for its test)
 };
 
@@ -108,6 +115,9 @@ struct dev_ctx {
     // both derived on the device before the first batch that wants them and after everything that moves boxes, positions or transforms
     DevBuf instRec; bool instRecValid = false;            // DScene::instRec (k_inst_records): one scene version only; re-derived with the own TLAS's triggers
     DevBuf itlas, imarks, ichunks; int itlasNeed = 1; uint32_t ichunkCount = 0; bool itlasValid = false, imarksValid = false;
+    // the packet walk's decision (host_launch.hpp packet_decide): 0 = probing (packets on, counters awaited), 1 = on, 2 = off; the kernel's counters arrive through host-mapped memory
+    // one or two batches late (k_packet_mirror): [1] packets, [2] node steps, [3] live lanes, [4] rays entered, [5] triangle rounds — totals since the last reset
+    int pkState = 0, pkBatchesSinceProbe = 0; unsigned long long* hPkStats = nullptr; unsigned long long* dPkStats = nullptr; unsigned long long pkSeen[6] = {0, 0, 0, 0, 0, 0}; float pkCam[36] = {0}; int pkW = 0, pkRows = 0, pkBatch = 0; float pkLastLive = -1.0f;
     float* hInstOverlap = nullptr; float* dInstOverlap = nullptr; bool instOverlapKnown = false, itlasBuilt = false, isieveWorth = false;   // host-mapped: instance boxes a random line meets (k_tlas_build); known = read at least once since the upload
     // scene versions: slot count a versioned buffer may grow to, per buffer the bytes of one state / the slot pitch / the slots its arena holds / the current slot
     int verSlots = 1; size_t vbytes[VB_COUNT] = {0}, vstride[VB_COUNT] = {0}; int valloc[VB_COUNT] = {1, 1, 1, 1, 1}, vcur[VB_COUNT] = {0};

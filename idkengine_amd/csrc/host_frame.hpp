@@ -141,7 +141,7 @@ static int ver_grow(dev_ctx* ctx, int b)
 static int ver_writable(dev_ctx* ctx, int b, bool full, char** src, char** dst)
 {
     if (b == VB_NODES || b == VB_TRIVERTS) { ctx->wideFillValid = false; ctx->imarksValid = false; }   // (node boxes or triangle positions are about to change: boxes and leaf records of the wide nodes, and the triangle marks, are re-derived before their next use)
-    if (b == VB_NODES || b == VB_XFORMS) ctx->itlasValid = false; ctx->instRecValid = false;        // (root boxes or transforms are about to change: the library's own TLAS is rebuilt before its next use)
+    if (b == VB_NODES || b == VB_XFORMS) { ctx->itlasValid = false; ctx->instRecValid = false; }    // (root boxes or transforms are about to change: the library's own TLAS is rebuilt before its next use)
     const int p = ctx->vcur[b];
     auto free_slot = [&](uint64_t busy) { if (ctx->verSlots > 1 && ctx->vbytes[b] > 0) for (int k = 0; k < ctx->verSlots; k++) if (!((busy >> k) & 1ull)) return k; return -1; };
     uint64_t pend = 0; for (const PendingSample& ps : ctx->pending) pend |= 1ull << ps.vs[b];

@@ -9,9 +9,10 @@ static int wide_stack_rows(const dev_ctx* ctx) { return std::min(96, std::max(4,
 // (re-)derives what is stale: the children lists after an upload / a node patch (k_wide_topo, one workgroup per BLAS), box bytes and leaf records after anything that
 // moved boxes or positions (k_wide_fill).  Stream-ordered in front of the batch that is about to be launched; with one scene version every update launches the queued samples first.
 static char* vb_ptr(dev_ctx* ctx, int b, int slot);
-// totals of the optional walks since idkptResetStats (idkpt_stats.Wide*, InstTlasFlaggedRays): eight 64-bit words, zeroed when first needed
+// totals of the optional walks since idkptResetStats (idkpt_stats.Wide*, InstTlasFlaggedRays, Packet*): sixteen 64-bit words ([0..3] wide, [4] own TLAS, [8..13] packets), zeroed when first needed
 static int inst_tlas_rows(const dev_ctx* ctx) { return std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount)); }   // LDS rows behind the BLAS stack: the own TLAS's stack, or an instance mask of 32 x that many bits
-static int totals_ensure(dev_ctx* ctx) { if (!ctx->wtotals.p) { HIPC(ctx->wtotals.ensure(64)); HIPC(hipMemsetAsync(ctx->wtotals.p, 0, 64, ctx->stream)); } return IDKPT_OK; }
+#define TOTALS_BYTES 128
+static int totals_ensure(dev_ctx* ctx) { if (!ctx->wtotals.p) { HIPC(ctx->wtotals.ensure(TOTALS_BYTES)); HIPC(hipMemsetAsync(ctx->wtotals.p, 0, TOTALS_BYTES, ctx->stream)); } return IDKPT_OK; }
 static int wide_prepare(dev_ctx* ctx)
 {
     if (ctx->wideTopoValid && ctx->wideFillValid) return IDKPT_OK;
@@ -61,6 +62,70 @@ static int inst_records_prepare(dev_ctx* ctx)
     return IDKPT_OK;
 }
 
+// ---- the per-triangle marks "not contained in its leaf box" (k_mark_triangles) of the walks that re-order a ray's candidates (k_trace_inst, k_trace_packet): derived on the
+// device before the first launch that wants them and after everything that moved boxes or positions (one scene version only)
+static int marks_prepare(dev_ctx* ctx)
+{
+    if (ctx->imarksValid) return IDKPT_OK;
+    hipStream_t st = ctx->stream;
+    if (ctx->ichunkCount == 0) {   // the flattened (BLAS, chunk of 256 nodes) table: once per upload
+        std::vector<uint32_t> tab;
+        for (size_t b = 0; b < ctx->hDescs.size(); b++) for (int first = 0; first < ctx->hDescs[b].NodeCount; first += 256) { tab.push_back((uint32_t)b); tab.push_back((uint32_t)first); }
+        ctx->ichunkCount = (uint32_t)(tab.size() / 2);
+        HIPC(ctx->ichunks.ensure(tab.size() * 4 + 8));
+        if (!tab.empty()) { HIPC(hipMemcpyAsync(ctx->ichunks.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }   // (tab is a stack vector)
+    }
+    HIPC(ctx->imarks.ensure((size_t)std::max(1, ctx->triCount)));
+    HIPC(hipMemsetAsync(ctx->imarks.p, 0, (size_t)std::max(1, ctx->triCount), st));
+    if (ctx->ichunkCount) hipLaunchKernelGGL(k_mark_triangles, dim3(ctx->ichunkCount), dim3(256), 0, st, (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]), (const float4*)vb_ptr(ctx, VB_TRIVERTS, ctx->vcur[VB_TRIVERTS]),
+                                             ctx->descs.as<GpuBlasDesc>(), (const uint2*)ctx->ichunks.as<uint2>(), ctx->imarks.as<uint8_t>());
+    HIPC(hipGetLastError());
+    ctx->imarksValid = true;
+    return IDKPT_OK;
+}
+
+// ---- the packet walk (kernels_packet.hpp): which primary launches use it ---------------------------------------------------------------------------------------------
+// One BLAS instance, closest hit, one scene version, the reference's counters not asked for, stock kernels; option packet = 1 additionally wants a pixel-major list and the
+// kernel's own counters in its favour (packet_decide).
+static bool packet_possible(const dev_ctx* ctx)
+{
+    return ctx->opt.packet != 0 && ctx->instanceCount == 1 && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && !ctx->opt.forceGeneric
+           && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);      // (with option "wide" as well: the packet walk takes the primary launch, the wide-node walk the bounces)
+}
+// Called once per batch whose primary launch could be a packet launch (flush_batch): reads what the kernel's counters said so far (host-mapped, written by k_packet_mirror behind every
+// packet launch: possibly a batch or two stale) and moves the decision: probing -> on / off by the live lanes per node step; on -> off when the view's coherence drops; off -> probing
+// when the camera, the frame size or the batch size changed (not more often than every 16 batches) or after 512 batches.  The decision only moves time, never a result.
+static bool packet_decide(dev_ctx* ctx, const Frame& f)
+{
+    if (!packet_possible(ctx)) return false;
+    if (ctx->opt.packet >= 2) return true;
+    if (!f.genPixelMajor) return false;
+    if (!ctx->hPkStats) return true;                                     // first packet launch of this context: probing
+    const volatile unsigned long long* h = ctx->hPkStats;
+    const unsigned long long steps = h[2], live = h[3];
+    if (steps < ctx->pkSeen[2]) { for (int i = 0; i < 6; i++) ctx->pkSeen[i] = 0; }                     // (idkptResetStats zeroed the totals)
+    const unsigned long long dSteps = steps - ctx->pkSeen[2], dLive = live - ctx->pkSeen[3];
+    const bool camSame = memcmp(ctx->pkCam, ctx->pending[0].cam, sizeof(ctx->pkCam)) == 0 && ctx->pkW == ctx->W && ctx->pkRows == ctx->rows && ctx->pkBatch == f.batch;
+    ctx->pkBatchesSinceProbe++;
+    if (ctx->pkState == 2) {
+        if ((!camSame && ctx->pkBatchesSinceProbe >= 16) || ctx->pkBatchesSinceProbe >= 512) { ctx->pkState = 0; ctx->pkBatchesSinceProbe = 0; ctx->pkSeen[2] = steps; ctx->pkSeen[3] = live; }
+    } else if (dSteps >= 4096ull) {                                       // enough node steps since the last look
+        const float frac = (float)((double)dLive / (64.0 * (double)dSteps));
+        ctx->pkLastLive = frac;
+        ctx->pkState = frac * 100.0f >= (float)ctx->opt.packetMinLive ? 1 : 2;
+        if (ctx->pkState == 2) ctx->pkBatchesSinceProbe = 0;
+        ctx->pkSeen[2] = steps; ctx->pkSeen[3] = live;
+    }
+    memcpy(ctx->pkCam, ctx->pending[0].cam, sizeof(ctx->pkCam)); ctx->pkW = ctx->W; ctx->pkRows = ctx->rows; ctx->pkBatch = f.batch;
+    return ctx->pkState != 2;
+}
+static int packet_prepare(dev_ctx* ctx)
+{
+    { int rc = totals_ensure(ctx); if (rc) return rc; }
+    if (!ctx->hPkStats) { HIPC(hipHostMalloc((void**)&ctx->hPkStats, 64, hipHostMallocMapped)); memset(ctx->hPkStats, 0, 64); HIPC(hipHostGetDevicePointer((void**)&ctx->dPkStats, ctx->hPkStats, 0)); }
+    return marks_prepare(ctx);
+}
+
 // ---- the library's own TLAS for the instance loop (kernels_trace_inst.hpp) ---------------------------------------------------------------------------------------
 // Several instances, no UseTlas, closest hit, one scene version, the reference's counters not asked for: everything else keeps the exact loop (k_trace2 MODE 1).
 static bool inst_tlas_wanted(const dev_ctx* ctx, bool sieve = false /* the same question for the exact loop with the instance sieve (option inst_sieve) */)
@@ -106,21 +171,7 @@ static int inst_tlas_prepare(dev_ctx* ctx, bool* useTlas, bool* useSieve)
     if (!tree && !sieve) return IDKPT_OK;
     { int rc = inst_records_prepare(ctx); if (rc) return rc; }
     if (!tree) { *useSieve = true; return IDKPT_OK; }
-    if (!ctx->imarksValid) {
-        if (ctx->ichunkCount == 0) {   // the flattened (BLAS, chunk of 256 nodes) table: once per upload
-            std::vector<uint32_t> tab;
-            for (size_t b = 0; b < ctx->hDescs.size(); b++) for (int first = 0; first < ctx->hDescs[b].NodeCount; first += 256) { tab.push_back((uint32_t)b); tab.push_back((uint32_t)first); }
-            ctx->ichunkCount = (uint32_t)(tab.size() / 2);
-            HIPC(ctx->ichunks.ensure(tab.size() * 4 + 8));
-            if (!tab.empty()) { HIPC(hipMemcpyAsync(ctx->ichunks.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }   // (tab is a stack vector)
-        }
-        HIPC(ctx->imarks.ensure((size_t)std::max(1, ctx->triCount)));
-        HIPC(hipMemsetAsync(ctx->imarks.p, 0, (size_t)std::max(1, ctx->triCount), st));
-        if (ctx->ichunkCount) hipLaunchKernelGGL(k_mark_triangles, dim3(ctx->ichunkCount), dim3(256), 0, st, nodes, (const float4*)vb_ptr(ctx, VB_TRIVERTS, ctx->vcur[VB_TRIVERTS]), ctx->descs.as<GpuBlasDesc>(),
-                                                 (const uint2*)ctx->ichunks.as<uint2>(), ctx->imarks.as<uint8_t>());
-        HIPC(hipGetLastError());
-        ctx->imarksValid = true;
-    }
+    { int rc = marks_prepare(ctx); if (rc) return rc; }
     *useTlas = true;
     return IDKPT_OK;
 }
@@ -132,6 +183,7 @@ static int inst_tlas_prepare(dev_ctx* ctx, bool* useTlas, bool* useSieve)
 //   k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>   any-hit queries (idkptTraceRays with IDKPT_TRACE_ANY_HIT), M = 0 / 1 / 2
 //   k_trace2s<P>                                      small launches of sparse views: long rays split across idle lanes (kernels_trace_split.hpp)
 //   k_trace_wide<P, C'> + k_trace2<P, false>          option "wide": the wide-node walk and the exact re-trace of the rays it does not vouch for (kernels_wide.hpp)
+//   k_trace_packet + k_trace2<true, false>            option "packet" (default: by measurement): primary launches as wave-uniform packets + the exact re-trace of the rays it does not vouch for (kernels_packet.hpp)
 //   k_trace_inst<P> + k_trace2<P, false, 16, .., 1>   option "inst_tlas" (default: from 8 instances on): the instance loop through the library's own TLAS + the exact loop for flagged rays
 // Developer builds (-DIDKPT_DEVELOPER, option "trace_variant") add the s_memtime-instrumented and the scheduling-probe instantiations.
 template <bool PRIMARY>
@@ -143,6 +195,19 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
 #define T2A(M) hipLaunchKernelGGL((k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         if (f.useTlas) T2A(2); else if (ctx->instanceCount > 1) T2A(1); else T2A(0);
 #undef T2A
+        return;
+    }
+    if (PRIMARY && bounce == 0 && f.packet && ctx->imarksValid && ctx->hPkStats && !s.ver && !f.useTlas && !f.queryMode && ctx->instanceCount == 1) {
+        // packet walk (kernels_packet.hpp), then — on the launch's own list of the rays it does not vouch for — the exact kernel
+        PacketBufs pb;
+        pb.marks = (const uint8_t*)ctx->imarks.as<uint8_t>(); pb.flagCount = work + 128; pb.flagA = ctx->sortKeys.as<uint32_t>(); pb.totals = ctx->wtotals.as<unsigned long long>() + 8;
+        const uint32_t pw = (uint32_t)std::min(32, std::max(1, ctx->opt.packetWaves > 0 ? ctx->opt.packetWaves : 28));
+        const uint32_t gp = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->numCUs * pw, (uint32_t)(((size_t)f.batch * ctx->W * ctx->rows + 63) / 64)));
+        hipLaunchKernelGGL((k_trace_packet<true>), dim3(gp), dim3(WAVE), 0, st, s, f, rays, tr, hits, list, cnt, work, pb);
+        hipLaunchKernelGGL(k_packet_mirror, dim3(1), dim3(64), 0, st, (const unsigned long long*)pb.totals, ctx->dPkStats);
+        TraceBufs trf = tr; trf.order = nullptr; trf.orderIdx = nullptr;
+        Frame ff = f; ff.gridRaysX4 = 6u; ff.gridMid = 0u;                       // (the device sizes the launch from its actual count: k_trace2's own rule)
+        hipLaunchKernelGGL((k_trace2<true, false>), dim3(std::min<uint32_t>(grid, 2048u)), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)pb.flagA, (const uint32_t*)pb.flagCount, work + 64, counters);
         return;
     }
     if (ctx->wideFillValid && ctx->wideTopoValid && wide_wanted(ctx) && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid) {

@@ -43,6 +43,9 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "inst_sieve_overlap") { REQUIRE(value >= 0 && value <= 100, "idkptSetDeveloperOption: inst_sieve_overlap is a percentage"); FLUSH(); o.instSieveOverlap = value; ctx->itlasValid = false; }
     else if (n == "inst_sieve") { REQUIRE(value >= 0, "idkptSetDeveloperOption: inst_sieve is >= 0"); FLUSH(); o.instSieve = value; ctx->itlasValid = false; }
     else if (n == "inst_tlas") { REQUIRE(value >= 0, "idkptSetDeveloperOption: inst_tlas is >= 0"); FLUSH(); o.instTlas = value; ctx->itlasValid = false; }   // (0: the exact instance loop only; n: the library's own TLAS from n instances on)
+    else if (n == "packet") { REQUIRE(value >= 0 && value <= 2, "idkptSetDeveloperOption: packet is 0..2"); o.packet = value; ctx->pkState = 0; ctx->pkBatchesSinceProbe = 0; }
+    else if (n == "packet_min_live") { REQUIRE(value >= 0 && value <= 100, "idkptSetDeveloperOption: packet_min_live is a percentage"); o.packetMinLive = value; ctx->pkState = 0; ctx->pkBatchesSinceProbe = 0; }
+    else if (n == "packet_waves") { REQUIRE(value >= 0 && value <= 32, "idkptSetDeveloperOption: packet_waves is 0 (default) or 1..32"); o.packetWaves = value; }
     else if (n == "wide") { REQUIRE(value >= 0 && value <= 1, "idkptSetDeveloperOption: wide is 0 or 1"); FLUSH(); o.wide = value; }
     else if (n == "wide_cap") { REQUIRE(value >= 0 && value <= 96, "idkptSetDeveloperOption: wide_cap is 0 (default) or 4..96 rows"); o.wideCap = value; }
     else if (n == "wide_count") o.wideCount = value != 0;

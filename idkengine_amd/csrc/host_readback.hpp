@@ -121,7 +121,8 @@ static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
     s.NodePairVisits = c[0]; s.TriangleTests = c[1];
     if (ctx->opt.traceVariant == 107 || ctx->opt.traceVariant == 113 || ctx->opt.traceVariant == 116 || ctx->opt.traceVariant == 213) { uint64_t d[16]; HIPC(hipMemcpyAsync(d, ctx->counters64.p, 128, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[idkpt prof] cycles refill %llu node %llu leaf %llu other %llu | refills %llu lanes %llu | nodeSteps %llu lanes %llu | leafPhases %llu lanes %llu | leafTests %llu leafTrips %llu\n", (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7], (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12], (unsigned long long)d[13], (unsigned long long)d[14], (unsigned long long)d[15]); }
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
-    if (ctx->wtotals.p) { uint64_t w[5] = {0, 0, 0, 0, 0}; HIPC(hipMemcpyAsync(w, ctx->wtotals.p, 40, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); s.WideFlaggedRays = w[0]; s.WideNodeVisits = w[1]; s.WideLeafRecords = w[2]; s.WideTriangleTests = w[3]; s.InstTlasFlaggedRays = w[4]; }
+    if (ctx->wtotals.p) { uint64_t w[16]; HIPC(hipMemcpyAsync(w, ctx->wtotals.p, TOTALS_BYTES, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); s.WideFlaggedRays = w[0]; s.WideNodeVisits = w[1]; s.WideLeafRecords = w[2]; s.WideTriangleTests = w[3]; s.InstTlasFlaggedRays = w[4];
+        s.PacketFlaggedRays = w[8]; s.PacketPackets = w[9]; s.PacketNodeSteps = w[10]; s.PacketLiveLanes = w[11]; s.PacketRaysEntered = w[12]; s.PacketTriangleRounds = w[13]; }
     *out = s;
     return IDKPT_OK;
 }
@@ -133,9 +134,11 @@ static int32_t dev_ResetStats(dev_ctx* ctx)
     FLUSH_KEEP();
     HIPC(hipStreamSynchronize(ctx->stream));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
+    if (ctx->hPkStats) memset(ctx->hPkStats, 0, 64);
+    for (int i = 0; i < 6; i++) ctx->pkSeen[i] = 0;
     ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;
     memset(ctx->hCounts, 0, (MAX_DEPTH_SLOTS - 1) * 4);     // (the last word, the length of the primary active list, is also the grid hint of the next batch: idkptGetStats reports it only once frames were rendered)
-    HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream)); if (ctx->wtotals.p) HIPC(hipMemsetAsync(ctx->wtotals.p, 0, 64, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
+    HIPC(hipMemsetAsync(ctx->counters64.p, 0, 128, ctx->stream)); if (ctx->wtotals.p) HIPC(hipMemsetAsync(ctx->wtotals.p, 0, TOTALS_BYTES, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream));
     return IDKPT_OK;
 }
 

@@ -133,6 +133,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     if (ctx->hCounts) (void)hipHostFree(ctx->hCounts);
     if (ctx->hOverflow) (void)hipHostFree(ctx->hOverflow);
     if (ctx->hInstOverlap) (void)hipHostFree(ctx->hInstOverlap);
+    if (ctx->hPkStats) (void)hipHostFree(ctx->hPkStats);
     if (ctx->hBases) (void)hipHostFree(ctx->hBases);
     if (ctx->hCams) (void)hipHostFree(ctx->hCams);
     for (int i = 0; i < 2; i++) if (ctx->evCams[i]) (void)hipEventDestroy(ctx->evCams[i]);
@@ -235,7 +236,7 @@ static int32_t dev_SetBandExchangeDevice(dev_ctx* ctx, idkpt_band_exchange_devic
 static int32_t dev_SetSettings(dev_ctx* ctx, const idkpt_settings* s)
 {
     if (!ctx || !s) return IDKPT_ERR_INVALID_ARGUMENT;
-    REQUIRE(s->RayDepth >= 1 && s->RayDepth < MAX_DEPTH_SLOTS - 1, "idkptSetSettings: RayDepth out of range");
+    REQUIRE(s->RayDepth >= 1 && s->RayDepth < MAX_DEPTH_SLOTS - 2, "idkptSetSettings: RayDepth out of range (1..61)");   // (count words MAX_DEPTH_SLOTS - 2 / - 1 are the pixel-major bounce list's and the primary list's lengths: host_schedule.hpp)
     REQUIRE(s->SamplesPerPixel >= 1, "idkptSetSettings: SamplesPerPixel must be >= 1");
     REQUIRE(s->BlasStackSize >= 0, "idkptSetSettings: BlasStackSize must be >= 0 (0 = derive from BlasDescs)");
     // BVH.BlasStackSize is the maximum RequiredStackSize of all BLASes (Bvh/BVH.cs:559-567): a smaller stack cannot hold the traversal

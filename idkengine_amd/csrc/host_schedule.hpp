@@ -218,12 +218,20 @@ static int flush_batch(dev_ctx* ctx)
     const uint32_t gridTotal = (total + 255) / 256;
     const bool fast = fast_path(ctx);
     if (fast && wide_wanted(ctx)) { int rc = wide_prepare(ctx); if (rc) { ctx->pending.clear(); return rc; } }
+    // (not where the samples of a batch are different frames — their own cameras or scene versions: the same pixel is then not the same ray, and under scene versions not even the
+    // same node addresses; measured on the animated bench, 8 / 32 frames in flight: 3 291 / 3 716 -> 3 011 / 3 117 Mray/s)
+    f.genPixelMajor = (fast && ctx->opt.genPixelMajor > 0 && B >= ctx->opt.genPixelMajor && !f.tilePerSample) ? 1 : 0;
+    // the primary launch as a packet launch (kernels_packet.hpp): one-BLAS scenes; by the kernel's own counters unless forced (host_launch.hpp packet_decide)
+    const bool packet = fast && !multiVer && !f.useTlas && packet_decide(ctx, f);
     // one launch for FirstHit + the last NHit (kernels_trace_fused.hpp): RayDepth 2, one BLAS instance, the last bounce deferred (no AOVs, no debug view), nothing that looks at
     // the primary hits or the visit counters, no per-bounce exchange with other contexts — and a launch small enough to be bound by its longest rays
     const bool fused = fast && ctx->st.RayDepth == 2 && ctx->opt.deferLast != 0 && !f.outputAovs && !f.g.DoDebugBVHTraversal && !f.useTlas && ctx->instanceCount == 1 && !multiVer && !ctx->counters
                        && !ctx->capturePrimary && !ctx->groupExchange && !ctx->exchangeFn && !ctx->bandExchangeFn && !ctx->bandExchangeDevFn && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100)
+                       && !(packet && ctx->opt.packet >= 2)             // (a forced packet walk is the tests' setting: nothing else takes the primary launch)
                        && !(wide_wanted(ctx) && ctx->opt.fused < 2)    // (the wide-node walk shortens the dependent chains the fused launch only stops paying launches for)
                        && want_fused(ctx, ctx->hCounts[MAX_DEPTH_SLOTS - 1], ctx->lastFast && ctx->lastBatch == B, B);
+    f.packet = (packet && !fused) ? 1 : 0;
+    if (f.packet) { int rc = packet_prepare(ctx); if (rc) { ctx->pending.clear(); return rc; } }
     f.hitsByRid = fused ? 1 : 0; f.shadeMin = ctx->opt.fusedShadeMin; f.scatterLog2 = ctx->opt.splitScatter;
     if (!fast && (B != 1 || multiVer)) { ctx->pending.clear(); return fail(ctx, IDKPT_ERR_UNKNOWN, "internal: generic path is never batched"); }
     unsigned long long* contMask = ctx->contMask.as<unsigned long long>();
@@ -234,7 +242,7 @@ static int flush_batch(dev_ctx* ctx)
     // ---- FirstHit
     uint32_t* activeList = ctx->sortVals.as<uint32_t>(); // scratch (capacity uints), free until the first sort
     uint32_t* activeCount = counts + (MAX_DEPTH_SLOTS - 1);
-    uint32_t* pmList = nullptr; uint32_t* const pmCount = counts + (MAX_DEPTH_SLOTS - 2); bool pmBounce = false;   // (RayDepth < MAX_DEPTH_SLOTS - 1: the word is nobody's queue length; reset with the others)
+    uint32_t* pmList = nullptr; uint32_t* const pmCount = counts + (MAX_DEPTH_SLOTS - 2); bool pmBounce = false;   // (RayDepth < MAX_DEPTH_SLOTS - 2, idkptSetSettings: the word is nobody's queue length — k_scan_blocks writes counts[1 .. RayDepth]; reset with the others)
     TraceBufs tr = {ctx->trRec.as<float4>(), nullptr, nullptr};
     TraceBufs trNone = {nullptr, nullptr, nullptr};
     uint32_t* waveLocal = waveCounts;                     // per-wave exclusive offset inside its 256-wave scan block
@@ -258,9 +266,6 @@ static int flush_batch(dev_ctx* ctx)
                 else hipLaunchKernelGGL((k_classify_tiles<false>), dim3((genWaves + 255) / 256, classSets), dim3(256), 0, st, s, f, ctx->tileClass.as<uint8_t>(), tilesX, tilesY);
                 tileClass = ctx->tileClass.as<uint8_t>();
             }
-            // (not where the samples of a batch are different frames — their own cameras or scene versions: the same pixel is then not the same ray, and under scene versions not even the
-            // same node addresses; measured on the animated bench, 8 / 32 frames in flight: 3 291 / 3 716 -> 3 011 / 3 117 Mray/s)
-            f.genPixelMajor = (ctx->opt.genPixelMajor > 0 && B >= ctx->opt.genPixelMajor && !f.tilePerSample) ? 1 : 0;
             const int genMax = std::min(16, std::max(1, ctx->opt.genGroupMax)), genGroups = (B + genMax - 1) / genMax, genPer = (B + genGroups - 1) / genGroups;     // pixel-major: the batch in equal groups of at most 16 samples, one wave per sample
             const dim3 genGrid = f.genPixelMajor ? dim3(genGroups, genWaves) : dim3(B, (genWaves + 15) / 16), genBlock = f.genPixelMajor ? dim3(64 * genPer) : dim3(1024);
             if (multiVer) hipLaunchKernelGGL((k_gen_primary<true>), genGrid, genBlock, 0, st, s, f, rays, tr, cull, activeList, activeCount, keysTmp, ctx->contFlag.as<uint8_t>(), tileClass, lean);

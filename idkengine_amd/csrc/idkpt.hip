@@ -23,6 +23,7 @@ using namespace ptd;
 #include "kernels_trace.hpp"
 #include "kernels_wide.hpp"
 #include "kernels_trace_inst.hpp"
+#include "kernels_packet.hpp"
 #include "kernels_trace_split.hpp"
 #include "kernels_query.hpp"
 #include "kernels_shade.hpp"

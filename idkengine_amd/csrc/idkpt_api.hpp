@@ -366,7 +366,8 @@ static inline uint32_t global_pixel(const idkpt_ctx* c, int d, uint32_t local)
 
 extern "C" {
 
-const char* idkptGetVersionString(void) { return "idkpt 0.2 (gfx950)"; }
+const char* idkptGetVersionString(void) { return "idkpt 0.3 (gfx950)"; }
+int32_t idkptGetAbiVersion(void) { return IDKPT_ABI_VERSION; }
 int32_t idkptGetDeviceCount(int32_t* outCount) { return dev_GetDeviceCount(outCount); }
 
 int32_t idkptCreate(int32_t deviceCount, const int32_t* deviceIds, idkpt_ctx** outCtx)
@@ -810,12 +811,20 @@ int32_t idkptGetStats(idkpt_ctx* c, idkpt_stats* out)
         idkpt_stats s; int rc = dev_GetStats(c->dev[d], &s); if (rc) return mfail(c, c->dev[d], rc);
         sum.RaysTraced += s.RaysTraced; sum.PrimaryRays += s.PrimaryRays; sum.NodePairVisits += s.NodePairVisits; sum.TriangleTests += s.TriangleTests;
         sum.WideFlaggedRays += s.WideFlaggedRays; sum.WideNodeVisits += s.WideNodeVisits; sum.WideLeafRecords += s.WideLeafRecords; sum.WideTriangleTests += s.WideTriangleTests; sum.InstTlasFlaggedRays += s.InstTlasFlaggedRays;
+        sum.PacketFlaggedRays += s.PacketFlaggedRays; sum.PacketPackets += s.PacketPackets; sum.PacketNodeSteps += s.PacketNodeSteps; sum.PacketLiveLanes += s.PacketLiveLanes; sum.PacketRaysEntered += s.PacketRaysEntered; sum.PacketTriangleRounds += s.PacketTriangleRounds;
         for (int j = 0; j < 16; j++) sum.LastAliveCounts[j] += s.LastAliveCounts[j];
         sum.LastFrameMs = std::max(sum.LastFrameMs, s.LastFrameMs); sum.LastTraceMs = std::max(sum.LastTraceMs, s.LastTraceMs);       // the devices run side by side
         sum.TraceMsTotal = std::max(sum.TraceMsTotal, s.TraceMsTotal);
         if (d == 0) { sum.Frames = s.Frames; sum.TraceLaunches = s.TraceLaunches; }
     }
     *out = sum;
+    return IDKPT_OK;
+}
+int32_t idkptGetStatsSized(idkpt_ctx* c, void* out, size_t bytes)
+{
+    if (!c || !out) return IDKPT_ERR_INVALID_ARGUMENT;
+    idkpt_stats s; const int32_t rc = idkptGetStats(c, &s); if (rc) return rc;
+    memcpy(out, &s, std::min(bytes, sizeof(s)));
     return IDKPT_OK;
 }
 int32_t idkptResetStats(idkpt_ctx* c) { REPLICATE(ResetStats); }

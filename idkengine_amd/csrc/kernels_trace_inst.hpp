@@ -293,10 +293,14 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                 if (RayTriangleIntersect(ro, rd, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), &by, &bz, &t)) {
                     const uint32_t id = i + triOff;
                     const bool other = id != hitTri || xformId != hitXform;     // (two instances may share a BLAS: the same triangle index under another transform is another candidate)
+                    const float leafT1 = gmin(i < leftEnd ? tL : __builtin_inff(), i >= rightStart ? tR : __builtin_inff());
+                    // the argument's one assumption, checked on every met hit as kernels_wide.hpp does: a triangle its leaf box contains is never hit more than 3 * 2^-16 in front of the box's
+                    // entry.  (A marked triangle may be — and is flagged when it wins; an unmarked one that is — host-patched nodes with loose boxes — takes the ray to the exact loop.)
+                    if (!EXACT && leafT1 > t * wide::ASSUME && ib.marks[id] == 0) flags |= 4u;
                     if (t < hitT) {
                         if (other) second = gmin(second, hitT);
                         hitT = t; cullT = EXACT ? t : t * wide::CULL; hbx = 1.0f - by - bz; hby = by; hitTri = id; hitXform = xformId;
-                        bestLeafT1 = gmin(i < leftEnd ? tL : __builtin_inff(), i >= rightStart ? tR : __builtin_inff());
+                        bestLeafT1 = leafT1;
                     } else if (other) second = gmin(second, t);
                 }
             }

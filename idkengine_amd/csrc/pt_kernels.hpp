@@ -75,6 +75,7 @@ struct Frame {
     int genPixelMajor;          // k_gen_primary appends a tile's survivors pixel by pixel over 16 samples (batches of >= 8 samples): kernels_trace.hpp
     int instSieve;              // several instances without USE_TLAS: the exact loop with the per-ray instance sieve (kernels_trace_inst.hpp, EXACT) instead of k_trace2 MODE 1
     int instTlas;               // several instances without USE_TLAS walked through the library's own TLAS (kernels_trace_inst.hpp): the producers of a ray also write its world 1/dir
+    int packet;                 // this batch's primary launch is a packet launch (kernels_packet.hpp; decided by the host per batch: host_launch.hpp packet_decide)
     int tilePerSample;          // k_classify_tiles ran once per sample of the batch (per-sample cameras or scene versions): tile classes are indexed [sample][tile]
 };
 #define MAX_BATCH 256

@@ -142,7 +142,19 @@ typedef struct idkpt_stats {
     uint64_t WideTriangleTests; /* ... triangle tests of the wide-node walk (every one beyond a record's first is another 48-byte fetch) */
     uint64_t InstTlasFlaggedRays; /* rays of multi-instance scenes without UseTlas that the walk through the library's own TLAS did not vouch for and the exact instance loop traced
                                    * again, since idkptResetStats (developer option "inst_tlas", kernels_trace_inst.hpp) */
+    /* ABI 3 (round 6): the packet walk of the primary launches (developer option "packet", kernels_packet.hpp), since idkptResetStats */
+    uint64_t PacketFlaggedRays;  /* rays the packet walk did not vouch for and the exact BVH2 kernel traced again */
+    uint64_t PacketPackets;      /* packets (waves of 64 consecutive work-list entries) walked */
+    uint64_t PacketNodeSteps;    /* node-pair steps of those walks (one 64-byte scalar fetch each) */
+    uint64_t PacketLiveLanes;    /* lanes that were live, summed over the node steps: / (64 x PacketNodeSteps) = what the automatic choice looks at */
+    uint64_t PacketRaysEntered;  /* rays that entered the BVH inside a packet */
+    uint64_t PacketTriangleRounds; /* wave-wide triangle tests (one 48-byte scalar fetch each) */
 } idkpt_stats;
+/* The layout above only ever GROWS at its end, and IDKPT_ABI_VERSION counts the growths (and every other change a host compiled against an older header could trip over: new
+ * enum values of idkpt_buffer, new fields of idkpt_texture).  A host that does not compile against this header (the C# LibraryImport struct of INTEGRATION.md) passes the size
+ * of ITS struct to idkptGetStatsSized and gets exactly that many bytes; idkptGetStats(ctx, out) is idkptGetStatsSized(ctx, out, sizeof(idkpt_stats)) of the header the LIBRARY
+ * was built with — for hosts built from the same tree.  idkptGetAbiVersion() lets a host refuse a library older than the header it was written against. */
+#define IDKPT_ABI_VERSION 3
 
 /* ---- lifetime --------------------------------------------------------------------------- */
 /* new PathTracer(w,h,settings) (PathTracer.cs:170-212).  deviceCount = 1: the reference's situation, one GPU.
@@ -201,6 +213,7 @@ IDKPT_API int32_t idkptSetErrorCallback(idkpt_ctx* ctx, idkpt_error_fn fn, void*
 /* Library/device probe usable before Create (NativeLibrary.TryLoad pattern, OIDN/OIDN.cs:11-20) */
 IDKPT_API int32_t idkptGetDeviceCount(int32_t* outCount);
 IDKPT_API const char* idkptGetVersionString(void);
+IDKPT_API int32_t idkptGetAbiVersion(void);   /* IDKPT_ABI_VERSION of the header the library was built with */
 
 /* ---- configuration ---------------------------------------------------------------------- */
 /* PathTracer.SetSize (PathTracer.cs:299-332): (re)allocates ray/queue/sort buffers and images, resets accumulation */
@@ -384,6 +397,7 @@ IDKPT_API int32_t idkptDownloadPrimaryHits(idkpt_ctx* ctx, float* t, uint32_t* t
 
 /* ---- instrumentation -------------------------------------------------------------------- */
 IDKPT_API int32_t idkptGetStats(idkpt_ctx* ctx, idkpt_stats* outStats);
+IDKPT_API int32_t idkptGetStatsSized(idkpt_ctx* ctx, void* outStats, size_t statsBytes);   /* writes min(statsBytes, sizeof(idkpt_stats)) bytes: see IDKPT_ABI_VERSION */
 IDKPT_API int32_t idkptResetStats(idkpt_ctx* ctx);
 /* enable=1: trace kernels also count node-pair visits / triangle tests (debugCost terms of BVHIntersect.glsl:45,60) */
 IDKPT_API int32_t idkptEnableCounters(idkpt_ctx* ctx, int32_t enable);
@@ -403,6 +417,10 @@ IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
  *     "pool_min"         >= 0 (12*)  (ray, triangle) pairs a wave must have parked before they are pooled
  *     "wide"             0* / 1      k_trace_wide: closest hits over the derived 4-wide nodes, unvouched rays re-traced by k_trace2 (csrc/wide_nodes.hpp; profiles/r05_wide_nodes.md)
  *     "wide_cap"         0* / 4-96   rows of its per-lane stack (0 = 24)        "wide_count" 0* / 1   count its node / leaf-record / triangle fetches (idkpt_stats.Wide*)
+ *     "packet"           0-2 (1*)    k_trace_packet: the primary launch of a one-BLAS scene as wave-uniform packets (one shared walk per wave of 64 consecutive work-list entries, node pairs and triangles
+ *                                    through the scalar cache), unvouched rays re-traced by k_trace2 (idkpt_stats.Packet*; csrc/kernels_packet.hpp, profiles/r06_packet.md): 0 never, 1 pixel-major lists
+ *                                    (batches of >= gen_pixel_major samples) while the kernel's own counters show the wave's rays wanting the same nodes, 2 every primary launch of a one-BLAS scene
+ *     "packet_min_live"  0-100 (60*) ... percent of a wave's lanes live in an average node step below which the automatic choice turns the packet walk off      "packet_waves" 0* / 1-32   its waves per CU (0 = 28)
  *     "inst_tlas"        >= 0 (8*)   k_trace_inst: scenes of at least this many BLAS instances rendered WITHOUT UseTlas (the reference's instance loop, BVHIntersect.glsl:275-287) walk a
  *                                    TLAS the library builds for itself; rays whose hit could depend on the loop's order are traced again by the exact loop (idkpt_stats.InstTlasFlaggedRays;
  *                                    csrc/kernels_trace_inst.hpp, profiles/r05_instance_tlas.md).  0 = the loop only.  Not used with the counting build, DoDebugBVHTraversal, scene versions.

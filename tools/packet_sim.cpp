@@ -84,7 +84,7 @@ static Hit ref_trace(const Scene& s, V3 ro, V3 rd, uint64_t& pairs, uint64_t& tr
     return h;
 }
 
-struct PStat { uint64_t packets = 0, rays = 0, nodeSteps = 0, liveLanes = 0, leafVisits = 0, triRounds = 0, triLanes = 0, flagged = 0, mismatchUnflagged = 0, maxSp = 0, refPairs = 0, refTris = 0, pops = 0; };
+struct PStat { uint64_t packets = 0, rays = 0, nodeSteps = 0, liveLanes = 0, leafVisits = 0, triRounds = 0, triLanes = 0, flagged = 0, mismatchUnflagged = 0, maxSp = 0, refPairs = 0, refTris = 0, pops = 0, popSkips = 0; };
 
 // Packet walk.  Stack entries carry the mask of lanes that hit the pushed child's box (their own test at push time); a popped entry is visited by the lanes of that mask whose
 // T still admits it... the entry distance is per lane, so the model keeps per-lane entry distances only implicitly: a popped node pair is re-tested by every lane of the mask (the test
@@ -98,14 +98,14 @@ static void packet_trace(const Scene& s, const V3* ro, const V3* rd, int n, Hit*
         float t; if (ray_box(ro[i], inv[i], s.nodes[1].mn, s.nodes[1].mx, &t) && t < FLOAT_MAX) live |= 1ull << i;
     }
     if (!live) return;
-    struct E { uint32_t node; uint64_t mask; } stack[256]; int sp = 0;
+    struct E { uint32_t node; uint64_t mask; float t1[64]; } stack[64]; int sp = 0; const bool popCull = getenv("POP_CULL") != nullptr;
     uint32_t top = 2; uint64_t mask = live;
     while (true) {
         st.nodeSteps++; st.liveLanes += __builtin_popcountll(mask);
         const Bvh2Node& L = s.nodes[top]; const Bvh2Node& R = s.nodes[top + 1];
-        uint64_t mL = 0, mR = 0; int votesL = 0, votesR = 0;
+        uint64_t mL = 0, mR = 0; int votesL = 0, votesR = 0; float t1L[64], t1R[64];
         for (int i = 0; i < n; i++) if (mask >> i & 1) {
-            float tl, tr;
+            float& tl = t1L[i]; float& tr = t1R[i];
             bool hl = ray_box(ro[i], inv[i], L.mn, L.mx, &tl) && tl <= out[i].T;
             bool hr = ray_box(ro[i], inv[i], R.mn, R.mx, &tr) && tr <= out[i].T;
             if (hl) mL |= 1ull << i; if (hr) mR |= 1ull << i;
@@ -133,12 +133,21 @@ static void packet_trace(const Scene& s, const V3* ro, const V3* rd, int n, Hit*
         const uint64_t tL = L.triCount == 0 ? mL : 0, tR = R.triCount == 0 ? mR : 0;
         if (tL && tR) {
             const bool lc = votesL >= votesR;
-            if (sp >= 255) { fprintf(stderr, "stack overflow\n"); exit(3); }
-            stack[sp++] = lc ? E{R.startOrChild, tR} : E{L.startOrChild, tL};
+            if (sp >= 63) { fprintf(stderr, "stack overflow\n"); exit(3); }
+            stack[sp].node = lc ? R.startOrChild : L.startOrChild; stack[sp].mask = lc ? tR : tL; memcpy(stack[sp].t1, lc ? t1R : t1L, sizeof(t1L)); sp++;
             if ((uint64_t)sp > st.maxSp) st.maxSp = sp;
             top = lc ? L.startOrChild : R.startOrChild; mask = lc ? tL : tR;
         } else if (tL || tR) { top = tL ? L.startOrChild : R.startOrChild; mask = tL ? tL : tR; }
-        else { if (sp == 0) break; --sp; st.pops++; top = stack[sp].node; mask = stack[sp].mask; }
+        else {
+            bool got = false;
+            while (sp > 0) {
+                --sp; st.pops++; top = stack[sp].node; mask = stack[sp].mask;
+                if (popCull) { for (int i = 0; i < n; i++) if ((mask >> i & 1) && !(stack[sp].t1[i] <= out[i].T)) mask &= ~(1ull << i); }
+                if (mask) { got = true; break; }
+                st.popSkips++;
+            }
+            if (!got) break;
+        }
     }
     for (int i = 0; i < n; i++) if (out[i].tri != ~0u && second[i] <= out[i].T * (1.0f + 1.0f / 65536.0f)) flag[i] = true;
 }
@@ -185,7 +194,7 @@ int main(int argc, char** argv)
         }
 #pragma omp critical
         { tot.packets += st.packets; tot.rays += st.rays; tot.nodeSteps += st.nodeSteps; tot.liveLanes += st.liveLanes; tot.leafVisits += st.leafVisits; tot.triRounds += st.triRounds; tot.triLanes += st.triLanes;
-          tot.flagged += st.flagged; tot.mismatchUnflagged += st.mismatchUnflagged; tot.maxSp = std::max(tot.maxSp, st.maxSp); tot.refPairs += st.refPairs; tot.refTris += st.refTris; tot.pops += st.pops; }
+          tot.flagged += st.flagged; tot.mismatchUnflagged += st.mismatchUnflagged; tot.maxSp = std::max(tot.maxSp, st.maxSp); tot.refPairs += st.refPairs; tot.refTris += st.refTris; tot.pops += st.pops; tot.popSkips += st.popSkips; }
     }
     const double P = (double)std::max<uint64_t>(tot.packets, 1), R = (double)std::max<uint64_t>(tot.rays, 1);
     printf("%s, packets of %d x %d pixels x %d samples: %llu packets with %.1f entering rays each\n", view.c_str(), PX, PXY, SMP, (unsigned long long)tot.packets, R / P);
@@ -193,6 +202,7 @@ int main(int argc, char** argv)
     printf("  packet walk  : %.1f node steps per packet (%.1f live lanes per step: %.2f of the entering rays), %.1f leaf visits, %.1f wave-wide triangle rounds (%.1f lanes each), stack depth <= %llu\n", tot.nodeSteps / P, (double)tot.liveLanes / tot.nodeSteps, (double)tot.liveLanes / tot.nodeSteps / (R / P),
            tot.leafVisits / P, tot.triRounds / P, (double)tot.triLanes / std::max<uint64_t>(tot.triRounds, 1), (unsigned long long)tot.maxSp);
     printf("  normalised to 64 entering rays: packet node steps %.0f vs while-while wave steps %.0f (x%.2f); triangle rounds %.0f\n", tot.nodeSteps / R * 64.0, 64.0 * tot.refPairs / R / 39.0, (tot.nodeSteps / R * 64.0) / (64.0 * tot.refPairs / R / 39.0), tot.triRounds / R * 64.0);
+    printf("  pops %.1f per packet, %.1f of them skipped whole (POP_CULL)\n", tot.pops / P, tot.popSkips / P);
     printf("  flagged for the exact re-trace %.4f %% of the rays; unflagged rays whose hit differs from the per-ray walk: %llu\n", 100.0 * tot.flagged / R, (unsigned long long)tot.mismatchUnflagged);
     return 0;
 }
