@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("IDKPT_LIB_PATH") or os.path.join(_HERE, "libidkpt.so"
 SYMBOLS = [
     "idkptCreate", "idkptDestroy", "idkptGetLastError", "idkptSetErrorCallback", "idkptGetDeviceCount", "idkptGetVersionString", "idkptGetAbiVersion", "idkptGetContextDeviceCount", "idkptGetTransportInfo", "idkptTransportSelfTest", "idkptSetGroupSharding",
     "idkptSetSize", "idkptSetSceneVersions", "idkptSetRowSharding", "idkptSetRowBands", "idkptSetRowRange", "idkptSetBounceExchange", "idkptSetBandExchange", "idkptSetBandExchangeDevice", "idkptSetSettings", "idkptGetSettings",
-    "idkptSetPerFrame", "idkptSetPerFrameData", "idkptUploadScene", "idkptUpdateBuffer", "idkptSetLightCount",
+    "idkptSetPerFrame", "idkptSetPerFrameData", "idkptUploadScene", "idkptUpdateBuffer", "idkptUpdateTexture", "idkptSetLightCount",
     "idkptBuildTlas", "idkptBuildTlasOnDevice", "idkptBuildBlasCore", "idkptBuildBlas", "idkptBuildBlasFetch", "idkptCbrtProbe", "idkptRefitBlas", "idkptUploadUnskinnedVertices", "idkptSkin", "idkptDownloadBuffer",
     "idkptResetAccumulation", "idkptGetAccumulatedSamples", "idkptSetSampleSequence", "idkptRender", "idkptSynchronize", "idkptDownload",
     "idkptDownloadRays", "idkptDownloadAliveQueue", "idkptEnablePrimaryHitCapture", "idkptDownloadPrimaryHits",
@@ -40,7 +40,7 @@ def load():
         "idkptGetDeviceCount": [C.POINTER(i32)], "idkptGetContextDeviceCount": [vp, C.POINTER(i32)], "idkptGetTransportInfo": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_char_p)], "idkptTransportSelfTest": [i32, C.POINTER(i32), C.c_char_p, sz], "idkptSetGroupSharding": [vp, i32], "idkptSetSize": [vp, i32, i32], "idkptSetRowSharding": [vp, i32, i32], "idkptSetSceneVersions": [vp, i32], "idkptSetRowBands": [vp, i32, i32, i32],
         "idkptSetRowRange": [vp, i32, i32], "idkptSetBounceExchange": [vp, vp, vp], "idkptSetBandExchange": [vp, vp, vp], "idkptSetBandExchangeDevice": [vp, vp, vp], "idkptSetSettings": [vp, vp], "idkptGetSettings": [vp, vp],
         "idkptSetPerFrame": [vp, vp, vp, vp], "idkptSetPerFrameData": [vp, vp], "idkptUploadScene": [vp, vp],
-        "idkptUpdateBuffer": [vp, i32, sz, sz, vp], "idkptSetLightCount": [vp, i32], "idkptBuildTlas": [vp, vp, i32], "idkptBuildTlasOnDevice": [vp, i32], "idkptBuildBlasCore": [vp, vp, i32, vp, vp, vp], "idkptBuildBlas": [vp, vp, i32, vp, i32, i32, C.c_float, vp], "idkptBuildBlasFetch": [vp, vp, vp, vp, vp], "idkptCbrtProbe": [vp, vp, vp, i32], "idkptTraceRays": [vp, vp, sz, u32, vp], "idkptTraceShadows": [vp, vp, vp, vp, vp], "idkptTraceRaysDevice": [vp, vp, sz, u32, vp], "idkptTraceShadowsDevice": [vp, vp, vp, vp, vp], "idkptSetFrameRing": [vp, i32], "idkptBeginFrame": [vp, C.POINTER(i32)],
+        "idkptUpdateBuffer": [vp, i32, sz, sz, vp], "idkptUpdateTexture": [vp, i32, vp], "idkptSetLightCount": [vp, i32], "idkptBuildTlas": [vp, vp, i32], "idkptBuildTlasOnDevice": [vp, i32], "idkptBuildBlasCore": [vp, vp, i32, vp, vp, vp], "idkptBuildBlas": [vp, vp, i32, vp, i32, i32, C.c_float, vp], "idkptBuildBlasFetch": [vp, vp, vp, vp, vp], "idkptCbrtProbe": [vp, vp, vp, i32], "idkptTraceRays": [vp, vp, sz, u32, vp], "idkptTraceShadows": [vp, vp, vp, vp, vp], "idkptTraceRaysDevice": [vp, vp, sz, u32, vp], "idkptTraceShadowsDevice": [vp, vp, vp, vp, vp], "idkptSetFrameRing": [vp, i32], "idkptBeginFrame": [vp, C.POINTER(i32)],
         "idkptDownloadFrame": [vp, i32, i32, vp, sz], "idkptGetFrameDevicePtr": [vp, i32, i32, C.POINTER(vp), C.POINTER(sz)],
         "idkptRefitBlas": [vp, i32], "idkptUploadUnskinnedVertices": [vp, vp, i32], "idkptSkin": [vp, u32, u32, u32, u32],
         "idkptDownloadBuffer": [vp, i32, sz, sz, vp], "idkptResetAccumulation": [vp], "idkptSetSampleSequence": [vp, u32, u32], "idkptGetAccumulatedSamples": [vp, C.POINTER(u32)],

@@ -101,7 +101,8 @@ struct dev_ctx {
     // scene
     bool haveScene = false, frameOk = false;
     DevBuf nodes, tris, triVerts, descs, instances, tlas, parents, leaves, positions, prevPositions, vertices, meshes, materials, xforms, lights, sky, texDescs, unskinned, joints, levelNodes, tlasScratch, queryIn, queryOut, queryRec, queryList, tileClass, gbases;   // (+ camTab below)
-    std::vector<DevBuf> texData; std::vector<std::pair<int, int>> texDims;
+    std::vector<DevBuf> texData; std::vector<std::pair<int, int>> texDims; std::vector<uint32_t> texState;   // per image: device copy, (width, height), TexDesc::state
+    DevBuf srgbLut;                                      // DScene::srgbLut (256 floats), made with the first scene
     std::vector<GpuBlasDesc> hDescs;
     std::vector<std::vector<uint32_t>> levelOffsets; // per BLAS: offsets into levelNodes (level l occupies [off[l], off[l+1]))
     std::vector<uint32_t> levelBase;                 // per BLAS base into levelNodes

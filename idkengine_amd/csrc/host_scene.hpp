@@ -123,7 +123,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* all[] = {&ctx->pmList, &ctx->instRec, &ctx->itlas, &ctx->imarks, &ctx->ichunks, &ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
+    DevBuf* all[] = {&ctx->srgbLut, &ctx->pmList, &ctx->instRec, &ctx->itlas, &ctx->imarks, &ctx->ichunks, &ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
                      &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->bandTab, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
@@ -282,6 +282,43 @@ static int upload(dev_ctx* ctx, DevBuf& b, const void* src, size_t bytes)
     return IDKPT_OK;
 }
 
+// ---- texture table (idkpt_texture: include/idkpt.h) -----------------------------------------------------------------------------------------------------------------
+static size_t tex_texel_bytes(int32_t format) { return format == IDKPT_TEXFMT_RGBA32F ? 16 : 4; }
+static int tex_validate(dev_ctx* ctx, const idkpt_texture& t, const char* who)
+{
+    if (!(t.width > 0 && t.height > 0 && t.rgba)) return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, std::string(who) + ": bad texture (size / data)");
+    if (!(t.wrapS >= 0 && t.wrapS <= 2 && t.wrapT >= 0 && t.wrapT <= 2 && t.magFilter >= 0 && t.magFilter <= 1 && t.format >= 0 && t.format <= 2))
+        return fail(ctx, IDKPT_ERR_INVALID_ARGUMENT, std::string(who) + ": bad texture (wrapS / wrapT are enum idkpt_wrap, magFilter enum idkpt_filter, format enum idkpt_texture_format)");
+    return IDKPT_OK;
+}
+static uint32_t tex_state(const idkpt_texture& t) { return (uint32_t)t.wrapS | ((uint32_t)t.wrapT << 2) | ((uint32_t)t.magFilter << 4) | ((uint32_t)t.format << 5); }
+// can a texel of this image be non-finite?  (k_shade_last's "no emission" shortcut: 0 x a texel is only 0 for a finite texel; 8-bit formats decode to [0, 1])
+static bool tex_all_finite(const idkpt_texture& t)
+{
+    if (t.format != IDKPT_TEXFMT_RGBA32F) return true;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(t.rgba); uint32_t bad = 0;
+    for (size_t k = 0, e = (size_t)t.width * t.height * 4; k < e; k++) bad |= (uint32_t)((w[k] & 0x7f800000u) == 0x7f800000u);
+    return !bad;
+}
+// the sRGB -> linear transfer function of GL 4.6 8.24 per byte value, evaluated in double and rounded once (the oracle makes the same table with the same expression)
+static int tex_srgb_lut(dev_ctx* ctx)
+{
+    if (ctx->srgbLut.p) return IDKPT_OK;
+    float lut[256];
+    for (int b = 0; b < 256; b++) { const double cs = (double)b / 255.0; lut[b] = (float)(cs <= 0.04045 ? cs / 12.92 : pow((cs + 0.055) / 1.055, 2.4)); }
+    HIPC(ctx->srgbLut.ensure(sizeof(lut)));
+    HIPC(hipMemcpy(ctx->srgbLut.p, lut, sizeof(lut), hipMemcpyHostToDevice));      // (lut is on the stack)
+    return IDKPT_OK;
+}
+static int tex_descs_upload(dev_ctx* ctx)
+{
+    std::vector<TexDesc> td;
+    for (size_t i = 0; i < ctx->texData.size(); i++) td.push_back({ctx->texData[i].p, ctx->texDims[i].first, ctx->texDims[i].second, ctx->texState[i], 0u});
+    { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
+    if (!td.empty()) HIPC(hipStreamSynchronize(ctx->stream));                       // (td is a stack vector)
+    return IDKPT_OK;
+}
+
 // The fast path stores nothing but a flag for pre-culled pixels of the most recent sample; this completes their ray state (origin,
 // direction, miss radiance) from the frame constants of that batch.  Must run while the scene the batch was rendered with is still
 // resident (the sky decides the miss radiance): called by idkptDownloadRays and before a new scene replaces the old one.
@@ -348,26 +385,23 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
         for (int i = 0; i < sc->TextureCount && none; i++) {      // (0 x a texel is only 0 for a finite texel)
             const idkpt_texture& t = sc->Textures[i];
             if (!(t.width > 0 && t.height > 0 && t.rgba)) { none = false; break; }
-            const uint32_t* w = reinterpret_cast<const uint32_t*>(t.rgba); uint32_t bad = 0;
-            for (size_t k = 0, e = (size_t)t.width * t.height * 4; k < e; k++) bad |= (uint32_t)((w[k] & 0x7f800000u) == 0x7f800000u);
-            none = !bad;
+            none = tex_all_finite(t);
         }
         ctx->sceneNoEmission = none;
     }
     ctx->skySize = (sc->SkyFaces && sc->SkyFaceSize > 0) ? sc->SkyFaceSize : 0;
     if ((rc = upload(ctx, ctx->sky, sc->SkyFaces, (size_t)6 * ctx->skySize * ctx->skySize * 16))) return rc;
     for (auto& t : ctx->texData) t.release();
-    ctx->texData.clear(); ctx->texDims.clear();
-    std::vector<TexDesc> td;
+    ctx->texData.clear(); ctx->texDims.clear(); ctx->texState.clear();
+    if ((rc = tex_srgb_lut(ctx))) return rc;
     for (int i = 0; i < sc->TextureCount; i++) {
         const idkpt_texture& t = sc->Textures[i];
-        REQUIRE(t.width > 0 && t.height > 0 && t.rgba, "idkptUploadScene: bad texture");
+        if ((rc = tex_validate(ctx, t, "idkptUploadScene"))) return rc;
         ctx->texData.emplace_back();
-        if ((rc = upload(ctx, ctx->texData.back(), t.rgba, (size_t)t.width * t.height * 16))) return rc;
-        td.push_back({ctx->texData.back().as<float4>(), t.width, t.height});
-        ctx->texDims.push_back({t.width, t.height});
+        if ((rc = upload(ctx, ctx->texData.back(), t.rgba, (size_t)t.width * t.height * tex_texel_bytes(t.format)))) return rc;
+        ctx->texDims.push_back({t.width, t.height}); ctx->texState.push_back(tex_state(t));
     }
-    if ((rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)))) return rc;
+    if ((rc = tex_descs_upload(ctx))) return rc;
     HIPC(ctx->triVerts.ensure((size_t)sc->BlasTriangleCount * 48));
     ctx->nodeCount = sc->BlasNodeCount; ctx->triCount = sc->BlasTriangleCount; ctx->instanceCount = sc->BlasInstanceCount; ctx->tlasCount = sc->TlasNodes ? sc->TlasNodeCount : 0;
     ctx->vertexCount = sc->VertexCount; ctx->meshCount = sc->MeshCount; ctx->materialCount = sc->MaterialCount; ctx->xformCount = sc->MeshTransformCount;
@@ -457,7 +491,7 @@ static int clone_prepare(dev_ctx* ctx, dev_ctx* src, std::vector<CloneItem>& ite
         items.push_back({d[i]->p, from, bytes});
     }
     for (auto& t : ctx->texData) t.release();
-    ctx->texData.clear(); ctx->texDims = src->texDims;
+    ctx->texData.clear(); ctx->texDims = src->texDims; ctx->texState = src->texState;
     for (size_t i = 0; i < src->texData.size(); i++) {
         ctx->texData.emplace_back();
         HIPC(ctx->texData.back().ensure(src->texData[i].bytes));
@@ -468,9 +502,8 @@ static int clone_prepare(dev_ctx* ctx, dev_ctx* src, std::vector<CloneItem>& ite
 static int clone_finish(dev_ctx* ctx, dev_ctx* src)
 {
     HIPC(hipSetDevice(ctx->device));
-    std::vector<TexDesc> td;
-    for (size_t i = 0; i < src->texData.size(); i++) td.push_back({ctx->texData[i].as<float4>(), src->texDims[i].first, src->texDims[i].second});
-    { int rc = upload(ctx, ctx->texDescs, td.data(), td.size() * sizeof(TexDesc)); if (rc) return rc; }
+    { int rc = tex_srgb_lut(ctx); if (rc) return rc; }
+    { int rc = tex_descs_upload(ctx); if (rc) return rc; }
     ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
     ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
     ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->hInst0Blas = src->hInst0Blas; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneNested = src->sceneNested; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed;
@@ -490,6 +523,23 @@ static int32_t dev_CloneSceneFrom(dev_ctx* ctx, dev_ctx* src)
     int rc = clone_prepare(ctx, src, items); if (rc) return rc;
     for (const CloneItem& it : items) HIPC(member_copy(ctx->peer, it.dst, ctx->device, it.src, src->device, it.bytes, ctx->stream));
     return clone_finish(ctx, src);
+}
+
+// idkptUpdateTexture: image `index` of the table gets new contents / size / format / sampler state.  The shading kernels of every queued sample read the table: they are launched first.
+static int32_t dev_UpdateTexture(dev_ctx* ctx, int32_t index, const idkpt_texture* t)
+{
+    if (!ctx || !t) return IDKPT_ERR_INVALID_ARGUMENT;
+    if (!ctx->haveScene) return fail(ctx, IDKPT_ERR_INVALID_OPERATION, "idkptUpdateTexture: no scene uploaded");
+    REQUIRE(index >= 0 && index < ctx->textureCount, "idkptUpdateTexture: index out of range");
+    { int rc = tex_validate(ctx, *t, "idkptUpdateTexture"); if (rc) return rc; }
+    HIPC(hipSetDevice(ctx->device));
+    FLUSH();
+    HIPC(hipStreamSynchronize(ctx->stream));                                        // (the old image may be released below: nothing in flight reads it any more)
+    { int rc = upload(ctx, ctx->texData[index], t->rgba, (size_t)t->width * t->height * tex_texel_bytes(t->format)); if (rc) return rc; }
+    HIPC(hipStreamSynchronize(ctx->stream));                                        // (the host's array is borrowed for the call only)
+    ctx->texDims[index] = {t->width, t->height}; ctx->texState[index] = tex_state(*t);
+    if (!tex_all_finite(*t)) ctx->sceneNoEmission = false;                          // (conservative: the shortcut stays off until the next idkptUploadScene)
+    return tex_descs_upload(ctx);
 }
 
 static int32_t dev_SetLightCount(dev_ctx* ctx, int32_t count)

@@ -14,7 +14,7 @@ static DScene make_dscene(dev_ctx* ctx, const uint8_t* slots, bool multi)
     s.instRec = nullptr;        // (set for the batches that walk the library's own TLAS, flush_batch)
     s.meshes = ctx->meshes.as<GpuMesh>(); s.materials = ctx->materials.as<GpuMaterial>(); s.xforms = (const float4*)at(VB_XFORMS);
     s.lights = ctx->lights.as<GpuLight>(); s.lightCount = ctx->lightCount; s.sky = ctx->sky.as<float4>(); s.skySize = ctx->skySize;
-    s.textures = ctx->texDescs.as<TexDesc>(); s.textureCount = ctx->textureCount;
+    s.textures = ctx->texDescs.as<TexDesc>(); s.textureCount = ctx->textureCount; s.srgbLut = ctx->srgbLut.as<float>();
     s.overflow = ctx->dOverflow;
     s.ver = multi ? ctx->verTab.as<uint32_t>() : nullptr;
     return s;

@@ -590,6 +590,7 @@ int32_t idkptUploadScene(idkpt_ctx* c, const idkpt_scene_desc* scene)
 int32_t idkptUpdateBuffer(idkpt_ctx* c, int32_t which, size_t offsetBytes, size_t bytes, const void* data) { REPLICATE_VERSIONED(UpdateBuffer, which, offsetBytes, bytes, data); }
 int32_t idkptSetSceneVersions(idkpt_ctx* c, int32_t versions) { REPLICATE(SetSceneVersions, versions); }
 int32_t idkptSetLightCount(idkpt_ctx* c, int32_t count) { REPLICATE(SetLightCount, count); }
+int32_t idkptUpdateTexture(idkpt_ctx* c, int32_t index, const idkpt_texture* texture) { REPLICATE(UpdateTexture, index, texture); }
 int32_t idkptSetDeveloperOption(idkpt_ctx* c, const char* name, int32_t value)
 {
     if (!c || !name) return IDKPT_ERR_INVALID_ARGUMENT;

@@ -12,7 +12,8 @@
 
 namespace ptd {
 
-struct TexDesc { const float4* data; int w, h; };
+// one image of the texture table: state = wrapS | wrapT << 2 | magFilter << 4 | format << 5 (enum idkpt_wrap / idkpt_filter / idkpt_texture_format, include/idkpt.h)
+struct TexDesc { const void* data; int w, h; uint32_t state; uint32_t pad; };
 
 struct DScene {
     const float4* nodes;        // 2 x float4 per GpuBlasNode: {Min.xyz, TriStartOrChild}, {Max.xyz, TriCount}
@@ -31,6 +32,7 @@ struct DScene {
     const GpuLight* lights; int lightCount;
     const float4* sky; int skySize;
     const TexDesc* textures; int textureCount;
+    const float* srgbLut;       // 256 floats: the sRGB -> linear transfer function of GL 4.6 8.24 per byte value (IDKPT_TEXFMT_SRGB8_A8 texels are decoded before filtering)
     uint32_t* overflow;         // host-mapped word: set when a traversal-stack push had to be dropped (idkpt.hip turns it into an error at the next sync)
     // scene versions (idkptSetSceneVersions): samples of one batch may see different states of the geometry (animated frames in flight).  Null: every sample
     // reads the pointers above.  Else the pointers above are the bases of the version arenas and row smp of this table holds, in 16-byte units, where the
@@ -388,19 +390,38 @@ DEV uint32_t first_hit_gid_seed(int W, int H, int px, int py)
 
 // ---------------------------------------------------------------------------------------------------------------
 // texture / sky stand-ins for the GL bindless samplers (DESIGN.md "Textures")
+// Texel selection of one axis (GL 4.6 8.14.2, table 8.20).  REPEAT keeps round 5's expression ((int)c % n on the floored coordinate and on floor + 1: the fixtures' bits).
+DEV int tex_wrap(int i, int n, uint32_t mode)
+{
+    if (mode == 1u) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);                                   // CLAMP_TO_EDGE: clamp(coord, 0, size - 1)
+    if (mode == 2u) { int m = i % (2 * n); if (m < 0) m += 2 * n; const int a = m - n; return (n - 1) - (a >= 0 ? a : -(1 + a)); }   // MIRRORED_REPEAT: (size - 1) - mirror((coord mod (2 size)) - size)
+    int k = i % n; if (k < 0) k += n; return k;                                                   // REPEAT: coord mod size
+}
+DEV float4 tex_fetch(const DScene& s, const TexDesc& t, int x, int y)
+{
+    const uint32_t fmt = t.state >> 5;
+    const size_t at = (size_t)y * (size_t)t.w + (size_t)x;
+    if (fmt == 0u) return ((const float4*)t.data)[at];
+    const uint32_t p = ((const uint32_t*)t.data)[at];                                              // bytes R, G, B, A
+    const float a = (float)(p >> 24) / 255.0f;
+    if (fmt == 1u) return make_float4((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f, a);
+    return make_float4(s.srgbLut[p & 255u], s.srgbLut[(p >> 8) & 255u], s.srgbLut[(p >> 16) & 255u], a);   // sRGB -> linear per texel, before the filter (GL 4.6 8.24): a 256-entry table made on the host
+}
 DEV float4 SampleTex(const DScene& s, uint64_t handle, float u, float v)
 {
     if (handle == 0 || handle > (uint64_t)s.textureCount) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    TexDesc t = s.textures[handle - 1];
-    if (t.w == 1 && t.h == 1) return t.data[0];
+    const TexDesc t = s.textures[handle - 1];
+    if (t.w == 1 && t.h == 1) return tex_fetch(s, t, 0, 0);
+    const uint32_t ws = t.state & 3u, wt = (t.state >> 2) & 3u;
+    if ((t.state >> 4) & 1u) {                                                                     // NEAREST: i = wrap(floor(u)) (8.14.2)
+        const int x = tex_wrap((int)gfloor(u * (float)t.w), t.w, ws), y = tex_wrap((int)gfloor(v * (float)t.h), t.h, wt);
+        return tex_fetch(s, t, x, y);
+    }
     float fx = u * (float)t.w - 0.5f, fy = v * (float)t.h - 0.5f;
     float x0f = gfloor(fx), y0f = gfloor(fy);
     float ax = fx - x0f, ay = fy - y0f;
-    int x0 = (int)x0f % t.w; if (x0 < 0) x0 += t.w;
-    int x1 = (int)(x0f + 1.0f) % t.w; if (x1 < 0) x1 += t.w;
-    int y0 = (int)y0f % t.h; if (y0 < 0) y0 += t.h;
-    int y1 = (int)(y0f + 1.0f) % t.h; if (y1 < 0) y1 += t.h;
-    float4 a = t.data[(size_t)y0 * t.w + x0], b = t.data[(size_t)y0 * t.w + x1], c = t.data[(size_t)y1 * t.w + x0], d = t.data[(size_t)y1 * t.w + x1];
+    const int x0 = tex_wrap((int)x0f, t.w, ws), x1 = tex_wrap((int)(x0f + 1.0f), t.w, ws), y0 = tex_wrap((int)y0f, t.h, wt), y1 = tex_wrap((int)(y0f + 1.0f), t.h, wt);
+    const float4 a = tex_fetch(s, t, x0, y0), b = tex_fetch(s, t, x1, y0), c = tex_fetch(s, t, x0, y1), d = tex_fetch(s, t, x1, y1);
     return make_float4(gmix(gmix(a.x, b.x, ax), gmix(c.x, d.x, ax), ay), gmix(gmix(a.y, b.y, ax), gmix(c.y, d.y, ax), ay),
                        gmix(gmix(a.z, b.z, ax), gmix(c.z, d.z, ax), ay), gmix(gmix(a.w, b.w, ax), gmix(c.w, d.w, ax), ay));
 }

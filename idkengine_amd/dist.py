@@ -115,7 +115,8 @@ def broadcast_scene(scene, src=0, device=None, group=None):
             meta.append((a.shape, a.nbytes))
         sky = None if scene.sky_faces is None else np.ascontiguousarray(scene.sky_faces, np.float32)
         meta.append((None if sky is None else sky.shape, 0 if sky is None else sky.nbytes))
-        meta.append((len(scene.textures), [np.asarray(t).shape for t in scene.textures], scene.blas_stack_size))
+        imgs = [T.TextureImage.of(t) for t in scene.textures]
+        meta.append((len(imgs), [(t.data.shape, t.data.dtype.str, t.wrap_s, t.wrap_t, t.mag_filter, t.format) for t in imgs], scene.blas_stack_size))
     box = [meta]
     dist.broadcast_object_list(box, src=src, group=group)
     meta = box[0]
@@ -143,9 +144,10 @@ def broadcast_scene(scene, src=0, device=None, group=None):
     ntex, tex_shapes, stack = meta[len(_SCENE_FIELDS) + 1]
     texs = []
     for k in range(ntex):
-        nb = int(np.prod(tex_shapes[k])) * 4
-        raw = bcast_bytes(np.ascontiguousarray(scene.textures[k], np.float32) if rank == src else None, nb)
-        texs.append(np.frombuffer(raw.tobytes(), np.float32).reshape(tex_shapes[k]).copy())
+        shape, dt, ws, wt, mf, fmt = tex_shapes[k]
+        nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+        raw = bcast_bytes(T.TextureImage.of(scene.textures[k]).data if rank == src else None, nb)
+        texs.append(T.TextureImage(np.frombuffer(raw.tobytes(), np.dtype(dt)).reshape(shape).copy(), ws, wt, mf, srgb=(fmt == T.IDKPT_TEXFMT_SRGB8_A8)))      # texels AND sampler state travel
     if rank != src:
         out.textures = texs
         out.blas_stack_size = stack

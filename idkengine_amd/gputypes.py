@@ -67,7 +67,40 @@ class Settings(C.Structure):
 
 
 class Texture(C.Structure):
-    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", C.c_void_p)]
+    """idkpt_texture (include/idkpt.h), 32 bytes."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", C.c_void_p), ("wrapS", C.c_int32), ("wrapT", C.c_int32), ("magFilter", C.c_int32), ("format", C.c_int32)]
+
+
+# enum idkpt_wrap / idkpt_filter / idkpt_texture_format
+IDKPT_WRAP_REPEAT, IDKPT_WRAP_CLAMP_TO_EDGE, IDKPT_WRAP_MIRRORED_REPEAT = range(3)
+IDKPT_FILTER_LINEAR, IDKPT_FILTER_NEAREST = range(2)
+IDKPT_TEXFMT_RGBA32F, IDKPT_TEXFMT_RGBA8, IDKPT_TEXFMT_SRGB8_A8 = range(3)
+GL_WRAP = {0x2901: IDKPT_WRAP_REPEAT, 0x812F: IDKPT_WRAP_CLAMP_TO_EDGE, 0x8370: IDKPT_WRAP_MIRRORED_REPEAT}      # GLSampler.WrapMode (glTF sampler.wrapS / wrapT) -> enum idkpt_wrap
+GL_MAG_FILTER = {0x2601: IDKPT_FILTER_LINEAR, 0x2600: IDKPT_FILTER_NEAREST}                                       # GLSampler.MagFilter -> enum idkpt_filter
+
+
+class TextureImage:
+    """One image of the texture table with its sampler state: what a GpuMaterial handle stands for in the reference (a bindless texture + the GLSampler.SamplerState of
+    Utils/ModelLoader.cs:1166-1197).  data: (h, w, 4) float32 (RGBA32F) or uint8 (RGBA8 / SRGB8_A8).  A bare float32 array in Scene.textures means REPEAT / REPEAT / LINEAR."""
+
+    def __init__(self, data, wrap_s=IDKPT_WRAP_REPEAT, wrap_t=IDKPT_WRAP_REPEAT, mag_filter=IDKPT_FILTER_LINEAR, srgb=False):
+        data = np.asarray(data)
+        if data.dtype == np.uint8:
+            self.data = np.ascontiguousarray(data); self.format = IDKPT_TEXFMT_SRGB8_A8 if srgb else IDKPT_TEXFMT_RGBA8
+        else:
+            assert not srgb, "sRGB storage is 8-bit"
+            self.data = np.ascontiguousarray(data, np.float32); self.format = IDKPT_TEXFMT_RGBA32F
+        assert self.data.ndim == 3 and self.data.shape[2] == 4
+        self.wrap_s, self.wrap_t, self.mag_filter = int(wrap_s), int(wrap_t), int(mag_filter)
+
+    @staticmethod
+    def of(t):
+        return t if isinstance(t, TextureImage) else TextureImage(t)
+
+    def fill(self, rec):
+        """Writes this image into a Texture record; the record borrows self.data."""
+        rec.height, rec.width, rec.rgba = self.data.shape[0], self.data.shape[1], self.data.ctypes.data
+        rec.wrapS, rec.wrapT, rec.magFilter, rec.format = self.wrap_s, self.wrap_t, self.mag_filter, self.format
 
 
 class SceneDesc(C.Structure):
@@ -123,7 +156,7 @@ class Scene:
         self.mesh_transforms = np.zeros(0, GpuMeshTransform)
         self.lights = np.zeros(0, GpuLight)
         self.sky_faces = None  # (6, S, S, 4) float32
-        self.textures = []     # list of (h, w, 4) float32 arrays
+        self.textures = []     # list of (h, w, 4) float32 arrays (REPEAT, LINEAR) or TextureImage objects (sampler state, 8-bit formats)
         self.blas_stack_size = 0
 
     def desc(self):
@@ -157,8 +190,8 @@ class Scene:
         if self.textures:
             arr = (Texture * len(self.textures))()
             for i, t in enumerate(self.textures):
-                t = c(t, np.float32)
-                arr[i].height, arr[i].width, arr[i].rgba = t.shape[0], t.shape[1], t.ctypes.data
+                t = TextureImage.of(t); keep.append(t)
+                t.fill(arr[i])
             keep.append(arr)
             d.Textures, d.TextureCount = C.addressof(arr), len(self.textures)
         return d, keep

@@ -356,6 +356,11 @@ class PathTracer:
         self._check(self._L.idkptDownloadPrimaryHits(self._ctx, t.ctypes.data, tri.ctypes.data, bary.ctypes.data, n))
         return t, tri, bary
 
+    def UpdateTexture(self, index, image):
+        """idkptUpdateTexture: image `index` of the texture table (a float32 array or a gputypes.TextureImage)."""
+        t = T.TextureImage.of(image); rec = T.Texture(); t.fill(rec)
+        self._check(self._L.idkptUpdateTexture(self._ctx, int(index), C.byref(rec)))
+
     def enable_counters(self, on=True):
         self._check(self._L.idkptEnableCounters(self._ctx, 1 if on else 0))
 

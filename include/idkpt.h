@@ -54,12 +54,22 @@ enum idkpt_buffer {
     IDKPT_BUF_WIDE_COUNTS = 11,    /* per BLAS: uint32 wide nodes in use, uint32 16-byte units of leaf records in use */
 };
 
-/* One RGBA32F image of the texture table (stand-in for GL bindless textures; sampled at LOD 0 with
- * bilinear filtering + repeat wrap as defined in DESIGN.md; 1x1 textures are exact). */
+/* One image of the texture table + the sampler state it is sampled with (stand-in for the GL bindless samplers of GpuMaterial: a texture object and the GLSampler.SamplerState
+ * ModelLoader.GetGLSamplerState derives from the glTF sampler, Utils/ModelLoader.cs:1166-1197).  The path tracer samples in compute shaders (`texture(gpuMaterial.X, uv)`,
+ * Shaders/include/Surface.glsl:49-77): no derivatives, level of detail 0, so of the sampler state exactly the two wrap modes and the MAGNIFICATION filter take part (GL 4.6
+ * 8.14: lambda = 0 selects the mag filter); texel selection and wrapping are the specification's (8.14.2, table 8.20), the linear filter is mix(mix(t00, t10, a), mix(t01, t11, a), b).
+ * 8-bit formats are decoded per texel BEFORE filtering (UNORM: c / 255; sRGB: the specification's transfer function on R, G, B, alpha linear — GL 4.6 8.24), as GL does.
+ * The zero value of every state field is the round-5 behaviour (REPEAT, REPEAT, LINEAR, RGBA32F): a zero-initialised struct with width / height / rgba set samples as before. */
+enum idkpt_wrap { IDKPT_WRAP_REPEAT = 0 /* GL_REPEAT 0x2901 */, IDKPT_WRAP_CLAMP_TO_EDGE = 1 /* GL_CLAMP_TO_EDGE 0x812F */, IDKPT_WRAP_MIRRORED_REPEAT = 2 /* GL_MIRRORED_REPEAT 0x8370 */ };
+enum idkpt_filter { IDKPT_FILTER_LINEAR = 0 /* GL_LINEAR 0x2601 */, IDKPT_FILTER_NEAREST = 1 /* GL_NEAREST 0x2600 */ };
+enum idkpt_texture_format { IDKPT_TEXFMT_RGBA32F = 0 /* 16 B / texel */, IDKPT_TEXFMT_RGBA8 = 1 /* GL_RGBA8: 4 B / texel, UNORM */, IDKPT_TEXFMT_SRGB8_A8 = 2 /* GL_SRGB8_ALPHA8: 4 B / texel */ };
 typedef struct idkpt_texture {
     int32_t width, height;
-    const float* rgba; /* width*height*4 floats, row-major, row 0 = v 0 */
-} idkpt_texture;
+    const void* rgba;  /* width*height texels, row-major, row 0 = v 0: 4 floats each (RGBA32F) or 4 bytes each (RGBA8, SRGB8_A8) */
+    int32_t wrapS, wrapT;   /* enum idkpt_wrap: GLSampler.SamplerState.WrapModeS / WrapModeT */
+    int32_t magFilter;      /* enum idkpt_filter: GLSampler.SamplerState.MagFilter */
+    int32_t format;         /* enum idkpt_texture_format */
+} idkpt_texture;            /* 32 B (ABI 3; round 5: 16 B) */
 
 /* ---- adjacent consumers of the traversal core ---- */
 /* One ray of a batched query = one call of TraceRay(ray, hitInfo, traceLights, maxDist)
@@ -271,6 +281,9 @@ IDKPT_API int32_t idkptUploadScene(idkpt_ctx* ctx, const idkpt_scene_desc* scene
  * patch also costs a device-to-host copy of the node array and two synchronisations).  Updates of up to 256 KB (joint matrices, transforms) do not wait
  * for the GPU. */
 IDKPT_API int32_t idkptUpdateBuffer(idkpt_ctx* ctx, int32_t which, size_t offsetBytes, size_t bytes, const void* data);
+/* Replaces image `index` of the texture table (contents, size, format and sampler state): a streamed-in higher mip as base level, a changed sampler.  Stream-ordered behind the
+ * samples already queued (they are launched first); the accumulation is the host's to reset, as after any scene update. */
+IDKPT_API int32_t idkptUpdateTexture(idkpt_ctx* ctx, int32_t index, const idkpt_texture* texture);
 IDKPT_API int32_t idkptSetLightCount(idkpt_ctx* ctx, int32_t count);
 /* BVH.TlasBuild upload (Bvh/BVH.cs:278-298): host-built TLAS nodes replace SSBO 27 */
 IDKPT_API int32_t idkptBuildTlas(idkpt_ctx* ctx, const GpuTlasNode* nodes, int32_t nodeCount);

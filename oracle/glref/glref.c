@@ -202,6 +202,21 @@ unsigned glref_texture2d(int w, int h, const float *rgba, int linear, int repeat
     p_glTextureParameteri(t, GL_TEXTURE_WRAP_T, repeat ? GL_REPEAT : GL_CLAMP_TO_EDGE);
     return t;
 }
+/* One image of the scene's texture table with the sampler state of its glTF sampler (ModelLoader.GetGLSamplerState, Utils/ModelLoader.cs:1166-1197): format 0 = GL_RGBA32F
+ * (float texels), 1 = GL_RGBA8, 2 = GL_SRGB8_ALPHA8 (byte texels); wrapS / wrapT 0 = GL_REPEAT, 1 = GL_CLAMP_TO_EDGE, 2 = GL_MIRRORED_REPEAT; nearest != 0 -> GL_NEAREST.
+ * One level (the compute shaders sample level 0: no derivatives), so the minification filter is the magnification filter and the texture is complete. */
+unsigned glref_texture2d_state(int w, int h, const void *texels, int format, int wrapS, int wrapT, int nearest)
+{
+    static const GLenum wraps[3] = {GL_REPEAT, GL_CLAMP_TO_EDGE, GL_MIRRORED_REPEAT};
+    GLuint t = 0; p_glCreateTextures(GL_TEXTURE_2D, 1, &t);
+    p_glTextureStorage2D(t, 1, format == 0 ? GL_RGBA32F : (format == 1 ? GL_RGBA8 : GL_SRGB8_ALPHA8), w, h);
+    if (texels) p_glTextureSubImage2D(t, 0, 0, 0, w, h, GL_RGBA, format == 0 ? GL_FLOAT : GL_UNSIGNED_BYTE, texels);
+    p_glTextureParameteri(t, GL_TEXTURE_MIN_FILTER, nearest ? GL_NEAREST : GL_LINEAR);
+    p_glTextureParameteri(t, GL_TEXTURE_MAG_FILTER, nearest ? GL_NEAREST : GL_LINEAR);
+    p_glTextureParameteri(t, GL_TEXTURE_WRAP_S, wraps[wrapS]);
+    p_glTextureParameteri(t, GL_TEXTURE_WRAP_T, wraps[wrapT]);
+    return t;
+}
 /* RGBA32F cube map, faces in GL order (+X,-X,+Y,-Y,+Z,-Z), s x s texels each */
 unsigned glref_cubemap(int s, const float *rgba6, int linear)
 {

@@ -87,6 +87,7 @@ def gl():
     L.glref_bind_ssbo.argtypes = [C.c_uint, C.c_uint]; L.glref_bind_ubo.argtypes = [C.c_uint, C.c_uint]
     L.glref_texture2d.restype = C.c_uint; L.glref_texture2d.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.glref_cubemap.restype = C.c_uint; L.glref_cubemap.argtypes = [C.c_int, C.c_void_p, C.c_int]
+    L.glref_texture2d_state.restype = C.c_uint; L.glref_texture2d_state.argtypes = [C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4
     L.glref_texture_write.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_void_p]
     L.glref_texture_read.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_void_p]
     L.glref_bind_texture.argtypes = [C.c_uint, C.c_uint]; L.glref_bind_image.argtypes = [C.c_uint, C.c_uint]
@@ -331,9 +332,11 @@ class _ReferenceHost:
         # reference would ever sample (its sky is an HDR or a computed atmosphere); a caller that compares such a case (oracle/glref/fuzz_reference.py) asks for GL_NEAREST
         # (`sky_nearest`), so that the comparison covers everything else of the case.
         t = L.glref_cubemap(sky.shape[1], sky.ctypes.data, 0 if getattr(self, "sky_nearest", False) else 1); self._texs.append(t); L.glref_bind_texture(0, t)
+        # every image with ITS sampler state (GLSampler.SamplerState of the glTF sampler, ModelLoader.cs:1166-1197: wrap S / T, magnification filter) and storage format
+        from idkengine_amd import gputypes as T
         white = np.ones((1, 1, 4), np.float32)
-        for i, tex in enumerate([white] + [np.ascontiguousarray(x, np.float32) for x in scene.textures]):
-            t = L.glref_texture2d(tex.shape[1], tex.shape[0], tex.ctypes.data, 1, 1); self._texs.append(t); L.glref_bind_texture(1 + i, t)
+        for i, tex in enumerate([T.TextureImage(white)] + [T.TextureImage.of(x) for x in scene.textures]):
+            t = L.glref_texture2d_state(tex.data.shape[1], tex.data.shape[0], tex.data.ctypes.data, tex.format, tex.wrap_s, tex.wrap_t, tex.mag_filter); self._texs.append(t); L.glref_bind_texture(1 + i, t)
 
     def _check_gl(self, what):
         err = self.L.glref_error()

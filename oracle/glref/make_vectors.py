@@ -6,6 +6,7 @@ swrast); the fixtures travel to the GPU box, this script's inputs do not.
     python oracle/glref/make_vectors.py --check [case ...]    regenerate in memory, compare with the committed fixtures bit for bit
     python oracle/glref/make_vectors.py --queries [--check]   ray-query (TraceRay / TraceRayAny) and ShadowsRayTraced vectors
     python oracle/glref/make_vectors.py --extended            three larger live comparisons (no fixtures), JSON on stdout
+    python oracle/glref/make_vectors.py --eight-bit           what llvmpipe does to RGBA8 / sRGB8 textures beside the specification's decode + float filter, JSON on stdout
     python oracle/glref/make_vectors.py --defect-d1           demonstrate reference defect D1 (glref.py ADAPTATIONS A7), JSON on stdout
 
 Per case the fixture holds
@@ -62,6 +63,30 @@ def defect_d1():
         pt.render()
         rep["with_A7" if fix else "reference_order"] = seen
         pt.close()
+    print(json.dumps(rep))
+
+
+def eight_bit_report():
+    """What llvmpipe makes of 8-bit textures, measured on the sampler wall of glref_cases._sampler_scene through the reference's FirstHit (AOV albedo = the texture tap):
+    RGBA8 under GL_NEAREST is the specification's c / 255; RGBA8 under GL_LINEAR is filtered in 8-bit fixed point (gallivm's AoS path); sRGB8 is decoded by a polynomial.
+    The oracle (and the HIP path) decode per texel as GL 4.6 2.3.5.1 / 8.24 write it and filter in float: the fixture pins the first, the other two are bounded here."""
+    from oracle.glref import glref as G
+    from oracle import oracle as O
+    from idkengine_amd import gputypes as T
+    import configs
+    import glref_cases
+    fac, camf, w, h, ov = glref_cases.GLREF_CASES["sampler_states_rgba8_d3"]
+    B = O.OracleBuilder(); rep = {}
+    for label, mf, srgb in (("rgba8_nearest", 1, False), ("rgba8_linear", 0, False), ("srgb8_nearest", 1, True), ("srgb8_linear", 0, True)):
+        sc = fac(B); cam = camf(w, h)
+        sc.textures = [T.TextureImage(t.data, t.wrap_s, t.wrap_t, mf, srgb=srgb) for t in sc.textures]
+        st = configs.apply_settings(T.Settings.default(), ov)
+        pt = G.ReferencePathTracer(sc, w, h, st); pt.set_camera(cam); pt.render()
+        ref = pt.image(1)[..., :3].reshape(-1, 3).astype(np.float64); pt.close()
+        o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.render()
+        alb = o.image(1)[..., :3].reshape(-1, 3).astype(np.float64); o.close()
+        d = np.abs(ref - alb); big = alb > 1e-2
+        rep[label] = {"pixels": int(len(alb)), "textured_pixels": int((alb.sum(1) > 0).sum()), "max_abs": float(d.max()), "max_rel": float((d[big] / alb[big]).max()), "pixels_beyond_1e-4": int(((d > 1e-4 * np.maximum(alb, 1e-3)).any(1)).sum())}
     print(json.dumps(rep))
 
 
@@ -321,6 +346,8 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     if "--defect-d1" in args:
         defect_d1()
+    elif "--eight-bit" in args:
+        eight_bit_report()
     elif "--extended" in args:
         extended()
     elif "--summary" in args:

@@ -41,6 +41,8 @@ def lib():
         L.ref_scene_destroy.argtypes = [C.c_void_p]
         L.ref_scene_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ref_scene_set_blas_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ref_scene_set_texture.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_sample_texture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_pt_create.restype = C.c_void_p; L.ref_pt_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ref_pt_destroy.argtypes = [C.c_void_p]
         L.ref_pt_set_settings.argtypes = [C.c_void_p, C.c_void_p]
@@ -125,6 +127,15 @@ class OracleBuilder:
         nodes = np.ascontiguousarray(nodes).copy(); positions = np.ascontiguousarray(positions, np.float32); tris = np.ascontiguousarray(tris)
         lib().ref_blas_refit(nodes.ctypes.data, len(nodes), positions.ctypes.data, tris.ctypes.data)
         return nodes
+
+
+def sample_texture(image, uv):
+    """One tap per (u, v) of the oracle's texture unit on `image` (an array or a gputypes.TextureImage): test hook."""
+    from idkengine_amd import gputypes as T
+    t = T.TextureImage.of(image); rec = T.Texture(); t.fill(rec)
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2); out = np.zeros((len(uv), 4), np.float32)
+    lib().ref_sample_texture(C.byref(rec), uv.ctypes.data, len(uv), out.ctypes.data)
+    return out
 
 
 def trace_rays(scene, rays, any_hit=False, trace_lights=False, use_tlas=False):
@@ -228,6 +239,12 @@ class OraclePathTracer:
     def set_positions(self, positions):
         p = np.ascontiguousarray(positions, np.float32)
         lib().ref_scene_set_positions(self._scene, p.ctypes.data, len(p))
+
+    def set_texture(self, index, image):
+        """checker for idkptUpdateTexture"""
+        from idkengine_amd import gputypes as T
+        t = T.TextureImage.of(image); rec = T.Texture(); t.fill(rec)
+        lib().ref_scene_set_texture(self._scene, int(index), C.byref(rec))
 
     def set_blas_nodes(self, nodes):
         n = np.ascontiguousarray(nodes)

@@ -26,7 +26,7 @@ struct Scene {
     std::vector<float> positions; std::vector<GpuVertex> vertices; std::vector<GpuMesh> meshes;
     std::vector<GpuMaterial> materials; std::vector<GpuMeshTransform> xforms; std::vector<GpuLight> lights;
     std::vector<float> sky; int skySize = 0;
-    struct Tex { int w, h; std::vector<float> rgba; };
+    struct Tex { int w, h; std::vector<float> rgba; int wrapS = 0, wrapT = 0, magFilter = 0, format = 0; };   // rgba: DECODED texels (8-bit formats are decoded per texel before the filter, GL 4.6 8.24: the decode of the load below)
     std::vector<Tex> textures;
 };
 
@@ -270,17 +270,43 @@ static RGBA SampleTexLlvmpipe(const Scene::Tex& t, v2 uv)
     }
     RGBA o = {c[0], c[1], c[2], c[3]}; return o;
 }
+// One image of the texture table as the sampler sees it: texels decoded to float (idkpt_texture, include/idkpt.h).  UNORM: c / (2^8 - 1) (GL 4.6 2.3.5.1); sRGB: the transfer
+// function of 8.24 on R, G, B — evaluated in double, rounded once — alpha linear.
+static Scene::Tex load_texture(const idkpt_texture& src)
+{
+    Scene::Tex t; t.w = src.width; t.h = src.height; t.wrapS = src.wrapS; t.wrapT = src.wrapT; t.magFilter = src.magFilter; t.format = src.format;
+    const size_t n = 4 * (size_t)t.w * t.h;
+    if (src.format == IDKPT_TEXFMT_RGBA32F) { const float* f = (const float*)src.rgba; t.rgba.assign(f, f + n); return t; }
+    const uint8_t* b = (const uint8_t*)src.rgba; t.rgba.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        if (src.format == IDKPT_TEXFMT_SRGB8_A8 && (k & 3) != 3) { const double cs = (double)b[k] / 255.0; t.rgba[k] = (float)(cs <= 0.04045 ? cs / 12.92 : pow((cs + 0.055) / 1.055, 2.4)); }
+        else t.rgba[k] = (float)b[k] / 255.0f;
+    }
+    return t;
+}
+// wrap(coord) of GL 4.6 table 8.20 on an integer texel coordinate (8.14.2): what the texture's WrapModeS / WrapModeT (Utils/ModelLoader.cs:1166-1197) select
+static int WrapTexel(int i, int n, int mode)
+{
+    if (mode == IDKPT_WRAP_CLAMP_TO_EDGE) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);                    // clamp(coord, 0, size - 1)
+    if (mode == IDKPT_WRAP_MIRRORED_REPEAT) { int m = i % (2 * n); if (m < 0) m += 2 * n; const int a = m - n; return (n - 1) - (a >= 0 ? a : -(1 + a)); }   // (size - 1) - mirror((coord mod (2 size)) - size), mirror(a) = a >= 0 ? a : -(1 + a)
+    int k = i % n; if (k < 0) k += n; return k;                                                          // coord mod size
+}
 static RGBA SampleTex(const Scene& s, uint64_t handle, v2 uv)
 {
     if (handle == 0 || handle > s.textures.size()) { RGBA w = {1, 1, 1, 1}; return w; }
     const Scene::Tex& t = s.textures[handle - 1];
     if (t.w == 1 && t.h == 1) { RGBA c = {t.rgba[0], t.rgba[1], t.rgba[2], t.rgba[3]}; return c; }
-    if (g_sampler_mode == 1) return SampleTexLlvmpipe(t, uv);
+    if (g_sampler_mode == 1 && t.wrapS == 0 && t.wrapT == 0 && t.magFilter == 0) return SampleTexLlvmpipe(t, uv);
+    if (t.magFilter == IDKPT_FILTER_NEAREST) {                                                          // 8.14.2: i = wrap(floor(u')), no filter
+        const int x = WrapTexel((int)gfloor(uv.x * (float)t.w), t.w, t.wrapS), y = WrapTexel((int)gfloor(uv.y * (float)t.h), t.h, t.wrapT);
+        const float* p = &t.rgba[4 * ((size_t)y * t.w + x)];
+        RGBA c = {p[0], p[1], p[2], p[3]}; return c;
+    }
     float fx = uv.x * (float)t.w - 0.5f, fy = uv.y * (float)t.h - 0.5f;
     float x0f = gfloor(fx), y0f = gfloor(fy);
     float ax = fx - x0f, ay = fy - y0f;
-    auto wrap = [](float v, int n) { int i = (int)v % n; if (i < 0) i += n; return i; };
-    int x0 = wrap(x0f, t.w), x1 = wrap(x0f + 1.0f, t.w), y0 = wrap(y0f, t.h), y1 = wrap(y0f + 1.0f, t.h);
+    auto wrapS = [&](float v) { return WrapTexel((int)v, t.w, t.wrapS); }; auto wrapT = [&](float v) { return WrapTexel((int)v, t.h, t.wrapT); };
+    int x0 = wrapS(x0f), x1 = wrapS(x0f + 1.0f), y0 = wrapT(y0f), y1 = wrapT(y0f + 1.0f);
     float c[4];
     for (int k = 0; k < 4; k++) {
         float a = t.rgba[4 * ((size_t)y0 * t.w + x0) + k], b = t.rgba[4 * ((size_t)y0 * t.w + x1) + k];
@@ -837,9 +863,16 @@ void* ref_scene_create(const idkpt_scene_desc* d)
     s->xforms.assign(d->MeshTransforms, d->MeshTransforms + d->MeshTransformCount);
     if (d->Lights) s->lights.assign(d->Lights, d->Lights + d->LightCount);
     if (d->SkyFaces && d->SkyFaceSize > 0) { s->skySize = d->SkyFaceSize; s->sky.assign(d->SkyFaces, d->SkyFaces + 6 * 4 * (size_t)d->SkyFaceSize * d->SkyFaceSize); }
-    for (int i = 0; i < d->TextureCount; i++) { Scene::Tex t; t.w = d->Textures[i].width; t.h = d->Textures[i].height; t.rgba.assign(d->Textures[i].rgba, d->Textures[i].rgba + 4 * (size_t)t.w * t.h); s->textures.push_back(t); }
+    for (int i = 0; i < d->TextureCount; i++) s->textures.push_back(load_texture(d->Textures[i]));
     return s;
 }
+// test hook: one tap of the texture unit, outside any scene (tests/test_oracle_kats.py: wrap modes / filters / decodes against an independent statement of GL 4.6 8.14.2)
+void ref_sample_texture(const idkpt_texture* t, const float* uv, int count, float* outRgba)
+{
+    Scene s; s.textures.push_back(load_texture(*t));
+    for (int i = 0; i < count; i++) { v2 q = {uv[2 * i], uv[2 * i + 1]}; const RGBA c = SampleTex(s, 1, q); outRgba[4 * i] = c.r; outRgba[4 * i + 1] = c.g; outRgba[4 * i + 2] = c.b; outRgba[4 * i + 3] = c.a; }
+}
+void ref_scene_set_texture(void* s, int index, const idkpt_texture* t) { ((Scene*)s)->textures[(size_t)index] = load_texture(*t); }    // checker for idkptUpdateTexture
 void ref_scene_destroy(void* s) { delete (Scene*)s; }
 void ref_scene_set_positions(void* s, const float* positions, int vertexCount) { ((Scene*)s)->positions.assign(positions, positions + 3 * (size_t)vertexCount); }
 void ref_scene_set_blas_nodes(void* s, const GpuBlasNode* nodes, int count) { ((Scene*)s)->nodes.assign(nodes, nodes + count); }

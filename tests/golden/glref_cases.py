@@ -70,6 +70,39 @@ def _bias_normalmap_scene(b):
     return sc
 
 
+def _sampler_scene(b, eight_bit=False):
+    """Per-texture sampler state (ModelLoader.GetGLSamplerState, Utils/ModelLoader.cs:1166-1197; taps Surface.glsl:49-77): a wall of 3 x 6 quads, one per (wrapS, wrapT,
+    magFilter) of {REPEAT, CLAMP_TO_EDGE, MIRRORED_REPEAT}^2 x {LINEAR, NEAREST}, each with its own non-square image as base colour and emission, uv running from -1.3 to 2.4
+    across the quad (negative and > 1 on both axes: every branch of table 8.20's wrap functions), above a glossy floor that carries the bounces.  eight_bit: the same wall with
+    RGBA8 images, all of them under GL_NEAREST — the one 8-bit configuration llvmpipe evaluates at full precision (it filters RGBA8 in 8-bit fixed point, up to 1.1 / 255 off the
+    float filter, and decodes sRGB with a polynomial 2.5 % off the specification's function: tests/test_glref.py bounds both live, tests/test_oracle_kats.py pins the decode)."""
+    from idkengine_amd import gputypes as T
+    rng = np.random.default_rng(33)
+    meshes, textures = [], []
+    combos = [(ws, wt, mf) for mf in (0, 1) for ws in (0, 1, 2) for wt in (0, 1, 2)]
+    for k, (ws, wt, mf) in enumerate(combos):
+        cx, cy = (k % 6) - 2.5, (k // 6) - 1.0
+        quad = S._quad((cx * 0.62 - 0.29, cy * 0.62 - 0.29, -0.6), (cx * 0.62 + 0.29, cy * 0.62 - 0.29, -0.6), (cx * 0.62 + 0.29, cy * 0.62 + 0.29, -0.6), (cx * 0.62 - 0.29, cy * 0.62 + 0.29, -0.6))
+        p, i, n, t = S.flat_shaded(quad)
+        uv = np.where(np.abs(p[:, :2] - np.float32([cx * 0.62, cy * 0.62])) > 0, (np.sign(p[:, :2] - np.float32([cx * 0.62, cy * 0.62])) * 0.5 + 0.5), 0.0)      # corner -> (0 / 1, 0 / 1)
+        uv = (np.float32([-1.3, -0.7]) + uv.astype(np.float32) * np.float32([3.7, 3.1])).astype(np.float32)
+        mat = S.make_material((1.0, 1.0, 1.0, 1.0), emissive=(0.6, 0.6, 0.6), roughness=0.9)
+        mat["BaseColorTexture"] = len(textures) + 1; mat["EmissiveTexture"] = len(textures) + 1
+        meshes.append(S.MeshInput(p, i, mat, n, t, uvs=uv))
+        w_, h_ = (5, 3) if k % 2 else (4, 7)
+        if eight_bit:
+            img = rng.integers(0, 256, (h_, w_, 4), dtype=np.uint8)
+            textures.append(T.TextureImage(img, ws, wt, T.IDKPT_FILTER_NEAREST))
+        else:
+            textures.append(T.TextureImage(rng.uniform(0.05, 1.0, (h_, w_, 4)).astype(np.float32), ws, wt, mf))
+    floor = S._quad((-2.2, -1.0, -0.6), (-2.2, -1.0, 2.0), (2.2, -1.0, 2.0), (2.2, -1.0, -0.6))
+    p, i, n, t = S.flat_shaded(floor)
+    meshes.append(S.MeshInput(p, i, S.make_material((0.7, 0.7, 0.7, 1.0), metallic=0.6, roughness=0.3), n, t))
+    sc = S.assemble([{"meshes": meshes}], b, sky_color=(0.1, 0.12, 0.15))
+    sc.textures = textures
+    return sc
+
+
 def _sky_scene(b):
     """Every face a different 5x5 image: the seamless GL_LINEAR cube-map filter across face edges and corners."""
     rng = np.random.default_rng(9)
@@ -85,6 +118,8 @@ GLREF_CASES.update({
     "cornell_lights_sort_d4": (_lights_scene, S.cornell_camera, 64, 64, dict(RayDepth=4, DoTraceLights=1, DoRaySorting=1)),
     "cornell_alpha_d6": (_alpha_scene, S.cornell_camera, 64, 64, dict(RayDepth=6)),
     "cornell_textured_aov_d5": (_textured_scene, S.cornell_camera, 64, 64, dict(RayDepth=5, OutputAOVs=1)),
+    "sampler_states_d3": (_sampler_scene, lambda w, h: S.Camera(w, h, position=(0.0, 0.1, 3.0), fovy_deg=48.0), 96, 56, dict(RayDepth=3, OutputAOVs=1)),
+    "sampler_states_rgba8_d3": (lambda b: _sampler_scene(b, True), lambda w, h: S.Camera(w, h, position=(0.0, 0.1, 3.0), fovy_deg=48.0), 96, 56, dict(RayDepth=3, OutputAOVs=1)),
     "cornell_bias_normalmap_d6": (_bias_normalmap_scene, S.cornell_camera, 64, 64, dict(RayDepth=6)),
     "cornell_odd_size_d3": (lambda b: S.cornell_scene(b, "mixed"), S.cornell_camera, 53, 37, dict(RayDepth=3)),
     "soup_sky_linear_aov_d3": (_sky_scene, lambda w, h: S.Camera(w, h, position=(0.0, 0.0, 0.0), view_dir=(1.0, 0.8, 0.9), fovy_deg=110.0), 96, 72, dict(RayDepth=3, OutputAOVs=1)),

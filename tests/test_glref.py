@@ -153,6 +153,21 @@ def test_live_reference_defect_d1_reorder_item_count():
 
 
 @live
+def test_live_llvmpipe_8bit_textures_pinned_where_it_is_exact_bounded_where_it_is_not():
+    """idkpt_texture's 8-bit formats (include/idkpt.h) decode per texel as GL 4.6 2.3.5.1 / 8.24 write it and filter in float.  llvmpipe agrees to an ulp where it evaluates at
+    full precision — RGBA8 under GL_NEAREST, the configuration the fixture sampler_states_rgba8_d3 pins — filters RGBA8 under GL_LINEAR in 8-bit fixed point (about one 8-bit step off
+    the float filter) and decodes sRGB8 with a polynomial (2.5 % off the transfer function): both are bounded here, and the decode itself is pinned by tests/test_oracle_kats.py."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glref", "make_vectors.py"), "--eight-bit"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert all(v["textured_pixels"] > 2000 for v in rep.values()), rep
+    assert rep["rgba8_nearest"]["pixels_beyond_1e-4"] == 0 and rep["rgba8_nearest"]["max_abs"] < 2e-7, rep
+    assert 1e-3 < rep["rgba8_linear"]["max_abs"] < 1.2 / 255.0, rep                                   # 8-bit fixed-point filter weights and results
+    assert 5e-4 < rep["srgb8_nearest"]["max_abs"] < 2e-3 and rep["srgb8_nearest"]["max_rel"] < 3e-2, rep   # polynomial sRGB decode
+    assert rep["srgb8_linear"]["max_abs"] < 2e-3 and rep["srgb8_linear"]["max_rel"] < 3e-2, rep           # ... filtered in float after it
+
+
+@live
 def test_live_preprocessor_follows_the_reference():
     """AppInclude is include-once, AppInsert falls back to 0, unreferenced storage blocks are dropped (BBG/Source/Objects/Shader.cs:177-335)."""
     code = ("import sys; sys.path.insert(0, %r)\n"
