@@ -301,6 +301,11 @@ def main():
             out["eager_last_bounce"] = {"mray_s": round(rays_rep / statistics.median(eager) / 1e6, 2), "ms_per_step": round(statistics.median(eager) / args.steps * 1e3, 4), "repeats": 3,
                                         "what": "the timed region re-run with idkptSetDeveloperOption(defer_last, 0): bit-identical frames and ray state, the last bounce's continuation computed every frame"}
             out["single_frame"] = safe(single_frame, pt, depth)
+            # the strict readings of the same workload beside `value` (config.headline_notes says what separates them): one frame at a time (SURVEY 8(d)'s protocol), the last bounce
+            # shaded eagerly, and the rays that actually enter the BVH
+            out["value_eager"] = out["eager_last_bounce"]["mray_s"]
+            out["value_one_frame"] = out["single_frame"].get("mray_s") if isinstance(out["single_frame"], dict) else None
+            out["value_traversed"] = out["traversed_mray_s"]
             if args.scene == "soup":
                 # secondary blocks: each one on its own — a failure inside one is reported in its place and costs neither the metric line nor the other blocks
                 out["interior"] = safe(interior_extras, S, pt, W, H, B)
@@ -311,6 +316,10 @@ def main():
                 out["animated"] = safe(animated_extras, S, NativeBuilder, pt)
                 safe(pt.UploadScene, scene)
                 out["wide_nodes"] = safe(wide_extras, S, NativeBuilder, pt, scene, cam, W, H, B)
+                safe(pt.UploadScene, scene)
+                out["packet"] = safe(packet_extras, S, NativeBuilder, pt, scene, cam, W, H, B)
+                safe(pt.UploadScene, scene)
+                out["sort_on_vs_off"] = safe(sort_extras, S, NativeBuilder, pt, scene, cam, W, H, B)
                 safe(pt.UploadScene, scene)
                 out["queries"] = safe(query_extras, S, pt, scene, cam)
             pt.UseTlas = 0; pt.SetCamera(cam); pt.RayDepth = depth; pt.set_max_batch(B)
@@ -482,7 +491,7 @@ def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, t
         pmc = pmc_passes(args, launches // max(1, args.repeats))
     traffic = None
     out = {"bound": "l2", "kernel": "k_trace2 (persistent while-while BVH traversal)", "achieved": round(achieved, 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
-           "frac": round(achieved / L2_PEAK_GBS, 4), "traffic": None,
+           "frac": round(achieved / L2_PEAK_GBS, 4), "frac_hbm_algorithmic": round(achieved / HBM_PEAK_GBS, 4), "frac_hbm_counters": None, "traffic": None,
            "peak_source": "MI355X_MICROARCH.md: aggregate L2 bandwidth ~34.5 TB/s (8 XCDs x 4 MiB); the working set of this kernel is L2 + Infinity-Cache resident, so HBM (8 TB/s) is not the roof - both HBM fractions are under `hbm`",
            "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": int(launches), "samples_per_launch": samples_per_launch,
            "alg_bytes_definition": "64 B x node-pair visits + 48 B x triangle tests + 72 B x rays entering the kernel (DESIGN.md 5), exact counts of the counting build",
@@ -495,6 +504,7 @@ def roofline(st, pairs, tri_tests, traversed, args, world, samples_per_launch, t
         traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # KiB -> bytes; FETCH_SIZE calibrated at 1.03 on this 64-B gather pattern (profiles/r01_bench_pmc_summary.json), no doubling
         out["traffic"] = int(traffic)
         out["hbm"]["counter_gbs"] = round(traffic / avg_launch_s / 1e9, 1); out["hbm"]["counter_frac"] = round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4)
+        out["frac_hbm_counters"] = out["hbm"]["counter_frac"]
         h, m, rq, ac = pmc.get("TCC_HIT_sum"), pmc.get("TCC_MISS_sum"), pmc.get("TCP_TCC_READ_REQ_sum"), pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum")
         out["pmc"] = {"source": "this run: its timed region re-executed under rocprofv3 --kernel-trace --pmc (3 passes), mean over the timed k_trace2 launches",
                       "fetch_bytes_per_launch": int(pmc["FETCH_SIZE"] * 1024.0), "write_bytes_per_launch": int(pmc["WRITE_SIZE"] * 1024.0),
@@ -604,6 +614,53 @@ def wide_extras(S, NativeBuilder, pt, scene, cam, w, h, B):
                            "rays_retraced_exactly": round(st["wide_flagged_rays"] / 4.0, 1), "rays": int(st["rays_traced"] / 4)}
         row["speedup_batched"] = round(row["wide"]["mray_s"] / row["default"]["mray_s"], 3)
         out[name] = row
+    return out
+
+
+def packet_extras(S, NativeBuilder, pt, scene, cam, w, h, B):
+    """Secondary block: the primary launch as a packet launch (developer option "packet", csrc/kernels_packet.hpp: one shared BVH2 walk per wave of 64 pixel-major work-list
+    entries, node pairs through the scalar cache; rays it does not vouch for re-traced by k_trace2; bit-identical frames, tests/test_gpu_packet.py).  Default = 1: by the
+    kernel's own counters (live lanes per node step) — on where every pixel traverses, off on the headline view whose pixels are wider than its triangles
+    (profiles/r06_packet.md).  RayDepth 1 rows time the primary launch alone."""
+    out = {"what": "option packet 0 (k_trace2 alone) / 2 (always) / 1 (default: by measurement): Mray/s with the bench's samples in flight; live = lanes live per node step / 64; rays re-traced by the exact kernel"}
+    atrium = S.atrium_scene(N_TRIS, NativeBuilder())
+    for name, sc, cm in (("headline", scene, cam), ("interior", scene, view_camera(S, "interior", w, h)), ("atrium", atrium, S.atrium_camera(w, h))):
+        pt.UploadScene(sc); pt.SetCamera(cm)
+        row = {}
+        for depth in (1, RAY_DEPTH):
+            pt.RayDepth = depth
+            for mode, key in ((0, "off"), (2, "forced"), (1, "default")):
+                pt.set_option("packet", mode)
+                rays, dt = timed_batch(pt, B, 2 * B, reps=3)
+                st = pt.stats()
+                e = {"mray_s": round(rays / dt / 1e6, 1)}
+                if st["packet_packets"]:
+                    e.update(live=round(st["packet_live_lanes"] / (64.0 * max(1, st["packet_node_steps"])), 3), node_steps_per_packet=round(st["packet_node_steps"] / st["packet_packets"], 1),
+                             triangle_rounds_per_packet=round(st["packet_triangle_rounds"] / st["packet_packets"], 1), retraced_fraction=round(st["packet_flagged_rays"] / max(1, st["packet_rays_entered"]), 5))
+                row.setdefault("primary_only" if depth == 1 else f"depth{depth}", {})[key] = e
+        for k in row:
+            row[k]["forced_vs_off"] = round(row[k]["forced"]["mray_s"] / row[k]["off"]["mray_s"], 3); row[k]["default_vs_off"] = round(row[k]["default"]["mray_s"] / row[k]["off"]["mray_s"], 3)
+        out[name] = row
+    pt.set_option("packet", 1)
+    return out
+
+
+def sort_extras(S, NativeBuilder, pt, scene, cam, w, h, B):
+    """BASELINE.json configs[2]'s second half: DoRaySorting on vs off (PathTracer.cs:273-297: a counting sort of every bounce's queue by the previous hit's triangle id, from the
+    second bounce on) — the headline view at RayDepth 2 (nothing is sorted there: the first sort precedes bounce 2) and 5, the interior view and the 262 k-triangle atrium at RayDepth 5,
+    the regime the reference built it for (Gui.cs:745-749)."""
+    out = {"what": "Mray/s with DoRaySorting 0 / 1, same protocol as the headline (samples in flight, defer_last); sort_pays = on / off"}
+    atrium = S.atrium_scene(262_000, NativeBuilder())
+    for name, sc, cm, depth in (("headline_depth2", scene, cam, 2), ("headline_depth5", scene, cam, 5), ("interior_depth5", scene, view_camera(S, "interior", w, h), 5), ("atrium_262k_depth5", atrium, S.atrium_camera(w, h), 5)):
+        pt.UploadScene(sc); pt.SetCamera(cm); pt.RayDepth = depth
+        row = {}
+        for srt in (0, 1):
+            pt.DoRaySorting = srt
+            rays, dt = timed_batch(pt, B, 2 * B, reps=3)
+            row["sort_on" if srt else "sort_off"] = {"mray_s": round(rays / dt / 1e6, 1), "ms_per_step": round(dt / (2 * B) * 1e3, 4)}
+        row["sort_pays"] = round(row["sort_on"]["mray_s"] / row["sort_off"]["mray_s"], 3)
+        out[name] = row
+    pt.DoRaySorting = 0
     return out
 
 

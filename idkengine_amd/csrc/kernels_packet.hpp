@@ -109,9 +109,10 @@ __global__ __launch_bounds__(WAVE) void k_trace_packet(DScene s, Frame f, RayBuf
         uint32_t top = 2u;
         int stkNode = 0, stkLo = 0, stkHi = 0, sp = 0;          // lane k of the three registers = stack entry k
         bool ovf = false;
+        const char* const nodeBytes = (const char*)nodes;
         while (mask != 0ull) {
             if (STATS) { nSteps++; nLive += (uint32_t)__builtin_popcountll(mask); }
-            const pk_u16v P = *(pk_c16*)(uintptr_t)(nodes + 2 * (size_t)top);          // {lmin.xyz, lStart}, {lmax.xyz, lCount}, {rmin.xyz, rStart}, {rmax.xyz, rCount}
+            const pk_u16v P = *(pk_c16*)(uintptr_t)(nodeBytes + ((size_t)top << 5));          // {lmin.xyz, lStart}, {lmax.xyz, lCount}, {rmin.xyz, rStart}, {rmax.xyz, rCount}
             const uint32_t lStart = P[3], lCount = P[7], rStart = P[11], rCount = P[15];
             float t1L, t2L, t1R, t2R;
             pk_box(ro, invDir, __uint_as_float(P[0]), __uint_as_float(P[1]), __uint_as_float(P[2]), __uint_as_float(P[4]), __uint_as_float(P[5]), __uint_as_float(P[6]), &t1L, &t2L);
@@ -120,14 +121,13 @@ __global__ __launch_bounds__(WAVE) void k_trace_packet(DScene s, Frame f, RayBuf
             u64 hL = mask & inL & PK_BALLOT(t1L <= cullT), hR = mask & inR & PK_BALLOT(t1R <= cullT);
             const u64 nm = mask & ((PK_BALLOT(t1L <= t2L * wide::NEAR_MISS) & ~inL) | (PK_BALLOT(t1R <= t2R * wide::NEAR_MISS) & ~inR));
             if (nm != 0ull) flags = PK_LANES(nm) ? (flags | 8u) : flags;
-            // leaf children first, left then right (BVHIntersect.glsl:54-79), by the lanes whose box test passed
-            const bool leafL = lCount != 0u && hL != 0ull, leafR = rCount != 0u && hR != 0ull;
-            if (leafL || leafR) {
+            if ((lCount | rCount) != 0u) {                      // (one test for the common case: both children internal)
+                // leaf children first, left then right (BVHIntersect.glsl:54-79), by the lanes whose box test passed
 #pragma unroll
                 for (int side = 0; side < 2; side++) {
-                    if (!(side ? leafR : leafL)) continue;
                     const uint32_t cnt = side ? rCount : lCount, first = (side ? rStart : lStart) + triOffset;
                     const u64 h = side ? hR : hL;
+                    if (cnt == 0u || h == 0ull) continue;
                     const float t1 = side ? t1R : t1L;
                     for (uint32_t k = 0; k < cnt; k++) {
                         if (STATS) nRounds++;
@@ -151,21 +151,21 @@ __global__ __launch_bounds__(WAVE) void k_trace_packet(DScene s, Frame f, RayBuf
                         cullT = hitT * wide::CULL;
                     }
                 }
-                // the lanes' T may have shrunk: the descent only where the child is still wanted
-                hL &= PK_BALLOT(t1L <= cullT); hR &= PK_BALLOT(t1R <= cullT);
+                // the descent: internal children only, and only where the lanes' (possibly shrunken) T still wants them
+                hL = lCount == 0u ? (hL & PK_BALLOT(t1L <= cullT)) : 0ull; hR = rCount == 0u ? (hR & PK_BALLOT(t1R <= cullT)) : 0ull;
             }
-            const u64 dL = lCount == 0u ? hL : 0ull, dR = rCount == 0u ? hR : 0ull;
-            if (dL != 0ull && dR != 0ull) {
+            if (hL != 0ull && hR != 0ull) {
                 const u64 nearL = PK_BALLOT(t1L < t1R);
-                const bool lc = __builtin_popcountll(dL & (~dR | nearL)) >= __builtin_popcountll(dR & (~dL | ~nearL));      // the side more lanes find nearer goes first
-                const u64 farMask = lc ? dR : dL;
+                const int vL = (int)__builtin_popcountll(hL & (~hR | nearL)), vR = (int)__builtin_popcountll(hR & ~(hL & nearL));
+                const bool lc = vL >= vR;                       // the side more lanes find nearer goes first
+                const u64 farMask = lc ? hR : hL;
                 if (sp >= 64) { ovf = true; break; }
                 const bool at = lane == (uint32_t)sp;           // (this compiler has no v_writelane builtin: one compare + three selects)
                 stkNode = at ? (int)(lc ? rStart : lStart) : stkNode; stkLo = at ? (int)(uint32_t)farMask : stkLo; stkHi = at ? (int)(uint32_t)(farMask >> 32) : stkHi;
                 sp++;
-                top = lc ? lStart : rStart; mask = lc ? dL : dR;
-            } else if ((dL | dR) != 0ull) {
-                top = dL != 0ull ? lStart : rStart; mask = dL | dR;
+                top = lc ? lStart : rStart; mask = lc ? hL : hR;
+            } else if ((hL | hR) != 0ull) {
+                top = hL != 0ull ? lStart : rStart; mask = hL | hR;
             } else {
                 if (sp == 0) break;
                 sp--;

@@ -20,17 +20,38 @@ def run_case(seed, builder, G, O, T, configs, glref_check, draw_case):
     sc, cam, w, h, ov, st, _opts, _frames, _batch, nb = draw_case(seed, builder)
     depth = int(st.RayDepth)
 
-    def oracle_state(d):
+    textured = bool(len(sc.textures))
+
+    def oracle_state(d, uv_stage=-1, uv_override=None, uv_dump=None):
         o = O.OraclePathTracer(sc, w, h); o.set_camera(cam); configs.apply_settings(o.settings, ov); o.settings.RayDepth = d; o.settings.SamplesPerPixel = 1
+        if uv_stage >= 0:
+            o.set_uv_hooks(uv_stage, uv_override, uv_dump)
         o.render(); r, q, k = o.rays().copy(), o.alive_queue().copy(), o.alive_keys().copy(); o.close()
         return r, q, k
     st1 = configs.apply_settings(T.Settings.default(), ov); st1.RayDepth = 1; st1.SamplesPerPixel = 1
     sky = sc.sky_faces
     distinct_1x1 = sky is not None and sky.shape[1] == 1 and not (np.asarray(sky) == np.asarray(sky)[0]).all()      # the C-ABI's "constant colour per face": unfiltered by definition
-    pt = G.ReferencePathTracer(sc, w, h, st1, sky_nearest=distinct_1x1); pt.set_camera(cam); pt.render()
+    pt = G.ReferencePathTracer(sc, w, h, st1, sky_nearest=distinct_1x1, dump_uv=textured); pt.set_camera(cam); pt.render()
     ref_rays, ref_q = pt.rays(T.GpuWavefrontRay), np.asarray(pt.final_alive, np.uint32); pt.accumulated = 0
     cur = oracle_state(1)
-    rep = {"seed": seed, "size": [w, h], "triangles": int(len(sc.blas_triangles)), "settings": ov, "textured": bool(len(sc.textures)), "stages": 0, "rays": 0, "flips": 0, "beyond_tol": 0, "key_diffs": 0, "max_rel": 0.0, "beyond_by_field": {}}
+    rep = {"seed": seed, "size": [w, h], "triangles": int(len(sc.blas_triangles)), "settings": ov, "textured": bool(len(sc.textures)), "stages": 0, "rays": 0, "flips": 0, "beyond_tol": 0, "key_diffs": 0, "max_rel": 0.0, "beyond_by_field": {},
+           # textured cases, stage by stage from identical inputs INCLUDING the texture coordinate of every tap (A9: the reference's own interpolated uv fed to the checker's stage)
+           "pinned": {"stages": 0, "rays": 0, "taps": 0, "flips": 0, "beyond_tol": 0, "max_rel": 0.0, "uv_max_diff": 0.0}}
+
+    def add_pinned(stage, ids, ref, rq, depth_now):
+        """The same stage with the checker reading the reference's texture coordinates: what is left is shading arithmetic on identical taps.  Also: how far the two
+        interpolated coordinates were apart (relative to max(1, |uv|)) — the input difference that the noise textures' contrast multiplies in the unpinned comparison."""
+        uv_ref = pt.take_uv_dump()
+        own = np.full_like(uv_ref, np.nan)
+        cand_r, cand_q, _k = oracle_state(depth_now, stage, uv_ref, own)
+        both = ~np.isnan(uv_ref[:, 0]) & ~np.isnan(own[:, 0])
+        P = rep["pinned"]
+        if both.any():
+            P["uv_max_diff"] = max(P["uv_max_diff"], float((np.abs(uv_ref[both].astype(np.float64) - own[both]) / np.maximum(1.0, np.abs(uv_ref[both]).max(axis=1, keepdims=True))).max()))
+        flips = np.setxor1d(cand_q, rq)
+        keep = ~np.isin(ids, flips)
+        beyond, _eq, worst = glref_check._compare_records(cand_r[ids][keep], ref[keep])
+        P["stages"] += 1; P["rays"] += int(len(ids)); P["taps"] += int(both.sum()); P["flips"] += int(len(flips)); P["beyond_tol"] += int(beyond.sum()); P["max_rel"] = max(P["max_rel"], worst)
 
     def add(ids, cand, ref, cand_q, rq):
         flips = np.setxor1d(cand_q, rq)
@@ -45,6 +66,8 @@ def run_case(seed, builder, G, O, T, configs, glref_check, draw_case):
                 if e.size and e.max() > glref_check.REL_TOL:
                     rep["beyond_by_field"][f] = max(rep["beyond_by_field"].get(f, 0.0), float(e.max()))
     add(np.arange(w * h), cur[0], ref_rays, cur[1], ref_q)
+    if textured:
+        add_pinned(0, np.arange(w * h), ref_rays, ref_q, 1)
     for j in range(1, depth):
         rin, qin = cur[0], cur[1]
         if len(qin) == 0:
@@ -56,6 +79,8 @@ def run_case(seed, builder, G, O, T, configs, glref_check, draw_case):
             ko = np.zeros(w * h, np.int64) - 1; ko[nxt[1].astype(np.int64)] = nxt[2]
             both = np.intersect1d(qout, nxt[1]); rep["key_diffs"] += int((kr[both] != ko[both]).sum())
         add(qin, nxt[0][qin], rout[qin], nxt[1], np.asarray(qout, np.uint32))
+        if textured:
+            add_pinned(j, qin, rout[qin], np.asarray(qout, np.uint32), j + 1)
         cur = nxt
     pt.close()
     return rep
@@ -87,6 +112,7 @@ def main():
            "cases_with_a_flip_or_a_value_beyond_tolerance": [r["seed"] for r in reps if r["flips"] or r["beyond_tol"]], "seconds": round(time.time() - t0, 1),
            "textured_cases": sum(1 for r in reps if r["textured"]), "beyond_tol_in_textured_cases": sum(r["beyond_tol"] for r in reps if r["textured"]), "beyond_tol_in_untextured_cases": sum(r["beyond_tol"] for r in reps if not r["textured"]),
            "worst_throughput_or_radiance_error_beyond_tolerance": max([max(r["beyond_by_field"].get("Throughput", 0.0), r["beyond_by_field"].get("Radiance", 0.0)) for r in reps] + [0.0]),
+           "textured_stages_from_identical_taps": {k: (max if k in ("max_rel", "uv_max_diff") else sum)(r["pinned"][k] for r in reps) for k in ("stages", "rays", "taps", "flips", "beyond_tol", "max_rel", "uv_max_diff")},
            "gate": {"rel_tol": glref_check.REL_TOL, "abs_floor": glref_check.ABS_FLOOR}, "checker_sampler": os.environ.get("FUZZ_SAMPLER") or "gl-spec"}
     print(json.dumps(tot))
     if out:

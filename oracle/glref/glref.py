@@ -43,6 +43,9 @@ ADAPTATIONS = """
      result does not depend on the subgroup size).
  A8  (ShadowsRayTraced only) `texelFetch(gBufferDataUBO.Depth/Normal, ..)` read bound sampler2D units and
      `image2D(pointShadow.RayTracedShadowMapImage)` is a bound rgba32f image (llvmpipe has no bindless images either).
+ A9  (opt-in, ReferencePathTracer(dump_uv=True): the textured-stage check of oracle/glref/fuzz_reference.py) FirstHit and NHit additionally WRITE the texture
+     coordinate they interpolated (`interpTexCoord`, FirstHit/compute.glsl:129, NHit/compute.glsl:115) to an extra SSBO indexed by the ray index: one store behind the
+     statement that computes it, one global that carries the ray index into TraceRay; no statement of the reference is changed or removed.
  A7  (host order, only with DoRaySorting; sort_count_fix=True) PingPongIndex is uploaded BEFORE RaySorting() instead of
      after it.  Reference defect D1: PathTracer.cs:232-244 runs Reorder while the buffer still holds the previous
      bounce's PingPongIndex, so Reorder's GetItemCount() (Reorder/compute.glsl:44-47) returns the PREVIOUS bounce's
@@ -248,6 +251,23 @@ def adapt_for_llvmpipe(src, n_textures, max_ssbo_bindings, have_image_formatted=
     return src, remap
 
 
+UV_DUMP_BINDING = 37      # A9: the extra SSBO (renumbered by A3 like every other binding beyond the limit)
+
+
+def inject_uv_dump(src):
+    """A9: see ADAPTATIONS.  Applied to the preprocessed FirstHit / NHit source BEFORE A1-A3."""
+    decl = ("layout(std430, binding = %d) restrict writeonly buffer GlrefUvDumpSSBO { vec2 Uv[]; } glrefUvDumpSSBO;\nuint glrefRayIndex = 0u;\n" % UV_DUMP_BINDING)
+    at = src.index("void main()")
+    src = src[:at] + decl + src[at:]
+    n0 = src.count("glrefRayIndex")
+    src = src.replace("    bool continueRay = TraceRay(wavefrontRay, aovRay);", "    glrefRayIndex = uint(imgCoord.y * imageSize(ImgResult).x + imgCoord.x);\n    bool continueRay = TraceRay(wavefrontRay, aovRay);")   # FirstHit main (:76-78)
+    src = src.replace("    bool continueRay = TraceRay(wavefrontRay, aovRay, sortingKey);", "    glrefRayIndex = rayIndex;\n    bool continueRay = TraceRay(wavefrontRay, aovRay, sortingKey);")                                        # NHit main (:56-62)
+    assert src.count("glrefRayIndex") == n0 + 1, "A9: the call of TraceRay in main() was not found"
+    m = re.search(r"^(\s*)vec2 interpTexCoord = Interpolate\([^;]*;\n", src, re.M)
+    assert m and len(re.findall(r"vec2 interpTexCoord = ", src)) == 1, "A9: the interpolation of the texture coordinate was not found"
+    return src[:m.end()] + m.group(1) + "glrefUvDumpSSBO.Uv[glrefRayIndex] = interpTexCoord;\n" + src[m.end():]
+
+
 def compile_compute(src, what):
     L = gl()
     log = C.create_string_buffer(1 << 16)
@@ -287,8 +307,10 @@ class _ReferenceHost:
         self.remap = {}
         self.sources = {}
 
-    def _program(self, path, source=None, post=None):
+    def _program(self, path, source=None, post=None, pre=None):
         src = preprocess(path, self.insertions, source=source)
+        if pre:
+            src = pre(src)
         src, remap = adapt_for_llvmpipe(src, self._ntex, self._max_b, self._img_fmt, self._subgroup)
         if post:
             src = post(src)
@@ -357,8 +379,9 @@ class ReferencePathTracer(_ReferenceHost):
     """Source/Render/PathTracer.cs driven over llvmpipe.  `scene` is idkengine_amd.gputypes.Scene (whose arrays are
     byte-exact mirrors of the reference's GPU structs, include/idkpt_types.h), `settings` is gputypes.Settings."""
 
-    def __init__(self, scene, width, height, settings, canonical_order=True, sort_count_fix=True, sky_nearest=False):
+    def __init__(self, scene, width, height, settings, canonical_order=True, sort_count_fix=True, sky_nearest=False, dump_uv=False):
         self.sky_nearest = sky_nearest
+        self.dump_uv = dump_uv
         self._init_host(scene, settings.UseTlas, settings.BlasStackSize,
                         {"PATH_TRACER_DO_RAY_SORTING": "1" if settings.DoRaySorting else "0",                 # PathTracer.cs:111
                          "PATH_TRACER_OUTPUT_AOVS": "1" if settings.OutputAOVs else "0"})                      # PathTracer.cs:123
@@ -369,8 +392,8 @@ class ReferencePathTracer(_ReferenceHost):
         self.st = settings
         self.accumulated = 0
         self.alive_counts = []
-        self.first_hit = self._program("PathTracing/FirstHit/compute.glsl")
-        self.n_hit = self._program("PathTracing/NHit/compute.glsl")
+        self.first_hit = self._program("PathTracing/FirstHit/compute.glsl", pre=inject_uv_dump if dump_uv else None)
+        self.n_hit = self._program("PathTracing/NHit/compute.glsl", pre=inject_uv_dump if dump_uv else None)
         self.final_draw = self._program("PathTracing/FinalDraw/compute.glsl")
         if settings.DoRaySorting:
             self.reorder = self._program("PathTracing/CountingSort/Reorder/compute.glsl")
@@ -384,6 +407,8 @@ class ReferencePathTracer(_ReferenceHost):
         self.b_sorted = self._ssbo(33, np.zeros(n, np.uint32)); self.b_keys = self._ssbo(34, np.zeros(n, np.uint32))
         self.b_wg_prefix = self._ssbo(35, np.zeros(PREFIX_SUM_CAPACITY, np.uint32))
         self.b_wg_sums = self._ssbo(36, np.zeros(PREFIX_SUM_CAPACITY >> GROUP_WISE_PROGRAM_STEPS, np.uint32))
+        if dump_uv:
+            self.b_uv = self._ssbo(UV_DUMP_BINDING, np.full(2 * n, np.nan, np.float32))     # A9: NaN = "this ray interpolated no texture coordinate in the stage"
         self.b_settings = self._ubo(0, 32)                                            # UBO 0 settings (std140: float float bool bool bool)
         # Result / Albedo / Normal images (PathTracer.cs:301-318)
         zero = np.zeros((height, width, 4), np.float32)
@@ -424,6 +449,15 @@ class ReferencePathTracer(_ReferenceHost):
         out = np.zeros(self.W * self.H, dtype)
         self.L.glref_buffer_read(self.b_rays, 0, out.nbytes, out.ctypes.data)
         return out
+
+    def take_uv_dump(self):
+        """A9: the texture coordinates the last stage(s) interpolated, per ray index ((n, 2) float32, NaN where none was); the buffer is reset to NaN."""
+        n = self.W * self.H
+        out = np.zeros(2 * n, np.float32)
+        self.L.glref_buffer_read(self.b_uv, 0, out.nbytes, out.ctypes.data)
+        nan = np.full(2 * n, np.nan, np.float32)
+        self.L.glref_buffer_write(self.b_uv, 0, nan.nbytes, nan.ctypes.data)
+        return out.reshape(n, 2)
 
     def aov(self, dtype):
         out = np.zeros(self.W * self.H, dtype)

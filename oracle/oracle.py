@@ -49,6 +49,7 @@ def lib():
         L.ref_pt_set_perframe.argtypes = [C.c_void_p] * 4
         L.ref_pt_reset_accumulation.argtypes = [C.c_void_p]
         L.ref_pt_set_sample_sequence.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.ref_pt_set_uv_hooks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_pt_enable_counters.argtypes = [C.c_void_p, C.c_int]
         L.ref_pt_render.argtypes = [C.c_void_p]
         L.ref_pt_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -249,6 +250,12 @@ class OraclePathTracer:
     def set_blas_nodes(self, nodes):
         n = np.ascontiguousarray(nodes)
         lib().ref_scene_set_blas_nodes(self._scene, n.ctypes.data, len(n))
+
+    def set_uv_hooks(self, stage, override=None, dump=None):
+        """Test hooks of the textured-stage check (oracle/glref/fuzz_reference.py): in stage `stage` (0 = FirstHit, j = NHit j) the texture coordinate every ray interpolates is
+        written to dump[ray] and / or replaced by override[ray] where that is not NaN ((W * H, 2) float32 arrays the caller keeps alive); stage -1 switches both off."""
+        self._uv_keep = (override, dump)
+        lib().ref_pt_set_uv_hooks(self._pt, int(stage), None if override is None else override.ctypes.data, None if dump is None else dump.ctypes.data)
 
     def set_sample_sequence(self, first, stride):
         """idkptSetSampleSequence: sample i draws the reference's RNG streams of AccumulatedSamples = first + i * stride."""

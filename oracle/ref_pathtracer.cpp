@@ -501,6 +501,9 @@ struct PT {
     idkpt_band_exchange_fn bandExchangeFn = nullptr; void* bandExchangeUser = nullptr;   // ... for interleaved rows / bands (idkptSetBandExchange)
     Counters counters; bool countersOn = false;
     uint64_t raysTraced = 0;
+    // test hooks (oracle/glref/fuzz_reference.py, the textured-stage check): in stage uvStage (0 = FirstHit, j = NHit j) the texture coordinate a ray interpolates is written to
+    // uvDump[2 * rayIndex ..] and / or replaced by uvOverride[2 * rayIndex ..] where that is not NaN — the taps of the stage then read exactly the coordinates another execution read
+    int uvStage = -1; const float* uvOverride = nullptr; float* uvDump = nullptr;
     double parallelSec = 0.0, totalSec = 0.0;   // cpu_baseline leg of bench.py: time inside the per-invocation (OpenMP) sections / whole RenderSample
 };
 
@@ -521,7 +524,7 @@ static void FirstHitGid(int W, int H, int px, int py, uint32_t* gx, uint32_t* gy
 }
 
 // FirstHit TraceRay (FirstHit/compute.glsl:100-234) and NHit TraceRay (NHit/compute.glsl:91-215) share this body.
-static bool ShadeRay(PT& pt, bool first, GpuWavefrontRay& wr, GpuAovRay& ar, Rng* rng, uint32_t gidSeed, uint32_t* sortingKey, Counters* cnt, float* outT, uint32_t* outTri, v2* outBary)
+static bool ShadeRay(PT& pt, bool first, GpuWavefrontRay& wr, GpuAovRay& ar, Rng* rng, uint32_t gidSeed, uint32_t* sortingKey, Counters* cnt, float* outT, uint32_t* outTri, v2* outBary, int stage = -2, size_t rayIndex = 0)
 {
     const Scene& s = *pt.scene;
     const GpuSettings& g = pt.st.Gpu;
@@ -549,6 +552,10 @@ static bool ShadeRay(PT& pt, bool first, GpuWavefrontRay& wr, GpuAovRay& ar, Rng
             v3 bary = V3(hit.bary.x, hit.bary.y, 1.0f - hit.bary.x - hit.bary.y);
             v2 t0 = {v0.TexCoord[0], v0.TexCoord[1]}, t1 = {v1.TexCoord[0], v1.TexCoord[1]}, t2 = {v2_.TexCoord[0], v2_.TexCoord[1]};
             v2 uv = Interpolate2(t0, t1, t2, bary);
+            if (stage == pt.uvStage) {                                                   // test hooks (struct PT)
+                if (pt.uvDump) { pt.uvDump[2 * rayIndex] = uv.x; pt.uvDump[2 * rayIndex + 1] = uv.y; }
+                if (pt.uvOverride && pt.uvOverride[2 * rayIndex] == pt.uvOverride[2 * rayIndex]) { uv.x = pt.uvOverride[2 * rayIndex]; uv.y = pt.uvOverride[2 * rayIndex + 1]; }
+            }
             v3 interpNormal = normalize(Interpolate(DecompressSR11G11B10(v0.Normal), DecompressSR11G11B10(v1.Normal), DecompressSR11G11B10(v2_.Normal), bary));
             v3 interpTangent = normalize(Interpolate(DecompressSR11G11B10(v0.Tangent), DecompressSR11G11B10(v1.Tangent), DecompressSR11G11B10(v2_.Tangent), bary));
             const GpuMeshTransform& xf = s.xforms[hit.MeshTransformId];
@@ -665,7 +672,7 @@ static void RenderSample(PT& pt)
             ar.Albedo[0] = ar.Albedo[1] = ar.Albedo[2] = 0.0f; ar.Normal[0] = ar.Normal[1] = ar.Normal[2] = 0.0f; ar.NewWeight = 1.0f; ar._pad0 = 0.0f;
             uint32_t gx, gy; FirstHitGid(W, pt.H, x, y, &gx, &gy);
             v2 pb;
-            bool c = ShadeRay(pt, true, wr, ar, &rng, gy * 4096u + gx, nullptr, pt.countersOn ? &rowCnt[ly] : nullptr, &pt.primT[rayIndex], &pt.primTri[rayIndex], &pb);
+            bool c = ShadeRay(pt, true, wr, ar, &rng, gy * 4096u + gx, nullptr, pt.countersOn ? &rowCnt[ly] : nullptr, &pt.primT[rayIndex], &pt.primTri[rayIndex], &pb, 0, rayIndex);
             pt.primBary[2 * rayIndex] = pb.x; pt.primBary[2 * rayIndex + 1] = pb.y;
             pt.rays[rayIndex] = wr;
             if (pt.st.OutputAOVs) pt.aov[rayIndex] = ar;
@@ -716,7 +723,7 @@ static void RenderSample(PT& pt)
                 Rng rng; rng.seed = gslot * 4096u + pt.sampleIndex();
                 GpuWavefrontRay wr = pt.rays[rayIndex]; GpuAovRay ar = pt.aov[rayIndex];
                 uint32_t key = 0;
-                bool c = ShadeRay(pt, false, wr, ar, &rng, gslot, &key, pt.countersOn ? &chunkCnt[chunk] : nullptr, nullptr, nullptr, nullptr);
+                bool c = ShadeRay(pt, false, wr, ar, &rng, gslot, &key, pt.countersOn ? &chunkCnt[chunk] : nullptr, nullptr, nullptr, nullptr, j, (size_t)rayIndex);
                 pt.rays[rayIndex] = wr;
                 if (pt.st.OutputAOVs) pt.aov[rayIndex] = ar;
                 cont2[slot] = c; keyOut[slot] = key & ((1u << IDKPT_SORT_KEY_BITS) - 1u);
@@ -939,6 +946,7 @@ void ref_pt_set_band_exchange(void* p, idkpt_band_exchange_fn fn, void* user) { 
 void ref_pt_set_settings(void* p, const idkpt_settings* s) { ((PT*)p)->st = *s; }
 void ref_pt_set_perframe(void* p, const float* invProj, const float* invView, const float* viewPos) { PT* pt = (PT*)p; memcpy(pt->invProj, invProj, 64); memcpy(pt->invView, invView, 64); memcpy(pt->viewPos, viewPos, 12); }
 void ref_pt_reset_accumulation(void* p) { ((PT*)p)->accumulated = 0; }
+void ref_pt_set_uv_hooks(void* p, int stage, const float* overrideUv, float* dumpUv) { PT* pt = (PT*)p; pt->uvStage = stage; pt->uvOverride = overrideUv; pt->uvDump = dumpUv; }   // test hooks (struct PT)
 void ref_pt_set_sample_sequence(void* p, uint32_t first, uint32_t stride) { PT* pt = (PT*)p; pt->seqFirst = first; pt->seqStride = stride; pt->accumulated = 0; }
 void ref_pt_enable_counters(void* p, int on) { ((PT*)p)->countersOn = on != 0; }
 void ref_pt_render(void* p) { PT* pt = (PT*)p; for (int i = 0; i < pt->st.SamplesPerPixel; i++) RenderSample(*pt); } // PathTracer.cs:218

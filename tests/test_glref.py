@@ -207,6 +207,12 @@ def test_live_reference_fuzz_textured_cases_within_the_sampler_spread():
     assert tot["beyond_tol_in_textured_cases"] <= A["max_fraction_of_rays"] * tot["rays"], tot
     assert tot["worst_throughput_or_radiance_error_beyond_tolerance"] <= A["max_throughput_or_radiance_error"], tot
     assert set(tot["worst_error_of_the_rays_beyond_tolerance_by_field"]) <= {"Throughput", "Radiance"}, tot       # (no origin, no direction: no other lobe, no other hit)
+    # the per-stage gate of the textured cases is north_star's own number: every textured stage once more with the checker's taps at the texture coordinates the
+    # REFERENCE interpolated (glref.py A9) — identical stage inputs down to the tap — leaves nothing beyond 1e-4 and no flip; the allowance above is for the
+    # free-running comparison (each side's own interpolated coordinate) only
+    P = tot["textured_stages_from_identical_taps"]
+    assert P["stages"] >= 60 and P["taps"] > 20000, P
+    assert P["beyond_tol"] == 0 and P["flips"] == 0 and P["max_rel"] <= glref_check.REL_TOL, P
 
 
 @live
