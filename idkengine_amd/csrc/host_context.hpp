@@ -65,6 +65,13 @@ struct DevOptions {
     int instTlasOverlap = 10;    // ... only where the instances' boxes overlap little: a random line through the scene meets at most this many PERCENT of them (k_tlas_build measures it).
                                  // 64 clusters at 5 / 10 / 20 / 30 %: the tree is 2.2x / 1.7x / 1.1x / 0.8x the loop seen from outside and 1.6x / 0.77x / 0.7x / 0.7x seen from inside;
                                  // soup-1M in 12 / 60 interleaved parts (72 / 37 %): 0.73-0.89x / 0.87-1.03x; the atrium's 87 meshes: 2.7 %.  100 = whatever the overlap
+    int instBraid = 0;           // ... and the tree's leaves are SUBTREES of the instances' BLASes (partial re-braiding, k_braid in kernels_scene.hpp): the entries with the largest boxes are opened
+                                 // into their node's children until the list has this many entries (0 = whole instances only).  Scenes whose BLAS boxes nest (dev_ctx::sceneNested).
+                                 // Measured (profiles/r06_braid.md): the walk's TLAS phase pays two dependent fetches per step and a RayTransform per entry, so more and smaller entries LOSE
+                                 // (atrium-87 2 018 -> 1 746 Mray/s at 2 048 entries, 3-part soup 2 721 -> 1 467): default 0; the idea pays where an entry costs nothing, inst_unify below
+    int instUnify = 4096;        // k_trace_inst<.., UNI>: scenes of >= 2 instances that all carry the SAME InvModel (bit for bit) and use every BLAS at most once — the reference's usual static scene —
+                                 // walk ONE tree in their common BLAS space: a PLOC top over this many subtrees of the BLASes at most (k_braid), the BLASes' own nodes below (k_unify_*,
+                                 // kernels_scene.hpp); flagged rays go to the exact loop as with the own TLAS.  0 = off.  Measured: profiles/r06_braid.md
     int packet = 1;              // k_trace_packet (kernels_packet.hpp): primary launches of one-BLAS scenes whose work list is pixel-major (batches of >= gen_pixel_major samples) walk the BVH2 as
                                  // packets — one shared walk per wave, node pairs through the scalar cache; rays it cannot vouch for are re-traced by k_trace2.  0 = never, 1 (default) = where the
                                  // kernel's own counters say the wave's rays want the same nodes (packet_decide: live lanes per node step), 2 = every primary launch of a one-BLAS scene
@@ -116,6 +123,9 @@ struct dev_ctx {
     // both derived on the device before the first batch that wants them and after everything that moves boxes, positions or transforms
     DevBuf instRec; bool instRecValid = false;            // DScene::instRec (k_inst_records): one scene version only; re-derived with the own TLAS's triggers
     DevBuf itlas, imarks, ichunks; int itlasNeed = 1; uint32_t ichunkCount = 0; bool itlasValid = false, imarksValid = false;
+    DevBuf unodes, utlas, uTabs, uniBuf; bool uniValid = false, uniEligible = false, uniTabsValid = false; int uniCap = 0, uniEntries = 0, uniDepth = 0; float* hUni = nullptr; float* dUni = nullptr;   // the unified tree (k_unify_*): nodes, its PLOC top, the per-BLAS tables; host-mapped: [1] entries, [2] depth of the top
+    std::vector<GpuBlasInstance> hInstances; std::vector<char> hXforms; uint64_t uniLaunches = 0;   // host copies of the instance list and of the GpuMeshTransforms as last uploaded / patched
+    DevBuf entRec, braidBuf; bool itlasBraided = false; int itlasDepth = 0, itlasEntries = 0;   // k_braid's entry records / (entries, areas, leaf boxes, count); the built tree's depth and leaf count as last read from the device (0: not known)
     // the packet walk's decision (host_launch.hpp packet_decide): 0 = probing (packets on, counters awaited), 1 = on, 2 = off; the kernel's counters arrive through host-mapped memory
     // one or two batches late (k_packet_mirror): [1] packets, [2] node steps, [3] live lanes, [4] rays entered, [5] triangle rounds — totals since the last reset
     int pkState = 0, pkBatchesSinceProbe = 0; unsigned long long* hPkStats = nullptr; unsigned long long* dPkStats = nullptr; unsigned long long pkSeen[6] = {0, 0, 0, 0, 0, 0}; float pkCam[36] = {0}; int pkW = 0, pkRows = 0, pkBatch = 0; float pkLastLive = -1.0f;

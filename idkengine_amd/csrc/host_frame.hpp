@@ -101,7 +101,7 @@ template <class T> static T* vb_cur(dev_ctx* ctx, int b) { return (T*)vb_ptr(ctx
 // after idkptUploadScene / a clone / a re-derived node order: one state per buffer, in slot 0 of whatever allocation the buffer has
 static void ver_reset(dev_ctx* ctx)
 {
-    ctx->wideTopoValid = false; ctx->wideFillValid = false; ctx->itlasValid = false; ctx->instRecValid = false; ctx->imarksValid = false; ctx->ichunkCount = 0; ctx->instOverlapKnown = false; ctx->itlasBuilt = false;
+    ctx->wideTopoValid = false; ctx->wideFillValid = false; ctx->itlasValid = false; ctx->instRecValid = false; ctx->imarksValid = false; ctx->ichunkCount = 0; ctx->instOverlapKnown = false; ctx->itlasBuilt = false; ctx->uniValid = false; ctx->uniTabsValid = false;
     const size_t one[VB_COUNT] = {(size_t)ctx->nodeCount * 32, (size_t)ctx->triCount * 48, (size_t)ctx->vertexCount * 16,
                                   (size_t)std::max(ctx->tlasCount, 2 * ctx->instanceCount - 1) * 32, (size_t)ctx->xformCount * sizeof(GpuMeshTransform)};
     for (int b = 0; b < VB_COUNT; b++) { ctx->vbytes[b] = one[b]; ctx->vstride[b] = (one[b] + 255) / 256 * 256; ctx->valloc[b] = 1; ctx->vcur[b] = 0; ctx->lastMask[b] = 0; ctx->lastSlots[b] = 0; }

@@ -10,7 +10,13 @@ static int wide_stack_rows(const dev_ctx* ctx) { return std::min(96, std::max(4,
 // moved boxes or positions (k_wide_fill).  Stream-ordered in front of the batch that is about to be launched; with one scene version every update launches the queued samples first.
 static char* vb_ptr(dev_ctx* ctx, int b, int slot);
 // totals of the optional walks since idkptResetStats (idkpt_stats.Wide*, InstTlasFlaggedRays, Packet*): sixteen 64-bit words ([0..3] wide, [4] own TLAS, [8..13] packets), zeroed when first needed
-static int inst_tlas_rows(const dev_ctx* ctx) { return std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount)); }   // LDS rows behind the BLAS stack: the own TLAS's stack, or an instance mask of 32 x that many bits
+// LDS rows behind the BLAS stack: the own TLAS's stack, or an instance mask of 32 x that many bits.  A tree over n leaves is never deeper than n; once k_tlas_build has reported the depth of the
+// tree it built (host-mapped, possibly one rebuild stale: a ray that needs more rows than it gets is flagged and traced by the exact loop) the rows are that depth, and what the mask needs
+static int inst_tlas_rows(const dev_ctx* ctx)
+{
+    if (ctx->itlasDepth > 0 && ctx->itlasBuilt) return std::min(TLAS_STACK_SIZE, std::max((ctx->instanceCount + 31) / 32, ctx->itlasDepth));
+    return std::min(TLAS_STACK_SIZE, std::max(1, ctx->instanceCount));
+}
 #define TOTALS_BYTES 128
 static int totals_ensure(dev_ctx* ctx) { if (!ctx->wtotals.p) { HIPC(ctx->wtotals.ensure(TOTALS_BYTES)); HIPC(hipMemsetAsync(ctx->wtotals.p, 0, TOTALS_BYTES, ctx->stream)); } return IDKPT_OK; }
 static int wide_prepare(dev_ctx* ctx)
@@ -64,17 +70,22 @@ static int inst_records_prepare(dev_ctx* ctx)
 
 // ---- the per-triangle marks "not contained in its leaf box" (k_mark_triangles) of the walks that re-order a ray's candidates (k_trace_inst, k_trace_packet): derived on the
 // device before the first launch that wants them and after everything that moved boxes or positions (one scene version only)
+static int chunks_ensure(dev_ctx* ctx)
+{
+    if (ctx->ichunkCount != 0) return IDKPT_OK;   // the flattened (BLAS, chunk of 256 nodes) table: once per upload
+    hipStream_t st = ctx->stream;
+    std::vector<uint32_t> tab;
+    for (size_t b = 0; b < ctx->hDescs.size(); b++) for (int first = 0; first < ctx->hDescs[b].NodeCount; first += 256) { tab.push_back((uint32_t)b); tab.push_back((uint32_t)first); }
+    ctx->ichunkCount = (uint32_t)(tab.size() / 2);
+    HIPC(ctx->ichunks.ensure(tab.size() * 4 + 8));
+    if (!tab.empty()) { HIPC(hipMemcpyAsync(ctx->ichunks.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }   // (tab is a stack vector)
+    return IDKPT_OK;
+}
 static int marks_prepare(dev_ctx* ctx)
 {
     if (ctx->imarksValid) return IDKPT_OK;
     hipStream_t st = ctx->stream;
-    if (ctx->ichunkCount == 0) {   // the flattened (BLAS, chunk of 256 nodes) table: once per upload
-        std::vector<uint32_t> tab;
-        for (size_t b = 0; b < ctx->hDescs.size(); b++) for (int first = 0; first < ctx->hDescs[b].NodeCount; first += 256) { tab.push_back((uint32_t)b); tab.push_back((uint32_t)first); }
-        ctx->ichunkCount = (uint32_t)(tab.size() / 2);
-        HIPC(ctx->ichunks.ensure(tab.size() * 4 + 8));
-        if (!tab.empty()) { HIPC(hipMemcpyAsync(ctx->ichunks.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st)); }   // (tab is a stack vector)
-    }
+    { int rc = chunks_ensure(ctx); if (rc) return rc; }
     HIPC(ctx->imarks.ensure((size_t)std::max(1, ctx->triCount)));
     HIPC(hipMemsetAsync(ctx->imarks.p, 0, (size_t)std::max(1, ctx->triCount), st));
     if (ctx->ichunkCount) hipLaunchKernelGGL(k_mark_triangles, dim3(ctx->ichunkCount), dim3(256), 0, st, (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]), (const float4*)vb_ptr(ctx, VB_TRIVERTS, ctx->vcur[VB_TRIVERTS]),
@@ -135,39 +146,130 @@ static bool inst_tlas_wanted(const dev_ctx* ctx, bool sieve = false /* the same 
     return from > 0 && ctx->instanceCount >= std::max(2, from) && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters
            && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);
 }
+// ---- the unified tree (kernels_trace_inst.hpp UNI; k_braid / k_unify_* in kernels_scene.hpp) -----------------------------------------------------------------------------
+// Same conditions as the own TLAS, from two instances on; additionally the BLAS boxes nest, every BLAS is used by at most one instance (a scene-wide triangle index then names its
+// instance), and every instance carries the same InvModel — all decided on the host (instances and transforms only ever arrive through it).
+static bool inst_unify_wanted(const dev_ctx* ctx)
+{
+    if (ctx->opt.instUnify <= 0 || ctx->instanceCount < 2 || ctx->instanceCount > 1024 || !ctx->sceneNested) return false;
+    return !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);
+}
+static int inst_unify_prepare(dev_ctx* ctx, bool first)
+{
+    ctx->uniValid = false;
+    if (!inst_unify_wanted(ctx)) return IDKPT_OK;
+    const int n = ctx->instanceCount, nb = (int)ctx->hDescs.size();
+    hipStream_t st = ctx->stream;
+    if (!ctx->uniTabsValid) {                           // once per upload: each BLAS used at most once?  The per-BLAS tables in ascending order of TriangleOffset
+        std::vector<int> user(nb, -1);
+        bool ok = (int)ctx->hInstances.size() == n;
+        for (int i = 0; i < n && ok; i++) { const int b = (int)ctx->hInstances[i].BlasId; if (b < 0 || b >= nb || user[b] >= 0) ok = false; else user[b] = i; }
+        ctx->uniEligible = ok; ctx->uniTabsValid = true;
+        if (!ok) return IDKPT_OK;
+        std::vector<int> order(nb); for (int b = 0; b < nb; b++) order[b] = b;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return ctx->hDescs[a].TriangleOffset < ctx->hDescs[b].TriangleOffset; });
+        std::vector<uint32_t> tab(2 * (size_t)nb);
+        for (int k = 0; k < nb; k++) { tab[k] = (uint32_t)ctx->hDescs[order[k]].TriangleOffset; tab[nb + k] = user[order[k]] >= 0 ? (uint32_t)ctx->hInstances[user[order[k]]].MeshTransformId : 0u; }
+        HIPC(ctx->uTabs.ensure(tab.size() * 4 + 16));
+        HIPC(hipMemcpyAsync(ctx->uTabs.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st));   // (tab is a stack vector)
+    }
+    if (!ctx->uniEligible) return IDKPT_OK;
+    {   // every instance's InvModel (rows 3-5 of its GpuMeshTransform) is instance 0's, bit for bit?  On the host's copy: transforms only ever arrive through the host
+        const size_t xb = sizeof(GpuMeshTransform);
+        const size_t t0 = (size_t)ctx->hInstances[0].MeshTransformId;
+        if ((t0 + 1) * xb > ctx->hXforms.size()) return IDKPT_OK;
+        for (int i = 1; i < n; i++) {
+            const size_t ti = (size_t)ctx->hInstances[i].MeshTransformId;
+            if ((ti + 1) * xb > ctx->hXforms.size() || memcmp(ctx->hXforms.data() + ti * xb + 48, ctx->hXforms.data() + t0 * xb + 48, 48) != 0) return IDKPT_OK;
+        }
+    }
+    if (!ctx->hUni) { HIPC(hipHostMalloc((void**)&ctx->hUni, 64, hipHostMallocMapped)); memset(ctx->hUni, 0, 64); HIPC(hipHostGetDevicePointer((void**)&ctx->dUni, ctx->hUni, 0)); }
+    { int rc = chunks_ensure(ctx); if (rc) return rc; }
+    const float4* nodes = (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]);
+    const float4* xf = (const float4*)vb_ptr(ctx, VB_XFORMS, ctx->vcur[VB_XFORMS]);
+    const int cap = std::max(n, std::min(ctx->opt.instUnify, 16384)), nodeCount = 2 * cap - 1;
+    const uint32_t baseB = 2u * (uint32_t)cap;
+    // k_braid's entries, areas, leaf boxes, count; k_tlas_build's scratch; the PLOC top; the unified nodes
+    const size_t entOff = 0, areaOff = entOff + (size_t)cap * 8, bleafOff = (areaOff + (size_t)cap * 4 + 15) & ~(size_t)15, cntOff = bleafOff + (size_t)cap * 32;
+    const size_t ubOff = cntOff + 16;
+    const size_t scOff = (ubOff + (size_t)cap * 4 + 255) & ~(size_t)255, leafOff = (size_t)nodeCount * 32, keyOff = leafOff + (size_t)cap * 32, prefOff = keyOff + (size_t)cap * 4;
+    HIPC(ctx->uniBuf.ensure(scOff + prefOff + (size_t)nodeCount * 4)); HIPC(ctx->utlas.ensure((size_t)nodeCount * 32));      // (its own buffers: the caller's launches on tlasScratch / braidBuf are in flight)
+    HIPC(ctx->unodes.ensure(((size_t)baseB + (size_t)ctx->nodeCount) * 32 + 64));
+    char* bb = ctx->uniBuf.as<char>(); char* sc = bb + scOff;
+    hipLaunchKernelGGL(k_braid, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, cap,
+                       (uint2*)(bb + entOff), (float*)(bb + areaOff), (float4*)nullptr, (float4*)(bb + bleafOff), (int*)(bb + cntOff), 1, (int*)(bb + ubOff));
+    BraidOut bo{(const float4*)(bb + bleafOff), (const int*)(bb + cntOff), (const int*)(bb + ubOff)};
+    hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, 15 /* TLAS.cs: SearchRadius */,
+                       ctx->utlas.as<float4>(), (float4*)sc, (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff), 1, ctx->dUni, 0, bo);
+    hipLaunchKernelGGL(k_unify_top, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, (const float4*)ctx->utlas.as<float4>(), (const int*)(bb + cntOff), (const uint2*)(bb + entOff), nodes, ctx->descs.as<GpuBlasDesc>(),
+                       ctx->instances.as<GpuBlasInstance>(), baseB, ctx->unodes.as<float4>());
+    if (ctx->ichunkCount) hipLaunchKernelGGL(k_unify_blas, dim3(ctx->ichunkCount), dim3(256), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), (const uint2*)ctx->ichunks.as<uint2>(), baseB, ctx->unodes.as<float4>());
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(st));                       // (waited for: the entries and the top's depth size this walk's stack; same-space scenes are static scenes, a re-derivation is rare)
+    (void)first;
+    const volatile float* h = ctx->hUni;
+    ctx->uniEntries = (int)h[1]; ctx->uniDepth = (int)h[2];
+    ctx->uniValid = ctx->uniDepth > 0 && ctx->uniEntries >= n;
+    // rows of this walk's stack: what the device derived from the BLASes' RequiredStackSize (validated >= the trees' real need at upload) and the top above them, never more than
+    // "the deepest BLAS under the whole top" (a ray that needs more rows is flagged and traced by the exact loop)
+    const int loose = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack) + std::max(1, ctx->uniDepth);
+    ctx->uniCap = std::min(96, std::max(4, std::min(loose, h[3] > 0.0f ? (int)h[3] + 1 : loose)));
+    return IDKPT_OK;
+}
+
 // derives what is stale and decides how the next batch of a several-instance scene without UseTlas is traced: through the library's own tree (*useTlas), by the exact loop with the
 // instance sieve (*useSieve), or by k_trace2 MODE 1 (neither).  The instances' overlap is measured on the device into host-mapped memory; the first measurement after an upload is
 // waited for, later ones (animated transforms) are read whenever they have arrived — the decision only moves time, never a result
 static int inst_tlas_prepare(dev_ctx* ctx, bool* useTlas, bool* useSieve)
 {
     *useTlas = false; *useSieve = false;
-    const bool wantT = inst_tlas_wanted(ctx), wantS = inst_tlas_wanted(ctx, true);
+    const bool wantU = inst_unify_wanted(ctx);
+    const bool wantT = inst_tlas_wanted(ctx) || wantU, wantS = inst_tlas_wanted(ctx, true);     // (the unified tree's launches use the own TLAS's top boxes for the primary rays' pre-cull, k_gen_primary)
     if (!wantT && !wantS) return IDKPT_OK;
     { int rc = totals_ensure(ctx); if (rc) return rc; }
     hipStream_t st = ctx->stream;
     const float4* nodes = (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]);
-    const int n = ctx->instanceCount, nodeCount = 2 * n - 1;
-    if (!ctx->hInstOverlap) { HIPC(hipHostMalloc((void**)&ctx->hInstOverlap, 64, hipHostMallocMapped)); *ctx->hInstOverlap = 0.0f; HIPC(hipHostGetDevicePointer((void**)&ctx->dInstOverlap, ctx->hInstOverlap, 0)); }
+    const int n = ctx->instanceCount;
+    if (!ctx->hInstOverlap) { HIPC(hipHostMalloc((void**)&ctx->hInstOverlap, 64, hipHostMallocMapped)); memset(ctx->hInstOverlap, 0, 64); HIPC(hipHostGetDevicePointer((void**)&ctx->dInstOverlap, ctx->hInstOverlap, 0)); }
     if (!ctx->itlasValid) {
-        const size_t leafOff = (size_t)nodeCount * 32, keyOff = leafOff + (size_t)n * 32, prefOff = keyOff + (size_t)n * 4;
-        HIPC(ctx->tlasScratch.ensure(prefOff + (size_t)n * 4)); HIPC(ctx->itlas.ensure((size_t)nodeCount * 32));
+        // partial re-braiding (k_braid): the tree's leaves are subtrees of the instances' BLASes, at most `cap` of them
+        const bool braid = wantT && ctx->opt.instBraid > 0 && ctx->sceneNested;
+        const int cap = braid ? std::max(n, std::min(ctx->opt.instBraid, 8192)) : n, nodeCount = 2 * cap - 1;
+        const size_t leafOff = (size_t)nodeCount * 32, keyOff = leafOff + (size_t)cap * 32, prefOff = keyOff + (size_t)cap * 4;
+        HIPC(ctx->tlasScratch.ensure(prefOff + (size_t)nodeCount * 4)); HIPC(ctx->itlas.ensure((size_t)nodeCount * 32));
         char* sc = ctx->tlasScratch.as<char>();
         const float4* xf = (const float4*)vb_ptr(ctx, VB_XFORMS, ctx->vcur[VB_XFORMS]);
+        BraidOut bo{nullptr, nullptr};
+        if (braid) {
+            const size_t entOff = 0, areaOff = entOff + (size_t)cap * 8, bleafOff = (areaOff + (size_t)cap * 4 + 15) & ~(size_t)15, cntOff = bleafOff + (size_t)cap * 32;
+            HIPC(ctx->braidBuf.ensure(cntOff + 16)); HIPC(ctx->entRec.ensure((size_t)cap * 96));
+            char* bb = ctx->braidBuf.as<char>();
+            hipLaunchKernelGGL(k_braid, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, cap,
+                               (uint2*)(bb + entOff), (float*)(bb + areaOff), ctx->entRec.as<float4>(), (float4*)(bb + bleafOff), (int*)(bb + cntOff));
+            HIPC(hipGetLastError());
+            bo.leaf = (const float4*)(bb + bleafOff); bo.count = (const int*)(bb + cntOff);
+        }
 #define ITLAS_BUILD(leavesOnly) hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, 15 /* TLAS.cs: SearchRadius */, \
-                                                   ctx->itlas.as<float4>(), (float4*)sc, (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff), 1, ctx->dInstOverlap, leavesOnly)
+                                                   ctx->itlas.as<float4>(), (float4*)sc, (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff), 1, ctx->dInstOverlap, leavesOnly, bo)
         ITLAS_BUILD(1);                                                       // the overlap of the boxes as they are now
         HIPC(hipGetLastError());
-        if (!ctx->instOverlapKnown) { HIPC(hipStreamSynchronize(st)); ctx->instOverlapKnown = true; }
-        const float met = *(volatile float*)ctx->hInstOverlap * 100.0f;      // percent of the instances' boxes a random line meets, x n
-        const bool worth = wantT && (ctx->opt.instTlasOverlap >= 100 || met <= (float)ctx->opt.instTlasOverlap * (float)n);
-        if (worth) { ITLAS_BUILD(0); HIPC(hipGetLastError()); }
+        const bool first = !ctx->instOverlapKnown;
+        if (first) { HIPC(hipStreamSynchronize(st)); ctx->instOverlapKnown = true; }
+        { int rc = inst_unify_prepare(ctx, first); if (rc) return rc; }
+        const float met = *(volatile float*)ctx->hInstOverlap * 100.0f;      // percent of the leaves' boxes a random line meets, x their number
+        const float leavesRead = ((volatile float*)ctx->hInstOverlap)[1], leaves = braid ? std::max((float)n, leavesRead) : (float)n;
+        const bool worth = ctx->uniValid || (inst_tlas_wanted(ctx) && (ctx->opt.instTlasOverlap >= 100 || met <= (float)ctx->opt.instTlasOverlap * leaves));
+        if (worth) { ITLAS_BUILD(0); HIPC(hipGetLastError()); if (first) HIPC(hipStreamSynchronize(st)); }   // (the first build's depth is waited for; later ones are read when they have arrived)
+        ctx->itlasBuilt = worth; ctx->itlasBraided = worth && braid; ctx->itlasEntries = (int)leaves;
+        ctx->itlasDepth = worth ? (int)((volatile float*)ctx->hInstOverlap)[2] : 0;
+        float metInst = met;                                                 // the sieve's question is about whole instances
+        if (braid && !worth && wantS) { bo = BraidOut{nullptr, nullptr}; ITLAS_BUILD(1); HIPC(hipGetLastError()); if (first) HIPC(hipStreamSynchronize(st)); metInst = *(volatile float*)ctx->hInstOverlap * 100.0f; }
 #undef ITLAS_BUILD
-        ctx->itlasBuilt = worth;
-        ctx->isieveWorth = !worth && wantS && (ctx->opt.instSieveOverlap >= 100 || met <= (float)ctx->opt.instSieveOverlap * (float)n);
+        ctx->isieveWorth = !worth && wantS && (ctx->opt.instSieveOverlap >= 100 || metInst <= (float)ctx->opt.instSieveOverlap * (float)n);
         ctx->itlasNeed = inst_tlas_rows(ctx);                                // (a ray that needs more rows is traced by the exact loop)
         ctx->itlasValid = true;
     }
-    const bool tree = ctx->itlasBuilt && wantT, sieve = !tree && wantS && (ctx->isieveWorth || ctx->itlasBuilt);   // (the options that change what is wanted invalidate the decision: host_options.hpp)
+    const bool tree = ctx->itlasBuilt && (ctx->uniValid ? wantU : inst_tlas_wanted(ctx)), sieve = !tree && wantS && (ctx->isieveWorth || ctx->itlasBuilt);   // (the options that change what is wanted invalidate the decision: host_options.hpp)
     if (!tree && !sieve) return IDKPT_OK;
     { int rc = inst_records_prepare(ctx); if (rc) return rc; }
     if (!tree) { *useSieve = true; return IDKPT_OK; }
@@ -233,8 +335,18 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
         // the instance loop through the library's own TLAS (kernels_trace_inst.hpp), then — on the launch's own list of flagged rays — the exact loop
         InstTlasBufs ib;
         ib.tlas = (const float4*)ctx->itlas.as<float4>(); ib.marks = (const uint8_t*)ctx->imarks.as<uint8_t>(); ib.tlasCap = ctx->itlasNeed;
+        ib.entRec = ctx->itlasBraided ? (const float4*)ctx->entRec.as<float4>() : s.instRec;
         ib.flagCount = work + 128; ib.flagA = ctx->sortKeys.as<uint32_t>(); ib.flagB = ctx->sortVals.as<uint32_t>(); ib.totals = ctx->wtotals.as<unsigned long long>() + 4;
         ib.maskWords = (ctx->instanceCount + 31) / 32;
+        if (ctx->uniValid) {
+            // every instance in one BLAS space: the unified tree (no TLAS phase, no TLAS rows: its stack is the top's depth on the deepest BLAS's)
+            ib.unodes = (const float4*)ctx->unodes.as<float4>(); ib.uniCap = ctx->uniCap; ib.blasCount = (int)ctx->hDescs.size();
+            ib.blasTriStart = (const uint32_t*)ctx->uTabs.as<uint32_t>(); ib.blasXform = ib.blasTriStart + ib.blasCount;
+            ib.uniXformId = (uint32_t)ctx->hInstances[0].MeshTransformId;
+            const size_t ldsU = (size_t)(ctx->uniCap + 2) * WAVE * 4 + (size_t)std::max(0, ctx->opt.ldsPad);
+            ctx->uniLaunches++;
+            hipLaunchKernelGGL((k_trace_inst<PRIMARY, false, 16, true>), dim3(grid), dim3(WAVE), ldsU, st, s, f, rays, tr, hits, list, cnt, work, ib);
+        } else
         hipLaunchKernelGGL((k_trace_inst<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, ib);
         TraceBufs trf = tr; trf.order = nullptr; trf.orderIdx = nullptr;
         if (!PRIMARY) { trf.order = ib.flagA; trf.orderIdx = ib.flagB; }

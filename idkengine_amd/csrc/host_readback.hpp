@@ -123,6 +123,7 @@ static int32_t dev_GetStats(dev_ctx* ctx, idkpt_stats* out)
     s.RaysTraced = s.PrimaryRays + c[2]; // N per sample + every alive-queue entry that entered a bounce
     if (ctx->wtotals.p) { uint64_t w[16]; HIPC(hipMemcpyAsync(w, ctx->wtotals.p, TOTALS_BYTES, hipMemcpyDeviceToHost, ctx->stream)); HIPC(hipStreamSynchronize(ctx->stream)); s.WideFlaggedRays = w[0]; s.WideNodeVisits = w[1]; s.WideLeafRecords = w[2]; s.WideTriangleTests = w[3]; s.InstTlasFlaggedRays = w[4];
         s.PacketFlaggedRays = w[8]; s.PacketPackets = w[9]; s.PacketNodeSteps = w[10]; s.PacketLiveLanes = w[11]; s.PacketRaysEntered = w[12]; s.PacketTriangleRounds = w[13]; }
+    s.InstUnifiedLaunches = ctx->uniLaunches; s.InstUnifiedEntries = ctx->uniValid ? (uint32_t)ctx->uniEntries : 0u; s.InstUnifiedTopDepth = ctx->uniValid ? (uint32_t)ctx->uniDepth : 0u;
     *out = s;
     return IDKPT_OK;
 }
@@ -133,7 +134,7 @@ static int32_t dev_ResetStats(dev_ctx* ctx)
     HIPC(hipSetDevice(ctx->device));
     FLUSH_KEEP();
     HIPC(hipStreamSynchronize(ctx->stream));
-    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    memset(&ctx->stats, 0, sizeof(ctx->stats)); ctx->uniLaunches = 0;
     if (ctx->hPkStats) memset(ctx->hPkStats, 0, 64);
     for (int i = 0; i < 6; i++) ctx->pkSeen[i] = 0;
     ctx->evUsed = 0; ctx->traceMsAcc = 0.0; ctx->traceLaunchesAcc = 0;

@@ -123,7 +123,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* all[] = {&ctx->srgbLut, &ctx->pmList, &ctx->instRec, &ctx->itlas, &ctx->imarks, &ctx->ichunks, &ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
+    DevBuf* all[] = {&ctx->srgbLut, &ctx->pmList, &ctx->instRec, &ctx->entRec, &ctx->braidBuf, &ctx->unodes, &ctx->utlas, &ctx->uTabs, &ctx->uniBuf, &ctx->itlas, &ctx->imarks, &ctx->ichunks, &ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
                      &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->bandTab, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
@@ -133,6 +133,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     if (ctx->hCounts) (void)hipHostFree(ctx->hCounts);
     if (ctx->hOverflow) (void)hipHostFree(ctx->hOverflow);
     if (ctx->hInstOverlap) (void)hipHostFree(ctx->hInstOverlap);
+    if (ctx->hUni) (void)hipHostFree(ctx->hUni);
     if (ctx->hPkStats) (void)hipHostFree(ctx->hPkStats);
     if (ctx->hBases) (void)hipHostFree(ctx->hBases);
     if (ctx->hCams) (void)hipHostFree(ctx->hCams);
@@ -407,6 +408,8 @@ static int32_t dev_UploadScene(dev_ctx* ctx, const idkpt_scene_desc* sc)
     ctx->vertexCount = sc->VertexCount; ctx->meshCount = sc->MeshCount; ctx->materialCount = sc->MaterialCount; ctx->xformCount = sc->MeshTransformCount;
     ctx->lightCount = sc->Lights ? sc->LightCount : 0; ctx->textureCount = sc->TextureCount;
     ctx->hDescs.assign(sc->BlasDescs, sc->BlasDescs + sc->BlasDescCount); ctx->hInst0Blas = (int)sc->BlasInstances[0].BlasId;
+    ctx->hInstances.assign(sc->BlasInstances, sc->BlasInstances + sc->BlasInstanceCount);
+    ctx->hXforms.assign((const char*)sc->MeshTransforms, (const char*)sc->MeshTransforms + (size_t)sc->MeshTransformCount * sizeof(GpuMeshTransform));
     ctx->sceneStack = maxStack; ctx->tlasNeed = std::max(1, tlasNeed);
     ctx->sceneNested = blas_nested(sc->BlasNodes, sc->BlasDescs, sc->BlasDescCount);
     ver_reset(ctx);                                   // one state per versioned buffer, in slot 0 (everything that read the old scene was launched by FLUSH above)
@@ -506,7 +509,7 @@ static int clone_finish(dev_ctx* ctx, dev_ctx* src)
     { int rc = tex_descs_upload(ctx); if (rc) return rc; }
     ctx->nodeCount = src->nodeCount; ctx->triCount = src->triCount; ctx->instanceCount = src->instanceCount; ctx->tlasCount = src->tlasCount; ctx->vertexCount = src->vertexCount;
     ctx->meshCount = src->meshCount; ctx->materialCount = src->materialCount; ctx->xformCount = src->xformCount; ctx->lightCount = src->lightCount; ctx->skySize = src->skySize;
-    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->hInst0Blas = src->hInst0Blas; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneNested = src->sceneNested; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed;
+    ctx->textureCount = src->textureCount; ctx->hDescs = src->hDescs; ctx->hInstances = src->hInstances; ctx->hXforms = src->hXforms; ctx->hInst0Blas = src->hInst0Blas; ctx->sceneNoEmission = src->sceneNoEmission; ctx->sceneNested = src->sceneNested; ctx->sceneStack = src->sceneStack; ctx->tlasNeed = src->tlasNeed;
     ctx->levelOffsets = src->levelOffsets; ctx->levelBase = src->levelBase; ctx->refitCoversAll = src->refitCoversAll;
     ver_reset(ctx);
     { int rc = ver_reserve(ctx); if (rc) return rc; }
@@ -612,6 +615,7 @@ static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes,
     char* dst = (char*)b->p;
     if (vb >= 0) { char* src; int rc = ver_writable(ctx, vb, offsetBytes == 0 && bytes == cap, &src, &dst); if (rc) return rc; }
     { int rc = staged_upload(ctx, dst + offsetBytes, data, bytes); if (rc) return rc; }   // (small updates — joints, transforms — do not wait for the stream)
+    if (which == IDKPT_BUF_MESH_TRANSFORMS && offsetBytes + bytes <= ctx->hXforms.size()) memcpy(ctx->hXforms.data() + offsetBytes, data, bytes);   // (the host's copy: "do all instances share one InvModel", host_launch.hpp)
     if (which == IDKPT_BUF_VERTEX_POSITIONS) { int rc = regather_triverts(ctx, 0, (uint32_t)ctx->triCount); if (rc) return rc; }
     return IDKPT_OK;
 }

@@ -813,6 +813,7 @@ int32_t idkptGetStats(idkpt_ctx* c, idkpt_stats* out)
         sum.RaysTraced += s.RaysTraced; sum.PrimaryRays += s.PrimaryRays; sum.NodePairVisits += s.NodePairVisits; sum.TriangleTests += s.TriangleTests;
         sum.WideFlaggedRays += s.WideFlaggedRays; sum.WideNodeVisits += s.WideNodeVisits; sum.WideLeafRecords += s.WideLeafRecords; sum.WideTriangleTests += s.WideTriangleTests; sum.InstTlasFlaggedRays += s.InstTlasFlaggedRays;
         sum.PacketFlaggedRays += s.PacketFlaggedRays; sum.PacketPackets += s.PacketPackets; sum.PacketNodeSteps += s.PacketNodeSteps; sum.PacketLiveLanes += s.PacketLiveLanes; sum.PacketRaysEntered += s.PacketRaysEntered; sum.PacketTriangleRounds += s.PacketTriangleRounds;
+        sum.InstUnifiedLaunches += s.InstUnifiedLaunches; if (d == 0) { sum.InstUnifiedEntries = s.InstUnifiedEntries; sum.InstUnifiedTopDepth = s.InstUnifiedTopDepth; }
         for (int j = 0; j < 16; j++) sum.LastAliveCounts[j] += s.LastAliveCounts[j];
         sum.LastFrameMs = std::max(sum.LastFrameMs, s.LastFrameMs); sum.LastTraceMs = std::max(sum.LastTraceMs, s.LastTraceMs);       // the devices run side by side
         sum.TraceMsTotal = std::max(sum.TraceMsTotal, s.TraceMsTotal);

@@ -23,7 +23,7 @@ __global__ void k_inst_records(const float4* blasNodes, const GpuBlasDesc* descs
     const float4 rmin = root[0], rmax = root[1];
     o[3] = make_float4(rmin.x, rmin.y, rmin.z, __uint_as_float((uint32_t)d.NodeOffset));
     o[4] = make_float4(rmax.x, rmax.y, rmax.z, __uint_as_float((uint32_t)d.TriangleOffset));
-    o[5] = make_float4(__uint_as_float((uint32_t)in.MeshTransformId), __uint_as_float((uint32_t)in.BlasId), 0.0f, 0.0f);
+    o[5] = make_float4(__uint_as_float((uint32_t)in.MeshTransformId), __uint_as_float((uint32_t)in.BlasId), __uint_as_float(2u) /* the pair a walk entered here starts at: the root's children */, __uint_as_float(1u) /* the node this record's box is of */);
 }
 
 #define TLAS_BUILD_THREADS 1024
@@ -32,6 +32,32 @@ DEV uint32_t tlas_to_uint_sat(float f) { if (f != f || f <= 0.0f) return 0u; if 
 DEV float tlas_minN(float a, float b) { return a < b ? a : b; }   // minps / float.MinNative (Shapes/Box.cs:40-50)
 DEV float tlas_maxN(float a, float b) { return a > b ? a : b; }
 DEV float tlas_half_area(float4 mn, float4 mx) { float sx = mx.x - mn.x, sy = mx.y - mn.y, sz = mx.z - mn.z; return __fmaf_rn(sx + sy, sz, sx * sy); }   // MyMath.cs:222-229
+
+// The library's own TLAS for the instance loop (kernels_trace_inst.hpp): the loop takes a ray into BLAS space with InvModel and nothing else (BVHIntersect.glsl:281-282), so the
+// world-space region whose rays can pass the test of a BLAS-space box is the image of that box under the inverse OF InvModel — inverted here, in double, whatever the host's Model
+// says — padded by 2^-10 of its size and of its distance from the origin (thousands of fp32 roundings of either transform).  A singular or non-finite InvModel: all of space.
+// x: the instance's GpuMeshTransform rows (x[3..5] = InvModel); rmin / rmax: the box in BLAS space.
+DEV void tlas_padded_world_box(const float4* x, const float4 rmin, const float4 rmax, float bmn[3], float bmx[3])
+{
+    const float4 i0 = x[3], i1 = x[4], i2 = x[5];
+    const double A[3][3] = {{i0.x, i0.y, i0.z}, {i1.x, i1.y, i1.z}, {i2.x, i2.y, i2.z}}, tb[3] = {i0.w, i1.w, i2.w};
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    const double inv[3][3] = {{c00 / det, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det},
+                              {c01 / det, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det},
+                              {c02 / det, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det}};
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    bool ok = det == det && fabs(det) > 1e-300;
+    for (int c = 0; c < 8; c++) {
+        const double q[3] = {(double)((c & 1) ? rmax.x : rmin.x) - tb[0], (double)((c & 2) ? rmax.y : rmin.y) - tb[1], (double)((c & 4) ? rmax.z : rmin.z) - tb[2]};
+        for (int k = 0; k < 3; k++) { const double w = inv[k][0] * q[0] + inv[k][1] * q[1] + inv[k][2] * q[2]; ok = ok && w == w && fabs(w) < 1e30; lo[k] = w < lo[k] ? w : lo[k]; hi[k] = w > hi[k] ? w : hi[k]; }
+    }
+    for (int k = 0; k < 3; k++) {
+        const double ext = hi[k] - lo[k], mag = fabs(lo[k]) > fabs(hi[k]) ? fabs(lo[k]) : fabs(hi[k]);
+        const double pad = (ext > mag ? ext : mag) * (1.0 / 1024.0) + 1e-30;
+        bmn[k] = ok ? (float)(lo[k] - pad) : -PT_FLOAT_MAX; bmx[k] = ok ? (float)(hi[k] + pad) : PT_FLOAT_MAX;
+    }
+}
 
 // ordered exclusive scan of two per-thread counters over the workgroup; returns this thread's bases and the totals
 DEV void block_scan2(uint32_t a, uint32_t b, uint32_t* sa, uint32_t* sb, uint32_t& baseA, uint32_t& baseB, uint32_t& totA, uint32_t& totB)
@@ -49,17 +75,28 @@ DEV void block_scan2(uint32_t a, uint32_t b, uint32_t* sa, uint32_t* sb, uint32_
     __syncthreads();
 }
 
+// (braid != nullptr — the library's own TLAS over the BRAIDED entries of k_braid below: the leaf boxes are taken from braid->leaf as they are, their number from braid->count;
+//  overlapOut[1] = that number.  padded, after a full build: overlapOut[2] = the depth of the tree = the rows a front-to-back walk's stack can need)
+struct BraidOut { const float4* leaf; const int* count; const int* ub = nullptr; };   // ub (unified tree only): per entry, an upper bound of the stack rows a walk of its subtree needs
 __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4* blasNodes, const GpuBlasDesc* descs, const GpuBlasInstance* instances, const float4* xforms,
                                                                     int n, int searchRadius, float4* nodes /* 2n-1 */, float4* temp /* 2n-1 */, float4* leaf /* n */, uint32_t* keys /* n */, int* pref /* n */,
-                                                                    int padded = 0, float* overlapOut = nullptr, int leavesOnly = 0)
+                                                                    int padded = 0, float* overlapOut = nullptr, int leavesOnly = 0, BraidOut braid = BraidOut{nullptr, nullptr})
 {
     __shared__ float red[6][TLAS_BUILD_THREADS / 64];
     __shared__ float gbox[6];
     __shared__ uint32_t sa[TLAS_BUILD_THREADS], sb[TLAS_BUILD_THREADS];
     const int t = (int)threadIdx.x, T = TLAS_BUILD_THREADS;
+    if (braid.count) n = *braid.count;
     const int nodeCount = 2 * n - 1;
     // ---- leaves: world-space bounds of every instance
     float mn[3] = {PT_FLOAT_MAX, PT_FLOAT_MAX, PT_FLOAT_MAX}, mx[3] = {-PT_FLOAT_MAX, -PT_FLOAT_MAX, -PT_FLOAT_MAX};
+    if (braid.leaf) {
+        for (int i = t; i < n; i += T) {
+            const float4 a = braid.leaf[2 * (size_t)i], b = braid.leaf[2 * (size_t)i + 1];
+            leaf[2 * (size_t)i] = a; leaf[2 * (size_t)i + 1] = b;
+            mn[0] = tlas_minN(mn[0], a.x); mn[1] = tlas_minN(mn[1], a.y); mn[2] = tlas_minN(mn[2], a.z); mx[0] = tlas_maxN(mx[0], b.x); mx[1] = tlas_maxN(mx[1], b.y); mx[2] = tlas_maxN(mx[2], b.z);
+        }
+    } else
     for (int i = t; i < n; i += T) {
         const GpuBlasInstance in = instances[i];
         const float4* root = blasNodes + 2 * ((size_t)descs[in.BlasId].NodeOffset + 1);
@@ -67,29 +104,8 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4*
         const float4* x = xforms + 9 * (size_t)in.MeshTransformId;
         const float4 m0 = x[0], m1 = x[1], m2 = x[2];
         float bmn[3] = {PT_FLOAT_MAX, PT_FLOAT_MAX, PT_FLOAT_MAX}, bmx[3] = {-PT_FLOAT_MAX, -PT_FLOAT_MAX, -PT_FLOAT_MAX};
-        if (padded) {
-            // The library's own TLAS for the instance loop (kernels_trace_inst.hpp): the loop takes a ray into BLAS space with InvModel and nothing else (BVHIntersect.glsl:281-282), so the
-            // world-space region whose rays can pass its root test is the image of the root box under the inverse OF InvModel — inverted here, in double, whatever the host's Model
-            // says — padded by 2^-10 of its size and of its distance from the origin (thousands of fp32 roundings of either transform).  A singular or non-finite InvModel: all of space.
-            const float4 i0 = x[3], i1 = x[4], i2 = x[5];
-            const double A[3][3] = {{i0.x, i0.y, i0.z}, {i1.x, i1.y, i1.z}, {i2.x, i2.y, i2.z}}, tb[3] = {i0.w, i1.w, i2.w};
-            const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
-            const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
-            const double inv[3][3] = {{c00 / det, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det},
-                                      {c01 / det, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det},
-                                      {c02 / det, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det}};
-            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-            bool ok = det == det && fabs(det) > 1e-300;
-            for (int c = 0; c < 8; c++) {
-                const double q[3] = {(double)((c & 1) ? rmax.x : rmin.x) - tb[0], (double)((c & 2) ? rmax.y : rmin.y) - tb[1], (double)((c & 4) ? rmax.z : rmin.z) - tb[2]};
-                for (int k = 0; k < 3; k++) { const double w = inv[k][0] * q[0] + inv[k][1] * q[1] + inv[k][2] * q[2]; ok = ok && w == w && fabs(w) < 1e30; lo[k] = w < lo[k] ? w : lo[k]; hi[k] = w > hi[k] ? w : hi[k]; }
-            }
-            for (int k = 0; k < 3; k++) {
-                const double ext = hi[k] - lo[k], mag = fabs(lo[k]) > fabs(hi[k]) ? fabs(lo[k]) : fabs(hi[k]);
-                const double pad = (ext > mag ? ext : mag) * (1.0 / 1024.0) + 1e-30;
-                bmn[k] = ok ? (float)(lo[k] - pad) : -PT_FLOAT_MAX; bmx[k] = ok ? (float)(hi[k] + pad) : PT_FLOAT_MAX;
-            }
-        } else
+        if (padded) tlas_padded_world_box(x, rmin, rmax, bmn, bmx);     // (the library's own TLAS for the instance loop, kernels_trace_inst.hpp)
+        else
         for (int c = 0; c < 8; c++) {
             const float cx = (c & 1) ? rmax.x : rmin.x, cy = (c & 2) ? rmax.y : rmin.y, cz = (c & 4) ? rmax.z : rmin.z;
             const float w[3] = {(cx * m0.x) + (cy * m0.y) + (cz * m0.z) + (1.0f * m0.w), (cx * m1.x) + (cy * m1.y) + (cz * m1.z) + (1.0f * m1.w), (cx * m2.x) + (cy * m2.y) + (cz * m2.z) + (1.0f * m2.w)};
@@ -122,6 +138,7 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4*
             const float all = tlas_half_area(make_float4(gbox[0], gbox[1], gbox[2], 0.0f), make_float4(gbox[3], gbox[4], gbox[5], 0.0f));
             const float e = tot / all;
             *overlapOut = (e == e && e >= 0.0f && e < 3.0e38f) ? e : (float)n;      // (degenerate or unbounded boxes: "every instance")
+            if (braid.count) overlapOut[1] = (float)n;
         }
         __syncthreads();
     }
@@ -197,6 +214,187 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4*
         __syncthreads();
         activeCount -= merged / 2; activeEnd -= merged;
     }
+    if (padded && overlapOut) {
+        // depth of the finished tree (children sit behind their parent in the array; level by level from the root, `pref` reused as the per-node depth)
+        int* const depth = pref;                                 // (2n - 1 words: the own-TLAS caller sizes `pref` for that)
+        for (int i = t; i < nodeCount; i += T) depth[i] = i == 0 ? 1 : 0;
+        if (t == 0) overlapOut[2] = (float)(4 * TLAS_STACK_SIZE);
+        __syncthreads();
+        for (int level = 1; level <= 4 * TLAS_STACK_SIZE; level++) {
+            uint32_t any = 0;
+            for (int i = t; i < nodeCount; i += T) {
+                if (depth[i] != level) continue;
+                const uint32_t packed = __float_as_uint(nodes[2 * (size_t)i].w);
+                if ((packed >> 31) == 0u) { depth[packed] = level + 1; depth[packed + 1] = level + 1; any = 1; }
+            }
+            sa[t] = any;
+            __syncthreads();
+            for (int off = T / 2; off > 0; off >>= 1) { if (t < off) sa[t] |= sa[t + off]; __syncthreads(); }
+            const uint32_t more = sa[0];
+            __syncthreads();
+            if (!more) { if (t == 0) overlapOut[2] = (float)level; break; }
+        }
+        if (braid.ub) {
+            // rows a walk of the whole tree needs: over the leaves, the inner nodes above one (the step at each can leave one entry on the stack) + its subtree's bound
+            uint32_t need = 0;
+            for (int i = t; i < nodeCount; i += T) {
+                const uint32_t packed = __float_as_uint(nodes[2 * (size_t)i].w);
+                if ((packed >> 31) == 1u) need = max(need, (uint32_t)max(0, depth[i] - 1 + braid.ub[packed & 0x7fffffffu]));
+            }
+            __syncthreads();
+            sa[t] = need;
+            __syncthreads();
+            for (int off = T / 2; off > 0; off >>= 1) { if (t < off) sa[t] = max(sa[t], sa[t + off]); __syncthreads(); }
+            if (t == 0) overlapOut[3] = (float)sa[0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Partial re-braiding for the library's own TLAS (kernels_trace_inst.hpp): the tree's leaves need not be whole instances.  The reference holds one BLAS per mesh (Bvh/BVH.cs:156) and a
+// building's meshes overlap: the atrium's 87 root boxes make a ray of the own-TLAS walk enter 2.2 x the nodes of the same triangles in one BLAS.  An ENTRY is (instance, BLAS node); the
+// list starts as (i, root) for every instance, and the entries with the largest world-space boxes are OPENED — replaced by the node's two children — until the list has `budget` entries
+// or nothing large is left to open.  A walk that enters an entry transforms the ray exactly as the loop does (the instance's InvModel), tests the entry's own BLAS box with the loop's
+// RayBoxIntersect and continues at the node's child pair: every number is still the loop's arithmetic on the loop's data, only more of the order is the tree's (the header of
+// kernels_trace_inst.hpp: the loop reaches the winning leaf because the boxes of its ancestors — now including the ones above the entry, never tested by this walk — contain the leaf
+// box, so their exact tests pass whenever the leaf's does; the host braids only scenes whose BLAS boxes nest, dev_ctx::sceneNested).  Opened are internal nodes whose two children are
+// internal (an entry's walk starts at a child PAIR).
+// One 1024-thread workgroup, rounds: area of the new entries, block maximum A over the openable ones, every openable entry with area >= A / 2 is opened while the budget lasts (in list
+// order: an ordered scan), the left child takes the parent's place, the right one is appended.  Deterministic; a few dozen rounds.
+// Output: ent[e] = (instance, node); rec = an instance record per ENTRY (k_inst_records' layout: InvModel rows, {node box, NodeOffset / TriangleOffset}, {MeshTransformId, BlasId,
+// child pair, node}); leaf = the entries' padded world boxes in k_tlas_build's leaf layout; *countOut = entries.
+// unified != 0 (k_unify_*, below: every instance has the same InvModel, so one BLAS space holds the whole scene): an entry's box is its BLAS box itself, no image, no padding, no
+// records.
+__global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_braid(const float4* blasNodes, const GpuBlasDesc* descs, const GpuBlasInstance* instances, const float4* xforms, int n0, int budget,
+                                                               uint2* ent /* budget */, float* area /* budget */, float4* rec /* 6 x budget */, float4* leaf /* 2 x budget */, int* countOut,
+                                                               int unified = 0, int* ub = nullptr /* budget: per entry, rows its subtree's walk can need (from BlasDesc.RequiredStackSize, one less per opening) */)
+{
+    __shared__ uint32_t sa[TLAS_BUILD_THREADS], sb[TLAS_BUILD_THREADS];
+    __shared__ float red[TLAS_BUILD_THREADS / 64];
+    const int t = (int)threadIdx.x, T = TLAS_BUILD_THREADS;
+    int count = n0;
+    for (int i = t; i < n0; i += T) { ent[i] = make_uint2((uint32_t)i, 1u); area[i] = -1.0f; if (ub) ub[i] = descs[instances[i].BlasId].RequiredStackSize; }
+    __syncthreads();
+    for (int round = 0; round < 96 && count < budget; round++) {
+        // areas of the entries made by the last round (0 = not openable)
+        float best = 0.0f;
+        for (int e = t; e < count; e += T) {
+            float a = area[e];
+            if (a < 0.0f) {
+                const uint2 en = ent[e];
+                const GpuBlasInstance in = instances[en.x];
+                const float4* nd = blasNodes + 2 * ((size_t)descs[in.BlasId].NodeOffset + en.y);
+                const float4 bmin = nd[0], bmax = nd[1];
+                a = 0.0f;
+                if (__float_as_uint(bmax.w) == 0u) {                                  // internal
+                    const float4* ch = blasNodes + 2 * ((size_t)descs[in.BlasId].NodeOffset + __float_as_uint(bmin.w));
+                    if (__float_as_uint(ch[1].w) == 0u && __float_as_uint(ch[3].w) == 0u) {   // both children internal
+                        float wmn[3] = {bmin.x, bmin.y, bmin.z}, wmx[3] = {bmax.x, bmax.y, bmax.z};
+                        if (!unified) tlas_padded_world_box(xforms + 9 * (size_t)in.MeshTransformId, bmin, bmax, wmn, wmx);
+                        const float h = tlas_half_area(make_float4(wmn[0], wmn[1], wmn[2], 0.0f), make_float4(wmx[0], wmx[1], wmx[2], 0.0f));
+                        a = (h == h && h > 0.0f && h < 3.0e38f) ? h : 0.0f;
+                    }
+                }
+                area[e] = a;
+            }
+            best = tlas_maxN(best, a);
+        }
+        for (int off = 32; off > 0; off >>= 1) best = tlas_maxN(best, __shfl_xor(best, off));
+        if ((t & 63) == 0) red[t >> 6] = best;
+        __syncthreads();
+        float A = 0.0f;
+        for (int w = 0; w < T / 64; w++) A = tlas_maxN(A, red[w]);
+        __syncthreads();
+        if (!(A > 0.0f)) break;
+        const float thresh = A * 0.5f;
+        const int chunk = (count + T - 1) / T, c0 = min(t * chunk, count), c1 = min(c0 + chunk, count);
+        uint32_t nOpen = 0;
+        for (int e = c0; e < c1; e++) nOpen += area[e] >= thresh ? 1u : 0u;
+        uint32_t base, dummy, total, dummyT;
+        block_scan2(nOpen, 0u, sa, sb, base, dummy, total, dummyT);
+        const uint32_t allowed = min(total, (uint32_t)(budget - count));
+        uint32_t rank = base;
+        for (int e = c0; e < c1; e++) {
+            if (!(area[e] >= thresh)) continue;
+            if (rank < allowed) {
+                const uint2 en = ent[e];
+                const uint32_t child = __float_as_uint(blasNodes[2 * ((size_t)descs[instances[en.x].BlasId].NodeOffset + en.y)].w);
+                ent[e] = make_uint2(en.x, child); area[e] = -1.0f;
+                ent[count + rank] = make_uint2(en.x, child + 1u); area[count + rank] = -1.0f;
+                if (ub) { const int u = max(0, ub[e] - 1); ub[e] = u; ub[count + rank] = u; }   // (need(parent) >= 1 + need(child))
+            }
+            rank++;
+        }
+        count += (int)allowed;
+        __syncthreads();
+    }
+    for (int e = t; e < count; e += T) {
+        const uint2 en = ent[e];
+        const GpuBlasInstance in = instances[en.x];
+        const GpuBlasDesc d = descs[in.BlasId];
+        const float4* nd = blasNodes + 2 * ((size_t)d.NodeOffset + en.y);
+        const float4 bmin = nd[0], bmax = nd[1];
+        const float4* x = xforms + 9 * (size_t)in.MeshTransformId;
+        if (unified) {
+            leaf[2 * (size_t)e] = make_float4(bmin.x, bmin.y, bmin.z, __uint_as_float((1u << 31) | (uint32_t)e));
+            leaf[2 * (size_t)e + 1] = make_float4(bmax.x, bmax.y, bmax.z, 0.0f);
+            continue;
+        }
+        float4* o = rec + 6 * (size_t)e;
+        o[0] = x[3]; o[1] = x[4]; o[2] = x[5];
+        o[3] = make_float4(bmin.x, bmin.y, bmin.z, __uint_as_float((uint32_t)d.NodeOffset));
+        o[4] = make_float4(bmax.x, bmax.y, bmax.z, __uint_as_float((uint32_t)d.TriangleOffset));
+        o[5] = make_float4(__uint_as_float((uint32_t)in.MeshTransformId), __uint_as_float((uint32_t)in.BlasId), en.y == 1u ? __uint_as_float(2u) : bmin.w /* the pair a walk entered here starts at: the root's children (k_inst_records), or the child pair of an opened node's internal child */, __uint_as_float(en.y));
+        float wmn[3], wmx[3];
+        tlas_padded_world_box(x, bmin, bmax, wmn, wmx);
+        leaf[2 * (size_t)e] = make_float4(wmn[0], wmn[1], wmn[2], __uint_as_float((1u << 31) | (uint32_t)e));
+        leaf[2 * (size_t)e + 1] = make_float4(wmx[0], wmx[1], wmx[2], 0.0f);
+    }
+    if (t == 0) *countOut = count;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The UNIFIED tree (kernels_trace_inst.hpp, UNI): when every instance of the scene carries the same InvModel — the reference's usual static scene, one BLAS per mesh of a model and
+// one node transform (Bvh/BVH.cs:156) — the loop takes every ray into the same BLAS space, and the instances' BLASes are subtrees of ONE BVH2 in that space.  The derived array:
+//   [0, 2 x cap)            the top: k_tlas_build's PLOC tree over k_braid's entries (their exact BLAS boxes), in GpuBlasNode's layout (root = node 1, its children = the pair at 2;
+//                           TLAS node i -> node i + 1); a leaf slot holds the entry's own BLAS node with its child rebased, so the walk runs through it into the BLAS below;
+//   [2 x cap, + all nodes)  every BLAS's nodes as uploaded, children rebased to this array, leaf ranges to scene-wide triangle indices.
+// Boxes are copied, never recomputed: every test is the loop's test on the loop's box; the top's inner boxes are exact unions (min / max) of the entries' boxes and only order the walk.
+__global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_unify_top(const float4* tlasNodes, const int* countPtr, const uint2* ent, const float4* blasNodes, const GpuBlasDesc* descs,
+                                                                   const GpuBlasInstance* instances, uint32_t baseB, float4* unodes)
+{
+    const int n = *countPtr, nodeCount = 2 * n - 1;
+    for (int i = (int)threadIdx.x; i < nodeCount; i += TLAS_BUILD_THREADS) {
+        const float4 mn = tlasNodes[2 * (size_t)i], mx = tlasNodes[2 * (size_t)i + 1];
+        const uint32_t packed = __float_as_uint(mn.w);
+        float4 o0, o1;
+        if ((packed >> 31) == 1u) {
+            const uint2 en = ent[packed & 0x7fffffffu];
+            const GpuBlasDesc d = descs[instances[en.x].BlasId];
+            const float4 bmin = blasNodes[2 * ((size_t)d.NodeOffset + en.y)], bmax = blasNodes[2 * ((size_t)d.NodeOffset + en.y) + 1];
+            const bool isLeaf = __float_as_uint(bmax.w) != 0u;
+            o0 = make_float4(bmin.x, bmin.y, bmin.z, __uint_as_float(__float_as_uint(bmin.w) + (isLeaf ? (uint32_t)d.TriangleOffset : baseB + (uint32_t)d.NodeOffset)));
+            o1 = bmax;
+        } else {
+            o0 = make_float4(mn.x, mn.y, mn.z, __uint_as_float(packed + 1u));
+            o1 = make_float4(mx.x, mx.y, mx.z, __uint_as_float(0u));
+        }
+        unodes[2 * (size_t)(i + 1)] = o0; unodes[2 * (size_t)(i + 1) + 1] = o1;
+    }
+    if (threadIdx.x == 0) { unodes[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); unodes[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+}
+// (chunk k of 256 nodes belongs to BLAS chunks[k].x and starts at its node chunks[k].y: k_mark_triangles' table)
+__global__ __launch_bounds__(256) void k_unify_blas(const float4* blasNodes, const GpuBlasDesc* descs, const uint2* chunks, uint32_t baseB, float4* unodes)
+{
+    const uint2 ch = chunks[blockIdx.x];
+    const GpuBlasDesc d = descs[ch.x];
+    const uint32_t k = ch.y + threadIdx.x;
+    if (k >= (uint32_t)d.NodeCount) return;
+    const size_t src = (size_t)d.NodeOffset + k;
+    const float4 bmin = blasNodes[2 * src], bmax = blasNodes[2 * src + 1];
+    const bool isLeaf = __float_as_uint(bmax.w) != 0u;
+    unodes[2 * (baseB + src)] = make_float4(bmin.x, bmin.y, bmin.z, __uint_as_float(__float_as_uint(bmin.w) + (isLeaf ? (uint32_t)d.TriangleOffset : baseB + (uint32_t)d.NodeOffset)));
+    unodes[2 * (baseB + src) + 1] = bmax;
 }
 
 // BLAS refit (Shaders/BLASRefit/compute.glsl).  The reference walks leaf->root inside one dispatch behind an

@@ -23,6 +23,12 @@
 //   accepts it, and nothing it meets later has t < T: same TriangleId, T, barycentrics, MeshTransformId, bit for bit.  A ray without any hit met a superset of what the loop
 //   meets.  Not covered, as there: the visit counters (DoDebugBVHTraversal, the counting build), any-hit queries (first found = list order) — those keep the loop.
 //
+// WHERE THE TREE'S LEAVES NEED NOT BE WHOLE INSTANCES (round 6, k_braid in kernels_scene.hpp; profiles/r06_braid.md).  A leaf may stand for a SUBTREE of an instance's BLAS: its record
+// (InstTlasBufs::entRec) carries the node's own BLAS box and the child pair a walk entered there starts at.  The argument above does not care where a BLAS is entered as long as every
+// box above the entry contains it (the loop's tests of those boxes pass whenever the entry's does): the host braids only scenes whose BLAS boxes nest.  Under this kernel's TLAS phase an
+// entry costs a RayTransform, so more entries lose (option inst_braid, default 0).  Under UNI (below) — every instance carries the same InvModel, the whole scene is ONE tree in one
+// BLAS space and an entry is just a node — it is the default for such scenes (option inst_unify): the atrium as 87 BLASes 1 756 -> 3 477 Mray/s.
+//
 // THE FLAGGED RAYS' LOOP (k_trace_inst<P, EXACT = true>).  The exact loop over 87 instances is 87 x three dependent fetches per ray before anything is walked, and a launch of a
 // few thousand flagged rays lasts as long as that chain — which a frame traced alone pays twice.  The EXACT instantiation is the loop itself with one thing hoisted: when a wave
 // takes new rays it runs over the instance records once, wave-uniformly (scalar loads, no dependent chain), and every lane notes in a bit mask (LDS rows) which root boxes its ray
@@ -32,12 +38,19 @@
 #pragma once
 
 struct InstTlasBufs {
-    const float4* tlas;                  // the library's own TLAS (GpuTlasNode layout: root = 0, children adjacent, bit 31 of .w = leaf, the rest = child / instance)
+    const float4* tlas;                  // the library's own TLAS (GpuTlasNode layout: root = 0, children adjacent, bit 31 of .w = leaf, the rest = child / ENTRY)
+    const float4* entRec;                // the records of the tree's leaves, 6 x float4 each in DScene::instRec's layout: the instance records themselves (an entry = a whole instance), or
+                                         // k_braid's (kernels_scene.hpp: an entry = a subtree of an instance's BLAS — its box, and in [5].z the node pair a walk entered through it starts at)
     const uint8_t* marks;                // per BLAS triangle (leaf order, scene-wide index): 1 = not contained in (one of) its leaf box(es)
     int tlasCap;                         // rows of the per-lane TLAS stack
     int maskWords;                       // EXACT: 32-bit words of a lane's instance mask (they use the TLAS rows: the host sizes LDS for the larger of the two)
     uint32_t* flagCount; uint32_t* flagA; uint32_t* flagB;    // this launch's list of flagged rays (kernels_wide.hpp has the same hand-over)
     unsigned long long* totals;          // [0] flagged rays since idkptResetStats
+    // UNI (every instance has the same InvModel: one BLAS space, one tree — k_unify_top / k_unify_blas in kernels_scene.hpp)
+    const float4* unodes;                // the unified node array (GpuBlasNode layout, root = node 1, children and leaf ranges scene-wide)
+    uint32_t uniXformId;                 // a MeshTransformId whose InvModel is the instances' common one (instance 0's)
+    int uniCap;                          // rows of the per-lane stack of this walk (the top's depth on top of the deepest BLAS's)
+    const uint32_t* blasTriStart; const uint32_t* blasXform; int blasCount;   // per BLAS in ascending order of TriangleOffset: that offset, and the MeshTransformId of the one instance that uses it
 };
 
 // marks[t] = 1 for every triangle of a leaf that the leaf's box does not contain.  One thread per BLAS node; chunk k of 256 nodes belongs to BLAS chunks[k].x and starts at
@@ -58,7 +71,10 @@ __global__ __launch_bounds__(256) void k_mark_triangles(const float4* nodes, con
     }
 }
 
-template <bool PRIMARY, bool EXACT = false, int REFILL_MIN = 16>
+// UNI = true (EXACT = false): the same walk without a TLAS phase — every instance has the same InvModel, so a ray is taken into the one BLAS space ONCE, with the loop's own
+// RayTransform, and walks the unified tree (kernels_scene.hpp k_unify_*: a PLOC top over subtrees of the BLASes, then the BLASes' own nodes) with k_trace2's node / leaf phases and the
+// slack culls.  An entry costs nothing: it is a node.  Each BLAS belongs to one instance, so a scene-wide triangle index names its instance (looked up once, when the ray retires).
+template <bool PRIMARY, bool EXACT = false, int REFILL_MIN = 16, bool UNI = false>
 __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, InstTlasBufs ib)
 {
     extern __shared__ uint32_t lds[];
@@ -66,9 +82,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
     // LDS rows as in k_trace2: row 0 = dummy, rows 1 .. cap = BLAS stack, row cap + 1 = spare, then the TLAS rows
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u32* const stkBase = (lds_u32*)lds + lane;
-    const int cap = f.stackCap;
+    static_assert(!(UNI && EXACT), "k_trace_inst: the unified tree is a walk that flags; the exact loop is the loop");
+    const int cap = UNI ? ib.uniCap : f.stackCap;
     lds_u32* const stkFull = stkBase + cap * WAVE;
     uint32_t* const tstk = lds + lane + (cap + 2) * WAVE;
+    const float4* const walkNodes = UNI ? ib.unodes : s.nodes;
+    M34 uniInv; uniInv.r0 = uniInv.r1 = uniInv.r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (UNI) uniInv = load_inv_model_at(s.xforms, ib.uniXformId);          // (wave-uniform: the instances' common InvModel)
     const uint32_t N = *countPtr;
     {
         uint32_t want = gridDim.x;
@@ -98,6 +118,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                 if (done) {
                     const float win = hitT * wide::WINDOW;
                     flagged = !EXACT && (flags != 0u || (hitTri != ~0u && (second <= win || bestLeafT1 > win || ib.marks[hitTri] != 0)));
+                    if (UNI && !flagged && hitTri != ~0u) {          // whose triangle it is: the last BLAS whose triangles start at or before it
+                        int lo = 0, hi = ib.blasCount;
+                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ib.blasTriStart[mid] <= hitTri) lo = mid; else hi = mid; }
+                        hitXform = ib.blasXform[lo];
+                    }
                     if (!flagged) store_hit(hits, slot, hitT, hbx, hby, hitTri, hitXform);
                     if (EXACT && flags != 0u) *s.overflow = 1u;          // (a dropped push: reported like k_trace2's, the upload-time validation makes it unreachable)
                     active = false;
@@ -161,6 +186,15 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                 const bool finite = EXACT || (gabs(c.x) < __builtin_inff() && gabs(c.y) < __builtin_inff() && gabs(c.z) < __builtin_inff());
                 if (!finite) flags = 1u;
                 active = true; leafPending = false; sp = stkBase; top = 0u; tsp = 0; tnode = 0u; moreInst = finite;
+                if (UNI) {
+                    // the loop's entry (BVHIntersect.glsl:281-282), once: every instance's InvModel is this one.  Root tests are skipped (a superset of what the loop enters)
+                    const float4 a = tr.rec[4 * (size_t)idx], b = tr.rec[4 * (size_t)idx + 1];
+                    ro = xform34(uniInv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(uniInv, mk3(b.x, b.y, b.z), 0.0f);
+                    invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    const bool fin = gabs(invDir.x) < __builtin_inff() && gabs(invDir.y) < __builtin_inff() && gabs(invDir.z) < __builtin_inff();
+                    if (!fin) flags |= 1u;
+                    nodeOff = 0u; triOff = 0u; xformId = 0u; moreInst = false; top = (finite && fin) ? 2u : 0u;
+                }
             }
             if (EXACT && __builtin_amdgcn_ballot_w64(fresh) != 0ull) {
                 // which root boxes the new rays meet at all: one wave-uniform pass over the instance records (see the header)
@@ -211,7 +245,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                 }
                 adv = active && !leafPending && top == 0u && moreInst;
             }
-        } else
+        } else if (!UNI)
         // ---- TLAS walk: lanes whose current BLAS is exhausted go on until they reach the next instance they enter, or the end
         {
             bool adv = active && !leafPending && top == 0u && moreInst;
@@ -221,17 +255,17 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                     const float4 pmin = ib.tlas[2 * (size_t)tnode];
                     const uint32_t packed = __float_as_uint(pmin.w), id = packed & 0x7fffffffu;
                     if ((packed >> 31) == 1u) {                                             // an instance: the loop's body (BVHIntersect.glsl:277-286, :32-39)
-                        const float4* ir = s.instRec + 6 * (size_t)id;                      // the instance's record (pt_kernels.hpp DScene::instRec; this walk is only launched with it)
+                        const float4* ir = ib.entRec + 6 * (size_t)id;                      // the entry's record: an instance (pt_kernels.hpp DScene::instRec) or one of its subtrees (k_braid)
                         M34 inv; inv.r0 = ir[0]; inv.r1 = ir[1]; inv.r2 = ir[2];
-                        const float4 rootMin = ir[3], rootMax = ir[4];
-                        nodeOff = __float_as_uint(rootMin.w); triOff = __float_as_uint(rootMax.w); xformId = __float_as_uint(ir[5].x);
+                        const float4 rootMin = ir[3], rootMax = ir[4], ids = ir[5];
+                        nodeOff = __float_as_uint(rootMin.w); triOff = __float_as_uint(rootMax.w); xformId = __float_as_uint(ids.x);
                         float4 a = tr.rec[4 * (size_t)rayIdx], b = tr.rec[4 * (size_t)rayIdx + 1];
                         ro = xform34(inv, mk3(a.x, a.y, a.z), 1.0f); rd = xform34(inv, mk3(b.x, b.y, b.z), 0.0f);
                         invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         float t1;
                         const bool enter = RayBoxIntersect(ro, invDir, rootMin, rootMax, &t1) && t1 <= cullT;
                         const bool finite = gabs(invDir.x) < __builtin_inff() && gabs(invDir.y) < __builtin_inff() && gabs(invDir.z) < __builtin_inff();
-                        sp = stkBase; top = (enter && finite) ? 2u : 0u;
+                        sp = stkBase; top = (enter && finite) ? __float_as_uint(ids.z) : 0u;      // (the root's children, or the children of the subtree's node)
                         if (tsp == 0) moreInst = false; else tnode = tstk[--tsp * WAVE];
                         if (!finite) { flags |= 1u; moreInst = false; }                     // (the exact loop traces this ray: nothing more to do for it here)
                     } else {
@@ -262,7 +296,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
             if (stepMask == 0ull) break;
             if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && leafPending)) >= f.leafMin) break;
             if (canStep) {
-                const float4* p = s.nodes + 2 * ((size_t)nodeOff + top);
+                const float4* p = walkNodes + 2 * ((size_t)nodeOff + top);
                 const uint32_t popped = sp[0];
                 float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
                 const uint32_t lStart = __float_as_uint(lmin.w), lCount = __float_as_uint(lmax.w), rStart = __float_as_uint(rmin.w), rCount = __float_as_uint(rmax.w);

@@ -130,7 +130,7 @@ class Stats(C.Structure):
                 ("NodePairVisits", C.c_uint64), ("TriangleTests", C.c_uint64),
                 ("TraceMsTotal", C.c_double), ("TraceLaunches", C.c_uint64),
                 ("WideFlaggedRays", C.c_uint64), ("WideNodeVisits", C.c_uint64), ("WideLeafRecords", C.c_uint64), ("WideTriangleTests", C.c_uint64), ("InstTlasFlaggedRays", C.c_uint64),
-                ("PacketFlaggedRays", C.c_uint64), ("PacketPackets", C.c_uint64), ("PacketNodeSteps", C.c_uint64), ("PacketLiveLanes", C.c_uint64), ("PacketRaysEntered", C.c_uint64), ("PacketTriangleRounds", C.c_uint64)]
+                ("PacketFlaggedRays", C.c_uint64), ("PacketPackets", C.c_uint64), ("PacketNodeSteps", C.c_uint64), ("PacketLiveLanes", C.c_uint64), ("PacketRaysEntered", C.c_uint64), ("PacketTriangleRounds", C.c_uint64), ("InstUnifiedLaunches", C.c_uint64), ("InstUnifiedEntries", C.c_uint32), ("InstUnifiedTopDepth", C.c_uint32)]
 
 
 def _ptr(a):

@@ -159,6 +159,10 @@ typedef struct idkpt_stats {
     uint64_t PacketLiveLanes;    /* lanes that were live, summed over the node steps: / (64 x PacketNodeSteps) = what the automatic choice looks at */
     uint64_t PacketRaysEntered;  /* rays that entered the BVH inside a packet */
     uint64_t PacketTriangleRounds; /* wave-wide triangle tests (one 48-byte scalar fetch each) */
+    /* the unified tree of same-space multi-instance scenes (developer option "inst_unify", kernels_trace_inst.hpp UNI) */
+    uint64_t InstUnifiedLaunches;  /* traversal launches that walked it, since idkptResetStats (their flagged rays count in InstTlasFlaggedRays) */
+    uint32_t InstUnifiedEntries;   /* subtrees of the BLASes under its top, as last derived (0: not in use) */
+    uint32_t InstUnifiedTopDepth;  /* depth of that top */
 } idkpt_stats;
 /* The layout above only ever GROWS at its end, and IDKPT_ABI_VERSION counts the growths (and every other change a host compiled against an older header could trip over: new
  * enum values of idkpt_buffer, new fields of idkpt_texture).  A host that does not compile against this header (the C# LibraryImport struct of INTEGRATION.md) passes the size
@@ -438,6 +442,11 @@ IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
  *                                    TLAS the library builds for itself; rays whose hit could depend on the loop's order are traced again by the exact loop (idkpt_stats.InstTlasFlaggedRays;
  *                                    csrc/kernels_trace_inst.hpp, profiles/r05_instance_tlas.md).  0 = the loop only.  Not used with the counting build, DoDebugBVHTraversal, scene versions.
  *     "inst_tlas_overlap" 0-100 (10*) ... only while a random line through the scene meets at most this many percent of the instances' boxes (measured on the device at every rebuild)
+ *     "inst_braid"       >= 0 (0*)   ... and the tree's leaves are subtrees of the instances' BLASes (partial re-braiding, k_braid in csrc/kernels_scene.hpp: the entries with the largest boxes are opened into
+ *                                    their node's children until the list has this many entries; scenes whose BLAS boxes nest).  0 = whole instances (measured: more entries lose, profiles/r06_braid.md)
+ *     "inst_unify"       >= 0 (4096*) scenes of >= 2 instances that all carry the same InvModel and use every BLAS at most once (the reference's usual static scene: one BLAS per mesh, Bvh/BVH.cs:156)
+ *                                    walk ONE tree in their common BLAS space — a top over at most this many subtrees of the BLASes, the BLASes' own nodes below (k_unify_*, csrc/kernels_scene.hpp);
+ *                                    the loop's hits, flagged rays traced again by the exact loop as with "inst_tlas".  0 = off.  profiles/r06_braid.md
  *     "inst_sieve"       >= 0 (8*)   k_trace_inst<EXACT>: scenes of at least this many instances (at most 1024) that keep the loop run it with the instances a ray's line cannot meet sieved out when
  *                                    the wave takes the ray — the loop itself, visit for visit (also: the kernel behind the own-TLAS walk's flagged rays, and idkptTraceRays' closest hits).  0 = k_trace2 MODE 1
  *     "inst_sieve_overlap" 0-100 (50*) ... only up to this overlap (as above)

@@ -36,7 +36,7 @@ def run_case(seed, builder, G, O, T, configs, glref_check, draw_case):
     cur = oracle_state(1)
     rep = {"seed": seed, "size": [w, h], "triangles": int(len(sc.blas_triangles)), "settings": ov, "textured": bool(len(sc.textures)), "stages": 0, "rays": 0, "flips": 0, "beyond_tol": 0, "key_diffs": 0, "max_rel": 0.0, "beyond_by_field": {},
            # textured cases, stage by stage from identical inputs INCLUDING the texture coordinate of every tap (A9: the reference's own interpolated uv fed to the checker's stage)
-           "pinned": {"stages": 0, "rays": 0, "taps": 0, "flips": 0, "beyond_tol": 0, "max_rel": 0.0, "uv_max_diff": 0.0}}
+           "pinned": {"stages": 0, "rays": 0, "taps": 0, "flips": 0, "beyond_tol": 0, "beyond_tol_with_a_tap": 0, "max_rel": 0.0, "uv_max_diff": 0.0, "beyond_by_field": {}}}
 
     def add_pinned(stage, ids, ref, rq, depth_now):
         """The same stage with the checker reading the reference's texture coordinates: what is left is shading arithmetic on identical taps.  Also: how far the two
@@ -52,6 +52,15 @@ def run_case(seed, builder, G, O, T, configs, glref_check, draw_case):
         keep = ~np.isin(ids, flips)
         beyond, _eq, worst = glref_check._compare_records(cand_r[ids][keep], ref[keep])
         P["stages"] += 1; P["rays"] += int(len(ids)); P["taps"] += int(both.sum()); P["flips"] += int(len(flips)); P["beyond_tol"] += int(beyond.sum()); P["max_rel"] = max(P["max_rel"], worst)
+        if beyond.any():      # which fields: what a texture feeds directly is Throughput / Radiance (base colour, emission, transmission tint); Origin / PackedDirection beyond the gate is geometry
+            a, b = cand_r[ids][keep], ref[keep]
+            tapped = both[ids][keep]
+            for f in glref_check.FIELDS:
+                e = glref_check.rel_err(np.asarray(a[f], np.float32).reshape(len(a), -1).astype(np.float64), np.asarray(b[f], np.float32).reshape(len(b), -1).astype(np.float64), f)
+                e = np.where(np.isnan(e), np.inf, e)
+                if e.size and e.max() > glref_check.REL_TOL:
+                    P["beyond_by_field"][f] = max(P["beyond_by_field"].get(f, 0.0), float(e.max()))
+            P["beyond_tol_with_a_tap"] += int((beyond & tapped).sum())
 
     def add(ids, cand, ref, cand_q, rq):
         flips = np.setxor1d(cand_q, rq)
@@ -112,7 +121,8 @@ def main():
            "cases_with_a_flip_or_a_value_beyond_tolerance": [r["seed"] for r in reps if r["flips"] or r["beyond_tol"]], "seconds": round(time.time() - t0, 1),
            "textured_cases": sum(1 for r in reps if r["textured"]), "beyond_tol_in_textured_cases": sum(r["beyond_tol"] for r in reps if r["textured"]), "beyond_tol_in_untextured_cases": sum(r["beyond_tol"] for r in reps if not r["textured"]),
            "worst_throughput_or_radiance_error_beyond_tolerance": max([max(r["beyond_by_field"].get("Throughput", 0.0), r["beyond_by_field"].get("Radiance", 0.0)) for r in reps] + [0.0]),
-           "textured_stages_from_identical_taps": {k: (max if k in ("max_rel", "uv_max_diff") else sum)(r["pinned"][k] for r in reps) for k in ("stages", "rays", "taps", "flips", "beyond_tol", "max_rel", "uv_max_diff")},
+           "textured_stages_from_identical_taps": dict({k: (max if k in ("max_rel", "uv_max_diff") else sum)(r["pinned"][k] for r in reps) for k in ("stages", "rays", "taps", "flips", "beyond_tol", "beyond_tol_with_a_tap", "max_rel", "uv_max_diff")},
+                                                       worst_error_beyond_tolerance_by_field={f: max(r["pinned"]["beyond_by_field"].get(f, 0.0) for r in reps) for f in glref_check.FIELDS if any(f in r["pinned"]["beyond_by_field"] for r in reps)}),
            "gate": {"rel_tol": glref_check.REL_TOL, "abs_floor": glref_check.ABS_FLOOR}, "checker_sampler": os.environ.get("FUZZ_SAMPLER") or "gl-spec"}
     print(json.dumps(tot))
     if out:

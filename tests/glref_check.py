@@ -220,6 +220,10 @@ def check_traversal_cost(fx, pairs, tri_tests):
 # So the allowance below is a bound on (texture gradient) x (input difference inside the gate), for the noise textures of the fuzz: textured cases only, at most one ray in
 # 10 000 of a run, at most 3e-3 in throughput / radiance (1 400 seeds: 6.7e-5 of the rays).  The same cases at contrast 0.02 get NO allowance (tests/test_glref.py), nor do
 # untextured cases (the lobe flips of those 1 400 seeds are outside the 60 seeds the gate runs on).
+# Round 6 closed the per-stage question with north_star's own number: the same textured stages with the checker's taps at the texture coordinates the REFERENCE interpolated
+# (glref.py A9 dumps them, ref_pt_set_uv_hooks feeds them in) — identical stage inputs down to the tap — leave NO ray that sampled a texture beyond 1e-4 (1 400 seeds, 1.25 M
+# taps; profiles/r06_reference_fuzz_1400_identical_taps.json; gate: tests/test_glref.py, textured_stages_from_identical_taps).  The allowance below is therefore for the comparison
+# in which each side interpolates its own coordinate (the free-running stage), and for nothing else.
 SAMPLER_SPREAD_ALLOW = {"max_fraction_of_rays": 1e-4, "max_throughput_or_radiance_error": 3e-3, "untextured_rays_beyond": 0, "alive_flips": 0, "key_diffs": 0}
 FULL_ALLOW_FREE = {"full_headline_d2": 8, "full_atrium1m_d2": 9}     # pixels of the free-running two-sample frame beyond tolerance: pixels of the listed closest-hit rays
 

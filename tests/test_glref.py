@@ -212,7 +212,9 @@ def test_live_reference_fuzz_textured_cases_within_the_sampler_spread():
     # free-running comparison (each side's own interpolated coordinate) only
     P = tot["textured_stages_from_identical_taps"]
     assert P["stages"] >= 60 and P["taps"] > 20000, P
-    assert P["beyond_tol"] == 0 and P["flips"] == 0 and P["max_rel"] <= glref_check.REL_TOL, P
+    assert P["beyond_tol"] == 0 and P["beyond_tol_with_a_tap"] == 0 and P["flips"] == 0 and P["max_rel"] <= glref_check.REL_TOL, P
+    # (1 400 seeds, profiles/r06_reference_fuzz_1400_identical_taps.json: 1.25 M taps, 0 rays WITH a tap beyond 1e-4; 11 of 2.1 M rays of those stages beyond it, none of which sampled a
+    #  texture — Origin / PackedDirection of grazing refractions, the untextured cases' rate of 4e-6 — and one lobe flip)
 
 
 @live

@@ -17,8 +17,11 @@ from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _from_two_instances_on(monkeypatch):
+@pytest.fixture(autouse=True, params=[2048, 0, 24], ids=["braid2048", "whole_instances", "braid24"])
+def _from_two_instances_on(monkeypatch, request):
+    # the own TLAS's leaves: subtrees of the instances' BLASes (partial re-braiding, k_braid — the default budget opens these small scenes down to their leaves' parents; 24 entries
+    # stops half way, so entries of very different sizes sit side by side) or whole instances
+    monkeypatch.setenv("IDKPT_INST_BRAID", str(request.param))
     monkeypatch.setenv("IDKPT_INST_TLAS", "2")        # (the default starts at 8 instances ...)
     monkeypatch.setenv("IDKPT_INST_TLAS_OVERLAP", "100")   # (... and asks for little overlap between them: these scenes interleave their BLASes on purpose)
 
@@ -157,4 +160,92 @@ def test_updates_rebuild_the_own_tlas_and_the_marks(native_builder, oracle_mod):
     sc.vertex_positions = pos; pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, pos)
     same()
     assert pt.stats()["inst_tlas_flagged_rays"] > f0
+    pt.Dispose()
+
+
+# ---- the unified tree (developer option "inst_unify"; k_braid / k_unify_* in csrc/kernels_scene.hpp, k_trace_inst<.., UNI>): every instance carries the same InvModel -------------
+def _same_space(native_builder, parts, tris, seed, matrix=None, presplit=False):
+    """`parts` interleaved soups, one BLAS each, all under ONE transform (identity, or `matrix`): the reference's usual static scene — one BLAS per mesh of a model."""
+    blases = []
+    per = tris // parts
+    for k in range(parts):
+        tp = S.soup_triangles(per, seed + 17 * k, 6.0, 0.35)
+        if presplit and k < 2:
+            tp = np.concatenate([tp, np.float32([[[-6, -6, -5.0 + k], [6, -6, -4.8 + k], [0, 6, 5.2 - k]]])])
+        p, i, nrm, tan = S.flat_shaded(tp)
+        blases.append({"meshes": [S.MeshInput(p, i, S.make_material((0.8, 0.75, 0.7, 1.0)), nrm, tan)], "transform": matrix})
+    return S.assemble(blases, native_builder)
+
+
+@pytest.mark.parametrize("parts,tris,depth,sort,lights,budget,shape", [(2, 3000, 4, 1, 0, 4096, "identity"), (9, 9000, 5, 0, 1, 4096, "sheared"), (40, 16000, 3, 1, 0, 64, "sheared"), (87, 30000, 3, 0, 0, 4096, "identity"),
+                                                                           (5, 6000, 4, 0, 0, 2, "presplit")])
+def test_unified_tree_equals_the_loop(native_builder, oracle_mod, monkeypatch, request, parts, tris, depth, sort, lights, budget, shape):
+    """Scenes of several BLASes in one space — identity, and a transform that is neither rigid nor axis-aligned (the ray is taken into the BLAS space once, with the loop's own
+    arithmetic); PreSplit fragments (marked triangles: handed back); budgets from "whole instances only" (2 < instances) to 4 096 subtrees: the loop's image, ray records, alive queue
+    and primary hits, bit for bit, and the launches really walked the unified tree."""
+    if request.node.callspec.params.get("_from_two_instances_on") != 2048:
+        pytest.skip("one run per case: the unified tree does not read inst_braid")
+    monkeypatch.setenv("IDKPT_INST_UNIFY", str(budget))
+    m = None
+    if shape == "sheared":
+        sh = np.eye(4); sh[0, 1] = 0.35; sh[2, 0] = -0.2
+        m = S.rotation_y(33.0) @ np.diag([1.3, 0.8, 1.1, 1.0]) @ sh @ S.translation((0.5, -0.25, 1.0))
+    sc = _same_space(native_builder, parts, tris, 50 + parts, matrix=m, presplit=shape == "presplit")
+    if lights:
+        sc.lights = S.make_lights([((0.0, 3.0, 14.0), 0.8, (9.0, 8.0, 7.0))])
+    w, h = 160, 96; cam = S.Camera(w, h, position=(1.0, 0.5, 19.0))
+    ov = dict(RayDepth=depth, DoRaySorting=sort, DoTraceLights=lights)
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=2, **ov)
+    a = gpu_render(sc, cam, w, h, counters=False, frames=2, **ov)
+    assert_equal(a, o, counters=False)
+    st = a.stats(); a.Dispose(); o.close()
+    assert st["inst_unified_launches"] >= depth and st["inst_unified_entries"] >= parts and st["inst_unified_top_depth"] >= 2, st
+    assert st["inst_tlas_flagged_rays"] < (0.6 if shape == "presplit" else 0.02) * st["rays_traced"], st
+
+
+def test_unified_tree_is_not_used_where_transforms_differ_or_a_blas_is_instanced(native_builder, oracle_mod, monkeypatch, request):
+    if request.node.callspec.params.get("_from_two_instances_on") != 2048:
+        pytest.skip("one run")
+    monkeypatch.setenv("IDKPT_INST_UNIFY", "4096")
+    w, h = 160, 96; cam = S.Camera(w, h, position=(1.0, 0.5, 24.0))
+    sc = S.soup_scene_multi(6000, native_builder, parts=4, seed=9)                         # rotated parts: four InvModels
+    flagged, rays = _check(oracle_mod, sc, cam, w, h, RayDepth=3)
+    from idkengine_amd.pathtracer import PathTracer
+    for scene in (sc, _instanced(native_builder, [np.eye(4), np.eye(4), np.eye(4)], [0, 1, 0])):   # ... and one InvModel, but BLAS 0 twice
+        pt = PathTracer(w, h); pt.UploadScene(scene); pt.SetCamera(cam); pt.RayDepth = 3; pt.Compute(); pt.flush()
+        st = pt.stats(); pt.Dispose()
+        assert st["inst_unified_launches"] == 0 and st["inst_unified_entries"] == 0, st
+
+
+def test_unified_tree_follows_transform_and_vertex_updates(native_builder, oracle_mod, monkeypatch, request):
+    """All transforms moved together (still one space: re-derived, still unified), then one of them alone (no longer one space: the own TLAS / the loop takes over), then vertices moved
+    without a refit (stale boxes: marked triangles): every frame equals the oracle's frame of the scene in that state."""
+    if request.node.callspec.params.get("_from_two_instances_on") != 2048:
+        pytest.skip("one run")
+    from idkengine_amd.pathtracer import PathTracer
+    monkeypatch.setenv("IDKPT_INST_UNIFY", "4096")
+    sc = _same_space(native_builder, 6, 6000, 71); w, h = 160, 96; cam = S.Camera(w, h, position=(1.0, 0.5, 19.0))
+    ov = dict(RayDepth=3)
+    pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); pt.UploadScene(sc); pt.SetCamera(cam)
+    def same():
+        o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+        pt.ResetAccumulation(); pt.Compute()
+        assert (bits(pt.Result) == bits(o.image(0))).all() and pt.rays().tobytes() == o.rays().tobytes()
+        o.close()
+    same(); assert pt.stats()["inst_unified_entries"] >= 6
+    xf = sc.mesh_transforms.copy()
+    for i in range(len(xf)):
+        xf[i] = S.transform_from_matrix(S.rotation_y(40.0) @ S.translation((1.0, 0.5, -1.0)))[0]
+    sc.mesh_transforms = xf; pt.UpdateBuffer(T.IDKPT_BUF_MESH_TRANSFORMS, xf)
+    same(); assert pt.stats()["inst_unified_entries"] >= 6
+    xf = xf.copy(); xf[2] = S.transform_from_matrix(S.rotation_y(-20.0) @ S.translation((-2.0, 0.0, 1.0)))[0]
+    sc.mesh_transforms = xf; pt.UpdateBuffer(T.IDKPT_BUF_MESH_TRANSFORMS, xf)
+    n0 = pt.stats()["inst_unified_launches"]
+    same(); st = pt.stats(); assert st["inst_unified_entries"] == 0 and st["inst_unified_launches"] == n0, st
+    xf = xf.copy(); xf[2] = xf[0]
+    sc.mesh_transforms = xf; pt.UpdateBuffer(T.IDKPT_BUF_MESH_TRANSFORMS, xf)
+    pos = sc.vertex_positions.copy(); pos[::7] += np.float32(0.05)
+    sc.vertex_positions = pos; pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, pos)
+    f0 = pt.stats()["inst_tlas_flagged_rays"]
+    same(); st = pt.stats(); assert st["inst_unified_entries"] >= 6 and st["inst_tlas_flagged_rays"] > f0, st
     pt.Dispose()

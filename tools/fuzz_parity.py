@@ -69,7 +69,11 @@ def random_scene(rng, builder):
         if k > 0 and rng.random() < 0.8:
             sc = np.diag([float(rng.uniform(0.5, 1.6))] * 3 + [1.0])
             tr = S.rotation_y(float(rng.uniform(0, 360))) @ S.translation(tuple(rng.uniform(-0.3 * extent, 0.3 * extent, 3))) @ sc
+        if os.environ.get("FUZZ_SAME_SPACE") and k > 0:     # a soak of the unified tree (k_trace_inst UNI): every BLAS under BLAS 1's transform (rotation, translation, scale — or none)
+            tr = blases[1]["transform"] if k > 1 else tr
         blases.append({"meshes": meshes, "transform": tr, "refittable": bool(rng.random() < 0.3)})
+    if os.environ.get("FUZZ_SAME_SPACE") and nb > 1:
+        blases[0]["transform"] = blases[1]["transform"]
     lights = None
     if rng.random() < 0.4:
         lights = S.make_lights([(tuple(rng.uniform(-0.6 * extent, 0.6 * extent, 3)), float(rng.uniform(0.05, 0.2) * extent), tuple(rng.uniform(0.5, 8.0, 3))) for _ in range(int(rng.integers(1, 4)))])
@@ -108,7 +112,8 @@ def draw_case(seed, builder):
     opts["wide"] = int(rng.choice([0, 1, 1])); opts["wide_cap"] = int(rng.choice([0, 0, 6]))     # the wide-node walk (kernels_wide.hpp) on the one-BLAS cases
     opts["inst_tlas_overlap"] = 100; opts["inst_tlas"] = int(rng.choice([2, 2, 0, 8])); opts["inst_sieve"] = int(rng.choice([0, 2])); opts["inst_sieve_overlap"] = 100; opts["gen_pixel_major"] = int(rng.choice([8, 2, 0])); opts["bounce_pixel_major"] = int(rng.choice([2, 1, 0]))                                            # the instance loop through the library's own TLAS (kernels_trace_inst.hpp) on the several-BLAS cases without UseTlas
     opts["packet"] = int(rng.choice([2, 2, 1, 0])); opts["packet_waves"] = int(rng.choice([0, 0, 1, 5])); opts["packet_min_live"] = int(rng.choice([60, 0, 100]))      # the packet walk of the primary launch (kernels_packet.hpp) on the one-BLAS cases
-    # free choices of the implementation: never visible in the output (split is drawn last: the cases of earlier rounds keep their scenes)
+    opts["inst_unify"] = int(rng.choice([4096, 4096, 3, 40, 0])); opts["inst_braid"] = int(rng.choice([0, 0, 16]))      # the unified tree of same-space scenes, entries under the own TLAS (drawn last: the cases of earlier rounds keep their scenes)
+    # free choices of the implementation: never visible in the output
     return sc, cam, w, h, ov, st, opts, frames, batch, nb
 
 
@@ -134,9 +139,9 @@ def one_case(seed, builder):
     if pt.rays().tobytes() != o.rays().tobytes(): bad.append("ray state")
     if not (pt.alive_queue().shape == o.alive_queue().shape and (pt.alive_queue() == o.alive_queue()).all()): bad.append("queue")
     if pt.stats()["rays_traced"] != o.stats()["rays_traced"]: bad.append("ray count")
-    rays = pt.stats()["rays_traced"]
+    rays = pt.stats()["rays_traced"]; uni = pt.stats()["inst_unified_launches"]
     pt.Dispose()
-    print(f"seed {seed}: {w}x{h} blases {nb} tris {len(sc.blas_triangles)} {ov} {opts} frames {frames} batch {batch} rays {rays}: {'OK' if not bad else 'MISMATCH ' + ', '.join(bad)}", flush=True)
+    print(f"seed {seed}: {w}x{h} blases {nb} tris {len(sc.blas_triangles)} {ov} {opts} frames {frames} batch {batch} rays {rays} unified launches {uni}: {'OK' if not bad else 'MISMATCH ' + ', '.join(bad)}", flush=True)
     return not bad
 
 

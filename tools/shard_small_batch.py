@@ -1,6 +1,6 @@
 """Developer tool (GPU box): what ONE rank of an N-GPU strong-scaling run does — the driver's 20 steps on 1/N of the frame's rows (bands of SHARD_BANDS rows,
 (y // band) % N == r) — timed on one GPU, with the scheduling options that matter for small launches.
-usage: [SHARD_BANDS=1,8] [SHARD_OPTS=grid|none|"k=v,k=v;k=v"] [SHARD_MODS=1,2,4,8] python tools/shard_small_batch.py [N=8] [steps=20]"""
+usage: [SHARD_SCENE=soup|atrium] [SHARD_BANDS=1,8] [SHARD_OPTS=grid|none|"k=v,k=v;k=v"] [SHARD_MODS=1,2,4,8] python tools/shard_small_batch.py [N=8] [steps=20]"""
 import os
 import sys
 import time
@@ -16,7 +16,10 @@ W, H = 1920, 1080
 if __name__ == "__main__" and os.environ.get("SHARD_TWO") != "1":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    sc = S.soup_scene(1000000, NativeBuilder(), seed=1); cam = S.Camera(W, H)
+    if os.environ.get("SHARD_SCENE", "soup") == "atrium":      # the Sponza-class hall (every pixel traverses, chains a third as long): the same projection beside the soup's
+        sc = S.atrium_scene(1000000, NativeBuilder()); cam = S.atrium_camera(W, H)
+    else:
+        sc = S.soup_scene(1000000, NativeBuilder(), seed=1); cam = S.Camera(W, H)
     mods = [int(v) for v in os.environ["SHARD_MODS"].split(",")] if os.environ.get("SHARD_MODS") else [1, N]
     bands = [int(v) for v in os.environ.get("SHARD_BANDS", "8").split(",")]
     for mod, band in [(m, b) for m in mods for b in (bands if m > 1 else bands[:1])]:
