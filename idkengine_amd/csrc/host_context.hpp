@@ -72,6 +72,7 @@ struct DevOptions {
     int instUnify = 4096;        // k_trace_inst<.., UNI>: scenes of >= 2 instances that all carry the SAME InvModel (bit for bit) and use every BLAS at most once — the reference's usual static scene —
                                  // walk ONE tree in their common BLAS space: a PLOC top over this many subtrees of the BLASes at most (k_braid), the BLASes' own nodes below (k_unify_*,
                                  // kernels_scene.hpp); flagged rays go to the exact loop as with the own TLAS.  0 = off.  Measured: profiles/r06_braid.md
+    int instUnifyRadius = 15;    // ... PLOC search radius of that top (TLAS.cs's SearchRadius is 15: the own TLAS keeps the reference's)
     int packet = 1;              // k_trace_packet (kernels_packet.hpp): primary launches of one-BLAS scenes whose work list is pixel-major (batches of >= gen_pixel_major samples) walk the BVH2 as
                                  // packets — one shared walk per wave, node pairs through the scalar cache; rays it cannot vouch for are re-traced by k_trace2.  0 = never, 1 (default) = where the
                                  // kernel's own counters say the wave's rays want the same nodes (packet_decide: live lanes per node step), 2 = every primary launch of a one-BLAS scene

@@ -96,11 +96,11 @@ static int marks_prepare(dev_ctx* ctx)
 }
 
 // ---- the packet walk (kernels_packet.hpp): which primary launches use it ---------------------------------------------------------------------------------------------
-// One BLAS instance, closest hit, one scene version, the reference's counters not asked for, stock kernels; option packet = 1 additionally wants a pixel-major list and the
+// One BLAS instance whose boxes nest (the walk's lenient inner-box test needs it), closest hit, one scene version, the reference's counters not asked for, stock kernels; option packet = 1 additionally wants a pixel-major list and the
 // kernel's own counters in its favour (packet_decide).
 static bool packet_possible(const dev_ctx* ctx)
 {
-    return ctx->opt.packet != 0 && ctx->instanceCount == 1 && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && !ctx->opt.forceGeneric
+    return ctx->opt.packet != 0 && ctx->instanceCount == 1 && ctx->sceneNested && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && !ctx->opt.forceGeneric
            && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);      // (with option "wide" as well: the packet walk takes the primary launch, the wide-node walk the bounces)
 }
 // Called once per batch whose primary launch could be a packet launch (flush_batch): reads what the kernel's counters said so far (host-mapped, written by k_packet_mirror behind every
@@ -199,7 +199,7 @@ static int inst_unify_prepare(dev_ctx* ctx, bool first)
     hipLaunchKernelGGL(k_braid, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, cap,
                        (uint2*)(bb + entOff), (float*)(bb + areaOff), (float4*)nullptr, (float4*)(bb + bleafOff), (int*)(bb + cntOff), 1, (int*)(bb + ubOff));
     BraidOut bo{(const float4*)(bb + bleafOff), (const int*)(bb + cntOff), (const int*)(bb + ubOff)};
-    hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, 15 /* TLAS.cs: SearchRadius */,
+    hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, ctx->opt.instUnifyRadius,
                        ctx->utlas.as<float4>(), (float4*)sc, (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff), 1, ctx->dUni, 0, bo);
     hipLaunchKernelGGL(k_unify_top, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, (const float4*)ctx->utlas.as<float4>(), (const int*)(bb + cntOff), (const uint2*)(bb + entOff), nodes, ctx->descs.as<GpuBlasDesc>(),
                        ctx->instances.as<GpuBlasInstance>(), baseB, ctx->unodes.as<float4>());

@@ -53,6 +53,22 @@ DEV void pk_box(const f3& o, const f3& inv, float mnx, float mny, float mnz, flo
     *t2 = gmin(gx, gmin(gy, gz));
 }
 
+// Both boxes of a pair at once: x / y of each box as above, the z slabs of the LEFT and the RIGHT box through one 2-wide vector each (the pair's two z bounds are not adjacent in
+// the node — two scalar moves make them a register pair; scalar issue has room, vector issue is what binds this walk).  Same operations on the same operands: bit-identical.
+DEV void pk_box2(const f3& o, const f3& inv, const pk_u16v& P, float* t1L, float* t2L, float* t1R, float* t2R)
+{
+    const v2f oxy = {o.x, o.y}, ixy = {inv.x, inv.y}, ozz = {o.z, o.z}, izz = {inv.z, inv.z};
+#define PKF(i) __uint_as_float(P[i])
+    const v2f aL = (v2f{PKF(0), PKF(1)} - oxy) * ixy, bL = (v2f{PKF(4), PKF(5)} - oxy) * ixy;
+    const v2f aR = (v2f{PKF(8), PKF(9)} - oxy) * ixy, bR = (v2f{PKF(12), PKF(13)} - oxy) * ixy;
+    const v2f az = (v2f{PKF(2), PKF(10)} - ozz) * izz, bz = (v2f{PKF(6), PKF(14)} - ozz) * izz;
+#undef PKF
+    *t1L = gmax(gmin(aL.x, bL.x), gmax(gmin(aL.y, bL.y), gmax(gmin(az.x, bz.x), 0.0f)));
+    *t2L = gmin(gmax(aL.x, bL.x), gmin(gmax(aL.y, bL.y), gmax(az.x, bz.x)));
+    *t1R = gmax(gmin(aR.x, bR.x), gmax(gmin(aR.y, bR.y), gmax(gmin(az.y, bz.y), 0.0f)));
+    *t2R = gmin(gmax(aR.x, bR.x), gmin(gmax(aR.y, bR.y), gmax(az.y, bz.y)));
+}
+
 // The walk is written in the MASK domain: which lanes a decision holds for is a wave-uniform 64-bit word (one v_cmp writes it, s_and / s_or combine it, __builtin_amdgcn_inverse_ballot_w64
 // hands it back to a select as its lane mask), never a per-lane bool that the compiler would have to carry through exec-mask regions; everything per lane is a select under full exec.
 #define PK_BALLOT(c) __builtin_amdgcn_ballot_w64(c)
@@ -103,31 +119,33 @@ __global__ __launch_bounds__(WAVE) void k_trace_packet(DScene s, Frame f, RayBuf
         }
         second = hitT; cullT = hitT * wide::CULL;
         const u64 entered = PK_BALLOT(enters);
-        u64 mask = entered;                                     // lanes the current node pair is live for
-        if (STATS) { nPackets++; nEnter += (uint32_t)__builtin_popcountll(mask); }
+        if (STATS) { nPackets++; nEnter += (uint32_t)__builtin_popcountll(entered); }
         // ---- the shared walk
-        uint32_t top = 2u;
+        uint32_t top = 2u, maskLo = (uint32_t)entered, maskHi = (uint32_t)(entered >> 32), ovf = 0u;      // the current node pair, the lanes it is live for; "the stack overflowed"
         int stkNode = 0, stkLo = 0, stkHi = 0, sp = 0;          // lane k of the three registers = stack entry k
-        bool ovf = false;
         const char* const nodeBytes = (const char*)nodes;
-        while (mask != 0ull) {
+        if (entered != 0ull)
+        do {
+            const u64 mask = (u64)maskLo | ((u64)maskHi << 32);
             if (STATS) { nSteps++; nLive += (uint32_t)__builtin_popcountll(mask); }
             const pk_u16v P = *(pk_c16*)(uintptr_t)(nodeBytes + ((size_t)top << 5));          // {lmin.xyz, lStart}, {lmax.xyz, lCount}, {rmin.xyz, rStart}, {rmax.xyz, rCount}
             const uint32_t lStart = P[3], lCount = P[7], rStart = P[11], rCount = P[15];
             float t1L, t2L, t1R, t2R;
-            pk_box(ro, invDir, __uint_as_float(P[0]), __uint_as_float(P[1]), __uint_as_float(P[2]), __uint_as_float(P[4]), __uint_as_float(P[5]), __uint_as_float(P[6]), &t1L, &t2L);
-            pk_box(ro, invDir, __uint_as_float(P[8]), __uint_as_float(P[9]), __uint_as_float(P[10]), __uint_as_float(P[12]), __uint_as_float(P[13]), __uint_as_float(P[14]), &t1R, &t2R);
-            const u64 inL = PK_BALLOT(t1L <= t2L), inR = PK_BALLOT(t1R <= t2R);
-            u64 hL = mask & inL & PK_BALLOT(t1L <= cullT), hR = mask & inR & PK_BALLOT(t1R <= cullT);
-            const u64 nm = mask & ((PK_BALLOT(t1L <= t2L * wide::NEAR_MISS) & ~inL) | (PK_BALLOT(t1R <= t2R * wide::NEAR_MISS) & ~inR));
-            if (nm != 0ull) flags = PK_LANES(nm) ? (flags | 8u) : flags;
+            pk_box2(ro, invDir, P, &t1L, &t2L, &t1R, &t2R);
+            // A child is WANTED while t1 <= min(t2 * NEAR_MISS, T * CULL): one compare per box.  For an inner child that is the box test made lenient by 2^-20 — it enters a superset of
+            // what the exact test enters, which only orders the walk (the BLAS boxes nest — packet_possible asks for it — so a leaf whose exact test passes has every ancestor's exact
+            // test pass: nothing is met that the reference cannot meet) and spares the near-miss bookkeeping: the narrowly failing boxes are simply entered.  A LEAF child is tested
+            // with the exact `t1 <= t2` below, and a lane that wanted it but fails that test by less than 2^-20 is flagged (NEAR_MISS, wide_nodes.hpp).
+            u64 hL = mask & PK_BALLOT(t1L <= gmin(t2L * wide::NEAR_MISS, cullT)), hR = mask & PK_BALLOT(t1R <= gmin(t2R * wide::NEAR_MISS, cullT));
             if ((lCount | rCount) != 0u) {                      // (one test for the common case: both children internal)
                 // leaf children first, left then right (BVHIntersect.glsl:54-79), by the lanes whose box test passed
 #pragma unroll
                 for (int side = 0; side < 2; side++) {
                     const uint32_t cnt = side ? rCount : lCount, first = (side ? rStart : lStart) + triOffset;
-                    const u64 h = side ? hR : hL;
-                    if (cnt == 0u || h == 0ull) continue;
+                    if (cnt == 0u || (side ? hR : hL) == 0ull) continue;
+                    const u64 in = side ? PK_BALLOT(t1R <= t2R) : PK_BALLOT(t1L <= t2L), h = (side ? hR : hL) & in, nm = (side ? hR : hL) & ~in;
+                    if (nm != 0ull) flags = PK_LANES(nm) ? (flags | 8u) : flags;
+                    if (h == 0ull) continue;
                     const float t1 = side ? t1R : t1L;
                     for (uint32_t k = 0; k < cnt; k++) {
                         if (STATS) nRounds++;
@@ -154,31 +172,77 @@ __global__ __launch_bounds__(WAVE) void k_trace_packet(DScene s, Frame f, RayBuf
                 // the descent: internal children only, and only where the lanes' (possibly shrunken) T still wants them
                 hL = lCount == 0u ? (hL & PK_BALLOT(t1L <= cullT)) : 0ull; hR = rCount == 0u ? (hR & PK_BALLOT(t1R <= cullT)) : 0ull;
             }
-            if (hL != 0ull && hR != 0ull) {
-                const u64 nearL = PK_BALLOT(t1L < t1R);
-                const int vL = (int)__builtin_popcountll(hL & (~hR | nearL)), vR = (int)__builtin_popcountll(hR & ~(hL & nearL));
-                const bool lc = vL >= vR;                       // the side more lanes find nearer goes first
-                const u64 farMask = lc ? hR : hL;
-                if (sp >= 64) { ovf = true; break; }
-                const bool at = lane == (uint32_t)sp;           // (this compiler has no v_writelane builtin: one compare + three selects)
-                stkNode = at ? (int)(lc ? rStart : lStart) : stkNode; stkLo = at ? (int)(uint32_t)farMask : stkLo; stkHi = at ? (int)(uint32_t)(farMask >> 32) : stkHi;
-                sp++;
-                top = lc ? lStart : rStart; mask = lc ? hL : hR;
-            } else if ((hL | hR) != 0ull) {
-                top = hL != 0ull ? lStart : rStart; mask = hL | hR;
-            } else {
-                if (sp == 0) break;
-                sp--;
-                top = (uint32_t)__builtin_amdgcn_readlane(stkNode, sp);
-                mask = (u64)(uint32_t)__builtin_amdgcn_readlane(stkLo, sp) | ((u64)(uint32_t)__builtin_amdgcn_readlane(stkHi, sp) << 32);
+            // ---- where to go next.  Hand-written: left to the compiler this three-way decision over 64-bit masks, the push and the pop cost 30-35 scalar instructions of materialised
+            // booleans per step, and the walk is bound by scalar issue (profiles/r06_packet.md: 52 scalar against 44 vector instructions per step, the SIMDs' scalar issue 90 % busy).
+            //   both children wanted: the side more lanes find nearer goes first, the other is pushed with the mask of the lanes that hit it (stack entry sp = lane sp of the three
+            //   registers: v_writelane_b32, the lane through m0); one child: go there; none: pop (v_readlane_b32); nothing to pop, or the stack full (64 entries; ovf = 1): mask = 0.
+            {
+                uint32_t pkA, pkB, pkC; u64 pkT;
+                asm volatile(
+                    "s_cmp_eq_u64 %[hL], 0\n\t"
+                    "s_cbranch_scc1 1f\n\t"
+                    "s_cmp_eq_u64 %[hR], 0\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "v_cmp_lt_f32 vcc, %[t1L], %[t1R]\n\t"            // nearL
+                    "s_orn2_b64 %[tt], vcc, %[hR]\n\t"
+                    "s_and_b64 %[tt], %[tt], %[hL]\n\t"
+                    "s_bcnt1_i32_b64 %[a], %[tt]\n\t"                  // lanes that want the left child first: hL & (~hR | nearL)
+                    "s_and_b64 %[tt], %[hL], vcc\n\t"
+                    "s_andn2_b64 %[tt], %[hR], %[tt]\n\t"
+                    "s_bcnt1_i32_b64 %[b], %[tt]\n\t"                  // ... the right one first: hR & ~(hL & nearL)
+                    "s_cmp_gt_i32 %[sp], 63\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_mov_b32 m0, %[sp]\n\t"
+                    "s_cmp_ge_i32 %[a], %[b]\n\t"                      // scc = left first
+                    "s_cselect_b32 %[top], %[sL], %[sR]\n\t"
+                    "s_cselect_b32 %[mlo], %[hLlo], %[hRlo]\n\t"
+                    "s_cselect_b32 %[mhi], %[hLhi], %[hRhi]\n\t"
+                    "s_cselect_b32 %[a], %[sR], %[sL]\n\t"             // the far child, the lanes that hit it
+                    "s_cselect_b32 %[b], %[hRlo], %[hLlo]\n\t"
+                    "s_cselect_b32 %[c], %[hRhi], %[hLhi]\n\t"
+                    "s_add_i32 %[sp], %[sp], 1\n\t"
+                    "v_writelane_b32 %[kn], %[a], m0\n\t"
+                    "v_writelane_b32 %[kl], %[b], m0\n\t"
+                    "v_writelane_b32 %[kh], %[c], m0\n\t"
+                    "s_branch 9f\n"
+                    "2:\n\t"                                           // left only
+                    "s_mov_b32 %[top], %[sL]\n\t"
+                    "s_mov_b32 %[mlo], %[hLlo]\n\t"
+                    "s_mov_b32 %[mhi], %[hLhi]\n\t"
+                    "s_branch 9f\n"
+                    "1:\n\t"
+                    "s_cmp_eq_u64 %[hR], 0\n\t"
+                    "s_cbranch_scc1 4f\n\t"
+                    "s_mov_b32 %[top], %[sR]\n\t"                     // right only
+                    "s_mov_b32 %[mlo], %[hRlo]\n\t"
+                    "s_mov_b32 %[mhi], %[hRhi]\n\t"
+                    "s_branch 9f\n"
+                    "4:\n\t"                                           // none: pop
+                    "s_cmp_eq_u32 %[sp], 0\n\t"
+                    "s_cbranch_scc1 5f\n\t"
+                    "s_add_i32 %[sp], %[sp], -1\n\t"
+                    "s_nop 0\n\t"
+                    "v_readlane_b32 %[top], %[kn], %[sp]\n\t"
+                    "v_readlane_b32 %[mlo], %[kl], %[sp]\n\t"
+                    "v_readlane_b32 %[mhi], %[kh], %[sp]\n\t"
+                    "s_branch 9f\n"
+                    "3:\n\t"
+                    "s_mov_b32 %[ovf], 1\n"
+                    "5:\n\t"
+                    "s_mov_b32 %[mlo], 0\n\t"
+                    "s_mov_b32 %[mhi], 0\n"
+                    "9:"
+                    : [top] "=&s"(top), [mlo] "=&s"(maskLo), [mhi] "=&s"(maskHi), [sp] "+s"(sp), [ovf] "+s"(ovf), [kn] "+v"(stkNode), [kl] "+v"(stkLo), [kh] "+v"(stkHi), [a] "=&s"(pkA), [b] "=&s"(pkB), [c] "=&s"(pkC), [tt] "=&s"(pkT)
+                    : [hL] "s"(hL), [hR] "s"(hR), [hLlo] "s"((uint32_t)hL), [hLhi] "s"((uint32_t)(hL >> 32)), [hRlo] "s"((uint32_t)hR), [hRhi] "s"((uint32_t)(hR >> 32)), [t1L] "v"(t1L), [t1R] "v"(t1R), [sL] "s"(lStart), [sR] "s"(rStart)
+                    : "vcc", "scc", "m0");
             }
-        }
+        } while ((maskLo | maskHi) != 0u);
         if (hitTri != ~0u) hitXform = inst.MeshTransformId;
         // ---- retire: store the hit, or hand the ray to the exact kernel
         bool flagged = false;
         if (valid) {
             const float win = hitT * wide::WINDOW;
-            flagged = flags != 0u || (ovf && PK_LANES(entered)) || (hitTri != ~0u && (second <= win || leafT1 > win || pb.marks[hitTri] != 0));
+            flagged = flags != 0u || (ovf != 0u && PK_LANES(entered)) || (hitTri != ~0u && (second <= win || leafT1 > win || pb.marks[hitTri] != 0));
             if (!flagged) store_hit(hits, rayIdx, hitT, hbx, hby, hitTri, hitXform);
         }
         const u64 fm = PK_BALLOT(flagged);

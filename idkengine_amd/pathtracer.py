@@ -16,7 +16,7 @@ from ._lib import IdkPtError
 
 # idkptSetDeveloperOption names; IDKPT_<NAME> in the environment is forwarded when a PathTracer is created (test / tuning hooks only)
 _OPTION_NAMES = ("force_generic", "no_tile_cull", "no_lean_primary", "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves", "grid_hint", "grid_rays_x4", "grid_mid_waves", "defer_last", "split", "split_donor", "split_peek", "group_threads", "query_scheduler", "split_scatter", "fused", "fused_shade_min", "leaf_pool", "pool_min", "adv_min",
-                 "wide", "wide_cap", "wide_count", "packet", "packet_min_live", "packet_waves", "inst_tlas", "inst_tlas_overlap", "inst_braid", "inst_unify", "inst_sieve", "inst_sieve_overlap", "gen_pixel_major", "gen_group_max", "bounce_pixel_major", "transport", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
+                 "wide", "wide_cap", "wide_count", "packet", "packet_min_live", "packet_waves", "inst_tlas", "inst_tlas_overlap", "inst_braid", "inst_unify", "inst_unify_radius", "inst_sieve", "inst_sieve_overlap", "gen_pixel_major", "gen_group_max", "bounce_pixel_major", "transport", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
 
 
 class PathTracer:
@@ -195,6 +195,16 @@ class PathTracer:
         """Batched TraceRay / TraceRayAny calls (Shaders/include/BVHIntersect.glsl:183-411) with per-ray maxDist.
         rays: array of gputypes.RayQuery; returns an array of gputypes.RayHit."""
         from . import gputypes as T
+        if hasattr(rays, "data_ptr") and getattr(rays, "is_cuda", False):
+            # rays already resident on this context's device (a torch tensor of count x 32 bytes, any dtype): the device entry point, no PCIe round trip (2 885 vs 252 Mray/s,
+            # profiles/r04_queries.md) — the hits come back as a device tensor (count x 8 float32 words = gputypes.RayHit records), asynchronously in the context's stream order
+            import torch
+            count = rays.numel() * rays.element_size() // T.RayQuery.itemsize
+            hit_bytes = T.RayHit.itemsize
+            hits = torch.empty(count * hit_bytes // 4, dtype=torch.float32, device=rays.device)
+            self.TraceRaysDevice(rays.data_ptr(), hits.data_ptr(), count, any_hit=any_hit, trace_lights=trace_lights)
+            self.synchronize()
+            return hits.view(count, hit_bytes // 4)
         r = np.ascontiguousarray(rays, T.RayQuery)
         out = np.zeros(len(r), T.RayHit)
         flags = (T.IDKPT_TRACE_ANY_HIT if any_hit else 0) | (T.IDKPT_TRACE_LIGHTS if trace_lights else 0)

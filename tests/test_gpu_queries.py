@@ -92,6 +92,9 @@ def test_device_pointer_queries_equal_the_host_pointer_calls(native_builder, ora
         pt.synchronize()
         got = np.frombuffer(d_hits.cpu().numpy().tobytes(), T.RayHit)
         assert got.tobytes() == pt.TraceRays(rays, any_hit=any_hit, trace_lights=True).tobytes() == oracle_mod.trace_rays(sc, rays, any_hit=any_hit, trace_lights=True).tobytes()
+        # the host mirror's TraceRays given a device tensor takes the device entry point by itself and returns a device tensor
+        dev_hits = pt.TraceRays(d_rays, any_hit=any_hit, trace_lights=True)
+        assert dev_hits.is_cuda and dev_hits.cpu().numpy().tobytes() == got.tobytes()
     hits = pt.TraceRays(rays)
     depth, normal = S.gbuffer_from_hits(sc, cam, w, h, rays, hits)
     p = T.ShadowParams.make(cam.inv_proj_view, w, h, light_index=0, samples=3, noise_index=4, jitter=(0.0005, -0.0003))
