@@ -100,7 +100,7 @@ static int marks_prepare(dev_ctx* ctx)
 // kernel's own counters in its favour (packet_decide).
 static bool packet_possible(const dev_ctx* ctx)
 {
-    return ctx->opt.packet != 0 && ctx->instanceCount == 1 && ctx->sceneNested && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && !ctx->opt.forceGeneric
+    return ctx->opt.packet != 0 && (ctx->instanceCount == 1 || (ctx->uniValid && ctx->itlasValid && ctx->itlasBuilt)) && ctx->sceneNested && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && !ctx->opt.forceGeneric
            && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);      // (with option "wide" as well: the packet walk takes the primary launch, the wide-node walk the bounces)
 }
 // Called once per batch whose primary launch could be a packet launch (flush_batch): reads what the kernel's counters said so far (host-mapped, written by k_packet_mirror behind every
@@ -297,6 +297,25 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
 #define T2A(M) hipLaunchKernelGGL((k_trace2<true, false, 32, 1, false, 24, M, 0, false, true>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, counters)
         if (f.useTlas) T2A(2); else if (ctx->instanceCount > 1) T2A(1); else T2A(0);
 #undef T2A
+        return;
+    }
+    if (PRIMARY && bounce == 0 && f.packet && f.instTlas && ctx->uniValid && ctx->itlasValid && ctx->imarksValid && ctx->hPkStats && s.instRec && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid && !ctx->counters) {
+        // the packet walk over the unified tree of a same-space multi-instance scene, then — on the launch's own list of the rays it does not vouch for — the exact loop (sieved)
+        PacketBufs pb;
+        pb.marks = (const uint8_t*)ctx->imarks.as<uint8_t>(); pb.flagCount = work + 128; pb.flagA = ctx->sortKeys.as<uint32_t>(); pb.totals = ctx->wtotals.as<unsigned long long>() + 8;
+        pb.unodes = (const float4*)ctx->unodes.as<float4>(); pb.uniXformId = (uint32_t)ctx->hInstances[0].MeshTransformId; pb.blasCount = (int)ctx->hDescs.size();
+        pb.blasTriStart = (const uint32_t*)ctx->uTabs.as<uint32_t>(); pb.blasXform = pb.blasTriStart + pb.blasCount;
+        const uint32_t pw = (uint32_t)std::min(32, std::max(1, ctx->opt.packetWaves > 0 ? ctx->opt.packetWaves : 28));
+        const uint32_t gp = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->numCUs * pw, (uint32_t)(((size_t)f.batch * ctx->W * ctx->rows + 63) / 64)));
+        ctx->uniLaunches++;
+        hipLaunchKernelGGL((k_trace_packet<true, true>), dim3(gp), dim3(WAVE), 0, st, s, f, rays, tr, hits, list, cnt, work, pb);
+        hipLaunchKernelGGL(k_packet_mirror, dim3(1), dim3(64), 0, st, (const unsigned long long*)pb.totals, ctx->dPkStats);
+        InstTlasBufs ib; memset(&ib, 0, sizeof(ib)); ib.maskWords = (ctx->instanceCount + 31) / 32; ib.totals = ctx->wtotals.as<unsigned long long>() + 4;
+        TraceBufs trf = tr; trf.order = nullptr; trf.orderIdx = nullptr;
+        Frame ff = f; ff.gridRaysX4 = 6u; ff.gridMid = 0u;
+        const uint32_t g2 = std::min<uint32_t>(grid, 2048u);
+        if (ib.maskWords <= inst_tlas_rows(ctx)) hipLaunchKernelGGL((k_trace_inst<true, true>), dim3(g2), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)pb.flagA, (const uint32_t*)pb.flagCount, work + 64, ib);
+        else hipLaunchKernelGGL((k_trace2<true, false, 16, 1, false, 24, 1, 0, false>), dim3(g2), dim3(WAVE), lds, st, s, ff, rays, trf, hits, (const uint32_t*)pb.flagA, (const uint32_t*)pb.flagCount, work + 64, counters);
         return;
     }
     if (PRIMARY && bounce == 0 && f.packet && ctx->imarksValid && ctx->hPkStats && !s.ver && !f.useTlas && !f.queryMode && ctx->instanceCount == 1) {

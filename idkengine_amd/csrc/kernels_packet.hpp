@@ -33,6 +33,8 @@ struct PacketBufs {
     const uint8_t* marks;                // per BLAS triangle (leaf order, scene-wide index): 1 = not contained in its leaf box (k_mark_triangles, kernels_trace_inst.hpp)
     uint32_t* flagCount; uint32_t* flagA;   // this launch's list of flagged rays (ray ids; kernels_wide.hpp has the same hand-over)
     unsigned long long* totals;          // [0] flagged rays since idkptResetStats, [1] packets, [2] node steps, [3] live lanes summed over the node steps, [4] rays that entered, [5] triangle rounds
+    // UNI: the unified tree of a same-space multi-instance scene (kernels_trace_inst.hpp InstTlasBufs, kernels_scene.hpp k_unify_*) instead of instance 0's BLAS
+    const float4* unodes; uint32_t uniXformId; const uint32_t* blasTriStart; const uint32_t* blasXform; int blasCount;
 };
 
 typedef uint32_t pk_u16v __attribute__((ext_vector_type(16)));
@@ -73,15 +75,21 @@ DEV void pk_box2(const f3& o, const f3& inv, const pk_u16v& P, float* t1L, float
 // hands it back to a select as its lane mask), never a per-lane bool that the compiler would have to carry through exec-mask regions; everything per lane is a select under full exec.
 #define PK_BALLOT(c) __builtin_amdgcn_ballot_w64(c)
 #define PK_LANES(m) __builtin_amdgcn_inverse_ballot_w64(m)
-template <bool STATS>
+// UNI: the walk over the unified tree of a scene whose instances all carry the same InvModel (one BVH2 in their common BLAS space: k_trace_inst's header, k_unify_* in kernels_scene.hpp).
+// A ray is taken into that space here, with the instance loop's own RayTransform arithmetic (BVHIntersect.glsl:281-282; its producers left the world ray in the record), every root
+// test is skipped (a superset of what the loop enters), triangle indices are scene-wide and name their instance (looked up when a hit is stored); the rays this walk does not vouch
+// for go to the exact LOOP (k_trace_inst<true, EXACT>), whose hits these are.
+template <bool STATS, bool UNI = false>
 __global__ __launch_bounds__(WAVE) void k_trace_packet(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, PacketBufs pb)
 {
     typedef unsigned long long u64;
     const uint32_t lane = threadIdx.x;
     const uint32_t N = *countPtr;
     const GpuBlasInstance inst = s.instances[0];
-    const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
-    const float4* const nodes = s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset;
+    const uint32_t triOffset = UNI ? 0u : (uint32_t)s.descs[inst.BlasId].TriangleOffset;
+    const float4* const nodes = UNI ? pb.unodes : s.nodes + 2 * (size_t)s.descs[inst.BlasId].NodeOffset;
+    M34 uniInv; uniInv.r0 = uniInv.r1 = uniInv.r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (UNI) uniInv = load_inv_model_at(s.xforms, pb.uniXformId);
     // the work list in packets of 64 entries, dealt over k_trace2's GRAB_SLICES counters (a slice owns runs of 2^grabUnitLog2 >= 64 consecutive entries: a packet never straddles two runs)
     uint32_t slice = blockIdx.x & (GRAB_SLICES - 1u), slicesDone = 0;
     const uint32_t unitLog2 = (uint32_t)f.grabUnitLog2;
@@ -112,7 +120,8 @@ __global__ __launch_bounds__(WAVE) void k_trace_packet(DScene s, Frame f, RayBuf
             }
             const float4 a = tr.rec[4 * (size_t)rayIdx], b = tr.rec[4 * (size_t)rayIdx + 1], c = tr.rec[4 * (size_t)rayIdx + 2];
             ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z);
-            const bool enter = a.w < hitT;                      // root test (:32-39): its arithmetic ran in the kernel that produced the ray (record[0].w = tMin, +inf = miss)
+            if (UNI) { ro = xform34(uniInv, ro, 1.0f); rd = xform34(uniInv, rd, 0.0f); invDir = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z); }
+            const bool enter = UNI || a.w < hitT;               // root test (:32-39): its arithmetic ran in the kernel that produced the ray (record[0].w = tMin, +inf = miss); UNI: no root tests
             const bool finite = gabs(invDir.x) < __builtin_inff() && gabs(invDir.y) < __builtin_inff() && gabs(invDir.z) < __builtin_inff();
             if (enter && !finite) flags = 1u;                   // a slab of this ray can be NaN: the monotonicity argument does not cover it
             enters = enter && finite;
@@ -237,7 +246,14 @@ __global__ __launch_bounds__(WAVE) void k_trace_packet(DScene s, Frame f, RayBuf
                     : "vcc", "scc", "m0");
             }
         } while ((maskLo | maskHi) != 0u);
-        if (hitTri != ~0u) hitXform = inst.MeshTransformId;
+        if (hitTri != ~0u) {
+            hitXform = inst.MeshTransformId;
+            if (UNI) {                                          // whose triangle it is: the last BLAS whose triangles start at or before it
+                int lo = 0, hi = pb.blasCount;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pb.blasTriStart[mid] <= hitTri) lo = mid; else hi = mid; }
+                hitXform = pb.blasXform[lo];
+            }
+        }
         // ---- retire: store the hit, or hand the ray to the exact kernel
         bool flagged = false;
         if (valid) {

@@ -179,13 +179,15 @@ def _same_space(native_builder, parts, tris, seed, matrix=None, presplit=False):
 
 @pytest.mark.parametrize("parts,tris,depth,sort,lights,budget,shape", [(2, 3000, 4, 1, 0, 4096, "identity"), (9, 9000, 5, 0, 1, 4096, "sheared"), (40, 16000, 3, 1, 0, 64, "sheared"), (87, 30000, 3, 0, 0, 4096, "identity"),
                                                                            (5, 6000, 4, 0, 0, 2, "presplit")])
-def test_unified_tree_equals_the_loop(native_builder, oracle_mod, monkeypatch, request, parts, tris, depth, sort, lights, budget, shape):
+@pytest.mark.parametrize("packet", [1, 2], ids=["lane_walk", "packet_walk_forced"])
+def test_unified_tree_equals_the_loop(native_builder, oracle_mod, monkeypatch, request, parts, tris, depth, sort, lights, budget, shape, packet):
     """Scenes of several BLASes in one space — identity, and a transform that is neither rigid nor axis-aligned (the ray is taken into the BLAS space once, with the loop's own
     arithmetic); PreSplit fragments (marked triangles: handed back); budgets from "whole instances only" (2 < instances) to 4 096 subtrees: the loop's image, ray records, alive queue
     and primary hits, bit for bit, and the launches really walked the unified tree."""
     if request.node.callspec.params.get("_from_two_instances_on") != 2048:
         pytest.skip("one run per case: the unified tree does not read inst_braid")
     monkeypatch.setenv("IDKPT_INST_UNIFY", str(budget))
+    monkeypatch.setenv("IDKPT_PACKET", str(packet))          # 2: the primary launch is k_trace_packet<.., UNI> over the same tree (its unvouched rays to the exact loop)
     m = None
     if shape == "sheared":
         sh = np.eye(4); sh[0, 1] = 0.35; sh[2, 0] = -0.2
@@ -200,6 +202,7 @@ def test_unified_tree_equals_the_loop(native_builder, oracle_mod, monkeypatch, r
     assert_equal(a, o, counters=False)
     st = a.stats(); a.Dispose(); o.close()
     assert st["inst_unified_launches"] >= depth and st["inst_unified_entries"] >= parts and st["inst_unified_top_depth"] >= 2, st
+    assert (st["packet_packets"] > 0) == (packet == 2), st
     assert st["inst_tlas_flagged_rays"] < (0.6 if shape == "presplit" else 0.02) * st["rays_traced"], st
 
 
