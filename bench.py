@@ -670,21 +670,23 @@ def atrium_per_mesh_extras(S, NativeBuilder, pt, w, h, B):
     sc = S.atrium_scene(N_TRIS, NativeBuilder(), per_mesh_blas=True)
     out = {"workload": f"procedural atrium, {len(sc.blas_descs)} BLASes (one per mesh), {len(sc.blas_triangles)} BLAS triangles, {w}x{h}, RayDepth {RAY_DEPTH}, camera inside"}
     pt.UploadScene(sc); pt.SetCamera(S.atrium_camera(w, h)); pt.RayDepth = RAY_DEPTH
-    # instance_loop: what a host that has not set UseTlas gets — the loop's hits, computed through the library's own TLAS from 8 instances on where their boxes overlap little
-    # (csrc/kernels_trace_inst.hpp; rays whose result could depend on the loop's order are traced again by the exact loop with its instance sieve); instance_loop_sieved: the
-    # exact loop with the sieve as the main kernel (what scenes of more overlap get); instance_loop_k_trace2: the loop inside k_trace2 (MODE 1: round 4's path, scenes of < 8 instances)
-    for name, tlas, own, sieve in (("instance_loop", 0, 8, 8), ("instance_loop_sieved", 0, 0, 8), ("instance_loop_k_trace2", 0, 0, 0), ("tlas_built_on_device", 1, 8, 8)):
+    # instance_loop: what a host that has not set UseTlas gets — the loop's hits.  The library's defaults: every instance of this scene carries the same transform, so the scene is
+    # walked as ONE tree in the instances' common BLAS space (round 6: k_braid + k_unify_* + k_trace_inst TREE 1, the primary launch as packets over the same tree; rays whose result
+    # could depend on the loop's order are traced again by the exact loop with its instance sieve; profiles/r06_braid.md).  instance_loop_own_tlas: round 5's path, the library's own TLAS
+    # over whole instances (what scenes of different transforms and little overlap get); instance_loop_sieved: the exact loop with the sieve as the main kernel (scenes of more
+    # overlap); instance_loop_k_trace2: the loop inside k_trace2 (MODE 1: round 4's path)
+    for name, tlas, own, sieve, unify in (("instance_loop", 0, 8, 8, 4096), ("instance_loop_own_tlas", 0, 8, 8, 0), ("instance_loop_sieved", 0, 0, 8, 0), ("instance_loop_k_trace2", 0, 0, 0, 0), ("tlas_built_on_device", 1, 8, 8, 4096)):
         if tlas:
             pt.BuildTlasOnDevice()
         pt.UseTlas = tlas
-        pt.set_option("inst_tlas", own); pt.set_option("inst_sieve", sieve)
+        pt.set_option("inst_tlas", own); pt.set_option("inst_sieve", sieve); pt.set_option("inst_unify", unify)
         pt.reset_stats()
         rays, dt = timed_batch(pt, B, B, reps=3)
-        flagged = pt.stats()["inst_tlas_flagged_rays"]; traced = pt.stats()["rays_traced"]
+        st = pt.stats(); flagged = st["inst_tlas_flagged_rays"] + st["packet_flagged_rays"]; traced = st["rays_traced"]
         out[name] = {"mray_s": round(rays / dt / 1e6, 1), "ms_per_step": round(dt / B * 1e3, 4), "single_frame_mray_s": single_frame(pt, RAY_DEPTH, frames=8)["mray_s"]}
         if name == "instance_loop":
-            out[name]["rays_retraced_by_the_exact_loop"] = round(flagged / max(traced, 1), 5)
-    pt.UseTlas = 0; pt.set_option("inst_tlas", 8); pt.set_option("inst_sieve", 8)
+            out[name].update(rays_retraced_by_the_exact_loop=round(flagged / max(traced, 1), 5), unified_tree_entries=st["inst_unified_entries"], unified_tree_top_depth=st["inst_unified_top_depth"])
+    pt.UseTlas = 0; pt.set_option("inst_tlas", 8); pt.set_option("inst_sieve", 8); pt.set_option("inst_unify", 4096)
     return out
 
 

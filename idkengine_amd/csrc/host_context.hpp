@@ -72,6 +72,11 @@ struct DevOptions {
     int instUnify = 4096;        // k_trace_inst<.., UNI>: scenes of >= 2 instances that all carry the SAME InvModel (bit for bit) and use every BLAS at most once — the reference's usual static scene —
                                  // walk ONE tree in their common BLAS space: a PLOC top over this many subtrees of the BLASes at most (k_braid), the BLASes' own nodes below (k_unify_*,
                                  // kernels_scene.hpp); flagged rays go to the exact loop as with the own TLAS.  0 = off.  Measured: profiles/r06_braid.md
+    int instGeneral = 0;         // k_trace_inst<.., TREE 2>: scenes of at least this many instances that are NOT one space (different transforms, or a BLAS used several times) walk the
+                                 // general array — a world-space top over subtrees, entries take the ray into their instance's space (kernels_scene.hpp k_unify_top, general).  0 = off
+                                 // (default).  Measured (profiles/r06_braid.md §5): with whole instances as entries it equals the own TLAS (2 754 vs 2 675 Mray/s on the 3 rotated
+                                 // soups, the loop: 3 628); with subtrees as entries it LOSES (4 096 entries: 2 182 | interior 428 vs 722): the world box of a rotated subtree is loose
+                                 // and every entry met costs a RayTransform, a stub step and a RESTORE step.  The idea pays only where an entry is free: one space (inst_unify)
     int instUnifyRadius = 15;    // ... PLOC search radius of that top (TLAS.cs's SearchRadius is 15: the own TLAS keeps the reference's)
     int packet = 1;              // k_trace_packet (kernels_packet.hpp): primary launches of one-BLAS scenes whose work list is pixel-major (batches of >= gen_pixel_major samples) walk the BVH2 as
                                  // packets — one shared walk per wave, node pairs through the scalar cache; rays it cannot vouch for are re-traced by k_trace2.  0 = never, 1 (default) = where the
@@ -124,7 +129,8 @@ struct dev_ctx {
     // both derived on the device before the first batch that wants them and after everything that moves boxes, positions or transforms
     DevBuf instRec; bool instRecValid = false;            // DScene::instRec (k_inst_records): one scene version only; re-derived with the own TLAS's triggers
     DevBuf itlas, imarks, ichunks; int itlasNeed = 1; uint32_t ichunkCount = 0; bool itlasValid = false, imarksValid = false;
-    DevBuf unodes, utlas, uTabs, uniBuf; bool uniValid = false, uniEligible = false, uniTabsValid = false; int uniCap = 0, uniEntries = 0, uniDepth = 0; float* hUni = nullptr; float* dUni = nullptr;   // the unified tree (k_unify_*): nodes, its PLOC top, the per-BLAS tables; host-mapped: [1] entries, [2] depth of the top
+    int uniMode = 0; uint32_t uniBaseB = 0, uniRestoreIdx = 0;   // uniMode: 1 = the unified tree of a same-space scene (TREE 1), 2 = the general array (TREE 2: world-space top, entries switch spaces)
+    DevBuf unodes, utlas, uTabs, uniBuf, uniEntRec; bool uniValid = false, uniEligible = false, uniTabsValid = false; int uniCap = 0, uniEntries = 0, uniDepth = 0; float* hUni = nullptr; float* dUni = nullptr;   // the unified tree (k_unify_*): nodes, its PLOC top, the per-BLAS tables; host-mapped: [1] entries, [2] depth of the top
     std::vector<GpuBlasInstance> hInstances; std::vector<char> hXforms; uint64_t uniLaunches = 0;   // host copies of the instance list and of the GpuMeshTransforms as last uploaded / patched
     DevBuf entRec, braidBuf; bool itlasBraided = false; int itlasDepth = 0, itlasEntries = 0;   // k_braid's entry records / (entries, areas, leaf boxes, count); the built tree's depth and leaf count as last read from the device (0: not known)
     // the packet walk's decision (host_launch.hpp packet_decide): 0 = probing (packets on, counters awaited), 1 = on, 2 = off; the kernel's counters arrive through host-mapped memory

@@ -100,7 +100,7 @@ static int marks_prepare(dev_ctx* ctx)
 // kernel's own counters in its favour (packet_decide).
 static bool packet_possible(const dev_ctx* ctx)
 {
-    return ctx->opt.packet != 0 && (ctx->instanceCount == 1 || (ctx->uniValid && ctx->itlasValid && ctx->itlasBuilt)) && ctx->sceneNested && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && !ctx->opt.forceGeneric
+    return ctx->opt.packet != 0 && (ctx->instanceCount == 1 || (ctx->uniValid && ctx->uniMode == 1 && ctx->itlasValid && ctx->itlasBuilt)) && ctx->sceneNested && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && !ctx->opt.forceGeneric
            && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);      // (with option "wide" as well: the packet walk takes the primary launch, the wide-node walk the bounces)
 }
 // Called once per batch whose primary launch could be a packet launch (flush_batch): reads what the kernel's counters said so far (host-mapped, written by k_packet_mirror behind every
@@ -156,7 +156,7 @@ static bool inst_unify_wanted(const dev_ctx* ctx)
 }
 static int inst_unify_prepare(dev_ctx* ctx, bool first)
 {
-    ctx->uniValid = false;
+    ctx->uniValid = false; ctx->uniMode = 0;
     if (!inst_unify_wanted(ctx)) return IDKPT_OK;
     const int n = ctx->instanceCount, nb = (int)ctx->hDescs.size();
     hipStream_t st = ctx->stream;
@@ -165,55 +165,65 @@ static int inst_unify_prepare(dev_ctx* ctx, bool first)
         bool ok = (int)ctx->hInstances.size() == n;
         for (int i = 0; i < n && ok; i++) { const int b = (int)ctx->hInstances[i].BlasId; if (b < 0 || b >= nb || user[b] >= 0) ok = false; else user[b] = i; }
         ctx->uniEligible = ok; ctx->uniTabsValid = true;
-        if (!ok) return IDKPT_OK;
-        std::vector<int> order(nb); for (int b = 0; b < nb; b++) order[b] = b;
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return ctx->hDescs[a].TriangleOffset < ctx->hDescs[b].TriangleOffset; });
-        std::vector<uint32_t> tab(2 * (size_t)nb);
-        for (int k = 0; k < nb; k++) { tab[k] = (uint32_t)ctx->hDescs[order[k]].TriangleOffset; tab[nb + k] = user[order[k]] >= 0 ? (uint32_t)ctx->hInstances[user[order[k]]].MeshTransformId : 0u; }
-        HIPC(ctx->uTabs.ensure(tab.size() * 4 + 16));
-        HIPC(hipMemcpyAsync(ctx->uTabs.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st));   // (tab is a stack vector)
-    }
-    if (!ctx->uniEligible) return IDKPT_OK;
-    {   // every instance's InvModel (rows 3-5 of its GpuMeshTransform) is instance 0's, bit for bit?  On the host's copy: transforms only ever arrive through the host
-        const size_t xb = sizeof(GpuMeshTransform);
-        const size_t t0 = (size_t)ctx->hInstances[0].MeshTransformId;
-        if ((t0 + 1) * xb > ctx->hXforms.size()) return IDKPT_OK;
-        for (int i = 1; i < n; i++) {
-            const size_t ti = (size_t)ctx->hInstances[i].MeshTransformId;
-            if ((ti + 1) * xb > ctx->hXforms.size() || memcmp(ctx->hXforms.data() + ti * xb + 48, ctx->hXforms.data() + t0 * xb + 48, 48) != 0) return IDKPT_OK;
+        if (ok) {
+            std::vector<int> order(nb); for (int b = 0; b < nb; b++) order[b] = b;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return ctx->hDescs[a].TriangleOffset < ctx->hDescs[b].TriangleOffset; });
+            std::vector<uint32_t> tab(2 * (size_t)nb);
+            for (int k = 0; k < nb; k++) { tab[k] = (uint32_t)ctx->hDescs[order[k]].TriangleOffset; tab[nb + k] = user[order[k]] >= 0 ? (uint32_t)ctx->hInstances[user[order[k]]].MeshTransformId : 0u; }
+            HIPC(ctx->uTabs.ensure(tab.size() * 4 + 16));
+            HIPC(hipMemcpyAsync(ctx->uTabs.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st)); HIPC(hipStreamSynchronize(st));   // (tab is a stack vector)
         }
     }
+    bool same = ctx->uniEligible && (int)ctx->hInstances.size() == n;
+    if (same) {   // every instance's InvModel (rows 3-5 of its GpuMeshTransform) is instance 0's, bit for bit?  On the host's copy: transforms only ever arrive through the host
+        const size_t xb = sizeof(GpuMeshTransform);
+        const size_t t0 = (size_t)ctx->hInstances[0].MeshTransformId;
+        if ((t0 + 1) * xb > ctx->hXforms.size()) same = false;
+        for (int i = 1; i < n && same; i++) {
+            const size_t ti = (size_t)ctx->hInstances[i].MeshTransformId;
+            if ((ti + 1) * xb > ctx->hXforms.size() || memcmp(ctx->hXforms.data() + ti * xb + 48, ctx->hXforms.data() + t0 * xb + 48, 48) != 0) same = false;
+        }
+    }
+    // one space: the unified tree (TREE 1).  Otherwise — different transforms, or a BLAS instanced several times — the general array (TREE 2, option inst_general): a world-space top
+    // whose entries take the ray into their instance's space
+    const int mode = same ? 1 : (ctx->opt.instGeneral > 0 && n >= ctx->opt.instGeneral ? 2 : 0);
+    if (mode == 0) return IDKPT_OK;
     if (!ctx->hUni) { HIPC(hipHostMalloc((void**)&ctx->hUni, 64, hipHostMallocMapped)); memset(ctx->hUni, 0, 64); HIPC(hipHostGetDevicePointer((void**)&ctx->dUni, ctx->hUni, 0)); }
     { int rc = chunks_ensure(ctx); if (rc) return rc; }
     const float4* nodes = (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]);
     const float4* xf = (const float4*)vb_ptr(ctx, VB_XFORMS, ctx->vcur[VB_XFORMS]);
     const int cap = std::max(n, std::min(ctx->opt.instUnify, 16384)), nodeCount = 2 * cap - 1;
-    const uint32_t baseB = 2u * (uint32_t)cap;
+    // the array: [0, 2 cap) the top; TREE 2: [2 cap, 4 cap) one stub pair per entry, then the RESTORE pair; then every BLAS's nodes
+    const uint32_t stubBase = 2u * (uint32_t)cap, restoreIdx = 4u * (uint32_t)cap, baseB = mode == 2 ? 4u * (uint32_t)cap + 2u : 2u * (uint32_t)cap;
     // k_braid's entries, areas, leaf boxes, count; k_tlas_build's scratch; the PLOC top; the unified nodes
     const size_t entOff = 0, areaOff = entOff + (size_t)cap * 8, bleafOff = (areaOff + (size_t)cap * 4 + 15) & ~(size_t)15, cntOff = bleafOff + (size_t)cap * 32;
     const size_t ubOff = cntOff + 16;
     const size_t scOff = (ubOff + (size_t)cap * 4 + 255) & ~(size_t)255, leafOff = (size_t)nodeCount * 32, keyOff = leafOff + (size_t)cap * 32, prefOff = keyOff + (size_t)cap * 4;
     HIPC(ctx->uniBuf.ensure(scOff + prefOff + (size_t)nodeCount * 4)); HIPC(ctx->utlas.ensure((size_t)nodeCount * 32));      // (its own buffers: the caller's launches on tlasScratch / braidBuf are in flight)
     HIPC(ctx->unodes.ensure(((size_t)baseB + (size_t)ctx->nodeCount) * 32 + 64));
+    if (mode == 2) HIPC(ctx->uniEntRec.ensure((size_t)cap * 96));
     char* bb = ctx->uniBuf.as<char>(); char* sc = bb + scOff;
     hipLaunchKernelGGL(k_braid, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, cap,
-                       (uint2*)(bb + entOff), (float*)(bb + areaOff), (float4*)nullptr, (float4*)(bb + bleafOff), (int*)(bb + cntOff), 1, (int*)(bb + ubOff));
+                       (uint2*)(bb + entOff), (float*)(bb + areaOff), mode == 2 ? ctx->uniEntRec.as<float4>() : (float4*)nullptr, (float4*)(bb + bleafOff), (int*)(bb + cntOff), mode == 1 ? 1 : 0, (int*)(bb + ubOff));
     BraidOut bo{(const float4*)(bb + bleafOff), (const int*)(bb + cntOff), (const int*)(bb + ubOff)};
     hipLaunchKernelGGL(k_tlas_build, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), ctx->instances.as<GpuBlasInstance>(), xf, n, ctx->opt.instUnifyRadius,
                        ctx->utlas.as<float4>(), (float4*)sc, (float4*)(sc + leafOff), (uint32_t*)(sc + keyOff), (int*)(sc + prefOff), 1, ctx->dUni, 0, bo);
     hipLaunchKernelGGL(k_unify_top, dim3(1), dim3(TLAS_BUILD_THREADS), 0, st, (const float4*)ctx->utlas.as<float4>(), (const int*)(bb + cntOff), (const uint2*)(bb + entOff), nodes, ctx->descs.as<GpuBlasDesc>(),
-                       ctx->instances.as<GpuBlasInstance>(), baseB, ctx->unodes.as<float4>());
+                       ctx->instances.as<GpuBlasInstance>(), baseB, ctx->unodes.as<float4>(), mode == 2 ? 1 : 0, stubBase, restoreIdx);
     if (ctx->ichunkCount) hipLaunchKernelGGL(k_unify_blas, dim3(ctx->ichunkCount), dim3(256), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), (const uint2*)ctx->ichunks.as<uint2>(), baseB, ctx->unodes.as<float4>());
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(st));                       // (waited for: the entries and the top's depth size this walk's stack; same-space scenes are static scenes, a re-derivation is rare)
+    HIPC(hipStreamSynchronize(st));                       // (waited for: the entries and the top's depth size this walk's stack; a re-derivation — transforms, refits — is rare on the scenes that use it)
     (void)first;
     const volatile float* h = ctx->hUni;
     ctx->uniEntries = (int)h[1]; ctx->uniDepth = (int)h[2];
     ctx->uniValid = ctx->uniDepth > 0 && ctx->uniEntries >= n;
+    ctx->uniMode = ctx->uniValid ? mode : 0; ctx->uniBaseB = baseB; ctx->uniRestoreIdx = restoreIdx;
     // rows of this walk's stack: what the device derived from the BLASes' RequiredStackSize (validated >= the trees' real need at upload) and the top above them, never more than
-    // "the deepest BLAS under the whole top" (a ray that needs more rows is flagged and traced by the exact loop)
-    const int loose = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack) + std::max(1, ctx->uniDepth);
-    ctx->uniCap = std::min(96, std::max(4, std::min(loose, h[3] > 0.0f ? (int)h[3] + 1 : loose)));
+    // "the deepest BLAS under the whole top" (a ray that needs more rows is flagged and traced by the exact loop).  TREE 2: an entry parks the node the lane was about to visit and the
+    // RESTORE pair under its subtree
+    const int extra = mode == 2 ? 3 : 1;
+    const int loose = std::max(1, ctx->st.BlasStackSize > 0 ? ctx->st.BlasStackSize : ctx->sceneStack) + std::max(1, ctx->uniDepth) + extra;
+    ctx->uniCap = std::min(96, std::max(4, std::min(loose, h[3] > 0.0f ? (int)h[3] + extra : loose)));
     return IDKPT_OK;
 }
 
@@ -299,7 +309,7 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
 #undef T2A
         return;
     }
-    if (PRIMARY && bounce == 0 && f.packet && f.instTlas && ctx->uniValid && ctx->itlasValid && ctx->imarksValid && ctx->hPkStats && s.instRec && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid && !ctx->counters) {
+    if (PRIMARY && bounce == 0 && f.packet && f.instTlas && ctx->uniValid && ctx->uniMode == 1 && ctx->itlasValid && ctx->imarksValid && ctx->hPkStats && s.instRec && !s.ver && !f.useTlas && !f.queryMode && !f.hitsByRid && !ctx->counters) {
         // the packet walk over the unified tree of a same-space multi-instance scene, then — on the launch's own list of the rays it does not vouch for — the exact loop (sieved)
         PacketBufs pb;
         pb.marks = (const uint8_t*)ctx->imarks.as<uint8_t>(); pb.flagCount = work + 128; pb.flagA = ctx->sortKeys.as<uint32_t>(); pb.totals = ctx->wtotals.as<unsigned long long>() + 8;
@@ -362,9 +372,11 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
             ib.unodes = (const float4*)ctx->unodes.as<float4>(); ib.uniCap = ctx->uniCap; ib.blasCount = (int)ctx->hDescs.size();
             ib.blasTriStart = (const uint32_t*)ctx->uTabs.as<uint32_t>(); ib.blasXform = ib.blasTriStart + ib.blasCount;
             ib.uniXformId = (uint32_t)ctx->hInstances[0].MeshTransformId;
-            const size_t ldsU = (size_t)(ctx->uniCap + 2) * WAVE * 4 + (size_t)std::max(0, ctx->opt.ldsPad);
             ctx->uniLaunches++;
-            hipLaunchKernelGGL((k_trace_inst<PRIMARY, false, 16, true>), dim3(grid), dim3(WAVE), ldsU, st, s, f, rays, tr, hits, list, cnt, work, ib);
+            ib.baseB = ctx->uniBaseB; ib.restoreIdx = ctx->uniRestoreIdx; if (ctx->uniMode == 2) ib.entRec = (const float4*)ctx->uniEntRec.as<float4>();
+            const size_t ldsU = (size_t)(ctx->uniCap + 2) * WAVE * 4 + (size_t)std::max(0, ctx->opt.ldsPad);
+            if (ctx->uniMode == 2) hipLaunchKernelGGL((k_trace_inst<PRIMARY, false, 16, 2>), dim3(grid), dim3(WAVE), ldsU, st, s, f, rays, tr, hits, list, cnt, work, ib);
+            else hipLaunchKernelGGL((k_trace_inst<PRIMARY, false, 16, 1>), dim3(grid), dim3(WAVE), ldsU, st, s, f, rays, tr, hits, list, cnt, work, ib);
         } else
         hipLaunchKernelGGL((k_trace_inst<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, ib);
         TraceBufs trf = tr; trf.order = nullptr; trf.orderIdx = nullptr;

@@ -123,7 +123,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* all[] = {&ctx->srgbLut, &ctx->pmList, &ctx->instRec, &ctx->entRec, &ctx->braidBuf, &ctx->unodes, &ctx->utlas, &ctx->uTabs, &ctx->uniBuf, &ctx->itlas, &ctx->imarks, &ctx->ichunks, &ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
+    DevBuf* all[] = {&ctx->srgbLut, &ctx->pmList, &ctx->instRec, &ctx->entRec, &ctx->braidBuf, &ctx->unodes, &ctx->utlas, &ctx->uTabs, &ctx->uniBuf, &ctx->uniEntRec, &ctx->itlas, &ctx->imarks, &ctx->ichunks, &ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
                      &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->bandTab, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};

@@ -360,15 +360,28 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_braid(const float4* blas
 //                           TLAS node i -> node i + 1); a leaf slot holds the entry's own BLAS node with its child rebased, so the walk runs through it into the BLAS below;
 //   [2 x cap, + all nodes)  every BLAS's nodes as uploaded, children rebased to this array, leaf ranges to scene-wide triangle indices.
 // Boxes are copied, never recomputed: every test is the loop's test on the loop's box; the top's inner boxes are exact unions (min / max) of the entries' boxes and only order the walk.
+// general != 0 (kernels_trace_inst.hpp TREE 2: the instances carry DIFFERENT transforms — the top lives in world space, every BLAS in its instance's space): the top's boxes are
+// the entries' padded world boxes (k_braid, unified = 0), and a leaf slot is an inner node over a two-node STUB at stubBase + 2 x entry: {always-hit box (-inf .. +inf), entry id,
+// count = UNIFY_MARK_ENTRY} and a never-hit sibling (NaN bounds: t2 = NaN, `t1 <= t2` false) — the walk's node step parks the lane on it as on a leaf, and its leaf phase, seeing the
+// mark instead of a triangle count, takes the ray into the entry's instance (RayTransform with the entry record's InvModel), pushes the RESTORE pair and continues at the entry's own
+// child pair in the BLAS region.  The RESTORE pair at restoreIdx = the same trick with UNIFY_MARK_RESTORE: popped when the instance's subtree is done, it puts the world ray back.
 __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_unify_top(const float4* tlasNodes, const int* countPtr, const uint2* ent, const float4* blasNodes, const GpuBlasDesc* descs,
-                                                                   const GpuBlasInstance* instances, uint32_t baseB, float4* unodes)
+                                                                   const GpuBlasInstance* instances, uint32_t baseB, float4* unodes, int general = 0, uint32_t stubBase = 0, uint32_t restoreIdx = 0)
 {
     const int n = *countPtr, nodeCount = 2 * n - 1;
+    const float inf = __builtin_inff(), nan = __builtin_nanf("");
     for (int i = (int)threadIdx.x; i < nodeCount; i += TLAS_BUILD_THREADS) {
         const float4 mn = tlasNodes[2 * (size_t)i], mx = tlasNodes[2 * (size_t)i + 1];
         const uint32_t packed = __float_as_uint(mn.w);
         float4 o0, o1;
-        if ((packed >> 31) == 1u) {
+        if ((packed >> 31) == 1u && general) {
+            const uint32_t e = packed & 0x7fffffffu;
+            o0 = make_float4(mn.x, mn.y, mn.z, __uint_as_float(stubBase + 2u * e));
+            o1 = make_float4(mx.x, mx.y, mx.z, __uint_as_float(0u));
+            float4* st = unodes + 2 * (size_t)(stubBase + 2u * e);
+            st[0] = make_float4(-inf, -inf, -inf, __uint_as_float(e)); st[1] = make_float4(inf, inf, inf, __uint_as_float(UNIFY_MARK_ENTRY));
+            st[2] = make_float4(nan, nan, nan, __uint_as_float(0u)); st[3] = make_float4(nan, nan, nan, __uint_as_float(0u));
+        } else if ((packed >> 31) == 1u) {
             const uint2 en = ent[packed & 0x7fffffffu];
             const GpuBlasDesc d = descs[instances[en.x].BlasId];
             const float4 bmin = blasNodes[2 * ((size_t)d.NodeOffset + en.y)], bmax = blasNodes[2 * ((size_t)d.NodeOffset + en.y) + 1];
@@ -381,7 +394,14 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_unify_top(const float4* 
         }
         unodes[2 * (size_t)(i + 1)] = o0; unodes[2 * (size_t)(i + 1) + 1] = o1;
     }
-    if (threadIdx.x == 0) { unodes[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); unodes[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+    if (threadIdx.x == 0) {
+        unodes[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); unodes[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (general) {
+            float4* st = unodes + 2 * (size_t)restoreIdx;
+            st[0] = make_float4(-inf, -inf, -inf, __uint_as_float(0u)); st[1] = make_float4(inf, inf, inf, __uint_as_float(UNIFY_MARK_RESTORE));
+            st[2] = make_float4(nan, nan, nan, __uint_as_float(0u)); st[3] = make_float4(nan, nan, nan, __uint_as_float(0u));
+        }
+    }
 }
 // (chunk k of 256 nodes belongs to BLAS chunks[k].x and starts at its node chunks[k].y: k_mark_triangles' table)
 __global__ __launch_bounds__(256) void k_unify_blas(const float4* blasNodes, const GpuBlasDesc* descs, const uint2* chunks, uint32_t baseB, float4* unodes)

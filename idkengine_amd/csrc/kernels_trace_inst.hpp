@@ -37,6 +37,10 @@
 // exact culls.  Nothing is approximated and nothing flagged: the same instances are entered in the same order with the same T.
 #pragma once
 
+// the general unified array's marked leaves (kernels_scene.hpp k_unify_top, general): a leaf's count word >= these is no triangle count
+#define UNIFY_MARK_ENTRY 0x80000000u
+#define UNIFY_MARK_RESTORE 0xC0000000u
+
 struct InstTlasBufs {
     const float4* tlas;                  // the library's own TLAS (GpuTlasNode layout: root = 0, children adjacent, bit 31 of .w = leaf, the rest = child / ENTRY)
     const float4* entRec;                // the records of the tree's leaves, 6 x float4 each in DScene::instRec's layout: the instance records themselves (an entry = a whole instance), or
@@ -50,6 +54,7 @@ struct InstTlasBufs {
     const float4* unodes;                // the unified node array (GpuBlasNode layout, root = node 1, children and leaf ranges scene-wide)
     uint32_t uniXformId;                 // a MeshTransformId whose InvModel is the instances' common one (instance 0's)
     int uniCap;                          // rows of the per-lane stack of this walk (the top's depth on top of the deepest BLAS's)
+    uint32_t baseB, restoreIdx;          // TREE 2: where the BLAS region of the array starts; the RESTORE pair
     const uint32_t* blasTriStart; const uint32_t* blasXform; int blasCount;   // per BLAS in ascending order of TriangleOffset: that offset, and the MeshTransformId of the one instance that uses it
 };
 
@@ -74,7 +79,12 @@ __global__ __launch_bounds__(256) void k_mark_triangles(const float4* nodes, con
 // UNI = true (EXACT = false): the same walk without a TLAS phase — every instance has the same InvModel, so a ray is taken into the one BLAS space ONCE, with the loop's own
 // RayTransform, and walks the unified tree (kernels_scene.hpp k_unify_*: a PLOC top over subtrees of the BLASes, then the BLASes' own nodes) with k_trace2's node / leaf phases and the
 // slack culls.  An entry costs nothing: it is a node.  Each BLAS belongs to one instance, so a scene-wide triangle index names its instance (looked up once, when the ray retires).
-template <bool PRIMARY, bool EXACT = false, int REFILL_MIN = 16, bool UNI = false>
+// TREE = 2 (EXACT = false): the instances carry DIFFERENT transforms, and the scene is still walked as one array (k_unify_top, general): the top over the entries' padded world
+// boxes is walked with the WORLD ray; an entry is a marked leaf (kernels_scene.hpp UNIFY_MARK_ENTRY) whose "leaf phase" is the loop's entry — RayTransform with the entry record's
+// InvModel, 1 / dir, the entry's own BLAS box with the slack cull — after which the lane saves the node it was about to visit, pushes the RESTORE pair and continues in the entry's
+// BLAS (rebased copy) with the instance-space ray; popping the RESTORE pair (UNIFY_MARK_RESTORE) puts the world ray back.  No TLAS phase, no second stack, one dependent fetch per
+// step everywhere; an entry costs one stub step and the transform.  A BLAS may be used by several instances (MeshTransformId is per lane, as in the own-TLAS walk).
+template <bool PRIMARY, bool EXACT = false, int REFILL_MIN = 16, int TREE = 0 /* 0: the own TLAS + the BLASes; 1: the unified tree of a same-space scene; 2: the general unified array */>
 __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, InstTlasBufs ib)
 {
     extern __shared__ uint32_t lds[];
@@ -82,11 +92,12 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
     // LDS rows as in k_trace2: row 0 = dummy, rows 1 .. cap = BLAS stack, row cap + 1 = spare, then the TLAS rows
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u32* const stkBase = (lds_u32*)lds + lane;
-    static_assert(!(UNI && EXACT), "k_trace_inst: the unified tree is a walk that flags; the exact loop is the loop");
-    const int cap = UNI ? ib.uniCap : f.stackCap;
+    constexpr bool UNI = TREE == 1, GEN = TREE == 2, ONE = TREE != 0;
+    static_assert(!(ONE && EXACT), "k_trace_inst: the unified trees are walks that flag; the exact loop is the loop");
+    const int cap = ONE ? ib.uniCap : f.stackCap;
     lds_u32* const stkFull = stkBase + cap * WAVE;
     uint32_t* const tstk = lds + lane + (cap + 2) * WAVE;
-    const float4* const walkNodes = UNI ? ib.unodes : s.nodes;
+    const float4* const walkNodes = ONE ? ib.unodes : s.nodes;
     M34 uniInv; uniInv.r0 = uniInv.r1 = uniInv.r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (UNI) uniInv = load_inv_model_at(s.xforms, ib.uniXformId);          // (wave-uniform: the instances' common InvModel)
     const uint32_t N = *countPtr;
@@ -186,6 +197,12 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                 const bool finite = EXACT || (gabs(c.x) < __builtin_inff() && gabs(c.y) < __builtin_inff() && gabs(c.z) < __builtin_inff());
                 if (!finite) flags = 1u;
                 active = true; leafPending = false; sp = stkBase; top = 0u; tsp = 0; tnode = 0u; moreInst = finite;
+                if (GEN) {
+                    // the top is walked with the world ray (its 1 / dir was written by the ray's producer: Frame::instTlas); entries switch to their instance's space
+                    const float4 a = tr.rec[4 * (size_t)idx], b = tr.rec[4 * (size_t)idx + 1];
+                    ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z);
+                    nodeOff = 0u; triOff = 0u; xformId = 0u; moreInst = false; top = finite ? 2u : 0u;
+                }
                 if (UNI) {
                     // the loop's entry (BVHIntersect.glsl:281-282), once: every instance's InvModel is this one.  Root tests are skipped (a superset of what the loop enters)
                     const float4 a = tr.rec[4 * (size_t)idx], b = tr.rec[4 * (size_t)idx + 1];
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
                 }
                 adv = active && !leafPending && top == 0u && moreInst;
             }
-        } else if (!UNI)
+        } else if (!ONE)
         // ---- TLAS walk: lanes whose current BLAS is exhausted go on until they reach the next instance they enter, or the end
         {
             bool adv = active && !leafPending && top == 0u && moreInst;
@@ -319,6 +336,37 @@ __global__ __launch_bounds__(WAVE, 1) void k_trace_inst(DScene s, Frame f, RayBu
             }
         }
         // ---- leaf phase
+        if (GEN && leafPending && leafEnd - leafFirst >= UNIFY_MARK_ENTRY) {
+            if (leafEnd - leafFirst >= UNIFY_MARK_RESTORE) {
+                // the instance's subtree is done: back to the world ray (the nodes below this stack entry are the top's)
+                const float4 a = tr.rec[4 * (size_t)rayIdx], b = tr.rec[4 * (size_t)rayIdx + 1], c = tr.rec[4 * (size_t)rayIdx + 2];
+                ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); invDir = mk3(c.x, c.y, c.z);
+            } else {
+                // an entry: the loop's body for its instance (BVHIntersect.glsl:277-286, :32-39 on the entry's own box)
+                const float4* ir = ib.entRec + 6 * (size_t)leafFirst;
+                M34 inv; inv.r0 = ir[0]; inv.r1 = ir[1]; inv.r2 = ir[2];
+                const float4 boxMin = ir[3], boxMax = ir[4], ids = ir[5];
+                const f3 lo = xform34(inv, ro, 1.0f), ld = xform34(inv, rd, 0.0f);                 // (ro / rd hold the world ray here: entries are met from the top only)
+                const f3 li = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+                float t1;
+                const bool enter = RayBoxIntersect(lo, li, boxMin, boxMax, &t1) && t1 <= cullT;
+                const bool fin = gabs(li.x) < __builtin_inff() && gabs(li.y) < __builtin_inff() && gabs(li.z) < __builtin_inff();
+                if (!fin) flags |= 1u;                                                          // (the exact loop traces this ray)
+                if (enter && fin) {
+                    // what the lane was about to visit in the top (its node step already chose it) waits under the RESTORE pair
+                    const bool later = top != 0u || sp != stkBase;
+                    const int need = (top != 0u ? 1 : 0) + (later ? 1 : 0);
+                    if (sp + need * (int)WAVE > stkFull) flags |= 2u;                            // (no room: the exact loop traces this ray)
+                    else {
+                        if (top != 0u) { sp[WAVE] = top; sp += WAVE; }
+                        if (later) { sp[WAVE] = ib.restoreIdx; sp += WAVE; }
+                        ro = lo; rd = ld; invDir = li; xformId = __float_as_uint(ids.x);
+                        top = ib.baseB + __float_as_uint(boxMin.w) + __float_as_uint(ids.z);      // the entry node's child pair, in the BLAS region of the array
+                    }
+                }
+            }
+            leafPending = false;
+        }
         if (leafPending) {
             for (uint32_t i = leafFirst; i < leafEnd; i++) {
                 const float4* tv = s.triVerts + 3 * (size_t)(i + triOff);

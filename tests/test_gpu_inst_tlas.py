@@ -17,11 +17,13 @@ from gpu_helpers import bits, gpu_render, oracle_render, assert_equal  # noqa: E
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2048, 0, 24], ids=["braid2048", "whole_instances", "braid24"])
+@pytest.fixture(autouse=True, params=[2048, 0, 24, -1], ids=["braid2048", "whole_instances", "braid24", "general_array"])
 def _from_two_instances_on(monkeypatch, request):
     # the own TLAS's leaves: subtrees of the instances' BLASes (partial re-braiding, k_braid — the default budget opens these small scenes down to their leaves' parents; 24 entries
-    # stops half way, so entries of very different sizes sit side by side) or whole instances
-    monkeypatch.setenv("IDKPT_INST_BRAID", str(request.param))
+    # stops half way, so entries of very different sizes sit side by side) or whole instances; "general_array": the same scenes through k_trace_inst<.., TREE 2> (one array, a
+    # world-space top whose entries take the ray into their instance's space: option inst_general) instead of the own TLAS
+    monkeypatch.setenv("IDKPT_INST_BRAID", str(max(request.param, 0)))
+    monkeypatch.setenv("IDKPT_INST_GENERAL", "2" if request.param == -1 else "0")
     monkeypatch.setenv("IDKPT_INST_TLAS", "2")        # (the default starts at 8 instances ...)
     monkeypatch.setenv("IDKPT_INST_TLAS_OVERLAP", "100")   # (... and asks for little overlap between them: these scenes interleave their BLASes on purpose)
 
@@ -252,3 +254,16 @@ def test_unified_tree_follows_transform_and_vertex_updates(native_builder, oracl
     f0 = pt.stats()["inst_tlas_flagged_rays"]
     same(); st = pt.stats(); assert st["inst_unified_entries"] >= 6 and st["inst_tlas_flagged_rays"] > f0, st
     pt.Dispose()
+
+
+def test_general_array_is_what_ran(native_builder, oracle_mod, request):
+    """Under the "general_array" parameter the scenes of this file whose instances carry different transforms (or share a BLAS) are walked as ONE array (TREE 2); under the others by
+    the own TLAS: the statistics say which."""
+    w, h = 160, 96; cam = S.Camera(w, h, position=(1.0, 0.5, 24.0))
+    sc = S.soup_scene_multi(6000, native_builder, parts=5, seed=13)
+    o = oracle_render(oracle_mod, sc, cam, w, h, frames=2, RayDepth=4)
+    a = gpu_render(sc, cam, w, h, counters=False, frames=2, RayDepth=4)
+    assert_equal(a, o, counters=False)
+    st = a.stats(); a.Dispose(); o.close()
+    general = request.node.callspec.params.get("_from_two_instances_on") == -1
+    assert (st["inst_unified_launches"] > 0) == general and (st["inst_unified_entries"] >= 5) == general, st

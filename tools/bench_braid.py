@@ -36,15 +36,21 @@ def modes(pt, B):
     for b in BUDGETS:
         pt.set_option("inst_braid", b)
         out["own_tlas_whole_instances" if b == 0 else f"own_tlas_braid_{b}"] = measure(pt, B)
-    pt.set_option("inst_braid", 0)
+    pt.set_option("inst_braid", 0); pt.set_option("inst_general", 0)
     for u in UNIFY:
         pt.set_option("inst_unify", u)
         m = measure(pt, B); st = pt.stats()
         if st["inst_unified_entries"] == 0:
             out["unified"] = "not one space (or a BLAS used twice): the unified tree does not apply"; break
         m.update(entries=st["inst_unified_entries"], top_depth=st["inst_unified_top_depth"]); out[f"unified_{u}"] = m
+    if "unified" in out:      # not one space: the general array (k_trace_inst TREE 2: a world-space top whose entries take the ray into their instance's space)
+        pt.set_option("inst_general", 2)
+        for u in UNIFY:
+            pt.set_option("inst_unify", u)
+            m = measure(pt, B); st = pt.stats()
+            m.update(entries=st["inst_unified_entries"], top_depth=st["inst_unified_top_depth"]); out[f"general_{u}"] = m
     # the library's defaults
-    pt.set_option("inst_unify", 4096); pt.set_option("inst_braid", 0); pt.set_option("inst_tlas", 8); pt.set_option("inst_tlas_overlap", 10); pt.set_option("inst_sieve", 8); pt.set_option("inst_sieve_overlap", 50)
+    pt.set_option("inst_unify", 4096); pt.set_option("inst_general", 0); pt.set_option("inst_braid", 0); pt.set_option("inst_tlas", 8); pt.set_option("inst_tlas_overlap", 10); pt.set_option("inst_sieve", 8); pt.set_option("inst_sieve_overlap", 50)
     out["default"] = measure(pt, B)
     uni = [k for k in out if k.startswith("unified_")]
     if uni:

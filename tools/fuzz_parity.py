@@ -112,7 +112,7 @@ def draw_case(seed, builder):
     opts["wide"] = int(rng.choice([0, 1, 1])); opts["wide_cap"] = int(rng.choice([0, 0, 6]))     # the wide-node walk (kernels_wide.hpp) on the one-BLAS cases
     opts["inst_tlas_overlap"] = 100; opts["inst_tlas"] = int(rng.choice([2, 2, 0, 8])); opts["inst_sieve"] = int(rng.choice([0, 2])); opts["inst_sieve_overlap"] = 100; opts["gen_pixel_major"] = int(rng.choice([8, 2, 0])); opts["bounce_pixel_major"] = int(rng.choice([2, 1, 0]))                                            # the instance loop through the library's own TLAS (kernels_trace_inst.hpp) on the several-BLAS cases without UseTlas
     opts["packet"] = int(rng.choice([2, 2, 1, 0])); opts["packet_waves"] = int(rng.choice([0, 0, 1, 5])); opts["packet_min_live"] = int(rng.choice([60, 0, 100]))      # the packet walk of the primary launch (kernels_packet.hpp) on the one-BLAS cases
-    opts["inst_unify"] = int(rng.choice([4096, 4096, 3, 40, 0])); opts["inst_braid"] = int(rng.choice([0, 0, 16]))      # the unified tree of same-space scenes, entries under the own TLAS (drawn last: the cases of earlier rounds keep their scenes)
+    opts["inst_unify"] = int(rng.choice([4096, 4096, 3, 40, 0])); opts["inst_braid"] = int(rng.choice([0, 0, 16])); opts["inst_general"] = int(rng.choice([2, 2, 0]))      # the unified tree of same-space scenes, entries under the own TLAS (drawn last: the cases of earlier rounds keep their scenes)
     # free choices of the implementation: never visible in the output
     return sc, cam, w, h, ov, st, opts, frames, batch, nb
 
