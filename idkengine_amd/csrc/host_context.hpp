@@ -78,6 +78,8 @@ struct DevOptions {
                                  // soups, the loop: 3 628); with subtrees as entries it LOSES (4 096 entries: 2 182 | interior 428 vs 722): the world box of a rotated subtree is loose
                                  // and every entry met costs a RayTransform, a stub step and a RESTORE step.  The idea pays only where an entry is free: one space (inst_unify)
     int instUnifyRadius = 15;    // ... PLOC search radius of that top (TLAS.cs's SearchRadius is 15: the own TLAS keeps the reference's)
+    int pairNodes = 1;           // k_trace2 FAST: one-BLAS closest-hit launches (one scene version, no counters) step on DScene::pairNodes, the sibling pairs regrouped for 2-wide
+                                 // arithmetic (+ 64 bytes per pair of device memory, re-derived after node updates): 62 -> 53 vector instructions per node step.  0 = the reference's layout
     int packet = 1;              // k_trace_packet (kernels_packet.hpp): primary launches of one-BLAS scenes whose work list is pixel-major (batches of >= gen_pixel_major samples) walk the BVH2 as
                                  // packets — one shared walk per wave, node pairs through the scalar cache; rays it cannot vouch for are re-traced by k_trace2.  0 = never, 1 (default) = where the
                                  // kernel's own counters say the wave's rays want the same nodes (packet_decide: live lanes per node step), 2 = every primary launch of a one-BLAS scene
@@ -127,6 +129,7 @@ struct dev_ctx {
     DevBuf wnodes, wleaf, wids, wpair, wcounts, wtotals; std::vector<uint32_t> wNodeOff, wLeafOff; bool wideTopoValid = false, wideFillValid = false;
     // the library's own TLAS for the instance loop (kernels_trace_inst.hpp): padded PLOC tree over the instances, and the per-triangle "not contained in its leaf box" marks;
     // both derived on the device before the first batch that wants them and after everything that moves boxes, positions or transforms
+    DevBuf pairNodes; bool pairValid = false;             // DScene::pairNodes (k_pair_nodes): re-derived after everything that changes node boxes or topology
     DevBuf instRec; bool instRecValid = false;            // DScene::instRec (k_inst_records): one scene version only; re-derived with the own TLAS's triggers
     DevBuf itlas, imarks, ichunks; int itlasNeed = 1; uint32_t ichunkCount = 0; bool itlasValid = false, imarksValid = false;
     int uniMode = 0; uint32_t uniBaseB = 0, uniRestoreIdx = 0;   // uniMode: 1 = the unified tree of a same-space scene (TREE 1), 2 = the general array (TREE 2: world-space top, entries switch spaces)

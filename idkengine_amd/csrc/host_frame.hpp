@@ -102,6 +102,8 @@ template <class T> static T* vb_cur(dev_ctx* ctx, int b) { return (T*)vb_ptr(ctx
 static void ver_reset(dev_ctx* ctx)
 {
     ctx->wideTopoValid = false; ctx->wideFillValid = false; ctx->itlasValid = false; ctx->instRecValid = false; ctx->imarksValid = false; ctx->ichunkCount = 0; ctx->instOverlapKnown = false; ctx->itlasBuilt = false; ctx->uniValid = false; ctx->uniTabsValid = false;
+    ctx->pairValid = false;
+    ctx->pkState = 0; ctx->pkBatchesSinceProbe = 0;      // (another scene: the packet walk's decision is probed again, packet_decide)
     const size_t one[VB_COUNT] = {(size_t)ctx->nodeCount * 32, (size_t)ctx->triCount * 48, (size_t)ctx->vertexCount * 16,
                                   (size_t)std::max(ctx->tlasCount, 2 * ctx->instanceCount - 1) * 32, (size_t)ctx->xformCount * sizeof(GpuMeshTransform)};
     for (int b = 0; b < VB_COUNT; b++) { ctx->vbytes[b] = one[b]; ctx->vstride[b] = (one[b] + 255) / 256 * 256; ctx->valloc[b] = 1; ctx->vcur[b] = 0; ctx->lastMask[b] = 0; ctx->lastSlots[b] = 0; }
@@ -140,6 +142,7 @@ static int ver_grow(dev_ctx* ctx, int b)
 // `full`: the update rewrites every byte of the buffer's state (nothing to carry over).  May launch queued samples / complete a deferred bounce when no slot is free.
 static int ver_writable(dev_ctx* ctx, int b, bool full, char** src, char** dst)
 {
+    if (b == VB_NODES) ctx->pairValid = false;
     if (b == VB_NODES || b == VB_TRIVERTS) { ctx->wideFillValid = false; ctx->imarksValid = false; }   // (node boxes or triangle positions are about to change: boxes and leaf records of the wide nodes, and the triangle marks, are re-derived before their next use)
     if (b == VB_NODES || b == VB_XFORMS) { ctx->itlasValid = false; ctx->instRecValid = false; }    // (root boxes or transforms are about to change: the library's own TLAS is rebuilt before its next use)
     const int p = ctx->vcur[b];

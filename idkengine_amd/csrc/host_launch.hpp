@@ -95,6 +95,24 @@ static int marks_prepare(dev_ctx* ctx)
     return IDKPT_OK;
 }
 
+// ---- DScene::pairNodes (k_pair_nodes) for k_trace2's FAST node step: one-BLAS scenes, one scene version; stream-ordered in front of the batch that is about to be launched ----------
+static bool pair_nodes_wanted(const dev_ctx* ctx)
+{
+    return ctx->opt.pairNodes != 0 && ctx->instanceCount == 1 && !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && !ctx->opt.forceGeneric
+           && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);
+}
+static int pair_nodes_prepare(dev_ctx* ctx)
+{
+    if (ctx->pairValid || !pair_nodes_wanted(ctx)) return IDKPT_OK;
+    { int rc = chunks_ensure(ctx); if (rc) return rc; }
+    HIPC(ctx->pairNodes.ensure((size_t)std::max(1, ctx->nodeCount) * 32 + 64));
+    if (ctx->ichunkCount) hipLaunchKernelGGL(k_pair_nodes, dim3(ctx->ichunkCount), dim3(256), 0, ctx->stream, (const float4*)vb_ptr(ctx, VB_NODES, ctx->vcur[VB_NODES]), ctx->descs.as<GpuBlasDesc>(),
+                                             (const uint2*)ctx->ichunks.as<uint2>(), ctx->pairNodes.as<float4>());
+    HIPC(hipGetLastError());
+    ctx->pairValid = true;
+    return IDKPT_OK;
+}
+
 // ---- the packet walk (kernels_packet.hpp): which primary launches use it ---------------------------------------------------------------------------------------------
 // One BLAS instance whose boxes nest (the walk's lenient inner-box test needs it), closest hit, one scene version, the reference's counters not asked for, stock kernels; option packet = 1 additionally wants a pixel-major list and the
 // kernel's own counters in its favour (packet_decide).
@@ -444,7 +462,13 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
     }
     if (f.useTlas) { T2N(2, false); return; }                   // TLAS walk inside the kernel
     if (ctx->instanceCount > 1) { T2N(1, false); return; }      // instance loop inside the kernel
-    if (ctx->counters) T2P(true, false); else T2P(false, false);
+    if (ctx->counters) T2P(true, false);
+    else if (s.pairNodes && ctx->pairValid && stock) {   // the FAST node step on the regrouped pairs (one stack row more: kernels_trace.hpp)
+        const size_t ldsF = lds + (size_t)WAVE * 4;
+        if (pool) hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, 16, false, false, true>), dim3(grid), dim3(WAVE), ldsF, st, s, f, rays, tr, hits, list, cnt, work, counters);
+        else hipLaunchKernelGGL((k_trace2<PRIMARY, false, 32, 1, false, 24, 0, 0, false, false, true>), dim3(grid), dim3(WAVE), ldsF, st, s, f, rays, tr, hits, list, cnt, work, counters);
+    }
+    else T2P(false, false);
 #undef T2N
 #undef T2M
 #undef T2P

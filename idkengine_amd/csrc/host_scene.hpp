@@ -123,7 +123,7 @@ static int32_t dev_Destroy(dev_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     ctx->pending.clear();
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* all[] = {&ctx->srgbLut, &ctx->pmList, &ctx->instRec, &ctx->entRec, &ctx->braidBuf, &ctx->unodes, &ctx->utlas, &ctx->uTabs, &ctx->uniBuf, &ctx->uniEntRec, &ctx->itlas, &ctx->imarks, &ctx->ichunks, &ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
+    DevBuf* all[] = {&ctx->srgbLut, &ctx->pmList, &ctx->pairNodes, &ctx->instRec, &ctx->entRec, &ctx->braidBuf, &ctx->unodes, &ctx->utlas, &ctx->uTabs, &ctx->uniBuf, &ctx->uniEntRec, &ctx->itlas, &ctx->imarks, &ctx->ichunks, &ctx->wnodes, &ctx->wleaf, &ctx->wids, &ctx->wpair, &ctx->wcounts, &ctx->wtotals, &ctx->nodes, &ctx->tris, &ctx->triVerts, &ctx->descs, &ctx->instances, &ctx->tlas, &ctx->parents, &ctx->leaves, &ctx->positions, &ctx->prevPositions, &ctx->vertices, &ctx->meshes,
                      &ctx->materials, &ctx->xforms, &ctx->lights, &ctx->sky, &ctx->texDescs, &ctx->unskinned, &ctx->joints, &ctx->levelNodes, &ctx->tlasScratch, &ctx->queryIn, &ctx->queryOut, &ctx->queryRec, &ctx->queryList, &ctx->bandTab, &ctx->tileClass, &ctx->gbases, &ctx->camTab, &ctx->verTab, &ctx->trRec, &ctx->contFlag, &ctx->blockSums, &ctx->rayO, &ctx->rayT, &ctx->rayR, &ctx->aovA, &ctx->aovN, &ctx->hit,
                      &ctx->hitCost, &ctx->primHit, &ctx->queue[0], &ctx->queue[1], &ctx->keys[0], &ctx->keys[1], &ctx->keysTmp, &ctx->sortKeys, &ctx->sortVals, &ctx->contMask, &ctx->waveCounts,
                      &ctx->counts, &ctx->work, &ctx->qwork, &ctx->radSave, &ctx->deferCount, &ctx->sortHist, &ctx->counters64, &ctx->bases, &ctx->img[0], &ctx->img[1], &ctx->img[2]};
@@ -598,7 +598,7 @@ static int32_t dev_UpdateBuffer(dev_ctx* ctx, int32_t which, size_t offsetBytes,
             REQUIRE(why == nullptr, std::string("idkptUpdateBuffer: ") + (why ? why : ""));
             REQUIRE(ctx->st.BlasStackSize == 0 || ctx->st.BlasStackSize >= maxStack, "idkptUpdateBuffer: the patched BLAS needs a deeper traversal stack than the BlasStackSize set with idkptSetSettings");
             HIPC(hipMemcpyAsync(cur + offsetBytes, data, bytes, hipMemcpyHostToDevice, ctx->stream));
-            ctx->sceneStack = maxStack; ctx->wideTopoValid = false; ctx->wideFillValid = false; ctx->itlasValid = false; ctx->instRecValid = false; ctx->imarksValid = false;   // (the tree itself may have changed: the wide nodes, the library's own TLAS and the triangle marks are derived anew)
+            ctx->sceneStack = maxStack; ctx->pairValid = false; ctx->wideTopoValid = false; ctx->wideFillValid = false; ctx->itlasValid = false; ctx->instRecValid = false; ctx->imarksValid = false;   // (the tree itself may have changed: the wide nodes, the library's own TLAS and the triangle marks are derived anew)
             ctx->sceneNested = blas_nested((const GpuBlasNode*)h.data(), ctx->hDescs.data(), (int)ctx->hDescs.size());
         } else {
             const char* why = nullptr;

@@ -12,6 +12,7 @@ static DScene make_dscene(dev_ctx* ctx, const uint8_t* slots, bool multi)
     s.descs = ctx->descs.as<GpuBlasDesc>(); s.instances = ctx->instances.as<GpuBlasInstance>(); s.instanceCount = ctx->instanceCount;
     s.tlas = (const float4*)at(VB_TLAS); s.tlasCount = ctx->tlasCount; s.vertices = (const uint4*)at(VB_VERTICES);
     s.instRec = nullptr;        // (set for the batches that walk the library's own TLAS, flush_batch)
+    s.pairNodes = nullptr;      // (set for the batches whose one-BLAS launches take k_trace2's FAST node step, flush_batch)
     s.meshes = ctx->meshes.as<GpuMesh>(); s.materials = ctx->materials.as<GpuMaterial>(); s.xforms = (const float4*)at(VB_XFORMS);
     s.lights = ctx->lights.as<GpuLight>(); s.lightCount = ctx->lightCount; s.sky = ctx->sky.as<float4>(); s.skySize = ctx->skySize;
     s.textures = ctx->texDescs.as<TexDesc>(); s.textureCount = ctx->textureCount; s.srgbLut = ctx->srgbLut.as<float>();
@@ -201,6 +202,7 @@ static int flush_batch(dev_ctx* ctx)
     f.leafMin = ctx->opt.leafMin > 0 ? ctx->opt.leafMin : (B >= 4 ? 16 : 12);        // (measured: 16-20 with many samples in flight, 12 for a frame traced alone; tools/sweep_sched.py)
     f.instTlas = 0;                                                           // the instance loop through the library's own TLAS (kernels_trace_inst.hpp): decided per batch, the rays' producers look at it too
     if (fast_path(ctx)) { bool useT = false, useS = false; int rc = inst_tlas_prepare(ctx, &useT, &useS); if (rc) { ctx->pending.clear(); return rc; } f.instTlas = useT ? 1 : 0; f.instSieve = useS ? 1 : 0; }
+    if (fast_path(ctx) && !multiVer && pair_nodes_wanted(ctx)) { int rc = pair_nodes_prepare(ctx); if (rc) { ctx->pending.clear(); return rc; } if (ctx->pairValid) s.pairNodes = (const float4*)ctx->pairNodes.as<float4>(); }
     if (f.instSieve) s.instRec = (const float4*)ctx->instRec.as<float4>();
     if (f.instTlas) { s.tlas = (const float4*)ctx->itlas.as<float4>(); s.tlasCount = 2 * ctx->instanceCount - 1; s.instRec = (const float4*)ctx->instRec.as<float4>(); }   // (what the kernels of this batch see as "the TLAS": only the primary rays' pre-cull and k_trace_inst look at it)
     size_t ldsBytes = (size_t)(f.stackCap + 2 + (f.useTlas ? f.tlasCap : ((f.instTlas || f.instSieve) ? inst_tlas_rows(ctx) : 0))) * WAVE * 4;   // + the dummy and the spare row of k_trace2's stack (kernels_trace.hpp)

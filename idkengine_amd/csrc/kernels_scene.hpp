@@ -417,6 +417,22 @@ __global__ __launch_bounds__(256) void k_unify_blas(const float4* blasNodes, con
     unodes[2 * (baseB + src) + 1] = bmax;
 }
 
+// DScene::pairNodes: every sibling pair of every BLAS with its fields regrouped for 2-wide arithmetic (k_trace2 FAST).  Chunk k of 256 nodes belongs to BLAS chunks[k].x and starts
+// at its node chunks[k].y (k_mark_triangles' table); a thread converts the pair that starts at its (even) node.  Plain copies: no arithmetic.
+__global__ __launch_bounds__(256) void k_pair_nodes(const float4* blasNodes, const GpuBlasDesc* descs, const uint2* chunks, float4* out)
+{
+    const uint2 ch = chunks[blockIdx.x];
+    const GpuBlasDesc d = descs[ch.x];
+    const uint32_t k = ch.y + threadIdx.x;
+    if ((k & 1u) != 0u || k + 1u >= (uint32_t)d.NodeCount) return;
+    const size_t at = 2 * ((size_t)d.NodeOffset + k);
+    const float4 lmin = blasNodes[at], lmax = blasNodes[at + 1], rmin = blasNodes[at + 2], rmax = blasNodes[at + 3];
+    out[at] = make_float4(lmin.x, lmin.y, rmin.x, rmin.y);
+    out[at + 1] = make_float4(lmax.x, lmax.y, rmax.x, rmax.y);
+    out[at + 2] = make_float4(lmin.z, rmin.z, lmax.z, rmax.z);
+    out[at + 3] = make_float4(lmin.w, lmax.w, rmin.w, rmax.w);
+}
+
 // BLAS refit (Shaders/BLASRefit/compute.glsl).  The reference walks leaf->root inside one dispatch behind an
 // atomicExchange "second arrival" lock; here the same unions are evaluated level by level (deepest first), one launch
 // per level, so no workgroup ever consumes another workgroup's stores inside a launch (per-XCD L2s are not coherent).

@@ -300,10 +300,15 @@ __global__ __launch_bounds__(1024) void k_gen_primary(DScene s0, Frame f, RayBuf
 // records (MULTI: also its TLAS and transforms) start, in 16-byte units, and adds it to every fetch.  Hit records stay version-independent.
 // ANY: TraceRayAny (BVHIntersect.glsl:107-181, 299-411) for idkptTraceRays' any-hit queries: inside a BLAS the left child is visited first whatever the distances, the first
 // triangle of a leaf with t < T ends the ray (its remaining triangles, its stack, its remaining instances / TLAS nodes are dropped); T is the query's maxDist until then.
-template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0, bool VER = false, bool ANY = false>
+// FAST (MODE 0, closest hit, one scene version, no counters — the launches the bench line prices): the node step on DScene::pairNodes, the same pairs with their fields regrouped so
+// that BOTH boxes' slabs are six 2-wide subtractions and six 2-wide multiplications (the reference's layout allows eight + eight scalar ones); leaf flags derived once; no stack-full
+// test (the stack is sized from the tree's validated need: k_trace2's own comment calls the test unreachable) and no stack-empty test (the row a pop of the empty stack reads holds 0,
+// and the lane is finished then): 62 -> 53 vector instructions per step, every number the same operation on the same operands — bit-identical (tests/test_gpu_parity.py & co.).
+template <bool PRIMARY, bool COUNT, int REFILL_MIN = 32, int OCC = 1, bool PROF = false, int LEAF_MIN = 24, int MODE = 0, int DBG = 0, bool VER = false, bool ANY = false, bool FAST = false>
 __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs rays, TraceBufs tr, HitBufs hits, const uint32_t* list, const uint32_t* countPtr, uint32_t* workCounter, uint64_t* counters)
 {
     static_assert(MODE >= 0 && MODE <= 2 && (DBG == 0 || DBG == 16), "k_trace2: MODE 0-2, DBG 0 or 16 (pooled leaf phase)");
+    static_assert(!FAST || (MODE == 0 && !COUNT && !VER && !ANY && !PROF), "k_trace2: FAST is the plain one-BLAS closest-hit walk");
     constexpr bool MULTI = MODE != 0, TLAS = MODE == 2;
     // DBG 16 ("pooled leaves", MODE 0): the leaf phase tests the wave's (ray, triangle) PAIRS with all 64 lanes in one round trip instead of every parked lane
     // walking its own 1-8 triangles one dependent fetch after the other with 18-22 lanes active (instrumented: 23-48 pairs per leaf phase in 2.0-3.1 loop trips).
@@ -316,7 +321,9 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     // LDS rows of this wave, one word per lane: row 0 = dummy (what a pop of the empty stack reads), rows 1 .. cap = stack entries 0 .. cap-1,
     // row cap + 1 = spare (takes the store of a full stack), then the TLAS rows.  The stack pointer IS an LDS address (stkBase + sp rows).
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    lds_u32* const stkBase = (lds_u32*)lds + lane;
+    // (FAST: one row more in front — row 0 stays the pooled leaf phase's table, row 1 is the dummy and holds 0, so that a pop of the empty stack yields "no node" by itself)
+    lds_u32* const stkBase = (lds_u32*)lds + lane + (FAST ? WAVE : 0);
+    if (FAST) stkBase[0] = 0u;
     const int cap = f.stackCap;
     lds_u32* const stkFull = stkBase + cap * WAVE;
     uint32_t* tstk = lds + lane + (cap + 2) * WAVE;     // TLAS only
@@ -333,6 +340,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
     const int nodeOffset = s.descs[inst.BlasId].NodeOffset;
     const uint32_t triOffset = (uint32_t)s.descs[inst.BlasId].TriangleOffset;
     const float4* nodes = s.nodes + 2 * (size_t)nodeOffset;
+    const float4* const pairBase = FAST ? s.pairNodes + 2 * (size_t)nodeOffset : nullptr;
 
     bool active = false, leafPending = false, workLeft = true;
     // work-list state of this wave (wave-uniform): the slice it grabs from, how many slices it has seen handed out, and the positions
@@ -489,6 +497,33 @@ __global__ __launch_bounds__(WAVE, OCC) void k_trace2(DScene s, Frame f, RayBufs
             if (stepMask == 0ull) break;
             if (LEAF_MIN <= 64 && __builtin_popcountll(__builtin_amdgcn_ballot_w64(active && leafPending)) >= (LEAF_MIN == 24 ? f.leafMin : LEAF_MIN)) break;   // (24 = "the host's choice")
             if (PROF) { pn[2]++; pn[3] += (unsigned long long)__builtin_popcountll(stepMask); }
+            if (FAST) {
+                if (canStep) {
+                    const float4* p = pairBase + 2 * (size_t)top;
+                    const uint32_t popped = sp[0];                      // (0 for an empty stack)
+                    const float4 A = p[0], B = p[1], Z = p[2], D = p[3];
+                    const uint32_t lStart = __float_as_uint(D.x), lCount = __float_as_uint(D.y), rStart = __float_as_uint(D.z), rCount = __float_as_uint(D.w);
+                    // RayBoxIntersect (pt_device.hpp) on both boxes: the same subtractions, multiplications, minima and maxima on the same operands
+                    const v2f oxy = {ro.x, ro.y}, ixy = {invDir.x, invDir.y}, ozz = {ro.z, ro.z}, izz = {invDir.z, invDir.z};
+                    const v2f aL = (v2f{A.x, A.y} - oxy) * ixy, aR = (v2f{A.z, A.w} - oxy) * ixy, bL = (v2f{B.x, B.y} - oxy) * ixy, bR = (v2f{B.z, B.w} - oxy) * ixy;
+                    const v2f az = (v2f{Z.x, Z.y} - ozz) * izz, bz = (v2f{Z.z, Z.w} - ozz) * izz;
+                    const float tMinLeft = gmax(gmin(aL.x, bL.x), gmax(gmin(aL.y, bL.y), gmax(gmin(az.x, bz.x), 0.0f))), tMaxLeft = gmin(gmax(aL.x, bL.x), gmin(gmax(aL.y, bL.y), gmax(az.x, bz.x)));
+                    const float tMinRight = gmax(gmin(aR.x, bR.x), gmax(gmin(aR.y, bR.y), gmax(gmin(az.y, bz.y), 0.0f))), tMaxRight = gmin(gmax(aR.x, bR.x), gmin(gmax(aR.y, bR.y), gmax(az.y, bz.y)));
+                    const bool hitLeft = tMinLeft <= tMaxLeft && tMinLeft <= hitT, hitRight = tMinRight <= tMaxRight && tMinRight <= hitT;
+                    const bool leafL = lCount != 0u, leafR = rCount != 0u;
+                    // ("inner" = not "leaf" through the lane mask — one compare per child; written as `lCount == 0` the compiler issues a second one)
+                    const bool innerL = __builtin_amdgcn_inverse_ballot_w64(~__builtin_amdgcn_ballot_w64(leafL)), innerR = __builtin_amdgcn_inverse_ballot_w64(~__builtin_amdgcn_ballot_w64(leafR));
+                    const bool intersectLeft = hitLeft && leafL, intersectRight = hitRight && leafR;
+                    leafFirst = intersectLeft ? lStart : rStart; leafEnd = !intersectRight ? lStart + lCount : rStart + rCount; leafPending = intersectLeft || intersectRight;
+                    const bool traverseLeft = hitLeft && innerL, traverseRight = hitRight && innerR;
+                    const bool both = traverseLeft && traverseRight, none = !(traverseLeft || traverseRight);
+                    const bool leftCloser = tMinLeft < tMinRight;
+                    const uint32_t nearChild = both ? (leftCloser ? lStart : rStart) : (traverseLeft ? lStart : rStart);
+                    sp[WAVE] = leftCloser ? rStart : lStart;
+                    top = none ? popped : nearChild;
+                    sp += both ? (int)WAVE : (none ? -(int)WAVE : 0);      // (a pop of the empty stack leaves sp one row low: the lane is finished, its next ray resets it)
+                }
+            } else
             if (canStep) {
                 if (COUNT) nPairs++;
                 const float4* p = (MULTI ? s.nodes + 2 * ((size_t)nodeOff + top) : nodes + 2 * (size_t)top) + (VER ? vNode : 0u);

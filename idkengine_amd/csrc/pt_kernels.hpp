@@ -17,6 +17,8 @@ struct TexDesc { const void* data; int w, h; uint32_t state; uint32_t pad; };
 
 struct DScene {
     const float4* nodes;        // 2 x float4 per GpuBlasNode: {Min.xyz, TriStartOrChild}, {Max.xyz, TriCount}
+    const float4* pairNodes;    // derived (k_pair_nodes, kernels_scene.hpp), or null: the same sibling pairs, 64 bytes each at the same index, fields regrouped for 2-wide arithmetic —
+                                // {lmin.xy, rmin.xy}, {lmax.xy, rmax.xy}, {lmin.z, rmin.z, lmax.z, rmax.z}, {lStart, lCount, rStart, rCount}: k_trace2's FAST node step (kernels_trace.hpp)
     const uint4* tris;          // GpuBlasTriangle
     const float4* triVerts;     // derived: 3 x float4 per BLAS triangle (leaf order): positions of X,Y,Z (w unused)
     const GpuBlasDesc* descs;

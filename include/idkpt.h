@@ -447,6 +447,8 @@ IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
  *     "inst_unify"       >= 0 (4096*) scenes of >= 2 instances that all carry the same InvModel and use every BLAS at most once (the reference's usual static scene: one BLAS per mesh, Bvh/BVH.cs:156)
  *                                    walk ONE tree in their common BLAS space — a top over at most this many subtrees of the BLASes, the BLASes' own nodes below (k_unify_*, csrc/kernels_scene.hpp);
  *                                    the loop's hits, flagged rays traced again by the exact loop as with "inst_tlas".  0 = off.  profiles/r06_braid.md
+ *     "pair_nodes"       0 / 1*      k_trace2 FAST: one-BLAS closest-hit launches step on a derived copy of the node pairs whose fields are regrouped for 2-wide arithmetic (64 bytes per pair more
+ *                                    device memory): 53 instead of 62 vector instructions per node step, bit-identical
  *     "inst_general"     >= 0 (0*)   scenes of at least this many instances that are NOT one space walk one array too (k_trace_inst TREE 2: a world-space top whose entries take the ray into their
  *                                    instance's space).  Measured: equal to the own TLAS with whole instances, slower with subtrees (loose world boxes, a RayTransform per entry): off
  *     "inst_unify_radius" 1-512 (15*) PLOC search radius of the unified tree's top (larger radii measured 2-30 % slower)

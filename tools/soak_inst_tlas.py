@@ -1,4 +1,4 @@
-"""Round 5 soak: the instance loop through the library's own TLAS / with the instance sieve against the loop inside k_trace2, GPU against GPU at full size — the frame, the whole ray
+"""Round 5 / 6 soak: the instance loop through the library's own TLAS / with the instance sieve / through the unified trees (round 6) against the loop inside k_trace2, GPU against GPU at full size — the frame, the whole ray
 state, the alive queue and the primary hits of every sample must be equal bit for bit.  Scenes: the atrium as 87 BLASes (connected surfaces, PreSplit fragments), 64 clusters, an
 instanced scene with tied copies.  Prints rays compared / rays traced again / mismatching samples."""
 import json, os, sys
@@ -58,11 +58,21 @@ def main():
         pt = PathTracer(W, H); pt.UploadScene(sc); pt.SetCamera(cam); pt.set_max_batch(8)
         row = {}
         for depth in (2, 5):
-            ref, st0 = run(pt, {"inst_tlas": 0, "inst_sieve": 0}, depth)
-            for label, opts in (("own_tlas", {"inst_tlas": 2, "inst_tlas_overlap": 100, "inst_sieve": 0}), ("sieved_loop", {"inst_tlas": 0, "inst_sieve": 2, "inst_sieve_overlap": 100})):
+            same_space = False
+            off = {"inst_unify": 0, "inst_general": 0, "inst_braid": 0, "packet": 1}
+            ref, st0 = run(pt, dict(off, inst_tlas=0, inst_sieve=0), depth)
+            # round 5: the own TLAS, the sieved loop; round 6: entries under the own TLAS, the unified tree of same-space scenes (lane walk; packets for the primary launch), the general array
+            for label, opts in (("own_tlas", dict(off, inst_tlas=2, inst_tlas_overlap=100, inst_sieve=0)), ("sieved_loop", dict(off, inst_tlas=0, inst_sieve=2, inst_sieve_overlap=100)),
+                                ("own_tlas_braid_512", dict(off, inst_tlas=2, inst_tlas_overlap=100, inst_sieve=0, inst_braid=512)),
+                                ("unified_tree", dict(off, inst_tlas=8, inst_sieve=8, inst_unify=4096, packet=0)), ("unified_tree_packets", dict(off, inst_tlas=8, inst_sieve=8, inst_unify=4096, packet=2)),
+                                ("general_array", dict(off, inst_tlas=8, inst_sieve=8, inst_unify=4096, inst_general=2))):
                 got, st = run(pt, opts, depth)
+                if label == "unified_tree": same_space = st["inst_unified_entries"] > 0
+                if (label.startswith("unified") and not same_space) or (label == "general_array" and (same_space or st["inst_unified_launches"] == 0)):
+                    continue                                     # (does not apply to this scene: not one space / one space)
                 bad = sum(1 for a, b in zip(ref, got) if not ((a[0] == b[0]).all() and a[1] == b[1] and a[2].shape == b[2].shape and (a[2] == b[2]).all()))
-                row[f"depth{depth}_{label}"] = {"rays": st["rays_traced"], "rays_traced_again": st["inst_tlas_flagged_rays"], "mismatching_checkpoints": bad, "checkpoints": len(ref)}
+                row[f"depth{depth}_{label}"] = {"rays": st["rays_traced"], "rays_traced_again": st["inst_tlas_flagged_rays"] + st["packet_flagged_rays"], "unified_launches": st["inst_unified_launches"], "packets": st["packet_packets"],
+                                                "mismatching_checkpoints": bad, "checkpoints": len(ref)}
         pt.Dispose()
         res[name] = row
         print(json.dumps({name: row}), flush=True)
