@@ -172,7 +172,7 @@ static bool inst_unify_wanted(const dev_ctx* ctx)
     if (ctx->opt.instUnify <= 0 || ctx->instanceCount < 2 || ctx->instanceCount > 1024 || !ctx->sceneNested) return false;
     return !ctx->st.UseTlas && !ctx->st.Gpu.DoDebugBVHTraversal && ctx->verSlots == 1 && !ctx->counters && (ctx->opt.traceVariant == 0 || ctx->opt.traceVariant == 100);
 }
-static int inst_unify_prepare(dev_ctx* ctx, bool first)
+static int inst_unify_prepare(dev_ctx* ctx)
 {
     ctx->uniValid = false; ctx->uniMode = 0;
     if (!inst_unify_wanted(ctx)) return IDKPT_OK;
@@ -231,7 +231,6 @@ static int inst_unify_prepare(dev_ctx* ctx, bool first)
     if (ctx->ichunkCount) hipLaunchKernelGGL(k_unify_blas, dim3(ctx->ichunkCount), dim3(256), 0, st, nodes, ctx->descs.as<GpuBlasDesc>(), (const uint2*)ctx->ichunks.as<uint2>(), baseB, ctx->unodes.as<float4>());
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(st));                       // (waited for: the entries and the top's depth size this walk's stack; a re-derivation — transforms, refits — is rare on the scenes that use it)
-    (void)first;
     const volatile float* h = ctx->hUni;
     ctx->uniEntries = (int)h[1]; ctx->uniDepth = (int)h[2];
     ctx->uniValid = ctx->uniDepth > 0 && ctx->uniEntries >= n;
@@ -283,7 +282,7 @@ static int inst_tlas_prepare(dev_ctx* ctx, bool* useTlas, bool* useSieve)
         HIPC(hipGetLastError());
         const bool first = !ctx->instOverlapKnown;
         if (first) { HIPC(hipStreamSynchronize(st)); ctx->instOverlapKnown = true; }
-        { int rc = inst_unify_prepare(ctx, first); if (rc) return rc; }
+        { int rc = inst_unify_prepare(ctx); if (rc) return rc; }
         const float met = *(volatile float*)ctx->hInstOverlap * 100.0f;      // percent of the leaves' boxes a random line meets, x their number
         const float leavesRead = ((volatile float*)ctx->hInstOverlap)[1], leaves = braid ? std::max((float)n, leavesRead) : (float)n;
         const bool worth = ctx->uniValid || (inst_tlas_wanted(ctx) && (ctx->opt.instTlasOverlap >= 100 || met <= (float)ctx->opt.instTlasOverlap * leaves));

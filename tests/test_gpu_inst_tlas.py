@@ -267,3 +267,35 @@ def test_general_array_is_what_ran(native_builder, oracle_mod, request):
     st = a.stats(); a.Dispose(); o.close()
     general = request.node.callspec.params.get("_from_two_instances_on") == -1
     assert (st["inst_unified_launches"] > 0) == general and (st["inst_unified_entries"] >= 5) == general, st
+
+
+def test_unified_tree_is_rederived_after_a_refit(native_builder, oracle_mod, monkeypatch, request):
+    """Four refittable BLASes in one space: vertices moved, every BLAS refitted on the device (BLASRefit), the unified tree re-derived from the new boxes: the frame equals the oracle's
+    frame of the scene with the moved vertices and the refitted nodes (the refit itself is pinned in tests/test_gpu_scene_updates.py and against the reference's shader in test_glref.py)."""
+    if request.node.callspec.params.get("_from_two_instances_on") != 2048:
+        pytest.skip("one run")
+    from idkengine_amd.pathtracer import PathTracer
+    monkeypatch.setenv("IDKPT_INST_UNIFY", "4096")
+    blases = []
+    for k in range(4):
+        p, i, nrm, tan = S.flat_shaded(S.soup_triangles(1500, 90 + 17 * k, 5.0, 0.4))
+        blases.append({"meshes": [S.MeshInput(p, i, S.make_material((0.8, 0.75, 0.7, 1.0)), nrm, tan)], "refittable": True})
+    sc = S.assemble(blases, native_builder); w, h = 160, 96; cam = S.Camera(w, h, position=(1.0, 0.5, 17.0))
+    ov = dict(RayDepth=3)
+    pt = PathTracer(w, h, settings=configs.apply_settings(T.Settings.default(), ov)); pt.UploadScene(sc); pt.SetCamera(cam)
+    def same():
+        o = oracle_render(oracle_mod, sc, cam, w, h, **ov)
+        pt.ResetAccumulation(); pt.Compute()
+        assert (bits(pt.Result) == bits(o.image(0))).all() and pt.rays().tobytes() == o.rays().tobytes()
+        o.close()
+    same(); assert pt.stats()["inst_unified_entries"] >= 4
+    rng = np.random.default_rng(5)
+    moved = (sc.vertex_positions + np.sin(sc.vertex_positions[:, ::-1] * 1.3).astype(np.float32) * np.float32(0.08) + rng.normal(0, 0.01, sc.vertex_positions.shape)).astype(np.float32)
+    pt.UpdateBuffer(T.IDKPT_BUF_VERTEX_POSITIONS, moved)
+    for b in range(4):
+        pt.RefitBlas(b)
+    sc.vertex_positions = moved
+    sc.blas_nodes = pt.DownloadBuffer(T.IDKPT_BUF_BLAS_NODES, T.GpuBlasNode, len(sc.blas_nodes))
+    n0 = pt.stats()["inst_unified_launches"]
+    same(); st = pt.stats(); assert st["inst_unified_entries"] >= 4 and st["inst_unified_launches"] > n0, st
+    pt.Dispose()
