@@ -190,9 +190,17 @@ __global__ __launch_bounds__(TLAS_BUILD_THREADS) void k_tlas_build(const float4*
         // contiguous chunk per thread so that the scan order is the serial loop's order
         const int chunk = (activeCount + T - 1) / T, c0 = min(t * chunk, activeCount), c1 = min(c0 + chunk, activeCount);
         uint32_t nPairs = 0, nOut = 0;
-        for (int i = c0; i < c1; i++) { const int b = pref[i]; const bool mutual = b >= 0 && pref[b] == i; if (mutual && i < b) nPairs++; if (!mutual || i < b) nOut++; }
         uint32_t basePairs, baseOut, totPairs, totOut;
-        block_scan2(nPairs, nOut, sa, sb, basePairs, baseOut, totPairs, totOut);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            nPairs = 0; nOut = 0;
+            for (int i = c0; i < c1; i++) { const int b = pref[i]; const bool mutual = b >= 0 && pref[b] == i; if (mutual && i < b) nPairs++; if (!mutual || i < b) nOut++; }
+            block_scan2(nPairs, nOut, sa, sb, basePairs, baseOut, totPairs, totOut);
+            if (totPairs != 0u || attempt == 1) break;
+            // No mutual pair at all: every union area was infinite or NaN (an instance under a singular transform has "all of space" as its padded box; FindBestMatch's strict '<'
+            // from FLT_MAX then never picks anybody, and the serial loop of TLAS.cs would not end either).  Merge the first two so that the build terminates.
+            if (t == 0) { pref[0] = 1; pref[1] = 0; }
+            __syncthreads();
+        }
         const int merged = 2 * (int)totPairs, unmerged = activeCount - merged, newNodes = merged / 2;
         const int mergedHead0 = activeEnd - merged, newBegin = mergedHead0 - unmerged - newNodes;
         int mergedHead = mergedHead0 + 2 * (int)basePairs, unmergedHead = newBegin + (int)baseOut;

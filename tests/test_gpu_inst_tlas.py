@@ -299,3 +299,17 @@ def test_unified_tree_is_rederived_after_a_refit(native_builder, oracle_mod, mon
     n0 = pt.stats()["inst_unified_launches"]
     same(); st = pt.stats(); assert st["inst_unified_entries"] >= 4 and st["inst_unified_launches"] > n0, st
     pt.Dispose()
+
+
+def test_singular_and_non_finite_transforms_terminate_and_equal_the_loop(native_builder, oracle_mod):
+    """An instance hidden by a zero scale (Model = InvModel = 0) and one whose InvModel is NaN: their padded world boxes are "all of space" with infinite union areas, which no
+    PLOC partner ever picks — the tree builders end anyway (k_tlas_build's guard), the walks hand the rays that meet such an instance to the exact loop, and the frame is the oracle's."""
+    m = [np.eye(4), S.rotation_y(30.0) @ S.translation((2.0, 0.0, 0.0)), S.rotation_y(-50.0) @ S.translation((-2.5, 0.5, 1.0)), S.translation((0.0, 3.0, -2.0)),
+         S.rotation_y(75.0) @ S.translation((1.0, -3.0, 0.0)), S.translation((0.5, 0.5, 0.5)), S.translation((-1.0, 1.0, 0.0)), S.rotation_y(10.0), S.translation((3.0, -1.0, 1.0))]
+    sc = _instanced(native_builder, m, [0, 1, 0, 1, 1, 0, 0, 1, 0])
+    xf = sc.mesh_transforms.copy()
+    xf["Model"][5] = 0.0; xf["InvModel"][5] = 0.0
+    xf["InvModel"][7] = np.float32("nan")
+    sc.mesh_transforms = xf
+    w, h = 160, 96; cam = S.Camera(w, h, position=(0.5, 0.5, 13.0), fovy_deg=60.0)
+    _check(oracle_mod, sc, cam, w, h, frames=2, RayDepth=3)
