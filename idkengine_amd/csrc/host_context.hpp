@@ -77,6 +77,7 @@ struct DevOptions {
                                  // (default).  Measured (profiles/r06_braid.md §5): with whole instances as entries it equals the own TLAS (2 754 vs 2 675 Mray/s on the 3 rotated
                                  // soups, the loop: 3 628); with subtrees as entries it LOSES (4 096 entries: 2 182 | interior 428 vs 722): the world box of a rotated subtree is loose
                                  // and every entry met costs a RayTransform, a stub step and a RESTORE step.  The idea pays only where an entry is free: one space (inst_unify)
+    int uniRefill = 32;          // ... idle lanes at which a wave of the unified walk takes new rays (16 or 32; measured: 32 is +0.6 % batched, +2 % one frame at a time on the atrium as 87 BLASes)
     int instUnifyRadius = 15;    // ... PLOC search radius of that top (TLAS.cs's SearchRadius is 15: the own TLAS keeps the reference's)
     int pairNodes = 1;           // k_trace2 FAST: one-BLAS closest-hit launches (one scene version, no counters) step on DScene::pairNodes, the sibling pairs regrouped for 2-wide
                                  // arithmetic (+ 64 bytes per pair of device memory, re-derived after node updates): 62 -> 53 vector instructions per node step.  0 = the reference's layout

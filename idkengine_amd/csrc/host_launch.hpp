@@ -393,6 +393,7 @@ static void launch_trace2(dev_ctx* ctx, uint32_t grid, size_t lds, hipStream_t s
             ib.baseB = ctx->uniBaseB; ib.restoreIdx = ctx->uniRestoreIdx; if (ctx->uniMode == 2) ib.entRec = (const float4*)ctx->uniEntRec.as<float4>();
             const size_t ldsU = (size_t)(ctx->uniCap + 2) * WAVE * 4 + (size_t)std::max(0, ctx->opt.ldsPad);
             if (ctx->uniMode == 2) hipLaunchKernelGGL((k_trace_inst<PRIMARY, false, 16, 2>), dim3(grid), dim3(WAVE), ldsU, st, s, f, rays, tr, hits, list, cnt, work, ib);
+            else if (ctx->opt.uniRefill == 32) hipLaunchKernelGGL((k_trace_inst<PRIMARY, false, 32, 1>), dim3(grid), dim3(WAVE), ldsU, st, s, f, rays, tr, hits, list, cnt, work, ib);
             else hipLaunchKernelGGL((k_trace_inst<PRIMARY, false, 16, 1>), dim3(grid), dim3(WAVE), ldsU, st, s, f, rays, tr, hits, list, cnt, work, ib);
         } else
         hipLaunchKernelGGL((k_trace_inst<PRIMARY>), dim3(grid), dim3(WAVE), lds, st, s, f, rays, tr, hits, list, cnt, work, ib);

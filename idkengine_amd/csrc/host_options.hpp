@@ -45,6 +45,7 @@ static int32_t dev_SetOption(dev_ctx* ctx, const char* name, int32_t value)
     else if (n == "inst_braid") { REQUIRE(value >= 0, "idkptSetDeveloperOption: inst_braid is >= 0"); FLUSH(); o.instBraid = value; ctx->itlasValid = false; }   // (entries of the own TLAS after partial re-braiding, k_braid; 0: whole instances)
     else if (n == "pair_nodes") { REQUIRE(value == 0 || value == 1, "idkptSetDeveloperOption: pair_nodes is 0 or 1"); o.pairNodes = value; }
     else if (n == "inst_general") { REQUIRE(value >= 0, "idkptSetDeveloperOption: inst_general is >= 0"); FLUSH(); o.instGeneral = value; ctx->itlasValid = false; }
+    else if (n == "uni_refill") { REQUIRE(value == 16 || value == 32, "idkptSetDeveloperOption: uni_refill is 16 or 32"); o.uniRefill = value; }
     else if (n == "inst_unify_radius") { REQUIRE(value >= 1 && value <= 512, "idkptSetDeveloperOption: inst_unify_radius is 1-512"); FLUSH(); o.instUnifyRadius = value; ctx->itlasValid = false; }
     else if (n == "inst_unify") { REQUIRE(value >= 0, "idkptSetDeveloperOption: inst_unify is >= 0"); FLUSH(); o.instUnify = value; ctx->itlasValid = false; }   // (subtrees under the unified tree's top, k_unify_*; 0: off)
     else if (n == "inst_tlas") { REQUIRE(value >= 0, "idkptSetDeveloperOption: inst_tlas is >= 0"); FLUSH(); o.instTlas = value; ctx->itlasValid = false; }   // (0: the exact instance loop only; n: the library's own TLAS from n instances on)

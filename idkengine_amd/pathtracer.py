@@ -16,7 +16,7 @@ from ._lib import IdkPtError
 
 # idkptSetDeveloperOption names; IDKPT_<NAME> in the environment is forwarded when a PathTracer is created (test / tuning hooks only)
 _OPTION_NAMES = ("force_generic", "no_tile_cull", "no_lean_primary", "leaf_min", "grab_unit_log2", "grab_fixed", "lds_pad", "trace_waves", "grid_hint", "grid_rays_x4", "grid_mid_waves", "defer_last", "split", "split_donor", "split_peek", "group_threads", "query_scheduler", "split_scatter", "fused", "fused_shade_min", "leaf_pool", "pool_min", "adv_min",
-                 "wide", "wide_cap", "wide_count", "packet", "packet_min_live", "packet_waves", "inst_tlas", "inst_tlas_overlap", "inst_braid", "inst_unify", "inst_unify_radius", "inst_general", "pair_nodes", "inst_sieve", "inst_sieve_overlap", "gen_pixel_major", "gen_group_max", "bounce_pixel_major", "transport", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
+                 "wide", "wide_cap", "wide_count", "packet", "packet_min_live", "packet_waves", "inst_tlas", "inst_tlas_overlap", "inst_braid", "inst_unify", "inst_unify_radius", "uni_refill", "inst_general", "pair_nodes", "inst_sieve", "inst_sieve_overlap", "gen_pixel_major", "gen_group_max", "bounce_pixel_major", "transport", "bvh_timing", "bvh_small", "bvh_stackopt_host", "force_no_peer", "trace_variant")
 
 
 class PathTracer:

@@ -451,6 +451,7 @@ IDKPT_API int32_t idkptEnableTiming(idkpt_ctx* ctx, int32_t enable);
  *                                    device memory): 53 instead of 62 vector instructions per node step, bit-identical
  *     "inst_general"     >= 0 (0*)   scenes of at least this many instances that are NOT one space walk one array too (k_trace_inst TREE 2: a world-space top whose entries take the ray into their
  *                                    instance's space).  Measured: equal to the own TLAS with whole instances, slower with subtrees (loose world boxes, a RayTransform per entry): off
+ *     "uni_refill"       16 / 32*    idle lanes at which a wave of the unified walk takes new rays
  *     "inst_unify_radius" 1-512 (15*) PLOC search radius of the unified tree's top (larger radii measured 2-30 % slower)
  *     "inst_sieve"       >= 0 (8*)   k_trace_inst<EXACT>: scenes of at least this many instances (at most 1024) that keep the loop run it with the instances a ray's line cannot meet sieved out when
  *                                    the wave takes the ray — the loop itself, visit for visit (also: the kernel behind the own-TLAS walk's flagged rays, and idkptTraceRays' closest hits).  0 = k_trace2 MODE 1
